@@ -1,0 +1,121 @@
+"""ctypes loader for libcytohip.so -- the only bridge between the Python host code and HIP.
+
+Loading is lazy and per-process: nothing touches HIP at import time, so the solver callable
+stays picklable and fork-safe (the reference ships it through ProcessPoolExecutor.submit,
+/root/reference/cytospace/cytospace.py:446-451).  There is NO fallback: if the library is
+missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcytohip.so")
+_lib = None
+
+CYTO_OK = 0
+_EXC = {1: ValueError, 2: ValueError, 3: MemoryError, 7: ValueError, 8: ValueError}
+
+
+class CytoHipError(RuntimeError):
+    pass
+
+
+class LapInfo(ctypes.Structure):
+    _fields_ = [("ms_colred", ctypes.c_double), ("ms_chain", ctypes.c_double), ("ms_total", ctypes.c_double)] + \
+        [(k, ctypes.c_int64) for k in (
+            "scans_colred", "scans_redtransfer", "scans_arr", "scans_aug_init", "scans_aug_relax",
+            "augmentations", "path_hops", "free_after_colred", "free_after_arr1", "free_after_arr2",
+            "hbm_row_reads")] + [("reserved", ctypes.c_int64 * 7)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+    @property
+    def row_scans(self):
+        return int(self.scans_colred + self.scans_redtransfer + self.scans_arr
+                   + self.scans_aug_init + self.scans_aug_relax)
+
+
+def lib():
+    """Return the loaded library (loading it on first use in this process)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CytoHipError(
+                f"{LIB_PATH} not found: build it with `python -m cytospace_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        L.cyto_strerror.restype = ctypes.c_char_p
+        L.cyto_strerror.argtypes = [ctypes.c_int]
+        L.cyto_last_hip_error.restype = ctypes.c_char_p
+        L.cyto_version.restype = ctypes.c_char_p
+        vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+        L.cyto_device_count.argtypes = [ctypes.POINTER(ctypes.c_int)]
+        L.cyto_device_name.argtypes = [i32, ctypes.c_char_p, ctypes.c_size_t]
+        L.cyto_malloc.argtypes = [ctypes.POINTER(vp), ctypes.c_size_t, i32]
+        L.cyto_free.argtypes = [vp, i32]
+        L.cyto_memcpy_h2d.argtypes = [vp, vp, ctypes.c_size_t, i32]
+        L.cyto_memcpy_d2h.argtypes = [vp, vp, ctypes.c_size_t, i32]
+        L.cyto_device_synchronize.argtypes = [i32]
+        for name in ("cyto_lap_f32", "cyto_lap_f64"):
+            getattr(L, name).argtypes = [i32, vp, i64, i32, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_double),
+                                         ctypes.POINTER(LapInfo), i32, vp]
+        for name in ("cyto_device_count", "cyto_device_name", "cyto_malloc", "cyto_free", "cyto_memcpy_h2d",
+                     "cyto_memcpy_d2h", "cyto_device_synchronize", "cyto_lap_f32", "cyto_lap_f64"):
+            getattr(L, name).restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def check(status):
+    """Turn a C status code into the Python exception the reference's path would raise."""
+    if status == CYTO_OK:
+        return
+    L = lib()
+    msg = L.cyto_strerror(status).decode()
+    if status == 5:
+        msg += ": " + L.cyto_last_hip_error().decode()
+    raise _EXC.get(status, CytoHipError)(f"cytohip status {status}: {msg}")
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    st = lib().cyto_device_count(ctypes.byref(n))
+    return n.value if st == CYTO_OK else 0
+
+
+class DeviceBuffer:
+    """A caller-owned HBM allocation (so a cost matrix can stay resident across solves)."""
+
+    def __init__(self, nbytes, device_id=0):
+        self.device_id = device_id
+        self.nbytes = int(nbytes)
+        p = ctypes.c_void_p()
+        check(lib().cyto_malloc(ctypes.byref(p), self.nbytes, device_id))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, arr, device_id=0):
+        import numpy as np
+        arr = np.ascontiguousarray(arr)
+        buf = cls(arr.nbytes, device_id)
+        check(lib().cyto_memcpy_h2d(buf.ptr, arr.ctypes.data, arr.nbytes, device_id))
+        return buf
+
+    def to_numpy(self, shape, dtype):
+        import numpy as np
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        check(lib().cyto_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes, self.device_id))
+        return out
+
+    def free(self):
+        if self.ptr:
+            check(lib().cyto_free(self.ptr, self.device_id))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,65 @@
+"""Python face of the HIP Jonker-Volgenant solver (C ABI: cyto_lap_f32 / cyto_lap_f64).
+
+`lapjv_hip(cost)` has the call shape of `lapjv.lapjv(cost)` as CytoSPACE uses it
+(/root/reference/cytospace/linear_assignment_solvers/linear_assignment_solvers.py:38):
+it returns the 3-tuple `(row_ind, col_ind, (total, u, v))`; CytoSPACE keeps `col_ind`
+(`_, y, _ = solver(cost_scaled)`), where `col_ind[j]` is the row (spot slot) given to column
+(cell) j.  It is a module-level function, hence picklable for ProcessPoolExecutor.submit
+(/root/reference/cytospace/cytospace.py:446-451); libcytohip.so is loaded lazily in the
+process that calls it.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def lap_solve(cost, dtype=np.float32, device_id=0, return_info=False, device_ptr=None, n=None, ld=None):
+    """Solve a square LAP on the GPU.
+
+    cost        2-D square array-like (host) -- cast to `dtype` -- or None with `device_ptr`
+    device_ptr  int address of a device-resident row-major matrix (then give n and ld)
+    Returns dict(rowsol, colsol, u, v, total[, info]).
+    """
+    L = _lib.lib()
+    if dtype not in (np.float32, np.float64):
+        raise TypeError("dtype must be numpy.float32 or numpy.float64")
+    if device_ptr is None:
+        c = np.ascontiguousarray(cost, dtype=dtype)
+        if c.ndim != 2 or c.shape[0] != c.shape[1]:
+            raise ValueError("cost must be a square 2-D matrix")
+        n = c.shape[0]
+        ld = n
+        ptr, on_device = c.ctypes.data, 0
+        if n == 0:
+            raise ValueError("cost must be non-empty")
+    else:
+        if n is None:
+            raise ValueError("n is required with device_ptr")
+        ld = n if ld is None else ld
+        ptr, on_device = int(device_ptr), 1
+    rowsol = np.empty(n, np.int32)
+    colsol = np.empty(n, np.int32)
+    u = np.empty(n, dtype)
+    v = np.empty(n, dtype)
+    total = ctypes.c_double()
+    info = _lib.LapInfo()
+    fn = L.cyto_lap_f32 if dtype == np.float32 else L.cyto_lap_f64
+    st = fn(n, ptr, ld, on_device, rowsol.ctypes.data, colsol.ctypes.data, u.ctypes.data, v.ctypes.data,
+            ctypes.byref(total), ctypes.byref(info), device_id, None)
+    _lib.check(st)
+    out = dict(rowsol=rowsol, colsol=colsol, u=u, v=v, total=total.value)
+    if return_info:
+        out["info"] = info
+    return out
+
+
+def lapjv_hip(cost, verbose=0, force_doubles=False):
+    """Drop-in for `lapjv.lapjv`: returns (row_ind, col_ind, (total_cost, u, v)).
+
+    Like lapjv 1.3.14 (recalled, unverified -- SURVEY.md section 8c) the solve runs in float32
+    unless force_doubles=True.
+    """
+    r = lap_solve(cost, dtype=np.float64 if force_doubles else np.float32)
+    return r["rowsol"], r["colsol"], (r["total"], r["u"], r["v"])

@@ -1,0 +1,82 @@
+/*
+ * cytohip.h -- C ABI of libcytohip.so, the MI355X (gfx950) implementation of CytoSPACE's
+ * cell-to-spot linear-assignment hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes, returns an int status
+ * (0 = CYTO_OK) and never throws.  Buffers are caller-owned and borrowed for the call only.
+ * The reference is pure Python; the "FFI" a maintainer binds is ctypes.
+ * Citations are into /root/reference/.
+ */
+#ifndef CYTOHIP_H
+#define CYTOHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (errors of the reference it stands for are noted) ---- */
+enum {
+    CYTO_OK = 0,
+    CYTO_ERR_BAD_ARG = 1,       /* non-square / null / negative sizes; reference: ValueError in lapjv */
+    CYTO_ERR_NONFINITE = 2,     /* NaN/Inf in the cost matrix (zero-variance column in common.py:197) */
+    CYTO_ERR_NOMEM = 3,         /* host or device allocation failed; reference: BrokenProcessPool/OOM */
+    CYTO_ERR_INTERNAL = 4,      /* solver invariant violated */
+    CYTO_ERR_HIP = 5,           /* a HIP runtime call failed; cyto_last_hip_error() has the text */
+    CYTO_ERR_NO_DEVICE = 6,     /* no gfx950 device visible */
+    CYTO_ERR_UNSUPPORTED = 7,   /* size outside what this build supports (n > 65536 per LAP) */
+    CYTO_ERR_SHAPE = 8          /* gene counts differ; reference: ValueError, common/common.py:191-192 */
+};
+
+const char *cyto_strerror(int status);
+const char *cyto_last_hip_error(void);   /* thread-local text of the last failing HIP call */
+const char *cyto_version(void);
+
+/* ---- device + memory plumbing (so callers can keep the cost matrix resident in HBM) ---- */
+int cyto_device_count(int *count);
+int cyto_device_name(int device_id, char *buf, size_t buflen);
+int cyto_malloc(void **dptr, size_t bytes, int device_id);
+int cyto_free(void *dptr, int device_id);
+int cyto_memcpy_h2d(void *dst, const void *src, size_t bytes, int device_id);
+int cyto_memcpy_d2h(void *dst, const void *src, size_t bytes, int device_id);
+int cyto_device_synchronize(int device_id);
+
+/* ---- A5: the LAP solve.  Replaces `_, y, _ = lapjv.lapjv(cost_scaled)`
+ * (cytospace/linear_assignment_solvers/linear_assignment_solvers.py:34-40; solver imported
+ * at :16-18).  Jonker-Volgenant: column reduction, reduction transfer, two augmenting row
+ * reduction sweeps, shortest-augmenting-path augmentation.
+ *
+ *   n, ld         square problem size and leading dimension (elements) of the row-major cost
+ *   cost          n x n costs; host pointer (cost_on_device = 0) or device pointer (= 1)
+ *   rowsol[i]     column assigned to row i                      (host, n, out; may be NULL)
+ *   colsol[j]     row assigned to column j -- CytoSPACE's `y`   (host, n, out; may be NULL)
+ *   u, v          dual variables                                 (host, n, out; may be NULL)
+ *   total         sum_i cost[i][rowsol[i]] accumulated in f64    (out; may be NULL)
+ *   info          timing/work counters                           (out; may be NULL)
+ *   stream        hipStream_t to launch on, NULL = the device's default stream
+ * Results are bit-identical to oracle/jv_oracle.c for the same dtype (tests/test_lap_gpu.py).
+ */
+typedef struct {
+    double ms_colred;        /* HIP-event time of the column-reduction kernels */
+    double ms_chain;         /* HIP-event time of the persistent RT+ARR+augmentation kernel */
+    double ms_total;         /* HIP-event time first launch -> last kernel done (no H2D/D2H) */
+    int64_t scans_colred, scans_redtransfer, scans_arr, scans_aug_init, scans_aug_relax;
+    int64_t augmentations, path_hops;
+    int64_t free_after_colred, free_after_arr1, free_after_arr2;
+    int64_t hbm_row_reads;   /* full cost rows the kernels actually fetched (<= algorithmic scans) */
+    int64_t reserved[7];
+} cyto_lap_info;
+
+int cyto_lap_f32(int n, const float *cost, int64_t ld, int cost_on_device,
+                 int32_t *rowsol, int32_t *colsol, float *u, float *v, double *total,
+                 cyto_lap_info *info, int device_id, void *stream);
+int cyto_lap_f64(int n, const double *cost, int64_t ld, int cost_on_device,
+                 int32_t *rowsol, int32_t *colsol, double *u, double *v, double *total,
+                 cyto_lap_info *info, int device_id, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CYTOHIP_H */

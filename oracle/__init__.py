@@ -1,0 +1,4 @@
+"""oracle/ -- CPU restatement of the reference hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package.  The product (cytospace_amd/) never does."""

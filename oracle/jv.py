@@ -1,0 +1,74 @@
+"""ctypes binding of oracle/liboracle.so (CPU Jonker-Volgenant oracle).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/jv_oracle_impl.h for what is restated
+(the `lapjv` call at /root/reference/cytospace/linear_assignment_solvers/
+linear_assignment_solvers.py:38) and why parity against lapjv itself is unpinned.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class JVStats(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int64) for k in (
+        "scans_colred", "scans_redtransfer", "scans_arr", "scans_aug_init", "scans_aug_relax",
+        "augmentations", "path_hops", "free_after_colred", "free_after_arr1", "free_after_arr2")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+    @property
+    def row_scans(self):
+        return int(self.scans_colred + self.scans_redtransfer + self.scans_arr
+                   + self.scans_aug_init + self.scans_aug_relax)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = ctypes.CDLL(path)
+    return _LIB
+
+
+def jv_oracle(cost, dtype=np.float32):
+    """Solve the square LAP on the CPU.  Returns dict(rowsol, colsol, u, v, total, total_T, stats).
+
+    `cost` is cast to `dtype` first (lapjv 1.3.14 is recalled to down-cast to float32
+    unless force_doubles is set -- SURVEY.md section 8c, UNVERIFIED)."""
+    c = np.ascontiguousarray(cost, dtype=dtype)
+    if c.ndim != 2 or c.shape[0] != c.shape[1]:
+        raise ValueError("cost must be a square 2-D array")
+    n = c.shape[0]
+    rowsol = np.empty(n, np.int32)
+    colsol = np.empty(n, np.int32)
+    u = np.empty(n, dtype)
+    v = np.empty(n, dtype)
+    tot = ctypes.c_double()
+    st = JVStats()
+    if dtype == np.float32:
+        fn, tt = _lib().jv_oracle_f32, ctypes.c_float()
+    elif dtype == np.float64:
+        fn, tt = _lib().jv_oracle_f64, ctypes.c_double()
+    else:
+        raise TypeError("dtype must be float32 or float64")
+    rc = fn(ctypes.c_int(n), c.ctypes.data_as(ctypes.c_void_p),
+            rowsol.ctypes.data_as(ctypes.c_void_p), colsol.ctypes.data_as(ctypes.c_void_p),
+            u.ctypes.data_as(ctypes.c_void_p), v.ctypes.data_as(ctypes.c_void_p),
+            ctypes.byref(tot), ctypes.byref(tt), ctypes.byref(st))
+    if rc == 2:
+        raise ValueError("cost matrix contains NaN/Inf")
+    if rc != 0:
+        raise RuntimeError(f"jv_oracle failed with status {rc}")
+    return dict(rowsol=rowsol, colsol=colsol, u=u, v=v, total=tot.value, total_T=tt.value, stats=st)

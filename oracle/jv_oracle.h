@@ -1,0 +1,31 @@
+/* jv_oracle.h -- C interface of the CPU Jonker-Volgenant oracle (test infrastructure only;
+ * see jv_oracle_impl.h for what it restates and for the tie-breaking contract). */
+#ifndef JV_ORACLE_H
+#define JV_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { JV_OK = 0, JV_ERR_BAD_ARG = 1, JV_ERR_NONFINITE = 2, JV_ERR_NOMEM = 3, JV_ERR_INTERNAL = 4 };
+
+/* Row-scan counters: one "scan" = one pass over one full cost row (n elements).
+ * bytes_JV = sizeof(T) * n * (scans_colred + scans_redtransfer + scans_arr
+ *                             + scans_aug_init + scans_aug_relax)       */
+typedef struct {
+    int64_t scans_colred, scans_redtransfer, scans_arr, scans_aug_init, scans_aug_relax;
+    int64_t augmentations, path_hops;
+    int64_t free_after_colred, free_after_arr1, free_after_arr2;
+} jv_stats;
+
+/* cost: row-major n x n.  rowsol[i] = column of row i, colsol[j] = row of column j
+ * (colsol is what CytoSPACE calls `y`, linear_assignment_solvers.py:38).  u, v duals. */
+int jv_oracle_f32(int n, const float *cost, int32_t *rowsol, int32_t *colsol, float *u, float *v,
+                  double *total_f64, float *total_T, jv_stats *st);
+int jv_oracle_f64(int n, const double *cost, int32_t *rowsol, int32_t *colsol, double *u, double *v,
+                  double *total_f64, double *total_T, jv_stats *st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,215 @@
+/*
+ * jv_oracle_impl.h -- body of the CPU Jonker-Volgenant oracle, included twice
+ * (T = float, T = double) by jv_oracle.c.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under cytospace_amd/ may call this.
+ *
+ * What it restates
+ * ----------------
+ * The reference reaches its LAP solver through ONE call,
+ *     `_, y, _ = solver(cost_scaled)`
+ * (/root/reference/cytospace/linear_assignment_solvers/linear_assignment_solvers.py:34-40,
+ *  solver imported at :16-18 as `from lapjv import lapjv`, PyPI lapjv==1.3.14 per
+ *  /root/reference/README.md:64-66).  That package is a third-party dependency whose
+ *  source is NOT under /root/reference and which is not installed in this image, so
+ *  the arithmetic below restates the PUBLISHED algorithm it implements:
+ *     R. Jonker, A. Volgenant, "A shortest augmenting path algorithm for dense and
+ *     sparse linear assignment problems", Computing 38 (1987) 325-340
+ * with the four phases BASELINE.json's north_star names: COLUMN REDUCTION,
+ * REDUCTION TRANSFER, AUGMENTING ROW REDUCTION (two sweeps), AUGMENTATION
+ * (Dijkstra-like shortest augmenting path, price update, path flip).
+ *
+ * PARITY UNPINNED against lapjv itself (no wheel, no source, no reference test
+ * holds a golden vector for this call).  It IS pinned against an independent exact
+ * solver (scipy.optimize.linear_sum_assignment) on uniqueness-certified instances:
+ * tests/test_oracle_jv.py, tests/golden/gv8_lap_*.npz.
+ *
+ * Tie-breaking contract (what "bit-exact" means for the HIP kernels)
+ * -----------------------------------------------------------------
+ * Every per-element operation is a subtract or a compare, evaluated in T with no
+ * FMA contraction, in the operand order written below.  Every arg-min resolves ties
+ * to the LOWEST index.  The augmentation scans, among the not-yet-scanned columns
+ * with minimal distance d, an unassigned column first (terminating the search),
+ * otherwise the lowest-index one.  (lapjv keeps a `collist` permutation and its AVX2
+ * lanes; that order is not reproducible from the publication and only matters when
+ * several columns tie EXACTLY; the optimal permutation of an instance with a unique
+ * optimum does not depend on it.)
+ */
+
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+#define FN(name) CAT(name, SUFFIX)
+
+/* lexicographic (value, index) two-smallest scan of h[j] = c[j] - v[j], j in [0,n)
+ * == the scalar loop of JV's augmenting row reduction, ties to the lowest index. */
+static void FN(top2_)(int n, const T *restrict c, const T *restrict v,
+                      T *umin_o, int *j1_o, T *usub_o, int *j2_o) {
+    T umin = c[0] - v[0];
+    int j1 = 0;
+    T usub = (T)INFINITY;
+    int j2 = -1;
+    for (int j = 1; j < n; j++) {
+        T h = c[j] - v[j];
+        if (h < usub) {
+            if (h >= umin) { usub = h; j2 = j; }
+            else { usub = umin; umin = h; j2 = j1; j1 = j; }
+        }
+    }
+    *umin_o = umin; *j1_o = j1; *usub_o = usub; *j2_o = j2;
+}
+
+int FN(jv_oracle_)(int n, const T *restrict cost, int32_t *restrict rowsol,
+                   int32_t *restrict colsol, T *restrict u, T *restrict v,
+                   double *total_f64, T *total_T, jv_stats *st) {
+    jv_stats s;
+    memset(&s, 0, sizeof s);
+    if (n <= 0) return JV_ERR_BAD_ARG;
+    const size_t N = (size_t)n;
+    for (size_t k = 0; k < N * N; k++)
+        if (!isfinite((double)cost[k])) return JV_ERR_NONFINITE;
+
+    int32_t *freerows = (int32_t *)malloc(N * sizeof(int32_t));
+    int32_t *matches = (int32_t *)calloc(N, sizeof(int32_t));
+    int32_t *pred = (int32_t *)malloc(N * sizeof(int32_t));
+    int32_t *imin = (int32_t *)malloc(N * sizeof(int32_t));
+    int32_t *lvl = (int32_t *)malloc(N * sizeof(int32_t));
+    uint8_t *scanned = (uint8_t *)malloc(N);
+    T *d = (T *)malloc(N * sizeof(T));
+    if (!freerows || !matches || !pred || !imin || !lvl || !scanned || !d) return JV_ERR_NOMEM;
+
+    /* ---- COLUMN REDUCTION: v[j] = min_i c[i][j] (lowest i on ties); columns are
+     * claimed from the last to the first, the first claim of a row wins. ---- */
+    for (int j = 0; j < n; j++) { v[j] = cost[j]; imin[j] = 0; }
+    for (int i = 1; i < n; i++) {
+        const T *restrict ci = cost + (size_t)i * N;
+        for (int j = 0; j < n; j++)
+            if (ci[j] < v[j]) { v[j] = ci[j]; imin[j] = i; }
+    }
+    s.scans_colred = n;
+    for (int i = 0; i < n; i++) rowsol[i] = -1;
+    for (int j = n - 1; j >= 0; j--) {
+        int i = imin[j];
+        if (++matches[i] == 1) { rowsol[i] = j; colsol[j] = i; }
+        else colsol[j] = -1;
+    }
+
+    /* ---- REDUCTION TRANSFER (rows in ascending order; later rows see the prices
+     * lowered by earlier ones). n == 1 has no other column to transfer from. ---- */
+    int numfree = 0;
+    for (int i = 0; i < n; i++) {
+        if (matches[i] == 0) freerows[numfree++] = i;
+        else if (matches[i] == 1 && n > 1) {
+            const int j1 = rowsol[i];
+            const T *restrict ci = cost + (size_t)i * N;
+            T mn = (T)INFINITY;
+            for (int j = 0; j < n; j++) {
+                T h = ci[j] - v[j];
+                if (j != j1 && h < mn) mn = h;
+            }
+            v[j1] = v[j1] - mn;
+            s.scans_redtransfer++;
+        }
+    }
+    s.free_after_colred = numfree;
+
+    /* ---- AUGMENTING ROW REDUCTION, two sweeps ---- */
+    for (int sweep = 0; sweep < 2; sweep++) {
+        int k = 0;
+        const int prevnumfree = numfree;
+        numfree = 0;
+        while (k < prevnumfree) {
+            const int i = freerows[k++];
+            T umin, usub; int j1, j2;
+            FN(top2_)(n, cost + (size_t)i * N, v, &umin, &j1, &usub, &j2);
+            s.scans_arr++;
+            int i0 = colsol[j1];
+            const T vj1_new = v[j1] - (usub - umin);
+            const int lowers = vj1_new < v[j1];
+            if (lowers) v[j1] = vj1_new;
+            else if (i0 >= 0) { j1 = j2; i0 = colsol[j2]; }
+            rowsol[i] = j1;
+            colsol[j1] = i;
+            if (i0 >= 0) {
+                if (lowers) freerows[--k] = i0;
+                else freerows[numfree++] = i0;
+            }
+        }
+        if (sweep == 0) s.free_after_arr1 = numfree;
+    }
+    s.free_after_arr2 = numfree;
+
+    /* ---- AUGMENTATION ---- */
+    for (int f = 0; f < numfree; f++) {
+        const int freerow = freerows[f];
+        const T *restrict cf = cost + (size_t)freerow * N;
+        for (int j = 0; j < n; j++) { d[j] = cf[j] - v[j]; pred[j] = freerow; scanned[j] = 0; }
+        s.scans_aug_init++;
+        int level = 0, have = 0, endofpath = -1;
+        T curmin = 0;
+        for (;;) {
+            /* pick: lexicographic min of (d, assigned?, j) over unscanned columns */
+            T dmin = (T)INFINITY;
+            for (int j = 0; j < n; j++) {
+                T dj = scanned[j] ? (T)INFINITY : d[j];
+                dmin = dj < dmin ? dj : dmin;
+            }
+            int jpick = -1, jfirst = -1;
+            for (int j = 0; j < n; j++) {
+                if (!scanned[j] && d[j] == dmin) {
+                    if (jfirst < 0) jfirst = j;
+                    if (colsol[j] < 0) { jpick = j; break; }
+                }
+            }
+            if (jpick < 0) jpick = jfirst;
+            if (jpick < 0) { free(freerows); free(matches); free(pred); free(imin); free(lvl); free(scanned); free(d); return JV_ERR_INTERNAL; }
+            if (!have || dmin != curmin) { level++; curmin = dmin; have = 1; }
+            if (colsol[jpick] < 0) { endofpath = jpick; break; }
+            scanned[jpick] = 1;
+            lvl[jpick] = level;
+            const int i = colsol[jpick];
+            const T *restrict ci = cost + (size_t)i * N;
+            const T h = (ci[jpick] - v[jpick]) - curmin;
+            for (int j = 0; j < n; j++) {
+                const T v2 = (ci[j] - v[j]) - h;
+                const int upd = (v2 < d[j]) & !scanned[j];
+                d[j] = upd ? v2 : d[j];
+                pred[j] = upd ? i : pred[j];
+            }
+            s.scans_aug_relax++;
+        }
+        /* price update: columns scanned at an earlier level than the final one */
+        for (int j = 0; j < n; j++)
+            if (scanned[j] && lvl[j] < level) v[j] = (v[j] + d[j]) - curmin;
+        /* flip the alternating path */
+        int i;
+        do {
+            i = pred[endofpath];
+            colsol[endofpath] = i;
+            const int j1 = endofpath;
+            endofpath = rowsol[i];
+            rowsol[i] = j1;
+            s.path_hops++;
+        } while (i != freerow);
+        s.augmentations++;
+    }
+
+    /* ---- duals and cost ---- */
+    double tot = 0.0;
+    T totT = 0;
+    for (int i = 0; i < n; i++) {
+        const int j = rowsol[i];
+        const T cij = cost[(size_t)i * N + j];
+        u[i] = cij - v[j];
+        totT = totT + cij;
+        tot += (double)cij;
+    }
+    if (total_f64) *total_f64 = tot;
+    if (total_T) *total_T = totT;
+    if (st) *st = s;
+    free(freerows); free(matches); free(pred); free(imin); free(lvl); free(scanned); free(d);
+    return JV_OK;
+}
+
+#undef FN
+#undef CAT
+#undef CAT_

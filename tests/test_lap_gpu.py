@@ -1,0 +1,89 @@
+"""GPU parity: HIP Jonker-Volgenant (through the C ABI) vs the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from cytospace_amd.lap import lap_solve, lapjv_hip
+from oracle.jv import jv_oracle
+
+pytestmark = pytest.mark.gpu
+
+STAT_KEYS = ["scans_colred", "scans_redtransfer", "scans_arr", "scans_aug_init", "scans_aug_relax",
+             "augmentations", "path_hops", "free_after_colred", "free_after_arr1", "free_after_arr2"]
+
+
+def _check(c, dtype):
+    o = jv_oracle(c, dtype)
+    g = lap_solve(c, dtype, return_info=True)
+    assert np.array_equal(g["rowsol"], o["rowsol"])
+    assert np.array_equal(g["colsol"], o["colsol"])
+    assert np.array_equal(g["v"], o["v"]), "dual prices v differ"
+    assert np.array_equal(g["u"], o["u"]), "duals u differ"
+    assert abs(g["total"] - o["total"]) <= 1e-5 * max(1.0, abs(o["total"]))   # tolerance from BASELINE.json
+    n = c.shape[0]
+    assert np.array_equal(np.sort(g["colsol"]), np.arange(n))
+    assert np.array_equal(g["rowsol"][g["colsol"]], np.arange(n))
+    od = o["stats"].as_dict()
+    gd = g["info"].as_dict()
+    for k in STAT_KEYS:
+        assert gd[k] == od[k], (k, gd[k], od[k])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 8, 63, 64, 65, 100, 256, 1000, 1023, 1024, 1025, 2500])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_uniform(n, dtype):
+    c = np.random.default_rng(n).random((n, n)).astype(np.float32)
+    _check(c, dtype)
+
+
+@pytest.mark.parametrize("n", [4100, 8200, 9000])
+def test_uniform_larger_variants(n):
+    # crosses the per-thread column-chunk variants (CH = 2 / 5 for float32)
+    c = np.random.default_rng(n).random((n, n)).astype(np.float32)
+    _check(c, np.float32)
+
+
+@pytest.mark.parametrize("n,slots", [(60, 5), (500, 5), (1000, 10), (2000, 4)])
+def test_duplicate_rows(n, slots):
+    # Visium-like: every spot row repeated `slots` times (linear_assignment_solvers.py:63-66)
+    rng = np.random.default_rng(n + slots)
+    base = -rng.random((n // slots, n)).astype(np.float32)
+    c = np.repeat(base, slots, axis=0)
+    _check(c, np.float32)
+
+
+@pytest.mark.parametrize("n", [16, 200, 1000])
+def test_integer_ties(n):
+    # heavy exact ties: small integer costs
+    c = np.random.default_rng(n).integers(0, 10, (n, n)).astype(np.float32)
+    _check(c, np.float32)
+    _check(c, np.float64)
+
+
+def test_negative_and_large_values():
+    rng = np.random.default_rng(5)
+    c = (rng.standard_normal((300, 300)) * 1e3).astype(np.float32)
+    _check(c, np.float32)
+
+
+def test_nan_rejected():
+    c = np.random.default_rng(0).random((64, 64)).astype(np.float32)
+    c[3, 5] = np.nan
+    with pytest.raises(ValueError):
+        lap_solve(c)
+    c[3, 5] = np.inf
+    with pytest.raises(ValueError):
+        lap_solve(c)
+
+
+def test_non_square_rejected():
+    with pytest.raises(ValueError):
+        lap_solve(np.zeros((3, 4), np.float32))
+
+
+def test_lapjv_call_shape():
+    # `_, y, _ = solver(cost)` (linear_assignment_solvers.py:38): y[j] = row of column j
+    c = np.random.default_rng(3).random((50, 50))
+    row_ind, col_ind, (total, u, v) = lapjv_hip(c)
+    o = jv_oracle(c, np.float32)
+    assert np.array_equal(col_ind, o["colsol"]) and np.array_equal(row_ind, o["rowsol"])
+    assert len(u) == 50 and len(v) == 50 and np.isfinite(total)
