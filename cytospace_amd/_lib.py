@@ -21,11 +21,12 @@ class CytoHipError(RuntimeError):
 
 
 class LapInfo(ctypes.Structure):
-    _fields_ = [("ms_colred", ctypes.c_double), ("ms_chain", ctypes.c_double), ("ms_total", ctypes.c_double)] + \
+    _fields_ = [("ms_colred", ctypes.c_double), ("ms_cache", ctypes.c_double), ("ms_chain", ctypes.c_double),
+                ("ms_total", ctypes.c_double)] + \
         [(k, ctypes.c_int64) for k in (
             "scans_colred", "scans_redtransfer", "scans_arr", "scans_aug_init", "scans_aug_relax",
             "augmentations", "path_hops", "free_after_colred", "free_after_arr1", "free_after_arr2",
-            "hbm_row_reads")] + [("reserved", ctypes.c_int64 * 7)]
+            "hbm_row_reads", "dense_refreshes")] + [("reserved", ctypes.c_int64 * 6)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -20,6 +20,7 @@
 // but nothing may be re-associated.
 #include "cyto_common.h"
 #include <math.h>
+#include <type_traits>
 
 namespace cyto {
 
@@ -520,9 +521,586 @@ __global__ __launch_bounds__(BLOCK) void jv_chain(ChainArgs<T> a) {
     }
 }
 
+
+// ==========================================================================================
+// float32 fast path ("v2").  Same arithmetic, same results, far fewer HBM row reads.
+//
+// Observation: during REDUCTION TRANSFER and AUGMENTING ROW REDUCTION the prices v[j] only ever
+// DECREASE (RT subtracts a non-negative minimum, ARR only stores vj1_new when vj1_new < v[j1]),
+// so every reduced cost h(i,j) = c[i][j] - v[j] only ever INCREASES.  Hence a row cache
+//     C_i = { j : h(i,j) < F_i }  (at most KC = 64 columns, with their raw c[i][j])  and the floor F_i
+// built at any earlier time stays a valid certificate: every column outside C_i still has
+// h >= F_i.  A later scan of row i only needs the cached columns: if the second-smallest
+// recomputed cached value is < F_i, the cached top-2 IS the exact lexicographic top-2 of the
+// whole row (bit-identical to the full scan).  Otherwise the row is re-scanned from HBM by the
+// whole workgroup (and its cache rebuilt).  The caches of all rows are built once, right after
+// the column reduction, by a full-chip streaming kernel (build_row_caches).
+//
+// A cached step runs on ONE wave (lane = cache entry): 2 coalesced 256-B loads, an LDS gather of
+// v, a DPP all-reduce on packed 64-bit keys (order-preserving float bits << 32 | column) and a
+// few scalar updates -- no barrier, no HBM row.
+// ==========================================================================================
+constexpr int KC = 64;             // cache entries per row (one per lane of a wave)
+constexpr uint64_t KEYMAX = ~0ull;
+constexpr uint32_t COLSENT = 0xFFFFFFFFu;
+enum { OP_EXIT = 0, OP_REFRESH = 1, OP_AUG = 2 };
+enum { C2_DENSE_REFRESH = C_NCOUNTERS, C2_NCOUNTERS };
+
+__device__ __forceinline__ uint32_t f2ord(float h) {
+    const uint32_t b = __float_as_uint(h + 0.0f);  // +0.0f: -0 -> +0 so that equal floats get equal keys
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+    return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
+}
+__device__ __forceinline__ uint64_t mkkey(float h, uint32_t lowbits) { return ((uint64_t)f2ord(h) << 32) | lowbits; }
+__device__ __forceinline__ float key_val(uint64_t k) { return ord2f((uint32_t)(k >> 32)); }
+__device__ __forceinline__ uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint64_t umax64(uint64_t a, uint64_t b) { return a < b ? b : a; }
+
+struct K2 { uint64_t m1, m2; };  // two smallest keys of a set of DISTINCT keys (or KEYMAX)
+__device__ __forceinline__ void k2_push(K2 &t, uint64_t k) {
+    const uint64_t lo = umin64(t.m1, k), hi = umax64(t.m1, k);
+    t.m1 = lo; t.m2 = umin64(t.m2, hi);
+}
+__device__ __forceinline__ void k2_merge(K2 &a, const K2 &b) {
+    const uint64_t lo = umin64(a.m1, b.m1), hi = umax64(a.m1, b.m1);
+    a.m2 = umin64(hi, umin64(a.m2, b.m2)); a.m1 = lo;
+}
+
+template <int CTRL> __device__ __forceinline__ uint32_t dpp32(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL> __device__ __forceinline__ uint64_t dpp64(uint64_t x) {
+    return ((uint64_t)dpp32<CTRL>((uint32_t)(x >> 32)) << 32) | dpp32<CTRL>((uint32_t)x);
+}
+__device__ __forceinline__ uint64_t readlane64(uint64_t x, int l) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(x >> 32), l) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, l);
+}
+// DPP controls quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror, row_mirror: a butterfly
+// inside each 16-lane row (the two merged sets are disjoint at every step).
+template <int CTRL> __device__ __forceinline__ void k2_step(K2 &t) {
+    K2 o; o.m1 = dpp64<CTRL>(t.m1); o.m2 = dpp64<CTRL>(t.m2);
+    k2_merge(t, o);
+}
+__device__ __forceinline__ void k2_row_allreduce(K2 &t) {
+    k2_step<0xB1>(t); k2_step<0x4E>(t); k2_step<0x141>(t); k2_step<0x140>(t);
+}
+__device__ __forceinline__ K2 k2_wave_allreduce(K2 t) {
+    k2_row_allreduce(t);
+    K2 r; r.m1 = readlane64(t.m1, 0); r.m2 = readlane64(t.m2, 0);
+#pragma unroll
+    for (int row = 1; row < 4; row++) {
+        K2 o; o.m1 = readlane64(t.m1, row * 16); o.m2 = readlane64(t.m2, row * 16);
+        k2_merge(r, o);
+    }
+    return r;
+}
+__device__ __forceinline__ uint64_t min64_row_allreduce(uint64_t x) {
+    x = umin64(x, dpp64<0xB1>(x)); x = umin64(x, dpp64<0x4E>(x));
+    x = umin64(x, dpp64<0x141>(x)); x = umin64(x, dpp64<0x140>(x));
+    return x;
+}
+__device__ __forceinline__ uint64_t min64_wave_allreduce(uint64_t x) {
+    x = min64_row_allreduce(x);
+    uint64_t r = readlane64(x, 0);
+#pragma unroll
+    for (int row = 1; row < 4; row++) r = umin64(r, readlane64(x, row * 16));
+    return r;
+}
+
+struct Scratch2 {
+    uint64_t m1[2][NW], m2[2][NW];
+    int cnt[2][NW];
+    int cmd_op, cmd_row;
+    double sum[NW];
+};
+
+__device__ __forceinline__ K2 wg_k2(K2 t, Scratch2 &s, int &par) {
+    t = k2_wave_allreduce(t);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { s.m1[par][w] = t.m1; s.m2[par][w] = t.m2; }
+    __syncthreads();
+    K2 r; r.m1 = s.m1[par][lane & (NW - 1)]; r.m2 = s.m2[par][lane & (NW - 1)];
+    k2_row_allreduce(r);
+    par ^= 1;
+    return r;
+}
+__device__ __forceinline__ uint64_t wg_min64(uint64_t x, Scratch2 &s, int &par) {
+    x = min64_wave_allreduce(x);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s.m1[par][w] = x;
+    __syncthreads();
+    uint64_t r = s.m1[par][lane & (NW - 1)];
+    r = min64_row_allreduce(r);
+    par ^= 1;
+    return r;
+}
+// sum over the waves of a wave-uniform int; *base = exclusive prefix for this wave
+__device__ __forceinline__ int wg_sum_waves(int wave_val, Scratch2 &s, int &par, int *base) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s.cnt[par][w] = wave_val;
+    __syncthreads();
+    int tot = 0, b = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) { const int c = s.cnt[par][i]; if (i < w) b += c; tot += c; }
+    par ^= 1;
+    if (base) *base = b;
+    return tot;
+}
+// exclusive scan of a per-thread int in thread order (set-up only; not on the hot path)
+__device__ __forceinline__ int wg_exscan2(int x, Scratch2 &s, int &par, int *total) {
+    const int lane = threadIdx.x & 63;
+    int inc = x;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(inc, off); if (lane >= off) inc += y; }
+    const int wtot = __shfl(inc, 63);
+    int base = 0;
+    *total = wg_sum_waves(wtot, s, par, &base);
+    return base + inc - x;
+}
+
+struct CachePtrs {
+    uint32_t *col;   // [n][KC]
+    float *val;      // [n][KC]  raw c[i][col]
+    float *floor;    // [n]      -inf: no usable cache
+};
+
+#define SLOT_COL(sl) ((((sl) / 4) * BLOCK + tid) * 4 + ((sl) % 4))
+
+// Full scan of row i by the whole workgroup: exact two smallest keys of (c[i][j]-v[j], j) over all
+// columns, plus a rebuilt cache for the row.  vreg = current prices of this thread's columns.
+// delta adapts the cache threshold tau = umin + delta so that KC/2..KC columns qualify.
+template <int CH>
+__device__ __forceinline__ K2 refresh_row(int i, int n, int64_t ld, const float *__restrict__ cost,
+                                          const float (&vreg)[CH * 4], uint64_t validm, const CachePtrs &cp,
+                                          float &delta, Scratch2 &s, int &par) {
+    constexpr int NC = CH * 4;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    float4 x[CH];
+    {
+        const float4 *rp = reinterpret_cast<const float4 *>(cost + (int64_t)i * ld);
+#pragma unroll
+        for (int m = 0; m < CH; m++) { const int q = m * BLOCK + tid; if (q * 4 < n) x[m] = rp[q]; }
+    }
+#define HVAL(sl) (vec_get<float>(x[(sl) / 4], (sl) % 4) - vreg[sl])
+    K2 loc; loc.m1 = KEYMAX; loc.m2 = KEYMAX;
+#pragma unroll
+    for (int sl = 0; sl < NC; sl++)
+        if ((validm >> sl) & 1) k2_push(loc, mkkey(HVAL(sl), (uint32_t)SLOT_COL(sl)));
+    const K2 g = wg_k2(loc, s, par);
+    const float umin = key_val(g.m1);
+
+    // threshold search (every thread computes the same sequence)
+    float lo = 0.0f, hi = INFINITY, tau = INFINITY;
+    int cnt = 0;
+    bool okc = false;
+    if (!(delta > 0.0f) || !(delta < 1e30f)) delta = 1e-3f;
+    for (int it = 0; it < 24 && !okc; it++) {
+        tau = umin + delta;
+        int wc = 0;
+#pragma unroll
+        for (int sl = 0; sl < NC; sl++) wc += __popcll(__ballot(((validm >> sl) & 1) && HVAL(sl) < tau));
+        cnt = wg_sum_waves(wc, s, par, nullptr);
+        if (cnt > KC) {
+            hi = delta;
+            const float mid = (lo > 0.0f) ? 0.5f * (lo + hi) : 0.5f * delta;
+            if (!(mid < hi) || !(mid > lo)) break;   // cannot separate: too many ties just above umin
+            delta = mid;
+        } else if (cnt < KC / 2 && cnt < n && delta < 1e30f) {
+            lo = delta;
+            const float mid = (hi < INFINITY) ? 0.5f * (lo + hi) : 2.0f * delta;
+            if (hi < INFINITY && (!(mid < hi) || !(mid > lo))) { okc = true; break; }  // best separable threshold
+            delta = mid;
+        } else {
+            okc = true;
+        }
+    }
+    if (!okc || cnt > KC) {
+        // last resort: use the largest threshold known to admit <= KC columns (possibly none)
+        if (lo > 0.0f) { delta = lo; tau = umin + lo; } else { tau = -INFINITY; }
+    }
+    // compaction: entries ordered by (wave, slot, lane); unused entries get the sentinel
+    int wc = 0;
+#pragma unroll
+    for (int sl = 0; sl < NC; sl++) wc += __popcll(__ballot(((validm >> sl) & 1) && HVAL(sl) < tau));
+    int base = 0;
+    cnt = wg_sum_waves(wc, s, par, &base);
+    if (cnt > KC) { tau = -INFINITY; cnt = 0; }   // (cannot happen; keeps the cache valid regardless)
+    uint32_t *ccol = cp.col + (int64_t)i * KC;
+    float *cval = cp.val + (int64_t)i * KC;
+    const uint64_t ltmask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int sl = 0; sl < NC; sl++) {
+        const bool q = ((validm >> sl) & 1) && HVAL(sl) < tau;
+        const uint64_t bm = __ballot(q);
+        if (q) {
+            const int pos = base + __popcll(bm & ltmask);
+            ccol[pos] = (uint32_t)SLOT_COL(sl);
+            cval[pos] = vec_get<float>(x[sl / 4], sl % 4);
+        }
+        base += __popcll(bm);
+    }
+    if (tid >= cnt && tid < KC) { ccol[tid] = COLSENT; cval[tid] = 0.0f; }
+    if (tid == 0) cp.floor[i] = tau;
+#undef HVAL
+    __syncthreads();  // the rebuilt cache is complete before anyone may read it
+    return g;
+}
+
+// Caches for all rows against the post-column-reduction prices: a full-chip streaming pass.
+template <int CH>
+__global__ __launch_bounds__(BLOCK) void build_row_caches(int n, int64_t ld, const float *__restrict__ cost,
+                                                          const float *__restrict__ v, CachePtrs cp) {
+    constexpr int NC = CH * 4;
+    __shared__ Scratch2 s;
+    const int tid = threadIdx.x;
+    int par = 0;
+    float vreg[NC];
+    uint64_t validm = 0;
+#pragma unroll
+    for (int sl = 0; sl < NC; sl++) {
+        const int c = SLOT_COL(sl);
+        vreg[sl] = 0.0f;
+        if (c < n) { validm |= (1ull << sl); vreg[sl] = v[c]; }
+    }
+    float delta = 0.0f;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) (void)refresh_row<CH>(i, n, ld, cost, vreg, validm, cp, delta, s, par);
+}
+
+struct Chain2Args {
+    int n;
+    int64_t ld;
+    const float *cost;
+    float *v;            // [n] in: column minima; out: final prices
+    float *u;            // [n] out
+    int32_t *rowsol;     // [n] in/out
+    int32_t *colsol;     // [n] in/out
+    int32_t *matches;    // [n] in
+    int32_t *freerows;   // [n] scratch
+    int32_t *rtrows;     // [n] scratch
+    int32_t *pred;       // [n] scratch
+    CachePtrs cp;
+    double *total;
+    long long *counters; // [C2_NCOUNTERS]
+    int *status;
+};
+
+// LDS_STATE: prices v (fp32) and colsol (u16, 0xFFFF = unassigned) live in LDS (n <= ~26k);
+// otherwise they live in global memory and are accessed L2-coherently.
+template <int CH, bool LDS_STATE>
+__global__ __launch_bounds__(BLOCK) void jv_chain2(Chain2Args a) {
+    constexpr int NC = CH * 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    __shared__ Scratch2 s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = a.n;
+    const int64_t ld = a.ld;
+    const float *__restrict__ cost = a.cost;
+    const int npad = (n + 3) & ~3;
+    float *s_v = reinterpret_cast<float *>(dyn_lds);
+    uint16_t *s_cs = reinterpret_cast<uint16_t *>(dyn_lds + (size_t)npad * 4);
+    int par = 0;
+
+    auto v_get = [&](int j) -> float {
+        if constexpr (LDS_STATE) return s_v[j];
+        else return __hip_atomic_load(a.v + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto v_set = [&](int j, float x) {
+        if constexpr (LDS_STATE) s_v[j] = x;
+        else __hip_atomic_store(a.v + j, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto cs_get = [&](int j) -> int32_t {
+        if constexpr (LDS_STATE) { const uint16_t c = s_cs[j]; return c == 0xFFFFu ? -1 : (int32_t)c; }
+        else return ld_i32(a.colsol + j);
+    };
+    auto cs_set = [&](int j, int32_t i) {
+        if constexpr (LDS_STATE) s_cs[j] = (uint16_t)i;
+        else st_i32(a.colsol + j, i);
+    };
+
+    uint64_t validm = 0;
+#pragma unroll
+    for (int sl = 0; sl < NC; sl++) if (SLOT_COL(sl) < n) validm |= (1ull << sl);
+
+    if constexpr (LDS_STATE) {
+        for (int c = tid; c < npad; c += BLOCK) {
+            s_v[c] = c < n ? a.v[c] : 0.0f;
+            const int32_t cs = c < n ? a.colsol[c] : -1;
+            s_cs[c] = cs < 0 ? (uint16_t)0xFFFFu : (uint16_t)cs;
+        }
+    }
+
+    // ---- free-row list (matches == 0) and reduction-transfer list (matches == 1), ascending ----
+    int numfree = 0, nrt = 0;
+    {
+        const int R = (n + BLOCK - 1) / BLOCK;
+        const int r0 = min(n, tid * R), r1 = min(n, r0 + R);
+        int f = 0, g = 0;
+        for (int i = r0; i < r1; i++) { const int mt = a.matches[i]; f += (mt == 0); g += (mt == 1); }
+        int of = wg_exscan2(f, s, par, &numfree);
+        int og = wg_exscan2(g, s, par, &nrt);
+        for (int i = r0; i < r1; i++) {
+            const int mt = a.matches[i];
+            if (mt == 0) st_i32(a.freerows + of++, i);
+            else if (mt == 1) st_i32(a.rtrows + og++, i);
+        }
+    }
+    __syncthreads();
+
+    float delta = 0.0f;
+    // current prices of this thread's columns (for the dense operations)
+    auto load_vreg = [&](float (&vreg)[NC]) {
+#pragma unroll
+        for (int m = 0; m < CH; m++) {
+            const int q = m * BLOCK + tid;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q * 4 < n) {
+                if constexpr (LDS_STATE) t = *reinterpret_cast<const float4 *>(s_v + q * 4);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int c = q * 4 + e;
+                        const float val = c < n ? v_get(c) : 0.0f;
+                        if (e == 0) t.x = val; else if (e == 1) t.y = val; else if (e == 2) t.z = val; else t.w = val;
+                    }
+                }
+            }
+            vreg[m * 4 + 0] = t.x; vreg[m * 4 + 1] = t.y; vreg[m * 4 + 2] = t.z; vreg[m * 4 + 3] = t.w;
+        }
+    };
+    auto do_refresh = [&](int i) -> K2 {
+        float vreg[NC];
+        load_vreg(vreg);
+        return refresh_row<CH>(i, n, ld, cost, vreg, validm, a.cp, delta, s, par);
+    };
+
+    long long c_augrelax = 0, c_hops = 0;
+    int aug_err = 0;
+    // One augmentation (all threads, uniform control): dense Dijkstra search from `freerow`,
+    // price update, path flip.  Same pick rule as the oracle: lexicographic minimum of
+    // (d, assigned?, column) over the unscanned columns.
+    auto do_augment = [&](int freerow) {
+        float vreg[NC], dreg[NC];
+        load_vreg(vreg);
+        uint64_t assignedm = 0, scannedm = 0, readym = 0;
+#pragma unroll
+        for (int sl = 0; sl < NC; sl++)
+            if (((validm >> sl) & 1) && cs_get(SLOT_COL(sl)) >= 0) assignedm |= (1ull << sl);
+        {
+            const float4 *rp = reinterpret_cast<const float4 *>(cost + (int64_t)freerow * ld);
+            float4 x[CH];
+#pragma unroll
+            for (int m = 0; m < CH; m++) { const int q = m * BLOCK + tid; if (q * 4 < n) x[m] = rp[q]; }
+#pragma unroll
+            for (int sl = 0; sl < NC; sl++) {
+                dreg[sl] = INFINITY;
+                if ((validm >> sl) & 1) { dreg[sl] = vec_get<float>(x[sl / 4], sl % 4) - vreg[sl]; a.pred[SLOT_COL(sl)] = freerow; }
+            }
+        }
+        bool have = false;
+        float curmin = 0.0f;
+        int endofpath = -1;
+        for (;;) {
+            uint64_t loc = KEYMAX;
+#pragma unroll
+            for (int sl = 0; sl < NC; sl++) {
+                if (((validm & ~scannedm) >> sl) & 1) {
+                    const uint32_t low = (uint32_t)SLOT_COL(sl) | (((assignedm >> sl) & 1) ? 0x80000000u : 0u);
+                    loc = umin64(loc, mkkey(dreg[sl], low));
+                }
+            }
+            const uint64_t g = wg_min64(loc, s, par);
+            if (g == KEYMAX) { aug_err = CYTO_ERR_INTERNAL; break; }
+            const int jp = (int)((uint32_t)g & 0x7FFFFFFFu);
+            const float dmin = key_val(g);
+            if (!have || dmin != curmin) { readym |= scannedm; curmin = dmin; have = true; }
+            if (!((uint32_t)g & 0x80000000u)) { endofpath = jp; break; }
+            {
+                const int q = jp >> 2;
+                if ((q % BLOCK) == tid) scannedm |= (1ull << ((q / BLOCK) * 4 + (jp & 3)));
+            }
+            const int i = cs_get(jp);
+            const float4 *rp = reinterpret_cast<const float4 *>(cost + (int64_t)i * ld);
+            float4 x[CH];
+#pragma unroll
+            for (int m = 0; m < CH; m++) { const int q = m * BLOCK + tid; if (q * 4 < n) x[m] = rp[q]; }
+            const float cip = cost[(int64_t)i * ld + jp];
+            const float h = (cip - v_get(jp)) - curmin;
+#pragma unroll
+            for (int sl = 0; sl < NC; sl++) {
+                if (((validm & ~scannedm) >> sl) & 1) {
+                    const float v2 = (vec_get<float>(x[sl / 4], sl % 4) - vreg[sl]) - h;
+                    if (v2 < dreg[sl]) { dreg[sl] = v2; a.pred[SLOT_COL(sl)] = i; }
+                }
+            }
+            c_augrelax++;
+        }
+        if (aug_err) return;
+#pragma unroll
+        for (int sl = 0; sl < NC; sl++)
+            if ((readym >> sl) & 1) v_set(SLOT_COL(sl), (vreg[sl] + dreg[sl]) - curmin);
+        __syncthreads();  // pred stores and price updates of all waves are complete
+        if (tid == 0) {
+            int ep = endofpath, i;
+            do {
+                i = ld_i32(a.pred + ep);
+                cs_set(ep, i);
+                const int j1 = ep;
+                ep = ld_i32(a.rowsol + i);
+                st_i32(a.rowsol + i, j1);
+                c_hops++;
+            } while (i != freerow);
+        }
+        __syncthreads();
+    };
+
+    long long c_rt = 0, c_arr = 0, c_augs = 0, c_dense = 0;
+    long long c_free_cr = numfree, c_free_a1 = 0, c_free_a2 = 0;
+
+    if (wave != 0) {
+        // service loop: wave 0 drives; the other waves help with dense operations
+        for (;;) {
+            __syncthreads();
+            const int op = s.cmd_op, row = s.cmd_row;
+            if (op == OP_EXIT) break;
+            if (op == OP_REFRESH) (void)do_refresh(row);
+            else do_augment(row);
+        }
+    } else {
+        auto dense_top2 = [&](int i) -> K2 {
+            if (lane == 0) { s.cmd_op = OP_REFRESH; s.cmd_row = i; }
+            __syncthreads();
+            c_dense++;
+            return do_refresh(i);
+        };
+        // two smallest keys among the cached columns of row i (column `excl` excluded)
+        auto cached_top2 = [&](int i, int excl, float *floor_out) -> K2 {
+            const uint32_t col = __hip_atomic_load(a.cp.col + (int64_t)i * KC + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float cv = __hip_atomic_load(a.cp.val + (int64_t)i * KC + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *floor_out = __hip_atomic_load(a.cp.floor + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            K2 t; t.m1 = KEYMAX; t.m2 = KEYMAX;
+            if (col != COLSENT && (int)col != excl) t.m1 = mkkey(cv - v_get((int)col), col);
+            return k2_wave_allreduce(t);
+        };
+
+        // ---- REDUCTION TRANSFER ----
+        if (n > 1) {
+            for (int k = 0; k < nrt; k++) {
+                const int i = ld_i32(a.rtrows + k);
+                const int j1 = ld_i32(a.rowsol + i);
+                float F;
+                K2 g = cached_top2(i, j1, &F);
+                float mn;
+                if (key_val(g.m1) < F) mn = key_val(g.m1);
+                else {
+                    g = dense_top2(i);
+                    mn = ((int)(uint32_t)g.m1 == j1) ? key_val(g.m2) : key_val(g.m1);
+                }
+                const float nv = v_get(j1) - mn;
+                if (lane == 0) v_set(j1, nv);
+                c_rt++;
+            }
+        }
+        // ---- AUGMENTING ROW REDUCTION ----
+        for (int sweep = 0; sweep < 2; sweep++) {
+            int k = 0;
+            const int prev = numfree;
+            numfree = 0;
+            int carry = -1;
+            while (carry >= 0 || k < prev) {
+                int i;
+                if (carry >= 0) { i = carry; carry = -1; }
+                else { i = ld_i32(a.freerows + k); k++; }
+                float F;
+                K2 g = cached_top2(i, -1, &F);
+                if (!(key_val(g.m2) < F)) g = dense_top2(i);
+                c_arr++;
+                const float umin = key_val(g.m1), usub = key_val(g.m2);
+                int j1 = (int)(uint32_t)g.m1;
+                const int j2 = (int)(uint32_t)g.m2;
+                int i0 = cs_get(j1);
+                const float vj1 = v_get(j1);
+                const float vnew = vj1 - (usub - umin);
+                const bool lowers = vnew < vj1;
+                if (lowers) { if (lane == 0) v_set(j1, vnew); }
+                else if (i0 >= 0) { j1 = j2; i0 = cs_get(j2); }
+                if (lane == 0) { st_i32(a.rowsol + i, j1); cs_set(j1, i); }
+                if (i0 >= 0) {
+                    if (lowers) carry = i0;
+                    else { if (lane == 0) st_i32(a.freerows + numfree, i0); numfree++; }
+                }
+            }
+            if (sweep == 0) c_free_a1 = numfree;
+        }
+        c_free_a2 = numfree;
+        // ---- AUGMENTATION ----
+        for (int f = 0; f < numfree && !aug_err; f++) {
+            const int freerow = ld_i32(a.freerows + f);
+            if (lane == 0) { s.cmd_op = OP_AUG; s.cmd_row = freerow; }
+            __syncthreads();
+            do_augment(freerow);
+            c_augs++;
+        }
+        if (lane == 0) { s.cmd_op = OP_EXIT; s.cmd_row = 0; }
+        __syncthreads();
+    }
+
+    // ---- write back prices and colsol, then duals u and the total ----
+    if constexpr (LDS_STATE) {
+        for (int c = tid; c < n; c += BLOCK) {
+            a.v[c] = s_v[c];
+            const uint16_t cs = s_cs[c];
+            a.colsol[c] = cs == 0xFFFFu ? -1 : (int32_t)cs;
+        }
+    }
+    __syncthreads();
+    double part = 0.0;
+    for (int i = tid; i < n; i += BLOCK) {
+        const int j = ld_i32(a.rowsol + i);
+        const float cij = cost[(int64_t)i * ld + j];
+        const float vj = __hip_atomic_load(a.v + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.u[i] = cij - vj;
+        part += (double)cij;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0) s.sum[wave] = part;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < NW; w++) t += s.sum[w];
+        *a.total = t;
+        a.counters[C_RT] = c_rt; a.counters[C_ARR] = c_arr; a.counters[C_AUG_INIT] = c_augs;
+        a.counters[C_AUG_RELAX] = c_augrelax; a.counters[C_AUGS] = c_augs; a.counters[C_HOPS] = c_hops;
+        a.counters[C_FREE_CR] = c_free_cr; a.counters[C_FREE_A1] = c_free_a1; a.counters[C_FREE_A2] = c_free_a2;
+        a.counters[C_ROWS_READ] = c_dense + c_augs + c_augrelax;
+        a.counters[C2_DENSE_REFRESH] = c_dense;
+        *a.status = aug_err;
+    }
+}
+#undef SLOT_COL
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+template <int CH, bool LDS_STATE>
+static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_cache_done, hipStream_t stream) {
+    const int npad = (args.n + 3) & ~3;
+    const size_t shmem = LDS_STATE ? (((size_t)npad * 6 + 15) / 16) * 16 : 16;
+    auto kern = jv_chain2<CH, LDS_STATE>;
+    CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL((build_row_caches<CH>), dim3(cache_grid), dim3(BLOCK), 0, stream, args.n, args.ld, args.cost,
+                       (const float *)args.v, args.cp);
+    CYTO_HIP(hipGetLastError());
+    CYTO_HIP(hipEventRecord(ev_cache_done, stream));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(BLOCK), shmem, stream, args);
+    CYTO_HIP(hipGetLastError());
+    return CYTO_OK;
+}
+
 template <typename T, int CH, bool LDSCS>
 static int launch_chain(const ChainArgs<T> &args, hipStream_t stream) {
     const size_t shmem = LDSCS ? (((size_t)args.n * sizeof(int32_t) + 15) / 16) * 16 : 16;
@@ -607,20 +1185,42 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
     ca.freerows = b_free.as<int32_t>(); ca.rtrows = b_rt.as<int32_t>(); ca.pred = b_pred.as<int32_t>();
     ca.total = d_total; ca.counters = d_counters; ca.status = d_status;
 
-    hipEvent_t e1b;
+    hipEvent_t e1b, e1c;
     CYTO_HIP(hipEventCreate(&e1b));
+    CYTO_HIP(hipEventCreate(&e1c));
     CYTO_HIP(hipEventRecord(e1b, stream));
     const int64_t per = (int64_t)VW * BLOCK;
-    if (n <= 2 * per) rc = launch_chain<T, 2, true>(ca, stream);
-    else if (n <= 5 * per) rc = launch_chain<T, 5, true>(ca, stream);
-    else if (n <= 8 * per) rc = launch_chain<T, 8, true>(ca, stream);
-    else rc = launch_chain<T, 16, false>(ca, stream);
-    if (rc) { cleanup(); (void)hipEventDestroy(e1b); return rc; }
+    DevBuf b_ccol, b_cval, b_cfloor;
+    bool fast = false;
+    if constexpr (std::is_same<T, float>::value) {
+        // float32 fast path: per-row top-K caches + single-wave cached chain steps
+        fast = true;
+        if ((rc = b_ccol.alloc((size_t)n * KC * sizeof(uint32_t))) || (rc = b_cval.alloc((size_t)n * KC * sizeof(float))) ||
+            (rc = b_cfloor.alloc(nT))) { cleanup(); return rc; }
+        Chain2Args c2;
+        c2.n = n; c2.ld = dld; c2.cost = dcost; c2.v = b_v.as<float>(); c2.u = b_u.as<float>();
+        c2.rowsol = ca.rowsol; c2.colsol = ca.colsol; c2.matches = ca.matches; c2.freerows = ca.freerows;
+        c2.rtrows = ca.rtrows; c2.pred = ca.pred; c2.total = d_total; c2.counters = d_counters; c2.status = d_status;
+        c2.cp.col = b_ccol.as<uint32_t>(); c2.cp.val = b_cval.as<float>(); c2.cp.floor = b_cfloor.as<float>();
+        const int cache_grid = max(1, min(n, 512));
+        if (n <= 2 * per) rc = launch_chain2<2, true>(c2, cache_grid, e1c, stream);
+        else if (n <= 5 * per) rc = launch_chain2<5, true>(c2, cache_grid, e1c, stream);
+        else if (n <= 26624) rc = launch_chain2<7, true>(c2, cache_grid, e1c, stream);
+        else if (n <= 8 * per) rc = launch_chain2<8, false>(c2, cache_grid, e1c, stream);
+        else rc = launch_chain2<16, false>(c2, cache_grid, e1c, stream);
+    } else {
+        CYTO_HIP(hipEventRecord(e1c, stream));
+        if (n <= 2 * per) rc = launch_chain<T, 2, true>(ca, stream);
+        else if (n <= 5 * per) rc = launch_chain<T, 5, true>(ca, stream);
+        else if (n <= 8 * per) rc = launch_chain<T, 8, true>(ca, stream);
+        else rc = launch_chain<T, 16, false>(ca, stream);
+    }
+    if (rc) { cleanup(); (void)hipEventDestroy(e1b); (void)hipEventDestroy(e1c); return rc; }
     CYTO_HIP(hipEventRecord(e2, stream));
     CYTO_HIP(hipStreamSynchronize(stream));
 
     int h_status = 0;
-    long long h_counters[C_NCOUNTERS];
+    long long h_counters[C2_NCOUNTERS] = {0};
     CYTO_HIP(hipMemcpy(&h_status, d_status, sizeof(int), hipMemcpyDeviceToHost));
     CYTO_HIP(hipMemcpy(h_counters, d_counters, sizeof(h_counters), hipMemcpyDeviceToHost));
     if (rowsol) CYTO_HIP(hipMemcpy(rowsol, b_rowsol.p, nI, hipMemcpyDeviceToHost));
@@ -632,8 +1232,9 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
         memset(info, 0, sizeof *info);
         float ms = 0;
         (void)hipEventElapsedTime(&ms, e0, e1); info->ms_colred = ms;
-        (void)hipEventElapsedTime(&ms, e1b, e2); info->ms_chain = ms;
-        info->ms_total = info->ms_colred + info->ms_chain;
+        (void)hipEventElapsedTime(&ms, e1b, e1c); info->ms_cache = ms;
+        (void)hipEventElapsedTime(&ms, e1c, e2); info->ms_chain = ms;
+        info->ms_total = info->ms_colred + info->ms_cache + info->ms_chain;
         info->scans_colred = n;
         info->scans_redtransfer = h_counters[C_RT];
         info->scans_arr = h_counters[C_ARR];
@@ -644,10 +1245,12 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
         info->free_after_colred = h_counters[C_FREE_CR];
         info->free_after_arr1 = h_counters[C_FREE_A1];
         info->free_after_arr2 = h_counters[C_FREE_A2];
-        info->hbm_row_reads = n + h_counters[C_ROWS_READ];
+        info->hbm_row_reads = n + (fast ? n : 0) + h_counters[C_ROWS_READ];
+        info->dense_refreshes = fast ? h_counters[C2_DENSE_REFRESH] : 0;
     }
     cleanup();
     (void)hipEventDestroy(e1b);
+    (void)hipEventDestroy(e1c);
     return h_status ? CYTO_ERR_INTERNAL : CYTO_OK;
 }
 
