@@ -528,7 +528,7 @@ __global__ __launch_bounds__(BLOCK) void jv_chain(ChainArgs<T> a) {
 // Observation: during REDUCTION TRANSFER and AUGMENTING ROW REDUCTION the prices v[j] only ever
 // DECREASE (RT subtracts a non-negative minimum, ARR only stores vj1_new when vj1_new < v[j1]),
 // so every reduced cost h(i,j) = c[i][j] - v[j] only ever INCREASES.  Hence a row cache
-//     C_i = { j : h(i,j) < F_i }  (at most KC = 64 columns, with their raw c[i][j])  and the floor F_i
+//     C_i = { j : h(i,j) < F_i }  (at most KCU = 63 columns, with their raw c[i][j])  and the floor F_i
 // built at any earlier time stays a valid certificate: every column outside C_i still has
 // h >= F_i.  A later scan of row i only needs the cached columns: if the second-smallest
 // recomputed cached value is < F_i, the cached top-2 IS the exact lexicographic top-2 of the
@@ -536,11 +536,14 @@ __global__ __launch_bounds__(BLOCK) void jv_chain(ChainArgs<T> a) {
 // whole workgroup (and its cache rebuilt).  The caches of all rows are built once, right after
 // the column reduction, by a full-chip streaming kernel (build_row_caches).
 //
-// A cached step runs on ONE wave (lane = cache entry): 2 coalesced 256-B loads, an LDS gather of
-// v, a DPP all-reduce on packed 64-bit keys (order-preserving float bits << 32 | column) and a
-// few scalar updates -- no barrier, no HBM row.
+// A cached step runs on ONE wave (lane = cache entry, lane 63 carries the floor): two coalesced
+// 256-B loads, LDS gathers of v and colsol, three 32-bit DPP all-reduces on order-preserving float
+// keys and a few scalar updates -- no barrier, no HBM row.
 // ==========================================================================================
-constexpr int KC = 64;             // cache entries per row (one per lane of a wave)
+constexpr int BLOCK2 = 512;        // 8 waves: 256 VGPRs per lane for the column-resident state
+constexpr int NW2 = BLOCK2 / 64;
+constexpr int KC = 64;             // cache slots per row (one per lane of a wave)
+constexpr int KCU = 63;            // usable entries; slot 63 = { COLSENT, floor }
 constexpr uint64_t KEYMAX = ~0ull;
 constexpr uint32_t COLSENT = 0xFFFFFFFFu;
 enum { OP_EXIT = 0, OP_REFRESH = 1, OP_AUG = 2 };
@@ -557,6 +560,7 @@ __device__ __forceinline__ uint64_t mkkey(float h, uint32_t lowbits) { return ((
 __device__ __forceinline__ float key_val(uint64_t k) { return ord2f((uint32_t)(k >> 32)); }
 __device__ __forceinline__ uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint64_t umax64(uint64_t a, uint64_t b) { return a < b ? b : a; }
+__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
 struct K2 { uint64_t m1, m2; };  // two smallest keys of a set of DISTINCT keys (or KEYMAX)
 __device__ __forceinline__ void k2_push(K2 &t, uint64_t k) {
@@ -568,18 +572,28 @@ __device__ __forceinline__ void k2_merge(K2 &a, const K2 &b) {
     a.m2 = umin64(hi, umin64(a.m2, b.m2)); a.m1 = lo;
 }
 
+// DPP controls quad_perm[1,0,3,2] (0xB1), quad_perm[2,3,0,1] (0x4E), row_half_mirror (0x141),
+// row_mirror (0x140): a butterfly inside each 16-lane row (merged sets are disjoint at every step).
 template <int CTRL> __device__ __forceinline__ uint32_t dpp32(uint32_t x) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xF, 0xF, true);
 }
 template <int CTRL> __device__ __forceinline__ uint64_t dpp64(uint64_t x) {
     return ((uint64_t)dpp32<CTRL>((uint32_t)(x >> 32)) << 32) | dpp32<CTRL>((uint32_t)x);
 }
+__device__ __forceinline__ uint32_t readlane32(uint32_t x, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, l); }
 __device__ __forceinline__ uint64_t readlane64(uint64_t x, int l) {
-    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(x >> 32), l) << 32) |
-           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, l);
+    return ((uint64_t)readlane32((uint32_t)(x >> 32), l) << 32) | readlane32((uint32_t)x, l);
 }
-// DPP controls quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror, row_mirror: a butterfly
-// inside each 16-lane row (the two merged sets are disjoint at every step).
+__device__ __forceinline__ uint32_t row_min_u32(uint32_t x) {
+    x = umin32(x, dpp32<0xB1>(x)); x = umin32(x, dpp32<0x4E>(x));
+    x = umin32(x, dpp32<0x141>(x)); x = umin32(x, dpp32<0x140>(x));
+    return x;
+}
+// all lanes active; result is wave-uniform (scalar)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
+    x = row_min_u32(x);
+    return umin32(umin32(readlane32(x, 0), readlane32(x, 16)), umin32(readlane32(x, 32), readlane32(x, 48)));
+}
 template <int CTRL> __device__ __forceinline__ void k2_step(K2 &t) {
     K2 o; o.m1 = dpp64<CTRL>(t.m1); o.m2 = dpp64<CTRL>(t.m2);
     k2_merge(t, o);
@@ -611,10 +625,10 @@ __device__ __forceinline__ uint64_t min64_wave_allreduce(uint64_t x) {
 }
 
 struct Scratch2 {
-    uint64_t m1[2][NW], m2[2][NW];
-    int cnt[2][NW];
+    uint64_t m1[2][NW2], m2[2][NW2];
+    int cnt[2][NW2];
     int cmd_op, cmd_row;
-    double sum[NW];
+    double sum[NW2];
 };
 
 __device__ __forceinline__ K2 wg_k2(K2 t, Scratch2 &s, int &par) {
@@ -622,9 +636,10 @@ __device__ __forceinline__ K2 wg_k2(K2 t, Scratch2 &s, int &par) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) { s.m1[par][w] = t.m1; s.m2[par][w] = t.m2; }
     __syncthreads();
-    K2 r; r.m1 = s.m1[par][lane & (NW - 1)]; r.m2 = s.m2[par][lane & (NW - 1)];
-    k2_row_allreduce(r);
+    K2 r; r.m1 = s.m1[par][lane & (NW2 - 1)]; r.m2 = s.m2[par][lane & (NW2 - 1)];
+    k2_step<0xB1>(r); k2_step<0x4E>(r); k2_step<0x141>(r);   // 8 distinct partials per half-row: 3 steps only
     par ^= 1;
+    r.m1 = readlane64(r.m1, 0); r.m2 = readlane64(r.m2, 0);
     return r;
 }
 __device__ __forceinline__ uint64_t wg_min64(uint64_t x, Scratch2 &s, int &par) {
@@ -632,11 +647,16 @@ __device__ __forceinline__ uint64_t wg_min64(uint64_t x, Scratch2 &s, int &par) 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) s.m1[par][w] = x;
     __syncthreads();
-    uint64_t r = s.m1[par][lane & (NW - 1)];
+    uint64_t r = s.m1[par][lane & (NW2 - 1)];
     r = min64_row_allreduce(r);
     par ^= 1;
-    return r;
+    return readlane64(r, 0);
 }
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
+    x += dpp32<0xB1>(x); x += dpp32<0x4E>(x); x += dpp32<0x141>(x); x += dpp32<0x140>(x);
+    return readlane32(x, 0) + readlane32(x, 16) + readlane32(x, 32) + readlane32(x, 48);
+}
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // sum over the waves of a wave-uniform int; *base = exclusive prefix for this wave
 __device__ __forceinline__ int wg_sum_waves(int wave_val, Scratch2 &s, int &par, int *base) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -644,7 +664,7 @@ __device__ __forceinline__ int wg_sum_waves(int wave_val, Scratch2 &s, int &par,
     __syncthreads();
     int tot = 0, b = 0;
 #pragma unroll
-    for (int i = 0; i < NW; i++) { const int c = s.cnt[par][i]; if (i < w) b += c; tot += c; }
+    for (int i = 0; i < NW2; i++) { const int c = s.cnt[par][i]; if (i < w) b += c; tot += c; }
     par ^= 1;
     if (base) *base = b;
     return tot;
@@ -662,34 +682,51 @@ __device__ __forceinline__ int wg_exscan2(int x, Scratch2 &s, int &par, int *tot
 }
 
 struct CachePtrs {
-    uint32_t *col;   // [n][KC]
-    float *val;      // [n][KC]  raw c[i][col]
-    float *floor;    // [n]      -inf: no usable cache
+    uint32_t *col;   // [n][KC]   slot 63: COLSENT
+    float *val;      // [n][KC]   raw c[i][col]; slot 63: the floor (-inf = no usable cache)
 };
 
-#define SLOT_COL(sl) ((((sl) / 4) * BLOCK + tid) * 4 + ((sl) % 4))
+#define SLOT_COL(sl) ((((sl) / 4) * BLOCK2 + tid) * 4 + ((sl) % 4))
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+// One cost row through a bounds-checked buffer descriptor: lane `tid` gets 16 bytes of every
+// 8 KiB chunk (a wave reads 1 KiB contiguous); bytes past the row pitch read as 0, so no branches.
+template <int CH>
+__device__ __forceinline__ void load_row4(const float *__restrict__ cost, int64_t ld, int i, int n, int tid, float4 (&x)[CH]) {
+    (void)n;
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(cost + (int64_t)i * ld), 0, (int)(ld * 4), 0x00020000);
+#pragma unroll
+    for (int m = 0; m < CH; m++) {
+        const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, m * BLOCK2 * 16, 0);
+        x[m] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+    }
+}
+__device__ __forceinline__ float fmin_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // Full scan of row i by the whole workgroup: exact two smallest keys of (c[i][j]-v[j], j) over all
 // columns, plus a rebuilt cache for the row.  vreg = current prices of this thread's columns.
-// delta adapts the cache threshold tau = umin + delta so that KC/2..KC columns qualify.
+// delta adapts the cache threshold tau = umin + delta so that KCU/2..KCU columns qualify.
 template <int CH>
 __device__ __forceinline__ K2 refresh_row(int i, int n, int64_t ld, const float *__restrict__ cost,
-                                          const float (&vreg)[CH * 4], uint64_t validm, const CachePtrs &cp,
-                                          float &delta, Scratch2 &s, int &par) {
+                                          const float (&vreg)[CH * 4], uint64_t validm, uint32_t *__restrict__ cache_col,
+                                          float *__restrict__ cache_val, float &delta, Scratch2 &s, int &par) {
     constexpr int NC = CH * 4;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     float4 x[CH];
-    {
-        const float4 *rp = reinterpret_cast<const float4 *>(cost + (int64_t)i * ld);
-#pragma unroll
-        for (int m = 0; m < CH; m++) { const int q = m * BLOCK + tid; if (q * 4 < n) x[m] = rp[q]; }
-    }
+    load_row4<CH>(cost, ld, i, n, tid, x);
 #define HVAL(sl) (vec_get<float>(x[(sl) / 4], (sl) % 4) - vreg[sl])
     K2 loc; loc.m1 = KEYMAX; loc.m2 = KEYMAX;
 #pragma unroll
-    for (int sl = 0; sl < NC; sl++)
+    for (int sl = 0; sl < NC; sl++) {
         if ((validm >> sl) & 1) k2_push(loc, mkkey(HVAL(sl), (uint32_t)SLOT_COL(sl)));
+        if ((sl & 3) == 3) SCHED_FENCE();
+    }
     const K2 g = wg_k2(loc, s, par);
     const float umin = key_val(g.m1);
 
@@ -700,16 +737,16 @@ __device__ __forceinline__ K2 refresh_row(int i, int n, int64_t ld, const float 
     if (!(delta > 0.0f) || !(delta < 1e30f)) delta = 1e-3f;
     for (int it = 0; it < 24 && !okc; it++) {
         tau = umin + delta;
-        int wc = 0;
+        uint32_t tc = 0;
 #pragma unroll
-        for (int sl = 0; sl < NC; sl++) wc += __popcll(__ballot(((validm >> sl) & 1) && HVAL(sl) < tau));
-        cnt = wg_sum_waves(wc, s, par, nullptr);
-        if (cnt > KC) {
+        for (int sl = 0; sl < NC; sl++) { tc += (((validm >> sl) & 1) && HVAL(sl) < tau) ? 1u : 0u; if ((sl & 3) == 3) SCHED_FENCE(); }
+        cnt = wg_sum_waves((int)wave_sum_u32(tc), s, par, nullptr);
+        if (cnt > KCU) {
             hi = delta;
             const float mid = (lo > 0.0f) ? 0.5f * (lo + hi) : 0.5f * delta;
             if (!(mid < hi) || !(mid > lo)) break;   // cannot separate: too many ties just above umin
             delta = mid;
-        } else if (cnt < KC / 2 && cnt < n && delta < 1e30f) {
+        } else if (cnt < KCU / 2 && cnt < n && delta < 1e30f) {
             lo = delta;
             const float mid = (hi < INFINITY) ? 0.5f * (lo + hi) : 2.0f * delta;
             if (hi < INFINITY && (!(mid < hi) || !(mid > lo))) { okc = true; break; }  // best separable threshold
@@ -718,33 +755,38 @@ __device__ __forceinline__ K2 refresh_row(int i, int n, int64_t ld, const float 
             okc = true;
         }
     }
-    if (!okc || cnt > KC) {
-        // last resort: use the largest threshold known to admit <= KC columns (possibly none)
+    if (!okc || cnt > KCU) {
+        // last resort: the largest threshold known to admit <= KCU columns (possibly none)
         if (lo > 0.0f) { delta = lo; tau = umin + lo; } else { tau = -INFINITY; }
     }
-    // compaction: entries ordered by (wave, slot, lane); unused entries get the sentinel
-    int wc = 0;
+    // compaction: entries ordered by (wave, lane, slot); unused entries get the sentinel
+    uint32_t tc = 0;
 #pragma unroll
-    for (int sl = 0; sl < NC; sl++) wc += __popcll(__ballot(((validm >> sl) & 1) && HVAL(sl) < tau));
+    for (int sl = 0; sl < NC; sl++) { tc += (((validm >> sl) & 1) && HVAL(sl) < tau) ? 1u : 0u; if ((sl & 3) == 3) SCHED_FENCE(); }
     int base = 0;
-    cnt = wg_sum_waves(wc, s, par, &base);
-    if (cnt > KC) { tau = -INFINITY; cnt = 0; }   // (cannot happen; keeps the cache valid regardless)
-    uint32_t *ccol = cp.col + (int64_t)i * KC;
-    float *cval = cp.val + (int64_t)i * KC;
-    const uint64_t ltmask = (1ull << lane) - 1ull;
+    cnt = wg_sum_waves((int)wave_sum_u32(tc), s, par, &base);
+    if (cnt > KCU) { tau = -INFINITY; cnt = 0; tc = 0; }   // (cannot happen; keeps the cache valid regardless)
+    uint32_t *ccol = cache_col + (int64_t)i * KC;
+    float *cval = cache_val + (int64_t)i * KC;
+    if (__ballot(tc != 0)) {
+        // exclusive prefix of the per-lane counts inside the wave
+        uint32_t inc = tc;
 #pragma unroll
-    for (int sl = 0; sl < NC; sl++) {
-        const bool q = ((validm >> sl) & 1) && HVAL(sl) < tau;
-        const uint64_t bm = __ballot(q);
-        if (q) {
-            const int pos = base + __popcll(bm & ltmask);
-            ccol[pos] = (uint32_t)SLOT_COL(sl);
-            cval[pos] = vec_get<float>(x[sl / 4], sl % 4);
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(inc, off); if (lane >= off) inc += y; }
+        int pos = base + (int)(inc - tc);
+        if (tc != 0) {
+#pragma unroll
+            for (int sl = 0; sl < NC; sl++) {
+                if (((validm >> sl) & 1) && HVAL(sl) < tau) {
+                    ccol[pos] = (uint32_t)SLOT_COL(sl);
+                    cval[pos] = vec_get<float>(x[sl / 4], sl % 4);
+                    pos++;
+                }
+            }
         }
-        base += __popcll(bm);
     }
-    if (tid >= cnt && tid < KC) { ccol[tid] = COLSENT; cval[tid] = 0.0f; }
-    if (tid == 0) cp.floor[i] = tau;
+    if (tid >= cnt && tid < KCU) { ccol[tid] = COLSENT; cval[tid] = 0.0f; }
+    if (tid == KCU) { ccol[KCU] = COLSENT; cval[KCU] = tau; }
 #undef HVAL
     __syncthreads();  // the rebuilt cache is complete before anyone may read it
     return g;
@@ -752,8 +794,9 @@ __device__ __forceinline__ K2 refresh_row(int i, int n, int64_t ld, const float 
 
 // Caches for all rows against the post-column-reduction prices: a full-chip streaming pass.
 template <int CH>
-__global__ __launch_bounds__(BLOCK) void build_row_caches(int n, int64_t ld, const float *__restrict__ cost,
-                                                          const float *__restrict__ v, CachePtrs cp) {
+__global__ __launch_bounds__(BLOCK2) void build_row_caches(int n, int64_t ld, const float *__restrict__ cost,
+                                                          const float *__restrict__ v, uint32_t *__restrict__ cache_col,
+                                                          float *__restrict__ cache_val) {
     constexpr int NC = CH * 4;
     __shared__ Scratch2 s;
     const int tid = threadIdx.x;
@@ -767,31 +810,266 @@ __global__ __launch_bounds__(BLOCK) void build_row_caches(int n, int64_t ld, con
         if (c < n) { validm |= (1ull << sl); vreg[sl] = v[c]; }
     }
     float delta = 0.0f;
-    for (int i = blockIdx.x; i < n; i += gridDim.x) (void)refresh_row<CH>(i, n, ld, cost, vreg, validm, cp, delta, s, par);
+    for (int i = blockIdx.x; i < n; i += gridDim.x)
+        (void)refresh_row<CH>(i, n, ld, cost, vreg, validm, cache_col, cache_val, delta, s, par);
 }
 
 struct Chain2Args {
     int n;
     int64_t ld;
     const float *cost;
-    float *v;            // [n] in: column minima; out: final prices
-    float *u;            // [n] out
-    int32_t *rowsol;     // [n] in/out
-    int32_t *colsol;     // [n] in/out
-    int32_t *matches;    // [n] in
-    int32_t *freerows;   // [n] scratch
-    int32_t *rtrows;     // [n] scratch
-    int32_t *pred;       // [n] scratch
-    CachePtrs cp;
-    double *total;
-    long long *counters; // [C2_NCOUNTERS]
-    int *status;
+    float *fws;          // float workspace: v[n] | u[n] | sumvd[n]
+    int32_t *iws;        // int workspace: rowsol | colsol | matches | freerows | rtrows | pred   (n each)
+    uint32_t *cache_col; // [n][KC]
+    float *cache_val;    // [n][KC]
+    char *misc;          // +8: double total; +16: long long counters[]; +4: int status
 };
 
-// LDS_STATE: prices v (fp32) and colsol (u16, 0xFFFF = unassigned) live in LDS (n <= ~26k);
-// otherwise they live in global memory and are accessed L2-coherently.
+// L2-coherent (agent-scope, relaxed) accesses to global state
+__device__ __forceinline__ float ld_f32(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_f32(float *p, float x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// State accessors.  LDS_STATE: prices v (fp32) and colsol (u16, 0xFFFF = unassigned) live in LDS
+// (n <= ~26k); otherwise they live in global memory and are accessed L2-coherently.
+template <bool LDS_STATE> __device__ __forceinline__ float st_vget(const float *s_v, const float *gv, int j) {
+    if constexpr (LDS_STATE) return s_v[j]; else return ld_f32(gv + j);
+}
+template <bool LDS_STATE> __device__ __forceinline__ void st_vset(float *s_v, float *gv, int j, float x) {
+    if constexpr (LDS_STATE) s_v[j] = x; else st_f32(gv + j, x);
+}
+template <bool LDS_STATE> __device__ __forceinline__ int32_t st_csget(const uint16_t *s_cs, const int32_t *gcs, int j) {
+    if constexpr (LDS_STATE) { const uint16_t c = s_cs[j]; return c == 0xFFFFu ? -1 : (int32_t)c; }
+    else return ld_i32(gcs + j);
+}
+template <bool LDS_STATE> __device__ __forceinline__ void st_csset(uint16_t *s_cs, int32_t *gcs, int j, int32_t i) {
+    if constexpr (LDS_STATE) s_cs[j] = (uint16_t)i; else st_i32(gcs + j, i);
+}
+
 template <int CH, bool LDS_STATE>
-__global__ __launch_bounds__(BLOCK) void jv_chain2(Chain2Args a) {
+__device__ __forceinline__ void load_vreg(const float *s_v, const float *gv, int n, int tid, float (&vreg)[CH * 4]) {
+#pragma unroll
+    for (int m = 0; m < CH; m++) {
+        const int q = m * BLOCK2 + tid;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q * 4 < n) {
+            if constexpr (LDS_STATE) t = *reinterpret_cast<const float4 *>(s_v + q * 4);
+            else {
+                const int c = q * 4;
+                t.x = ld_f32(gv + c);
+                t.y = c + 1 < n ? ld_f32(gv + c + 1) : 0.f;
+                t.z = c + 2 < n ? ld_f32(gv + c + 2) : 0.f;
+                t.w = c + 3 < n ? ld_f32(gv + c + 3) : 0.f;
+            }
+        }
+        vreg[m * 4 + 0] = t.x; vreg[m * 4 + 1] = t.y; vreg[m * 4 + 2] = t.z; vreg[m * 4 + 3] = t.w;
+    }
+}
+
+__device__ __forceinline__ uint32_t wg_min_u32(uint32_t x, Scratch2 &s, int &par) {
+    const uint32_t w0 = wave_min_u32(x);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t *buf = reinterpret_cast<uint32_t *>(&s.cnt[par][0]);
+    if (lane == 0) buf[w] = w0;
+    __syncthreads();
+    uint32_t r = buf[lane & (NW2 - 1)];
+    r = row_min_u32(r);
+    par ^= 1;
+    return readlane32(r, 0);
+}
+
+// One augmentation (all threads, uniform control): dense Dijkstra search from `freerow`, price
+// update, path flip.  Same pick rule as the oracle: lexicographic minimum of (d, assigned?, column)
+// over the unscanned columns.  Per column the owning lane keeps, in VGPRs, the distance d (+inf
+// once the column is scanned), the price vm (-inf once scanned: every later relaxation of that
+// column is then a no-op) and the predecessor row; relax + running minimum are 6 VALU operations
+// per column.  The arg-min is found in two steps: the minimum value first (one 32-bit all-reduce
+// on order-preserving keys), then the column among the few lanes that hold that value.
+template <int CH, bool LDS_STATE>
+__device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__restrict__ cost, float *gv, float *sumvd,
+                                             int32_t *rowsol, int32_t *gcolsol, int32_t *pred, float *s_v, uint16_t *s_cs,
+                                             int freerow, uint64_t validm, Scratch2 &s, int &par, long long &c_relax,
+                                             long long &c_hops) {
+    constexpr int NC = CH * 4;
+    const int tid = threadIdx.x;
+    float vm[NC], dreg[NC], cm[CH];
+    int32_t preg[NC];
+    load_vreg<CH, LDS_STATE>(s_v, gv, n, tid, vm);
+    uint64_t assignedm = 0, scannedm = 0, readym = 0;
+#pragma unroll
+    for (int sl = 0; sl < NC; sl++)
+        if (((validm >> sl) & 1) && st_csget<LDS_STATE>(s_cs, gcolsol, SLOT_COL(sl)) >= 0) assignedm |= (1ull << sl);
+    {
+        float4 x[CH];
+        load_row4<CH>(cost, ld, freerow, n, tid, x);
+#pragma unroll
+        for (int sl = 0; sl < NC; sl++) {
+            const bool ok = (validm >> sl) & 1;
+            dreg[sl] = ok ? vec_get<float>(x[sl / 4], sl % 4) - vm[sl] : INFINITY;
+            vm[sl] = ok ? vm[sl] : -INFINITY;
+            preg[sl] = freerow;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < CH; m++)
+        cm[m] = fmin_raw(fmin_raw(dreg[m * 4], dreg[m * 4 + 1]), fmin_raw(dreg[m * 4 + 2], dreg[m * 4 + 3]));
+    bool have = false;
+    float curmin = 0.0f;
+    int endofpath = -1;
+    for (;;) {
+        // pick: smallest d; among equal d an unassigned column first, then the lowest column
+        float lm = cm[0];
+#pragma unroll
+        for (int m = 1; m < CH; m++) lm = fmin_raw(lm, cm[m]);
+        const uint32_t omin = wg_min_u32(f2ord(lm), s, par);
+        const float dmin = ord2f(omin);
+        uint32_t lk = 0xFFFFFFFFu;
+        if (lm == dmin) {
+#pragma unroll
+            for (int m = 0; m < CH; m++) {
+                if (cm[m] == dmin) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int sl = m * 4 + e;
+                        if (dreg[sl] == dmin)
+                            lk = umin32(lk, (uint32_t)SLOT_COL(sl) | (((assignedm >> sl) & 1) ? 0x80000000u : 0u));
+                    }
+                }
+            }
+        }
+        const uint32_t g = wg_min_u32(lk, s, par);
+        if (g == 0xFFFFFFFFu || !(dmin < INFINITY)) return CYTO_ERR_INTERNAL;
+        const int jp = (int)(g & 0x7FFFFFFFu);
+        if (!have || dmin != curmin) { readym |= scannedm; curmin = dmin; have = true; }
+        if (!(g & 0x80000000u)) { endofpath = jp; break; }
+        const int i = __builtin_amdgcn_readfirstlane(st_csget<LDS_STATE>(s_cs, gcolsol, jp));
+        float4 x[CH];
+        load_row4<CH>(cost, ld, i, n, tid, x);
+        const float cip = cost[(int64_t)i * ld + jp];
+        const float vjp = st_vget<LDS_STATE>(s_v, gv, jp);
+        const float h = (cip - vjp) - curmin;
+        {   // retire column jp: remember v+d for the price update, mask the column out
+            const int q = jp >> 2;
+            const int sj = (q / BLOCK2) * 4 + (jp & 3);   // uniform
+            const bool own = (q % BLOCK2) == tid;
+            if (own) { scannedm |= (1ull << sj); sumvd[jp] = vjp + dmin; }
+#define MASK_CASE(K) case K: if constexpr (K < NC) { if (own) { vm[K < NC ? K : 0] = -INFINITY; dreg[K < NC ? K : 0] = INFINITY; } } break;
+            switch (sj) {
+            MASK_CASE(0)
+            MASK_CASE(1)
+            MASK_CASE(2)
+            MASK_CASE(3)
+            MASK_CASE(4)
+            MASK_CASE(5)
+            MASK_CASE(6)
+            MASK_CASE(7)
+            MASK_CASE(8)
+            MASK_CASE(9)
+            MASK_CASE(10)
+            MASK_CASE(11)
+            MASK_CASE(12)
+            MASK_CASE(13)
+            MASK_CASE(14)
+            MASK_CASE(15)
+            MASK_CASE(16)
+            MASK_CASE(17)
+            MASK_CASE(18)
+            MASK_CASE(19)
+            MASK_CASE(20)
+            MASK_CASE(21)
+            MASK_CASE(22)
+            MASK_CASE(23)
+            MASK_CASE(24)
+            MASK_CASE(25)
+            MASK_CASE(26)
+            MASK_CASE(27)
+            MASK_CASE(28)
+            MASK_CASE(29)
+            MASK_CASE(30)
+            MASK_CASE(31)
+            MASK_CASE(32)
+            MASK_CASE(33)
+            MASK_CASE(34)
+            MASK_CASE(35)
+            MASK_CASE(36)
+            MASK_CASE(37)
+            MASK_CASE(38)
+            MASK_CASE(39)
+            MASK_CASE(40)
+            MASK_CASE(41)
+            MASK_CASE(42)
+            MASK_CASE(43)
+            MASK_CASE(44)
+            MASK_CASE(45)
+            MASK_CASE(46)
+            MASK_CASE(47)
+            MASK_CASE(48)
+            MASK_CASE(49)
+            MASK_CASE(50)
+            MASK_CASE(51)
+            MASK_CASE(52)
+            MASK_CASE(53)
+            MASK_CASE(54)
+            MASK_CASE(55)
+            MASK_CASE(56)
+            MASK_CASE(57)
+            MASK_CASE(58)
+            MASK_CASE(59)
+            MASK_CASE(60)
+            MASK_CASE(61)
+            MASK_CASE(62)
+            MASK_CASE(63)
+            default: break;
+            }
+#undef MASK_CASE
+        }
+#pragma unroll
+        for (int m = 0; m < CH; m++) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int sl = m * 4 + e;
+                const float v2 = (vec_get<float>(x[m], e) - vm[sl]) - h;
+                const bool upd = v2 < dreg[sl];
+                dreg[sl] = upd ? v2 : dreg[sl];
+                preg[sl] = upd ? i : preg[sl];
+            }
+            cm[m] = fmin_raw(fmin_raw(dreg[m * 4], dreg[m * 4 + 1]), fmin_raw(dreg[m * 4 + 2], dreg[m * 4 + 3]));
+            SCHED_FENCE();
+        }
+        c_relax++;
+    }
+    // price update (columns scanned at an earlier level than the final one) and pred hand-off
+#pragma unroll
+    for (int sl = 0; sl < NC; sl++)
+        if ((readym >> sl) & 1) st_vset<LDS_STATE>(s_v, gv, SLOT_COL(sl), sumvd[SLOT_COL(sl)] - curmin);
+    {
+        const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(pred, 0, n * 4, 0x00020000);
+#pragma unroll
+        for (int m = 0; m < CH; m++) {
+            const u32x4_t t = {(uint32_t)preg[m * 4], (uint32_t)preg[m * 4 + 1], (uint32_t)preg[m * 4 + 2], (uint32_t)preg[m * 4 + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(t, pr, tid * 16, m * BLOCK2 * 16, 0);
+        }
+    }
+    __syncthreads();  // pred stores and price updates of all waves are complete
+    if (tid == 0) {
+        int ep = endofpath, i;
+        do {
+            i = ld_i32(pred + ep);
+            st_csset<LDS_STATE>(s_cs, gcolsol, ep, i);
+            const int j1 = ep;
+            ep = ld_i32(rowsol + i);
+            st_i32(rowsol + i, j1);
+            c_hops++;
+        } while (i != freerow);
+    }
+    __syncthreads();
+    return 0;
+}
+
+enum { PH_RT = 0, PH_ARR = 1, PH_AUG = 2 };
+
+template <int CH, bool LDS_STATE>
+__global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
     constexpr int NC = CH * 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     __shared__ Scratch2 s;
@@ -799,36 +1077,23 @@ __global__ __launch_bounds__(BLOCK) void jv_chain2(Chain2Args a) {
     const int n = a.n;
     const int64_t ld = a.ld;
     const float *__restrict__ cost = a.cost;
+    float *gv = a.fws;
+    float *sumvd = a.fws + 2 * (int64_t)n;
+    int32_t *rowsol = a.iws, *gcolsol = a.iws + n, *matches = a.iws + 2 * (int64_t)n;
+    int32_t *freerows = a.iws + 3 * (int64_t)n, *rtrows = a.iws + 4 * (int64_t)n, *pred = a.iws + 5 * (int64_t)n;
     const int npad = (n + 3) & ~3;
     float *s_v = reinterpret_cast<float *>(dyn_lds);
     uint16_t *s_cs = reinterpret_cast<uint16_t *>(dyn_lds + (size_t)npad * 4);
     int par = 0;
-
-    auto v_get = [&](int j) -> float {
-        if constexpr (LDS_STATE) return s_v[j];
-        else return __hip_atomic_load(a.v + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    auto v_set = [&](int j, float x) {
-        if constexpr (LDS_STATE) s_v[j] = x;
-        else __hip_atomic_store(a.v + j, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    auto cs_get = [&](int j) -> int32_t {
-        if constexpr (LDS_STATE) { const uint16_t c = s_cs[j]; return c == 0xFFFFu ? -1 : (int32_t)c; }
-        else return ld_i32(a.colsol + j);
-    };
-    auto cs_set = [&](int j, int32_t i) {
-        if constexpr (LDS_STATE) s_cs[j] = (uint16_t)i;
-        else st_i32(a.colsol + j, i);
-    };
 
     uint64_t validm = 0;
 #pragma unroll
     for (int sl = 0; sl < NC; sl++) if (SLOT_COL(sl) < n) validm |= (1ull << sl);
 
     if constexpr (LDS_STATE) {
-        for (int c = tid; c < npad; c += BLOCK) {
-            s_v[c] = c < n ? a.v[c] : 0.0f;
-            const int32_t cs = c < n ? a.colsol[c] : -1;
+        for (int c = tid; c < npad; c += BLOCK2) {
+            s_v[c] = c < n ? gv[c] : 0.0f;
+            const int32_t cs = c < n ? gcolsol[c] : -1;
             s_cs[c] = cs < 0 ? (uint16_t)0xFFFFu : (uint16_t)cs;
         }
     }
@@ -836,233 +1101,169 @@ __global__ __launch_bounds__(BLOCK) void jv_chain2(Chain2Args a) {
     // ---- free-row list (matches == 0) and reduction-transfer list (matches == 1), ascending ----
     int numfree = 0, nrt = 0;
     {
-        const int R = (n + BLOCK - 1) / BLOCK;
+        const int R = (n + BLOCK2 - 1) / BLOCK2;
         const int r0 = min(n, tid * R), r1 = min(n, r0 + R);
         int f = 0, g = 0;
-        for (int i = r0; i < r1; i++) { const int mt = a.matches[i]; f += (mt == 0); g += (mt == 1); }
+        for (int i = r0; i < r1; i++) { const int mt = matches[i]; f += (mt == 0); g += (mt == 1); }
         int of = wg_exscan2(f, s, par, &numfree);
         int og = wg_exscan2(g, s, par, &nrt);
         for (int i = r0; i < r1; i++) {
-            const int mt = a.matches[i];
-            if (mt == 0) st_i32(a.freerows + of++, i);
-            else if (mt == 1) st_i32(a.rtrows + og++, i);
+            const int mt = matches[i];
+            if (mt == 0) st_i32(freerows + of++, i);
+            else if (mt == 1) st_i32(rtrows + og++, i);
         }
     }
     __syncthreads();
 
     float delta = 0.0f;
-    // current prices of this thread's columns (for the dense operations)
-    auto load_vreg = [&](float (&vreg)[NC]) {
-#pragma unroll
-        for (int m = 0; m < CH; m++) {
-            const int q = m * BLOCK + tid;
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q * 4 < n) {
-                if constexpr (LDS_STATE) t = *reinterpret_cast<const float4 *>(s_v + q * 4);
-                else {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int c = q * 4 + e;
-                        const float val = c < n ? v_get(c) : 0.0f;
-                        if (e == 0) t.x = val; else if (e == 1) t.y = val; else if (e == 2) t.z = val; else t.w = val;
+    long long c_relax = 0, c_hops = 0, c_rt = 0, c_arr = 0, c_augs = 0, c_dense = 0;
+    long long c_free_cr = numfree, c_free_a1 = 0, c_free_a2 = 0;
+    int err = 0;
+
+    // chain state (meaningful in wave 0 only; uniform there)
+    int phase = (n > 1) ? PH_RT : PH_ARR;
+    int k = 0, sweep = 0, prev = numfree, carry = -1, cur_i = -1;
+    if (phase == PH_ARR) numfree = 0;
+    bool have_dense = false;
+    K2 gd; gd.m1 = KEYMAX; gd.m2 = KEYMAX;
+
+    for (;;) {
+        if (wave == 0) {
+            // wave 0 runs cached steps until it needs the whole workgroup (dense re-scan, an
+            // augmentation) or is done; it then posts a command and falls through to the barrier.
+            for (;;) {
+                if (!have_dense) {
+                    if (phase == PH_RT) {
+                        if (k >= nrt) { phase = PH_ARR; sweep = 0; k = 0; prev = numfree; numfree = 0; carry = -1; continue; }
+                        cur_i = __builtin_amdgcn_readfirstlane(ld_i32(rtrows + k)); k++;
+                    } else if (phase == PH_ARR) {
+                        if (carry >= 0) { cur_i = carry; carry = -1; }
+                        else if (k < prev) { cur_i = __builtin_amdgcn_readfirstlane(ld_i32(freerows + k)); k++; }
+                        else if (sweep == 0) { c_free_a1 = numfree; sweep = 1; k = 0; prev = numfree; numfree = 0; continue; }
+                        else { c_free_a2 = numfree; phase = PH_AUG; k = 0; continue; }
+                    } else {
+                        if (k >= numfree || err) { if (lane == 0) { s.cmd_op = OP_EXIT; s.cmd_row = 0; } break; }
+                        cur_i = __builtin_amdgcn_readfirstlane(ld_i32(freerows + k)); k++;
+                        if (lane == 0) { s.cmd_op = OP_AUG; s.cmd_row = cur_i; }
+                        c_augs++;
+                        break;
+                    }
+                }
+                const int i = cur_i;
+                if (phase == PH_RT) {
+                    // v[j1] -= min over j != j1 of (c[i][j] - v[j])
+                    const int j1 = __builtin_amdgcn_readfirstlane(ld_i32(rowsol + i));
+                    float mn;
+                    if (have_dense) {
+                        have_dense = false;
+                        mn = ((int)(uint32_t)gd.m1 == j1) ? key_val(gd.m2) : key_val(gd.m1);
+                    } else {
+                        const uint32_t col = ld_u32(a.cache_col + (int64_t)i * KC + lane);
+                        const float cv = ld_f32(a.cache_val + (int64_t)i * KC + lane);
+                        const float F = __uint_as_float(readlane32(__float_as_uint(cv), KCU));
+                        const bool valid = col != COLSENT && (int)col != j1;
+                        const float vj = st_vget<LDS_STATE>(s_v, gv, valid ? (int)col : 0);
+                        mn = ord2f(wave_min_u32(valid ? f2ord(cv - vj) : 0xFFFFFFFFu));
+                        if (!(mn < F)) {
+                            if (lane == 0) { s.cmd_op = OP_REFRESH; s.cmd_row = i; }
+                            c_dense++;
+                            break;
+                        }
+                    }
+                    const float nv = st_vget<LDS_STATE>(s_v, gv, j1) - mn;
+                    if (lane == 0) st_vset<LDS_STATE>(s_v, gv, j1, nv);
+                    c_rt++;
+                } else {
+                    float umin, usub, vj1;
+                    int j1, j2 = -1, i0, i02 = -1;
+                    if (have_dense) {
+                        have_dense = false;
+                        umin = key_val(gd.m1); usub = key_val(gd.m2);
+                        j1 = (int)(uint32_t)gd.m1; j2 = (int)(uint32_t)gd.m2;
+                        vj1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(st_vget<LDS_STATE>(s_v, gv, j1))));
+                        i0 = __builtin_amdgcn_readfirstlane(st_csget<LDS_STATE>(s_cs, gcolsol, j1));
+                        i02 = __builtin_amdgcn_readfirstlane(st_csget<LDS_STATE>(s_cs, gcolsol, j2));
+                    } else {
+                        const uint32_t col = ld_u32(a.cache_col + (int64_t)i * KC + lane);
+                        const float cv = ld_f32(a.cache_val + (int64_t)i * KC + lane);
+                        const float F = __uint_as_float(readlane32(__float_as_uint(cv), KCU));
+                        const bool valid = col != COLSENT;
+                        const float vj = st_vget<LDS_STATE>(s_v, gv, valid ? (int)col : 0);
+                        const int32_t csj = st_csget<LDS_STATE>(s_cs, gcolsol, valid ? (int)col : 0);
+                        const uint32_t ord = valid ? f2ord(cv - vj) : 0xFFFFFFFFu;
+                        // minimum, its lane (ties: lowest column), then the minimum of the rest
+                        const uint32_t o1 = wave_min_u32(ord);
+                        const uint64_t m1 = __ballot(ord == o1);
+                        int l1 = __builtin_ctzll(m1);
+                        if (m1 & (m1 - 1)) {
+                            const uint32_t cmin = wave_min_u32(ord == o1 ? col : 0xFFFFFFFFu);
+                            l1 = __builtin_ctzll(__ballot(col == cmin));
+                        }
+                        const uint32_t o2 = wave_min_u32(lane == l1 ? 0xFFFFFFFFu : ord);
+                        if (!(ord2f(o2) < F)) {
+                            if (lane == 0) { s.cmd_op = OP_REFRESH; s.cmd_row = i; }
+                            c_dense++;
+                            break;
+                        }
+                        umin = ord2f(o1); usub = ord2f(o2);
+                        j1 = (int)readlane32(col, l1);
+                        vj1 = __uint_as_float(readlane32(__float_as_uint(vj), l1));
+                        i0 = (int)readlane32((uint32_t)csj, l1);
+                        if (!((vj1 - (usub - umin)) < vj1) && i0 >= 0) {
+                            const uint64_t m2 = __ballot(ord == o2 && lane != l1);
+                            int l2 = __builtin_ctzll(m2);
+                            if (m2 & (m2 - 1)) {
+                                const uint32_t cmin2 = wave_min_u32((ord == o2 && lane != l1) ? col : 0xFFFFFFFFu);
+                                l2 = __builtin_ctzll(__ballot(col == cmin2));
+                            }
+                            j2 = (int)readlane32(col, l2);
+                            i02 = (int)readlane32((uint32_t)csj, l2);
+                        }
+                    }
+                    c_arr++;
+                    const float vnew = vj1 - (usub - umin);
+                    const bool lowers = vnew < vj1;
+                    if (lowers) { if (lane == 0) st_vset<LDS_STATE>(s_v, gv, j1, vnew); }
+                    else if (i0 >= 0) { j1 = j2; i0 = i02; }
+                    if (lane == 0) { st_i32(rowsol + i, j1); st_csset<LDS_STATE>(s_cs, gcolsol, j1, i); }
+                    if (i0 >= 0) {
+                        if (lowers) carry = i0;
+                        else { if (lane == 0) st_i32(freerows + numfree, i0); numfree++; }
                     }
                 }
             }
-            vreg[m * 4 + 0] = t.x; vreg[m * 4 + 1] = t.y; vreg[m * 4 + 2] = t.z; vreg[m * 4 + 3] = t.w;
-        }
-    };
-    auto do_refresh = [&](int i) -> K2 {
-        float vreg[NC];
-        load_vreg(vreg);
-        return refresh_row<CH>(i, n, ld, cost, vreg, validm, a.cp, delta, s, par);
-    };
-
-    long long c_augrelax = 0, c_hops = 0;
-    int aug_err = 0;
-    // One augmentation (all threads, uniform control): dense Dijkstra search from `freerow`,
-    // price update, path flip.  Same pick rule as the oracle: lexicographic minimum of
-    // (d, assigned?, column) over the unscanned columns.
-    auto do_augment = [&](int freerow) {
-        float vreg[NC], dreg[NC];
-        load_vreg(vreg);
-        uint64_t assignedm = 0, scannedm = 0, readym = 0;
-#pragma unroll
-        for (int sl = 0; sl < NC; sl++)
-            if (((validm >> sl) & 1) && cs_get(SLOT_COL(sl)) >= 0) assignedm |= (1ull << sl);
-        {
-            const float4 *rp = reinterpret_cast<const float4 *>(cost + (int64_t)freerow * ld);
-            float4 x[CH];
-#pragma unroll
-            for (int m = 0; m < CH; m++) { const int q = m * BLOCK + tid; if (q * 4 < n) x[m] = rp[q]; }
-#pragma unroll
-            for (int sl = 0; sl < NC; sl++) {
-                dreg[sl] = INFINITY;
-                if ((validm >> sl) & 1) { dreg[sl] = vec_get<float>(x[sl / 4], sl % 4) - vreg[sl]; a.pred[SLOT_COL(sl)] = freerow; }
-            }
-        }
-        bool have = false;
-        float curmin = 0.0f;
-        int endofpath = -1;
-        for (;;) {
-            uint64_t loc = KEYMAX;
-#pragma unroll
-            for (int sl = 0; sl < NC; sl++) {
-                if (((validm & ~scannedm) >> sl) & 1) {
-                    const uint32_t low = (uint32_t)SLOT_COL(sl) | (((assignedm >> sl) & 1) ? 0x80000000u : 0u);
-                    loc = umin64(loc, mkkey(dreg[sl], low));
-                }
-            }
-            const uint64_t g = wg_min64(loc, s, par);
-            if (g == KEYMAX) { aug_err = CYTO_ERR_INTERNAL; break; }
-            const int jp = (int)((uint32_t)g & 0x7FFFFFFFu);
-            const float dmin = key_val(g);
-            if (!have || dmin != curmin) { readym |= scannedm; curmin = dmin; have = true; }
-            if (!((uint32_t)g & 0x80000000u)) { endofpath = jp; break; }
-            {
-                const int q = jp >> 2;
-                if ((q % BLOCK) == tid) scannedm |= (1ull << ((q / BLOCK) * 4 + (jp & 3)));
-            }
-            const int i = cs_get(jp);
-            const float4 *rp = reinterpret_cast<const float4 *>(cost + (int64_t)i * ld);
-            float4 x[CH];
-#pragma unroll
-            for (int m = 0; m < CH; m++) { const int q = m * BLOCK + tid; if (q * 4 < n) x[m] = rp[q]; }
-            const float cip = cost[(int64_t)i * ld + jp];
-            const float h = (cip - v_get(jp)) - curmin;
-#pragma unroll
-            for (int sl = 0; sl < NC; sl++) {
-                if (((validm & ~scannedm) >> sl) & 1) {
-                    const float v2 = (vec_get<float>(x[sl / 4], sl % 4) - vreg[sl]) - h;
-                    if (v2 < dreg[sl]) { dreg[sl] = v2; a.pred[SLOT_COL(sl)] = i; }
-                }
-            }
-            c_augrelax++;
-        }
-        if (aug_err) return;
-#pragma unroll
-        for (int sl = 0; sl < NC; sl++)
-            if ((readym >> sl) & 1) v_set(SLOT_COL(sl), (vreg[sl] + dreg[sl]) - curmin);
-        __syncthreads();  // pred stores and price updates of all waves are complete
-        if (tid == 0) {
-            int ep = endofpath, i;
-            do {
-                i = ld_i32(a.pred + ep);
-                cs_set(ep, i);
-                const int j1 = ep;
-                ep = ld_i32(a.rowsol + i);
-                st_i32(a.rowsol + i, j1);
-                c_hops++;
-            } while (i != freerow);
         }
         __syncthreads();
-    };
-
-    long long c_rt = 0, c_arr = 0, c_augs = 0, c_dense = 0;
-    long long c_free_cr = numfree, c_free_a1 = 0, c_free_a2 = 0;
-
-    if (wave != 0) {
-        // service loop: wave 0 drives; the other waves help with dense operations
-        for (;;) {
-            __syncthreads();
-            const int op = s.cmd_op, row = s.cmd_row;
-            if (op == OP_EXIT) break;
-            if (op == OP_REFRESH) (void)do_refresh(row);
-            else do_augment(row);
+        const int op = s.cmd_op, row = s.cmd_row;
+        if (op == OP_EXIT) break;
+        if (op == OP_REFRESH) {
+            float vreg[NC];
+            load_vreg<CH, LDS_STATE>(s_v, gv, n, tid, vreg);
+            gd = refresh_row<CH>(row, n, ld, cost, vreg, validm, a.cache_col, a.cache_val, delta, s, par);
+            have_dense = true;
+        } else {
+            const int e = chain_augment<CH, LDS_STATE>(n, ld, cost, gv, sumvd, rowsol, gcolsol, pred, s_v, s_cs, row, validm, s, par,
+                                                       c_relax, c_hops);
+            if (e) err = e;
         }
-    } else {
-        auto dense_top2 = [&](int i) -> K2 {
-            if (lane == 0) { s.cmd_op = OP_REFRESH; s.cmd_row = i; }
-            __syncthreads();
-            c_dense++;
-            return do_refresh(i);
-        };
-        // two smallest keys among the cached columns of row i (column `excl` excluded)
-        auto cached_top2 = [&](int i, int excl, float *floor_out) -> K2 {
-            const uint32_t col = __hip_atomic_load(a.cp.col + (int64_t)i * KC + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float cv = __hip_atomic_load(a.cp.val + (int64_t)i * KC + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *floor_out = __hip_atomic_load(a.cp.floor + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            K2 t; t.m1 = KEYMAX; t.m2 = KEYMAX;
-            if (col != COLSENT && (int)col != excl) t.m1 = mkkey(cv - v_get((int)col), col);
-            return k2_wave_allreduce(t);
-        };
-
-        // ---- REDUCTION TRANSFER ----
-        if (n > 1) {
-            for (int k = 0; k < nrt; k++) {
-                const int i = ld_i32(a.rtrows + k);
-                const int j1 = ld_i32(a.rowsol + i);
-                float F;
-                K2 g = cached_top2(i, j1, &F);
-                float mn;
-                if (key_val(g.m1) < F) mn = key_val(g.m1);
-                else {
-                    g = dense_top2(i);
-                    mn = ((int)(uint32_t)g.m1 == j1) ? key_val(g.m2) : key_val(g.m1);
-                }
-                const float nv = v_get(j1) - mn;
-                if (lane == 0) v_set(j1, nv);
-                c_rt++;
-            }
-        }
-        // ---- AUGMENTING ROW REDUCTION ----
-        for (int sweep = 0; sweep < 2; sweep++) {
-            int k = 0;
-            const int prev = numfree;
-            numfree = 0;
-            int carry = -1;
-            while (carry >= 0 || k < prev) {
-                int i;
-                if (carry >= 0) { i = carry; carry = -1; }
-                else { i = ld_i32(a.freerows + k); k++; }
-                float F;
-                K2 g = cached_top2(i, -1, &F);
-                if (!(key_val(g.m2) < F)) g = dense_top2(i);
-                c_arr++;
-                const float umin = key_val(g.m1), usub = key_val(g.m2);
-                int j1 = (int)(uint32_t)g.m1;
-                const int j2 = (int)(uint32_t)g.m2;
-                int i0 = cs_get(j1);
-                const float vj1 = v_get(j1);
-                const float vnew = vj1 - (usub - umin);
-                const bool lowers = vnew < vj1;
-                if (lowers) { if (lane == 0) v_set(j1, vnew); }
-                else if (i0 >= 0) { j1 = j2; i0 = cs_get(j2); }
-                if (lane == 0) { st_i32(a.rowsol + i, j1); cs_set(j1, i); }
-                if (i0 >= 0) {
-                    if (lowers) carry = i0;
-                    else { if (lane == 0) st_i32(a.freerows + numfree, i0); numfree++; }
-                }
-            }
-            if (sweep == 0) c_free_a1 = numfree;
-        }
-        c_free_a2 = numfree;
-        // ---- AUGMENTATION ----
-        for (int f = 0; f < numfree && !aug_err; f++) {
-            const int freerow = ld_i32(a.freerows + f);
-            if (lane == 0) { s.cmd_op = OP_AUG; s.cmd_row = freerow; }
-            __syncthreads();
-            do_augment(freerow);
-            c_augs++;
-        }
-        if (lane == 0) { s.cmd_op = OP_EXIT; s.cmd_row = 0; }
-        __syncthreads();
     }
 
     // ---- write back prices and colsol, then duals u and the total ----
     if constexpr (LDS_STATE) {
-        for (int c = tid; c < n; c += BLOCK) {
-            a.v[c] = s_v[c];
+        for (int c = tid; c < n; c += BLOCK2) {
+            gv[c] = s_v[c];
             const uint16_t cs = s_cs[c];
-            a.colsol[c] = cs == 0xFFFFu ? -1 : (int32_t)cs;
+            gcolsol[c] = cs == 0xFFFFu ? -1 : (int32_t)cs;
         }
     }
     __syncthreads();
+    float *gu = a.fws + n;
     double part = 0.0;
-    for (int i = tid; i < n; i += BLOCK) {
-        const int j = ld_i32(a.rowsol + i);
+    for (int i = tid; i < n; i += BLOCK2) {
+        const int j = ld_i32(rowsol + i);
         const float cij = cost[(int64_t)i * ld + j];
-        const float vj = __hip_atomic_load(a.v + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.u[i] = cij - vj;
+        const float vj = ld_f32(gv + j);
+        gu[i] = cij - vj;
         part += (double)cij;
     }
 #pragma unroll
@@ -1071,14 +1272,15 @@ __global__ __launch_bounds__(BLOCK) void jv_chain2(Chain2Args a) {
     __syncthreads();
     if (tid == 0) {
         double t = 0.0;
-        for (int w = 0; w < NW; w++) t += s.sum[w];
-        *a.total = t;
-        a.counters[C_RT] = c_rt; a.counters[C_ARR] = c_arr; a.counters[C_AUG_INIT] = c_augs;
-        a.counters[C_AUG_RELAX] = c_augrelax; a.counters[C_AUGS] = c_augs; a.counters[C_HOPS] = c_hops;
-        a.counters[C_FREE_CR] = c_free_cr; a.counters[C_FREE_A1] = c_free_a1; a.counters[C_FREE_A2] = c_free_a2;
-        a.counters[C_ROWS_READ] = c_dense + c_augs + c_augrelax;
-        a.counters[C2_DENSE_REFRESH] = c_dense;
-        *a.status = aug_err;
+        for (int w = 0; w < NW2; w++) t += s.sum[w];
+        *reinterpret_cast<double *>(a.misc + 8) = t;
+        long long *counters = reinterpret_cast<long long *>(a.misc + 16);
+        counters[C_RT] = c_rt; counters[C_ARR] = c_arr; counters[C_AUG_INIT] = c_augs;
+        counters[C_AUG_RELAX] = c_relax; counters[C_AUGS] = c_augs; counters[C_HOPS] = c_hops;
+        counters[C_FREE_CR] = c_free_cr; counters[C_FREE_A1] = c_free_a1; counters[C_FREE_A2] = c_free_a2;
+        counters[C_ROWS_READ] = c_dense + c_augs + c_relax;
+        counters[C2_DENSE_REFRESH] = c_dense;
+        *reinterpret_cast<int *>(a.misc + 4) = err;
     }
 }
 #undef SLOT_COL
@@ -1092,11 +1294,11 @@ static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_c
     const size_t shmem = LDS_STATE ? (((size_t)npad * 6 + 15) / 16) * 16 : 16;
     auto kern = jv_chain2<CH, LDS_STATE>;
     CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL((build_row_caches<CH>), dim3(cache_grid), dim3(BLOCK), 0, stream, args.n, args.ld, args.cost,
-                       (const float *)args.v, args.cp);
+    hipLaunchKernelGGL((build_row_caches<CH>), dim3(cache_grid), dim3(BLOCK2), 0, stream, args.n, args.ld, args.cost,
+                       (const float *)args.fws, args.cache_col, args.cache_val);
     CYTO_HIP(hipGetLastError());
     CYTO_HIP(hipEventRecord(ev_cache_done, stream));
-    hipLaunchKernelGGL(kern, dim3(1), dim3(BLOCK), shmem, stream, args);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(BLOCK2), shmem, stream, args);
     CYTO_HIP(hipGetLastError());
     return CYTO_OK;
 }
@@ -1142,21 +1344,23 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
     const int rows_per_block = (n + rowblocks - 1) / rowblocks;
     rowblocks = (n + rows_per_block - 1) / rows_per_block;
 
-    DevBuf b_v, b_u, b_rowsol, b_colsol, b_matches, b_imin, b_free, b_rt, b_pred, b_pmin, b_parg, b_misc;
+    DevBuf b_fws, b_iws, b_imin, b_pmin, b_parg, b_misc;
     const size_t nT = (size_t)n * sizeof(T), nI = (size_t)n * sizeof(int32_t);
-    if ((rc = b_v.alloc(nT)) || (rc = b_u.alloc(nT)) || (rc = b_rowsol.alloc(nI)) || (rc = b_colsol.alloc(nI)) ||
-        (rc = b_matches.alloc(nI)) || (rc = b_imin.alloc(nI)) || (rc = b_free.alloc(nI)) || (rc = b_rt.alloc(nI)) ||
-        (rc = b_pred.alloc(nI)) || (rc = b_pmin.alloc((size_t)rowblocks * nT)) ||
-        (rc = b_parg.alloc((size_t)rowblocks * nI)) || (rc = b_misc.alloc(256)))
+    if ((rc = b_fws.alloc(3 * nT)) || (rc = b_iws.alloc(6 * nI)) || (rc = b_imin.alloc(nI)) ||
+        (rc = b_pmin.alloc((size_t)rowblocks * nT)) || (rc = b_parg.alloc((size_t)rowblocks * nI)) || (rc = b_misc.alloc(256)))
         return rc;
+    // float workspace: v | u ; int workspace: rowsol | colsol | matches | freerows | rtrows | pred
+    T *d_v = b_fws.as<T>(), *d_u = b_fws.as<T>() + n;
+    int32_t *d_rowsol = b_iws.as<int32_t>(), *d_colsol = d_rowsol + n, *d_matches = d_rowsol + 2 * (size_t)n;
+    int32_t *d_free = d_rowsol + 3 * (size_t)n, *d_rt = d_rowsol + 4 * (size_t)n, *d_pred = d_rowsol + 5 * (size_t)n;
     // misc: [0] nonfinite flag (int), [1] chain status (int), [8..16) total (double), [16..) counters
     int *d_nonfinite = b_misc.as<int>();
     int *d_status = b_misc.as<int>() + 1;
     double *d_total = reinterpret_cast<double *>(b_misc.as<char>() + 8);
     long long *d_counters = reinterpret_cast<long long *>(b_misc.as<char>() + 16);
     CYTO_HIP(hipMemsetAsync(b_misc.p, 0, 256, stream));
-    CYTO_HIP(hipMemsetAsync(b_rowsol.p, 0xFF, nI, stream));
-    CYTO_HIP(hipMemsetAsync(b_matches.p, 0, nI, stream));
+    CYTO_HIP(hipMemsetAsync(d_rowsol, 0xFF, nI, stream));
+    CYTO_HIP(hipMemsetAsync(d_matches, 0, nI, stream));
 
     hipEvent_t e0, e1, e2;
     CYTO_HIP(hipEventCreate(&e0));
@@ -1168,9 +1372,9 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
     hipLaunchKernelGGL(colred_partial<T>, dim3(colblocks, rowblocks), dim3(256), 0, stream, n, dld, dcost, rows_per_block,
                        b_pmin.as<T>(), b_parg.as<int32_t>(), d_nonfinite);
     hipLaunchKernelGGL(colred_finish<T>, dim3((n + 255) / 256), dim3(256), 0, stream, n, rowblocks, b_pmin.as<T>(),
-                       b_parg.as<int32_t>(), b_v.as<T>(), b_imin.as<int32_t>(), b_rowsol.as<int32_t>(), b_matches.as<int32_t>());
+                       b_parg.as<int32_t>(), d_v, b_imin.as<int32_t>(), d_rowsol, d_matches);
     hipLaunchKernelGGL(colred_assign, dim3((n + 255) / 256), dim3(256), 0, stream, n, b_imin.as<int32_t>(),
-                       b_rowsol.as<int32_t>(), b_colsol.as<int32_t>());
+                       d_rowsol, d_colsol);
     CYTO_HIP(hipEventRecord(e1, stream));
 
     // a non-finite cost makes every later comparison meaningless: stop before the chain
@@ -1180,9 +1384,9 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
     if (h_nonfinite) { cleanup(); return CYTO_ERR_NONFINITE; }
 
     ChainArgs<T> ca;
-    ca.n = n; ca.ld = dld; ca.cost = dcost; ca.v = b_v.as<T>(); ca.u = b_u.as<T>();
-    ca.rowsol = b_rowsol.as<int32_t>(); ca.colsol = b_colsol.as<int32_t>(); ca.matches = b_matches.as<int32_t>();
-    ca.freerows = b_free.as<int32_t>(); ca.rtrows = b_rt.as<int32_t>(); ca.pred = b_pred.as<int32_t>();
+    ca.n = n; ca.ld = dld; ca.cost = dcost; ca.v = d_v; ca.u = d_u;
+    ca.rowsol = d_rowsol; ca.colsol = d_colsol; ca.matches = d_matches;
+    ca.freerows = d_free; ca.rtrows = d_rt; ca.pred = d_pred;
     ca.total = d_total; ca.counters = d_counters; ca.status = d_status;
 
     hipEvent_t e1b, e1c;
@@ -1190,24 +1394,28 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
     CYTO_HIP(hipEventCreate(&e1c));
     CYTO_HIP(hipEventRecord(e1b, stream));
     const int64_t per = (int64_t)VW * BLOCK;
-    DevBuf b_ccol, b_cval, b_cfloor;
+    DevBuf b_ccol, b_cval;
     bool fast = false;
     if constexpr (std::is_same<T, float>::value) {
-        // float32 fast path: per-row top-K caches + single-wave cached chain steps
-        fast = true;
-        if ((rc = b_ccol.alloc((size_t)n * KC * sizeof(uint32_t))) || (rc = b_cval.alloc((size_t)n * KC * sizeof(float))) ||
-            (rc = b_cfloor.alloc(nT))) { cleanup(); return rc; }
-        Chain2Args c2;
-        c2.n = n; c2.ld = dld; c2.cost = dcost; c2.v = b_v.as<float>(); c2.u = b_u.as<float>();
-        c2.rowsol = ca.rowsol; c2.colsol = ca.colsol; c2.matches = ca.matches; c2.freerows = ca.freerows;
-        c2.rtrows = ca.rtrows; c2.pred = ca.pred; c2.total = d_total; c2.counters = d_counters; c2.status = d_status;
-        c2.cp.col = b_ccol.as<uint32_t>(); c2.cp.val = b_cval.as<float>(); c2.cp.floor = b_cfloor.as<float>();
-        const int cache_grid = max(1, min(n, 512));
-        if (n <= 2 * per) rc = launch_chain2<2, true>(c2, cache_grid, e1c, stream);
-        else if (n <= 5 * per) rc = launch_chain2<5, true>(c2, cache_grid, e1c, stream);
-        else if (n <= 26624) rc = launch_chain2<7, true>(c2, cache_grid, e1c, stream);
-        else if (n <= 8 * per) rc = launch_chain2<8, false>(c2, cache_grid, e1c, stream);
-        else rc = launch_chain2<16, false>(c2, cache_grid, e1c, stream);
+        // float32 fast path (n <= 32768): per-row top-K caches + single-wave cached chain steps
+        fast = n <= 16 * 4 * BLOCK2;
+    }
+    if (fast) {
+        if constexpr (std::is_same<T, float>::value) {
+            if ((rc = b_ccol.alloc((size_t)n * KC * sizeof(uint32_t))) || (rc = b_cval.alloc((size_t)n * KC * sizeof(float)))) {
+                cleanup(); return rc;
+            }
+            Chain2Args c2;
+            c2.n = n; c2.ld = dld; c2.cost = dcost; c2.fws = d_v; c2.iws = d_rowsol;
+            c2.cache_col = b_ccol.as<uint32_t>(); c2.cache_val = b_cval.as<float>(); c2.misc = b_misc.as<char>();
+            const int cache_grid = max(1, min(n, 1024));
+            const int per2 = 4 * BLOCK2;
+            if (n <= 2 * per2) rc = launch_chain2<2, true>(c2, cache_grid, e1c, stream);
+            else if (n <= 5 * per2) rc = launch_chain2<5, true>(c2, cache_grid, e1c, stream);
+            else if (n <= 10 * per2) rc = launch_chain2<10, true>(c2, cache_grid, e1c, stream);
+            else if (n <= 13 * per2) rc = launch_chain2<13, true>(c2, cache_grid, e1c, stream);
+            else rc = launch_chain2<16, false>(c2, cache_grid, e1c, stream);
+        }
     } else {
         CYTO_HIP(hipEventRecord(e1c, stream));
         if (n <= 2 * per) rc = launch_chain<T, 2, true>(ca, stream);
@@ -1223,10 +1431,10 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
     long long h_counters[C2_NCOUNTERS] = {0};
     CYTO_HIP(hipMemcpy(&h_status, d_status, sizeof(int), hipMemcpyDeviceToHost));
     CYTO_HIP(hipMemcpy(h_counters, d_counters, sizeof(h_counters), hipMemcpyDeviceToHost));
-    if (rowsol) CYTO_HIP(hipMemcpy(rowsol, b_rowsol.p, nI, hipMemcpyDeviceToHost));
-    if (colsol) CYTO_HIP(hipMemcpy(colsol, b_colsol.p, nI, hipMemcpyDeviceToHost));
-    if (u) CYTO_HIP(hipMemcpy(u, b_u.p, nT, hipMemcpyDeviceToHost));
-    if (v) CYTO_HIP(hipMemcpy(v, b_v.p, nT, hipMemcpyDeviceToHost));
+    if (rowsol) CYTO_HIP(hipMemcpy(rowsol, d_rowsol, nI, hipMemcpyDeviceToHost));
+    if (colsol) CYTO_HIP(hipMemcpy(colsol, d_colsol, nI, hipMemcpyDeviceToHost));
+    if (u) CYTO_HIP(hipMemcpy(u, d_u, nT, hipMemcpyDeviceToHost));
+    if (v) CYTO_HIP(hipMemcpy(v, d_v, nT, hipMemcpyDeviceToHost));
     if (total) CYTO_HIP(hipMemcpy(total, d_total, sizeof(double), hipMemcpyDeviceToHost));
     if (info) {
         memset(info, 0, sizeof *info);
