@@ -37,6 +37,11 @@ class LapInfo(ctypes.Structure):
                    + self.scans_aug_init + self.scans_aug_relax)
 
 
+class AssignInfo(ctypes.Structure):
+    _fields_ = [("ms_standardize", ctypes.c_double), ("ms_gemm", ctypes.c_double), ("gemm_flops", ctypes.c_double),
+                ("lap", LapInfo)]
+
+
 def lib():
     """Return the loaded library (loading it on first use in this process)."""
     global _lib
@@ -61,6 +66,13 @@ def lib():
         for name in ("cyto_lap_f32", "cyto_lap_f64"):
             getattr(L, name).argtypes = [i32, vp, i64, i32, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(LapInfo), i32, vp]
+        dp = ctypes.POINTER(ctypes.c_double)
+        L.cyto_normalize_data.argtypes = [i32, i32, vp, i64, i32, vp, i64, i32]
+        L.cyto_standardize.argtypes = [i32, i32, vp, i64, i32, i32, i32, vp, i64, i32, i32, vp]
+        L.cyto_cost_pearson.argtypes = [i32, i32, i32, vp, i64, vp, i64, vp, vp, i64, dp, i32, vp]
+        L.cyto_assign_pearson.argtypes = [i32, i32, i32, vp, vp, vp, i32, vp, dp, ctypes.POINTER(AssignInfo), i32]
+        for name in ("cyto_normalize_data", "cyto_standardize", "cyto_cost_pearson", "cyto_assign_pearson"):
+            getattr(L, name).restype = ctypes.c_int
         for name in ("cyto_device_count", "cyto_device_name", "cyto_malloc", "cyto_free", "cyto_memcpy_h2d",
                      "cyto_memcpy_d2h", "cyto_device_synchronize", "cyto_lap_f32", "cyto_lap_f64"):
             getattr(L, name).restype = ctypes.c_int

@@ -1,0 +1,412 @@
+// cost.hip -- the correlation cost-matrix build for gfx950 (MI355X), hand-written HIP.
+//
+// Replaces, on the device, the reference's numpy passes
+//   normalize_data              /root/reference/cytospace/common/common.py:142-147
+//   matrix_correlation_pearson  /root/reference/cytospace/common/common.py:190-199
+//   calculate_cost (lapjv/Pearson branch: negate + repeat each spot row slots[s] times)
+//                               /root/reference/cytospace/linear_assignment_solvers/linear_assignment_solvers.py:42-69
+//
+// Formulation.  The reference computes (v2^T v1 - outer(sum2,sum1)/G) / outer(std2,std1) / G in
+// float64, i.e. a dot product minus a product of sums (catastrophic cancellation in float32).
+// Here every column is first STANDARDISED in float64 and stored as float32
+//     z[g][c] = (y[g][c] - mean_c) / (std_c * sqrt(G)),     y = log2(x * 1e6 / colsum + 1)
+// so the contraction   corr[s][c] = sum_g zst[g][s] * zsc[g][c]   IS the correlation and needs no
+// cancellation; it runs on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32) with fp32
+// accumulation.  Zero-variance columns give inf/NaN exactly where the reference divides by zero;
+// the LAP entry point then reports CYTO_ERR_NONFINITE.
+//
+// Kernels
+//   colsum_partial / colmoments_partial / col_finish : per-column statistics (HBM-bound streaming;
+//       lanes run along the contiguous cell/spot axis, partial sums over blocks of genes).
+//   standardize_write : z in float32 into a zero-padded [Gpad][pitch] buffer (pitch % 128 == 0)
+//   normalize_write   : y in float64 (only for callers that want normalize_data itself)
+//   pearson_gemm      : 128x128x32 LDS-tiled TN GEMM on 32x32x2 fp32 MFMA, epilogue negates and
+//                       writes each spot row to its slots[s] consecutive LAP rows.
+#include "cyto_common.h"
+#include <math.h>
+#include <vector>
+
+namespace cyto {
+
+constexpr int GB = 64;  // genes per partial-statistics block
+
+template <typename TIn> __device__ __forceinline__ double clean(TIn x) {
+    // np.nan_to_num: NaN -> 0, +-inf -> +-max finite
+    double d = (double)x;
+    if (d != d) return 0.0;
+    if (d > 1.7976931348623157e308) return 1.7976931348623157e308;
+    if (d < -1.7976931348623157e308) return -1.7976931348623157e308;
+    return d;
+}
+
+// partial column sums of the cleaned input over a block of GB genes
+template <typename TIn>
+__global__ __launch_bounds__(256) void colsum_partial(int G, int C, const TIn *__restrict__ x, int64_t ldx,
+                                                      double *__restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int g0 = blockIdx.y * GB, g1 = min(G, g0 + GB);
+    double s = 0.0;
+    for (int g = g0; g < g1; g++) s += clean<TIn>(x[(int64_t)g * ldx + c]);
+    part[(int64_t)blockIdx.y * C + c] = s;
+}
+
+// y = log2(x * 1e6 / colsum + 1) with NaN -> 0 (an all-zero column is 0/0)
+template <typename TIn> __device__ __forceinline__ double normalized(TIn x, double scale, bool already) {
+    if (already) return clean<TIn>(x);
+    double y = log2(clean<TIn>(x) * scale + 1.0);
+    if (y != y) y = 0.0;
+    if (y > 1.7976931348623157e308) y = 1.7976931348623157e308;
+    return y;
+}
+
+// partial first and second moments of y over a block of genes
+template <typename TIn>
+__global__ __launch_bounds__(256) void colmoments_partial(int G, int C, const TIn *__restrict__ x, int64_t ldx,
+                                                          const double *__restrict__ colsum, int already,
+                                                          double *__restrict__ p1, double *__restrict__ p2) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int g0 = blockIdx.y * GB, g1 = min(G, g0 + GB);
+    const double scale = already ? 1.0 : 1e6 / colsum[c];
+    double s1 = 0.0, s2 = 0.0;
+    for (int g = g0; g < g1; g++) {
+        const double y = normalized<TIn>(x[(int64_t)g * ldx + c], scale, already);
+        s1 += y;
+        s2 += y * y;
+    }
+    p1[(int64_t)blockIdx.y * C + c] = s1;
+    p2[(int64_t)blockIdx.y * C + c] = s2;
+}
+
+// combine the partials in ascending block order
+__global__ void col_finish_sum(int C, int nblk, const double *__restrict__ part, double *__restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; b++) s += part[(int64_t)b * C + c];
+    out[c] = s;
+}
+
+// mean and 1 / (std * sqrt(G)) per column (population std, ddof = 0, as numpy's default)
+__global__ void col_finish_moments(int G, int C, int nblk, const double *__restrict__ p1, const double *__restrict__ p2,
+                                   double *__restrict__ mean, double *__restrict__ inv) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; b++) { s1 += p1[(int64_t)b * C + c]; s2 += p2[(int64_t)b * C + c]; }
+    const double m = s1 / G;
+    double var = s2 / G - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = m;
+    inv[c] = 1.0 / (sqrt(var) * sqrt((double)G));   // var == 0 -> inf, like the reference's /0
+}
+
+template <typename TIn>
+__global__ __launch_bounds__(256) void standardize_write(int G, int C, const TIn *__restrict__ x, int64_t ldx,
+                                                         const double *__restrict__ colsum, const double *__restrict__ mean,
+                                                         const double *__restrict__ inv, int already,
+                                                         float *__restrict__ z, int64_t ldz) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int g0 = blockIdx.y * GB, g1 = min(G, g0 + GB);
+    const double scale = already ? 1.0 : 1e6 / colsum[c];
+    const double m = mean[c], iv = inv[c];
+    for (int g = g0; g < g1; g++) {
+        const double y = normalized<TIn>(x[(int64_t)g * ldx + c], scale, already);
+        z[(int64_t)g * ldz + c] = (float)((y - m) * iv);
+    }
+}
+
+template <typename TIn>
+__global__ __launch_bounds__(256) void normalize_write(int G, int C, const TIn *__restrict__ x, int64_t ldx,
+                                                       const double *__restrict__ colsum, double *__restrict__ y, int64_t ldy) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int g0 = blockIdx.y * GB, g1 = min(G, g0 + GB);
+    const double scale = 1e6 / colsum[c];
+    for (int g = g0; g < g1; g++) y[(int64_t)g * ldy + c] = normalized<TIn>(x[(int64_t)g * ldx + c], scale, false);
+}
+
+// ------------------------------------------------------------------------------------------
+// cost[r][c] = - sum_g zst[g][s] * zsc[g][c]   for every LAP row r of spot s
+// TN GEMM: both operands are stored gene-major, so a k-slice of either tile is a contiguous row
+// segment (coalesced 16-B global loads, conflict-free ds_read_b32 fragment reads).
+// Block tile 128 (spots) x 128 (cells) x 32 (genes), 4 waves, each wave 64x64 = 2x2 MFMA tiles.
+// ------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 32;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void pearson_gemm(int Gpad, int S, int C, const float *__restrict__ A, int64_t lda,
+                                                    const float *__restrict__ B, int64_t ldb,
+                                                    const int *__restrict__ rowstart, float *__restrict__ cost, int64_t ldc,
+                                                    int tiles_n) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware tile order: consecutive workgroup ids land on different XCDs (private L2s), so give
+    // each XCD a contiguous band of tiles that share operand panels
+    const int nwg = gridDim.x;
+    int wg = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = wg / tiles_n, tn = wg % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+
+    // staging: 4 float4 per thread per operand per k-tile
+    float4 ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int idx = tid + t * 256;
+            const int k = idx >> 5, c4 = idx & 31;
+            ra[t] = *reinterpret_cast<const float4 *>(A + (int64_t)(k0 + k) * lda + m0 + c4 * 4);
+            rb[t] = *reinterpret_cast<const float4 *>(B + (int64_t)(k0 + k) * ldb + n0 + c4 * 4);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int idx = tid + t * 256;
+            const int k = idx >> 5, c4 = idx & 31;
+            *reinterpret_cast<float4 *>(&As[buf][k][c4 * 4]) = ra[t];
+            *reinterpret_cast<float4 *>(&Bs[buf][k][c4 * 4]) = rb[t];
+        }
+    };
+
+    const int nk = Gpad / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int li = lane & 31, lk = lane >> 5;
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a0 = As[buf][kk + lk][wm * 64 + li];
+            const float a1 = As[buf][kk + lk][wm * 64 + 32 + li];
+            const float b0 = Bs[buf][kk + lk][wn * 64 + li];
+            const float b1 = Bs[buf][kk + lk][wn * 64 + 32 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int c = n0 + wn * 64 + b * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int s = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (s < S && c < C) {
+                    const float val = -acc[a][b][r];
+                    const int r0 = rowstart[s], r1 = rowstart[s + 1];
+                    for (int row = r0; row < r1; row++) cost[(int64_t)row * ldc + c] = val;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// Column statistics + standardised float32 matrix for one input (genes x columns).
+// z must hold Gpad x ldz floats and be zero-filled by the caller (padding must stay zero).
+template <typename TIn>
+static int standardize_dev(int G, int C, const TIn *dx, int64_t ldx, int already, float *z, int64_t ldz, double *ynorm,
+                           int64_t ldy, hipStream_t stream) {
+    const int nblk = (G + GB - 1) / GB;
+    DevBuf part1, part2, colsum, mean, inv;
+    int rc;
+    if ((rc = part1.alloc((size_t)nblk * C * sizeof(double))) || (rc = part2.alloc((size_t)nblk * C * sizeof(double))) ||
+        (rc = colsum.alloc((size_t)C * sizeof(double))) || (rc = mean.alloc((size_t)C * sizeof(double))) ||
+        (rc = inv.alloc((size_t)C * sizeof(double))))
+        return rc;
+    const dim3 grid((C + 255) / 256, nblk), blk(256);
+    const dim3 g1((C + 255) / 256);
+    if (!already) {
+        hipLaunchKernelGGL(colsum_partial<TIn>, grid, blk, 0, stream, G, C, dx, ldx, part1.as<double>());
+        hipLaunchKernelGGL(col_finish_sum, g1, blk, 0, stream, C, nblk, part1.as<double>(), colsum.as<double>());
+    }
+    if (ynorm) {
+        hipLaunchKernelGGL(normalize_write<TIn>, grid, blk, 0, stream, G, C, dx, ldx, colsum.as<double>(), ynorm, ldy);
+    }
+    if (z) {
+        hipLaunchKernelGGL(colmoments_partial<TIn>, grid, blk, 0, stream, G, C, dx, ldx, colsum.as<double>(), already,
+                           part1.as<double>(), part2.as<double>());
+        hipLaunchKernelGGL(col_finish_moments, g1, blk, 0, stream, G, C, nblk, part1.as<double>(), part2.as<double>(),
+                           mean.as<double>(), inv.as<double>());
+        hipLaunchKernelGGL(standardize_write<TIn>, grid, blk, 0, stream, G, C, dx, ldx, colsum.as<double>(), mean.as<double>(),
+                           inv.as<double>(), already, z, ldz);
+    }
+    CYTO_HIP(hipGetLastError());
+    CYTO_HIP(hipStreamSynchronize(stream));   // the temporaries above die with this scope
+    return CYTO_OK;
+}
+
+}  // namespace cyto
+
+using namespace cyto;
+
+extern "C" {
+
+// A1: normalize_data (common/common.py:142-147) on the device; out is float64 like the reference's.
+int cyto_normalize_data(int G, int C, const void *x, int64_t ldx, int x_is_f64, double *out, int64_t ldo, int device_id) {
+    if (G <= 0 || C <= 0 || !x || !out || ldx < C || ldo < C) return CYTO_ERR_BAD_ARG;
+    int rc = select_device(device_id);
+    if (rc) return rc;
+    const size_t esz = x_is_f64 ? 8 : 4;
+    DevBuf dx, dy;
+    if ((rc = dx.alloc((size_t)G * C * esz)) || (rc = dy.alloc((size_t)G * C * 8))) return rc;
+    CYTO_HIP(hipMemcpy2D(dx.p, (size_t)C * esz, x, (size_t)ldx * esz, (size_t)C * esz, G, hipMemcpyHostToDevice));
+    if (x_is_f64) rc = standardize_dev<double>(G, C, dx.as<double>(), C, 0, nullptr, 0, dy.as<double>(), C, nullptr);
+    else rc = standardize_dev<float>(G, C, dx.as<float>(), C, 0, nullptr, 0, dy.as<double>(), C, nullptr);
+    if (rc) return rc;
+    CYTO_HIP(hipMemcpy2D(out, (size_t)ldo * 8, dy.p, (size_t)C * 8, (size_t)C * 8, G, hipMemcpyDeviceToHost));
+    return CYTO_OK;
+}
+
+// A1+A2 (first half): per-column normalise (unless already_normalized) and standardise; writes the
+// float32 matrix z (device pointer, Gpad x ldz, pre-zeroed by this call) used by cyto_cost_pearson.
+int cyto_standardize(int G, int C, const void *x, int64_t ldx, int x_is_f64, int x_on_device, int already_normalized,
+                     float *z_dev, int64_t ldz, int Gpad, int device_id, void *stream_) {
+    if (G <= 0 || C <= 0 || !x || !z_dev || ldx < C || ldz < C || Gpad < G) return CYTO_ERR_BAD_ARG;
+    int rc = select_device(device_id);
+    if (rc) return rc;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const size_t esz = x_is_f64 ? 8 : 4;
+    DevBuf dx;
+    const void *src = x;
+    int64_t sld = ldx;
+    if (!x_on_device) {
+        if ((rc = dx.alloc((size_t)G * C * esz))) return rc;
+        CYTO_HIP(hipMemcpy2DAsync(dx.p, (size_t)C * esz, x, (size_t)ldx * esz, (size_t)C * esz, G, hipMemcpyHostToDevice, stream));
+        src = dx.p;
+        sld = C;
+    }
+    CYTO_HIP(hipMemsetAsync(z_dev, 0, (size_t)Gpad * ldz * sizeof(float), stream));
+    if (x_is_f64) return standardize_dev<double>(G, C, (const double *)src, sld, already_normalized, z_dev, ldz, nullptr, 0, stream);
+    return standardize_dev<float>(G, C, (const float *)src, sld, already_normalized, z_dev, ldz, nullptr, 0, stream);
+}
+
+// A2+A3: cost = -corr, each spot row written to its slots[s] LAP rows (spot order).
+// zst: Gpad x ldzst, zsc: Gpad x ldzsc (device, zero padded: Gpad % 32 == 0, ld % 128 == 0).
+// cost: device, (sum slots) x ldc.  gemm_ms (optional): HIP-event time of the GEMM kernel.
+int cyto_cost_pearson(int Gpad, int S, int C, const float *zst, int64_t ldzst, const float *zsc, int64_t ldzsc,
+                      const int64_t *slots, float *cost_dev, int64_t ldc, double *gemm_ms, int device_id, void *stream_) {
+    if (Gpad <= 0 || S <= 0 || C <= 0 || !zst || !zsc || !slots || !cost_dev) return CYTO_ERR_BAD_ARG;
+    if (Gpad % BK || ldzst % BM || ldzsc % BN || ldzst < S || ldzsc < C || ldc < C) return CYTO_ERR_BAD_ARG;
+    int rc = select_device(device_id);
+    if (rc) return rc;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    std::vector<int> rowstart((size_t)S + 1);
+    int64_t acc = 0;
+    for (int s = 0; s < S; s++) {
+        if (slots[s] < 0) return CYTO_ERR_BAD_ARG;
+        rowstart[s] = (int)acc;
+        acc += slots[s];
+        if (acc > 0x7FFFFFFF) return CYTO_ERR_UNSUPPORTED;
+    }
+    rowstart[S] = (int)acc;
+    DevBuf drs;
+    if ((rc = drs.alloc(((size_t)S + 1) * sizeof(int)))) return rc;
+    CYTO_HIP(hipMemcpyAsync(drs.p, rowstart.data(), ((size_t)S + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
+    const int tiles_m = (S + BM - 1) / BM, tiles_n = (C + BN - 1) / BN;
+    hipEvent_t e0, e1;
+    CYTO_HIP(hipEventCreate(&e0));
+    CYTO_HIP(hipEventCreate(&e1));
+    CYTO_HIP(hipEventRecord(e0, stream));
+    hipLaunchKernelGGL(pearson_gemm, dim3(tiles_m * tiles_n), dim3(256), 0, stream, Gpad, S, C, zst, ldzst, zsc, ldzsc,
+                       drs.as<int>(), cost_dev, ldc, tiles_n);
+    CYTO_HIP(hipGetLastError());
+    CYTO_HIP(hipEventRecord(e1, stream));
+    CYTO_HIP(hipStreamSynchronize(stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (gemm_ms) *gemm_ms = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return CYTO_OK;
+}
+
+// A7: the fused per-chunk path of solve_linear_assignment_problem (cytospace/cytospace.py:304-351)
+// for solver_method == "lapjv", distance_metric == "Pearson_correlation": cost build on the device,
+// JV solve on the device, mapped_spot[c] = spot of the LAP row given to cell c.
+// sc: G x C, st: G x S (host, row-major, float64 like the reference's arrays).  sum(slots) must be C.
+// The 1e-16 perturbation of cytospace.py:325-327 is not applied: it is a no-op in float32.
+int cyto_assign_pearson(int G, int C, int S, const double *sc, const double *st, const int64_t *slots, int already_normalized,
+                        int64_t *mapped_spot, double *total_cost, cyto_assign_info *info, int device_id) {
+    if (G <= 0 || C <= 0 || S <= 0 || !sc || !st || !slots || !mapped_spot) return CYTO_ERR_BAD_ARG;
+    int64_t N = 0;
+    for (int s = 0; s < S; s++) { if (slots[s] < 0) return CYTO_ERR_BAD_ARG; N += slots[s]; }
+    if (N != C) return CYTO_ERR_BAD_ARG;   // the LAP must be square
+    int rc = select_device(device_id);
+    if (rc) return rc;
+    const int Gpad = (int)round_up(G, BK);
+    const int64_t ldzst = round_up(S, BM), ldzsc = round_up(C, BN), ldc = round_up(C, 4);
+    DevBuf zst, zsc, cost;
+    if ((rc = zst.alloc((size_t)Gpad * ldzst * 4)) || (rc = zsc.alloc((size_t)Gpad * ldzsc * 4)) ||
+        (rc = cost.alloc((size_t)N * ldc * 4)))
+        return rc;
+    hipEvent_t e0, e1;
+    CYTO_HIP(hipEventCreate(&e0));
+    CYTO_HIP(hipEventCreate(&e1));
+    CYTO_HIP(hipEventRecord(e0, nullptr));
+    if ((rc = cyto_standardize(G, S, st, S, 1, 0, already_normalized, zst.as<float>(), ldzst, Gpad, device_id, nullptr))) return rc;
+    if ((rc = cyto_standardize(G, C, sc, C, 1, 0, already_normalized, zsc.as<float>(), ldzsc, Gpad, device_id, nullptr))) return rc;
+    CYTO_HIP(hipEventRecord(e1, nullptr));
+    CYTO_HIP(hipEventSynchronize(e1));
+    float ms_std = 0;
+    (void)hipEventElapsedTime(&ms_std, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    double ms_gemm = 0;
+    if ((rc = cyto_cost_pearson(Gpad, S, C, zst.as<float>(), ldzst, zsc.as<float>(), ldzsc, slots, cost.as<float>(), ldc,
+                                &ms_gemm, device_id, nullptr)))
+        return rc;
+    std::vector<int32_t> colsol((size_t)N);
+    cyto_lap_info li;
+    double total = 0;
+    if ((rc = cyto_lap_f32((int)N, cost.as<float>(), ldc, 1, nullptr, colsol.data(), nullptr, nullptr, &total, &li, device_id, nullptr)))
+        return rc;
+    // location_repeat[y] (cytospace.py:331): LAP row -> spot
+    std::vector<int32_t> rowspot((size_t)N);
+    {
+        int64_t r = 0;
+        for (int s = 0; s < S; s++) for (int64_t k = 0; k < slots[s]; k++) rowspot[(size_t)r++] = s;
+    }
+    for (int64_t c = 0; c < C; c++) mapped_spot[c] = rowspot[(size_t)colsol[(size_t)c]];
+    if (total_cost) *total_cost = total;
+    if (info) {
+        memset(info, 0, sizeof *info);
+        info->ms_standardize = ms_std;   // includes the host-to-device copies of sc and st
+        info->ms_gemm = ms_gemm;
+        info->lap = li;
+        info->gemm_flops = 2.0 * Gpad * (double)S * (double)C;
+    }
+    return CYTO_OK;
+}
+
+}  // extern "C"

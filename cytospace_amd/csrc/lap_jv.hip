@@ -364,12 +364,20 @@ __global__ __launch_bounds__(BLOCK) void jv_chain(ChainArgs<T> a) {
     }
 
     // ---- AUGMENTING ROW REDUCTION, two sweeps ----
+    const long long arr_budget = 1000ll * n + 1000000ll;   // == JV_ARR_BUDGET(n) of the oracle
     for (int sweep = 0; sweep < 2; sweep++) {
         int k = 0;
         const int prev = numfree;
         numfree = 0;
         int carry = -1;
         while (carry >= 0 || k < prev) {
+            if (c_arr >= arr_budget) {
+                // step budget exhausted (see oracle/jv_oracle_impl.h): hand the waiting rows to the
+                // augmentation phase, the displaced row first, then the rest in list order
+                if (carry >= 0) { if (tid == 0) st_i32(a.freerows + numfree, carry); numfree++; carry = -1; }
+                while (k < prev) { const int r = ld_i32(a.freerows + k); k++; if (tid == 0) st_i32(a.freerows + numfree, r); numfree++; }
+                break;
+            }
             int i;
             if (carry >= 0) { i = carry; carry = -1; }
             else { i = ld_i32(a.freerows + k); k++; }
@@ -1120,6 +1128,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
     long long c_free_cr = numfree, c_free_a1 = 0, c_free_a2 = 0;
     int err = 0;
 
+    const long long arr_budget = 1000ll * n + 1000000ll;   // == JV_ARR_BUDGET(n) of the oracle
     // chain state (meaningful in wave 0 only; uniform there)
     int phase = (n > 1) ? PH_RT : PH_ARR;
     int k = 0, sweep = 0, prev = numfree, carry = -1, cur_i = -1;
@@ -1137,6 +1146,17 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
                         if (k >= nrt) { phase = PH_ARR; sweep = 0; k = 0; prev = numfree; numfree = 0; carry = -1; continue; }
                         cur_i = __builtin_amdgcn_readfirstlane(ld_i32(rtrows + k)); k++;
                     } else if (phase == PH_ARR) {
+                        if (c_arr >= arr_budget && (carry >= 0 || k < prev)) {
+                            // step budget exhausted (see oracle/jv_oracle_impl.h): hand the waiting rows
+                            // to the augmentation phase, the displaced row first, then the list order
+                            if (carry >= 0) { if (lane == 0) st_i32(freerows + numfree, carry); numfree++; carry = -1; }
+                            while (k < prev) {
+                                const int r = __builtin_amdgcn_readfirstlane(ld_i32(freerows + k)); k++;
+                                if (lane == 0) st_i32(freerows + numfree, r);
+                                numfree++;
+                            }
+                            continue;
+                        }
                         if (carry >= 0) { cur_i = carry; carry = -1; }
                         else if (k < prev) { cur_i = __builtin_amdgcn_readfirstlane(ld_i32(freerows + k)); k++; }
                         else if (sweep == 0) { c_free_a1 = numfree; sweep = 1; k = 0; prev = numfree; numfree = 0; continue; }

@@ -1,0 +1,126 @@
+"""Per-chunk solve and chunk fan-out, mirroring the reference's driver functions
+(/root/reference/cytospace/cytospace.py:150-209, 304-351, 354-469) for the HIP path.
+
+`solve_linear_assignment_problem` keeps the reference's signature; with solver_method == "lapjv_hip"
+the whole chunk (cost build + LAP) stays on the GPU (C ABI: cyto_assign_pearson).
+`assign_chunks` is the multi-chunk seam: independent square sub-LAPs, one GPU each, no data-path
+collective (the chunks are independent; cytospace.py:430-451 ships them to a process pool).
+"""
+import ctypes
+import time
+
+import numpy as np
+
+from . import _lib
+from .linear_assignment_solvers import calculate_cost, call_solver
+
+
+def partition_indices(indices, split_by_category_list=None, split_by_interval_int=None, shuffle=True):
+    """cytospace.py:150-209: split `indices` at category boundaries and every `interval` inside a
+    category longer than the interval (np.array_split); optional in-place legacy shuffle."""
+    indices = np.asarray(indices)
+    num = len(indices)
+    if shuffle:
+        np.random.shuffle(indices)
+    cuts = {0, num}
+    if split_by_category_list is not None:
+        if np.sum(split_by_category_list) != num:
+            print('Warning: sum of counts in each category does not match the full length')
+        cuts.update(int(b) for b in np.cumsum(split_by_category_list))
+    base = sorted(cuts)
+    if split_by_interval_int is not None:
+        for lo, hi in zip(base[:-1], base[1:]):
+            if hi - lo > split_by_interval_int:
+                cuts.update(range(lo, hi, split_by_interval_int))
+    return np.array_split(indices, sorted(cuts)[1:-1])
+
+
+def assign_pearson(sc, st, slots, already_normalized=True, device_id=0, return_info=False):
+    """Fused chunk solve on one GPU: returns mapped_st_index (np.int64[C]) [, total, info]."""
+    sc = np.ascontiguousarray(sc, dtype=np.float64)
+    st = np.ascontiguousarray(st, dtype=np.float64)
+    if sc.ndim != 2 or st.ndim != 2:
+        raise ValueError("sc and st must be 2-D genes x columns matrices")
+    if sc.shape[0] != st.shape[0]:
+        raise ValueError("The two matrices v1 and v2 must have equal dimensions; "
+                         "ST and scRNA data must have the same genes")
+    slots = np.ascontiguousarray(slots, dtype=np.int64)
+    G, C = sc.shape
+    S = st.shape[1]
+    if len(slots) != S:
+        raise ValueError("one slot count per spot is required")
+    mapped = np.empty(C, np.int64)
+    total = ctypes.c_double()
+    info = _lib.AssignInfo()
+    _lib.check(_lib.lib().cyto_assign_pearson(G, C, S, sc.ctypes.data, st.ctypes.data, slots.ctypes.data,
+                                              int(already_normalized), mapped.ctypes.data, ctypes.byref(total),
+                                              ctypes.byref(info), device_id))
+    if return_info:
+        return mapped, total.value, info
+    return mapped
+
+
+def solve_linear_assignment_problem(scRNA_norm_data, st_norm_data, cell_number_to_node_assignment,
+                                    solver_method, solver, seed, distance_metric, process_idx=None, device_id=0):
+    """cytospace.py:304-351.  Returns (mapped_st_index: list[int] of length C, process_idx).
+
+    "lapjv_hip" + "Pearson_correlation": fused on the device (the +1e-16*rand tie-breaker of
+    cytospace.py:325-327 is a no-op in float32 and is skipped).  Other shortest-augmenting-path solvers
+    follow the reference's sequence with the device-built cost matrix."""
+    if solver_method == "lapjv_hip" and distance_metric == "Pearson_correlation":
+        print('Solving linear assignment problem ...')
+        t0 = time.perf_counter()
+        mapped = assign_pearson(scRNA_norm_data, st_norm_data, cell_number_to_node_assignment,
+                                already_normalized=True, device_id=device_id)
+        print(f"Time to solve linear assignment problem: {round(time.perf_counter() - t0, 2)} seconds")
+        return mapped.tolist(), process_idx
+    if solver_method in ('lapjv', 'lapjv_compat', 'lapjv_hip'):
+        distance_repeat, location_repeat = calculate_cost(scRNA_norm_data, st_norm_data, cell_number_to_node_assignment,
+                                                          solver_method, distance_metric)
+        print('Solving linear assignment problem ...')
+        np.random.seed(seed)
+        cost_scaled = distance_repeat + 1e-16 * np.random.rand(distance_repeat.shape[0], distance_repeat.shape[1])
+        t0 = time.perf_counter()
+        assignment = call_solver(solver, solver_method, cost_scaled)
+        print(f"Time to solve linear assignment problem: {round(time.perf_counter() - t0, 2)} seconds")
+        return np.transpose(location_repeat[assignment]).tolist(), process_idx
+    raise ValueError("Invalid solver_method provided")
+
+
+def schedule_chunks(sizes, n_devices):
+    """Longest-processing-time-first placement of independent sub-LAPs on devices (cost ~ n^2.5)."""
+    order = np.argsort([-float(s) ** 2.5 for s in sizes], kind="stable")
+    load = [0.0] * n_devices
+    owner = [0] * len(sizes)
+    for idx in order:
+        d = int(np.argmin(load))
+        owner[idx] = d
+        load[d] += float(sizes[idx]) ** 2.5
+    return owner
+
+
+def assign_chunks(scRNA_norm, st_norm, cell_number_to_node_assignment, index_sc_list, index_st_list=None,
+                  subsampled_slots_list=None, rank=0, world_size=1, device_id=0):
+    """The chunk fan-out of apply_linear_assignment (cytospace.py:405-467) for one rank of a
+    one-process-per-GPU job: this rank solves the chunks the LPT schedule gives it and returns
+    {chunk index: mapped_st_index}.  Inputs are already normalised numpy arrays (genes x cells/spots)."""
+    if (index_st_list is not None) and (subsampled_slots_list is not None):
+        raise ValueError("index_st_list and subsampled_cell_number_to_node_assignment_list cannot both be specified")
+    n_chunks = len(index_sc_list)
+    owner = schedule_chunks([len(ix) for ix in index_sc_list], world_size)
+    out = {}
+    for idx in range(n_chunks):
+        if owner[idx] != rank:
+            continue
+        sc = scRNA_norm[:, index_sc_list[idx]]
+        if index_st_list is not None:
+            st = st_norm[:, index_st_list[idx]]
+            slots = np.asarray(cell_number_to_node_assignment)[index_st_list[idx]]
+        elif subsampled_slots_list is not None:
+            st = st_norm
+            slots = subsampled_slots_list[idx]
+        else:
+            st = st_norm
+            slots = cell_number_to_node_assignment
+        out[idx] = assign_pearson(sc, st, slots, already_normalized=True, device_id=device_id)
+    return out

@@ -78,6 +78,46 @@ int cyto_lap_f64(int n, const double *cost, int64_t ld, int cost_on_device,
                  int32_t *rowsol, int32_t *colsol, double *u, double *v, double *total,
                  cyto_lap_info *info, int device_id, void *stream);
 
+/* ---- A1: normalize_data (cytospace/common/common.py:142-147): nan_to_num, per-column counts per
+ * million over the gene axis, log2(x + 1), nan_to_num.  x: G x C host matrix (float64 if x_is_f64
+ * else float32), out: G x C host float64.  Computed on the device in float64. */
+int cyto_normalize_data(int G, int C, const void *x, int64_t ldx, int x_is_f64, double *out, int64_t ldo,
+                        int device_id);
+
+/* ---- A1 + first half of A2: per-column normalise (skipped if already_normalized) and standardise:
+ *   z[g][c] = (y[g][c] - mean_c) / (std_c * sqrt(G))   (population std, like numpy's .std(0))
+ * written as float32 into the DEVICE buffer z_dev (Gpad x ldz, zero padded by this call;
+ * Gpad % 32 == 0 and ldz % 128 == 0 are what cyto_cost_pearson needs).  x may be a host or a
+ * device pointer.  With these z the contraction of cyto_cost_pearson IS the Pearson correlation
+ * of matrix_correlation_pearson (cytospace/common/common.py:190-199). */
+int cyto_standardize(int G, int C, const void *x, int64_t ldx, int x_is_f64, int x_on_device,
+                     int already_normalized, float *z_dev, int64_t ldz, int Gpad, int device_id, void *stream);
+
+/* ---- second half of A2 + A3: cost = -corr on the fp32 matrix cores, each spot row written to its
+ * slots[s] consecutive LAP rows in spot order (calculate_cost, lapjv/Pearson branch:
+ * cytospace/linear_assignment_solvers/linear_assignment_solvers.py:42-69).
+ * zst: Gpad x ldzst, zsc: Gpad x ldzsc (device); slots: host int64[S]; cost_dev: device,
+ * (sum slots) x ldc float32.  gemm_ms (optional) = HIP-event time of the GEMM kernel. */
+int cyto_cost_pearson(int Gpad, int S, int C, const float *zst, int64_t ldzst, const float *zsc, int64_t ldzsc,
+                      const int64_t *slots, float *cost_dev, int64_t ldc, double *gemm_ms, int device_id,
+                      void *stream);
+
+/* ---- A7: the fused per-chunk path.  Replaces solve_linear_assignment_problem
+ * (cytospace/cytospace.py:304-351) for solver_method "lapjv" + "Pearson_correlation": cost build and
+ * JV solve on the device; mapped_spot[c] = index (into st's columns) of the spot cell c is mapped to.
+ * sc: G x C, st: G x S host float64 row-major; slots: int64[S] with sum == C (square LAP).
+ * ValueError-equivalents: CYTO_ERR_BAD_ARG (not square), CYTO_ERR_NONFINITE (zero-variance column). */
+typedef struct {
+    double ms_standardize;   /* normalise + standardise kernels incl. the H2D copies of sc and st */
+    double ms_gemm;          /* HIP-event time of the MFMA cost GEMM */
+    double gemm_flops;       /* 2 * Gpad * S * C */
+    cyto_lap_info lap;
+} cyto_assign_info;
+
+int cyto_assign_pearson(int G, int C, int S, const double *sc, const double *st, const int64_t *slots,
+                        int already_normalized, int64_t *mapped_spot, double *total_cost,
+                        cyto_assign_info *info, int device_id);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,8 @@ _LIB = None
 class JVStats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int64) for k in (
         "scans_colred", "scans_redtransfer", "scans_arr", "scans_aug_init", "scans_aug_relax",
-        "augmentations", "path_hops", "free_after_colred", "free_after_arr1", "free_after_arr2")]
+        "augmentations", "path_hops", "free_after_colred", "free_after_arr1", "free_after_arr2",
+        "arr_budget_hit")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

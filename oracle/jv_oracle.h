@@ -16,7 +16,11 @@ typedef struct {
     int64_t scans_colred, scans_redtransfer, scans_arr, scans_aug_init, scans_aug_relax;
     int64_t augmentations, path_hops;
     int64_t free_after_colred, free_after_arr1, free_after_arr2;
+    int64_t arr_budget_hit;
 } jv_stats;
+
+/* maximum number of augmenting-row-reduction steps (see jv_oracle_impl.h) */
+#define JV_ARR_BUDGET(n) (1000 * (int64_t)(n) + 1000000)
 
 /* cost: row-major n x n.  rowsol[i] = column of row i, colsol[j] = row of column j
  * (colsol is what CytoSPACE calls `y`, linear_assignment_solvers.py:38).  u, v duals. */

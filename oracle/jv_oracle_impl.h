@@ -112,12 +112,23 @@ int FN(jv_oracle_)(int n, const T *restrict cost, int32_t *restrict rowsol,
     }
     s.free_after_colred = numfree;
 
-    /* ---- AUGMENTING ROW REDUCTION, two sweeps ---- */
+    /* ---- AUGMENTING ROW REDUCTION, two sweeps ----
+     * Step budget (JV_ARR_BUDGET): ARR is an initialisation heuristic that can be cut short at
+     * any point without affecting optimality.  With near-tied rows (e.g. duplicated spot rows
+     * whose ties were broken by a 1e-16 perturbation, solved in float64) it degenerates into a
+     * price war of ~1e14 one-ulp steps; after the budget the rows still waiting are handed to
+     * the augmentation phase in list order.  The HIP kernels apply the identical rule. */
+    const int64_t arr_budget = JV_ARR_BUDGET(n);
     for (int sweep = 0; sweep < 2; sweep++) {
         int k = 0;
         const int prevnumfree = numfree;
         numfree = 0;
         while (k < prevnumfree) {
+            if (s.scans_arr >= arr_budget) {
+                while (k < prevnumfree) freerows[numfree++] = freerows[k++];
+                s.arr_budget_hit = 1;
+                break;
+            }
             const int i = freerows[k++];
             T umin, usub; int j1, j2;
             FN(top2_)(n, cost + (size_t)i * N, v, &umin, &j1, &usub, &j2);

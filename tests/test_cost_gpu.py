@@ -1,0 +1,127 @@
+"""GPU parity of the cost build and the fused chunk solve against the golden vectors captured from
+the reference and against the numpy/C oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from cytospace_amd import common as gcommon
+from cytospace_amd import cytospace as gcyto
+from cytospace_amd import linear_assignment_solvers as gsolvers
+from oracle import cost as ocost
+from oracle.jv import jv_oracle
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def test_gv1_normalize_data():
+    for f in ("gv1_normalize.npz", "gv1b_normalize_int.npz"):
+        d = load(f)
+        out = gcommon.normalize_data(d["counts"])
+        assert out.dtype == np.float64 and out.shape == d["out"].shape
+        np.testing.assert_allclose(out, d["out"], rtol=1e-12, atol=1e-12)     # float64 on the device
+    d = load("gv1_normalize.npz")
+    out = gcommon.normalize_data(d["counts"])
+    assert np.all(out[:, 4] == 0.0) and np.all(np.isfinite(out))
+
+
+def test_gv2_pearson_correlation():
+    d = load("gv2_pearson.npz")
+    corr = gcommon.matrix_correlation_pearson(d["sc_norm"], d["st_norm"])
+    assert corr.shape == d["corr"].shape
+    np.testing.assert_allclose(corr, d["corr"], rtol=0, atol=2e-6)            # fp32 contraction tolerance
+    with pytest.raises(ValueError):
+        gcommon.matrix_correlation_pearson(d["sc_norm"][:-1], d["st_norm"])
+
+
+def test_gv3_calculate_cost_rows_and_slots():
+    d = load("gv3_calculate_cost.npz")
+    dist, loc = gsolvers.calculate_cost(d["sc_norm"], d["st_norm"], d["slots"], "lapjv_hip", "Pearson_correlation")
+    assert np.array_equal(loc, d["location_repeat"])
+    assert dist.shape == d["distance_repeat"].shape
+    np.testing.assert_allclose(dist, d["distance_repeat"], rtol=0, atol=2e-6)
+    # repeated rows are bit-identical copies of their spot row
+    for r in range(1, len(loc)):
+        if loc[r] == loc[r - 1]:
+            assert np.array_equal(dist[r], dist[r - 1])
+
+
+@pytest.mark.parametrize("G,S,C", [(33, 5, 7), (200, 130, 260), (1000, 257, 513)])
+def test_cost_vs_numpy_odd_shapes(G, S, C):
+    rng = np.random.default_rng(G + S + C)
+    sc = rng.poisson(3.0, (G, C)).astype(np.float64)
+    st = rng.poisson(9.0, (G, S)).astype(np.float64)
+    scn, stn = ocost.normalize_data(sc), ocost.normalize_data(st)
+    ref = ocost.matrix_correlation_pearson(scn, stn)
+    got = gcommon.matrix_correlation_pearson(scn, stn)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)
+
+
+def test_standardize_from_raw_counts_matches_two_step():
+    rng = np.random.default_rng(4)
+    x = rng.poisson(2.0, (150, 70)).astype(np.float64)
+    z1 = gcommon.StandardizedMatrix(x, already_normalized=False).to_numpy()
+    y = ocost.normalize_data(x)
+    z2 = (y - y.mean(0)) / (y.std(0) * np.sqrt(x.shape[0]))
+    np.testing.assert_allclose(z1, z2, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("key", ["visium_s1", "visium_s7", "single_s1", "single_s7"])
+def test_gv5_fused_chunk_solve_spot_level(key):
+    d = load("gv5_solve_lap.npz")
+    slots = d[key + "_slots"]
+    mapped, pidx = gcyto.solve_linear_assignment_problem(d[key + "_sc_norm"], d[key + "_st_norm"], slots, "lapjv_hip",
+                                                         gsolvers.import_solver("lapjv_hip"), 1, "Pearson_correlation",
+                                                         process_idx=3)
+    assert pidx == 3 and len(mapped) == int(slots.sum())
+    assert np.array_equal(np.bincount(mapped, minlength=len(slots)), slots)
+    assert np.array_equal(np.asarray(mapped), d[key + "_mapped"])            # spot level == reference + exact solver
+
+
+def test_fused_total_cost_on_reference_cost_matrix():
+    # total cost of the GPU assignment evaluated on the float64 reference cost within 1e-5 of the optimum
+    d = load("gv5_solve_lap.npz")
+    key = "single_s1"
+    dist, loc = ocost.calculate_cost(d[key + "_sc_norm"], d[key + "_st_norm"], d[key + "_slots"])
+    mapped, total, info = gcyto.assign_pearson(d[key + "_sc_norm"], d[key + "_st_norm"], d[key + "_slots"], return_info=True)
+    o = jv_oracle(dist, np.float64)
+    # slots are all 1 here: row == spot
+    mine = dist[mapped, np.arange(len(mapped))].sum()
+    assert abs(mine - o["total"]) <= 1e-5 * max(1.0, abs(o["total"]))
+    assert abs(total - o["total"]) <= 1e-4
+    assert info.gemm_flops > 0 and info.lap.scans_colred == len(mapped)
+
+
+def test_zero_variance_column_is_reported():
+    rng = np.random.default_rng(1)
+    sc = rng.random((50, 20))
+    st = rng.random((50, 20))
+    sc[:, 3] = 0.25                         # zero variance -> reference divides by zero (common.py:197)
+    with pytest.raises(ValueError):
+        gcyto.assign_pearson(sc, st, np.ones(20, np.int64))
+
+
+def test_non_square_chunk_rejected():
+    rng = np.random.default_rng(2)
+    with pytest.raises(ValueError):
+        gcyto.assign_pearson(rng.random((30, 10)), rng.random((30, 4)), np.array([1, 2, 3, 3]))
+
+
+def test_plugin_surface_roundtrip():
+    # cost built on the device, perturbed and solved through import_solver/call_solver like the reference does
+    d = load("gv5_solve_lap.npz")
+    key = "visium_s7"
+    solver = gsolvers.import_solver("lapjv_hip")
+    dist, loc = gsolvers.calculate_cost(d[key + "_sc_norm"], d[key + "_st_norm"], d[key + "_slots"], "lapjv_hip",
+                                        "Pearson_correlation")
+    np.random.seed(7)
+    cost_scaled = dist + 1e-16 * np.random.rand(*dist.shape)
+    y = gsolvers.call_solver(solver, "lapjv_hip", cost_scaled)
+    assert np.array_equal(loc[y], d[key + "_mapped"])
+    with pytest.raises(NotImplementedError):
+        gsolvers.import_solver("nonsense")

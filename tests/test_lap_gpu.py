@@ -1,4 +1,6 @@
 """GPU parity: HIP Jonker-Volgenant (through the C ABI) vs the CPU oracle, bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -6,6 +8,8 @@ from cytospace_amd.lap import lap_solve, lapjv_hip
 from oracle.jv import jv_oracle
 
 pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 STAT_KEYS = ["scans_colred", "scans_redtransfer", "scans_arr", "scans_aug_init", "scans_aug_relax",
              "augmentations", "path_hops", "free_after_colred", "free_after_arr1", "free_after_arr2"]
@@ -87,3 +91,27 @@ def test_lapjv_call_shape():
     o = jv_oracle(c, np.float32)
     assert np.array_equal(col_ind, o["colsol"]) and np.array_equal(row_ind, o["rowsol"])
     assert len(u) == 50 and len(v) == 50 and np.isfinite(total)
+
+
+def test_arr_step_budget_price_war():
+    # float64 solve of duplicated spot rows whose ties were broken by CytoSPACE's 1e-16 perturbation
+    # (cytospace.py:325-327): the augmenting row reduction degenerates into a one-ulp price war; the
+    # oracle and the kernels cut it at the same step budget and must still agree bit for bit.
+    from oracle import cost as ocost
+    d = np.load(os.path.join(GOLD, "gv5_solve_lap.npz"))
+    dist, loc = ocost.calculate_cost(d["visium_s1_sc_norm"], d["visium_s1_st_norm"], d["visium_s1_slots"])
+    c = ocost.perturb(dist, 1)
+    o = jv_oracle(c, np.float64)
+    assert o["stats"].arr_budget_hit == 1
+    _check(c, np.float64)
+    _check(c, np.float32)
+    g = lap_solve(c, np.float64)
+    assert np.array_equal(loc[g["colsol"]], d["visium_s1_mapped"])
+
+
+@pytest.mark.parametrize("n", [64, 256])
+def test_golden_known_answers(n):
+    d = np.load(os.path.join(GOLD, "gv8_lap.npz"))
+    g = lap_solve(d[f"n{n}_cost"], np.float32)
+    assert np.array_equal(g["colsol"], d[f"n{n}_colsol"]) and np.array_equal(g["rowsol"], d[f"n{n}_rowsol"])
+    assert abs(g["total"] - float(d[f"n{n}_total"])) <= 1e-5

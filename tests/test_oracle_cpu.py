@@ -1,0 +1,126 @@
+"""CPU tests: the oracle (oracle/) against the golden vectors captured from the reference and
+against an independent exact LAP solver.  No GPU needed."""
+import os
+
+import numpy as np
+import pytest
+from scipy.optimize import linear_sum_assignment
+
+from oracle import cost as ocost
+from oracle.jv import jv_oracle
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+def test_gv1_normalize():
+    for f in ("gv1_normalize.npz", "gv1b_normalize_int.npz"):
+        d = load(f)
+        out = ocost.normalize_data(d["counts"])
+        assert out.dtype == np.float64
+        np.testing.assert_allclose(out, d["out"], rtol=1e-12, atol=0)
+    d = load("gv1_normalize.npz")
+    assert np.all(ocost.normalize_data(d["counts"])[:, 4] == 0.0)      # all-zero column -> zeros
+
+
+def test_gv2_pearson():
+    d = load("gv2_pearson.npz")
+    c = ocost.matrix_correlation_pearson(d["sc_norm"], d["st_norm"])
+    assert c.shape == (16, 48)
+    np.testing.assert_allclose(c, d["corr"], rtol=0, atol=1e-12)
+    with pytest.raises(ValueError):
+        ocost.matrix_correlation_pearson(d["sc_norm"][:-1], d["st_norm"])
+
+
+def test_gv3_calculate_cost():
+    d = load("gv3_calculate_cost.npz")
+    dist, loc = ocost.calculate_cost(d["sc_norm"], d["st_norm"], d["slots"])
+    assert np.array_equal(loc, d["location_repeat"])
+    np.testing.assert_allclose(dist, d["distance_repeat"], rtol=0, atol=1e-12)
+    assert dist.shape[0] == d["slots"].sum() == dist.shape[1]
+
+
+def test_gv4_perturbation_stream():
+    d = load("gv4_rand.npz")
+    z = np.zeros((4, 4))
+    assert np.array_equal(ocost.perturb(z, 1), 1e-16 * d["seed1_4x4"])
+    assert np.array_equal(ocost.perturb(np.zeros((3, 5)), 7), 1e-16 * d["seed7_3x5"])
+    # the perturbation is a no-op once the cost is cast to float32 (|cost| <= 1)
+    c = -np.random.default_rng(0).random((50, 50))
+    assert np.array_equal(ocost.perturb(c, 1).astype(np.float32), c.astype(np.float32))
+
+
+@pytest.mark.parametrize("key", ["visium_s1", "visium_s7", "single_s1", "single_s7"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_gv5_solve_lap_spot_level(key, dtype):
+    d = load("gv5_solve_lap.npz")
+    seed = int(key[-1])
+    mapped, pidx = ocost.solve_linear_assignment_problem(d[key + "_sc_norm"], d[key + "_st_norm"], d[key + "_slots"],
+                                                         seed=seed, dtype=dtype, process_idx=3)
+    assert pidx == 3
+    assert np.array_equal(np.bincount(mapped, minlength=len(d[key + "_slots"])), d[key + "_slots"])
+    assert np.array_equal(np.asarray(mapped), d[key + "_mapped"])
+
+
+def test_gv6_partition_indices():
+    d = load("gv6_partition.npz")
+    p = ocost.partition_indices(np.arange(0, 2500), split_by_interval_int=1000, shuffle=False)
+    assert np.array_equal([len(x) for x in p], d["ex1_lens"]) and np.array_equal([x[0] for x in p], d["ex1_first"])
+    p = ocost.partition_indices(np.arange(0, 1800), np.array([500, 1000, 300]), 400, shuffle=False)
+    assert np.array_equal([len(x) for x in p], d["ex2_lens"]) and np.array_equal([x[0] for x in p], d["ex2_first"])
+    p = ocost.partition_indices(np.arange(0, 8000), np.array([3000, 5000]), 2000, shuffle=False)
+    assert np.array_equal([len(x) for x in p], d["ex3_lens"]) and np.array_equal([x[0] for x in p], d["ex3_first"])
+    np.random.seed(5)
+    p = ocost.partition_indices(np.arange(0, 37), split_by_interval_int=10, shuffle=True)
+    assert np.array_equal(np.concatenate(p), d["shuf_concat"]) and np.array_equal([len(x) for x in p], d["shuf_lens"])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 64, 256])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_gv8_lap_known_answers(n, dtype):
+    d = load("gv8_lap.npz")
+    r = jv_oracle(d[f"n{n}_cost"], dtype)
+    assert np.array_equal(r["rowsol"], d[f"n{n}_rowsol"])
+    assert np.array_equal(r["colsol"], d[f"n{n}_colsol"])
+    assert abs(r["total"] - float(d[f"n{n}_total"])) <= 1e-5 * max(1.0, abs(float(d[f"n{n}_total"])))
+
+
+def test_gv8_duplicate_rows_spot_level():
+    d = load("gv8_lap.npz")
+    r = jv_oracle(d["dup_cost"], np.float32)
+    assert np.array_equal(r["colsol"] // 5, d["dup_spot_of_col"])
+    assert abs(r["total"] - float(d["dup_total"])) <= 1e-5
+
+
+@pytest.mark.parametrize("n", [5, 33, 128, 500, 1200])
+def test_jv_oracle_vs_scipy_random(n):
+    c = np.random.default_rng(1000 + n).random((n, n)).astype(np.float32)
+    r = jv_oracle(c, np.float32)
+    ri, ci = linear_sum_assignment(c.astype(np.float64))
+    assert np.array_equal(r["rowsol"], ci)
+    # dual feasibility and complementary slackness in the solve precision
+    u, v = r["u"].astype(np.float64), r["v"].astype(np.float64)
+    red = c.astype(np.float64) - u[:, None] - v[None, :]
+    assert red.min() > -1e-5
+    assert np.abs(red[np.arange(n), r["rowsol"]]).max() < 1e-5
+
+
+def test_jv_oracle_rejects_nan_and_nonsquare():
+    c = np.ones((4, 4), np.float32)
+    c[1, 2] = np.nan
+    with pytest.raises(ValueError):
+        jv_oracle(c)
+    with pytest.raises(ValueError):
+        jv_oracle(np.ones((3, 4), np.float32))
+
+
+def test_jv_oracle_scan_counters():
+    n = 300
+    c = np.random.default_rng(9).random((n, n)).astype(np.float32)
+    st = jv_oracle(c)["stats"]
+    assert st.scans_colred == n
+    assert st.row_scans == (st.scans_colred + st.scans_redtransfer + st.scans_arr + st.scans_aug_init + st.scans_aug_relax)
+    assert st.scans_aug_init == st.augmentations == st.free_after_arr2
