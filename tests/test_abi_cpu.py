@@ -1,0 +1,122 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol include/cytohip.h declares,
+argument validation that needs no device, host-side logic, and a world_size-2 gloo run of the
+chunk scheduler."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from cytospace_amd import _lib
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "cytohip.h")).read()
+    names = sorted(set(re.findall(r"\b(cyto_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 14
+    for nme in names:
+        assert hasattr(L, nme), f"{nme} declared in cytohip.h but not exported"
+    assert L.cyto_version().decode().startswith("cytohip")
+    assert L.cyto_strerror(2).decode() == "cost matrix contains NaN or Inf"
+
+
+def test_status_to_exception_mapping():
+    from cytospace_amd import _lib
+    _lib.lib()
+    with pytest.raises(ValueError):
+        _lib.check(1)
+    with pytest.raises(ValueError):
+        _lib.check(2)
+    with pytest.raises(MemoryError):
+        _lib.check(3)
+    with pytest.raises(_lib.CytoHipError):
+        _lib.check(4)
+    _lib.check(0)
+
+
+def test_no_cpu_fallback_product_fails_loudly_without_device():
+    from cytospace_amd import _lib
+    from cytospace_amd.lap import lap_solve
+    if _lib.device_count() > 0:
+        pytest.skip("a device is visible")
+    with pytest.raises(Exception):
+        lap_solve(np.ones((4, 4), np.float32))
+
+
+def test_python_argument_validation():
+    from cytospace_amd.lap import lap_solve
+    with pytest.raises(ValueError):
+        lap_solve(np.zeros((3, 4), np.float32))
+    with pytest.raises(TypeError):
+        lap_solve(np.zeros((3, 3)), dtype=np.int32)
+    from cytospace_amd import linear_assignment_solvers as gs
+    assert "lapjv_hip" in gs.SOLVER_METHODS
+    assert gs.import_solver("lapjv_hip").__name__ == "lapjv_hip"
+    with pytest.raises(NotImplementedError):
+        gs.import_solver("bogus")
+    import pickle
+    assert pickle.loads(pickle.dumps(gs.import_solver("lapjv_hip"))) is gs.import_solver("lapjv_hip")  # picklable callable
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "cytospace_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_partition_indices_matches_golden():
+    from cytospace_amd.cytospace import partition_indices
+    d = np.load(os.path.join(ROOT, "tests", "golden", "gv6_partition.npz"))
+    p = partition_indices(np.arange(0, 1800), np.array([500, 1000, 300]), 400, shuffle=False)
+    assert np.array_equal([len(x) for x in p], d["ex2_lens"]) and np.array_equal([x[0] for x in p], d["ex2_first"])
+    np.random.seed(5)
+    p = partition_indices(np.arange(0, 37), split_by_interval_int=10, shuffle=True)
+    assert np.array_equal(np.concatenate(p), d["shuf_concat"])
+
+
+def test_schedule_chunks_lpt():
+    from cytospace_amd.cytospace import schedule_chunks
+    owner = schedule_chunks([10000, 10000, 10000, 10000, 5000, 5000, 5000, 5000], 4)
+    assert sorted(owner[:4]) == [0, 1, 2, 3]            # the four big chunks go to four different devices
+    assert len(set(owner)) == 4
+    assert schedule_chunks([5, 3], 1) == [0, 0]
+
+
+_GLOO_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch.distributed as dist
+from cytospace_amd.cytospace import schedule_chunks, partition_indices
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+idx = partition_indices(np.arange(2300), split_by_interval_int=500, shuffle=False)
+owner = schedule_chunks([len(i) for i in idx], world)
+mine = [k for k in range(len(idx)) if owner[k] == rank]
+got = [None] * world
+dist.all_gather_object(got, mine)
+allc = sorted(sum(got, []))
+assert allc == list(range(len(idx))), allc          # every chunk solved exactly once
+assert all(len(g) > 0 for g in got)
+dist.barrier()
+if rank == 0:
+    print("GLOO_OK", got)
+"""
+
+
+def test_chunk_sharding_world_size_2_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29517", str(script), ROOT],
+                       capture_output=True, text=True, timeout=280, env=env)
+    assert "GLOO_OK" in r.stdout, r.stdout + r.stderr
