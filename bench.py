@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=20000, help="LAP size (default: BASELINE.json configs[1])")
-    ap.add_argument("--cpu-n", type=int, default=9000, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-n", type=int, default=16000, help="size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
