@@ -26,7 +26,8 @@ class LapInfo(ctypes.Structure):
         [(k, ctypes.c_int64) for k in (
             "scans_colred", "scans_redtransfer", "scans_arr", "scans_aug_init", "scans_aug_relax",
             "augmentations", "path_hops", "free_after_colred", "free_after_arr1", "free_after_arr2",
-            "hbm_row_reads", "dense_refreshes")] + [("reserved", ctypes.c_int64 * 6)]
+            "hbm_row_reads", "dense_refreshes")] + [("ms_arr", ctypes.c_double), ("ms_aug", ctypes.c_double),
+                                                        ("reserved", ctypes.c_int64 * 4)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -961,75 +961,13 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
             const int sj = (q / BLOCK2) * 4 + (jp & 3);   // uniform
             const bool own = (q % BLOCK2) == tid;
             if (own) { scannedm |= (1ull << sj); sumvd[jp] = vjp + dmin; }
-#define MASK_CASE(K) case K: if constexpr (K < NC) { if (own) { vm[K < NC ? K : 0] = -INFINITY; dreg[K < NC ? K : 0] = INFINITY; } } break;
-            switch (sj) {
-            MASK_CASE(0)
-            MASK_CASE(1)
-            MASK_CASE(2)
-            MASK_CASE(3)
-            MASK_CASE(4)
-            MASK_CASE(5)
-            MASK_CASE(6)
-            MASK_CASE(7)
-            MASK_CASE(8)
-            MASK_CASE(9)
-            MASK_CASE(10)
-            MASK_CASE(11)
-            MASK_CASE(12)
-            MASK_CASE(13)
-            MASK_CASE(14)
-            MASK_CASE(15)
-            MASK_CASE(16)
-            MASK_CASE(17)
-            MASK_CASE(18)
-            MASK_CASE(19)
-            MASK_CASE(20)
-            MASK_CASE(21)
-            MASK_CASE(22)
-            MASK_CASE(23)
-            MASK_CASE(24)
-            MASK_CASE(25)
-            MASK_CASE(26)
-            MASK_CASE(27)
-            MASK_CASE(28)
-            MASK_CASE(29)
-            MASK_CASE(30)
-            MASK_CASE(31)
-            MASK_CASE(32)
-            MASK_CASE(33)
-            MASK_CASE(34)
-            MASK_CASE(35)
-            MASK_CASE(36)
-            MASK_CASE(37)
-            MASK_CASE(38)
-            MASK_CASE(39)
-            MASK_CASE(40)
-            MASK_CASE(41)
-            MASK_CASE(42)
-            MASK_CASE(43)
-            MASK_CASE(44)
-            MASK_CASE(45)
-            MASK_CASE(46)
-            MASK_CASE(47)
-            MASK_CASE(48)
-            MASK_CASE(49)
-            MASK_CASE(50)
-            MASK_CASE(51)
-            MASK_CASE(52)
-            MASK_CASE(53)
-            MASK_CASE(54)
-            MASK_CASE(55)
-            MASK_CASE(56)
-            MASK_CASE(57)
-            MASK_CASE(58)
-            MASK_CASE(59)
-            MASK_CASE(60)
-            MASK_CASE(61)
-            MASK_CASE(62)
-            MASK_CASE(63)
-            default: break;
+            // (runs while the row loads are in flight; sj is wave-uniform, `own` selects one lane)
+#pragma unroll
+            for (int sl = 0; sl < NC; sl++) {
+                const bool hit = own && (sl == sj);
+                vm[sl] = hit ? -INFINITY : vm[sl];
+                dreg[sl] = hit ? INFINITY : dreg[sl];
             }
-#undef MASK_CASE
         }
 #pragma unroll
         for (int m = 0; m < CH; m++) {
@@ -1081,7 +1019,9 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
     constexpr int NC = CH * 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     __shared__ Scratch2 s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // provably wave-uniform wave id: the wave-0 state machine below then lives in SGPRs with scalar branches
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = a.n;
     const int64_t ld = a.ld;
     const float *__restrict__ cost = a.cost;
@@ -1124,11 +1064,11 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
     __syncthreads();
 
     float delta = 0.0f;
-    long long c_relax = 0, c_hops = 0, c_rt = 0, c_arr = 0, c_augs = 0, c_dense = 0;
-    long long c_free_cr = numfree, c_free_a1 = 0, c_free_a2 = 0;
+    int c_rt = 0, c_arr = 0, c_dense = 0;
+    int c_free_cr = numfree, c_free_a1 = 0, c_free_a2 = 0;
     int err = 0;
 
-    const long long arr_budget = 1000ll * n + 1000000ll;   // == JV_ARR_BUDGET(n) of the oracle
+    const int arr_budget = 1000 * n + 1000000;   // == JV_ARR_BUDGET(n) of the oracle (n <= 32768 here)
     // chain state (meaningful in wave 0 only; uniform there)
     int phase = (n > 1) ? PH_RT : PH_ARR;
     int k = 0, sweep = 0, prev = numfree, carry = -1, cur_i = -1;
@@ -1138,9 +1078,10 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
 
     for (;;) {
         if (wave == 0) {
-            // wave 0 runs cached steps until it needs the whole workgroup (dense re-scan, an
-            // augmentation) or is done; it then posts a command and falls through to the barrier.
+            // wave 0 runs cached steps until it needs the whole workgroup (a dense re-scan) or is done;
+            // it then posts a command and falls through to the barrier below.
             for (;;) {
+                // ---------- slow path: choose the next row (phase changes, new chains, budget) ----------
                 if (!have_dense) {
                     if (phase == PH_RT) {
                         if (k >= nrt) { phase = PH_ARR; sweep = 0; k = 0; prev = numfree; numfree = 0; carry = -1; continue; }
@@ -1162,16 +1103,14 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
                         else if (sweep == 0) { c_free_a1 = numfree; sweep = 1; k = 0; prev = numfree; numfree = 0; continue; }
                         else { c_free_a2 = numfree; phase = PH_AUG; k = 0; continue; }
                     } else {
-                        if (k >= numfree || err) { if (lane == 0) { s.cmd_op = OP_EXIT; s.cmd_row = 0; } break; }
-                        cur_i = __builtin_amdgcn_readfirstlane(ld_i32(freerows + k)); k++;
-                        if (lane == 0) { s.cmd_op = OP_AUG; s.cmd_row = cur_i; }
-                        c_augs++;
+                        // RT and ARR are done: the augmentation runs in its own kernel (jv_aug2)
+                        if (lane == 0) { s.cmd_op = OP_EXIT; s.cmd_row = 0; }
                         break;
                     }
                 }
-                const int i = cur_i;
                 if (phase == PH_RT) {
                     // v[j1] -= min over j != j1 of (c[i][j] - v[j])
+                    const int i = cur_i;
                     const int j1 = __builtin_amdgcn_readfirstlane(ld_i32(rowsol + i));
                     float mn;
                     if (have_dense) {
@@ -1193,10 +1132,15 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
                     const float nv = st_vget<LDS_STATE>(s_v, gv, j1) - mn;
                     if (lane == 0) st_vset<LDS_STATE>(s_v, gv, j1, nv);
                     c_rt++;
-                } else {
+                    continue;
+                }
+                // ---------- ARR: tight loop that follows one displacement chain ----------
+                bool need_dense = false;
+                for (;;) {
+                    const int i = cur_i;
                     float umin, usub, vj1;
                     int j1, j2 = -1, i0, i02 = -1;
-                    if (have_dense) {
+                    if (__builtin_expect(have_dense, 0)) {
                         have_dense = false;
                         umin = key_val(gd.m1); usub = key_val(gd.m2);
                         j1 = (int)(uint32_t)gd.m1; j2 = (int)(uint32_t)gd.m2;
@@ -1206,30 +1150,32 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
                     } else {
                         const uint32_t col = ld_u32(a.cache_col + (int64_t)i * KC + lane);
                         const float cv = ld_f32(a.cache_val + (int64_t)i * KC + lane);
-                        const float F = __uint_as_float(readlane32(__float_as_uint(cv), KCU));
                         const bool valid = col != COLSENT;
                         const float vj = st_vget<LDS_STATE>(s_v, gv, valid ? (int)col : 0);
                         const int32_t csj = st_csget<LDS_STATE>(s_cs, gcolsol, valid ? (int)col : 0);
+                        const float F = __uint_as_float(readlane32(__float_as_uint(cv), KCU));
                         const uint32_t ord = valid ? f2ord(cv - vj) : 0xFFFFFFFFu;
                         // minimum, its lane (ties: lowest column), then the minimum of the rest
                         const uint32_t o1 = wave_min_u32(ord);
                         const uint64_t m1 = __ballot(ord == o1);
                         int l1 = __builtin_ctzll(m1);
-                        if (m1 & (m1 - 1)) {
+                        if (__builtin_expect((m1 & (m1 - 1)) != 0, 0)) {
                             const uint32_t cmin = wave_min_u32(ord == o1 ? col : 0xFFFFFFFFu);
                             l1 = __builtin_ctzll(__ballot(col == cmin));
                         }
                         const uint32_t o2 = wave_min_u32(lane == l1 ? 0xFFFFFFFFu : ord);
-                        if (!(ord2f(o2) < F)) {
+                        usub = ord2f(o2);
+                        if (__builtin_expect(!(usub < F), 0)) {
                             if (lane == 0) { s.cmd_op = OP_REFRESH; s.cmd_row = i; }
                             c_dense++;
+                            need_dense = true;
                             break;
                         }
-                        umin = ord2f(o1); usub = ord2f(o2);
+                        umin = ord2f(o1);
                         j1 = (int)readlane32(col, l1);
                         vj1 = __uint_as_float(readlane32(__float_as_uint(vj), l1));
                         i0 = (int)readlane32((uint32_t)csj, l1);
-                        if (!((vj1 - (usub - umin)) < vj1) && i0 >= 0) {
+                        if (__builtin_expect(!((vj1 - (usub - umin)) < vj1) && i0 >= 0, 0)) {
                             const uint64_t m2 = __ballot(ord == o2 && lane != l1);
                             int l2 = __builtin_ctzll(m2);
                             if (m2 & (m2 - 1)) {
@@ -1243,31 +1189,89 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
                     c_arr++;
                     const float vnew = vj1 - (usub - umin);
                     const bool lowers = vnew < vj1;
-                    if (lowers) { if (lane == 0) st_vset<LDS_STATE>(s_v, gv, j1, vnew); }
-                    else if (i0 >= 0) { j1 = j2; i0 = i02; }
-                    if (lane == 0) { st_i32(rowsol + i, j1); st_csset<LDS_STATE>(s_cs, gcolsol, j1, i); }
-                    if (i0 >= 0) {
-                        if (lowers) carry = i0;
-                        else { if (lane == 0) st_i32(freerows + numfree, i0); numfree++; }
+                    const bool swap = !lowers && i0 >= 0;
+                    const int jj = swap ? j2 : j1;
+                    const int i0f = swap ? i02 : i0;
+                    // rowsol is not read during ARR and equals the inverse of colsol: it is rebuilt after the chain
+                    if (lane == 0) {
+                        if (lowers) st_vset<LDS_STATE>(s_v, gv, j1, vnew);
+                        st_csset<LDS_STATE>(s_cs, gcolsol, jj, i);
                     }
+                    if (__builtin_expect(i0f >= 0 && lowers && c_arr < arr_budget, 1)) { cur_i = i0f; continue; }   // chain goes on
+                    if (i0f >= 0) {
+                        if (lowers) carry = i0f;       // budget reached: the slow path flushes it
+                        else { if (lane == 0) st_i32(freerows + numfree, i0f); numfree++; }
+                    }
+                    break;
                 }
+                if (need_dense) break;
             }
         }
         __syncthreads();
         const int op = s.cmd_op, row = s.cmd_row;
         if (op == OP_EXIT) break;
-        if (op == OP_REFRESH) {
+        {
             float vreg[NC];
             load_vreg<CH, LDS_STATE>(s_v, gv, n, tid, vreg);
             gd = refresh_row<CH>(row, n, ld, cost, vreg, validm, a.cache_col, a.cache_val, delta, s, par);
             have_dense = true;
-        } else {
-            const int e = chain_augment<CH, LDS_STATE>(n, ld, cost, gv, sumvd, rowsol, gcolsol, pred, s_v, s_cs, row, validm, s, par,
-                                                       c_relax, c_hops);
-            if (e) err = e;
         }
     }
 
+    // ---- write back prices and colsol for the augmentation kernel; rowsol = inverse of colsol ----
+    __syncthreads();
+    for (int c = tid; c < n; c += BLOCK2) {
+        const int32_t r = st_csget<LDS_STATE>(s_cs, gcolsol, c);
+        if constexpr (LDS_STATE) { gv[c] = s_v[c]; gcolsol[c] = r; }
+        if (r >= 0) rowsol[r] = c;
+    }
+    if (tid == 0) {
+        long long *counters = reinterpret_cast<long long *>(a.misc + 16);
+        counters[C_RT] = c_rt; counters[C_ARR] = c_arr;
+        counters[C_FREE_CR] = c_free_cr; counters[C_FREE_A1] = c_free_a1; counters[C_FREE_A2] = c_free_a2;
+        counters[C2_DENSE_REFRESH] = c_dense;
+        *reinterpret_cast<int *>(a.misc + 128) = numfree;
+    }
+}
+
+// AUGMENTATION + duals + total: one persistent workgroup, all lanes active (see chain_augment).
+template <int CH, bool LDS_STATE>
+__global__ __launch_bounds__(BLOCK2) void jv_aug2(Chain2Args a) {
+    constexpr int NC = CH * 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    __shared__ Scratch2 s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = a.n;
+    const int64_t ld = a.ld;
+    const float *__restrict__ cost = a.cost;
+    float *gv = a.fws;
+    float *sumvd = a.fws + 2 * (int64_t)n;
+    int32_t *rowsol = a.iws, *gcolsol = a.iws + n;
+    int32_t *freerows = a.iws + 3 * (int64_t)n, *pred = a.iws + 5 * (int64_t)n;
+    const int npad = (n + 3) & ~3;
+    float *s_v = reinterpret_cast<float *>(dyn_lds);
+    uint16_t *s_cs = reinterpret_cast<uint16_t *>(dyn_lds + (size_t)npad * 4);
+    int par = 0;
+    uint64_t validm = 0;
+#pragma unroll
+    for (int sl = 0; sl < NC; sl++) if (SLOT_COL(sl) < n) validm |= (1ull << sl);
+    if constexpr (LDS_STATE) {
+        for (int c = tid; c < npad; c += BLOCK2) {
+            s_v[c] = c < n ? gv[c] : 0.0f;
+            const int32_t cs = c < n ? gcolsol[c] : -1;
+            s_cs[c] = cs < 0 ? (uint16_t)0xFFFFu : (uint16_t)cs;
+        }
+    }
+    __syncthreads();
+    const int numfree = *reinterpret_cast<const int *>(a.misc + 128);
+    long long c_relax = 0, c_hops = 0, c_augs = 0;
+    int err = 0;
+    for (int f = 0; f < numfree && !err; f++) {
+        const int freerow = __builtin_amdgcn_readfirstlane(ld_i32(freerows + f));
+        err = chain_augment<CH, LDS_STATE>(n, ld, cost, gv, sumvd, rowsol, gcolsol, pred, s_v, s_cs, freerow, validm, s, par,
+                                           c_relax, c_hops);
+        c_augs++;
+    }
     // ---- write back prices and colsol, then duals u and the total ----
     if constexpr (LDS_STATE) {
         for (int c = tid; c < n; c += BLOCK2) {
@@ -1295,11 +1299,8 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
         for (int w = 0; w < NW2; w++) t += s.sum[w];
         *reinterpret_cast<double *>(a.misc + 8) = t;
         long long *counters = reinterpret_cast<long long *>(a.misc + 16);
-        counters[C_RT] = c_rt; counters[C_ARR] = c_arr; counters[C_AUG_INIT] = c_augs;
-        counters[C_AUG_RELAX] = c_relax; counters[C_AUGS] = c_augs; counters[C_HOPS] = c_hops;
-        counters[C_FREE_CR] = c_free_cr; counters[C_FREE_A1] = c_free_a1; counters[C_FREE_A2] = c_free_a2;
-        counters[C_ROWS_READ] = c_dense + c_augs + c_relax;
-        counters[C2_DENSE_REFRESH] = c_dense;
+        counters[C_AUG_INIT] = c_augs; counters[C_AUG_RELAX] = c_relax; counters[C_AUGS] = c_augs; counters[C_HOPS] = c_hops;
+        counters[C_ROWS_READ] = counters[C2_DENSE_REFRESH] + c_augs + c_relax;
         *reinterpret_cast<int *>(a.misc + 4) = err;
     }
 }
@@ -1309,7 +1310,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
 // host side
 // ------------------------------------------------------------------------------------------
 template <int CH, bool LDS_STATE>
-static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_cache_done, hipStream_t stream) {
+static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_cache_done, hipEvent_t ev_arr_done, hipStream_t stream) {
     const int npad = (args.n + 3) & ~3;
     const size_t shmem = LDS_STATE ? (((size_t)npad * 6 + 15) / 16) * 16 : 16;
     auto kern = jv_chain2<CH, LDS_STATE>;
@@ -1319,6 +1320,11 @@ static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_c
     CYTO_HIP(hipGetLastError());
     CYTO_HIP(hipEventRecord(ev_cache_done, stream));
     hipLaunchKernelGGL(kern, dim3(1), dim3(BLOCK2), shmem, stream, args);
+    CYTO_HIP(hipGetLastError());
+    CYTO_HIP(hipEventRecord(ev_arr_done, stream));
+    auto kaug = jv_aug2<CH, LDS_STATE>;
+    CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kaug), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(kaug, dim3(1), dim3(BLOCK2), shmem, stream, args);
     CYTO_HIP(hipGetLastError());
     return CYTO_OK;
 }
@@ -1409,9 +1415,10 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
     ca.freerows = d_free; ca.rtrows = d_rt; ca.pred = d_pred;
     ca.total = d_total; ca.counters = d_counters; ca.status = d_status;
 
-    hipEvent_t e1b, e1c;
+    hipEvent_t e1b, e1c, e1d;
     CYTO_HIP(hipEventCreate(&e1b));
     CYTO_HIP(hipEventCreate(&e1c));
+    CYTO_HIP(hipEventCreate(&e1d));
     CYTO_HIP(hipEventRecord(e1b, stream));
     const int64_t per = (int64_t)VW * BLOCK;
     DevBuf b_ccol, b_cval;
@@ -1430,20 +1437,21 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
             c2.cache_col = b_ccol.as<uint32_t>(); c2.cache_val = b_cval.as<float>(); c2.misc = b_misc.as<char>();
             const int cache_grid = max(1, min(n, 1024));
             const int per2 = 4 * BLOCK2;
-            if (n <= 2 * per2) rc = launch_chain2<2, true>(c2, cache_grid, e1c, stream);
-            else if (n <= 5 * per2) rc = launch_chain2<5, true>(c2, cache_grid, e1c, stream);
-            else if (n <= 10 * per2) rc = launch_chain2<10, true>(c2, cache_grid, e1c, stream);
-            else if (n <= 13 * per2) rc = launch_chain2<13, true>(c2, cache_grid, e1c, stream);
-            else rc = launch_chain2<16, false>(c2, cache_grid, e1c, stream);
+            if (n <= 2 * per2) rc = launch_chain2<2, true>(c2, cache_grid, e1c, e1d, stream);
+            else if (n <= 5 * per2) rc = launch_chain2<5, true>(c2, cache_grid, e1c, e1d, stream);
+            else if (n <= 10 * per2) rc = launch_chain2<10, true>(c2, cache_grid, e1c, e1d, stream);
+            else if (n <= 13 * per2) rc = launch_chain2<13, true>(c2, cache_grid, e1c, e1d, stream);
+            else rc = launch_chain2<16, false>(c2, cache_grid, e1c, e1d, stream);
         }
     } else {
         CYTO_HIP(hipEventRecord(e1c, stream));
+        CYTO_HIP(hipEventRecord(e1d, stream));
         if (n <= 2 * per) rc = launch_chain<T, 2, true>(ca, stream);
         else if (n <= 5 * per) rc = launch_chain<T, 5, true>(ca, stream);
         else if (n <= 8 * per) rc = launch_chain<T, 8, true>(ca, stream);
         else rc = launch_chain<T, 16, false>(ca, stream);
     }
-    if (rc) { cleanup(); (void)hipEventDestroy(e1b); (void)hipEventDestroy(e1c); return rc; }
+    if (rc) { cleanup(); (void)hipEventDestroy(e1b); (void)hipEventDestroy(e1c); (void)hipEventDestroy(e1d); return rc; }
     CYTO_HIP(hipEventRecord(e2, stream));
     CYTO_HIP(hipStreamSynchronize(stream));
 
@@ -1462,6 +1470,7 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
         (void)hipEventElapsedTime(&ms, e0, e1); info->ms_colred = ms;
         (void)hipEventElapsedTime(&ms, e1b, e1c); info->ms_cache = ms;
         (void)hipEventElapsedTime(&ms, e1c, e2); info->ms_chain = ms;
+        if (fast) { (void)hipEventElapsedTime(&ms, e1c, e1d); info->ms_arr = ms; (void)hipEventElapsedTime(&ms, e1d, e2); info->ms_aug = ms; }
         info->ms_total = info->ms_colred + info->ms_cache + info->ms_chain;
         info->scans_colred = n;
         info->scans_redtransfer = h_counters[C_RT];
@@ -1479,6 +1488,7 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
     cleanup();
     (void)hipEventDestroy(e1b);
     (void)hipEventDestroy(e1c);
+    (void)hipEventDestroy(e1d);
     return h_status ? CYTO_ERR_INTERNAL : CYTO_OK;
 }
 

@@ -61,14 +61,16 @@ int cyto_device_synchronize(int device_id);
 typedef struct {
     double ms_colred;        /* HIP-event time of the column-reduction kernels */
     double ms_cache;         /* HIP-event time of the row-cache build kernel (float32 path; else 0) */
-    double ms_chain;         /* HIP-event time of the persistent RT+ARR+augmentation kernel */
+    double ms_chain;         /* HIP-event time of the persistent chain kernels (RT+ARR, then augmentation) */
     double ms_total;         /* sum of the three (kernel time only: no H2D/D2H, no allocation) */
     int64_t scans_colred, scans_redtransfer, scans_arr, scans_aug_init, scans_aug_relax;
     int64_t augmentations, path_hops;
     int64_t free_after_colred, free_after_arr1, free_after_arr2;
     int64_t hbm_row_reads;   /* full cost rows the kernels actually fetched from HBM */
     int64_t dense_refreshes; /* RT/ARR steps whose row cache was exhausted (full re-scan) */
-    int64_t reserved[6];
+    double ms_arr;           /* float32 path: the RT+ARR kernel (jv_chain2) alone */
+    double ms_aug;           /* float32 path: the augmentation kernel (jv_aug2) alone */
+    int64_t reserved[4];
 } cyto_lap_info;
 
 int cyto_lap_f32(int n, const float *cost, int64_t ld, int cost_on_device,
