@@ -370,13 +370,17 @@ int cyto_assign_pearson(int G, int C, int S, const double *sc, const double *st,
     if ((rc = zst.alloc((size_t)Gpad * ldzst * 4)) || (rc = zsc.alloc((size_t)Gpad * ldzsc * 4)) ||
         (rc = cost.alloc((size_t)N * ldc * 4)))
         return rc;
+    // a private stream, so that several host threads can run chunks concurrently on one GPU
+    hipStream_t stream = nullptr;
+    CYTO_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { if (s) (void)hipStreamDestroy(s); } } guard{stream};
     hipEvent_t e0, e1;
     CYTO_HIP(hipEventCreate(&e0));
     CYTO_HIP(hipEventCreate(&e1));
-    CYTO_HIP(hipEventRecord(e0, nullptr));
-    if ((rc = cyto_standardize(G, S, st, S, 1, 0, already_normalized, zst.as<float>(), ldzst, Gpad, device_id, nullptr))) return rc;
-    if ((rc = cyto_standardize(G, C, sc, C, 1, 0, already_normalized, zsc.as<float>(), ldzsc, Gpad, device_id, nullptr))) return rc;
-    CYTO_HIP(hipEventRecord(e1, nullptr));
+    CYTO_HIP(hipEventRecord(e0, stream));
+    if ((rc = cyto_standardize(G, S, st, S, 1, 0, already_normalized, zst.as<float>(), ldzst, Gpad, device_id, stream))) return rc;
+    if ((rc = cyto_standardize(G, C, sc, C, 1, 0, already_normalized, zsc.as<float>(), ldzsc, Gpad, device_id, stream))) return rc;
+    CYTO_HIP(hipEventRecord(e1, stream));
     CYTO_HIP(hipEventSynchronize(e1));
     float ms_std = 0;
     (void)hipEventElapsedTime(&ms_std, e0, e1);
@@ -384,12 +388,12 @@ int cyto_assign_pearson(int G, int C, int S, const double *sc, const double *st,
     (void)hipEventDestroy(e1);
     double ms_gemm = 0;
     if ((rc = cyto_cost_pearson(Gpad, S, C, zst.as<float>(), ldzst, zsc.as<float>(), ldzsc, slots, cost.as<float>(), ldc,
-                                &ms_gemm, device_id, nullptr)))
+                                &ms_gemm, device_id, stream)))
         return rc;
     std::vector<int32_t> colsol((size_t)N);
     cyto_lap_info li;
     double total = 0;
-    if ((rc = cyto_lap_f32((int)N, cost.as<float>(), ldc, 1, nullptr, colsol.data(), nullptr, nullptr, &total, &li, device_id, nullptr)))
+    if ((rc = cyto_lap_f32((int)N, cost.as<float>(), ldc, 1, nullptr, colsol.data(), nullptr, nullptr, &total, &li, device_id, stream)))
         return rc;
     // location_repeat[y] (cytospace.py:331): LAP row -> spot
     std::vector<int32_t> rowspot((size_t)N);

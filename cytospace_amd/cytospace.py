@@ -100,15 +100,16 @@ def schedule_chunks(sizes, n_devices):
 
 
 def assign_chunks(scRNA_norm, st_norm, cell_number_to_node_assignment, index_sc_list, index_st_list=None,
-                  subsampled_slots_list=None, rank=0, world_size=1, device_id=0):
+                  subsampled_slots_list=None, rank=0, world_size=1, device_id=0, max_concurrent=8):
     """The chunk fan-out of apply_linear_assignment (cytospace.py:405-467) for one rank of a
     one-process-per-GPU job: this rank solves the chunks the LPT schedule gives it and returns
     {chunk index: mapped_st_index}.  Inputs are already normalised numpy arrays (genes x cells/spots)."""
     if (index_st_list is not None) and (subsampled_slots_list is not None):
         raise ValueError("index_st_list and subsampled_cell_number_to_node_assignment_list cannot both be specified")
+    from concurrent.futures import ThreadPoolExecutor
     n_chunks = len(index_sc_list)
     owner = schedule_chunks([len(ix) for ix in index_sc_list], world_size)
-    out = {}
+    jobs = {}
     for idx in range(n_chunks):
         if owner[idx] != rank:
             continue
@@ -122,5 +123,9 @@ def assign_chunks(scRNA_norm, st_norm, cell_number_to_node_assignment, index_sc_
         else:
             st = st_norm
             slots = cell_number_to_node_assignment
-        out[idx] = assign_pearson(sc, st, slots, already_normalized=True, device_id=device_id)
-    return out
+        jobs[idx] = (sc, st, slots)
+    # the sequential part of one solve occupies one workgroup: run this rank's chunks side by side
+    # (ctypes releases the GIL; every call uses its own HIP stream)
+    with ThreadPoolExecutor(max_workers=max(1, min(max_concurrent, max(1, len(jobs))))) as ex:
+        futs = {idx: ex.submit(assign_pearson, sc, st, slots, True, device_id) for idx, (sc, st, slots) in jobs.items()}
+        return {idx: f.result() for idx, f in futs.items()}

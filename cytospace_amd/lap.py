@@ -63,3 +63,37 @@ def lapjv_hip(cost, verbose=0, force_doubles=False):
     """
     r = lap_solve(cost, dtype=np.float64 if force_doubles else np.float32)
     return r["rowsol"], r["colsol"], (r["total"], r["u"], r["v"])
+
+
+def lap_solve_batch(costs, device_id=0, max_concurrent=0, return_info=False):
+    """Solve several independent square LAPs concurrently on one GPU (C ABI: cyto_lap_batch_f32).
+
+    costs: list of 2-D float arrays (host).  Returns a list of dicts like lap_solve()."""
+    L = _lib.lib()
+    nb = len(costs)
+    if nb == 0:
+        return []
+    mats = [np.ascontiguousarray(c, dtype=np.float32) for c in costs]
+    for c in mats:
+        if c.ndim != 2 or c.shape[0] != c.shape[1] or c.shape[0] == 0:
+            raise ValueError("every cost must be a non-empty square 2-D matrix")
+    ns = (ctypes.c_int * nb)(*[c.shape[0] for c in mats])
+    lds = (ctypes.c_int64 * nb)(*[c.shape[0] for c in mats])
+    outs = [dict(rowsol=np.empty(c.shape[0], np.int32), colsol=np.empty(c.shape[0], np.int32),
+                 u=np.empty(c.shape[0], np.float32), v=np.empty(c.shape[0], np.float32)) for c in mats]
+
+    def ptrs(key):
+        return (ctypes.c_void_p * nb)(*[o[key].ctypes.data for o in outs])
+
+    cptr = (ctypes.c_void_p * nb)(*[c.ctypes.data for c in mats])
+    totals = (ctypes.c_double * nb)()
+    infos = (_lib.LapInfo * nb)()
+    status = (ctypes.c_int * nb)()
+    st = L.cyto_lap_batch_f32(nb, ns, cptr, lds, 0, ptrs("rowsol"), ptrs("colsol"), ptrs("u"), ptrs("v"), totals, infos,
+                              status, max_concurrent, device_id)
+    _lib.check(st)
+    for b, o in enumerate(outs):
+        o["total"] = totals[b]
+        if return_info:
+            o["info"] = infos[b]
+    return outs

@@ -80,6 +80,24 @@ int cyto_lap_f64(int n, const double *cost, int64_t ld, int cost_on_device,
                  int32_t *rowsol, int32_t *colsol, double *u, double *v, double *total,
                  cyto_lap_info *info, int device_id, void *stream);
 
+/* ---- A8 (one GPU): nb independent LAPs solved concurrently.  Replaces the per-chunk worker processes of
+ * apply_linear_assignment (cytospace/cytospace.py:430-451) for the solver-only seam: the sequential
+ * chain of one solve occupies one workgroup, so chunks run side by side (one HIP stream each).
+ * n[b], cost[b], ld[b]: per problem; outputs are arrays of per-problem host pointers (each may be NULL);
+ * total/info/status_out: arrays of length nb (may be NULL).  max_concurrent <= 0 -> min(nb, 32). */
+int cyto_lap_batch_f32(int nb, const int *n, const float *const *cost, const int64_t *ld, int cost_on_device,
+                       int32_t *const *rowsol, int32_t *const *colsol, float *const *u, float *const *v,
+                       double *total, cyto_lap_info *info, int *status_out, int max_concurrent, int device_id);
+
+/* ---- A8 (several GPUs, one process each): the only collective on the path is the broadcast of the
+ * shared standardised ST matrix (RCCL over xGMI).  id128: 128-byte ncclUniqueId made on one rank by
+ * cyto_comm_unique_id and handed to the others by the launcher (bench/driver: torch.distributed, MPI,
+ * a file ...).  The reference has no counterpart: it pickles the matrix to every worker (cytospace.py:446-451). */
+int cyto_comm_unique_id(char *id128);
+int cyto_comm_init(const char *id128, int rank, int nranks, int device_id, void **comm_out);
+int cyto_comm_bcast_f32(void *comm, float *dev_buf, size_t count, int root, int device_id, void *stream);
+int cyto_comm_destroy(void *comm);
+
 /* ---- A1: normalize_data (cytospace/common/common.py:142-147): nan_to_num, per-column counts per
  * million over the gene axis, log2(x + 1), nan_to_num.  x: G x C host matrix (float64 if x_is_f64
  * else float32), out: G x C host float64.  Computed on the device in float64. */

@@ -125,3 +125,24 @@ def test_plugin_surface_roundtrip():
     assert np.array_equal(loc[y], d[key + "_mapped"])
     with pytest.raises(NotImplementedError):
         gsolvers.import_solver("nonsense")
+
+
+def test_assign_chunks_concurrent_matches_sequential():
+    # sub-spot sampling style chunks (cytospace.py:650-660): every chunk sees the full ST matrix
+    rng = np.random.default_rng(3)
+    G, S, k = 120, 30, 4
+    sc = ocost.normalize_data(rng.poisson(3.0, (G, S * k)).astype(np.float64))
+    st = ocost.normalize_data(rng.poisson(9.0, (G, S)).astype(np.float64))
+    index_sc = gcyto.partition_indices(np.arange(S * k), split_by_interval_int=40, shuffle=False)
+    slot_ids = np.repeat(np.arange(S), k)
+    slots_list = [np.bincount(slot_ids[ix], minlength=S) for ix in index_sc]
+    res = gcyto.assign_chunks(sc, st, None, index_sc, subsampled_slots_list=slots_list, max_concurrent=3)
+    assert sorted(res) == list(range(len(index_sc)))
+    for idx, ix in enumerate(index_sc):
+        ref = gcyto.assign_pearson(sc[:, ix], st, slots_list[idx])
+        assert np.array_equal(res[idx], ref)
+        assert np.array_equal(np.bincount(res[idx], minlength=S), slots_list[idx])
+    # two ranks: every chunk is solved exactly once
+    r0 = gcyto.assign_chunks(sc, st, None, index_sc, subsampled_slots_list=slots_list, rank=0, world_size=2)
+    r1 = gcyto.assign_chunks(sc, st, None, index_sc, subsampled_slots_list=slots_list, rank=1, world_size=2)
+    assert sorted(list(r0) + list(r1)) == list(range(len(index_sc)))

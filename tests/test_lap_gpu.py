@@ -115,3 +115,35 @@ def test_golden_known_answers(n):
     g = lap_solve(d[f"n{n}_cost"], np.float32)
     assert np.array_equal(g["colsol"], d[f"n{n}_colsol"]) and np.array_equal(g["rowsol"], d[f"n{n}_rowsol"])
     assert abs(g["total"] - float(d[f"n{n}_total"])) <= 1e-5
+
+
+def test_batch_of_independent_laps():
+    from cytospace_amd.lap import lap_solve_batch
+    sizes = [5, 300, 1200, 64, 2100, 700, 33]
+    costs = [np.random.default_rng(100 + n).random((n, n)).astype(np.float32) for n in sizes]
+    res = lap_solve_batch(costs, max_concurrent=4, return_info=True)
+    assert len(res) == len(sizes)
+    for c, r in zip(costs, res):
+        o = jv_oracle(c, np.float32)
+        assert np.array_equal(r["colsol"], o["colsol"]) and np.array_equal(r["rowsol"], o["rowsol"])
+        assert np.array_equal(r["u"], o["u"]) and np.array_equal(r["v"], o["v"])
+        assert r["info"].row_scans == o["stats"].row_scans
+    bad = [costs[0], np.full((4, 4), np.nan, np.float32)]
+    with pytest.raises(ValueError):
+        lap_solve_batch(bad)
+
+
+def test_rccl_broadcast_single_rank():
+    import ctypes
+    from cytospace_amd import _lib
+    L = _lib.lib()
+    idb = ctypes.create_string_buffer(128)
+    _lib.check(L.cyto_comm_unique_id(idb))
+    comm = ctypes.c_void_p()
+    _lib.check(L.cyto_comm_init(idb, 0, 1, 0, ctypes.byref(comm)))
+    x = np.arange(4096, dtype=np.float32)
+    buf = _lib.DeviceBuffer.from_numpy(x)
+    _lib.check(L.cyto_comm_bcast_f32(comm, buf.ptr, x.size, 0, 0, None))
+    assert np.array_equal(buf.to_numpy(x.shape, np.float32), x)
+    _lib.check(L.cyto_comm_destroy(comm))
+    buf.free()
