@@ -51,6 +51,10 @@ def lib():
             raise CytoHipError(
                 f"{LIB_PATH} not found: build it with `python -m cytospace_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # Independent chunk solves run on separate HIP streams; the runtime's default of 4 hardware queues
+        # would serialise them (measured: 32 concurrent 10k x 10k LAPs 3.6 s -> 1.06 s with 64 queues).
+        # Must be set before the HIP runtime initialises, i.e. before the first call into the library.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "64")
         L = ctypes.CDLL(LIB_PATH)
         L.cyto_strerror.restype = ctypes.c_char_p
         L.cyto_strerror.argtypes = [ctypes.c_int]

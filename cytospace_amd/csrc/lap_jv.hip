@@ -1135,7 +1135,13 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
                     continue;
                 }
                 // ---------- ARR: tight loop that follows one displacement chain ----------
+                // Software pipelining: the row that will be displaced (the next row of the chain) is known
+                // right after the first reduction, so its cache is requested then and arrives while the second
+                // reduction and the bookkeeping of the current step run.
                 bool need_dense = false;
+                int pf_row = -1;
+                uint32_t pf_col = 0;
+                float pf_cv = 0.0f;
                 for (;;) {
                     const int i = cur_i;
                     float umin, usub, vj1;
@@ -1148,8 +1154,13 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
                         i0 = __builtin_amdgcn_readfirstlane(st_csget<LDS_STATE>(s_cs, gcolsol, j1));
                         i02 = __builtin_amdgcn_readfirstlane(st_csget<LDS_STATE>(s_cs, gcolsol, j2));
                     } else {
-                        const uint32_t col = ld_u32(a.cache_col + (int64_t)i * KC + lane);
-                        const float cv = ld_f32(a.cache_val + (int64_t)i * KC + lane);
+                        uint32_t col;
+                        float cv;
+                        if (pf_row == i) { col = pf_col; cv = pf_cv; }          // requested during the previous step
+                        else {
+                            col = ld_u32(a.cache_col + (int64_t)i * KC + lane);
+                            cv = ld_f32(a.cache_val + (int64_t)i * KC + lane);
+                        }
                         const bool valid = col != COLSENT;
                         const float vj = st_vget<LDS_STATE>(s_v, gv, valid ? (int)col : 0);
                         const int32_t csj = st_csget<LDS_STATE>(s_cs, gcolsol, valid ? (int)col : 0);
@@ -1162,6 +1173,12 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
                         if (__builtin_expect((m1 & (m1 - 1)) != 0, 0)) {
                             const uint32_t cmin = wave_min_u32(ord == o1 ? col : 0xFFFFFFFFu);
                             l1 = __builtin_ctzll(__ballot(col == cmin));
+                        }
+                        // the current owner of the best column is (almost always) the next row of the chain
+                        pf_row = (int)readlane32((uint32_t)csj, l1);
+                        if (pf_row >= 0) {
+                            pf_col = ld_u32(a.cache_col + (int64_t)pf_row * KC + lane);
+                            pf_cv = ld_f32(a.cache_val + (int64_t)pf_row * KC + lane);
                         }
                         const uint32_t o2 = wave_min_u32(lane == l1 ? 0xFFFFFFFFu : ord);
                         usub = ord2f(o2);
