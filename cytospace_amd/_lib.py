@@ -27,7 +27,8 @@ class LapInfo(ctypes.Structure):
             "scans_colred", "scans_redtransfer", "scans_arr", "scans_aug_init", "scans_aug_relax",
             "augmentations", "path_hops", "free_after_colred", "free_after_arr1", "free_after_arr2",
             "hbm_row_reads", "dense_refreshes")] + [("ms_arr", ctypes.c_double), ("ms_aug", ctypes.c_double),
-                                                        ("reserved", ctypes.c_int64 * 4)]
+                                                        ("aug_scans_skipped", ctypes.c_int64),
+                                                        ("row_groups", ctypes.c_int64), ("reserved", ctypes.c_int64 * 2)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

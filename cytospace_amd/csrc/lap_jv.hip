@@ -40,6 +40,9 @@ template <> __device__ __forceinline__ float vec_get<float>(const float4 &x, int
 }
 template <> __device__ __forceinline__ double vec_get<double>(const double2 &x, int e) { return e == 0 ? x.x : x.y; }
 
+__device__ __forceinline__ bool memcmp_neq(float a, float b) { return __float_as_uint(a) != __float_as_uint(b); }
+__device__ __forceinline__ bool memcmp_neq(double a, double b) { return __double_as_longlong(a) != __double_as_longlong(b); }
+
 // ------------------------------------------------------------------------------------------
 // COLUMN REDUCTION
 // ------------------------------------------------------------------------------------------
@@ -111,6 +114,67 @@ __global__ void colred_assign(int n, const int32_t *__restrict__ imin, const int
     if (j >= n) return;
     const int i = imin[j];
     colsol[j] = (rowsol[i] == j) ? i : -1;
+}
+
+// ------------------------------------------------------------------------------------------
+// Duplicate-row groups.  CytoSPACE repeats every spot row slots[s] times
+// (linear_assignment_solvers.py:63-66), so the LAP often has runs of bitwise identical rows.
+// same_prev[i] = 1 iff row i equals row i-1 bit for bit (early exit on the first differing 4 KiB:
+// distinct rows cost one chunk, identical rows one full read).  Used by the augmentation to skip
+// scans that provably change nothing (see chain_augment).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rows_same_as_prev(int n, int64_t ld, const T *__restrict__ cost, int32_t *__restrict__ same_prev) {
+    using V = typename VecOf<T>::type;
+    constexpr int VW = VecOf<T>::W;
+    __shared__ int s_diff;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        if (i == 0) { if (threadIdx.x == 0) same_prev[0] = 0; continue; }
+        const V *a = reinterpret_cast<const V *>(cost + (int64_t)i * ld);
+        const V *b = reinterpret_cast<const V *>(cost + (int64_t)(i - 1) * ld);
+        const int nv = (n + VW - 1) / VW;
+        int diff = 0;
+        for (int q0 = 0; q0 < nv; q0 += 256) {
+            const int q = q0 + threadIdx.x;
+            bool d = false;
+            if (q < nv) {
+                const V x = a[q], y = b[q];
+#pragma unroll
+                for (int e = 0; e < VW; e++)
+                    if (q * VW + e < n) d |= memcmp_neq(vec_get<T>(x, e), vec_get<T>(y, e));
+            }
+            if (threadIdx.x == 0) s_diff = 0;
+            __syncthreads();
+            if (d) s_diff = 1;
+            __syncthreads();
+            diff = s_diff;
+            __syncthreads();
+            if (diff) break;
+        }
+        if (threadIdx.x == 0) same_prev[i] = diff ? 0 : 1;
+    }
+}
+
+// gid[i] = number of group starts in rows 0..i, minus 1; *ngroups = number of groups (one workgroup)
+__global__ __launch_bounds__(1024) void rows_group_ids(int n, const int32_t *__restrict__ same_prev, int32_t *__restrict__ gid,
+                                                       int *__restrict__ ngroups) {
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x;
+    const int R = (n + 1023) / 1024;
+    const int r0 = min(n, tid * R), r1 = min(n, r0 + R);
+    int c = 0;
+    for (int i = r0; i < r1; i++) c += same_prev[i] ? 0 : 1;
+    s_part[tid] = c;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int y = tid >= off ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += y;
+        __syncthreads();
+    }
+    int run = s_part[tid] - c;
+    for (int i = r0; i < r1; i++) { run += same_prev[i] ? 0 : 1; gid[i] = run - 1; }
+    if (tid == 1023) *ngroups = s_part[1023];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -555,7 +619,7 @@ constexpr int KCU = 63;            // usable entries; slot 63 = { COLSENT, floor
 constexpr uint64_t KEYMAX = ~0ull;
 constexpr uint32_t COLSENT = 0xFFFFFFFFu;
 enum { OP_EXIT = 0, OP_REFRESH = 1, OP_AUG = 2 };
-enum { C2_DENSE_REFRESH = C_NCOUNTERS, C2_NCOUNTERS };
+enum { C2_DENSE_REFRESH = C_NCOUNTERS, C2_AUG_SKIPPED, C2_NCOUNTERS };
 
 __device__ __forceinline__ uint32_t f2ord(float h) {
     const uint32_t b = __float_as_uint(h + 0.0f);  // +0.0f: -0 -> +0 so that equal floats get equal keys
@@ -826,11 +890,16 @@ struct Chain2Args {
     int n;
     int64_t ld;
     const float *cost;
-    float *fws;          // float workspace: v[n] | u[n] | sumvd[n]
-    int32_t *iws;        // int workspace: rowsol | colsol | matches | freerows | rtrows | pred   (n each)
+    float *fws;          // float workspace: v[n] | u[n] | sumvd[n] | cassign[n] (= c[colsol[j]][j])
+    int32_t *iws;        // int workspace: rowsol | colsol | matches | freerows | rtrows | pred | colgroup   (n each)
     uint32_t *cache_col; // [n][KC]
     float *cache_val;    // [n][KC]
     char *misc;          // +8: double total; +16: long long counters[]; +4: int status
+    int32_t *rowgid;     // [n] duplicate-row group of every row (consecutive identical rows share an id)
+    float *g_hbest;      // [ngroups] scratch for gmode 2
+    int32_t *g_hstamp;   // [ngroups] scratch for gmode 2 (zeroed)
+    int ngroups;
+    int gmode;           // 0: no duplicate rows; 1: per-group state in LDS; 2: in global memory
 };
 
 // L2-coherent (agent-scope, relaxed) accesses to global state
@@ -895,9 +964,10 @@ __device__ __forceinline__ uint32_t wg_min_u32(uint32_t x, Scratch2 &s, int &par
 // on order-preserving keys), then the column among the few lanes that hold that value.
 template <int CH, bool LDS_STATE>
 __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__restrict__ cost, float *gv, float *sumvd,
-                                             int32_t *rowsol, int32_t *gcolsol, int32_t *pred, float *s_v, uint16_t *s_cs,
-                                             int freerow, uint64_t validm, Scratch2 &s, int &par, long long &c_relax,
-                                             long long &c_hops) {
+                                             float *cassign, int32_t *rowsol, int32_t *gcolsol, int32_t *pred, float *s_v,
+                                             uint16_t *s_cs, int freerow, uint64_t validm, Scratch2 &s, int &par,
+                                             long long &c_relax, long long &c_hops, long long &c_skipped, int gmode,
+                                             const int32_t *rowgid, int32_t *colgroup, float *hb, int32_t *hs, int stamp) {
     constexpr int NC = CH * 4;
     const int tid = threadIdx.x;
     float vm[NC], dreg[NC], cm[CH];
@@ -924,6 +994,8 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
     bool have = false;
     float curmin = 0.0f;
     int endofpath = -1;
+    int pend_g = -1;
+    float pend_h = 0.0f;
     for (;;) {
         // pick: smallest d; among equal d an unassigned column first, then the lowest column
         float lm = cm[0];
@@ -931,6 +1003,13 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
         for (int m = 1; m < CH; m++) lm = fmin_raw(lm, cm[m]);
         const uint32_t omin = wg_min_u32(f2ord(lm), s, par);
         const float dmin = ord2f(omin);
+        if (pend_g >= 0) {   // every wave is past the barrier above, i.e. done reading the group state of the last step
+            if (tid == 0) {
+                if (gmode == 1) { hb[pend_g] = pend_h; hs[pend_g] = stamp; }
+                else { st_f32(hb + pend_g, pend_h); st_i32(hs + pend_g, stamp); }
+            }
+            pend_g = -1;
+        }
         uint32_t lk = 0xFFFFFFFFu;
         if (lm == dmin) {
 #pragma unroll
@@ -950,12 +1029,30 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
         const int jp = (int)(g & 0x7FFFFFFFu);
         if (!have || dmin != curmin) { readym |= scannedm; curmin = dmin; have = true; }
         if (!(g & 0x80000000u)) { endofpath = jp; break; }
+        // three independent loads as soon as the pick is known: owner row (LDS), its cost at jp and its
+        // duplicate-row group (L2)
+        const float cip_raw = ld_f32(cassign + jp);   // c[i][jp]
+        const int g_raw = gmode ? ld_i32(colgroup + jp) : 0;
         const int i = __builtin_amdgcn_readfirstlane(st_csget<LDS_STATE>(s_cs, gcolsol, jp));
-        float4 x[CH];
-        load_row4<CH>(cost, ld, i, n, tid, x);
-        const float cip = cost[(int64_t)i * ld + jp];
+        const float cip = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(cip_raw)));
         const float vjp = st_vget<LDS_STATE>(s_v, gv, jp);
         const float h = (cip - vjp) - curmin;
+        // Exact skip for duplicated rows: if a bitwise identical row was already scanned in THIS search with an
+        // offset hb >= h, every relaxation through row i is a no-op: fl(x - h) >= fl(x - hb) >= d[j] for every
+        // unscanned column (prices do not change during a search and d only decreases).  The column is retired
+        // exactly as usual, only the row read and the compare sweep are elided.
+        bool skip = false;
+        if (gmode) {
+            const int g = __builtin_amdgcn_readfirstlane(g_raw);
+            float hbv; int hsv;
+            if (gmode == 1) { hbv = hb[g]; hsv = hs[g]; }
+            else { hbv = ld_f32(hb + g); hsv = ld_i32(hs + g); }
+            skip = (hsv == stamp) && (h <= hbv);
+            // the new best offset of the group is published after the next barrier (all waves have read by then)
+            if (!skip) { pend_g = g; pend_h = h; }
+        }
+        float4 x[CH];
+        if (!skip) load_row4<CH>(cost, ld, i, n, tid, x);
         {   // retire column jp: remember v+d for the price update, mask the column out
             const int q = jp >> 2;
             const int sj = (q / BLOCK2) * 4 + (jp & 3);   // uniform
@@ -968,6 +1065,14 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
                 vm[sl] = hit ? -INFINITY : vm[sl];
                 dreg[sl] = hit ? INFINITY : dreg[sl];
             }
+        }
+        if (skip) {
+#pragma unroll
+            for (int m = 0; m < CH; m++)
+                cm[m] = fmin_raw(fmin_raw(dreg[m * 4], dreg[m * 4 + 1]), fmin_raw(dreg[m * 4 + 2], dreg[m * 4 + 3]));
+            c_relax++;
+            c_skipped++;
+            continue;
         }
 #pragma unroll
         for (int m = 0; m < CH; m++) {
@@ -1002,6 +1107,8 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
         do {
             i = ld_i32(pred + ep);
             st_csset<LDS_STATE>(s_cs, gcolsol, ep, i);
+            st_f32(cassign + ep, cost[(int64_t)i * ld + ep]);
+            if (gmode) st_i32(colgroup + ep, rowgid[i]);
             const int j1 = ep;
             ep = ld_i32(rowsol + i);
             st_i32(rowsol + i, j1);
@@ -1144,12 +1251,13 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
                 float pf_cv = 0.0f;
                 for (;;) {
                     const int i = cur_i;
-                    float umin, usub, vj1;
+                    float umin, usub, vj1, cj1 = 0.0f, cj2 = 0.0f;
                     int j1, j2 = -1, i0, i02 = -1;
                     if (__builtin_expect(have_dense, 0)) {
                         have_dense = false;
                         umin = key_val(gd.m1); usub = key_val(gd.m2);
                         j1 = (int)(uint32_t)gd.m1; j2 = (int)(uint32_t)gd.m2;
+                        cj1 = a.cost[(int64_t)i * a.ld + j1]; cj2 = a.cost[(int64_t)i * a.ld + j2];
                         vj1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(st_vget<LDS_STATE>(s_v, gv, j1))));
                         i0 = __builtin_amdgcn_readfirstlane(st_csget<LDS_STATE>(s_cs, gcolsol, j1));
                         i02 = __builtin_amdgcn_readfirstlane(st_csget<LDS_STATE>(s_cs, gcolsol, j2));
@@ -1191,6 +1299,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
                         umin = ord2f(o1);
                         j1 = (int)readlane32(col, l1);
                         vj1 = __uint_as_float(readlane32(__float_as_uint(vj), l1));
+                        cj1 = __uint_as_float(readlane32(__float_as_uint(cv), l1));
                         i0 = (int)readlane32((uint32_t)csj, l1);
                         if (__builtin_expect(!((vj1 - (usub - umin)) < vj1) && i0 >= 0, 0)) {
                             const uint64_t m2 = __ballot(ord == o2 && lane != l1);
@@ -1200,6 +1309,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
                                 l2 = __builtin_ctzll(__ballot(col == cmin2));
                             }
                             j2 = (int)readlane32(col, l2);
+                            cj2 = __uint_as_float(readlane32(__float_as_uint(cv), l2));
                             i02 = (int)readlane32((uint32_t)csj, l2);
                         }
                     }
@@ -1209,6 +1319,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
                     const bool swap = !lowers && i0 >= 0;
                     const int jj = swap ? j2 : j1;
                     const int i0f = swap ? i02 : i0;
+                    (void)cj1; (void)cj2;
                     // rowsol is not read during ARR and equals the inverse of colsol: it is rebuilt after the chain
                     if (lane == 0) {
                         if (lowers) st_vset<LDS_STATE>(s_v, gv, j1, vnew);
@@ -1236,11 +1347,17 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
     }
 
     // ---- write back prices and colsol for the augmentation kernel; rowsol = inverse of colsol ----
+    float *cassign = a.fws + 3 * (int64_t)n;
+    int32_t *colgroup = a.iws + 6 * (int64_t)n;
     __syncthreads();
     for (int c = tid; c < n; c += BLOCK2) {
         const int32_t r = st_csget<LDS_STATE>(s_cs, gcolsol, c);
         if constexpr (LDS_STATE) { gv[c] = s_v[c]; gcolsol[c] = r; }
-        if (r >= 0) rowsol[r] = c;
+        if (r >= 0) {
+            rowsol[r] = c;
+            cassign[c] = cost[(int64_t)r * ld + c];                 // c[colsol[j]][j] for the augmentation kernel
+            colgroup[c] = a.gmode ? a.rowgid[r] : 0;               // duplicate-row group of the row that owns column c
+        }
     }
     if (tid == 0) {
         long long *counters = reinterpret_cast<long long *>(a.misc + 16);
@@ -1279,14 +1396,24 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug2(Chain2Args a) {
             s_cs[c] = cs < 0 ? (uint16_t)0xFFFFu : (uint16_t)cs;
         }
     }
+    // per-group best offset of the current search (duplicate-row skip): LDS if it fits (gmode 1)
+    float *hb = a.g_hbest;
+    int32_t *hs = a.g_hstamp;
+    const int gmode = a.gmode;
+    if (gmode == 1) {
+        hb = reinterpret_cast<float *>(dyn_lds + (size_t)npad * 6);
+        hs = reinterpret_cast<int32_t *>(dyn_lds + (size_t)npad * 6 + (size_t)a.ngroups * 4);
+        for (int g = tid; g < a.ngroups; g += BLOCK2) hs[g] = 0;
+    }
+    float *cassign = a.fws + 3 * (int64_t)n;
     __syncthreads();
     const int numfree = *reinterpret_cast<const int *>(a.misc + 128);
-    long long c_relax = 0, c_hops = 0, c_augs = 0;
+    long long c_relax = 0, c_hops = 0, c_augs = 0, c_skipped = 0;
     int err = 0;
     for (int f = 0; f < numfree && !err; f++) {
         const int freerow = __builtin_amdgcn_readfirstlane(ld_i32(freerows + f));
-        err = chain_augment<CH, LDS_STATE>(n, ld, cost, gv, sumvd, rowsol, gcolsol, pred, s_v, s_cs, freerow, validm, s, par,
-                                           c_relax, c_hops);
+        err = chain_augment<CH, LDS_STATE>(n, ld, cost, gv, sumvd, cassign, rowsol, gcolsol, pred, s_v, s_cs, freerow, validm, s,
+                                           par, c_relax, c_hops, c_skipped, gmode, a.rowgid, a.iws + 6 * (int64_t)n, hb, hs, f + 1);
         c_augs++;
     }
     // ---- write back prices and colsol, then duals u and the total ----
@@ -1317,7 +1444,8 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug2(Chain2Args a) {
         *reinterpret_cast<double *>(a.misc + 8) = t;
         long long *counters = reinterpret_cast<long long *>(a.misc + 16);
         counters[C_AUG_INIT] = c_augs; counters[C_AUG_RELAX] = c_relax; counters[C_AUGS] = c_augs; counters[C_HOPS] = c_hops;
-        counters[C_ROWS_READ] = counters[C2_DENSE_REFRESH] + c_augs + c_relax;
+        counters[C_ROWS_READ] = counters[C2_DENSE_REFRESH] + c_augs + c_relax - c_skipped;
+        counters[C2_AUG_SKIPPED] = c_skipped;
         *reinterpret_cast<int *>(a.misc + 4) = err;
     }
 }
@@ -1330,6 +1458,7 @@ template <int CH, bool LDS_STATE>
 static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_cache_done, hipEvent_t ev_arr_done, hipStream_t stream) {
     const int npad = (args.n + 3) & ~3;
     const size_t shmem = LDS_STATE ? (((size_t)npad * 6 + 15) / 16) * 16 : 16;
+    const size_t shmem_aug = (((LDS_STATE ? (size_t)npad * 6 : 0) + (args.gmode == 1 ? (size_t)args.ngroups * 8 : 0) + 15) / 16) * 16 + 16;
     auto kern = jv_chain2<CH, LDS_STATE>;
     CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL((build_row_caches<CH>), dim3(cache_grid), dim3(BLOCK2), 0, stream, args.n, args.ld, args.cost,
@@ -1340,8 +1469,8 @@ static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_c
     CYTO_HIP(hipGetLastError());
     CYTO_HIP(hipEventRecord(ev_arr_done, stream));
     auto kaug = jv_aug2<CH, LDS_STATE>;
-    CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kaug), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(kaug, dim3(1), dim3(BLOCK2), shmem, stream, args);
+    CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kaug), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_aug));
+    hipLaunchKernelGGL(kaug, dim3(1), dim3(BLOCK2), shmem_aug, stream, args);
     CYTO_HIP(hipGetLastError());
     return CYTO_OK;
 }
@@ -1389,7 +1518,7 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
 
     DevBuf b_fws, b_iws, b_imin, b_pmin, b_parg, b_misc;
     const size_t nT = (size_t)n * sizeof(T), nI = (size_t)n * sizeof(int32_t);
-    if ((rc = b_fws.alloc(3 * nT)) || (rc = b_iws.alloc(6 * nI)) || (rc = b_imin.alloc(nI)) ||
+    if ((rc = b_fws.alloc(4 * nT)) || (rc = b_iws.alloc(7 * nI)) || (rc = b_imin.alloc(nI)) ||
         (rc = b_pmin.alloc((size_t)rowblocks * nT)) || (rc = b_parg.alloc((size_t)rowblocks * nI)) || (rc = b_misc.alloc(256)))
         return rc;
     // float workspace: v | u ; int workspace: rowsol | colsol | matches | freerows | rtrows | pred
@@ -1420,9 +1549,19 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
                        d_rowsol, d_colsol);
     CYTO_HIP(hipEventRecord(e1, stream));
 
+    // duplicate-row groups (float32 fast path only): runs of bitwise identical consecutive rows
+    DevBuf b_same, b_gid;
+    int *d_ngroups = b_misc.as<int>() + 36;   // misc + 144
+    const bool want_groups = std::is_same<T, float>::value && n <= 16 * 4 * 512 && n >= 2;
+    if (want_groups) {
+        if ((rc = b_same.alloc(nI)) || (rc = b_gid.alloc(nI))) { cleanup(); return rc; }
+        hipLaunchKernelGGL(rows_same_as_prev<T>, dim3(min(n, 2048)), dim3(256), 0, stream, n, dld, dcost, b_same.as<int32_t>());
+        hipLaunchKernelGGL(rows_group_ids, dim3(1), dim3(1024), 0, stream, n, b_same.as<int32_t>(), b_gid.as<int32_t>(), d_ngroups);
+    }
     // a non-finite cost makes every later comparison meaningless: stop before the chain
-    int h_nonfinite = 0;
+    int h_nonfinite = 0, h_ngroups = n;
     CYTO_HIP(hipMemcpyAsync(&h_nonfinite, d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (want_groups) CYTO_HIP(hipMemcpyAsync(&h_ngroups, d_ngroups, sizeof(int), hipMemcpyDeviceToHost, stream));
     CYTO_HIP(hipStreamSynchronize(stream));
     if (h_nonfinite) { cleanup(); return CYTO_ERR_NONFINITE; }
 
@@ -1438,7 +1577,7 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
     CYTO_HIP(hipEventCreate(&e1d));
     CYTO_HIP(hipEventRecord(e1b, stream));
     const int64_t per = (int64_t)VW * BLOCK;
-    DevBuf b_ccol, b_cval;
+    DevBuf b_ccol, b_cval, b_ghb, b_ghs;
     bool fast = false;
     if constexpr (std::is_same<T, float>::value) {
         // float32 fast path (n <= 32768): per-row top-K caches + single-wave cached chain steps
@@ -1452,6 +1591,18 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
             Chain2Args c2;
             c2.n = n; c2.ld = dld; c2.cost = dcost; c2.fws = d_v; c2.iws = d_rowsol;
             c2.cache_col = b_ccol.as<uint32_t>(); c2.cache_val = b_cval.as<float>(); c2.misc = b_misc.as<char>();
+            // duplicate-row skip: per-group state in LDS when it fits beside v (4 B) and colsol (2 B) per column
+            c2.rowgid = b_gid.as<int32_t>(); c2.ngroups = h_ngroups; c2.gmode = 0; c2.g_hbest = nullptr; c2.g_hstamp = nullptr;
+            if (want_groups && h_ngroups < n) {
+                const size_t lds_state = (n <= 13 * 4 * BLOCK2) ? (size_t)((n + 3) & ~3) * 6 : 0;
+                if (lds_state + (size_t)h_ngroups * 8 + 4096 <= 160 * 1024) c2.gmode = 1;
+                else {
+                    c2.gmode = 2;
+                    if ((rc = b_ghb.alloc((size_t)h_ngroups * 4)) || (rc = b_ghs.alloc((size_t)h_ngroups * 4))) { cleanup(); return rc; }
+                    CYTO_HIP(hipMemsetAsync(b_ghs.p, 0, (size_t)h_ngroups * 4, stream));
+                    c2.g_hbest = b_ghb.as<float>(); c2.g_hstamp = b_ghs.as<int32_t>();
+                }
+            }
             const int cache_grid = max(1, min(n, 1024));
             const int per2 = 4 * BLOCK2;
             if (n <= 2 * per2) rc = launch_chain2<2, true>(c2, cache_grid, e1c, e1d, stream);
@@ -1501,6 +1652,8 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
         info->free_after_arr2 = h_counters[C_FREE_A2];
         info->hbm_row_reads = n + (fast ? n : 0) + h_counters[C_ROWS_READ];
         info->dense_refreshes = fast ? h_counters[C2_DENSE_REFRESH] : 0;
+        info->aug_scans_skipped = fast ? h_counters[C2_AUG_SKIPPED] : 0;
+        info->row_groups = h_ngroups;
     }
     cleanup();
     (void)hipEventDestroy(e1b);

@@ -70,7 +70,9 @@ typedef struct {
     int64_t dense_refreshes; /* RT/ARR steps whose row cache was exhausted (full re-scan) */
     double ms_arr;           /* float32 path: the RT+ARR kernel (jv_chain2) alone */
     double ms_aug;           /* float32 path: the augmentation kernel (jv_aug2) alone */
-    int64_t reserved[4];
+    int64_t aug_scans_skipped; /* augmentation scans elided as provable no-ops (duplicate rows) */
+    int64_t row_groups;      /* number of runs of bitwise identical consecutive rows (== n: none) */
+    int64_t reserved[2];
 } cyto_lap_info;
 
 int cyto_lap_f32(int n, const float *cost, int64_t ld, int cost_on_device,

@@ -147,3 +147,19 @@ def test_rccl_broadcast_single_rank():
     assert np.array_equal(buf.to_numpy(x.shape, np.float32), x)
     _lib.check(L.cyto_comm_destroy(comm))
     buf.free()
+
+
+@pytest.mark.parametrize("n,slots", [(3000, 5), (6000, 10)])
+def test_duplicate_rows_skip_is_exact_and_deterministic(n, slots):
+    # Visium-like: runs of identical rows trigger the exact no-op-scan elision in the augmentation;
+    # results, duals and the algorithmic scan counters must still equal the oracle's, run after run
+    rng = np.random.default_rng(n)
+    base = -(rng.random((n // slots, n)) ** 3).astype(np.float32)
+    c = np.repeat(base, slots, axis=0)
+    o = jv_oracle(c, np.float32)
+    for _ in range(3):
+        g = lap_solve(c, np.float32, return_info=True)
+        assert np.array_equal(g["rowsol"], o["rowsol"]) and np.array_equal(g["colsol"], o["colsol"])
+        assert np.array_equal(g["u"], o["u"]) and np.array_equal(g["v"], o["v"])
+        assert g["info"].scans_aug_relax == o["stats"].scans_aug_relax
+        assert g["info"].row_groups == n // slots and g["info"].aug_scans_skipped > 0
