@@ -5,8 +5,8 @@
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one full solve of BASELINE.json's configs[1]: a 20000 x 20000 dense synthetic float32 cost
-matrix already resident in HBM -> assignment (column reduction, row-cache build, the RT/ARR/augmentation
-chain).  With N GPUs every rank solves its own, differently seeded, instance of the same size (the
+matrix already resident in HBM -> assignment (column reduction, row-cache build, the RT/ARR chain kernel,
+the augmentation kernel).  With N GPUs every rank solves its own, differently seeded, instance of the same size (the
 reference shards independent sub-LAPs across workers: cytospace.py:430-451; no data-path collective),
 so scaling is "weak" and value = N * n / max-over-ranks time.
 
@@ -90,10 +90,11 @@ def main():
         res = lap_solve(None, np.float32, device_id=dev, return_info=True, device_ptr=buf.ptr, n=n, ld=n)
     barrier()
     t0 = time.perf_counter()
-    chain_ms, total_ms = [], []
+    arr_ms_l, aug_ms_l, total_ms = [], [], []
     for _ in range(args.steps):
         res = lap_solve(None, np.float32, device_id=dev, return_info=True, device_ptr=buf.ptr, n=n, ld=n)
-        chain_ms.append(res["info"].ms_chain)
+        arr_ms_l.append(res["info"].ms_arr)
+        aug_ms_l.append(res["info"].ms_aug)
         total_ms.append(res["info"].ms_total)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -122,21 +123,38 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * n * args.steps / elapsed
 
-    # roofline of the dominant kernel (jv_chain2: RT + ARR + augmentation), per launch, HIP events on
-    # the launch stream (cyto_lap_info.ms_chain).  Algorithmic bytes = 4 * n * row scans.
-    chain_scans = info.scans_redtransfer + info.scans_arr + info.scans_aug_init + info.scans_aug_relax
-    chain_bytes = 4.0 * n * chain_scans
-    chain_avg_ms = float(np.mean(chain_ms))
-    achieved = chain_bytes / (chain_avg_ms * 1e-3) / 1e9
+    # roofline of the dominant kernel, per launch, timed with HIP events on the launch stream
+    # (cyto_lap_info.ms_arr / ms_aug).  jv_chain2 = reduction transfer + augmenting row reduction (the
+    # longest kernel), jv_aug2 = augmentation.  Algorithmic bytes = 4 * n * row scans.
+    arr_scans = info.scans_redtransfer + info.scans_arr
+    aug_scans = info.scans_aug_init + info.scans_aug_relax
+    arr_ms = float(np.mean(arr_ms_l))
+    aug_ms = float(np.mean(aug_ms_l))
+    dom = ("jv_chain2", arr_scans, arr_ms) if arr_ms >= aug_ms else ("jv_aug2", aug_scans, aug_ms)
+    dom_bytes = 4.0 * n * dom[1]
+    achieved = dom_bytes / (dom[2] * 1e-3) / 1e9
+    traffic = None
+    try:   # HBM bytes from the separate rocprofv3 --pmc pass committed under profiles/ (same n, same instance)
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_n20000.json")))
+        if pm.get("n") == n:
+            key = [k for k in pm["kernels"] if k.startswith(dom[0] + "<")]
+            if key:
+                traffic = pm["kernels"][key[0]]["hbm_read_bytes"] + pm["kernels"][key[0]]["hbm_write_bytes_uncalibrated"]
+    except (OSError, ValueError, KeyError):
+        traffic = None
+    total_avg_ms = float(np.mean(total_ms))
     roofline = {
-        "bound": "hbm", "kernel": "jv_chain2", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-        "algorithmic_bytes_per_launch": chain_bytes, "row_scans_per_launch": int(chain_scans),
-        "kernel_ms_avg": round(chain_avg_ms, 3),
-        "whole_solve": {"row_scans": int(info.row_scans), "bytes": 4.0 * n * info.row_scans,
-                        "kernel_ms_avg": round(float(np.mean(total_ms)), 3),
-                        "achieved_GBs": round(4.0 * n * info.row_scans / (float(np.mean(total_ms)) * 1e-3) / 1e9, 2),
-                        "floor_4n2_frac": round(4.0 * n * n / (float(np.mean(total_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
+        "bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "algorithmic_bytes_per_launch": dom_bytes, "row_scans_per_launch": int(dom[1]), "kernel_ms_avg": round(dom[2], 3),
+        "other_kernels": {
+            "jv_chain2": {"ms": round(arr_ms, 3), "row_scans": int(arr_scans), "algorithmic_GBs": round(4.0 * n * arr_scans / (arr_ms * 1e-3) / 1e9, 2)},
+            "jv_aug2": {"ms": round(aug_ms, 3), "row_scans": int(aug_scans), "algorithmic_GBs": round(4.0 * n * aug_scans / max(aug_ms, 1e-9) / 1e-3 / 1e9, 2)},
+            "colred(3 kernels)": {"ms": round(float(info.ms_colred), 3), "GBs": round(4.0 * n * n / (info.ms_colred * 1e-3) / 1e9, 1)},
+            "build_row_caches": {"ms": round(float(info.ms_cache), 3), "GBs": round(4.0 * n * n / (info.ms_cache * 1e-3) / 1e9, 1)}},
+        "whole_solve": {"row_scans": int(info.row_scans), "bytes": 4.0 * n * info.row_scans, "kernel_ms_avg": round(total_avg_ms, 3),
+                        "achieved_GBs": round(4.0 * n * info.row_scans / (total_avg_ms * 1e-3) / 1e9, 2),
+                        "floor_4n2_frac": round(4.0 * n * n / (total_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
         "hbm_rows_actually_read": int(info.hbm_row_reads),
     }
 
