@@ -696,6 +696,13 @@ __device__ __forceinline__ uint64_t min64_wave_allreduce(uint64_t x) {
     return r;
 }
 
+// Barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its outstanding global
+// stores/loads (a plain __syncthreads() carries s_waitcnt vmcnt(0): in the augmentation that made every
+// step wait for the owner lane's global store to be acknowledged by HBM).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 struct Scratch2 {
     uint64_t m1[2][NW2], m2[2][NW2];
     int cnt[2][NW2];
@@ -900,6 +907,7 @@ struct Chain2Args {
     int32_t *g_hstamp;   // [ngroups] scratch for gmode 2 (zeroed)
     int ngroups;
     int gmode;           // 0: no duplicate rows; 1: per-group state in LDS; 2: in global memory
+    int auxlds;          // augmentation: cassign (f32) + colgroup (u16) per column also in LDS
 };
 
 // L2-coherent (agent-scope, relaxed) accesses to global state
@@ -948,7 +956,7 @@ __device__ __forceinline__ uint32_t wg_min_u32(uint32_t x, Scratch2 &s, int &par
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t *buf = reinterpret_cast<uint32_t *>(&s.cnt[par][0]);
     if (lane == 0) buf[w] = w0;
-    __syncthreads();
+    lds_barrier();
     uint32_t r = buf[lane & (NW2 - 1)];
     r = row_min_u32(r);
     par ^= 1;
@@ -967,7 +975,8 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
                                              float *cassign, int32_t *rowsol, int32_t *gcolsol, int32_t *pred, float *s_v,
                                              uint16_t *s_cs, int freerow, uint64_t validm, Scratch2 &s, int &par,
                                              long long &c_relax, long long &c_hops, long long &c_skipped, int gmode,
-                                             const int32_t *rowgid, int32_t *colgroup, float *hb, int32_t *hs, int stamp) {
+                                             const int32_t *rowgid, int32_t *colgroup, float *hb, int32_t *hs, int stamp, float *s_ca,
+                                             uint16_t *s_cg) {
     constexpr int NC = CH * 4;
     const int tid = threadIdx.x;
     float vm[NC], dreg[NC], cm[CH];
@@ -1031,8 +1040,8 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
         if (!(g & 0x80000000u)) { endofpath = jp; break; }
         // three independent loads as soon as the pick is known: owner row (LDS), its cost at jp and its
         // duplicate-row group (L2)
-        const float cip_raw = ld_f32(cassign + jp);   // c[i][jp]
-        const int g_raw = gmode ? ld_i32(colgroup + jp) : 0;
+        const float cip_raw = s_ca ? s_ca[jp] : ld_f32(cassign + jp);   // c[i][jp]
+        const int g_raw = gmode ? (s_cg ? (int)s_cg[jp] : ld_i32(colgroup + jp)) : 0;
         const int i = __builtin_amdgcn_readfirstlane(st_csget<LDS_STATE>(s_cs, gcolsol, jp));
         const float cip = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(cip_raw)));
         const float vjp = st_vget<LDS_STATE>(s_v, gv, jp);
@@ -1107,8 +1116,9 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
         do {
             i = ld_i32(pred + ep);
             st_csset<LDS_STATE>(s_cs, gcolsol, ep, i);
-            st_f32(cassign + ep, cost[(int64_t)i * ld + ep]);
-            if (gmode) st_i32(colgroup + ep, rowgid[i]);
+            const float cie = cost[(int64_t)i * ld + ep];
+            if (s_ca) s_ca[ep] = cie; else st_f32(cassign + ep, cie);
+            if (gmode) { const int gi = rowgid[i]; if (s_cg) s_cg[ep] = (uint16_t)gi; else st_i32(colgroup + ep, gi); }
             const int j1 = ep;
             ep = ld_i32(rowsol + i);
             st_i32(rowsol + i, j1);
@@ -1406,6 +1416,16 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug2(Chain2Args a) {
         for (int g = tid; g < a.ngroups; g += BLOCK2) hs[g] = 0;
     }
     float *cassign = a.fws + 3 * (int64_t)n;
+    // per-column auxiliaries (assigned cost, owner's row group) in LDS when they fit (a.auxlds)
+    float *s_ca = nullptr;
+    uint16_t *s_cg = nullptr;
+    if (a.auxlds) {
+        const size_t off = (size_t)npad * 6 + (gmode == 1 ? (size_t)a.ngroups * 8 : 0);
+        s_ca = reinterpret_cast<float *>(dyn_lds + ((off + 15) & ~(size_t)15));
+        s_cg = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(s_ca) + (size_t)npad * 4);
+        const int32_t *colgroup = a.iws + 6 * (int64_t)n;
+        for (int c = tid; c < n; c += BLOCK2) { s_ca[c] = cassign[c]; s_cg[c] = (uint16_t)(gmode ? colgroup[c] : 0); }
+    }
     __syncthreads();
     const int numfree = *reinterpret_cast<const int *>(a.misc + 128);
     long long c_relax = 0, c_hops = 0, c_augs = 0, c_skipped = 0;
@@ -1413,7 +1433,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug2(Chain2Args a) {
     for (int f = 0; f < numfree && !err; f++) {
         const int freerow = __builtin_amdgcn_readfirstlane(ld_i32(freerows + f));
         err = chain_augment<CH, LDS_STATE>(n, ld, cost, gv, sumvd, cassign, rowsol, gcolsol, pred, s_v, s_cs, freerow, validm, s,
-                                           par, c_relax, c_hops, c_skipped, gmode, a.rowgid, a.iws + 6 * (int64_t)n, hb, hs, f + 1);
+                                           par, c_relax, c_hops, c_skipped, gmode, a.rowgid, a.iws + 6 * (int64_t)n, hb, hs, f + 1, s_ca, s_cg);
         c_augs++;
     }
     // ---- write back prices and colsol, then duals u and the total ----
@@ -1458,7 +1478,10 @@ template <int CH, bool LDS_STATE>
 static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_cache_done, hipEvent_t ev_arr_done, hipStream_t stream) {
     const int npad = (args.n + 3) & ~3;
     const size_t shmem = LDS_STATE ? (((size_t)npad * 6 + 15) / 16) * 16 : 16;
-    const size_t shmem_aug = (((LDS_STATE ? (size_t)npad * 6 : 0) + (args.gmode == 1 ? (size_t)args.ngroups * 8 : 0) + 15) / 16) * 16 + 16;
+    const size_t base_aug = (((LDS_STATE ? (size_t)npad * 6 : 0) + (args.gmode == 1 ? (size_t)args.ngroups * 8 : 0) + 15) / 16) * 16;
+    Chain2Args aug_args = args;
+    aug_args.auxlds = (LDS_STATE && args.ngroups < 65536 && base_aug + (size_t)npad * 6 + 4096 <= 160 * 1024) ? 1 : 0;
+    const size_t shmem_aug = base_aug + (aug_args.auxlds ? (size_t)npad * 6 : 0) + 32;
     auto kern = jv_chain2<CH, LDS_STATE>;
     CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL((build_row_caches<CH>), dim3(cache_grid), dim3(BLOCK2), 0, stream, args.n, args.ld, args.cost,
@@ -1470,7 +1493,7 @@ static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_c
     CYTO_HIP(hipEventRecord(ev_arr_done, stream));
     auto kaug = jv_aug2<CH, LDS_STATE>;
     CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kaug), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_aug));
-    hipLaunchKernelGGL(kaug, dim3(1), dim3(BLOCK2), shmem_aug, stream, args);
+    hipLaunchKernelGGL(kaug, dim3(1), dim3(BLOCK2), shmem_aug, stream, aug_args);
     CYTO_HIP(hipGetLastError());
     return CYTO_OK;
 }
@@ -1593,6 +1616,7 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
             c2.cache_col = b_ccol.as<uint32_t>(); c2.cache_val = b_cval.as<float>(); c2.misc = b_misc.as<char>();
             // duplicate-row skip: per-group state in LDS when it fits beside v (4 B) and colsol (2 B) per column
             c2.rowgid = b_gid.as<int32_t>(); c2.ngroups = h_ngroups; c2.gmode = 0; c2.g_hbest = nullptr; c2.g_hstamp = nullptr;
+            c2.auxlds = 0;
             if (want_groups && h_ngroups < n) {
                 const size_t lds_state = (n <= 13 * 4 * BLOCK2) ? (size_t)((n + 3) & ~3) * 6 : 0;
                 if (lds_state + (size_t)h_ngroups * 8 + 4096 <= 160 * 1024) c2.gmode = 1;
