@@ -164,49 +164,55 @@ __global__ __launch_bounds__(256) void pearson_gemm(int Gpad, int S, int C, cons
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
 
-    // staging: 4 float4 per thread per operand per k-tile
+    // staging: 4 float4 per thread per operand per k-tile, register-staged double buffering:
+    // the global loads of tile t+1 are issued before the MFMAs of tile t and written to the other LDS
+    // buffer afterwards; inside a tile the A/B fragments of step kk+2 are read from LDS before the four
+    // MFMAs of step kk are issued (explicit register ping-pong), so LDS latency hides under the matrix pipe.
     float4 ra[4], rb[4];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int idx = tid + t * 256;
-            const int k = idx >> 5, c4 = idx & 31;
-            ra[t] = *reinterpret_cast<const float4 *>(A + (int64_t)(k0 + k) * lda + m0 + c4 * 4);
-            rb[t] = *reinterpret_cast<const float4 *>(B + (int64_t)(k0 + k) * ldb + n0 + c4 * 4);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int idx = tid + t * 256;
-            const int k = idx >> 5, c4 = idx & 31;
-            *reinterpret_cast<float4 *>(&As[buf][k][c4 * 4]) = ra[t];
-            *reinterpret_cast<float4 *>(&Bs[buf][k][c4 * 4]) = rb[t];
-        }
-    };
-
+    const int st_k = tid >> 5, st_c = (tid & 31) * 4;   // this thread's row / column inside a staging pass
+    const float *gA = A + (int64_t)st_k * lda + m0 + st_c;
+    const float *gB = B + (int64_t)st_k * ldb + n0 + st_c;
+#define GLOAD(k0)                                                                                   \
+    _Pragma("unroll") for (int t = 0; t < 4; t++) {                                                 \
+        ra[t] = *reinterpret_cast<const float4 *>(gA + (int64_t)((k0) + t * 8) * lda);              \
+        rb[t] = *reinterpret_cast<const float4 *>(gB + (int64_t)((k0) + t * 8) * ldb);              \
+    }
+#define LSTORE(buf)                                                                                 \
+    _Pragma("unroll") for (int t = 0; t < 4; t++) {                                                 \
+        *reinterpret_cast<float4 *>(&As[buf][st_k + t * 8][st_c]) = ra[t];                          \
+        *reinterpret_cast<float4 *>(&Bs[buf][st_k + t * 8][st_c]) = rb[t];                          \
+    }
     const int nk = Gpad / BK;
-    gload(0);
-    lstore(0);
+    GLOAD(0)
+    LSTORE(0)
     __syncthreads();
     const int li = lane & 31, lk = lane >> 5;
+    const int ao = wm * 64 + li, bo = wn * 64 + li;
     for (int kt = 0; kt < nk; kt++) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK);
+        if (kt + 1 < nk) { GLOAD((kt + 1) * BK) }
+        float a0 = As[buf][lk][ao], a1 = As[buf][lk][ao + 32];
+        float b0 = Bs[buf][lk][bo], b1 = Bs[buf][lk][bo + 32];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float a0 = As[buf][kk + lk][wm * 64 + li];
-            const float a1 = As[buf][kk + lk][wm * 64 + 32 + li];
-            const float b0 = Bs[buf][kk + lk][wn * 64 + li];
-            const float b1 = Bs[buf][kk + lk][wn * 64 + 32 + li];
+            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+            if (kk + 2 < BK) {
+                na0 = As[buf][kk + 2 + lk][ao]; na1 = As[buf][kk + 2 + lk][ao + 32];
+                nb0 = Bs[buf][kk + 2 + lk][bo]; nb1 = Bs[buf][kk + 2 + lk][bo + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the reads of step kk+2 ahead of the MFMAs of step kk
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
+        if (kt + 1 < nk) { LSTORE(buf ^ 1) }
         __syncthreads();
     }
+#undef GLOAD
+#undef LSTORE
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
