@@ -21,6 +21,8 @@
 #include "cyto_common.h"
 #include <math.h>
 #include <type_traits>
+#include <stdlib.h>
+#include <string.h>
 
 namespace cyto {
 
@@ -893,6 +895,92 @@ __global__ __launch_bounds__(BLOCK2) void build_row_caches(int n, int64_t ld, co
         (void)refresh_row<CH>(i, n, ld, cost, vreg, validm, cache_col, cache_val, delta, s, par);
 }
 
+// Streaming variant of refresh_row for large n: no per-lane arrays.  The row and the prices come through
+// bounds-checked buffer descriptors (num_records = 4n, so the ragged tail needs no branches beyond the
+// per-column validity compare) and the row is swept several times -- the first sweep from HBM, the rest
+// from L2: top-2 keys, threshold search (count sweeps), per-lane counts, compaction.  Same cache contract
+// as refresh_row.  VAUX = cache policy of the price loads: 0x10 (sc1, agent scope) inside the chain where
+// wave 0 updates prices with agent-scope stores, 0 for the read-only build pass.
+#define STREAM_SWEEP(BODY)                                                                               \
+    for (int q = tid; q < nquad; q += BLOCK2) {                                                          \
+        const u32x4_t xr_ = __builtin_amdgcn_raw_buffer_load_b128(rrow, q * 16, 0, 0);                   \
+        const u32x4_t vr_ = __builtin_amdgcn_raw_buffer_load_b128(rv, q * 16, 0, VAUX);                  \
+        const uint32_t c0_ = (uint32_t)q * 4;                                                            \
+        { const float raw = __uint_as_float(xr_.x); const float h = raw - __uint_as_float(vr_.x); const uint32_t c = c0_;     if (c < (uint32_t)n) { BODY } } \
+        { const float raw = __uint_as_float(xr_.y); const float h = raw - __uint_as_float(vr_.y); const uint32_t c = c0_ + 1; if (c < (uint32_t)n) { BODY } } \
+        { const float raw = __uint_as_float(xr_.z); const float h = raw - __uint_as_float(vr_.z); const uint32_t c = c0_ + 2; if (c < (uint32_t)n) { BODY } } \
+        { const float raw = __uint_as_float(xr_.w); const float h = raw - __uint_as_float(vr_.w); const uint32_t c = c0_ + 3; if (c < (uint32_t)n) { BODY } } \
+    }
+template <int VAUX>
+__device__ __forceinline__ K2 refresh_row_stream(int i, int n, int64_t ld, const float *__restrict__ cost, const float *gv,
+                                                 uint32_t *__restrict__ cache_col, float *__restrict__ cache_val, float &delta,
+                                                 Scratch2 &s, int &par) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nquad = (n + 3) >> 2;
+    const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(cost + (int64_t)i * ld), 0, n * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gv), 0, n * 4, 0x00020000);
+    K2 loc; loc.m1 = KEYMAX; loc.m2 = KEYMAX;
+    STREAM_SWEEP((void)raw; k2_push(loc, mkkey(h, c));)
+    const K2 g = wg_k2(loc, s, par);
+    const float umin = key_val(g.m1);
+
+    float lo = 0.0f, hi = INFINITY, tau = INFINITY;
+    int cnt = 0;
+    bool okc = false;
+    if (!(delta > 0.0f) || !(delta < 1e30f)) delta = 1e-3f;
+    for (int it = 0; it < 24 && !okc; it++) {
+        tau = umin + delta;
+        uint32_t tc = 0;
+        STREAM_SWEEP((void)raw; tc += (h < tau) ? 1u : 0u;)
+        cnt = wg_sum_waves((int)wave_sum_u32(tc), s, par, nullptr);
+        if (cnt > KCU) {
+            hi = delta;
+            const float mid = (lo > 0.0f) ? 0.5f * (lo + hi) : 0.5f * delta;
+            if (!(mid < hi) || !(mid > lo)) break;
+            delta = mid;
+        } else if (cnt < KCU / 2 && cnt < n && delta < 1e30f) {
+            lo = delta;
+            const float mid = (hi < INFINITY) ? 0.5f * (lo + hi) : 2.0f * delta;
+            if (hi < INFINITY && (!(mid < hi) || !(mid > lo))) { okc = true; break; }
+            delta = mid;
+        } else {
+            okc = true;
+        }
+    }
+    if (!okc || cnt > KCU) {
+        if (lo > 0.0f) { delta = lo; tau = umin + lo; } else { tau = -INFINITY; }
+    }
+    uint32_t tc = 0;
+    STREAM_SWEEP((void)raw; tc += (h < tau) ? 1u : 0u;)
+    int base = 0;
+    cnt = wg_sum_waves((int)wave_sum_u32(tc), s, par, &base);
+    if (cnt > KCU) { tau = -INFINITY; cnt = 0; tc = 0; }
+    uint32_t *ccol = cache_col + (int64_t)i * KC;
+    float *cval = cache_val + (int64_t)i * KC;
+    uint32_t inc = tc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(inc, off); if (lane >= off) inc += y; }
+    int pos = base + (int)(inc - tc);
+    if (tc != 0) {
+        STREAM_SWEEP(if (h < tau) { ccol[pos] = c; cval[pos] = raw; pos++; })
+    }
+    if (tid >= cnt && tid < KCU) { ccol[tid] = COLSENT; cval[tid] = 0.0f; }
+    if (tid == KCU) { ccol[KCU] = COLSENT; cval[KCU] = tau; }
+    __syncthreads();
+    return g;
+}
+
+__global__ __launch_bounds__(BLOCK2) void build_row_caches_stream(int n, int64_t ld, const float *__restrict__ cost,
+                                                                 const float *v, uint32_t *__restrict__ cache_col,
+                                                                 float *__restrict__ cache_val) {
+    __shared__ Scratch2 s;
+    int par = 0;
+    float delta = 0.0f;
+    for (int i = blockIdx.x; i < n; i += gridDim.x)
+        (void)refresh_row_stream<0>(i, n, ld, cost, v, cache_col, cache_val, delta, s, par);
+}
+
 struct Chain2Args {
     int n;
     int64_t ld;
@@ -1185,7 +1273,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
     int c_free_cr = numfree, c_free_a1 = 0, c_free_a2 = 0;
     int err = 0;
 
-    const int arr_budget = 1000 * n + 1000000;   // == JV_ARR_BUDGET(n) of the oracle (n <= 32768 here)
+    const int arr_budget = 1000 * n + 1000000;   // == JV_ARR_BUDGET(n) of the oracle (fits: n <= FAST_NMAX)
     // chain state (meaningful in wave 0 only; uniform there)
     int phase = (n > 1) ? PH_RT : PH_ARR;
     int k = 0, sweep = 0, prev = numfree, carry = -1, cur_i = -1;
@@ -1348,8 +1436,11 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
         __syncthreads();
         const int op = s.cmd_op, row = s.cmd_row;
         if (op == OP_EXIT) break;
-        {
-            float vreg[NC];
+        if constexpr (CH == 0) {
+            gd = refresh_row_stream<0x10>(row, n, ld, cost, gv, a.cache_col, a.cache_val, delta, s, par);
+            have_dense = true;
+        } else {
+            float vreg[NC > 0 ? NC : 1];
             load_vreg<CH, LDS_STATE>(s_v, gv, n, tid, vreg);
             gd = refresh_row<CH>(row, n, ld, cost, vreg, validm, a.cache_col, a.cache_val, delta, s, par);
             have_dense = true;
@@ -1472,6 +1563,251 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug2(Chain2Args a) {
 #undef SLOT_COL
 
 // ------------------------------------------------------------------------------------------
+// Streaming augmentation for large n (prices/distances do not fit the register+LDS budget of jv_aug2).
+// Same search, same pick rule, same results; every per-column quantity lives in (L2-resident) global
+// memory and each step is two coalesced sweeps by 1024 threads:
+//   sweep A  relax through the picked row (cost row from HBM; vwork, d, pred from L2) fused with the
+//            running minimum of d (lowest column on ties: columns are visited in ascending order per lane)
+//   sweep B  the (few) still unassigned columns: an unassigned column whose d equals the minimum wins
+// vwork is the price vector with scanned columns masked to -inf (their relaxation becomes a no-op).
+// ------------------------------------------------------------------------------------------
+constexpr int BLOCK3 = 1024;
+constexpr int FAST_NMAX = 1 << 18;   // float32 cached-chain path (index arithmetic is 32-bit in bytes per row)
+constexpr int NW3 = BLOCK3 / 64;
+
+struct AugStreamArgs {
+    int n;
+    int64_t ld;
+    const float *cost;
+    float *gv, *gu, *sumvd, *cassign, *vwork, *d;     // [n] each
+    int32_t *rowsol, *colsol, *freerows, *pred, *colgroup, *ulist, *slist, *slevel;   // [n] each
+    const int32_t *rowgid;
+    float *g_hbest; int32_t *g_hstamp;                 // gmode 2
+    char *misc;
+    int ngroups, gmode;
+};
+
+__device__ __forceinline__ uint64_t wg3_min64(uint64_t x, uint64_t *buf /* [2][NW3] */, int &par) {
+    x = min64_wave_allreduce(x);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) buf[par * NW3 + w] = x;
+    lds_barrier();                       // LDS hand-off only: no wait for this wave's global stores
+    uint64_t r = buf[par * NW3 + (lane & (NW3 - 1))];
+    r = min64_row_allreduce(r);
+    par ^= 1;
+    return readlane64(r, 0);
+}
+
+// Ownership rule that makes the sweeps barrier-free: column c is read and written ONLY by lane
+// ((c >> 2) % BLOCK3) during a search (d, vwork, pred), so program order of that lane is all the ordering
+// needed; the unassigned-column bitmap and the per-group offsets live in LDS.
+__global__ __launch_bounds__(BLOCK3) void jv_aug_stream(AugStreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    __shared__ uint64_t s_red[2 * NW3];
+    __shared__ double s_sum[NW3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = a.n;
+    const int64_t ld = a.ld;
+    const float *__restrict__ cost = a.cost;
+    const int nqfull = n >> 2;                         // float4 chunks completely inside [0, n)
+    const int nwords = (n + 31) >> 5;
+    int par = 0;
+    const int gmode = a.gmode;
+    uint32_t *s_un = reinterpret_cast<uint32_t *>(dyn_lds);               // bit c set: column c unassigned
+    float *hb = a.g_hbest;
+    int32_t *hs = a.g_hstamp;
+    if (gmode == 1) {
+        hb = reinterpret_cast<float *>(dyn_lds + (size_t)nwords * 4);
+        hs = reinterpret_cast<int32_t *>(dyn_lds + (size_t)nwords * 4 + (size_t)a.ngroups * 4);
+        for (int g = tid; g < a.ngroups; g += BLOCK3) hs[g] = 0;
+    }
+    for (int w = tid; w < nwords; w += BLOCK3) {
+        uint32_t m = 0;
+        for (int b = 0; b < 32; b++) { const int c = w * 32 + b; if (c < n && a.colsol[c] < 0) m |= (1u << b); }
+        s_un[w] = m;
+    }
+    __syncthreads();
+    const int numfree = *reinterpret_cast<const int *>(a.misc + 128);
+    long long c_relax = 0, c_hops = 0, c_augs = 0, c_skipped = 0;
+    int err = 0;
+    const float4 *vp = reinterpret_cast<const float4 *>(a.vwork);
+    float4 *dp = reinterpret_cast<float4 *>(a.d);
+
+    for (int f = 0; f < numfree && !err; f++) {
+        const int freerow = a.freerows[f];
+        const int stamp = f + 1;
+        // running minima of this lane: over all its columns, and over its unassigned columns
+        float bestv = INFINITY, bestu = INFINITY;
+        int bestc = -1, bestuc = -1;
+#define TRACK(dd, c, ubit)                                         \
+    { if ((dd) < bestv) { bestv = (dd); bestc = (c); }             \
+      if ((ubit) && (dd) < bestu) { bestu = (dd); bestuc = (c); } }
+        // ---- initialise d = c[freerow] - v, pred = freerow, vwork = v ----
+        {
+            const float *rowp = cost + (int64_t)freerow * ld;
+            for (int q = tid; q * 4 < n; q += BLOCK3) {
+                const uint32_t um = s_un[q >> 3] >> ((q & 7) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int c = q * 4 + e;
+                    if (c < n) {
+                        const float vv = a.gv[c];
+                        const float dd = rowp[c] - vv;
+                        a.d[c] = dd; a.pred[c] = freerow; a.vwork[c] = vv;
+                        TRACK(dd, c, (um >> e) & 1u)
+                    }
+                }
+            }
+        }
+        bool have = false;
+        float curmin = 0.0f;
+        int endofpath = -1, level = 0, nscan = 0;
+        int pend_g = -1;
+        float pend_h = 0.0f;
+        for (;;) {
+            // ---- pick: smallest d, an unassigned column first among equals, then the lowest column ----
+            uint64_t key = KEYMAX;
+            if (bestc >= 0) {
+                if (bestuc >= 0 && bestu == bestv) key = mkkey(bestu, (uint32_t)bestuc);
+                else key = mkkey(bestv, (uint32_t)bestc | 0x80000000u);
+                // (a lane's overall best may be unassigned with bestu == bestv: handled by the first branch)
+            }
+            const uint64_t g = wg3_min64(key, s_red, par);
+            const float dmin = key_val(g);
+            if (g == KEYMAX || !(dmin < INFINITY)) { err = CYTO_ERR_INTERNAL; break; }
+            if (pend_g >= 0) {
+                if (tid == 0) { if (gmode == 1) { hb[pend_g] = pend_h; hs[pend_g] = stamp; } else { st_f32(hb + pend_g, pend_h); st_i32(hs + pend_g, stamp); } }
+                pend_g = -1;
+            }
+            const int jp = (int)((uint32_t)g & 0x7FFFFFFFu);
+            if (!have || dmin != curmin) { level++; curmin = dmin; have = true; }
+            if (!((uint32_t)g & 0x80000000u)) { endofpath = jp; break; }
+            // ---- scan column jp through its row ----
+            const int i = a.colsol[jp];
+            const float cip = a.cassign[jp];
+            const float vjp = a.gv[jp];
+            const float h = (cip - vjp) - curmin;
+            bool skip = false;
+            if (gmode) {
+                const int gq = a.colgroup[jp];
+                float hbv; int hsv;
+                if (gmode == 1) { hbv = hb[gq]; hsv = hs[gq]; } else { hbv = ld_f32(hb + gq); hsv = ld_i32(hs + gq); }
+                skip = (hsv == stamp) && (h <= hbv);
+                if (!skip) { pend_g = gq; pend_h = h; }
+            }
+            if (tid == 0) { a.sumvd[jp] = vjp + dmin; a.slist[nscan] = jp; a.slevel[nscan] = level; }
+            nscan++;
+            if (((jp >> 2) % BLOCK3) == tid) { a.d[jp] = INFINITY; a.vwork[jp] = -INFINITY; }   // the owner masks it
+            bestv = INFINITY; bestu = INFINITY; bestc = -1; bestuc = -1;
+            if (!skip) {
+                const float4 *rp = reinterpret_cast<const float4 *>(cost + (int64_t)i * ld);
+                // batches of 4 chunks per lane: all 12 loads are issued before the first use
+                for (int q0 = tid; q0 < nqfull; q0 += 4 * BLOCK3) {
+                    float4 x[4], vv[4], dd[4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const int q = q0 + t * BLOCK3;
+                        if (q < nqfull) { x[t] = rp[q]; vv[t] = vp[q]; dd[t] = dp[q]; }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const int q = q0 + t * BLOCK3;
+                        if (q < nqfull) {
+                            const int c0 = q * 4;
+                            const uint32_t um = s_un[q >> 3] >> ((q & 7) * 4);
+                            const float v0 = (x[t].x - vv[t].x) - h, v1 = (x[t].y - vv[t].y) - h;
+                            const float v2 = (x[t].z - vv[t].z) - h, v3 = (x[t].w - vv[t].w) - h;
+                            const bool u0 = v0 < dd[t].x, u1 = v1 < dd[t].y, u2 = v2 < dd[t].z, u3 = v3 < dd[t].w;
+                            if (u0 | u1 | u2 | u3) {
+                                dd[t].x = u0 ? v0 : dd[t].x; dd[t].y = u1 ? v1 : dd[t].y;
+                                dd[t].z = u2 ? v2 : dd[t].z; dd[t].w = u3 ? v3 : dd[t].w;
+                                dp[q] = dd[t];
+                                if (u0) a.pred[c0] = i;
+                                if (u1) a.pred[c0 + 1] = i;
+                                if (u2) a.pred[c0 + 2] = i;
+                                if (u3) a.pred[c0 + 3] = i;
+                            }
+                            TRACK(dd[t].x, c0, um & 1u)
+                            TRACK(dd[t].y, c0 + 1, (um >> 1) & 1u)
+                            TRACK(dd[t].z, c0 + 2, (um >> 2) & 1u)
+                            TRACK(dd[t].w, c0 + 3, (um >> 3) & 1u)
+                        }
+                    }
+                }
+                if (tid == (nqfull % BLOCK3)) {       // ragged tail (n % 4 columns) belongs to the lane that owns chunk nqfull
+                    for (int c = nqfull * 4; c < n; c++) {
+                        const float v2 = (cost[(int64_t)i * ld + c] - a.vwork[c]) - h;
+                        float dd = a.d[c];
+                        if (v2 < dd) { dd = v2; a.d[c] = v2; a.pred[c] = i; }
+                        TRACK(dd, c, (s_un[c >> 5] >> (c & 31)) & 1u)
+                    }
+                }
+            } else {
+                for (int q = tid; q < nqfull; q += BLOCK3) {
+                    const float4 dd = dp[q];
+                    const int c0 = q * 4;
+                    const uint32_t um = s_un[q >> 3] >> ((q & 7) * 4);
+                    TRACK(dd.x, c0, um & 1u)
+                    TRACK(dd.y, c0 + 1, (um >> 1) & 1u)
+                    TRACK(dd.z, c0 + 2, (um >> 2) & 1u)
+                    TRACK(dd.w, c0 + 3, (um >> 3) & 1u)
+                }
+                if (tid == (nqfull % BLOCK3)) {
+                    for (int c = nqfull * 4; c < n; c++) { const float dd = a.d[c]; TRACK(dd, c, (s_un[c >> 5] >> (c & 31)) & 1u) }
+                }
+                c_skipped++;
+            }
+            c_relax++;
+        }
+#undef TRACK
+        if (err) break;
+        // ---- price update: columns scanned at an earlier level than the final one ----
+        __syncthreads();
+        for (int k = tid; k < nscan; k += BLOCK3)
+            if (a.slevel[k] < level) { const int j = a.slist[k]; a.gv[j] = a.sumvd[j] - curmin; }
+        __syncthreads();
+        if (tid == 0) {
+            int ep = endofpath, i;
+            do {
+                i = a.pred[ep];
+                a.colsol[ep] = i;
+                a.cassign[ep] = cost[(int64_t)i * ld + ep];
+                if (gmode) a.colgroup[ep] = a.rowgid[i];
+                const int j1 = ep;
+                ep = a.rowsol[i];
+                a.rowsol[i] = j1;
+                c_hops++;
+            } while (i != freerow);
+            s_un[endofpath >> 5] &= ~(1u << (endofpath & 31));     // no longer unassigned
+        }
+        c_augs++;
+        __syncthreads();
+    }
+    // ---- duals u and the total ----
+    double part = 0.0;
+    for (int i = tid; i < n; i += BLOCK3) {
+        const int j = a.rowsol[i];
+        const float cij = cost[(int64_t)i * ld + j];
+        a.gu[i] = cij - a.gv[j];
+        part += (double)cij;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0) s_sum[wave] = part;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < NW3; w++) t += s_sum[w];
+        *reinterpret_cast<double *>(a.misc + 8) = t;
+        long long *counters = reinterpret_cast<long long *>(a.misc + 16);
+        counters[C_AUG_INIT] = c_augs; counters[C_AUG_RELAX] = c_relax; counters[C_AUGS] = c_augs; counters[C_HOPS] = c_hops;
+        counters[C_ROWS_READ] = counters[C2_DENSE_REFRESH] + c_augs + c_relax - c_skipped;
+        counters[C2_AUG_SKIPPED] = c_skipped;
+        *reinterpret_cast<int *>(a.misc + 4) = err;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 template <int CH, bool LDS_STATE>
@@ -1484,16 +1820,37 @@ static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_c
     const size_t shmem_aug = base_aug + (aug_args.auxlds ? (size_t)npad * 6 : 0) + 32;
     auto kern = jv_chain2<CH, LDS_STATE>;
     CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL((build_row_caches<CH>), dim3(cache_grid), dim3(BLOCK2), 0, stream, args.n, args.ld, args.cost,
-                       (const float *)args.fws, args.cache_col, args.cache_val);
+    if constexpr (CH == 0)
+        hipLaunchKernelGGL(build_row_caches_stream, dim3(cache_grid), dim3(BLOCK2), 0, stream, args.n, args.ld, args.cost,
+                           (const float *)args.fws, args.cache_col, args.cache_val);
+    else
+        hipLaunchKernelGGL((build_row_caches<CH>), dim3(cache_grid), dim3(BLOCK2), 0, stream, args.n, args.ld, args.cost,
+                           (const float *)args.fws, args.cache_col, args.cache_val);
     CYTO_HIP(hipGetLastError());
     CYTO_HIP(hipEventRecord(ev_cache_done, stream));
     hipLaunchKernelGGL(kern, dim3(1), dim3(BLOCK2), shmem, stream, args);
     CYTO_HIP(hipGetLastError());
     CYTO_HIP(hipEventRecord(ev_arr_done, stream));
-    auto kaug = jv_aug2<CH, LDS_STATE>;
-    CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kaug), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_aug));
-    hipLaunchKernelGGL(kaug, dim3(1), dim3(BLOCK2), shmem_aug, stream, aug_args);
+    if constexpr (LDS_STATE) {
+        auto kaug = jv_aug2<CH, LDS_STATE>;
+        CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kaug), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_aug));
+        hipLaunchKernelGGL(kaug, dim3(1), dim3(BLOCK2), shmem_aug, stream, aug_args);
+    } else {
+        // large n: streaming augmentation (per-column state in L2-resident global memory)
+        const int n = args.n;
+        AugStreamArgs sa;
+        sa.n = n; sa.ld = args.ld; sa.cost = args.cost;
+        sa.gv = args.fws; sa.gu = args.fws + n; sa.sumvd = args.fws + 2 * (int64_t)n; sa.cassign = args.fws + 3 * (int64_t)n;
+        sa.vwork = args.fws + 4 * (int64_t)n; sa.d = args.fws + 5 * (int64_t)n;
+        sa.rowsol = args.iws; sa.colsol = args.iws + n; sa.freerows = args.iws + 3 * (int64_t)n; sa.pred = args.iws + 5 * (int64_t)n;
+        sa.colgroup = args.iws + 6 * (int64_t)n; sa.ulist = args.iws + 7 * (int64_t)n; sa.slist = args.iws + 8 * (int64_t)n;
+        sa.slevel = args.iws + 9 * (int64_t)n;
+        sa.rowgid = args.rowgid; sa.g_hbest = args.g_hbest; sa.g_hstamp = args.g_hstamp; sa.misc = args.misc;
+        sa.ngroups = args.ngroups; sa.gmode = args.gmode;
+        const size_t shm = (size_t)((n + 31) / 32) * 4 + (args.gmode == 1 ? (size_t)args.ngroups * 8 : 0) + 32;
+        CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jv_aug_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        hipLaunchKernelGGL(jv_aug_stream, dim3(1), dim3(BLOCK3), shm, stream, sa);
+    }
     CYTO_HIP(hipGetLastError());
     return CYTO_OK;
 }
@@ -1541,7 +1898,7 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
 
     DevBuf b_fws, b_iws, b_imin, b_pmin, b_parg, b_misc;
     const size_t nT = (size_t)n * sizeof(T), nI = (size_t)n * sizeof(int32_t);
-    if ((rc = b_fws.alloc(4 * nT)) || (rc = b_iws.alloc(7 * nI)) || (rc = b_imin.alloc(nI)) ||
+    if ((rc = b_fws.alloc(6 * nT)) || (rc = b_iws.alloc(10 * nI)) || (rc = b_imin.alloc(nI)) ||
         (rc = b_pmin.alloc((size_t)rowblocks * nT)) || (rc = b_parg.alloc((size_t)rowblocks * nI)) || (rc = b_misc.alloc(256)))
         return rc;
     // float workspace: v | u ; int workspace: rowsol | colsol | matches | freerows | rtrows | pred
@@ -1575,7 +1932,7 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
     // duplicate-row groups (float32 fast path only): runs of bitwise identical consecutive rows
     DevBuf b_same, b_gid;
     int *d_ngroups = b_misc.as<int>() + 36;   // misc + 144
-    const bool want_groups = std::is_same<T, float>::value && n <= 16 * 4 * 512 && n >= 2;
+    const bool want_groups = std::is_same<T, float>::value && n <= FAST_NMAX && n >= 2;
     if (want_groups) {
         if ((rc = b_same.alloc(nI)) || (rc = b_gid.alloc(nI))) { cleanup(); return rc; }
         hipLaunchKernelGGL(rows_same_as_prev<T>, dim3(min(n, 2048)), dim3(256), 0, stream, n, dld, dcost, b_same.as<int32_t>());
@@ -1603,8 +1960,8 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
     DevBuf b_ccol, b_cval, b_ghb, b_ghs;
     bool fast = false;
     if constexpr (std::is_same<T, float>::value) {
-        // float32 fast path (n <= 32768): per-row top-K caches + single-wave cached chain steps
-        fast = n <= 16 * 4 * BLOCK2;
+        // float32 fast path: per-row top-K caches + single-wave cached chain steps
+        fast = n <= FAST_NMAX;
     }
     if (fast) {
         if constexpr (std::is_same<T, float>::value) {
@@ -1618,8 +1975,11 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
             c2.rowgid = b_gid.as<int32_t>(); c2.ngroups = h_ngroups; c2.gmode = 0; c2.g_hbest = nullptr; c2.g_hstamp = nullptr;
             c2.auxlds = 0;
             if (want_groups && h_ngroups < n) {
-                const size_t lds_state = (n <= 13 * 4 * BLOCK2) ? (size_t)((n + 3) & ~3) * 6 : 0;
-                if (lds_state + (size_t)h_ngroups * 8 + 4096 <= 160 * 1024) c2.gmode = 1;
+                // LDS beside the group state: v (4 B) + colsol (2 B) per column on the LDS-resident path,
+                // the unassigned-column bitmap on the streaming path
+                const size_t lds_state = (n <= 13 * 4 * BLOCK2 && !getenv("CYTO_FORCE_STREAM")) ? (size_t)((n + 3) & ~3) * 6
+                                                                                               : (size_t)((n + 31) / 32) * 4;
+                if (lds_state + (size_t)h_ngroups * 8 + 8192 <= 160 * 1024) c2.gmode = 1;
                 else {
                     c2.gmode = 2;
                     if ((rc = b_ghb.alloc((size_t)h_ngroups * 4)) || (rc = b_ghs.alloc((size_t)h_ngroups * 4))) { cleanup(); return rc; }
@@ -1629,11 +1989,21 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
             }
             const int cache_grid = max(1, min(n, 1024));
             const int per2 = 4 * BLOCK2;
-            if (n <= 2 * per2) rc = launch_chain2<2, true>(c2, cache_grid, e1c, e1d, stream);
+            // CYTO_FORCE_STREAM=1 (tests): take the large-n code path (state in global memory, streaming
+            // augmentation) at any size
+            const bool force_stream = getenv("CYTO_FORCE_STREAM") != nullptr;
+            // (=2: also the streaming dense refresh used beyond 32768 columns)
+            const bool force_refresh_stream = force_stream && strcmp(getenv("CYTO_FORCE_STREAM"), "2") == 0;
+            if (force_refresh_stream) rc = launch_chain2<0, false>(c2, cache_grid, e1c, e1d, stream);
+            else if (force_stream && n <= 5 * per2) rc = launch_chain2<5, false>(c2, cache_grid, e1c, e1d, stream);
+            else if (force_stream && n <= 16 * per2) rc = launch_chain2<16, false>(c2, cache_grid, e1c, e1d, stream);
+            else if (force_stream) rc = launch_chain2<0, false>(c2, cache_grid, e1c, e1d, stream);
+            else if (n <= 2 * per2) rc = launch_chain2<2, true>(c2, cache_grid, e1c, e1d, stream);
             else if (n <= 5 * per2) rc = launch_chain2<5, true>(c2, cache_grid, e1c, e1d, stream);
             else if (n <= 10 * per2) rc = launch_chain2<10, true>(c2, cache_grid, e1c, e1d, stream);
             else if (n <= 13 * per2) rc = launch_chain2<13, true>(c2, cache_grid, e1c, e1d, stream);
-            else rc = launch_chain2<16, false>(c2, cache_grid, e1c, e1d, stream);
+            else if (n <= 16 * per2) rc = launch_chain2<16, false>(c2, cache_grid, e1c, e1d, stream);
+            else rc = launch_chain2<0, false>(c2, cache_grid, e1c, e1d, stream);   // streaming dense refresh, any n
         }
     } else {
         CYTO_HIP(hipEventRecord(e1c, stream));

@@ -163,3 +163,22 @@ def test_duplicate_rows_skip_is_exact_and_deterministic(n, slots):
         assert np.array_equal(g["u"], o["u"]) and np.array_equal(g["v"], o["v"])
         assert g["info"].scans_aug_relax == o["stats"].scans_aug_relax
         assert g["info"].row_groups == n // slots and g["info"].aug_scans_skipped > 0
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_large_n_code_path_forced_at_small_n(monkeypatch, mode):
+    # CYTO_FORCE_STREAM routes any size through the large-n kernels (state in L2-resident global memory,
+    # streaming augmentation; "2": also the streaming dense refresh used beyond 32768 columns); they must
+    # be bit-identical too.  The real switch-overs are at n > 26624 and n > 32768.
+    monkeypatch.setenv("CYTO_FORCE_STREAM", mode)
+    for n in (5, 64, 700, 2300):
+        c = np.random.default_rng(n).random((n, n)).astype(np.float32)
+        _check(c, np.float32)
+    rng = np.random.default_rng(8)
+    base = -(rng.random((300, 1500)) ** 3).astype(np.float32)
+    c = np.repeat(base, 5, axis=0)
+    g = lap_solve(c, np.float32, return_info=True)
+    _check(c, np.float32)
+    assert g["info"].aug_scans_skipped > 0
+    c = np.random.default_rng(3).integers(0, 10, (400, 400)).astype(np.float32)
+    _check(c, np.float32)
