@@ -22,7 +22,7 @@
  * PARITY UNPINNED against lapjv itself (no wheel, no source, no reference test
  * holds a golden vector for this call).  It IS pinned against an independent exact
  * solver (scipy.optimize.linear_sum_assignment) on uniqueness-certified instances:
- * tests/test_oracle_jv.py, tests/golden/gv8_lap_*.npz.
+ * tests/test_oracle_cpu.py, tests/golden/gv8_lap.npz.
  *
  * Tie-breaking contract (what "bit-exact" means for the HIP kernels)
  * -----------------------------------------------------------------
