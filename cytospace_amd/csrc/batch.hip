@@ -35,6 +35,7 @@ int cyto_lap_batch_f32(int nb, const int *n, const float *const *cost, const int
         for (;;) {
             const int b = next.fetch_add(1);
             if (b >= nb) break;
+            cyto::tl_single_cu_only = 1;
             st[(size_t)b] = cyto_lap_f32(n[b], cost[b], ld[b], cost_on_device, rowsol ? rowsol[b] : nullptr,
                                          colsol ? colsol[b] : nullptr, u ? u[b] : nullptr, v ? v[b] : nullptr,
                                          total ? &total[b] : nullptr, info ? &info[b] : nullptr, device_id, stream);

@@ -32,4 +32,7 @@ struct DevBuf {
 
 int select_device(int device_id);
 
+// set by callers that run several solves concurrently on one GPU (cyto_lap_batch_f32): the cooperative
+// augmentation spins on its peers and must not compete with other cooperative launches for CUs
+extern thread_local int tl_single_cu_only;
 }  // namespace cyto

@@ -25,6 +25,7 @@
 #include <string.h>
 
 namespace cyto {
+thread_local int tl_single_cu_only = 0;
 
 constexpr int BLOCK = 1024;
 constexpr int NW = BLOCK / 64;
@@ -896,8 +897,8 @@ __global__ __launch_bounds__(BLOCK2) void build_row_caches(int n, int64_t ld, co
 }
 
 // Streaming variant of refresh_row for large n: no per-lane arrays.  The row and the prices come through
-// bounds-checked buffer descriptors (num_records = 4n, so the ragged tail needs no branches beyond the
-// per-column validity compare) and the row is swept several times -- the first sweep from HBM, the rest
+// bounds-checked buffer descriptors (whole quads stay in range: ld % 4 == 0 and v is followed by u in the
+// workspace; the ragged tail is handled by the per-column validity compare) and the row is swept several times -- the first sweep from HBM, the rest
 // from L2: top-2 keys, threshold search (count sweeps), per-lane counts, compaction.  Same cache contract
 // as refresh_row.  VAUX = cache policy of the price loads: 0x10 (sc1, agent scope) inside the chain where
 // wave 0 updates prices with agent-scope stores, 0 for the read-only build pass.
@@ -918,8 +919,8 @@ __device__ __forceinline__ K2 refresh_row_stream(int i, int n, int64_t ld, const
     const int tid = threadIdx.x, lane = tid & 63;
     const int nquad = (n + 3) >> 2;
     const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(cost + (int64_t)i * ld), 0, n * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gv), 0, n * 4, 0x00020000);
+        const_cast<float *>(cost + (int64_t)i * ld), 0, (int)(ld * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gv), 0, nquad * 16, 0x00020000);
     K2 loc; loc.m1 = KEYMAX; loc.m2 = KEYMAX;
     STREAM_SWEEP((void)raw; k2_push(loc, mkkey(h, c));)
     const K2 g = wg_k2(loc, s, par);
@@ -1808,10 +1809,319 @@ __global__ __launch_bounds__(BLOCK3) void jv_aug_stream(AugStreamArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Cooperative augmentation: W single-wave workers on W compute units, each owning a contiguous slice of
+// 4*QW columns (d, masked price, pred, colsol, ... in its own LDS).  A row scan is split W ways, so the
+// per-step HBM fetch is n/W columns per CU instead of n.  The replicated control state (level, curmin,
+// duplicate-row table, path walk) is kept identical on every worker by ONE all-to-all exchange per step:
+// every worker publishes its local candidate as a data-tagged record {key, hp, row, group} (agent-scope
+// 8-byte stores, double-buffered by round parity) and polls the W records; the winner is the 64-bit
+// minimum, exactly the oracle's lexicographic (d, assigned?, column) pick.  A worker can be at most one
+// round ahead of the slowest one, so two record buffers suffice; spins are bounded (abort flag).
+// Workers are launched as blocks b with b % stride == 0 (stride 8: all on one XCD -> one shared L2).
+// ------------------------------------------------------------------------------------------
+struct CoopArgs {
+    int n;
+    int64_t ld;
+    const float *cost;
+    float *gv, *cassign;
+    int32_t *rowsol, *colsol, *freerows, *colgroup;
+    const int32_t *rowgid;
+    float *g_hbest; int32_t *g_hstamp;     // gmode 2: [W][ngroups] private tables in global memory
+    char *misc;
+    uint64_t *slots;                       // [2][64][4]
+    int *abort_flag;
+    int ngroups, gmode;
+    int W, stride, QW;
+};
+constexpr uint32_t COOP_KEYLO_MAX = 0xFFFFFF00u;
+__device__ __forceinline__ uint64_t ld_u64(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_u64(uint64_t *p, uint64_t x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct CoopRec { uint64_t a, b, c; };
+// publish my record for round t and collect everybody's; returns the winning record (uniform), false on abort
+__device__ __forceinline__ bool coop_exchange(const CoopArgs &a, int w, int lane, uint32_t t, uint64_t ka, uint64_t kb, uint64_t kc,
+                                              CoopRec &win, uint64_t &second_a) {
+    const uint32_t tag = t & 0xFFu;
+    uint64_t *my = a.slots + ((size_t)(t & 1u) * 64 + w) * 4;
+    if (lane == 0) { st_u64(my + 1, kb | tag); st_u64(my + 2, kc | tag); st_u64(my, ka | tag); }
+    const uint64_t *peer = a.slots + ((size_t)(t & 1u) * 64 + lane) * 4;
+    uint64_t pa = ((uint64_t)0xFFFFFFFFu << 32) | COOP_KEYLO_MAX | tag, pb = tag, pc = tag;
+    const long long spin0 = wall_clock64();
+    int it = 0;
+    for (;;) {
+        bool ok = true;
+        if (lane < a.W) {
+            pa = ld_u64(peer); pb = ld_u64(peer + 1); pc = ld_u64(peer + 2);
+            ok = ((uint32_t)pa & 0xFFu) == tag && ((uint32_t)pb & 0xFFu) == tag && ((uint32_t)pc & 0xFFu) == tag;
+        }
+        if (__ballot(ok) == ~0ull) break;
+        if ((++it & 255) == 0) {
+            if (wall_clock64() - spin0 > 200000000LL) { if (lane == 0) atomicExch(a.abort_flag, 1); return false; }   // 2 s
+            if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+        }
+    }
+    K2 k; k.m1 = pa; k.m2 = KEYMAX;
+    k = k2_wave_allreduce(k);
+    const int wl = __builtin_ctzll(__ballot(pa == k.m1));
+    win.a = k.m1;
+    win.b = readlane64(pb, wl);
+    win.c = readlane64(pc, wl);
+    second_a = k.m2;
+    return true;
+}
+
+__global__ __launch_bounds__(64) void jv_aug_coop(CoopArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    if (blockIdx.x % a.stride) return;
+    const int w = blockIdx.x / a.stride;
+    if (w >= a.W) return;
+    const int lane = threadIdx.x;
+    const int n = a.n;
+    const int64_t ld = a.ld;
+    const float *__restrict__ cost = a.cost;
+    const int C = 4 * a.QW;                              // columns per worker (LDS arrays are this long)
+    const int c_lo = min(n, w * C);
+    const int ncols = max(0, min(n, c_lo + C) - c_lo);
+    const int nq = (ncols + 3) >> 2;                     // quads that hold at least one valid column
+    float *s_d = reinterpret_cast<float *>(dyn_lds);
+    float *s_vw = s_d + C, *s_v = s_vw + C, *s_sumvd = s_v + C, *s_ca = s_sumvd + C;
+    int32_t *s_pred = reinterpret_cast<int32_t *>(s_ca + C), *s_cs = s_pred + C, *s_lvl = s_cs + C, *s_cg = s_lvl + C;
+    uint32_t *s_un = reinterpret_cast<uint32_t *>(s_cg + C);   // [(C+31)/32]   bit k: local column k unassigned
+    const int nwords = (C + 31) >> 5;
+    const int gmode = a.gmode;
+    float *hb = nullptr; int32_t *hs = nullptr;
+    if (gmode == 1) { hb = reinterpret_cast<float *>(s_un + nwords); hs = reinterpret_cast<int32_t *>(hb + a.ngroups); }
+    else if (gmode == 2) { hb = a.g_hbest + (size_t)w * a.ngroups; hs = a.g_hstamp + (size_t)w * a.ngroups; }
+    if (gmode == 1) for (int g = lane; g < a.ngroups; g += 64) hs[g] = 0;
+    if (gmode == 2) for (int g = lane; g < a.ngroups; g += 64) st_i32(hs + g, 0);
+    for (int k = lane; k < C; k += 64) {
+        const int c = c_lo + k;
+        const bool valid = k < ncols;
+        s_v[k] = valid ? a.gv[c] : 0.0f;
+        s_cs[k] = valid ? a.colsol[c] : 0;
+        s_ca[k] = valid ? a.cassign[c] : 0.0f;
+        s_cg[k] = (valid && gmode) ? a.colgroup[c] : 0;
+        s_lvl[k] = 0; s_d[k] = INFINITY; s_vw[k] = -INFINITY; s_sumvd[k] = 0.0f; s_pred[k] = -1;
+    }
+    __syncthreads();
+    for (int wd = lane; wd < nwords; wd += 64) {
+        uint32_t m = 0;
+        for (int b = 0; b < 32; b++) { const int k = wd * 32 + b; if (k < ncols && s_cs[k] < 0) m |= (1u << b); }
+        s_un[wd] = m;
+    }
+    __syncthreads();
+    const int numfree = *reinterpret_cast<const int *>(a.misc + 128);
+    long long c_relax = 0, c_hops = 0, c_augs = 0, c_skipped = 0;
+    int err = 0;
+    uint32_t t = 0;                                      // exchange round (identical on every worker)
+
+#define COOP_TRACK(dd, kk, ubit)                                    \
+    { if ((dd) < bestv) { bestv = (dd); bestk = (kk); }             \
+      if ((ubit) && (dd) < bestu) { bestu = (dd); bestuk = (kk); } }
+
+    for (int f = 0; f < numfree && !err; f++) {
+        const int freerow = a.freerows[f];
+        const int stamp = f + 1;
+        float bestv = INFINITY, bestu = INFINITY;
+        int bestk = -1, bestuk = -1;
+        // ---- d = c[freerow] - v, pred = freerow, vwork = v (my slice) ----
+        {
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(cost + (int64_t)freerow * ld), 0, (int)(ld * 4), 0x00020000);
+            for (int q = lane; q < nq; q += 64) {
+                const u32x4_t xr = __builtin_amdgcn_raw_buffer_load_b128(rr, (c_lo + q * 4) * 4, 0, 0);
+                const float xs[4] = {__uint_as_float(xr.x), __uint_as_float(xr.y), __uint_as_float(xr.z), __uint_as_float(xr.w)};
+                const uint32_t um = s_un[q >> 3] >> ((q & 7) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int k = q * 4 + e;
+                    if (k < ncols) {
+                        const float vv = s_v[k];
+                        const float dd = xs[e] - vv;
+                        s_d[k] = dd; s_pred[k] = freerow; s_vw[k] = vv;
+                        COOP_TRACK(dd, k, (um >> e) & 1u)
+                    }
+                }
+            }
+        }
+        bool have = false;
+        float curmin = 0.0f;
+        int endofpath = -1, level = 0;
+        for (;;) {
+            // ---- my candidate: smallest d, an unassigned column first among equals, then the lowest column ----
+            uint64_t key = KEYMAX;
+            if (bestk >= 0) {
+                if (bestuk >= 0 && bestu == bestv) key = mkkey(bestu, (uint32_t)(c_lo + bestuk) << 8);
+                else key = mkkey(bestv, ((uint32_t)(c_lo + bestk) << 8) | 0x80000000u);
+            }
+            key = min64_wave_allreduce(key);
+            uint64_t ka = ((uint64_t)0xFFFFFFFFu << 32) | COOP_KEYLO_MAX, kb = 0, kc = 0;
+            if (key != KEYMAX) {
+                ka = key;
+                if ((uint32_t)key & 0x80000000u) {
+                    const int kl = (int)(((uint32_t)key & 0x7FFFFFFFu) >> 8) - c_lo;
+                    const float hp = s_ca[kl] - s_v[kl];
+                    kb = ((uint64_t)__float_as_uint(hp) << 32) | ((uint32_t)s_cs[kl] << 8);
+                    kc = (uint64_t)(uint32_t)s_cg[kl] << 32;
+                }
+            }
+            CoopRec win; uint64_t second;
+            if (!coop_exchange(a, w, lane, t, ka, kb, kc, win, second)) { err = CYTO_ERR_INTERNAL; break; }
+            t++;
+            const float dmin = key_val(win.a);
+            if ((win.a >> 32) == 0xFFFFFFFFull || !(dmin < INFINITY)) { err = CYTO_ERR_INTERNAL; break; }
+            const int jp = (int)(((uint32_t)win.a & 0x7FFFFFFFu) >> 8);
+            if (!have || dmin != curmin) { level++; curmin = dmin; have = true; }
+            if (!((uint32_t)win.a & 0x80000000u)) { endofpath = jp; break; }
+            // ---- scan column jp through its row ----
+            const int i = (int)((uint32_t)win.b >> 8);
+            const float hp = __uint_as_float((uint32_t)(win.b >> 32));
+            const float h = hp - curmin;
+            bool skip = false;
+            if (gmode) {
+                const int gq = (int)(uint32_t)(win.c >> 32);
+                float hbv; int hsv;
+                if (gmode == 1) { hbv = hb[gq]; hsv = hs[gq]; } else { hbv = ld_f32(hb + gq); hsv = ld_i32(hs + gq); }
+                skip = (hsv == stamp) && (h <= hbv);
+                if (!skip && lane == 0) {
+                    if (gmode == 1) { hb[gq] = h; hs[gq] = stamp; } else { st_f32(hb + gq, h); st_i32(hs + gq, stamp); }
+                }
+            }
+            if (jp >= c_lo && jp < c_lo + ncols && lane == 0) {     // the owner retires it
+                const int kl = jp - c_lo;
+                s_lvl[kl] = level; s_sumvd[kl] = s_v[kl] + dmin; s_d[kl] = INFINITY; s_vw[kl] = -INFINITY;
+            }
+            bestv = INFINITY; bestu = INFINITY; bestk = -1; bestuk = -1;
+            if (!skip) {
+                const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float *>(cost + (int64_t)i * ld), 0, (int)(ld * 4), 0x00020000);
+                for (int q0 = lane; q0 < nq; q0 += 64 * 8) {
+                    u32x4_t xr[8];
+#pragma unroll
+                    for (int b = 0; b < 8; b++) xr[b] = __builtin_amdgcn_raw_buffer_load_b128(rr, (c_lo + (q0 + b * 64) * 4) * 4, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < 8; b++) {
+                        const int q = q0 + b * 64;
+                        if (q < nq) {
+                            const int k0 = q * 4;
+                            const float4 vv = *reinterpret_cast<const float4 *>(s_vw + k0);
+                            float4 dd = *reinterpret_cast<const float4 *>(s_d + k0);
+                            const uint32_t um = s_un[q >> 3] >> ((q & 7) * 4);
+                            const float v0 = (__uint_as_float(xr[b].x) - vv.x) - h, v1 = (__uint_as_float(xr[b].y) - vv.y) - h;
+                            const float v2 = (__uint_as_float(xr[b].z) - vv.z) - h, v3 = (__uint_as_float(xr[b].w) - vv.w) - h;
+                            const bool u0 = v0 < dd.x, u1 = v1 < dd.y, u2 = v2 < dd.z, u3 = v3 < dd.w;
+                            if (u0 | u1 | u2 | u3) {
+                                dd.x = u0 ? v0 : dd.x; dd.y = u1 ? v1 : dd.y; dd.z = u2 ? v2 : dd.z; dd.w = u3 ? v3 : dd.w;
+                                *reinterpret_cast<float4 *>(s_d + k0) = dd;
+                                if (u0) s_pred[k0] = i;
+                                if (u1) s_pred[k0 + 1] = i;
+                                if (u2) s_pred[k0 + 2] = i;
+                                if (u3) s_pred[k0 + 3] = i;
+                            }
+                            COOP_TRACK(dd.x, k0, um & 1u)
+                            COOP_TRACK(dd.y, k0 + 1, (um >> 1) & 1u)
+                            COOP_TRACK(dd.z, k0 + 2, (um >> 2) & 1u)
+                            COOP_TRACK(dd.w, k0 + 3, (um >> 3) & 1u)
+                        }
+                    }
+                }
+            } else {
+                for (int q = lane; q < nq; q += 64) {
+                    const int k0 = q * 4;
+                    const float4 dd = *reinterpret_cast<const float4 *>(s_d + k0);
+                    const uint32_t um = s_un[q >> 3] >> ((q & 7) * 4);
+                    COOP_TRACK(dd.x, k0, um & 1u)
+                    COOP_TRACK(dd.y, k0 + 1, (um >> 1) & 1u)
+                    COOP_TRACK(dd.z, k0 + 2, (um >> 2) & 1u)
+                    COOP_TRACK(dd.w, k0 + 3, (um >> 3) & 1u)
+                }
+                c_skipped++;
+            }
+            c_relax++;
+        }
+        if (err) break;
+        // ---- price update: my columns scanned at an earlier level than the final one ----
+        for (int k = lane; k < ncols; k += 64) {
+            const int lv = s_lvl[k];
+            if (lv != 0) { if (lv < level) s_v[k] = s_sumvd[k] - curmin; s_lvl[k] = 0; }
+        }
+        // ---- flip the alternating path: one exchange round per hop, driven by the owner of the column ----
+        int ep = endofpath;
+        for (;;) {
+            uint64_t ka = ((uint64_t)0xFFFFFFFFu << 32) | COOP_KEYLO_MAX, kb = 0, kc = 0;
+            if (ep >= c_lo && ep < c_lo + ncols) {
+                const int kl = ep - c_lo;
+                const int i = s_pred[kl];
+                int nxt = 0;
+                if (lane == 0) {
+                    s_cs[kl] = i;
+                    s_ca[kl] = cost[(int64_t)i * ld + ep];
+                    if (gmode) s_cg[kl] = a.rowgid[i];
+                    s_un[kl >> 5] &= ~(1u << (kl & 31));
+                    nxt = ld_i32(a.rowsol + i);
+                    st_i32(a.rowsol + i, ep);
+                }
+                nxt = __builtin_amdgcn_readfirstlane(nxt);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                ka = 0;
+                kb = ((uint64_t)(uint32_t)nxt << 32) | ((uint32_t)i << 8);
+            }
+            CoopRec win; uint64_t second;
+            if (!coop_exchange(a, w, lane, t, ka, kb, kc, win, second)) { err = CYTO_ERR_INTERNAL; break; }
+            t++;
+            if ((win.a >> 32) != 0) { err = CYTO_ERR_INTERNAL; break; }
+            const int i = (int)((uint32_t)win.b >> 8);
+            ep = (int)(uint32_t)(win.b >> 32);
+            c_hops++;
+            if (i == freerow) break;
+        }
+        c_augs++;
+    }
+#undef COOP_TRACK
+    // ---- write my slice of the prices and the column assignment back ----
+    for (int k = lane; k < ncols; k += 64) { a.gv[c_lo + k] = s_v[k]; a.colsol[c_lo + k] = s_cs[k]; }
+    if (w == 0 && lane == 0) {
+        long long *counters = reinterpret_cast<long long *>(a.misc + 16);
+        counters[C_AUG_INIT] = c_augs; counters[C_AUG_RELAX] = c_relax; counters[C_AUGS] = c_augs; counters[C_HOPS] = c_hops;
+        counters[C_ROWS_READ] = counters[C2_DENSE_REFRESH] + c_augs + c_relax - c_skipped;
+        counters[C2_AUG_SKIPPED] = c_skipped;
+    }
+    if (err && lane == 0) *reinterpret_cast<int *>(a.misc + 4) = err;
+}
+
+// duals u and the total after the cooperative augmentation (needs every worker's write-back: own launch)
+__global__ __launch_bounds__(BLOCK3) void jv_finish_duals(int n, int64_t ld, const float *__restrict__ cost, const float *__restrict__ gv,
+                                                         float *__restrict__ gu, const int32_t *__restrict__ rowsol, char *misc) {
+    __shared__ double s_sum[NW3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double part = 0.0;
+    for (int i = tid; i < n; i += BLOCK3) {
+        const int j = rowsol[i];
+        const float cij = cost[(int64_t)i * ld + j];
+        gu[i] = cij - gv[j];
+        part += (double)cij;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0) s_sum[wave] = part;
+    __syncthreads();
+    if (tid == 0) {
+        double tt = 0.0;
+        for (int w = 0; w < NW3; w++) tt += s_sum[w];
+        *reinterpret_cast<double *>(misc + 8) = tt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+struct CoopPlan { bool enabled; CoopArgs args; size_t shm; };
 template <int CH, bool LDS_STATE>
-static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_cache_done, hipEvent_t ev_arr_done, hipStream_t stream) {
+static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_cache_done, hipEvent_t ev_arr_done, hipStream_t stream,
+                         const CoopPlan &plan) {
+    const bool coop = plan.enabled;
+    CoopArgs ca = plan.args;
+    const size_t coop_shm = plan.shm;
     const int npad = (args.n + 3) & ~3;
     const size_t shmem = LDS_STATE ? (((size_t)npad * 6 + 15) / 16) * 16 : 16;
     const size_t base_aug = (((LDS_STATE ? (size_t)npad * 6 : 0) + (args.gmode == 1 ? (size_t)args.ngroups * 8 : 0) + 15) / 16) * 16;
@@ -1831,10 +2141,22 @@ static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_c
     hipLaunchKernelGGL(kern, dim3(1), dim3(BLOCK2), shmem, stream, args);
     CYTO_HIP(hipGetLastError());
     CYTO_HIP(hipEventRecord(ev_arr_done, stream));
+    if (coop) {
+        CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jv_aug_coop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_shm));
+    }
     if constexpr (LDS_STATE) {
+      if (!coop) {
         auto kaug = jv_aug2<CH, LDS_STATE>;
         CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kaug), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_aug));
         hipLaunchKernelGGL(kaug, dim3(1), dim3(BLOCK2), shmem_aug, stream, aug_args);
+      }
+    }
+    if (LDS_STATE && !coop) {
+    } else if (coop) {
+        hipLaunchKernelGGL(jv_aug_coop, dim3(ca.W * ca.stride), dim3(64), coop_shm, stream, ca);
+        CYTO_HIP(hipGetLastError());
+        hipLaunchKernelGGL(jv_finish_duals, dim3(1), dim3(BLOCK3), 0, stream, args.n, args.ld, args.cost, (const float *)args.fws,
+                           args.fws + args.n, (const int32_t *)args.iws, args.misc);
     } else {
         // large n: streaming augmentation (per-column state in L2-resident global memory)
         const int n = args.n;
@@ -1957,7 +2279,7 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
     CYTO_HIP(hipEventCreate(&e1d));
     CYTO_HIP(hipEventRecord(e1b, stream));
     const int64_t per = (int64_t)VW * BLOCK;
-    DevBuf b_ccol, b_cval, b_ghb, b_ghs;
+    DevBuf b_ccol, b_cval, b_ghb, b_ghs, b_coop, b_cghb, b_cghs;
     bool fast = false;
     if constexpr (std::is_same<T, float>::value) {
         // float32 fast path: per-row top-K caches + single-wave cached chain steps
@@ -1987,6 +2309,50 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
                     c2.g_hbest = b_ghb.as<float>(); c2.g_hstamp = b_ghs.as<int32_t>();
                 }
             }
+            // ---- augmentation kernel choice: cooperative (W workers on W CUs) above a size threshold ----
+            CoopPlan plan; memset(&plan, 0, sizeof plan);
+            {
+                const char *e = getenv("CYTO_AUG");
+                const char *emin = getenv("CYTO_COOP_MIN_N");
+                const int coop_min_n = emin ? atoi(emin) : 0;   // opt-in: CYTO_AUG=coop or CYTO_COOP_MIN_N=<n>
+                const bool want = !tl_single_cu_only && ((e && strcmp(e, "coop") == 0) || (emin && n >= coop_min_n));
+                if (want) {
+                    const char *ew = getenv("CYTO_COOP_W"), *es = getenv("CYTO_COOP_STRIDE");
+                    int W = ew ? max(1, min(64, atoi(ew))) : 16;
+                    const int stride = es ? max(1, atoi(es)) : 8;
+                    const int nquad = (n + 3) / 4;
+                    const size_t lds_max = 150 * 1024;
+                    size_t shm = 0; int QW = 0;
+                    for (;;) {
+                        QW = (nquad + W - 1) / W;
+                        const size_t C = (size_t)4 * QW;
+                        shm = C * 36 + ((C + 31) / 32) * 4 + 64;
+                        if (shm <= lds_max || W >= 64) break;
+                        W = min(64, W * 2);
+                    }
+                    if (shm <= lds_max) {
+                        CoopArgs &ca = plan.args;
+                        ca.n = n; ca.ld = dld; ca.cost = dcost; ca.gv = d_v; ca.cassign = d_v + 3 * (int64_t)n;
+                        ca.rowsol = d_rowsol; ca.colsol = d_colsol; ca.freerows = d_free; ca.colgroup = d_rowsol + 6 * (int64_t)n;
+                        ca.rowgid = b_gid.as<int32_t>(); ca.misc = b_misc.as<char>();
+                        ca.ngroups = h_ngroups; ca.gmode = 0; ca.g_hbest = nullptr; ca.g_hstamp = nullptr;
+                        ca.W = W; ca.stride = stride; ca.QW = QW;
+                        if (c2.gmode) {
+                            if (shm + (size_t)h_ngroups * 8 <= lds_max + 6 * 1024) { ca.gmode = 1; shm += (size_t)h_ngroups * 8; }
+                            else {
+                                ca.gmode = 2;
+                                if ((rc = b_cghb.alloc((size_t)W * h_ngroups * 4)) || (rc = b_cghs.alloc((size_t)W * h_ngroups * 4))) { cleanup(); return rc; }
+                                ca.g_hbest = b_cghb.as<float>(); ca.g_hstamp = b_cghs.as<int32_t>();
+                            }
+                        }
+                        if ((rc = b_coop.alloc(4096 + 64))) { cleanup(); return rc; }
+                        CYTO_HIP(hipMemsetAsync(b_coop.p, 0xFF, 4096, stream));
+                        CYTO_HIP(hipMemsetAsync(b_coop.as<char>() + 4096, 0, 64, stream));
+                        ca.slots = b_coop.as<uint64_t>(); ca.abort_flag = reinterpret_cast<int *>(b_coop.as<char>() + 4096);
+                        plan.shm = shm; plan.enabled = true;
+                    }
+                }
+            }
             const int cache_grid = max(1, min(n, 1024));
             const int per2 = 4 * BLOCK2;
             // CYTO_FORCE_STREAM=1 (tests): take the large-n code path (state in global memory, streaming
@@ -1994,16 +2360,16 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
             const bool force_stream = getenv("CYTO_FORCE_STREAM") != nullptr;
             // (=2: also the streaming dense refresh used beyond 32768 columns)
             const bool force_refresh_stream = force_stream && strcmp(getenv("CYTO_FORCE_STREAM"), "2") == 0;
-            if (force_refresh_stream) rc = launch_chain2<0, false>(c2, cache_grid, e1c, e1d, stream);
-            else if (force_stream && n <= 5 * per2) rc = launch_chain2<5, false>(c2, cache_grid, e1c, e1d, stream);
-            else if (force_stream && n <= 16 * per2) rc = launch_chain2<16, false>(c2, cache_grid, e1c, e1d, stream);
-            else if (force_stream) rc = launch_chain2<0, false>(c2, cache_grid, e1c, e1d, stream);
-            else if (n <= 2 * per2) rc = launch_chain2<2, true>(c2, cache_grid, e1c, e1d, stream);
-            else if (n <= 5 * per2) rc = launch_chain2<5, true>(c2, cache_grid, e1c, e1d, stream);
-            else if (n <= 10 * per2) rc = launch_chain2<10, true>(c2, cache_grid, e1c, e1d, stream);
-            else if (n <= 13 * per2) rc = launch_chain2<13, true>(c2, cache_grid, e1c, e1d, stream);
-            else if (n <= 16 * per2) rc = launch_chain2<16, false>(c2, cache_grid, e1c, e1d, stream);
-            else rc = launch_chain2<0, false>(c2, cache_grid, e1c, e1d, stream);   // streaming dense refresh, any n
+            if (force_refresh_stream) rc = launch_chain2<0, false>(c2, cache_grid, e1c, e1d, stream, plan);
+            else if (force_stream && n <= 5 * per2) rc = launch_chain2<5, false>(c2, cache_grid, e1c, e1d, stream, plan);
+            else if (force_stream && n <= 16 * per2) rc = launch_chain2<16, false>(c2, cache_grid, e1c, e1d, stream, plan);
+            else if (force_stream) rc = launch_chain2<0, false>(c2, cache_grid, e1c, e1d, stream, plan);
+            else if (n <= 2 * per2) rc = launch_chain2<2, true>(c2, cache_grid, e1c, e1d, stream, plan);
+            else if (n <= 5 * per2) rc = launch_chain2<5, true>(c2, cache_grid, e1c, e1d, stream, plan);
+            else if (n <= 10 * per2) rc = launch_chain2<10, true>(c2, cache_grid, e1c, e1d, stream, plan);
+            else if (n <= 13 * per2) rc = launch_chain2<13, true>(c2, cache_grid, e1c, e1d, stream, plan);
+            else if (n <= 16 * per2) rc = launch_chain2<16, false>(c2, cache_grid, e1c, e1d, stream, plan);
+            else rc = launch_chain2<0, false>(c2, cache_grid, e1c, e1d, stream, plan);   // streaming dense refresh, any n
         }
     } else {
         CYTO_HIP(hipEventRecord(e1c, stream));

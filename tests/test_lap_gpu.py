@@ -182,3 +182,25 @@ def test_large_n_code_path_forced_at_small_n(monkeypatch, mode):
     assert g["info"].aug_scans_skipped > 0
     c = np.random.default_rng(3).integers(0, 10, (400, 400)).astype(np.float32)
     _check(c, np.float32)
+
+
+@pytest.mark.parametrize("W,stride", [("16", "8"), ("64", "1"), ("3", "8")])
+def test_cooperative_augmentation_forced(monkeypatch, W, stride):
+    # CYTO_AUG=coop routes the augmentation through the (opt-in) multi-CU cooperative kernel; W workers, placed on one XCD (stride 8) or round-robin over all XCDs (stride 1).
+    monkeypatch.setenv("CYTO_AUG", "coop")
+    monkeypatch.setenv("CYTO_COOP_W", W)
+    monkeypatch.setenv("CYTO_COOP_STRIDE", stride)
+    for n in (1, 2, 5, 64, 257, 700, 2300):
+        c = np.random.default_rng(n).random((n, n)).astype(np.float32)
+        _check(c, np.float32)
+    rng = np.random.default_rng(8)
+    base = -(rng.random((300, 1500)) ** 3).astype(np.float32)
+    c = np.repeat(base, 5, axis=0)
+    g = lap_solve(c, np.float32, return_info=True)
+    _check(c, np.float32)
+    assert g["info"].aug_scans_skipped > 0
+    c = np.random.default_rng(3).integers(0, 10, (400, 400)).astype(np.float32)
+    _check(c, np.float32)
+    monkeypatch.setenv("CYTO_FORCE_STREAM", "2")
+    c = np.random.default_rng(5).random((1500, 1500)).astype(np.float32)
+    _check(c, np.float32)
