@@ -28,7 +28,8 @@ class LapInfo(ctypes.Structure):
             "augmentations", "path_hops", "free_after_colred", "free_after_arr1", "free_after_arr2",
             "hbm_row_reads", "dense_refreshes")] + [("ms_arr", ctypes.c_double), ("ms_aug", ctypes.c_double),
                                                         ("aug_scans_skipped", ctypes.c_int64),
-                                                        ("row_groups", ctypes.c_int64), ("reserved", ctypes.c_int64 * 2)]
+                                                        ("row_groups", ctypes.c_int64), ("aug_dense_scans", ctypes.c_int64),
+                                                        ("reserved", ctypes.c_int64 * 1)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

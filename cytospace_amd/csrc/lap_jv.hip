@@ -22,6 +22,7 @@
 #include <math.h>
 #include <type_traits>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 
 namespace cyto {
@@ -2113,12 +2114,418 @@ __global__ __launch_bounds__(BLOCK3) void jv_finish_duals(int n, int64_t ld, con
 }
 
 // ------------------------------------------------------------------------------------------
+// Cache-certified augmentation ("lazy" Dijkstra): the row caches also serve the augmentation.
+//
+// Prices never increase (RT/ARR lower them; the augmentation's update v += d - curmin has d < curmin;
+// the one-ulp rounding exception is handled below), so a row's cache floor F_i stays a lower bound of the
+// reduced cost of every column outside its cache.  Let T be the smallest distance of an unassigned column
+// seen so far in this search: the search ends at a distance <= T, and a column whose distance is > T when
+// the search ends is never scanned, so its d and pred are never observed.  A scan of row i with offset h
+// changes a non-cached column j to fl(fl(c-v_j) - h) >= fl(F_i - h); if that bound is > T the scan is
+// observably identical to relaxing the <= 63 cached columns only.  Strictness matters: an update equal to
+// T could decide a tie between two unassigned columns.  Otherwise the whole workgroup scans the row.
+//
+// State: one 64-bit word per column in L2-resident global memory, (ordered d << 32) | step of the scan
+// that set it (unsigned min == "strictly smaller d wins, the earlier scan on equal d", i.e. the oracle's
+// `v2 < d` rule; pred is recovered as the row of that step); 0 once the column is scanned.  The pick
+// structure is in LDS: for each block of 64 columns the smallest (d, assigned?, column) key.  A cached
+// step runs on wave 0 alone: LDS min over the block keys, three independent loads (cache row, the picked
+// column's block for its new minimum, c[i][jp]), <= 63 fire-and-forget 64-bit atomic mins + LDS mins.
+// Columns whose price ROSE by rounding in a price update (possible only by an ulp when v+d crosses a
+// binade) are kept in an exception list and relaxed explicitly in every cached step.
+// ------------------------------------------------------------------------------------------
+struct LazyArgs {
+    int n;
+    int64_t ld;
+    const float *cost;
+    float *gv, *gu, *sumvd, *cassign;
+    uint64_t *dkey;                                   // [n]
+    int32_t *rowsol, *colsol, *freerows, *predstep, *srow, *slist, *slevel;   // [n] each (srow: [n+1])
+    const int32_t *rowgid;
+    const uint32_t *cache_col;
+    const float *cache_val;
+    float *g_hbest; int32_t *g_hstamp;
+    char *misc;
+    int ngroups, gmode;
+};
+struct LazyCmd { int op, row, step, endofpath, level, nscan, err; float h, curmin; };
+enum { LZ_DENSE = 1, LZ_END = 2, LZ_ERR = 3 };
+enum { C2_AUG_DENSE = C2_NCOUNTERS, C3_NCOUNTERS };
+constexpr int LZ_MAXEXC = 64;
+
+__device__ __forceinline__ void lds_min_u64(uint64_t *p, uint64_t x) {
+    (void)__hip_atomic_fetch_min(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void gl_min_u64(uint64_t *p, uint64_t x) {
+    (void)__hip_atomic_fetch_min(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#ifdef LZ_PROF
+#define LZ_STAMP(k) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)"); \
+                      if ((k) > 0) prof[k] += now_ - tlast; else if (tlast) prof[0] += 0; tlast = now_; profn[k]++; }
+#define LZ_WAITVM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+#define LZ_STAMP(k)
+#define LZ_WAITVM
+#endif
+// lexicographic minimum of 64-bit keys over a wave as two 32-bit all-reduces (value, then the low word
+// among the lanes holding that value): much shorter dependency chains than a 64-bit DPP butterfly
+__device__ __forceinline__ uint64_t wave_lexmin_u64(uint64_t k) {
+    const uint32_t hi = (uint32_t)(k >> 32), lo = (uint32_t)k;
+    const uint32_t m = wave_min_u32(hi);
+    const uint32_t l = wave_min_u32(hi == m ? lo : 0xFFFFFFFFu);
+    return ((uint64_t)m << 32) | l;
+}
+template <bool LDS_STATE>
+__global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
+#ifdef LZ_PROF
+    long long prof[6] = {0, 0, 0, 0, 0, 0}, profn[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+#endif
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    __shared__ Scratch2 s;
+    __shared__ LazyCmd cmd;
+    __shared__ int s_nexc;
+    __shared__ uint32_t s_T;          // ordered key of T (wave 0 lowers it with LDS atomic mins)
+    __shared__ int s_exc[LZ_MAXEXC];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = a.n;
+    const int64_t ld = a.ld;
+    const float *__restrict__ cost = a.cost;
+    const int nquad = (n + 3) >> 2, npad = nquad * 4, nb = (n + 63) >> 6;
+    float *gv = a.gv;
+    size_t off = 0;
+    float *s_v = nullptr;
+    uint16_t *s_cs = nullptr;
+    if constexpr (LDS_STATE) {
+        s_v = reinterpret_cast<float *>(dyn_lds);
+        s_cs = reinterpret_cast<uint16_t *>(dyn_lds + (size_t)npad * 4);
+        off = ((size_t)npad * 6 + 15) & ~(size_t)15;
+    }
+    const int nbp = (nb + 511) & ~511;               // padded with KEYMAX: the pick reads 8 keys per lane, unpredicated
+    uint64_t *bmin = reinterpret_cast<uint64_t *>(dyn_lds + off); off += (size_t)nbp * 8;
+    uint32_t *s_sc = reinterpret_cast<uint32_t *>(dyn_lds + off); off += (size_t)nb * 8;   // 2 words per block
+    uint32_t *s_un = reinterpret_cast<uint32_t *>(dyn_lds + off); off += (size_t)nb * 8;
+    const int gmode = a.gmode;
+    float *hb = a.g_hbest;
+    int32_t *hs = a.g_hstamp;
+    if (gmode == 1) {
+        hb = reinterpret_cast<float *>(dyn_lds + off);
+        hs = reinterpret_cast<int32_t *>(dyn_lds + off + (size_t)a.ngroups * 4);
+        for (int g = tid; g < a.ngroups; g += BLOCK2) hs[g] = 0;
+    }
+    int par = 0;
+    if constexpr (LDS_STATE) {
+        for (int c = tid; c < npad; c += BLOCK2) {
+            s_v[c] = c < n ? gv[c] : 0.0f;
+            const int32_t cs = c < n ? a.colsol[c] : -1;
+            s_cs[c] = cs < 0 ? (uint16_t)0xFFFFu : (uint16_t)cs;
+        }
+    }
+    for (int w = tid; w < 2 * nb; w += BLOCK2) {
+        uint32_t m = 0;
+        for (int b = 0; b < 32; b++) { const int c = w * 32 + b; if (c < n && a.colsol[c] < 0) m |= (1u << b); }
+        s_un[w] = m;
+    }
+    if (tid == 0) s_nexc = 0;
+    for (int b = nb + tid; b < nbp; b += BLOCK2) bmin[b] = KEYMAX;
+    __syncthreads();
+    const int numfree = *reinterpret_cast<const int *>(a.misc + 128);
+    long long c_relax = 0, c_hops = 0, c_augs = 0, c_skipped = 0, c_dense = 0;
+    int err = 0;
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(gv, 0, nquad * 16, 0x00020000);
+
+    for (int f = 0; f < numfree && !err; f++) {
+        const int freerow = __builtin_amdgcn_readfirstlane(ld_i32(a.freerows + f));
+        const int stamp = f + 1;
+        // ================= init: d = c[freerow] - v for every column (whole workgroup) =================
+        for (int w = tid; w < 2 * nb; w += BLOCK2) s_sc[w] = 0;
+        float tl = INFINITY;
+        {
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(cost + (int64_t)freerow * ld), 0, (int)(ld * 4), 0x00020000);
+            for (int q0 = 0; q0 < nquad; q0 += BLOCK2) {
+                const int q = q0 + tid;
+                uint64_t bk = KEYMAX;
+                if (q < nquad) {
+                    const u32x4_t xr = __builtin_amdgcn_raw_buffer_load_b128(rr, q * 16, 0, 0);
+                    float4 vv;
+                    if constexpr (LDS_STATE) vv = *reinterpret_cast<const float4 *>(s_v + q * 4);
+                    else {
+                        const u32x4_t vr = __builtin_amdgcn_raw_buffer_load_b128(rv, q * 16, 0, 0x10);
+                        vv = make_float4(__uint_as_float(vr.x), __uint_as_float(vr.y), __uint_as_float(vr.z), __uint_as_float(vr.w));
+                    }
+                    const uint32_t um = (s_un[q >> 3] >> ((q & 7) * 4)) & 0xFu;
+                    const float xs[4] = {__uint_as_float(xr.x), __uint_as_float(xr.y), __uint_as_float(xr.z), __uint_as_float(xr.w)};
+                    const float vs[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int c = q * 4 + e;
+                        if (c < n) {
+                            const float dd = xs[e] - vs[e];
+                            const uint32_t od = f2ord(dd);
+                            const bool un = (um >> e) & 1u;
+                            st_u64(a.dkey + c, (uint64_t)od << 32);            // step 0 = the free row
+                            bk = umin64(bk, ((uint64_t)od << 32) | (un ? 0u : 0x80000000u) | (uint32_t)c);
+                            if (un) tl = fminf(tl, dd);
+                        }
+                    }
+                }
+                bk = min64_row_allreduce(bk);          // 16 lanes = 16 quads = one block of 64 columns
+                if ((lane & 15) == 0 && q < nquad) bmin[q >> 4] = bk;
+            }
+        }
+        if (tid == 0) st_i32(a.srow, freerow);
+        {
+            const uint32_t t0 = wg_min_u32(f2ord(tl), s, par);
+            if (tid == 0) s_T = t0;
+        }
+        __syncthreads();
+        // ================= search =================
+        bool have = false;
+        float curmin = 0.0f;
+        int level = 0, nscan = 0, endofpath = -1;
+        for (;;) {
+            if (wave == 0) {
+                for (;;) {
+                    LZ_STAMP(0)
+                    // ---- pick: smallest (d, assigned?, column) over the block minima ----
+                    uint64_t k = KEYMAX;
+                    for (int b0 = 0; b0 < nbp; b0 += 512) {
+                        uint64_t kk[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) kk[u] = bmin[b0 + u * 64 + lane];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) k = umin64(k, kk[u]);
+                    }
+                    k = wave_lexmin_u64(k);
+                    const float dmin = key_val(k);
+                    if (k == KEYMAX || !(dmin < INFINITY)) { if (lane == 0) { cmd.op = LZ_ERR; } break; }
+                    const int jp = (int)((uint32_t)k & 0x7FFFFFFFu);
+                    LZ_STAMP(1)
+                    if (!have || dmin != curmin) { level++; curmin = dmin; have = true; }
+                    if (!((uint32_t)k & 0x80000000u)) {
+                        endofpath = jp;
+                        if (lane == 0) { cmd.op = LZ_END; cmd.endofpath = jp; cmd.level = level; cmd.nscan = nscan; cmd.curmin = curmin; }
+                        break;
+                    }
+                    const int i = __builtin_amdgcn_readfirstlane(st_csget<LDS_STATE>(s_cs, a.colsol, jp));
+                    const float vjp = st_vget<LDS_STATE>(s_v, gv, jp);
+                    const int step = nscan + 1;
+                    const int blk = jp >> 6;
+                    const int jb = blk * 64 + lane;
+                    // independent loads: c[i][jp], the row's cache, the picked column's block, the row's group
+                    const float cip_raw = ld_f32(a.cassign + jp);
+                    const uint32_t cc = ld_u32(a.cache_col + (int64_t)i * KC + lane);
+                    const float cv = ld_f32(a.cache_val + (int64_t)i * KC + lane);
+                    const uint64_t dk = jb < n ? ld_u64(a.dkey + jb) : 0ull;
+                    const int g_raw = gmode ? a.rowgid[i] : 0;
+                    // retire column jp
+                    if (lane == 0) {
+                        st_i32(a.slist + nscan, jp); st_i32(a.slevel + nscan, level); st_f32(a.sumvd + jp, vjp + dmin);
+                        st_i32(a.srow + step, i);
+                        atomicOr(&s_sc[jp >> 5], 1u << (jp & 31));
+                    }
+                    const uint32_t scw = s_sc[blk * 2 + (lane >> 5)], unw = s_un[blk * 2 + (lane >> 5)];
+                    LZ_WAITVM
+                    LZ_STAMP(2)
+                    const float cip = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(cip_raw)));
+                    const float h = (cip - vjp) - curmin;
+                    if (jb == jp) { st_i32(a.predstep + jp, (int32_t)(uint32_t)dk); st_u64(a.dkey + jp, 0ull); }
+                    bool skip = false;
+                    if (gmode) {
+                        const int g = __builtin_amdgcn_readfirstlane(g_raw);
+                        float hbv; int hsv;
+                        if (gmode == 1) { hbv = hb[g]; hsv = hs[g]; } else { hbv = ld_f32(hb + g); hsv = ld_i32(hs + g); }
+                        skip = (hsv == stamp) && (h <= hbv);
+                        if (!skip && lane == 0) {
+                            if (gmode == 1) { hb[g] = h; hs[g] = stamp; } else { st_f32(hb + g, h); st_i32(hs + g, stamp); }
+                        }
+                    }
+                    // new minimum of the picked column's block (this step's relaxations are applied after it)
+                    {
+                        const bool live = jb < n && !((scw >> (lane & 31)) & 1u);
+                        uint64_t kb = KEYMAX;
+                        if (live) kb = (dk & 0xFFFFFFFF00000000ull) | (((unw >> (lane & 31)) & 1u) ? 0u : 0x80000000u) | (uint32_t)jb;
+                        kb = wave_lexmin_u64(kb);
+                        if (lane == 0) bmin[blk] = kb;
+                    }
+                    nscan++;
+                    c_relax++;
+                    LZ_STAMP(3)
+                    if (skip) { c_skipped++; continue; }
+                    const float floor_i = __uint_as_float(readlane32(__float_as_uint(cv), KCU));
+                    const float T = ord2f(s_T);
+                    if (!((floor_i - h) > T)) {
+                        if (lane == 0) { cmd.op = LZ_DENSE; cmd.row = i; cmd.step = step; cmd.h = h; }
+                        break;
+                    }
+                    // ---- cached relaxation: lane = cache entry; plus the (normally empty) exception list ----
+                    if (lane < KCU && cc != COLSENT) {
+                        const int j = (int)cc;
+                        const float vj = st_vget<LDS_STATE>(s_v, gv, j);
+                        const float v2 = (cv - vj) - h;
+                        const bool scn = (s_sc[j >> 5] >> (j & 31)) & 1u;
+                        if (!scn && !(v2 > T)) {
+                            const bool un = (s_un[j >> 5] >> (j & 31)) & 1u;
+                            const uint32_t o2 = f2ord(v2);
+                            gl_min_u64(a.dkey + j, ((uint64_t)o2 << 32) | (uint32_t)step);
+                            lds_min_u64(bmin + (j >> 6), ((uint64_t)o2 << 32) | (un ? 0u : 0x80000000u) | (uint32_t)j);
+                            if (un) atomicMin(&s_T, o2);
+                        }
+                    }
+                    LZ_STAMP(4)
+                    const int nexc = s_nexc;
+                    if (nexc > 0 && lane < nexc) {
+                        const int j = s_exc[lane];
+                        const float vj = st_vget<LDS_STATE>(s_v, gv, j);
+                        const float v2 = (cost[(int64_t)i * ld + j] - vj) - h;
+                        const bool scn = (s_sc[j >> 5] >> (j & 31)) & 1u;
+                        if (!scn) {
+                            const bool un = (s_un[j >> 5] >> (j & 31)) & 1u;
+                            const uint32_t o2 = f2ord(v2);
+                            gl_min_u64(a.dkey + j, ((uint64_t)o2 << 32) | (uint32_t)step);
+                            lds_min_u64(bmin + (j >> 6), ((uint64_t)o2 << 32) | (un ? 0u : 0x80000000u) | (uint32_t)j);
+                            if (un) atomicMin(&s_T, o2);
+                        }
+                    }
+                    LZ_STAMP(5)
+                }
+            }
+            __syncthreads();                           // command posted; wave 0's global traffic drained
+            const int op = cmd.op;
+            if (op == LZ_ERR) { err = CYTO_ERR_INTERNAL; break; }
+            if (op == LZ_END) break;
+            // ================= dense scan of row cmd.row (certificate failed): whole workgroup =================
+            {
+                const int i = cmd.row, step = cmd.step;
+                const float h = cmd.h;
+                const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float *>(cost + (int64_t)i * ld), 0, (int)(ld * 4), 0x00020000);
+                float tl2 = INFINITY;
+                for (int q0 = 0; q0 < nquad; q0 += BLOCK2) {
+                    const int q = q0 + tid;
+                    uint64_t bk = KEYMAX;
+                    if (q < nquad) {
+                        const u32x4_t xr = __builtin_amdgcn_raw_buffer_load_b128(rr, q * 16, 0, 0);
+                        float4 vv;
+                        if constexpr (LDS_STATE) vv = *reinterpret_cast<const float4 *>(s_v + q * 4);
+                        else {
+                            const u32x4_t vr = __builtin_amdgcn_raw_buffer_load_b128(rv, q * 16, 0, 0x10);
+                            vv = make_float4(__uint_as_float(vr.x), __uint_as_float(vr.y), __uint_as_float(vr.z), __uint_as_float(vr.w));
+                        }
+                        const uint32_t um = (s_un[q >> 3] >> ((q & 7) * 4)) & 0xFu;
+                        const uint32_t sm = (s_sc[q >> 3] >> ((q & 7) * 4)) & 0xFu;
+                        const float xs[4] = {__uint_as_float(xr.x), __uint_as_float(xr.y), __uint_as_float(xr.z), __uint_as_float(xr.w)};
+                        const float vs[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int c = q * 4 + e;
+                            if (c < n && !((sm >> e) & 1u)) {
+                                uint64_t dkc = ld_u64(a.dkey + c);
+                                const float v2 = (xs[e] - vs[e]) - h;
+                                const uint32_t o2 = f2ord(v2);
+                                if (o2 < (uint32_t)(dkc >> 32)) { dkc = ((uint64_t)o2 << 32) | (uint32_t)step; st_u64(a.dkey + c, dkc); }
+                                const bool un = (um >> e) & 1u;
+                                bk = umin64(bk, (dkc & 0xFFFFFFFF00000000ull) | (un ? 0u : 0x80000000u) | (uint32_t)c);
+                                if (un) tl2 = fminf(tl2, ord2f((uint32_t)(dkc >> 32)));
+                            }
+                        }
+                    }
+                    bk = min64_row_allreduce(bk);
+                    if ((lane & 15) == 0 && q < nquad) bmin[q >> 4] = bk;
+                }
+                {
+                    const uint32_t t2 = wg_min_u32(f2ord(tl2), s, par);
+                    if (tid == 0) atomicMin(&s_T, t2);
+                }
+                c_dense++;
+                __syncthreads();
+            }
+        }
+        if (err) break;
+        // ================= price update, path flip =================
+        level = cmd.level; nscan = cmd.nscan; curmin = cmd.curmin; endofpath = cmd.endofpath;
+        for (int k = tid; k < nscan; k += BLOCK2) {
+            if (ld_i32(a.slevel + k) < level) {
+                const int j = ld_i32(a.slist + k);
+                const float vold = st_vget<LDS_STATE>(s_v, gv, j);
+                const float vnew = ld_f32(a.sumvd + j) - curmin;
+                st_vset<LDS_STATE>(s_v, gv, j, vnew);
+                if (vnew > vold) {       // rounding pushed a price UP: column j leaves the cache certificates
+                    const int e = atomicAdd(&s_nexc, 1);
+                    if (e < LZ_MAXEXC) s_exc[e] = j;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (s_nexc > LZ_MAXEXC) err = CYTO_ERR_INTERNAL;
+            int ep = endofpath;
+            int i = ld_i32(a.srow + (int32_t)(uint32_t)ld_u64(a.dkey + ep));
+            for (;;) {
+                st_csset<LDS_STATE>(s_cs, a.colsol, ep, i);
+                st_f32(a.cassign + ep, cost[(int64_t)i * ld + ep]);
+                const int j1 = ep;
+                ep = ld_i32(a.rowsol + i);
+                st_i32(a.rowsol + i, j1);
+                c_hops++;
+                if (i == freerow) break;
+                i = ld_i32(a.srow + ld_i32(a.predstep + ep));
+            }
+            s_un[endofpath >> 5] &= ~(1u << (endofpath & 31));
+            cmd.err = err;
+        }
+        c_augs++;
+        __syncthreads();
+        err = cmd.err;
+    }
+    // ---- write back prices and colsol, then duals u and the total ----
+    if constexpr (LDS_STATE) {
+        for (int c = tid; c < n; c += BLOCK2) {
+            gv[c] = s_v[c];
+            const uint16_t cs = s_cs[c];
+            a.colsol[c] = cs == 0xFFFFu ? -1 : (int32_t)cs;
+        }
+    }
+    __syncthreads();
+    double part = 0.0;
+    for (int i = tid; i < n; i += BLOCK2) {
+        const int j = ld_i32(a.rowsol + i);
+        const float cij = cost[(int64_t)i * ld + j];
+        const float vj = ld_f32(gv + j);
+        a.gu[i] = cij - vj;
+        part += (double)cij;
+    }
+#pragma unroll
+    for (int off2 = 32; off2 >= 1; off2 >>= 1) part += __shfl_xor(part, off2);
+    if (lane == 0) s.sum[wave] = part;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < NW2; w++) t += s.sum[w];
+        *reinterpret_cast<double *>(a.misc + 8) = t;
+        long long *counters = reinterpret_cast<long long *>(a.misc + 16);
+        counters[C_AUG_INIT] = c_augs; counters[C_AUG_RELAX] = c_relax; counters[C_AUGS] = c_augs; counters[C_HOPS] = c_hops;
+        counters[C_ROWS_READ] = counters[C2_DENSE_REFRESH] + c_augs + c_dense;
+        counters[C2_AUG_SKIPPED] = c_skipped;
+        counters[C2_AUG_DENSE] = c_dense;
+        *reinterpret_cast<int *>(a.misc + 4) = err;
+#ifdef LZ_PROF
+        long long *pp = reinterpret_cast<long long *>(a.misc + 152);
+        for (int k = 0; k < 6; k++) { pp[k] = prof[k]; pp[6 + k] = profn[k]; }
+#endif
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 struct CoopPlan { bool enabled; CoopArgs args; size_t shm; };
+struct LazyPlan { bool enabled, lds_state; LazyArgs args; size_t shm; };
 template <int CH, bool LDS_STATE>
 static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_cache_done, hipEvent_t ev_arr_done, hipStream_t stream,
-                         const CoopPlan &plan) {
+                         const CoopPlan &plan, const LazyPlan &lz) {
     const bool coop = plan.enabled;
     CoopArgs ca = plan.args;
     const size_t coop_shm = plan.shm;
@@ -2141,6 +2548,25 @@ static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_c
     hipLaunchKernelGGL(kern, dim3(1), dim3(BLOCK2), shmem, stream, args);
     CYTO_HIP(hipGetLastError());
     CYTO_HIP(hipEventRecord(ev_arr_done, stream));
+    if (lz.enabled) {
+        // fresh caches (floors against the prices the augmentation starts from), then the cache-certified search
+        if constexpr (CH == 0)
+            hipLaunchKernelGGL(build_row_caches_stream, dim3(cache_grid), dim3(BLOCK2), 0, stream, args.n, args.ld, args.cost,
+                               (const float *)args.fws, args.cache_col, args.cache_val);
+        else
+            hipLaunchKernelGGL((build_row_caches<CH>), dim3(cache_grid), dim3(BLOCK2), 0, stream, args.n, args.ld, args.cost,
+                               (const float *)args.fws, args.cache_col, args.cache_val);
+        CYTO_HIP(hipGetLastError());
+        if (lz.lds_state) {
+            CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jv_aug_lazy<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lz.shm));
+            hipLaunchKernelGGL(jv_aug_lazy<true>, dim3(1), dim3(BLOCK2), lz.shm, stream, lz.args);
+        } else {
+            CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jv_aug_lazy<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lz.shm));
+            hipLaunchKernelGGL(jv_aug_lazy<false>, dim3(1), dim3(BLOCK2), lz.shm, stream, lz.args);
+        }
+        CYTO_HIP(hipGetLastError());
+        return CYTO_OK;
+    }
     if (coop) {
         CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jv_aug_coop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_shm));
     }
@@ -2296,6 +2722,36 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
             // duplicate-row skip: per-group state in LDS when it fits beside v (4 B) and colsol (2 B) per column
             c2.rowgid = b_gid.as<int32_t>(); c2.ngroups = h_ngroups; c2.gmode = 0; c2.g_hbest = nullptr; c2.g_hstamp = nullptr;
             c2.auxlds = 0;
+            // ---- cache-certified augmentation (CYTO_AUG=lazy) ----
+            LazyPlan lz; memset(&lz, 0, sizeof lz);
+            DevBuf b_lzhb, b_lzhs;
+            {
+                const char *e = getenv("CYTO_AUG");
+                if (e && strcmp(e, "lazy") == 0) {
+                    const size_t npad6 = (((size_t)((n + 3) & ~3) * 6) + 15) & ~(size_t)15, nb24 = (size_t)((((n + 63) / 64) + 511) & ~511) * 8 + (size_t)((n + 63) / 64) * 16;
+                    const size_t lds_budget = 160 * 1024 - 2048;       // static __shared__ of the kernel
+                    lz.enabled = true;
+                    lz.lds_state = n <= 65535 && !getenv("CYTO_FORCE_STREAM") && npad6 + nb24 <= lds_budget;
+                    lz.shm = (lz.lds_state ? npad6 : 0) + nb24;
+                    LazyArgs &la = lz.args;
+                    la.n = n; la.ld = dld; la.cost = dcost; la.gv = d_v; la.gu = d_u; la.sumvd = d_v + 2 * (int64_t)n;
+                    la.cassign = d_v + 3 * (int64_t)n; la.dkey = reinterpret_cast<uint64_t *>(d_v + 4 * (int64_t)n);
+                    la.rowsol = d_rowsol; la.colsol = d_colsol; la.freerows = d_free; la.predstep = d_rowsol + 5 * (int64_t)n;
+                    la.srow = d_rowsol + 6 * (int64_t)n;      // [n+1]: runs into the next slot, which the lazy path does not use
+                    la.slist = d_rowsol + 8 * (int64_t)n; la.slevel = d_rowsol + 9 * (int64_t)n;
+                    la.rowgid = b_gid.as<int32_t>(); la.cache_col = b_ccol.as<uint32_t>(); la.cache_val = b_cval.as<float>();
+                    la.misc = b_misc.as<char>(); la.ngroups = h_ngroups; la.gmode = 0; la.g_hbest = nullptr; la.g_hstamp = nullptr;
+                    if (want_groups && h_ngroups < n) {
+                        if (lz.shm + (size_t)h_ngroups * 8 <= lds_budget) { la.gmode = 1; lz.shm += (size_t)h_ngroups * 8; }
+                        else {
+                            la.gmode = 2;
+                            if ((rc = b_lzhb.alloc((size_t)h_ngroups * 4)) || (rc = b_lzhs.alloc((size_t)h_ngroups * 4))) { cleanup(); return rc; }
+                            CYTO_HIP(hipMemsetAsync(b_lzhs.p, 0, (size_t)h_ngroups * 4, stream));
+                            la.g_hbest = b_lzhb.as<float>(); la.g_hstamp = b_lzhs.as<int32_t>();
+                        }
+                    }
+                }
+            }
             if (want_groups && h_ngroups < n) {
                 // LDS beside the group state: v (4 B) + colsol (2 B) per column on the LDS-resident path,
                 // the unassigned-column bitmap on the streaming path
@@ -2360,16 +2816,16 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
             const bool force_stream = getenv("CYTO_FORCE_STREAM") != nullptr;
             // (=2: also the streaming dense refresh used beyond 32768 columns)
             const bool force_refresh_stream = force_stream && strcmp(getenv("CYTO_FORCE_STREAM"), "2") == 0;
-            if (force_refresh_stream) rc = launch_chain2<0, false>(c2, cache_grid, e1c, e1d, stream, plan);
-            else if (force_stream && n <= 5 * per2) rc = launch_chain2<5, false>(c2, cache_grid, e1c, e1d, stream, plan);
-            else if (force_stream && n <= 16 * per2) rc = launch_chain2<16, false>(c2, cache_grid, e1c, e1d, stream, plan);
-            else if (force_stream) rc = launch_chain2<0, false>(c2, cache_grid, e1c, e1d, stream, plan);
-            else if (n <= 2 * per2) rc = launch_chain2<2, true>(c2, cache_grid, e1c, e1d, stream, plan);
-            else if (n <= 5 * per2) rc = launch_chain2<5, true>(c2, cache_grid, e1c, e1d, stream, plan);
-            else if (n <= 10 * per2) rc = launch_chain2<10, true>(c2, cache_grid, e1c, e1d, stream, plan);
-            else if (n <= 13 * per2) rc = launch_chain2<13, true>(c2, cache_grid, e1c, e1d, stream, plan);
-            else if (n <= 16 * per2) rc = launch_chain2<16, false>(c2, cache_grid, e1c, e1d, stream, plan);
-            else rc = launch_chain2<0, false>(c2, cache_grid, e1c, e1d, stream, plan);   // streaming dense refresh, any n
+            if (force_refresh_stream) rc = launch_chain2<0, false>(c2, cache_grid, e1c, e1d, stream, plan, lz);
+            else if (force_stream && n <= 5 * per2) rc = launch_chain2<5, false>(c2, cache_grid, e1c, e1d, stream, plan, lz);
+            else if (force_stream && n <= 16 * per2) rc = launch_chain2<16, false>(c2, cache_grid, e1c, e1d, stream, plan, lz);
+            else if (force_stream) rc = launch_chain2<0, false>(c2, cache_grid, e1c, e1d, stream, plan, lz);
+            else if (n <= 2 * per2) rc = launch_chain2<2, true>(c2, cache_grid, e1c, e1d, stream, plan, lz);
+            else if (n <= 5 * per2) rc = launch_chain2<5, true>(c2, cache_grid, e1c, e1d, stream, plan, lz);
+            else if (n <= 10 * per2) rc = launch_chain2<10, true>(c2, cache_grid, e1c, e1d, stream, plan, lz);
+            else if (n <= 13 * per2) rc = launch_chain2<13, true>(c2, cache_grid, e1c, e1d, stream, plan, lz);
+            else if (n <= 16 * per2) rc = launch_chain2<16, false>(c2, cache_grid, e1c, e1d, stream, plan, lz);
+            else rc = launch_chain2<0, false>(c2, cache_grid, e1c, e1d, stream, plan, lz);   // streaming dense refresh, any n
         }
     } else {
         CYTO_HIP(hipEventRecord(e1c, stream));
@@ -2384,9 +2840,18 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
     CYTO_HIP(hipStreamSynchronize(stream));
 
     int h_status = 0;
-    long long h_counters[C2_NCOUNTERS] = {0};
+    long long h_counters[C3_NCOUNTERS] = {0};
     CYTO_HIP(hipMemcpy(&h_status, d_status, sizeof(int), hipMemcpyDeviceToHost));
     CYTO_HIP(hipMemcpy(h_counters, d_counters, sizeof(h_counters), hipMemcpyDeviceToHost));
+#ifdef LZ_PROF
+    {
+        long long pp[12];
+        CYTO_HIP(hipMemcpy(pp, b_misc.as<char>() + 152, sizeof pp, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[lazy prof] cycles:");
+        for (int k = 1; k < 6; k++) fprintf(stderr, " seg%d %.0f/step (n=%lld)", k, pp[6 + k] ? (double)pp[k] / pp[6 + k] : 0.0, pp[6 + k]);
+        fprintf(stderr, "\n");
+    }
+#endif
     if (rowsol) CYTO_HIP(hipMemcpy(rowsol, d_rowsol, nI, hipMemcpyDeviceToHost));
     if (colsol) CYTO_HIP(hipMemcpy(colsol, d_colsol, nI, hipMemcpyDeviceToHost));
     if (u) CYTO_HIP(hipMemcpy(u, d_u, nT, hipMemcpyDeviceToHost));
@@ -2413,6 +2878,7 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
         info->hbm_row_reads = n + (fast ? n : 0) + h_counters[C_ROWS_READ];
         info->dense_refreshes = fast ? h_counters[C2_DENSE_REFRESH] : 0;
         info->aug_scans_skipped = fast ? h_counters[C2_AUG_SKIPPED] : 0;
+        info->aug_dense_scans = fast ? h_counters[C2_AUG_DENSE] : 0;
         info->row_groups = h_ngroups;
     }
     cleanup();

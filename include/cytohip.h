@@ -72,7 +72,8 @@ typedef struct {
     double ms_aug;           /* float32 path: the augmentation kernel (jv_aug2) alone */
     int64_t aug_scans_skipped; /* augmentation scans elided as provable no-ops (duplicate rows) */
     int64_t row_groups;      /* number of runs of bitwise identical consecutive rows (== n: none) */
-    int64_t reserved[2];
+    int64_t aug_dense_scans; /* augmentation scans that had to read the full cost row (cache certificate failed) */
+    int64_t reserved[1];
 } cyto_lap_info;
 
 int cyto_lap_f32(int n, const float *cost, int64_t ld, int cost_on_device,

@@ -204,3 +204,24 @@ def test_cooperative_augmentation_forced(monkeypatch, W, stride):
     monkeypatch.setenv("CYTO_FORCE_STREAM", "2")
     c = np.random.default_rng(5).random((1500, 1500)).astype(np.float32)
     _check(c, np.float32)
+
+
+def test_cache_certified_augmentation_forced(monkeypatch):
+    # CYTO_AUG=lazy: the augmentation relaxes only the cached columns of a row whenever the cache floor
+    # certifies that no other column can matter; results must stay bit-identical to the oracle.
+    monkeypatch.setenv("CYTO_AUG", "lazy")
+    for n in (1, 2, 5, 64, 65, 257, 700, 2300, 5000):
+        c = np.random.default_rng(n).random((n, n)).astype(np.float32)
+        _check(c, np.float32)
+    rng = np.random.default_rng(8)
+    base = -(rng.random((300, 1500)) ** 3).astype(np.float32)
+    c = np.repeat(base, 5, axis=0)
+    g = lap_solve(c, np.float32, return_info=True)
+    _check(c, np.float32)
+    assert g["info"].aug_scans_skipped > 0 and g["info"].aug_dense_scans < g["info"].scans_aug_relax
+    c = np.random.default_rng(3).integers(0, 10, (400, 400)).astype(np.float32)
+    _check(c, np.float32)
+    monkeypatch.setenv("CYTO_FORCE_STREAM", "2")
+    for n in (130, 1500):
+        c = np.random.default_rng(n + 1).random((n, n)).astype(np.float32)
+        _check(c, np.float32)
