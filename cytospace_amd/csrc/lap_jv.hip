@@ -2234,6 +2234,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
     long long c_relax = 0, c_hops = 0, c_augs = 0, c_skipped = 0, c_dense = 0;
     int err = 0;
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(gv, 0, nquad * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdk = __builtin_amdgcn_make_buffer_rsrc(a.dkey, 0, nquad * 32, 0x00020000);
 
     for (int f = 0; f < numfree && !err; f++) {
         const int freerow = __builtin_amdgcn_readfirstlane(ld_i32(a.freerows + f));
@@ -2258,6 +2259,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                     const uint32_t um = (s_un[q >> 3] >> ((q & 7) * 4)) & 0xFu;
                     const float xs[4] = {__uint_as_float(xr.x), __uint_as_float(xr.y), __uint_as_float(xr.z), __uint_as_float(xr.w)};
                     const float vs[4] = {vv.x, vv.y, vv.z, vv.w};
+                    uint64_t dq[4] = {0, 0, 0, 0};
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const int c = q * 4 + e;
@@ -2265,11 +2267,16 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                             const float dd = xs[e] - vs[e];
                             const uint32_t od = f2ord(dd);
                             const bool un = (um >> e) & 1u;
-                            st_u64(a.dkey + c, (uint64_t)od << 32);            // step 0 = the free row
+                            dq[e] = (uint64_t)od << 32;                       // step 0 = the free row
                             bk = umin64(bk, ((uint64_t)od << 32) | (un ? 0u : 0x80000000u) | (uint32_t)c);
                             if (un) tl = fminf(tl, dd);
                         }
                     }
+                    // dkey has npad entries: whole quads are stored (the pad words are never read)
+                    const u32x4_t w0 = {(uint32_t)dq[0], (uint32_t)(dq[0] >> 32), (uint32_t)dq[1], (uint32_t)(dq[1] >> 32)};
+                    const u32x4_t w1 = {(uint32_t)dq[2], (uint32_t)(dq[2] >> 32), (uint32_t)dq[3], (uint32_t)(dq[3] >> 32)};
+                    __builtin_amdgcn_raw_buffer_store_b128(w0, rdk, q * 32, 0, 0x10);
+                    __builtin_amdgcn_raw_buffer_store_b128(w1, rdk, q * 32 + 16, 0, 0x10);
                 }
                 bk = min64_row_allreduce(bk);          // 16 lanes = 16 quads = one block of 64 columns
                 if ((lane & 15) == 0 && q < nquad) bmin[q >> 4] = bk;
@@ -2298,7 +2305,15 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
 #pragma unroll
                         for (int u = 0; u < 8; u++) k = umin64(k, kk[u]);
                     }
-                    k = wave_lexmin_u64(k);
+                    {   // value first; the low word only needs a second reduction when several lanes tie on d
+                        const uint32_t hi = (uint32_t)(k >> 32);
+                        const uint32_t m = wave_min_u32(hi);
+                        const uint64_t eq = __ballot(hi == m);
+                        uint32_t lo;
+                        if (__builtin_popcountll(eq) == 1) lo = readlane32((uint32_t)k, __builtin_ctzll(eq));
+                        else lo = wave_min_u32(hi == m ? (uint32_t)k : 0xFFFFFFFFu);
+                        k = ((uint64_t)m << 32) | lo;
+                    }
                     const float dmin = key_val(k);
                     if (k == KEYMAX || !(dmin < INFINITY)) { if (lane == 0) { cmd.op = LZ_ERR; } break; }
                     const int jp = (int)((uint32_t)k & 0x7FFFFFFFu);
@@ -2306,7 +2321,9 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                     if (!have || dmin != curmin) { level++; curmin = dmin; have = true; }
                     if (!((uint32_t)k & 0x80000000u)) {
                         endofpath = jp;
-                        if (lane == 0) { cmd.op = LZ_END; cmd.endofpath = jp; cmd.level = level; cmd.nscan = nscan; cmd.curmin = curmin; }
+                        if (lane == 0) {
+                            cmd.op = LZ_END; cmd.endofpath = jp; cmd.level = level; cmd.nscan = nscan; cmd.curmin = curmin;
+                        }
                         break;
                     }
                     const int i = __builtin_amdgcn_readfirstlane(st_csget<LDS_STATE>(s_cs, a.colsol, jp));
@@ -2315,11 +2332,12 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                     const int blk = jp >> 6;
                     const int jb = blk * 64 + lane;
                     // independent loads: c[i][jp], the row's cache, the picked column's block, the row's group
+                    // (the cache row last: a skipped scan continues without waiting for it)
                     const float cip_raw = ld_f32(a.cassign + jp);
-                    const uint32_t cc = ld_u32(a.cache_col + (int64_t)i * KC + lane);
-                    const float cv = ld_f32(a.cache_val + (int64_t)i * KC + lane);
                     const uint64_t dk = jb < n ? ld_u64(a.dkey + jb) : 0ull;
                     const int g_raw = gmode ? a.rowgid[i] : 0;
+                    const uint32_t cc = ld_u32(a.cache_col + (int64_t)i * KC + lane);
+                    const float cv = ld_f32(a.cache_val + (int64_t)i * KC + lane);
                     // retire column jp
                     if (lane == 0) {
                         st_i32(a.slist + nscan, jp); st_i32(a.slevel + nscan, level); st_f32(a.sumvd + jp, vjp + dmin);
@@ -2345,9 +2363,15 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                     // new minimum of the picked column's block (this step's relaxations are applied after it)
                     {
                         const bool live = jb < n && !((scw >> (lane & 31)) & 1u);
+                        const bool unb = (unw >> (lane & 31)) & 1u;
+                        const uint32_t hi = live ? (uint32_t)(dk >> 32) : 0xFFFFFFFFu;
+                        const uint32_t m = wave_min_u32(hi);
+                        const uint64_t eq = __ballot(live && hi == m), equ = __ballot(live && hi == m && unb);
                         uint64_t kb = KEYMAX;
-                        if (live) kb = (dk & 0xFFFFFFFF00000000ull) | (((unw >> (lane & 31)) & 1u) ? 0u : 0x80000000u) | (uint32_t)jb;
-                        kb = wave_lexmin_u64(kb);
+                        if (eq) {   // lane order is column order inside a block: lowest unassigned lane, else lowest lane
+                            const int wl = equ ? __builtin_ctzll(equ) : __builtin_ctzll(eq);
+                            kb = ((uint64_t)m << 32) | (equ ? 0u : 0x80000000u) | (uint32_t)(blk * 64 + wl);
+                        }
                         if (lane == 0) bmin[blk] = kb;
                     }
                     nscan++;
@@ -2646,7 +2670,7 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
 
     DevBuf b_fws, b_iws, b_imin, b_pmin, b_parg, b_misc;
     const size_t nT = (size_t)n * sizeof(T), nI = (size_t)n * sizeof(int32_t);
-    if ((rc = b_fws.alloc(6 * nT)) || (rc = b_iws.alloc(10 * nI)) || (rc = b_imin.alloc(nI)) ||
+    if ((rc = b_fws.alloc(6 * nT + 64)) || (rc = b_iws.alloc(10 * nI + 64)) || (rc = b_imin.alloc(nI)) ||
         (rc = b_pmin.alloc((size_t)rowblocks * nT)) || (rc = b_parg.alloc((size_t)rowblocks * nI)) || (rc = b_misc.alloc(256)))
         return rc;
     // float workspace: v | u ; int workspace: rowsol | colsol | matches | freerows | rtrows | pred
@@ -2726,8 +2750,10 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
             LazyPlan lz; memset(&lz, 0, sizeof lz);
             DevBuf b_lzhb, b_lzhs;
             {
+                // default for n >= 12288 (below that the register-resident dense search is faster); CYTO_AUG=lazy
+                // forces it at any size, CYTO_AUG=single|stream|coop selects the older kernels
                 const char *e = getenv("CYTO_AUG");
-                if (e && strcmp(e, "lazy") == 0) {
+                if (e ? strcmp(e, "lazy") == 0 : n >= 12288) {
                     const size_t npad6 = (((size_t)((n + 3) & ~3) * 6) + 15) & ~(size_t)15, nb24 = (size_t)((((n + 63) / 64) + 511) & ~511) * 8 + (size_t)((n + 63) / 64) * 16;
                     const size_t lds_budget = 160 * 1024 - 2048;       // static __shared__ of the kernel
                     lz.enabled = true;
