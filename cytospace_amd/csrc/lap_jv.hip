@@ -2149,8 +2149,8 @@ struct LazyArgs {
     int ngroups, gmode;
 };
 struct LazyCmd { int op, row, step, endofpath, level, nscan, err; float h, curmin; };
-enum { LZ_DENSE = 1, LZ_END = 2, LZ_ERR = 3 };
-enum { C2_AUG_DENSE = C2_NCOUNTERS, C3_NCOUNTERS };
+enum { LZ_DENSE = 1, LZ_END = 2, LZ_ERR = 3, LZ_INIT_DENSE = 4 };
+enum { C2_AUG_DENSE = C2_NCOUNTERS, C2_AUG_SPARSE_INIT, C3_NCOUNTERS };
 constexpr int LZ_MAXEXC = 64;
 
 __device__ __forceinline__ void lds_min_u64(uint64_t *p, uint64_t x) {
@@ -2168,6 +2168,19 @@ __device__ __forceinline__ void gl_min_u64(uint64_t *p, uint64_t x) {
 #define LZ_STAMP(k)
 #define LZ_WAITVM
 #endif
+constexpr uint64_t LZ_INFKEY = 0xFFFFFFFF00000000ull;   // "no distance yet": any real d wins the unsigned min
+// Before a column's word is used in this search its block of 64 words must hold this search's values:
+// blocks are reset lazily (all 64 words = "no distance") the first time a search touches them.
+__device__ __forceinline__ void lz_touch_blocks(bool act, int myblk, uint64_t *dkey, int32_t *s_ep, int stamp, int npad, int lane) {
+    uint64_t todo = __ballot(act && s_ep[myblk] != stamp);
+    while (todo) {
+        const int l = __builtin_ctzll(todo);
+        const int b = (int)readlane32((uint32_t)myblk, l);
+        if (b * 64 + lane < npad) st_u64(dkey + b * 64 + lane, LZ_INFKEY);
+        if (lane == 0) s_ep[b] = stamp;
+        todo &= ~__ballot(myblk == b);
+    }
+}
 // lexicographic minimum of 64-bit keys over a wave as two 32-bit all-reduces (value, then the low word
 // among the lanes holding that value): much shorter dependency chains than a 64-bit DPP butterfly
 __device__ __forceinline__ uint64_t wave_lexmin_u64(uint64_t k) {
@@ -2206,6 +2219,8 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
     uint64_t *bmin = reinterpret_cast<uint64_t *>(dyn_lds + off); off += (size_t)nbp * 8;
     uint32_t *s_sc = reinterpret_cast<uint32_t *>(dyn_lds + off); off += (size_t)nb * 8;   // 2 words per block
     uint32_t *s_un = reinterpret_cast<uint32_t *>(dyn_lds + off); off += (size_t)nb * 8;
+    int32_t *s_ep = reinterpret_cast<int32_t *>(dyn_lds + off); off += (size_t)nb * 4;   // search stamp of each block's dkey words
+    off = (off + 7) & ~(size_t)7;
     const int gmode = a.gmode;
     float *hb = a.g_hbest;
     int32_t *hs = a.g_hstamp;
@@ -2228,6 +2243,8 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
         s_un[w] = m;
     }
     if (tid == 0) s_nexc = 0;
+    for (int b = tid; b < nb; b += BLOCK2) s_ep[b] = 0;
+    long long c_sparse = 0;
     for (int b = nb + tid; b < nbp; b += BLOCK2) bmin[b] = KEYMAX;
     __syncthreads();
     const int numfree = *reinterpret_cast<const int *>(a.misc + 128);
@@ -2239,62 +2256,46 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
     for (int f = 0; f < numfree && !err; f++) {
         const int freerow = __builtin_amdgcn_readfirstlane(ld_i32(a.freerows + f));
         const int stamp = f + 1;
-        // ================= init: d = c[freerow] - v for every column (whole workgroup) =================
+        // ================= per-search reset (LDS only): scanned bits, block minima =================
         for (int w = tid; w < 2 * nb; w += BLOCK2) s_sc[w] = 0;
-        float tl = INFINITY;
-        {
-            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float *>(cost + (int64_t)freerow * ld), 0, (int)(ld * 4), 0x00020000);
-            for (int q0 = 0; q0 < nquad; q0 += BLOCK2) {
-                const int q = q0 + tid;
-                uint64_t bk = KEYMAX;
-                if (q < nquad) {
-                    const u32x4_t xr = __builtin_amdgcn_raw_buffer_load_b128(rr, q * 16, 0, 0);
-                    float4 vv;
-                    if constexpr (LDS_STATE) vv = *reinterpret_cast<const float4 *>(s_v + q * 4);
-                    else {
-                        const u32x4_t vr = __builtin_amdgcn_raw_buffer_load_b128(rv, q * 16, 0, 0x10);
-                        vv = make_float4(__uint_as_float(vr.x), __uint_as_float(vr.y), __uint_as_float(vr.z), __uint_as_float(vr.w));
-                    }
-                    const uint32_t um = (s_un[q >> 3] >> ((q & 7) * 4)) & 0xFu;
-                    const float xs[4] = {__uint_as_float(xr.x), __uint_as_float(xr.y), __uint_as_float(xr.z), __uint_as_float(xr.w)};
-                    const float vs[4] = {vv.x, vv.y, vv.z, vv.w};
-                    uint64_t dq[4] = {0, 0, 0, 0};
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int c = q * 4 + e;
-                        if (c < n) {
-                            const float dd = xs[e] - vs[e];
-                            const uint32_t od = f2ord(dd);
-                            const bool un = (um >> e) & 1u;
-                            dq[e] = (uint64_t)od << 32;                       // step 0 = the free row
-                            bk = umin64(bk, ((uint64_t)od << 32) | (un ? 0u : 0x80000000u) | (uint32_t)c);
-                            if (un) tl = fminf(tl, dd);
-                        }
-                    }
-                    // dkey has npad entries: whole quads are stored (the pad words are never read)
-                    const u32x4_t w0 = {(uint32_t)dq[0], (uint32_t)(dq[0] >> 32), (uint32_t)dq[1], (uint32_t)(dq[1] >> 32)};
-                    const u32x4_t w1 = {(uint32_t)dq[2], (uint32_t)(dq[2] >> 32), (uint32_t)dq[3], (uint32_t)(dq[3] >> 32)};
-                    __builtin_amdgcn_raw_buffer_store_b128(w0, rdk, q * 32, 0, 0x10);
-                    __builtin_amdgcn_raw_buffer_store_b128(w1, rdk, q * 32 + 16, 0, 0x10);
-                }
-                bk = min64_row_allreduce(bk);          // 16 lanes = 16 quads = one block of 64 columns
-                if ((lane & 15) == 0 && q < nquad) bmin[q >> 4] = bk;
-            }
-        }
-        if (tid == 0) st_i32(a.srow, freerow);
-        {
-            const uint32_t t0 = wg_min_u32(f2ord(tl), s, par);
-            if (tid == 0) s_T = t0;
-        }
+        for (int b = tid; b < nb; b += BLOCK2) bmin[b] = KEYMAX;
         __syncthreads();
         // ================= search =================
         bool have = false;
         float curmin = 0.0f;
         int level = 0, nscan = 0, endofpath = -1;
+        bool started = false;
         for (;;) {
             if (wave == 0) {
-                for (;;) {
+                bool go = true;
+                if (!started) {
+                    // ---- certified sparse init: if the free row's cache floor is above the distance of an
+                    // unassigned cached column, no column outside the cache can matter in this search ----
+                    started = true;
+                    const uint32_t cc = ld_u32(a.cache_col + (int64_t)freerow * KC + lane);
+                    const float cv = ld_f32(a.cache_val + (int64_t)freerow * KC + lane);
+                    const bool valid = lane < KCU && cc != COLSENT;
+                    const int j = valid ? (int)cc : 0;
+                    const float dd = cv - st_vget<LDS_STATE>(s_v, gv, j);
+                    const bool un = valid && ((s_un[j >> 5] >> (j & 31)) & 1u);
+                    const uint32_t t0 = wave_min_u32(un ? f2ord(dd) : 0xFFFFFFFFu);
+                    const float floor_f = __uint_as_float(readlane32(__float_as_uint(cv), KCU));
+                    if (s_nexc == 0 && t0 != 0xFFFFFFFFu && floor_f > ord2f(t0)) {
+                        const bool act = valid && !(dd > ord2f(t0));
+                        lz_touch_blocks(act, j >> 6, a.dkey, s_ep, stamp, npad, lane);
+                        if (act) {
+                            const uint32_t od = f2ord(dd);
+                            st_u64(a.dkey + j, (uint64_t)od << 32);                 // step 0 = the free row
+                            lds_min_u64(bmin + (j >> 6), ((uint64_t)od << 32) | (un ? 0u : 0x80000000u) | (uint32_t)j);
+                        }
+                        if (lane == 0) { s_T = t0; st_i32(a.srow, freerow); }
+                        c_sparse++;
+                    } else {
+                        if (lane == 0) cmd.op = LZ_INIT_DENSE;
+                        go = false;
+                    }
+                }
+                if (go) for (;;) {
                     LZ_STAMP(0)
                     // ---- pick: smallest (d, assigned?, column) over the block minima ----
                     uint64_t k = KEYMAX;
@@ -2385,12 +2386,15 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                         break;
                     }
                     // ---- cached relaxation: lane = cache entry; plus the (normally empty) exception list ----
-                    if (lane < KCU && cc != COLSENT) {
-                        const int j = (int)cc;
+                    {
+                        const bool valid = lane < KCU && cc != COLSENT;
+                        const int j = valid ? (int)cc : 0;
                         const float vj = st_vget<LDS_STATE>(s_v, gv, j);
                         const float v2 = (cv - vj) - h;
                         const bool scn = (s_sc[j >> 5] >> (j & 31)) & 1u;
-                        if (!scn && !(v2 > T)) {
+                        const bool act = valid && !scn && !(v2 > T);
+                        lz_touch_blocks(act, j >> 6, a.dkey, s_ep, stamp, npad, lane);
+                        if (act) {
                             const bool un = (s_un[j >> 5] >> (j & 31)) & 1u;
                             const uint32_t o2 = f2ord(v2);
                             gl_min_u64(a.dkey + j, ((uint64_t)o2 << 32) | (uint32_t)step);
@@ -2400,12 +2404,14 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                     }
                     LZ_STAMP(4)
                     const int nexc = s_nexc;
-                    if (nexc > 0 && lane < nexc) {
-                        const int j = s_exc[lane];
+                    if (nexc > 0) {
+                        const bool ev = lane < nexc;
+                        const int j = ev ? s_exc[lane] : 0;
                         const float vj = st_vget<LDS_STATE>(s_v, gv, j);
-                        const float v2 = (cost[(int64_t)i * ld + j] - vj) - h;
+                        const float v2 = ev ? (cost[(int64_t)i * ld + j] - vj) - h : 0.0f;
                         const bool scn = (s_sc[j >> 5] >> (j & 31)) & 1u;
-                        if (!scn) {
+                        lz_touch_blocks(ev && !scn, j >> 6, a.dkey, s_ep, stamp, npad, lane);
+                        if (ev && !scn) {
                             const bool un = (s_un[j >> 5] >> (j & 31)) & 1u;
                             const uint32_t o2 = f2ord(v2);
                             gl_min_u64(a.dkey + j, ((uint64_t)o2 << 32) | (uint32_t)step);
@@ -2420,6 +2426,57 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
             const int op = cmd.op;
             if (op == LZ_ERR) { err = CYTO_ERR_INTERNAL; break; }
             if (op == LZ_END) break;
+            if (op == LZ_INIT_DENSE) {
+                // ================= dense init: d = c[freerow] - v for every column (whole workgroup) =================
+                        float tl = INFINITY;
+                {
+                    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<float *>(cost + (int64_t)freerow * ld), 0, (int)(ld * 4), 0x00020000);
+                    for (int q0 = 0; q0 < nquad; q0 += BLOCK2) {
+                        const int q = q0 + tid;
+                        uint64_t bk = KEYMAX;
+                        if (q < nquad) {
+                            const u32x4_t xr = __builtin_amdgcn_raw_buffer_load_b128(rr, q * 16, 0, 0);
+                            float4 vv;
+                            if constexpr (LDS_STATE) vv = *reinterpret_cast<const float4 *>(s_v + q * 4);
+                            else {
+                                const u32x4_t vr = __builtin_amdgcn_raw_buffer_load_b128(rv, q * 16, 0, 0x10);
+                                vv = make_float4(__uint_as_float(vr.x), __uint_as_float(vr.y), __uint_as_float(vr.z), __uint_as_float(vr.w));
+                            }
+                            const uint32_t um = (s_un[q >> 3] >> ((q & 7) * 4)) & 0xFu;
+                            const float xs[4] = {__uint_as_float(xr.x), __uint_as_float(xr.y), __uint_as_float(xr.z), __uint_as_float(xr.w)};
+                            const float vs[4] = {vv.x, vv.y, vv.z, vv.w};
+                            uint64_t dq[4] = {0, 0, 0, 0};
+        #pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const int c = q * 4 + e;
+                                if (c < n) {
+                                    const float dd = xs[e] - vs[e];
+                                    const uint32_t od = f2ord(dd);
+                                    const bool un = (um >> e) & 1u;
+                                    dq[e] = (uint64_t)od << 32;                       // step 0 = the free row
+                                    bk = umin64(bk, ((uint64_t)od << 32) | (un ? 0u : 0x80000000u) | (uint32_t)c);
+                                    if (un) tl = fminf(tl, dd);
+                                }
+                            }
+                            // dkey has npad entries: whole quads are stored (the pad words are never read)
+                            const u32x4_t w0 = {(uint32_t)dq[0], (uint32_t)(dq[0] >> 32), (uint32_t)dq[1], (uint32_t)(dq[1] >> 32)};
+                            const u32x4_t w1 = {(uint32_t)dq[2], (uint32_t)(dq[2] >> 32), (uint32_t)dq[3], (uint32_t)(dq[3] >> 32)};
+                            __builtin_amdgcn_raw_buffer_store_b128(w0, rdk, q * 32, 0, 0x10);
+                            __builtin_amdgcn_raw_buffer_store_b128(w1, rdk, q * 32 + 16, 0, 0x10);
+                        }
+                        bk = min64_row_allreduce(bk);          // 16 lanes = 16 quads = one block of 64 columns
+                        if ((lane & 15) == 0 && q < nquad) { bmin[q >> 4] = bk; s_ep[q >> 4] = stamp; }
+                    }
+                }
+                if (tid == 0) st_i32(a.srow, freerow);
+                {
+                    const uint32_t t0 = wg_min_u32(f2ord(tl), s, par);
+                    if (tid == 0) s_T = t0;
+                }
+                __syncthreads();
+                continue;
+            }
             // ================= dense scan of row cmd.row (certificate failed): whole workgroup =================
             {
                 const int i = cmd.row, step = cmd.step;
@@ -2440,16 +2497,19 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                         }
                         const uint32_t um = (s_un[q >> 3] >> ((q & 7) * 4)) & 0xFu;
                         const uint32_t sm = (s_sc[q >> 3] >> ((q & 7) * 4)) & 0xFu;
+                        const bool fresh = s_ep[q >> 4] == stamp;
                         const float xs[4] = {__uint_as_float(xr.x), __uint_as_float(xr.y), __uint_as_float(xr.z), __uint_as_float(xr.w)};
                         const float vs[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
                             const int c = q * 4 + e;
                             if (c < n && !((sm >> e) & 1u)) {
-                                uint64_t dkc = ld_u64(a.dkey + c);
+                                uint64_t dkc = fresh ? ld_u64(a.dkey + c) : LZ_INFKEY;
                                 const float v2 = (xs[e] - vs[e]) - h;
                                 const uint32_t o2 = f2ord(v2);
-                                if (o2 < (uint32_t)(dkc >> 32)) { dkc = ((uint64_t)o2 << 32) | (uint32_t)step; st_u64(a.dkey + c, dkc); }
+                                bool wr = !fresh;
+                                if (o2 < (uint32_t)(dkc >> 32)) { dkc = ((uint64_t)o2 << 32) | (uint32_t)step; wr = true; }
+                                if (wr) st_u64(a.dkey + c, dkc);
                                 const bool un = (um >> e) & 1u;
                                 bk = umin64(bk, (dkc & 0xFFFFFFFF00000000ull) | (un ? 0u : 0x80000000u) | (uint32_t)c);
                                 if (un) tl2 = fminf(tl2, ord2f((uint32_t)(dkc >> 32)));
@@ -2457,7 +2517,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                         }
                     }
                     bk = min64_row_allreduce(bk);
-                    if ((lane & 15) == 0 && q < nquad) bmin[q >> 4] = bk;
+                    if ((lane & 15) == 0 && q < nquad) { bmin[q >> 4] = bk; s_ep[q >> 4] = stamp; }
                 }
                 {
                     const uint32_t t2 = wg_min_u32(f2ord(tl2), s, par);
@@ -2531,9 +2591,10 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
         *reinterpret_cast<double *>(a.misc + 8) = t;
         long long *counters = reinterpret_cast<long long *>(a.misc + 16);
         counters[C_AUG_INIT] = c_augs; counters[C_AUG_RELAX] = c_relax; counters[C_AUGS] = c_augs; counters[C_HOPS] = c_hops;
-        counters[C_ROWS_READ] = counters[C2_DENSE_REFRESH] + c_augs + c_dense;
+        counters[C_ROWS_READ] = counters[C2_DENSE_REFRESH] + (c_augs - c_sparse) + c_dense;
         counters[C2_AUG_SKIPPED] = c_skipped;
         counters[C2_AUG_DENSE] = c_dense;
+        counters[C2_AUG_SPARSE_INIT] = c_sparse;
         *reinterpret_cast<int *>(a.misc + 4) = err;
 #ifdef LZ_PROF
         long long *pp = reinterpret_cast<long long *>(a.misc + 152);
@@ -2754,7 +2815,7 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
                 // forces it at any size, CYTO_AUG=single|stream|coop selects the older kernels
                 const char *e = getenv("CYTO_AUG");
                 if (e ? strcmp(e, "lazy") == 0 : n >= 12288) {
-                    const size_t npad6 = (((size_t)((n + 3) & ~3) * 6) + 15) & ~(size_t)15, nb24 = (size_t)((((n + 63) / 64) + 511) & ~511) * 8 + (size_t)((n + 63) / 64) * 16;
+                    const size_t npad6 = (((size_t)((n + 3) & ~3) * 6) + 15) & ~(size_t)15, nb24 = (size_t)((((n + 63) / 64) + 511) & ~511) * 8 + (size_t)((n + 63) / 64) * 20 + 16;
                     const size_t lds_budget = 160 * 1024 - 2048;       // static __shared__ of the kernel
                     lz.enabled = true;
                     lz.lds_state = n <= 65535 && !getenv("CYTO_FORCE_STREAM") && npad6 + nb24 <= lds_budget;
@@ -2905,6 +2966,7 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
         info->dense_refreshes = fast ? h_counters[C2_DENSE_REFRESH] : 0;
         info->aug_scans_skipped = fast ? h_counters[C2_AUG_SKIPPED] : 0;
         info->aug_dense_scans = fast ? h_counters[C2_AUG_DENSE] : 0;
+        info->aug_sparse_inits = fast ? h_counters[C2_AUG_SPARSE_INIT] : 0;
         info->row_groups = h_ngroups;
     }
     cleanup();

@@ -73,7 +73,7 @@ typedef struct {
     int64_t aug_scans_skipped; /* augmentation scans elided as provable no-ops (duplicate rows) */
     int64_t row_groups;      /* number of runs of bitwise identical consecutive rows (== n: none) */
     int64_t aug_dense_scans; /* augmentation scans that had to read the full cost row (cache certificate failed) */
-    int64_t reserved[1];
+    int64_t aug_sparse_inits; /* augmentations whose initial row scan was served from the row cache */
 } cyto_lap_info;
 
 int cyto_lap_f32(int n, const float *cost, int64_t ld, int cost_on_device,

@@ -30,7 +30,7 @@ def main():
         print(f"n={n} wall={dt*1e3:.1f}ms colred={i.ms_colred:.3f}ms chain={i.ms_chain:.1f}ms scans={R} "
               f"us/scan={i.ms_chain*1e3/max(1,chain_scans):.3f} algGB/s={4*n*R/ (i.ms_total*1e-3)/1e9:.1f} "
               f"colredGB/s={4*n*n/(i.ms_colred*1e-3)/1e9:.0f} assign/s={n/(i.ms_total*1e-3):.0f} "
-              f"arr={i.scans_arr} augrelax={i.scans_aug_relax} cache_ms={i.ms_cache:.3f} arr_ms={i.ms_arr:.1f} aug_ms={i.ms_aug:.1f} us/arr={i.ms_arr*1e3/max(1,i.scans_arr+i.scans_redtransfer):.3f} us/aug={i.ms_aug*1e3/max(1,i.scans_aug_relax+i.scans_aug_init):.3f} dense_refresh={i.dense_refreshes} groups={i.row_groups} aug_skipped={i.aug_scans_skipped} hbm_rows={i.hbm_row_reads} aug_dense={i.aug_dense_scans}", flush=True)
+              f"arr={i.scans_arr} augrelax={i.scans_aug_relax} cache_ms={i.ms_cache:.3f} arr_ms={i.ms_arr:.1f} aug_ms={i.ms_aug:.1f} us/arr={i.ms_arr*1e3/max(1,i.scans_arr+i.scans_redtransfer):.3f} us/aug={i.ms_aug*1e3/max(1,i.scans_aug_relax+i.scans_aug_init):.3f} dense_refresh={i.dense_refreshes} groups={i.row_groups} aug_skipped={i.aug_scans_skipped} hbm_rows={i.hbm_row_reads} aug_dense={i.aug_dense_scans} augs={i.augmentations} sparse_init={i.aug_sparse_inits}", flush=True)
         buf.free()
 
 main()
