@@ -2148,8 +2148,8 @@ struct LazyArgs {
     char *misc;
     int ngroups, gmode;
 };
-struct LazyCmd { int op, row, step, endofpath, level, nscan, err; float h, curmin; };
-enum { LZ_DENSE = 1, LZ_END = 2, LZ_ERR = 3, LZ_INIT_DENSE = 4 };
+struct LazyCmd { int op, row, step, stamp; float h; };
+enum { LZ_DENSE = 1, LZ_EXIT = 2, LZ_ERR = 3, LZ_INIT_DENSE = 4 };
 enum { C2_AUG_DENSE = C2_NCOUNTERS, C2_AUG_SPARSE_INIT, C3_NCOUNTERS };
 constexpr int LZ_MAXEXC = 64;
 
@@ -2164,20 +2164,25 @@ __device__ __forceinline__ void gl_min_u64(uint64_t *p, uint64_t x) {
 #define LZ_STAMP(k) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)"); \
                       if ((k) > 0) prof[k] += now_ - tlast; else if (tlast) prof[0] += 0; tlast = now_; profn[k]++; }
 #define LZ_WAITVM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define LZ_STAMP2(k) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)"); \
+                       prof2[k] += now_ - tlast2; tlast2 = now_; }
 #else
 #define LZ_STAMP(k)
+#define LZ_STAMP2(k)
 #define LZ_WAITVM
 #endif
 constexpr uint64_t LZ_INFKEY = 0xFFFFFFFF00000000ull;   // "no distance yet": any real d wins the unsigned min
 // Before a column's word is used in this search its block of 64 words must hold this search's values:
 // blocks are reset lazily (all 64 words = "no distance") the first time a search touches them.
-__device__ __forceinline__ void lz_touch_blocks(bool act, int myblk, uint64_t *dkey, int32_t *s_ep, int stamp, int npad, int lane) {
+__device__ __forceinline__ void lz_touch_blocks(bool act, int myblk, uint64_t *dkey, int32_t *s_ep, int32_t *s_tl, int &ntouch,
+                                                int stamp, int npad, int lane) {
     uint64_t todo = __ballot(act && s_ep[myblk] != stamp);
     while (todo) {
         const int l = __builtin_ctzll(todo);
         const int b = (int)readlane32((uint32_t)myblk, l);
         if (b * 64 + lane < npad) st_u64(dkey + b * 64 + lane, LZ_INFKEY);
-        if (lane == 0) s_ep[b] = stamp;
+        if (lane == 0) { s_ep[b] = stamp; s_tl[ntouch] = b; }
+        ntouch++;
         todo &= ~__ballot(myblk == b);
     }
 }
@@ -2193,6 +2198,7 @@ template <bool LDS_STATE>
 __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
 #ifdef LZ_PROF
     long long prof[6] = {0, 0, 0, 0, 0, 0}, profn[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+    long long prof2[4] = {0, 0, 0, 0}, tlast2 = 0;
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     __shared__ Scratch2 s;
@@ -2220,6 +2226,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
     uint32_t *s_sc = reinterpret_cast<uint32_t *>(dyn_lds + off); off += (size_t)nb * 8;   // 2 words per block
     uint32_t *s_un = reinterpret_cast<uint32_t *>(dyn_lds + off); off += (size_t)nb * 8;
     int32_t *s_ep = reinterpret_cast<int32_t *>(dyn_lds + off); off += (size_t)nb * 4;   // search stamp of each block's dkey words
+    int32_t *s_tl = reinterpret_cast<int32_t *>(dyn_lds + off); off += (size_t)nb * 4;   // blocks touched by the current search
     off = (off + 7) & ~(size_t)7;
     const int gmode = a.gmode;
     float *hb = a.g_hbest;
@@ -2245,7 +2252,9 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
     if (tid == 0) s_nexc = 0;
     for (int b = tid; b < nb; b += BLOCK2) s_ep[b] = 0;
     long long c_sparse = 0;
-    for (int b = nb + tid; b < nbp; b += BLOCK2) bmin[b] = KEYMAX;
+    // between searches: every block minimum is "empty", no column is marked scanned
+    for (int b = tid; b < nbp; b += BLOCK2) bmin[b] = KEYMAX;
+    for (int w = tid; w < 2 * nb; w += BLOCK2) s_sc[w] = 0;
     __syncthreads();
     const int numfree = *reinterpret_cast<const int *>(a.misc + 128);
     long long c_relax = 0, c_hops = 0, c_augs = 0, c_skipped = 0, c_dense = 0;
@@ -2253,36 +2262,86 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(gv, 0, nquad * 16, 0x00020000);
     const __amdgpu_buffer_rsrc_t rdk = __builtin_amdgcn_make_buffer_rsrc(a.dkey, 0, nquad * 32, 0x00020000);
 
-    for (int f = 0; f < numfree && !err; f++) {
-        const int freerow = __builtin_amdgcn_readfirstlane(ld_i32(a.freerows + f));
-        const int stamp = f + 1;
-        // ================= per-search reset (LDS only): scanned bits, block minima =================
-        for (int w = tid; w < 2 * nb; w += BLOCK2) s_sc[w] = 0;
-        for (int b = tid; b < nb; b += BLOCK2) bmin[b] = KEYMAX;
-        __syncthreads();
-        // ================= search =================
-        bool have = false;
-        float curmin = 0.0f;
-        int level = 0, nscan = 0, endofpath = -1;
-        bool started = false;
-        for (;;) {
-            if (wave == 0) {
-                bool go = true;
-                if (!started) {
+    // Wave 0 owns the control flow: it runs whole searches (sparse init, cached steps, price update, path flip)
+    // on its own and calls the other waves in -- through `cmd` and the barrier below -- only for an operation
+    // that needs a full cost row (dense init of a search, dense scan of a row).
+    int f = 0, freerow = -1, stamp = 0;
+    bool insearch = false, have = false, dense_used = false, isparse = false;
+    float curmin = 0.0f, icv = 0.0f;
+    uint32_t icc = COLSENT;
+    int level = 0, nscan = 0, ntouch = 0;
+    // software pipeline over searches: id of the free row after next, cache row of the next one
+    int id_next = -1, id1_saved = -1;
+    uint32_t ncc = COLSENT;
+    float ncv = 0.0f;
+    if (wave == 0 && numfree > 0) {
+        const int id0 = __builtin_amdgcn_readfirstlane(ld_i32(a.freerows));
+        ncc = ld_u32(a.cache_col + (int64_t)id0 * KC + lane);
+        ncv = ld_f32(a.cache_val + (int64_t)id0 * KC + lane);
+        id_next = numfree > 1 ? ld_i32(a.freerows + 1) : -1;
+        freerow = id0;
+    }
+    for (;;) {
+        if (wave == 0) {
+            bool post = false;
+            while (!post) {
+                if (!insearch) {
+                    if (f >= numfree || err) { if (lane == 0) cmd.op = err ? LZ_ERR : LZ_EXIT; break; }
+                    LZ_STAMP2(0)
+                    // (freerow, ncc, ncv) were requested during the previous search; request the next ones now
+                    const uint32_t cc = ncc;
+                    const float cv = ncv;
+                    const int id1 = __builtin_amdgcn_readfirstlane(id_next);
+                    id1_saved = id1;
+                    if (id1 >= 0) {
+                        ncc = ld_u32(a.cache_col + (int64_t)id1 * KC + lane);
+                        ncv = ld_f32(a.cache_val + (int64_t)id1 * KC + lane);
+                    }
+                    id_next = f + 2 < numfree ? ld_i32(a.freerows + f + 2) : -1;
+                    stamp = f + 1;
+                    have = false; curmin = 0.0f; level = 0; nscan = 0; ntouch = 0; dense_used = false; insearch = true;
                     // ---- certified sparse init: if the free row's cache floor is above the distance of an
                     // unassigned cached column, no column outside the cache can matter in this search ----
-                    started = true;
-                    const uint32_t cc = ld_u32(a.cache_col + (int64_t)freerow * KC + lane);
-                    const float cv = ld_f32(a.cache_val + (int64_t)freerow * KC + lane);
                     const bool valid = lane < KCU && cc != COLSENT;
                     const int j = valid ? (int)cc : 0;
                     const float dd = cv - st_vget<LDS_STATE>(s_v, gv, j);
                     const bool un = valid && ((s_un[j >> 5] >> (j & 31)) & 1u);
-                    const uint32_t t0 = wave_min_u32(un ? f2ord(dd) : 0xFFFFFFFFu);
+                    const uint32_t odd = valid ? f2ord(dd) : 0xFFFFFFFFu;
+                    const uint32_t t0 = wave_min_u32(un ? odd : 0xFFFFFFFFu);
                     const float floor_f = __uint_as_float(readlane32(__float_as_uint(cv), KCU));
-                    if (s_nexc == 0 && t0 != 0xFFFFFFFFu && floor_f > ord2f(t0)) {
+                    const bool cert0 = s_nexc == 0 && t0 != 0xFFFFFFFFu && floor_f > ord2f(t0);
+                    if (cert0 && wave_min_u32(odd) == t0) {
+                        // ---- single-edge search: the smallest distance of the whole row belongs to an unassigned
+                        // column (the oracle's first pick ends the search at once: no scan, no price update);
+                        // nothing of the pick structure is touched ----
+                        const uint64_t me = __ballot(un && odd == t0);
+                        int le = __builtin_ctzll(me);
+                        if (me & (me - 1)) {    // several unassigned columns tie: the lowest column (reduction outside any divergent branch)
+                            const uint32_t cmin = wave_min_u32((un && odd == t0) ? cc : 0xFFFFFFFFu);
+                            le = __builtin_ctzll(__ballot(un && odd == t0 && cc == cmin));
+                        }
+                        const int ep = (int)readlane32(cc, le);
+                        const float cie = __uint_as_float(readlane32(__float_as_uint(cv), le));
+#ifdef LZ_DEBUG
+                        if (lane == 0 && (f < 12 || ep < 0 || ep >= n || freerow < 0 || freerow >= n))
+                            printf("fast f=%d freerow=%d ep=%d le=%d me=%llx t0=%x numfree=%d id1=%d\n", f, freerow, ep, le, (unsigned long long)me, t0, numfree, id1_saved);
+#endif
+                        if (lane == 0) {
+                            st_csset<LDS_STATE>(s_cs, a.colsol, ep, freerow);
+                            st_f32(a.cassign + ep, cie);
+                            st_i32(a.rowsol + freerow, ep);
+                            s_un[ep >> 5] &= ~(1u << (ep & 31));
+                        }
+                        c_hops++; c_augs++; c_sparse++;
+                        f++;
+                        freerow = id1_saved;
+                        insearch = false;
+                        LZ_STAMP2(1)
+                        continue;
+                    }
+                    if (cert0) {
                         const bool act = valid && !(dd > ord2f(t0));
-                        lz_touch_blocks(act, j >> 6, a.dkey, s_ep, stamp, npad, lane);
+                        lz_touch_blocks(act, j >> 6, a.dkey, s_ep, s_tl, ntouch, stamp, npad, lane);
                         if (act) {
                             const uint32_t od = f2ord(dd);
                             st_u64(a.dkey + j, (uint64_t)od << 32);                 // step 0 = the free row
@@ -2290,12 +2349,15 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                         }
                         if (lane == 0) { s_T = t0; st_i32(a.srow, freerow); }
                         c_sparse++;
+                        isparse = true; icc = cc; icv = cv;
+                        LZ_STAMP2(1)
                     } else {
-                        if (lane == 0) cmd.op = LZ_INIT_DENSE;
-                        go = false;
+                        if (lane == 0) { cmd.op = LZ_INIT_DENSE; cmd.row = freerow; cmd.stamp = stamp; }
+                        isparse = false; dense_used = true; post = true;
+                        continue;
                     }
                 }
-                if (go) for (;;) {
+                for (;;) {
                     LZ_STAMP(0)
                     // ---- pick: smallest (d, assigned?, column) over the block minima ----
                     uint64_t k = KEYMAX;
@@ -2316,15 +2378,64 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                         k = ((uint64_t)m << 32) | lo;
                     }
                     const float dmin = key_val(k);
-                    if (k == KEYMAX || !(dmin < INFINITY)) { if (lane == 0) { cmd.op = LZ_ERR; } break; }
+                    if (k == KEYMAX || !(dmin < INFINITY)) { err = CYTO_ERR_INTERNAL; insearch = false; break; }
                     const int jp = (int)((uint32_t)k & 0x7FFFFFFFu);
                     LZ_STAMP(1)
                     if (!have || dmin != curmin) { level++; curmin = dmin; have = true; }
                     if (!((uint32_t)k & 0x80000000u)) {
-                        endofpath = jp;
-                        if (lane == 0) {
-                            cmd.op = LZ_END; cmd.endofpath = jp; cmd.level = level; cmd.nscan = nscan; cmd.curmin = curmin;
+                        // ======== end of the search (wave 0 alone): price update, path flip, clean-up ========
+                        LZ_STAMP2(2)
+                        const int endofpath = jp;
+                        for (int k2 = lane; k2 < nscan; k2 += 64) {
+                            if (ld_i32(a.slevel + k2) < level) {
+                                const int j = ld_i32(a.slist + k2);
+                                const float vold = st_vget<LDS_STATE>(s_v, gv, j);
+                                const float vnew = ld_f32(a.sumvd + j) - curmin;
+                                st_vset<LDS_STATE>(s_v, gv, j, vnew);
+                                if (vnew > vold) {   // rounding pushed a price UP: column j leaves the cache certificates
+                                    const int e = atomicAdd(&s_nexc, 1);
+                                    if (e < LZ_MAXEXC) s_exc[e] = j;
+                                }
+                            }
                         }
+                        if (s_nexc > LZ_MAXEXC) err = CYTO_ERR_INTERNAL;
+                        // c[freerow][endofpath] is in the sparse init's cache row when the path is a single edge
+                        float cie0 = 0.0f;
+                        bool have_cie0 = false;
+                        if (nscan == 0 && isparse) {
+                            const uint64_t mm = __ballot(lane < KCU && icc == (uint32_t)endofpath);
+                            if (mm) { cie0 = __uint_as_float(readlane32(__float_as_uint(icv), __builtin_ctzll(mm))); have_cie0 = true; }
+                        }
+                        int hops = 0;
+                        if (lane == 0) {
+                            int ep = endofpath;
+                            const int st0 = nscan == 0 ? 0 : (int32_t)(uint32_t)ld_u64(a.dkey + ep);
+                            int i = st0 == 0 ? freerow : ld_i32(a.srow + st0);
+                            for (;;) {
+                                st_csset<LDS_STATE>(s_cs, a.colsol, ep, i);
+                                st_f32(a.cassign + ep, (have_cie0 && hops == 0) ? cie0 : cost[(int64_t)i * ld + ep]);
+                                const int j1 = ep;
+                                if (i != freerow) ep = ld_i32(a.rowsol + i);      // (the free row owns no column)
+                                st_i32(a.rowsol + i, j1);
+                                hops++;
+                                if (i == freerow) break;
+                                const int stp = ld_i32(a.predstep + ep);
+                                i = stp == 0 ? freerow : ld_i32(a.srow + stp);
+                            }
+                            s_un[endofpath >> 5] &= ~(1u << (endofpath & 31));
+                        }
+                        c_hops += __builtin_amdgcn_readfirstlane(hops);
+                        // back to the between-searches state of the LDS pick structure
+                        if (!dense_used) {
+                            for (int k2 = lane; k2 < ntouch; k2 += 64) { const int b = s_tl[k2]; bmin[b] = KEYMAX; s_sc[2 * b] = 0; s_sc[2 * b + 1] = 0; }
+                        } else {
+                            for (int b = lane; b < nb; b += 64) { bmin[b] = KEYMAX; s_sc[2 * b] = 0; s_sc[2 * b + 1] = 0; }
+                        }
+                        LZ_STAMP2(3)
+                        c_augs++;
+                        f++;
+                        freerow = id1_saved;
+                        insearch = false;
                         break;
                     }
                     const int i = __builtin_amdgcn_readfirstlane(st_csget<LDS_STATE>(s_cs, a.colsol, jp));
@@ -2382,7 +2493,8 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                     const float floor_i = __uint_as_float(readlane32(__float_as_uint(cv), KCU));
                     const float T = ord2f(s_T);
                     if (!((floor_i - h) > T)) {
-                        if (lane == 0) { cmd.op = LZ_DENSE; cmd.row = i; cmd.step = step; cmd.h = h; }
+                        if (lane == 0) { cmd.op = LZ_DENSE; cmd.row = i; cmd.step = step; cmd.h = h; cmd.stamp = stamp; }
+                        dense_used = true; post = true;
                         break;
                     }
                     // ---- cached relaxation: lane = cache entry; plus the (normally empty) exception list ----
@@ -2393,7 +2505,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                         const float v2 = (cv - vj) - h;
                         const bool scn = (s_sc[j >> 5] >> (j & 31)) & 1u;
                         const bool act = valid && !scn && !(v2 > T);
-                        lz_touch_blocks(act, j >> 6, a.dkey, s_ep, stamp, npad, lane);
+                        lz_touch_blocks(act, j >> 6, a.dkey, s_ep, s_tl, ntouch, stamp, npad, lane);
                         if (act) {
                             const bool un = (s_un[j >> 5] >> (j & 31)) & 1u;
                             const uint32_t o2 = f2ord(v2);
@@ -2410,7 +2522,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                         const float vj = st_vget<LDS_STATE>(s_v, gv, j);
                         const float v2 = ev ? (cost[(int64_t)i * ld + j] - vj) - h : 0.0f;
                         const bool scn = (s_sc[j >> 5] >> (j & 31)) & 1u;
-                        lz_touch_blocks(ev && !scn, j >> 6, a.dkey, s_ep, stamp, npad, lane);
+                        lz_touch_blocks(ev && !scn, j >> 6, a.dkey, s_ep, s_tl, ntouch, stamp, npad, lane);
                         if (ev && !scn) {
                             const bool un = (s_un[j >> 5] >> (j & 31)) & 1u;
                             const uint32_t o2 = f2ord(v2);
@@ -2422,11 +2534,15 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                     LZ_STAMP(5)
                 }
             }
-            __syncthreads();                           // command posted; wave 0's global traffic drained
+        }
+        __syncthreads();                               // command posted; wave 0's global traffic drained
+        {
             const int op = cmd.op;
             if (op == LZ_ERR) { err = CYTO_ERR_INTERNAL; break; }
-            if (op == LZ_END) break;
+            if (op == LZ_EXIT) break;
+            const int stamp = cmd.stamp;               // (shadows wave 0's copy with the same value)
             if (op == LZ_INIT_DENSE) {
+                const int freerow = cmd.row;
                 // ================= dense init: d = c[freerow] - v for every column (whole workgroup) =================
                         float tl = INFINITY;
                 {
@@ -2527,42 +2643,6 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                 __syncthreads();
             }
         }
-        if (err) break;
-        // ================= price update, path flip =================
-        level = cmd.level; nscan = cmd.nscan; curmin = cmd.curmin; endofpath = cmd.endofpath;
-        for (int k = tid; k < nscan; k += BLOCK2) {
-            if (ld_i32(a.slevel + k) < level) {
-                const int j = ld_i32(a.slist + k);
-                const float vold = st_vget<LDS_STATE>(s_v, gv, j);
-                const float vnew = ld_f32(a.sumvd + j) - curmin;
-                st_vset<LDS_STATE>(s_v, gv, j, vnew);
-                if (vnew > vold) {       // rounding pushed a price UP: column j leaves the cache certificates
-                    const int e = atomicAdd(&s_nexc, 1);
-                    if (e < LZ_MAXEXC) s_exc[e] = j;
-                }
-            }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            if (s_nexc > LZ_MAXEXC) err = CYTO_ERR_INTERNAL;
-            int ep = endofpath;
-            int i = ld_i32(a.srow + (int32_t)(uint32_t)ld_u64(a.dkey + ep));
-            for (;;) {
-                st_csset<LDS_STATE>(s_cs, a.colsol, ep, i);
-                st_f32(a.cassign + ep, cost[(int64_t)i * ld + ep]);
-                const int j1 = ep;
-                ep = ld_i32(a.rowsol + i);
-                st_i32(a.rowsol + i, j1);
-                c_hops++;
-                if (i == freerow) break;
-                i = ld_i32(a.srow + ld_i32(a.predstep + ep));
-            }
-            s_un[endofpath >> 5] &= ~(1u << (endofpath & 31));
-            cmd.err = err;
-        }
-        c_augs++;
-        __syncthreads();
-        err = cmd.err;
     }
     // ---- write back prices and colsol, then duals u and the total ----
     if constexpr (LDS_STATE) {
@@ -2599,6 +2679,8 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
 #ifdef LZ_PROF
         long long *pp = reinterpret_cast<long long *>(a.misc + 152);
         for (int k = 0; k < 6; k++) { pp[k] = prof[k]; pp[6 + k] = profn[k]; }
+        for (int k = 0; k < 4; k++) pp[k] = prof2[k] / (c_augs ? c_augs : 1);
+        pp[6] = c_augs;
 #endif
     }
 }
@@ -2815,7 +2897,7 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
                 // forces it at any size, CYTO_AUG=single|stream|coop selects the older kernels
                 const char *e = getenv("CYTO_AUG");
                 if (e ? strcmp(e, "lazy") == 0 : n >= 12288) {
-                    const size_t npad6 = (((size_t)((n + 3) & ~3) * 6) + 15) & ~(size_t)15, nb24 = (size_t)((((n + 63) / 64) + 511) & ~511) * 8 + (size_t)((n + 63) / 64) * 20 + 16;
+                    const size_t npad6 = (((size_t)((n + 3) & ~3) * 6) + 15) & ~(size_t)15, nb24 = (size_t)((((n + 63) / 64) + 511) & ~511) * 8 + (size_t)((n + 63) / 64) * 24 + 16;
                     const size_t lds_budget = 160 * 1024 - 2048;       // static __shared__ of the kernel
                     lz.enabled = true;
                     lz.lds_state = n <= 65535 && !getenv("CYTO_FORCE_STREAM") && npad6 + nb24 <= lds_budget;
@@ -2935,7 +3017,8 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
         long long pp[12];
         CYTO_HIP(hipMemcpy(pp, b_misc.as<char>() + 152, sizeof pp, hipMemcpyDeviceToHost));
         fprintf(stderr, "[lazy prof] cycles:");
-        for (int k = 1; k < 6; k++) fprintf(stderr, " seg%d %.0f/step (n=%lld)", k, pp[6 + k] ? (double)pp[k] / pp[6 + k] : 0.0, pp[6 + k]);
+        fprintf(stderr, " per search (n=%lld): gap+start %lld init %lld steps %lld end %lld;", pp[6], pp[0], pp[1], pp[2], pp[3]);
+        for (int k = 4; k < 6; k++) fprintf(stderr, " seg%d %.0f/step (n=%lld)", k, pp[6 + k] ? (double)pp[k] / pp[6 + k] : 0.0, pp[6 + k]);
         fprintf(stderr, "\n");
     }
 #endif
