@@ -36,8 +36,8 @@ if __name__ == "__main__":
     d = {k: getattr(info, k) for k, _ in info._fields_ if not k.startswith("reserved") and k != "lap"}
     print("assign_pearson wall %.2fs (includes 2x H2D of f64 inputs)" % wall, d, flush=True)
     li = info.lap
-    print("LAP: n=%d ms_total=%.1f colred=%.1f cache=%.1f arr=%.1f aug=%.1f scans: arr=%d aug=%d skipped=%d dense=%d groups=%d augmentations=%d sparse_inits=%d" % (
+    print("LAP: n=%d ms_total=%.1f colred=%.1f cache=%.1f arr=%.1f aug=%.1f scans: arr=%d aug=%d skipped=%d dense=%d groups=%d augmentations=%d sparse_inits=%d rt=%d arr_dense_refresh=%d free_cr=%d free_a1=%d free_a2=%d" % (
         C, li.ms_total, li.ms_colred, li.ms_cache, li.ms_arr, li.ms_aug, li.scans_arr, li.scans_aug_relax, li.aug_scans_skipped,
-        li.aug_dense_scans, li.row_groups, li.augmentations, li.aug_sparse_inits), flush=True)
+        li.aug_dense_scans, li.row_groups, li.augmentations, li.aug_sparse_inits, li.scans_redtransfer, li.dense_refreshes, li.free_after_colred, li.free_after_arr1, li.free_after_arr2), flush=True)
     ok = np.array_equal(np.bincount(mapped, minlength=S), slots)
     print("bincount == slots:", ok, " total cost %.6f" % total, " assignments/s (kernels) %.0f" % (C / (li.ms_total * 1e-3)))
