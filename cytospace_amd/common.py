@@ -31,25 +31,30 @@ def normalize_data(data, device_id=0):
     return out
 
 
-class StandardizedMatrix:
-    """A gene x column matrix standardised on the device: float32, zero padded, resident in HBM."""
+METRICS = {"Pearson_correlation": 0, "Spearman_correlation": 1, "Euclidean": 2}   # CYTO_METRIC_*
 
-    def __init__(self, data, already_normalized=False, device_id=0):
+
+class StandardizedMatrix:
+    """A gene x column matrix as the float32 GEMM operand of a metric, zero padded, resident in HBM:
+    standardised values (Pearson), standardised average-tie ranks (Spearman) or the plain values (Euclidean)."""
+
+    def __init__(self, data, already_normalized=False, device_id=0, metric="Pearson_correlation"):
         x, is64 = _as_matrix(data)
         self.G, self.C = x.shape
         self.Gpad = -(-self.G // _BK) * _BK
         self.ld = -(-self.C // _BM) * _BM
         self.device_id = device_id
         self.buf = _lib.DeviceBuffer(self.Gpad * self.ld * 4, device_id)
-        _lib.check(_lib.lib().cyto_standardize(self.G, self.C, x.ctypes.data, self.C, is64, 0, int(already_normalized),
-                                               self.buf.ptr, self.ld, self.Gpad, device_id, None))
+        _lib.check(_lib.lib().cyto_transform(METRICS[metric], self.G, self.C, x.ctypes.data, self.C, is64, 0,
+                                             int(already_normalized), self.buf.ptr, self.ld, self.Gpad, device_id, None))
 
     def to_numpy(self):
         return self.buf.to_numpy((self.Gpad, self.ld), np.float32)[:self.G, :self.C]
 
 
-def pearson_cost_device(sc_norm, st_norm, slots, device_id=0, already_normalized=True):
-    """-corr with every spot row repeated slots[s] times, left in HBM.
+def pearson_cost_device(sc_norm, st_norm, slots, device_id=0, already_normalized=True, metric="Pearson_correlation"):
+    """The cost matrix of calculate_cost's lapjv branch (-Pearson, -Spearman or Euclidean distance, spots x cells)
+    with every spot row repeated slots[s] times, left in HBM.
 
     Returns (DeviceBuffer cost, N, ld, gemm_ms).  sc_norm: G x C, st_norm: G x S."""
     sc_norm = np.asarray(sc_norm)
@@ -60,15 +65,17 @@ def pearson_cost_device(sc_norm, st_norm, slots, device_id=0, already_normalized
     slots = np.ascontiguousarray(slots, dtype=np.int64)
     if slots.ndim != 1 or len(slots) != st_norm.shape[1] or (slots < 0).any():
         raise ValueError("cell_number_to_node_assignment must hold one non-negative count per spot")
-    zsc = StandardizedMatrix(sc_norm, already_normalized, device_id)
-    zst = StandardizedMatrix(st_norm, already_normalized, device_id)
+    if metric not in METRICS:
+        raise ValueError(f"unknown distance_metric {metric!r}")
+    zsc = StandardizedMatrix(sc_norm, already_normalized, device_id, metric)
+    zst = StandardizedMatrix(st_norm, already_normalized, device_id, metric)
     N = int(slots.sum())
     C = zsc.C
     ld = -(-C // 4) * 4
     cost = _lib.DeviceBuffer(max(N, 1) * ld * 4, device_id)
     ms = ctypes.c_double()
-    _lib.check(_lib.lib().cyto_cost_pearson(zst.Gpad, zst.C, C, zst.buf.ptr, zst.ld, zsc.buf.ptr, zsc.ld,
-                                            slots.ctypes.data, cost.ptr, ld, ctypes.byref(ms), device_id, None))
+    _lib.check(_lib.lib().cyto_cost_metric(METRICS[metric], zst.Gpad, zst.C, C, zst.buf.ptr, zst.ld, zsc.buf.ptr, zsc.ld,
+                                           slots.ctypes.data, cost.ptr, ld, ctypes.byref(ms), device_id, None))
     zsc.buf.free()
     zst.buf.free()
     return cost, N, ld, ms.value
@@ -84,6 +91,20 @@ def matrix_correlation_pearson(v1, v2, device_id=0):
                          "ST and scRNA data must have the same genes")
     S, C = v2.shape[1], v1.shape[1]
     cost, N, ld, _ = pearson_cost_device(v1, v2, np.ones(S, np.int64), device_id, already_normalized=True)
+    out = cost.to_numpy((N, ld), np.float32)[:, :C]
+    cost.free()
+    return -out
+
+
+def matrix_correlation_spearman(v1, v2, device_id=0):
+    """cytospace/common/common.py:202-215 on the GPU: Pearson correlation of the per-column average-tie ranks."""
+    v1 = np.asarray(v1)
+    v2 = np.asarray(v2)
+    if v1.shape[0] != v2.shape[0]:
+        raise ValueError("The two matrices v1 and v2 must have equal dimensions; "
+                         "ST and scRNA data must have the same genes")
+    S, C = v2.shape[1], v1.shape[1]
+    cost, N, ld, _ = pearson_cost_device(v1, v2, np.ones(S, np.int64), device_id, True, "Spearman_correlation")
     out = cost.to_numpy((N, ld), np.float32)[:, :C]
     cost.free()
     return -out

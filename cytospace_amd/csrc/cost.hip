@@ -128,6 +128,68 @@ __global__ __launch_bounds__(256) void normalize_write(int G, int C, const TIn *
     for (int g = g0; g < g1; g++) y[(int64_t)g * ldy + c] = normalized<TIn>(x[(int64_t)g * ldx + c], scale, false);
 }
 
+// z = y as float32 (no centring, no scaling): operand of the Euclidean metric
+template <typename TIn>
+__global__ __launch_bounds__(256) void convert_write(int G, int C, const TIn *__restrict__ x, int64_t ldx,
+                                                     const double *__restrict__ colsum, int already,
+                                                     float *__restrict__ z, int64_t ldz) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int g0 = blockIdx.y * GB, g1 = min(G, g0 + GB);
+    const double scale = already ? 1.0 : 1e6 / colsum[c];
+    for (int g = g0; g < g1; g++) z[(int64_t)g * ldz + c] = (float)normalized<TIn>(x[(int64_t)g * ldx + c], scale, already);
+}
+
+// partial column sums of squares of a float32 matrix (the rounded values the matrix cores will see)
+__global__ __launch_bounds__(256) void colsq_partial(int G, int C, const float *__restrict__ z, int64_t ldz, double *__restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int g0 = blockIdx.y * GB, g1 = min(G, g0 + GB);
+    double s = 0.0;
+    for (int g = g0; g < g1; g++) { const double v = (double)z[(int64_t)g * ldz + c]; s += v * v; }
+    part[(int64_t)blockIdx.y * C + c] = s;
+}
+
+// Per-column ranks, ties averaged, 1-based: pandas.DataFrame.rank() defaults, as used by
+// matrix_correlation_spearman (/root/reference/cytospace/common/common.py:202-215).
+// rank_i = #{x_j < x_i} + (#{x_j == x_i} + 1) / 2, counted exactly in float64: one workgroup per column, every
+// thread keeps MOWN of the column's values in registers and streams the whole column past them through LDS
+// (broadcast reads).  O(G^2) compares per column, but they are full-rate VALU work: c3 (20k genes x 55k
+// columns) is 2.2e13 compares.  Ranks are half-integers <= G: exact in float32.
+// The transform normalize_data applies before (log2(x * 1e6 / colsum + 1)) is strictly increasing per column, so
+// ranking the cleaned input gives the ranks of the normalised values.
+constexpr int RANK_CHUNK = 4096;
+template <typename TIn, int MOWN>
+__global__ __launch_bounds__(1024) void rank_columns(int G, int C, const TIn *__restrict__ x, int64_t ldx,
+                                                     float *__restrict__ r, int64_t ldr) {
+    __shared__ double chunk[RANK_CHUNK];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double own[MOWN];
+    int lt[MOWN], eq[MOWN];
+#pragma unroll
+    for (int e = 0; e < MOWN; e++) {
+        const int g = tid + e * 1024;
+        own[e] = g < G ? clean<TIn>(x[(int64_t)g * ldx + c]) : __longlong_as_double(0x7FF8000000000000ll);   // NaN: never <, never ==
+        lt[e] = 0; eq[e] = 0;
+    }
+    for (int j0 = 0; j0 < G; j0 += RANK_CHUNK) {
+        const int cnt = min(RANK_CHUNK, G - j0);
+        __syncthreads();
+        for (int j = tid; j < cnt; j += 1024) chunk[j] = clean<TIn>(x[(int64_t)(j0 + j) * ldx + c]);
+        __syncthreads();
+        for (int j = 0; j < cnt; j++) {
+            const double xj = chunk[j];
+#pragma unroll
+            for (int e = 0; e < MOWN; e++) { lt[e] += (xj < own[e]) ? 1 : 0; eq[e] += (xj == own[e]) ? 1 : 0; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < MOWN; e++) {
+        const int g = tid + e * 1024;
+        if (g < G) r[(int64_t)g * ldr + c] = (float)((double)lt[e] + 0.5 * (double)(eq[e] + 1));
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // cost[r][c] = - sum_g zst[g][s] * zsc[g][c]   for every LAP row r of spot s
 // TN GEMM: both operands are stored gene-major, so a k-slice of either tile is a contiguous row
@@ -137,10 +199,13 @@ __global__ __launch_bounds__(256) void normalize_write(int G, int C, const TIn *
 constexpr int BM = 128, BN = 128, BK = 32;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// EPI 0: cost = -dot (Pearson / Spearman on standardised operands);
+// EPI 1: cost = sqrt(|a|^2 + |b|^2 - 2 dot) (Euclidean; squared norms in float64, sum and root in float64)
+template <int EPI>
 __global__ __launch_bounds__(256) void pearson_gemm(int Gpad, int S, int C, const float *__restrict__ A, int64_t lda,
                                                     const float *__restrict__ B, int64_t ldb,
                                                     const int *__restrict__ rowstart, float *__restrict__ cost, int64_t ldc,
-                                                    int tiles_n) {
+                                                    int tiles_n, const double *__restrict__ na, const double *__restrict__ nb) {
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -224,7 +289,9 @@ __global__ __launch_bounds__(256) void pearson_gemm(int Gpad, int S, int C, cons
             for (int r = 0; r < 16; r++) {
                 const int s = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (s < S && c < C) {
-                    const float val = -acc[a][b][r];
+                    float val;
+                    if constexpr (EPI == 0) val = -acc[a][b][r];
+                    else { const double d2 = na[s] + nb[c] - 2.0 * (double)acc[a][b][r]; val = (float)sqrt(d2 > 0.0 ? d2 : 0.0); }
                     const int r0 = rowstart[s], r1 = rowstart[s + 1];
                     for (int row = r0; row < r1; row++) cost[(int64_t)row * ldc + c] = val;
                 }
@@ -240,9 +307,26 @@ static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * 
 
 // Column statistics + standardised float32 matrix for one input (genes x columns).
 // z must hold Gpad x ldz floats and be zero-filled by the caller (padding must stay zero).
+// transform: 0 standardise (Pearson), 1 rank then standardise (Spearman), 2 plain float32 conversion (Euclidean)
 template <typename TIn>
 static int standardize_dev(int G, int C, const TIn *dx, int64_t ldx, int already, float *z, int64_t ldz, double *ynorm,
-                           int64_t ldy, hipStream_t stream) {
+                           int64_t ldy, hipStream_t stream, int transform = 0) {
+    if (transform == 1) {
+        // ranks into a float32 matrix, then the usual standardisation of that matrix
+        if (G > 32 * 1024) return CYTO_ERR_UNSUPPORTED;
+        DevBuf ranks;
+        int rc2;
+        if ((rc2 = ranks.alloc((size_t)G * C * sizeof(float)))) return rc2;
+        const int m = (G + 1023) / 1024;
+        float *rp = ranks.as<float>();
+        if (m <= 4) hipLaunchKernelGGL((rank_columns<TIn, 4>), dim3(C), dim3(1024), 0, stream, G, C, dx, ldx, rp, (int64_t)C);
+        else if (m <= 8) hipLaunchKernelGGL((rank_columns<TIn, 8>), dim3(C), dim3(1024), 0, stream, G, C, dx, ldx, rp, (int64_t)C);
+        else if (m <= 16) hipLaunchKernelGGL((rank_columns<TIn, 16>), dim3(C), dim3(1024), 0, stream, G, C, dx, ldx, rp, (int64_t)C);
+        else if (m <= 24) hipLaunchKernelGGL((rank_columns<TIn, 24>), dim3(C), dim3(1024), 0, stream, G, C, dx, ldx, rp, (int64_t)C);
+        else hipLaunchKernelGGL((rank_columns<TIn, 32>), dim3(C), dim3(1024), 0, stream, G, C, dx, ldx, rp, (int64_t)C);
+        CYTO_HIP(hipGetLastError());
+        return standardize_dev<float>(G, C, rp, C, 1, z, ldz, nullptr, 0, stream, 0);
+    }
     const int nblk = (G + GB - 1) / GB;
     DevBuf part1, part2, colsum, mean, inv;
     int rc;
@@ -259,7 +343,9 @@ static int standardize_dev(int G, int C, const TIn *dx, int64_t ldx, int already
     if (ynorm) {
         hipLaunchKernelGGL(normalize_write<TIn>, grid, blk, 0, stream, G, C, dx, ldx, colsum.as<double>(), ynorm, ldy);
     }
-    if (z) {
+    if (z && transform == 2) {
+        hipLaunchKernelGGL(convert_write<TIn>, grid, blk, 0, stream, G, C, dx, ldx, colsum.as<double>(), already, z, ldz);
+    } else if (z) {
         hipLaunchKernelGGL(colmoments_partial<TIn>, grid, blk, 0, stream, G, C, dx, ldx, colsum.as<double>(), already,
                            part1.as<double>(), part2.as<double>());
         hipLaunchKernelGGL(col_finish_moments, g1, blk, 0, stream, G, C, nblk, part1.as<double>(), part2.as<double>(),
@@ -296,9 +382,10 @@ int cyto_normalize_data(int G, int C, const void *x, int64_t ldx, int x_is_f64, 
 
 // A1+A2 (first half): per-column normalise (unless already_normalized) and standardise; writes the
 // float32 matrix z (device pointer, Gpad x ldz, pre-zeroed by this call) used by cyto_cost_pearson.
-int cyto_standardize(int G, int C, const void *x, int64_t ldx, int x_is_f64, int x_on_device, int already_normalized,
-                     float *z_dev, int64_t ldz, int Gpad, int device_id, void *stream_) {
+int cyto_transform(int transform, int G, int C, const void *x, int64_t ldx, int x_is_f64, int x_on_device, int already_normalized,
+                   float *z_dev, int64_t ldz, int Gpad, int device_id, void *stream_) {
     if (G <= 0 || C <= 0 || !x || !z_dev || ldx < C || ldz < C || Gpad < G) return CYTO_ERR_BAD_ARG;
+    if (transform < CYTO_TRANSFORM_STANDARDIZE || transform > CYTO_TRANSFORM_RAW) return CYTO_ERR_BAD_ARG;
     int rc = select_device(device_id);
     if (rc) return rc;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -313,15 +400,21 @@ int cyto_standardize(int G, int C, const void *x, int64_t ldx, int x_is_f64, int
         sld = C;
     }
     CYTO_HIP(hipMemsetAsync(z_dev, 0, (size_t)Gpad * ldz * sizeof(float), stream));
-    if (x_is_f64) return standardize_dev<double>(G, C, (const double *)src, sld, already_normalized, z_dev, ldz, nullptr, 0, stream);
-    return standardize_dev<float>(G, C, (const float *)src, sld, already_normalized, z_dev, ldz, nullptr, 0, stream);
+    if (x_is_f64) return standardize_dev<double>(G, C, (const double *)src, sld, already_normalized, z_dev, ldz, nullptr, 0, stream, transform);
+    return standardize_dev<float>(G, C, (const float *)src, sld, already_normalized, z_dev, ldz, nullptr, 0, stream, transform);
+}
+
+int cyto_standardize(int G, int C, const void *x, int64_t ldx, int x_is_f64, int x_on_device, int already_normalized,
+                     float *z_dev, int64_t ldz, int Gpad, int device_id, void *stream_) {
+    return cyto_transform(CYTO_TRANSFORM_STANDARDIZE, G, C, x, ldx, x_is_f64, x_on_device, already_normalized, z_dev, ldz, Gpad,
+                          device_id, stream_);
 }
 
 // A2+A3: cost = -corr, each spot row written to its slots[s] LAP rows (spot order).
 // zst: Gpad x ldzst, zsc: Gpad x ldzsc (device, zero padded: Gpad % 32 == 0, ld % 128 == 0).
 // cost: device, (sum slots) x ldc.  gemm_ms (optional): HIP-event time of the GEMM kernel.
-int cyto_cost_pearson(int Gpad, int S, int C, const float *zst, int64_t ldzst, const float *zsc, int64_t ldzsc,
-                      const int64_t *slots, float *cost_dev, int64_t ldc, double *gemm_ms, int device_id, void *stream_) {
+static int cost_gemm(int euclid, int Gpad, int S, int C, const float *zst, int64_t ldzst, const float *zsc, int64_t ldzsc,
+                     const int64_t *slots, float *cost_dev, int64_t ldc, double *gemm_ms, int device_id, void *stream_) {
     if (Gpad <= 0 || S <= 0 || C <= 0 || !zst || !zsc || !slots || !cost_dev) return CYTO_ERR_BAD_ARG;
     if (Gpad % BK || ldzst % BM || ldzsc % BN || ldzst < S || ldzsc < C || ldc < C) return CYTO_ERR_BAD_ARG;
     int rc = select_device(device_id);
@@ -343,9 +436,24 @@ int cyto_cost_pearson(int Gpad, int S, int C, const float *zst, int64_t ldzst, c
     hipEvent_t e0, e1;
     CYTO_HIP(hipEventCreate(&e0));
     CYTO_HIP(hipEventCreate(&e1));
+    DevBuf na, nb, part;
+    if (euclid) {
+        // squared column norms of the float32 operands, in float64
+        const int nblk = Gpad / GB + (Gpad % GB ? 1 : 0);
+        const int Cmax = S > C ? S : C;
+        if ((rc = na.alloc((size_t)S * 8)) || (rc = nb.alloc((size_t)C * 8)) || (rc = part.alloc((size_t)nblk * Cmax * 8))) return rc;
+        hipLaunchKernelGGL(colsq_partial, dim3((S + 255) / 256, nblk), dim3(256), 0, stream, Gpad, S, zst, ldzst, part.as<double>());
+        hipLaunchKernelGGL(col_finish_sum, dim3((S + 255) / 256), dim3(256), 0, stream, S, nblk, part.as<double>(), na.as<double>());
+        hipLaunchKernelGGL(colsq_partial, dim3((C + 255) / 256, nblk), dim3(256), 0, stream, Gpad, C, zsc, ldzsc, part.as<double>());
+        hipLaunchKernelGGL(col_finish_sum, dim3((C + 255) / 256), dim3(256), 0, stream, C, nblk, part.as<double>(), nb.as<double>());
+    }
     CYTO_HIP(hipEventRecord(e0, stream));
-    hipLaunchKernelGGL(pearson_gemm, dim3(tiles_m * tiles_n), dim3(256), 0, stream, Gpad, S, C, zst, ldzst, zsc, ldzsc,
-                       drs.as<int>(), cost_dev, ldc, tiles_n);
+    if (euclid)
+        hipLaunchKernelGGL(pearson_gemm<1>, dim3(tiles_m * tiles_n), dim3(256), 0, stream, Gpad, S, C, zst, ldzst, zsc, ldzsc,
+                           drs.as<int>(), cost_dev, ldc, tiles_n, na.as<double>(), nb.as<double>());
+    else
+        hipLaunchKernelGGL(pearson_gemm<0>, dim3(tiles_m * tiles_n), dim3(256), 0, stream, Gpad, S, C, zst, ldzst, zsc, ldzsc,
+                           drs.as<int>(), cost_dev, ldc, tiles_n, (const double *)nullptr, (const double *)nullptr);
     CYTO_HIP(hipGetLastError());
     CYTO_HIP(hipEventRecord(e1, stream));
     CYTO_HIP(hipStreamSynchronize(stream));
@@ -357,13 +465,30 @@ int cyto_cost_pearson(int Gpad, int S, int C, const float *zst, int64_t ldzst, c
     return CYTO_OK;
 }
 
+int cyto_cost_pearson(int Gpad, int S, int C, const float *zst, int64_t ldzst, const float *zsc, int64_t ldzsc,
+                      const int64_t *slots, float *cost_dev, int64_t ldc, double *gemm_ms, int device_id, void *stream_) {
+    return cost_gemm(0, Gpad, S, C, zst, ldzst, zsc, ldzsc, slots, cost_dev, ldc, gemm_ms, device_id, stream_);
+}
+
+// The other distance metrics of calculate_cost (linear_assignment_solvers.py:53-59) through the same contraction:
+// Spearman = the Pearson epilogue on rank-transformed operands (cyto_transform(CYTO_TRANSFORM_RANK, ...));
+// Euclidean = sqrt(|a|^2 + |b|^2 - 2 a.b) on the plain float32 operands (cyto_transform(CYTO_TRANSFORM_RAW, ...)).
+int cyto_cost_metric(int metric, int Gpad, int S, int C, const float *zst, int64_t ldzst, const float *zsc, int64_t ldzsc,
+                     const int64_t *slots, float *cost_dev, int64_t ldc, double *gemm_ms, int device_id, void *stream_) {
+    if (metric < CYTO_METRIC_PEARSON || metric > CYTO_METRIC_EUCLIDEAN) return CYTO_ERR_BAD_ARG;
+    return cost_gemm(metric == CYTO_METRIC_EUCLIDEAN, Gpad, S, C, zst, ldzst, zsc, ldzsc, slots, cost_dev, ldc, gemm_ms, device_id, stream_);
+}
+
 // A7: the fused per-chunk path of solve_linear_assignment_problem (cytospace/cytospace.py:304-351)
 // for solver_method == "lapjv", distance_metric == "Pearson_correlation": cost build on the device,
 // JV solve on the device, mapped_spot[c] = spot of the LAP row given to cell c.
 // sc: G x C, st: G x S (host, row-major, float64 like the reference's arrays).  sum(slots) must be C.
 // The 1e-16 perturbation of cytospace.py:325-327 is not applied: it is a no-op in float32.
-int cyto_assign_pearson(int G, int C, int S, const double *sc, const double *st, const int64_t *slots, int already_normalized,
-                        int64_t *mapped_spot, double *total_cost, cyto_assign_info *info, int device_id) {
+int cyto_assign_metric(int metric, int G, int C, int S, const double *sc, const double *st, const int64_t *slots, int already_normalized,
+                       int64_t *mapped_spot, double *total_cost, cyto_assign_info *info, int device_id) {
+    if (metric < CYTO_METRIC_PEARSON || metric > CYTO_METRIC_EUCLIDEAN) return CYTO_ERR_BAD_ARG;
+    const int transform = metric == CYTO_METRIC_PEARSON ? CYTO_TRANSFORM_STANDARDIZE
+                        : metric == CYTO_METRIC_SPEARMAN ? CYTO_TRANSFORM_RANK : CYTO_TRANSFORM_RAW;
     if (G <= 0 || C <= 0 || S <= 0 || !sc || !st || !slots || !mapped_spot) return CYTO_ERR_BAD_ARG;
     int64_t N = 0;
     for (int s = 0; s < S; s++) { if (slots[s] < 0) return CYTO_ERR_BAD_ARG; N += slots[s]; }
@@ -384,8 +509,8 @@ int cyto_assign_pearson(int G, int C, int S, const double *sc, const double *st,
     CYTO_HIP(hipEventCreate(&e0));
     CYTO_HIP(hipEventCreate(&e1));
     CYTO_HIP(hipEventRecord(e0, stream));
-    if ((rc = cyto_standardize(G, S, st, S, 1, 0, already_normalized, zst.as<float>(), ldzst, Gpad, device_id, stream))) return rc;
-    if ((rc = cyto_standardize(G, C, sc, C, 1, 0, already_normalized, zsc.as<float>(), ldzsc, Gpad, device_id, stream))) return rc;
+    if ((rc = cyto_transform(transform, G, S, st, S, 1, 0, already_normalized, zst.as<float>(), ldzst, Gpad, device_id, stream))) return rc;
+    if ((rc = cyto_transform(transform, G, C, sc, C, 1, 0, already_normalized, zsc.as<float>(), ldzsc, Gpad, device_id, stream))) return rc;
     CYTO_HIP(hipEventRecord(e1, stream));
     CYTO_HIP(hipEventSynchronize(e1));
     float ms_std = 0;
@@ -393,8 +518,8 @@ int cyto_assign_pearson(int G, int C, int S, const double *sc, const double *st,
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     double ms_gemm = 0;
-    if ((rc = cyto_cost_pearson(Gpad, S, C, zst.as<float>(), ldzst, zsc.as<float>(), ldzsc, slots, cost.as<float>(), ldc,
-                                &ms_gemm, device_id, stream)))
+    if ((rc = cyto_cost_metric(metric, Gpad, S, C, zst.as<float>(), ldzst, zsc.as<float>(), ldzsc, slots, cost.as<float>(), ldc,
+                               &ms_gemm, device_id, stream)))
         return rc;
     std::vector<int32_t> colsol((size_t)N);
     cyto_lap_info li;
@@ -417,6 +542,11 @@ int cyto_assign_pearson(int G, int C, int S, const double *sc, const double *st,
         info->gemm_flops = 2.0 * Gpad * (double)S * (double)C;
     }
     return CYTO_OK;
+}
+
+int cyto_assign_pearson(int G, int C, int S, const double *sc, const double *st, const int64_t *slots, int already_normalized,
+                        int64_t *mapped_spot, double *total_cost, cyto_assign_info *info, int device_id) {
+    return cyto_assign_metric(CYTO_METRIC_PEARSON, G, C, S, sc, st, slots, already_normalized, mapped_spot, total_cost, info, device_id);
 }
 
 }  // extern "C"

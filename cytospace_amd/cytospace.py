@@ -35,8 +35,12 @@ def partition_indices(indices, split_by_category_list=None, split_by_interval_in
     return np.array_split(indices, sorted(cuts)[1:-1])
 
 
-def assign_pearson(sc, st, slots, already_normalized=True, device_id=0, return_info=False):
+def assign_pearson(sc, st, slots, already_normalized=True, device_id=0, return_info=False,
+                   distance_metric="Pearson_correlation"):
     """Fused chunk solve on one GPU: returns mapped_st_index (np.int64[C]) [, total, info]."""
+    from .common import METRICS
+    if distance_metric not in METRICS:
+        raise ValueError(f"unknown distance_metric {distance_metric!r}")
     sc = np.ascontiguousarray(sc, dtype=np.float64)
     st = np.ascontiguousarray(st, dtype=np.float64)
     if sc.ndim != 2 or st.ndim != 2:
@@ -52,9 +56,9 @@ def assign_pearson(sc, st, slots, already_normalized=True, device_id=0, return_i
     mapped = np.empty(C, np.int64)
     total = ctypes.c_double()
     info = _lib.AssignInfo()
-    _lib.check(_lib.lib().cyto_assign_pearson(G, C, S, sc.ctypes.data, st.ctypes.data, slots.ctypes.data,
-                                              int(already_normalized), mapped.ctypes.data, ctypes.byref(total),
-                                              ctypes.byref(info), device_id))
+    _lib.check(_lib.lib().cyto_assign_metric(METRICS[distance_metric], G, C, S, sc.ctypes.data, st.ctypes.data,
+                                             slots.ctypes.data, int(already_normalized), mapped.ctypes.data,
+                                             ctypes.byref(total), ctypes.byref(info), device_id))
     if return_info:
         return mapped, total.value, info
     return mapped
@@ -64,14 +68,14 @@ def solve_linear_assignment_problem(scRNA_norm_data, st_norm_data, cell_number_t
                                     solver_method, solver, seed, distance_metric, process_idx=None, device_id=0):
     """cytospace.py:304-351.  Returns (mapped_st_index: list[int] of length C, process_idx).
 
-    "lapjv_hip" + "Pearson_correlation": fused on the device (the +1e-16*rand tie-breaker of
+    "lapjv_hip" (any of the three distance metrics): fused on the device (the +1e-16*rand tie-breaker of
     cytospace.py:325-327 is a no-op in float32 and is skipped).  Other shortest-augmenting-path solvers
     follow the reference's sequence with the device-built cost matrix."""
-    if solver_method == "lapjv_hip" and distance_metric == "Pearson_correlation":
+    if solver_method == "lapjv_hip" and distance_metric in ("Pearson_correlation", "Spearman_correlation", "Euclidean"):
         print('Solving linear assignment problem ...')
         t0 = time.perf_counter()
         mapped = assign_pearson(scRNA_norm_data, st_norm_data, cell_number_to_node_assignment,
-                                already_normalized=True, device_id=device_id)
+                                already_normalized=True, device_id=device_id, distance_metric=distance_metric)
         print(f"Time to solve linear assignment problem: {round(time.perf_counter() - t0, 2)} seconds")
         return mapped.tolist(), process_idx
     if solver_method in ('lapjv', 'lapjv_compat', 'lapjv_hip'):

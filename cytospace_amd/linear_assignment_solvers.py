@@ -44,14 +44,18 @@ def call_solver(solver, solver_method, cost_scaled):
 
 def calculate_cost(expressions_tpm_scRNA_log, expressions_tpm_st_log, cell_number_to_node_assignment,
                    solver_method, distance_metric):
-    """linear_assignment_solvers.py:42-69 for the shortest-augmenting-path solvers and
-    Pearson_correlation: returns (distance_repeat [N x C float32], location_repeat [N int])."""
-    if solver_method == "lap_CSPR" or distance_metric != "Pearson_correlation":
-        raise NotImplementedError("the HIP cost build covers the lapjv-family / Pearson_correlation branch")
+    """linear_assignment_solvers.py:42-69 for the shortest-augmenting-path solvers (Pearson_correlation,
+    Spearman_correlation, Euclidean): returns (distance_repeat [N x C float32], location_repeat [N int])."""
+    if solver_method == "lap_CSPR":
+        raise NotImplementedError("the HIP cost build covers the lapjv-family branch (cost spots x cells)")
+    if distance_metric not in common.METRICS:
+        # the reference leaves `cost` unbound here and dies with UnboundLocalError; say what is wrong instead
+        raise ValueError(f"unknown distance_metric {distance_metric!r}")
     print("Building cost matrix ...")
     t0 = time.perf_counter()
     slots = np.asarray(cell_number_to_node_assignment)
-    cost, N, ld, _ = common.pearson_cost_device(expressions_tpm_scRNA_log, expressions_tpm_st_log, slots)
+    cost, N, ld, _ = common.pearson_cost_device(expressions_tpm_scRNA_log, expressions_tpm_st_log, slots,
+                                                metric=distance_metric)
     C = np.asarray(expressions_tpm_scRNA_log).shape[1]
     distance_repeat = np.ascontiguousarray(cost.to_numpy((N, ld), np.float32)[:, :C])
     cost.free()

@@ -141,6 +141,23 @@ int cyto_assign_pearson(int G, int C, int S, const double *sc, const double *st,
                         int already_normalized, int64_t *mapped_spot, double *total_cost,
                         cyto_assign_info *info, int device_id);
 
+/* ---- the other distance metrics of calculate_cost
+ * (cytospace/linear_assignment_solvers/linear_assignment_solvers.py:53-59) through the same contraction.
+ * Spearman_correlation: matrix_correlation_spearman (cytospace/common/common.py:202-215) = per-column average-tie
+ * ranks (pandas rank() defaults), then the Pearson formula; Euclidean: scipy cdist(..., 'euclidean') transposed.
+ * cyto_transform writes the float32 GEMM operand of one matrix: standardised values, standardised ranks, or the
+ * plain values; cyto_cost_metric / cyto_assign_metric are cyto_cost_pearson / cyto_assign_pearson with a metric. */
+enum { CYTO_METRIC_PEARSON = 0, CYTO_METRIC_SPEARMAN = 1, CYTO_METRIC_EUCLIDEAN = 2 };
+enum { CYTO_TRANSFORM_STANDARDIZE = 0, CYTO_TRANSFORM_RANK = 1, CYTO_TRANSFORM_RAW = 2 };
+int cyto_transform(int transform, int G, int C, const void *x, int64_t ldx, int x_is_f64, int x_on_device,
+                   int already_normalized, float *z_dev, int64_t ldz, int Gpad, int device_id, void *stream);
+int cyto_cost_metric(int metric, int Gpad, int S, int C, const float *zst, int64_t ldzst, const float *zsc, int64_t ldzsc,
+                     const int64_t *slots, float *cost_dev, int64_t ldc, double *gemm_ms, int device_id, void *stream);
+int cyto_assign_metric(int metric, int G, int C, int S, const double *sc, const double *st, const int64_t *slots,
+                       int already_normalized, int64_t *mapped_spot, double *total_cost,
+                       cyto_assign_info *info, int device_id);
+
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,12 +35,51 @@ def matrix_correlation_pearson(v1, v2):
         return (v2.T.dot(v1) - sums / n) / stds / n
 
 
+def rank_columns(v):
+    """pandas.DataFrame(v).rank() with its defaults (ascending, ties averaged, 1-based), per column."""
+    v = np.asarray(v, dtype=np.float64)
+    out = np.empty_like(v)
+    for c in range(v.shape[1]):
+        col = v[:, c]
+        order = np.argsort(col, kind="stable")
+        s = col[order]
+        starts = np.flatnonzero(np.r_[True, s[1:] != s[:-1]])
+        ends = np.r_[starts[1:], len(s)]
+        r = np.empty(len(s))
+        for a, b in zip(starts, ends):
+            r[a:b] = 0.5 * (a + 1 + b)
+        out[order, c] = r
+    return out
+
+
+def matrix_correlation_spearman(v1, v2):
+    """cytospace/common/common.py:202-215 -- the Pearson formula on the per-column ranks."""
+    if v1.shape[0] != v2.shape[0]:
+        raise ValueError("The two matrices v1 and v2 must have equal dimensions; "
+                         "ST and scRNA data must have the same genes")
+    return matrix_correlation_pearson(rank_columns(v1), rank_columns(v2))
+
+
+def euclidean_cost(sc_norm, st_norm):
+    """np.transpose(scipy cdist(sc.T, st.T, 'euclidean')) (linear_assignment_solvers.py:58-59): spots x cells."""
+    a = np.asarray(st_norm, dtype=np.float64).T[:, None, :]
+    b = np.asarray(sc_norm, dtype=np.float64).T[None, :, :]
+    return np.sqrt(((a - b) ** 2).sum(-1))
+
+
 def calculate_cost(sc_norm, st_norm, slots, solver_method="lapjv", distance_metric="Pearson_correlation"):
-    """cytospace/linear_assignment_solvers/linear_assignment_solvers.py:42-69, the non-CSPR Pearson
-    branch: cost = -corr (spots x cells), rows repeated slots[s] times in spot order."""
-    if distance_metric != "Pearson_correlation" or solver_method == "lap_CSPR":
-        raise NotImplementedError("oracle restates the lapjv / Pearson branch only")
-    cost = -matrix_correlation_pearson(sc_norm, st_norm)
+    """cytospace/linear_assignment_solvers/linear_assignment_solvers.py:42-69, the non-CSPR branch:
+    cost (spots x cells) = -Pearson, -Spearman or Euclidean distance; rows repeated slots[s] times in spot order."""
+    if solver_method == "lap_CSPR":
+        raise NotImplementedError("oracle restates the lapjv branch only")
+    if distance_metric == "Pearson_correlation":
+        cost = -matrix_correlation_pearson(sc_norm, st_norm)
+    elif distance_metric == "Spearman_correlation":
+        cost = -matrix_correlation_spearman(sc_norm, st_norm)
+    elif distance_metric == "Euclidean":
+        cost = euclidean_cost(sc_norm, st_norm)
+    else:
+        raise ValueError(distance_metric)
     location_repeat = np.repeat(np.arange(len(slots)), slots).astype(int)
     return cost[location_repeat, :], location_repeat
 

@@ -146,3 +146,52 @@ def test_assign_chunks_concurrent_matches_sequential():
     r0 = gcyto.assign_chunks(sc, st, None, index_sc, subsampled_slots_list=slots_list, rank=0, world_size=2)
     r1 = gcyto.assign_chunks(sc, st, None, index_sc, subsampled_slots_list=slots_list, rank=1, world_size=2)
     assert sorted(list(r0) + list(r1)) == list(range(len(index_sc)))
+
+
+# ---- Spearman_correlation and Euclidean through the same contraction ----
+
+def test_gv2b_spearman_correlation():
+    d = load("gv2b_spearman.npz")
+    corr = gcommon.matrix_correlation_spearman(d["sc_norm"], d["st_norm"])
+    np.testing.assert_allclose(corr, d["corr"], rtol=0, atol=2e-6)     # ranks are exact; fp32 contraction tolerance
+
+
+@pytest.mark.parametrize("tag,metric,rtol,atol", [("spearman", "Spearman_correlation", 0.0, 2e-6),
+                                                  ("euclidean", "Euclidean", 2e-6, 1e-5)])
+def test_gv9_calculate_cost_other_metrics(tag, metric, rtol, atol):
+    d = load("gv9_metrics_cost.npz")
+    dist, loc = gsolvers.calculate_cost(d["sc_norm"], d["st_norm"], d["slots"], "lapjv_hip", metric)
+    assert np.array_equal(loc, d[tag + "_location_repeat"]) and dist.shape == d[tag + "_distance_repeat"].shape
+    np.testing.assert_allclose(dist, d[tag + "_distance_repeat"], rtol=rtol, atol=atol)
+    # repeated spot rows are bit-identical copies
+    for s in np.flatnonzero(d["slots"] > 1):
+        rows = np.flatnonzero(loc == s)
+        assert all(np.array_equal(dist[rows[0]], dist[r]) for r in rows[1:])
+    with pytest.raises(ValueError):
+        gsolvers.calculate_cost(d["sc_norm"], d["st_norm"], d["slots"], "lapjv_hip", "Manhattan")
+
+
+@pytest.mark.parametrize("G", [5, 1000, 1025, 4100])
+def test_spearman_ranks_exact_with_heavy_ties(G):
+    # count data: most entries tie at 0; the device ranks (average ties, float64 compares) must equal the oracle's
+    rng = np.random.default_rng(G)
+    sc = rng.poisson(0.7, (G, 7)).astype(np.float64)
+    st = rng.poisson(2.0, (G, 3)).astype(np.float64)
+    got = gcommon.matrix_correlation_spearman(sc, st)
+    want = ocost.matrix_correlation_spearman(sc, st)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("tag,metric", [("spearman", "Spearman_correlation"), ("euclidean", "Euclidean")])
+def test_gv10_fused_solve_other_metrics_spot_level(tag, metric):
+    d = load("gv10_metrics_solve.npz")
+    mapped, pidx = gcyto.solve_linear_assignment_problem(d["sc_norm"], d["st_norm"], d["slots"], "lapjv_hip", None, 1,
+                                                         metric, process_idx=5)
+    assert pidx == 5
+    mapped = np.asarray(mapped)
+    assert np.array_equal(np.bincount(mapped, minlength=len(d["slots"])), d["slots"])
+    # spot level == reference + exact solver, or (degenerate optimum) the same total on the reference's float64 cost
+    if not np.array_equal(mapped, d[tag + "_mapped"]):
+        cost64, _ = ocost.calculate_cost(d["sc_norm"], d["st_norm"], np.ones(len(d["slots"]), np.int64), "lapjv", metric)
+        cells = np.arange(len(mapped))
+        assert abs(cost64[mapped, cells].sum() - cost64[d[tag + "_mapped"], cells].sum()) <= 1e-5 * max(1.0, abs(cost64[mapped, cells].sum()))

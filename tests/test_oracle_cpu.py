@@ -124,3 +124,19 @@ def test_jv_oracle_scan_counters():
     assert st.scans_colred == n
     assert st.row_scans == (st.scans_colred + st.scans_redtransfer + st.scans_arr + st.scans_aug_init + st.scans_aug_relax)
     assert st.scans_aug_init == st.augmentations == st.free_after_arr2
+
+
+def test_gv9_other_metrics_cost():
+    # oracle restatement of the Spearman / Euclidean branches of calculate_cost vs arrays captured from the reference
+    d = np.load(os.path.join(G, "gv9_metrics_cost.npz"))
+    for tag, metric in (("spearman", "Spearman_correlation"), ("euclidean", "Euclidean")):
+        dist, loc = ocost.calculate_cost(d["sc_norm"], d["st_norm"], d["slots"], "lapjv", metric)
+        assert np.array_equal(loc, d[tag + "_location_repeat"])
+        np.testing.assert_allclose(dist, d[tag + "_distance_repeat"], rtol=1e-12, atol=1e-12)
+    d2 = np.load(os.path.join(G, "gv2b_spearman.npz"))
+    np.testing.assert_allclose(ocost.matrix_correlation_spearman(d2["sc_norm"], d2["st_norm"]), d2["corr"], rtol=0, atol=1e-12)
+
+
+def test_rank_columns_average_ties():
+    v = np.array([[3.0, 0.0], [1.0, 0.0], [3.0, 5.0], [0.0, 0.0], [3.0, 5.0]])
+    np.testing.assert_array_equal(ocost.rank_columns(v), np.array([[4.0, 2.0], [2.0, 2.0], [4.0, 4.5], [1.0, 2.0], [4.0, 4.5]]))
