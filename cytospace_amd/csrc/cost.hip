@@ -152,35 +152,59 @@ __global__ __launch_bounds__(256) void colsq_partial(int G, int C, const float *
 
 // Per-column ranks, ties averaged, 1-based: pandas.DataFrame.rank() defaults, as used by
 // matrix_correlation_spearman (/root/reference/cytospace/common/common.py:202-215).
-// rank_i = #{x_j < x_i} + (#{x_j == x_i} + 1) / 2, counted exactly in float64: one workgroup per column, every
-// thread keeps MOWN of the column's values in registers and streams the whole column past them through LDS
-// (broadcast reads).  O(G^2) compares per column, but they are full-rate VALU work: c3 (20k genes x 55k
-// columns) is 2.2e13 compares.  Ranks are half-integers <= G: exact in float32.
-// The transform normalize_data applies before (log2(x * 1e6 / colsum + 1)) is strictly increasing per column, so
-// ranking the cleaned input gives the ranks of the normalised values.
-constexpr int RANK_CHUNK = 4096;
+// rank_i = #{x_j < x_i} + (#{x_j == x_i} + 1) / 2, exact in float64 order: one workgroup per column; the column is
+// taken in chunks of 8192 values that are sorted in LDS as order-preserving 64-bit keys (bitonic network, 1024
+// threads), and every value of the column binary-searches each sorted chunk for its lower and upper bound.
+// Ranks are half-integers <= G: exact in float32.  The transform normalize_data applies before
+// (log2(x * 1e6 / colsum + 1)) is strictly increasing per column, so ranking the cleaned input gives the ranks of
+// the normalised values.
+constexpr int RANK_CHUNK = 8192;
+__device__ __forceinline__ uint64_t d2ord(double x) {
+    const uint64_t b = (uint64_t)__double_as_longlong(x + 0.0);          // +0.0: -0 -> +0
+    return b ^ ((b >> 63) ? ~0ull : 0x8000000000000000ull);
+}
 template <typename TIn, int MOWN>
 __global__ __launch_bounds__(1024) void rank_columns(int G, int C, const TIn *__restrict__ x, int64_t ldx,
                                                      float *__restrict__ r, int64_t ldr) {
-    __shared__ double chunk[RANK_CHUNK];
+    __shared__ uint64_t sk[RANK_CHUNK];
     const int c = blockIdx.x, tid = threadIdx.x;
-    double own[MOWN];
+    uint64_t own[MOWN];
     int lt[MOWN], eq[MOWN];
 #pragma unroll
     for (int e = 0; e < MOWN; e++) {
         const int g = tid + e * 1024;
-        own[e] = g < G ? clean<TIn>(x[(int64_t)g * ldx + c]) : __longlong_as_double(0x7FF8000000000000ll);   // NaN: never <, never ==
+        own[e] = g < G ? d2ord(clean<TIn>(x[(int64_t)g * ldx + c])) : 0ull;
         lt[e] = 0; eq[e] = 0;
     }
     for (int j0 = 0; j0 < G; j0 += RANK_CHUNK) {
-        const int cnt = min(RANK_CHUNK, G - j0);
         __syncthreads();
-        for (int j = tid; j < cnt; j += 1024) chunk[j] = clean<TIn>(x[(int64_t)(j0 + j) * ldx + c]);
+        for (int j = tid; j < RANK_CHUNK; j += 1024)
+            sk[j] = (j0 + j < G) ? d2ord(clean<TIn>(x[(int64_t)(j0 + j) * ldx + c])) : ~0ull;   // pad: above every key
         __syncthreads();
-        for (int j = 0; j < cnt; j++) {
-            const double xj = chunk[j];
+        for (int k = 2; k <= RANK_CHUNK; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < RANK_CHUNK / 2; t += 1024) {
+                    const int i = 2 * t - (t & (j - 1)), l = i + j;
+                    const uint64_t a = sk[i], b2 = sk[l];
+                    if ((a > b2) == ((i & k) == 0)) { sk[i] = b2; sk[l] = a; }
+                }
+                __syncthreads();
+            }
+        }
 #pragma unroll
-            for (int e = 0; e < MOWN; e++) { lt[e] += (xj < own[e]) ? 1 : 0; eq[e] += (xj == own[e]) ? 1 : 0; }
+        for (int e = 0; e < MOWN; e++) {
+            if (tid + e * 1024 < G) {
+                const uint64_t key = own[e];
+                int lo = 0, hi = 0;
+#pragma unroll
+                for (int step = RANK_CHUNK / 2; step >= 1; step >>= 1) {
+                    if (sk[lo + step - 1] < key) lo += step;
+                    if (sk[hi + step - 1] <= key) hi += step;
+                }
+                if (sk[lo] < key) lo++;
+                if (sk[hi] <= key) hi++;
+                lt[e] += lo; eq[e] += hi - lo;
+            }
         }
     }
 #pragma unroll
