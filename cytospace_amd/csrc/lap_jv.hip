@@ -2785,7 +2785,8 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
                      T *u, T *v, double *total, cyto_lap_info *info, int device_id, void *stream_) {
     constexpr int VW = VecOf<T>::W;
     if (n <= 0 || !cost || ld < n) return CYTO_ERR_BAD_ARG;
-    const int64_t cap = (int64_t)16 * VW * BLOCK;
+    // float32: the cached-chain path takes any n up to FAST_NMAX; float64: the generic kernel's register budget
+    const int64_t cap = std::is_same<T, float>::value ? (int64_t)FAST_NMAX : (int64_t)16 * VW * BLOCK;
     if (n > cap) return CYTO_ERR_UNSUPPORTED;
     int rc = select_device(device_id);
     if (rc) return rc;
