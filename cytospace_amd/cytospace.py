@@ -133,3 +133,61 @@ def assign_chunks(scRNA_norm, st_norm, cell_number_to_node_assignment, index_sc_
     with ThreadPoolExecutor(max_workers=max(1, min(max_concurrent, max(1, len(jobs))))) as ex:
         futs = {idx: ex.submit(assign_pearson, sc, st, slots, True, device_id) for idx, (sc, st, slots) in jobs.items()}
         return {idx: f.result() for idx, f in futs.items()}
+
+
+def apply_linear_assignment(scRNA_data, st_data, coordinates_data, cell_number_to_node_assignment,
+                            solver_method, solver, seed, distance_metric, number_of_processors,
+                            index_sc_list, index_st_list=None, subsampled_cell_number_to_node_assignment_list=None,
+                            rank=0, world_size=1, device_id=0):
+    """cytospace/cytospace.py:354-469 with the reference's arguments (pandas DataFrames as read by read_data):
+    normalise once, solve every chunk, map the assigned spot indices to coordinates.
+
+    Returns (assigned_locations: pd.DataFrame, cell_ids_selected: np.ndarray); the nth cell id is mapped to the
+    nth row of assigned_locations.  The reference forks one process per chunk (number_of_processors bounds the
+    pool); here `number_of_processors` bounds the chunks solved side by side on this rank's GPU, and with
+    world_size > 1 (one process per GPU) each rank returns the chunks the LPT schedule gives it, in chunk order
+    (the reference concatenates in completion order: compare as a set of (cell, spot) pairs)."""
+    import pandas as pd
+    from . import common
+    if (index_st_list is not None) and (subsampled_cell_number_to_node_assignment_list is not None):
+        raise ValueError("index_st_list and subsampled_cell_number_to_node_assignment_list cannot both be specified")
+    if solver_method != "lapjv_hip":
+        raise ValueError("apply_linear_assignment of this package drives the lapjv_hip solver")
+    scRNA_norm_np = common.normalize_data(scRNA_data.to_numpy(), device_id)
+    st_norm_np = common.normalize_data(st_data.to_numpy(), device_id)
+    cell_ids = scRNA_data.columns.values
+    slots_all = np.asarray(cell_number_to_node_assignment)
+    if (index_st_list is None) and (subsampled_cell_number_to_node_assignment_list is None):
+        mapped_st_index, _ = solve_linear_assignment_problem(
+            scRNA_norm_np[:, index_sc_list[0]], st_norm_np, slots_all, solver_method, solver, seed, distance_metric,
+            device_id=device_id)
+        return coordinates_data.iloc[mapped_st_index], cell_ids[index_sc_list[0]]
+    num_iters = len(index_st_list) if index_st_list is not None else len(subsampled_cell_number_to_node_assignment_list)
+    print(f"Number of required processors: {num_iters}")
+    n_chunks = num_iters
+    from concurrent.futures import ThreadPoolExecutor
+    owner = schedule_chunks([len(index_sc_list[idx]) for idx in range(n_chunks)], world_size)
+    mine = [idx for idx in range(n_chunks) if owner[idx] == rank]
+
+    def one(idx):
+        if index_st_list is not None:
+            st_sel = st_norm_np[:, index_st_list[idx]]
+            slots = slots_all[index_st_list[idx]]
+        else:
+            st_sel = st_norm_np
+            slots = np.asarray(subsampled_cell_number_to_node_assignment_list[idx])
+        mapped = assign_pearson(scRNA_norm_np[:, index_sc_list[idx]], st_sel, slots, True, device_id,
+                                distance_metric=distance_metric)
+        return idx, mapped
+
+    with ThreadPoolExecutor(max_workers=max(1, min(len(mine) or 1, int(number_of_processors)))) as ex:
+        results = list(ex.map(one, mine))
+    assigned_locations_list, cell_ids_selected_list = [], []
+    for idx, mapped in results:
+        loc = coordinates_data.iloc[index_st_list[idx]].iloc[mapped] if index_st_list is not None \
+            else coordinates_data.iloc[mapped]
+        assigned_locations_list.append(loc)
+        cell_ids_selected_list.append(cell_ids[index_sc_list[idx]])
+    if not results:
+        return coordinates_data.iloc[[]], cell_ids[[]]
+    return pd.concat(assigned_locations_list), np.concatenate(cell_ids_selected_list, axis=0)

@@ -195,3 +195,34 @@ def test_gv10_fused_solve_other_metrics_spot_level(tag, metric):
         cost64, _ = ocost.calculate_cost(d["sc_norm"], d["st_norm"], np.ones(len(d["slots"]), np.int64), "lapjv", metric)
         cells = np.arange(len(mapped))
         assert abs(cost64[mapped, cells].sum() - cost64[d[tag + "_mapped"], cells].sum()) <= 1e-5 * max(1.0, abs(cost64[mapped, cells].sum()))
+
+
+@pytest.mark.parametrize("mode", ["sc", "ss"])
+def test_gv11_apply_linear_assignment_chunked_modes(mode):
+    # A8: the reference's apply_linear_assignment (chunk fan-out) on the same DataFrames; the reference concatenates in
+    # completion order, so compare as a set of (cell, spot coordinates) pairs
+    import pandas as pd
+    d = load("gv11_apply_linear_assignment.npz")
+    sc, st, slots = d[mode + "_counts"], d[mode + "_st_counts"], d[mode + "_slots"]
+    G, C = sc.shape
+    S = st.shape[1]
+    sc_df = pd.DataFrame(sc, index=[f"g{i}" for i in range(G)], columns=[f"c{i}" for i in range(C)])
+    st_df = pd.DataFrame(st, index=sc_df.index, columns=[f"s{i}" for i in range(S)])
+    ncol = 10 if mode == "sc" else 4
+    coords = pd.DataFrame({"row": np.arange(S) // ncol, "col": np.arange(S) % ncol}, index=st_df.columns)
+    idx_sc = np.split(d[mode + "_idx_sc"], np.cumsum(d[mode + "_idx_sc_lens"])[:-1])
+    kw = {}
+    if mode == "sc":
+        kw["index_st_list"] = np.split(d["sc_idx_st"], np.cumsum(d["sc_idx_st_lens"])[:-1])
+    else:
+        kw["subsampled_cell_number_to_node_assignment_list"] = list(d["ss_sub"])
+    loc, ids = gcyto.apply_linear_assignment(sc_df, st_df, coords, slots, "lapjv_hip", None, 1, "Pearson_correlation", 2,
+                                             idx_sc, **kw)
+    got = {(int(c[1:]), int(r), int(k)) for c, (r, k) in zip(ids, loc.to_numpy())}
+    want = {(int(c), int(r), int(k)) for c, (r, k) in zip(d[mode + "_out_cell"], d[mode + "_out_rowcol"])}
+    assert len(got) == len(ids) == len(want) and got == want
+    # two ranks split the chunks and together give the same pairs
+    parts = [gcyto.apply_linear_assignment(sc_df, st_df, coords, slots, "lapjv_hip", None, 1, "Pearson_correlation", 2,
+                                           idx_sc, rank=r, world_size=2, **kw) for r in range(2)]
+    got2 = {(int(c[1:]), int(r), int(k)) for loc2, ids2 in parts for c, (r, k) in zip(ids2, loc2.to_numpy())}
+    assert got2 == want
