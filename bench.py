@@ -125,13 +125,13 @@ def main():
 
     # roofline of the dominant kernel, per launch, timed with HIP events on the launch stream
     # (cyto_lap_info.ms_arr / ms_aug).  jv_chain2 = reduction transfer + augmenting row reduction (the
-    # longest kernel), jv_aug_lazy (n >= 12288; jv_aug2 below) = augmentation.  Algorithmic bytes =
+    # longest kernel), jv_aug_lazy (n > 5120; jv_aug2 below) = augmentation.  Algorithmic bytes =
     # 4 * n * row scans.
     arr_scans = info.scans_redtransfer + info.scans_arr
     aug_scans = info.scans_aug_init + info.scans_aug_relax
     arr_ms = float(np.mean(arr_ms_l))
     aug_ms = float(np.mean(aug_ms_l))
-    aug_name = "jv_aug_lazy" if n >= 12288 else "jv_aug2"
+    aug_name = "jv_aug_lazy" if n > 5120 else "jv_aug2"
     dom = ("jv_chain2", arr_scans, arr_ms) if arr_ms >= aug_ms else (aug_name, aug_scans, aug_ms)
     dom_bytes = 4.0 * n * dom[1]
     achieved = dom_bytes / (dom[2] * 1e-3) / 1e9

@@ -6,15 +6,20 @@
 // Same four phases, same operand order and the same lowest-index tie-breaking as the CPU
 // oracle (oracle/jv_oracle_impl.h), so rowsol/colsol/u/v are bit-identical to it.
 //
-// Kernel plan
-//   colred_partial / colred_finish / colred_assign : COLUMN REDUCTION.  The only phase with
-//       N^2 independent work: a full-chip streaming pass (float4 per lane, >=2k workgroups).
-//   jv_chain : REDUCTION TRANSFER, AUGMENTING ROW REDUCTION and AUGMENTATION are a chain of
-//       dependent row scans (each scan's arg-min chooses the next row).  One persistent
-//       1024-thread workgroup runs the chain: dual prices v and Dijkstra distances d live in
-//       VGPRs (each lane owns fixed columns), colsol lives in LDS, every row scan is one
-//       coalesced 16 B/lane sweep of the cost row from HBM followed by a wave64 shuffle
-//       reduction and one cross-wave LDS step.  No grid-wide synchronisation is needed.
+// Kernel plan (float32 path; DESIGN.md section 4.1 has the exactness arguments and the measurements)
+//   colred_partial / colred_finish / colred_assign : COLUMN REDUCTION.  The only phase with N^2 independent
+//       work: a full-chip streaming pass (float4 per lane, >= 2k workgroups).
+//   rows_same_as_prev / rows_group_ids : runs of bitwise identical rows (CytoSPACE repeats every spot row
+//       slots[s] times); used to elide provably useless scans in the augmentation.
+//   build_row_caches<CH> / build_row_caches_stream : per row, the <= 63 columns with the smallest reduced cost
+//       plus a floor that bounds every other column (a certificate while prices only decrease).
+//   jv_chain2<CH, LDS_STATE> : REDUCTION TRANSFER + AUGMENTING ROW REDUCTION, a chain of dependent row scans.
+//       One persistent 512-thread workgroup; a scan is served from the row's cache by wave 0 alone whenever the
+//       cache certifies its top-2, otherwise the workgroup re-scans the row (refresh_row / refresh_row_stream).
+//   jv_aug_lazy<LDS_STATE> (n > 5120) : AUGMENTATION with cache-certified scans and sparse search initialisation.
+//   jv_aug2<CH, LDS_STATE> (n <= 5120), jv_aug_stream, jv_aug_coop : dense augmentation kernels (register /
+//       L2-resident / multi-CU column state); the last two are kept for comparison (CYTO_AUG=stream|coop).
+//   jv_chain<T, CH> : the generic dense chain (1024 threads) -- float64 only.
 //
 // Compile with -ffp-contract=off (build.py does): the arithmetic is subtract/compare only,
 // but nothing may be re-associated.
@@ -2322,10 +2327,6 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                         }
                         const int ep = (int)readlane32(cc, le);
                         const float cie = __uint_as_float(readlane32(__float_as_uint(cv), le));
-#ifdef LZ_DEBUG
-                        if (lane == 0 && (f < 12 || ep < 0 || ep >= n || freerow < 0 || freerow >= n))
-                            printf("fast f=%d freerow=%d ep=%d le=%d me=%llx t0=%x numfree=%d id1=%d\n", f, freerow, ep, le, (unsigned long long)me, t0, numfree, id1_saved);
-#endif
                         if (lane == 0) {
                             st_csset<LDS_STATE>(s_cs, a.colsol, ep, freerow);
                             st_f32(a.cassign + ep, cie);
@@ -2894,10 +2895,11 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
             LazyPlan lz; memset(&lz, 0, sizeof lz);
             DevBuf b_lzhb, b_lzhs;
             {
-                // default for n >= 12288 (below that the register-resident dense search is faster); CYTO_AUG=lazy
-                // forces it at any size, CYTO_AUG=single|stream|coop selects the older kernels
+                // default for n > 5120 (measured cross-over with the register-resident dense search, uniform and
+                // duplicated-row instances); CYTO_AUG=lazy forces it at any size, CYTO_AUG=single|stream|coop selects
+                // the older kernels
                 const char *e = getenv("CYTO_AUG");
-                if (e ? strcmp(e, "lazy") == 0 : n >= 12288) {
+                if (e ? strcmp(e, "lazy") == 0 : n > 5120) {
                     const size_t npad6 = (((size_t)((n + 3) & ~3) * 6) + 15) & ~(size_t)15, nb24 = (size_t)((((n + 63) / 64) + 511) & ~511) * 8 + (size_t)((n + 63) / 64) * 24 + 16;
                     const size_t lds_budget = 160 * 1024 - 2048;       // static __shared__ of the kernel
                     lz.enabled = true;
