@@ -80,6 +80,10 @@ def lib():
         L.cyto_transform.argtypes = [i32, i32, i32, vp, i64, i32, i32, i32, vp, i64, i32, i32, vp]
         L.cyto_cost_metric.argtypes = [i32, i32, i32, i32, vp, i64, vp, i64, vp, vp, i64, dp, i32, vp]
         L.cyto_assign_metric.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32, vp, dp, ctypes.POINTER(AssignInfo), i32]
+        L.cyto_ctx_create.argtypes = [i32, i32, i32, i32, vp, vp, i32, i32, ctypes.POINTER(vp)]
+        L.cyto_ctx_assign_chunk.argtypes = [vp, vp, i32, vp, i32, vp, vp, dp, ctypes.POINTER(AssignInfo)]
+        L.cyto_ctx_destroy.argtypes = [vp]
+        L.cyto_ctx_destroy.restype = None
         L.cyto_assign_pearson.argtypes = [i32, i32, i32, vp, vp, vp, i32, vp, dp, ctypes.POINTER(AssignInfo), i32]
         L.cyto_lap_batch_f32.argtypes = [i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32]
         L.cyto_comm_unique_id.argtypes = [ctypes.c_char_p]

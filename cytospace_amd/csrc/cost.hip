@@ -25,6 +25,8 @@
 #include "cyto_common.h"
 #include <math.h>
 #include <vector>
+#include <new>
+#include <string.h>
 
 namespace cyto {
 
@@ -324,6 +326,16 @@ __global__ __launch_bounds__(256) void pearson_gemm(int Gpad, int S, int C, cons
     }
 }
 
+// out[g][c'] = z[g][idx[c']] for c' < nsel (columns beyond nsel are left zero): the GEMM operand of one chunk
+__global__ __launch_bounds__(256) void gather_columns(int Gpad, int nsel, const float *__restrict__ z, int64_t ldz,
+                                                      const int32_t *__restrict__ idx, float *__restrict__ out, int64_t ldo) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= nsel) return;
+    const int src = idx[c];
+    const int g0 = blockIdx.y * GB, g1 = min(Gpad, g0 + GB);
+    for (int g = g0; g < g1; g++) out[(int64_t)g * ldo + c] = z[(int64_t)g * ldz + src];
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -564,6 +576,123 @@ int cyto_assign_metric(int metric, int G, int C, int S, const double *sc, const 
         info->ms_gemm = ms_gemm;
         info->lap = li;
         info->gemm_flops = 2.0 * Gpad * (double)S * (double)C;
+    }
+    return CYTO_OK;
+}
+
+// ---- multi-chunk seam (apply_linear_assignment, cytospace/cytospace.py:354-469): the two expression matrices are
+// uploaded and transformed ONCE; every chunk then gathers its cells / spots out of the resident operands ----
+struct cyto_expr_ctx {
+    int metric, G, Gpad, C, S, device_id;
+    int64_t ldsc, ldst;
+    DevBuf zsc, zst;
+};
+
+int cyto_ctx_create(int metric, int G, int C, int S, const double *sc, const double *st, int already_normalized, int device_id,
+                    cyto_expr_ctx **out) {
+    if (!out || G <= 0 || C <= 0 || S <= 0 || !sc || !st) return CYTO_ERR_BAD_ARG;
+    if (metric < CYTO_METRIC_PEARSON || metric > CYTO_METRIC_EUCLIDEAN) return CYTO_ERR_BAD_ARG;
+    int rc = select_device(device_id);
+    if (rc) return rc;
+    cyto_expr_ctx *ctx = new (std::nothrow) cyto_expr_ctx();
+    if (!ctx) return CYTO_ERR_NOMEM;
+    ctx->metric = metric; ctx->G = G; ctx->Gpad = (int)round_up(G, BK); ctx->C = C; ctx->S = S; ctx->device_id = device_id;
+    ctx->ldsc = round_up(C, BN); ctx->ldst = round_up(S, BM);
+    const int transform = metric == CYTO_METRIC_PEARSON ? CYTO_TRANSFORM_STANDARDIZE
+                        : metric == CYTO_METRIC_SPEARMAN ? CYTO_TRANSFORM_RANK : CYTO_TRANSFORM_RAW;
+    if ((rc = ctx->zsc.alloc((size_t)ctx->Gpad * ctx->ldsc * 4)) || (rc = ctx->zst.alloc((size_t)ctx->Gpad * ctx->ldst * 4)) ||
+        (rc = cyto_transform(transform, G, S, st, S, 1, 0, already_normalized, ctx->zst.as<float>(), ctx->ldst, ctx->Gpad, device_id, nullptr)) ||
+        (rc = cyto_transform(transform, G, C, sc, C, 1, 0, already_normalized, ctx->zsc.as<float>(), ctx->ldsc, ctx->Gpad, device_id, nullptr))) {
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return CYTO_OK;
+}
+
+void cyto_ctx_destroy(cyto_expr_ctx *ctx) {
+    if (!ctx) return;
+    (void)select_device(ctx->device_id);
+    delete ctx;
+}
+
+// One chunk: cells idx_sc[0..n_sc) against spots idx_st[0..n_st) (NULL: all S spots) with slots[k] cells for the k-th
+// listed spot; sum(slots) must be n_sc.  mapped_spot[c] = position in the chunk's spot list (what the reference's
+// solve_linear_assignment_problem returns for the chunk, cytospace.py:331-332).  Spots with slots == 0 are not
+// contracted at all.  Thread-safe on one context (private stream and buffers per call).
+int cyto_ctx_assign_chunk(cyto_expr_ctx *ctx, const int64_t *idx_sc, int n_sc, const int64_t *idx_st, int n_st,
+                          const int64_t *slots, int64_t *mapped_spot, double *total_cost, cyto_assign_info *info) {
+    if (!ctx || !idx_sc || n_sc <= 0 || !slots || !mapped_spot) return CYTO_ERR_BAD_ARG;
+    const int nst = idx_st ? n_st : ctx->S;
+    if (nst <= 0) return CYTO_ERR_BAD_ARG;
+    int rc = select_device(ctx->device_id);
+    if (rc) return rc;
+    // the spots that actually receive cells
+    std::vector<int32_t> h_st, h_pos, h_sc((size_t)n_sc);
+    std::vector<int64_t> h_slots;
+    int64_t N = 0;
+    for (int k = 0; k < nst; k++) {
+        if (slots[k] < 0) return CYTO_ERR_BAD_ARG;
+        const int64_t s = idx_st ? idx_st[k] : k;
+        if (s < 0 || s >= ctx->S) return CYTO_ERR_BAD_ARG;
+        if (slots[k] > 0) { h_st.push_back((int32_t)s); h_pos.push_back(k); h_slots.push_back(slots[k]); N += slots[k]; }
+    }
+    if (N != n_sc) return CYTO_ERR_BAD_ARG;                 // the LAP must be square
+    for (int c = 0; c < n_sc; c++) {
+        if (idx_sc[c] < 0 || idx_sc[c] >= ctx->C) return CYTO_ERR_BAD_ARG;
+        h_sc[(size_t)c] = (int32_t)idx_sc[c];
+    }
+    const int Su = (int)h_st.size();
+    const int64_t ldzst = round_up(Su, BM), ldzsc = round_up(n_sc, BN), ldc = round_up(n_sc, 4);
+    DevBuf zst, zsc, cost, dsc, dst;
+    if ((rc = zst.alloc((size_t)ctx->Gpad * ldzst * 4)) || (rc = zsc.alloc((size_t)ctx->Gpad * ldzsc * 4)) ||
+        (rc = cost.alloc((size_t)N * ldc * 4)) || (rc = dsc.alloc((size_t)n_sc * 4)) || (rc = dst.alloc((size_t)Su * 4)))
+        return rc;
+    hipStream_t stream = nullptr;
+    CYTO_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { if (s) (void)hipStreamDestroy(s); } } guard{stream};
+    hipEvent_t e0, e1;
+    CYTO_HIP(hipEventCreate(&e0));
+    CYTO_HIP(hipEventCreate(&e1));
+    CYTO_HIP(hipEventRecord(e0, stream));
+    CYTO_HIP(hipMemcpyAsync(dsc.p, h_sc.data(), (size_t)n_sc * 4, hipMemcpyHostToDevice, stream));
+    CYTO_HIP(hipMemcpyAsync(dst.p, h_st.data(), (size_t)Su * 4, hipMemcpyHostToDevice, stream));
+    CYTO_HIP(hipMemsetAsync(zst.p, 0, (size_t)ctx->Gpad * ldzst * 4, stream));
+    CYTO_HIP(hipMemsetAsync(zsc.p, 0, (size_t)ctx->Gpad * ldzsc * 4, stream));
+    const int nblk = (ctx->Gpad + GB - 1) / GB;
+    hipLaunchKernelGGL(gather_columns, dim3((Su + 255) / 256, nblk), dim3(256), 0, stream, ctx->Gpad, Su, ctx->zst.as<float>(),
+                       ctx->ldst, dst.as<int32_t>(), zst.as<float>(), ldzst);
+    hipLaunchKernelGGL(gather_columns, dim3((n_sc + 255) / 256, nblk), dim3(256), 0, stream, ctx->Gpad, n_sc, ctx->zsc.as<float>(),
+                       ctx->ldsc, dsc.as<int32_t>(), zsc.as<float>(), ldzsc);
+    CYTO_HIP(hipGetLastError());
+    CYTO_HIP(hipEventRecord(e1, stream));
+    CYTO_HIP(hipEventSynchronize(e1));
+    float ms_gather = 0;
+    (void)hipEventElapsedTime(&ms_gather, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    double ms_gemm = 0;
+    if ((rc = cyto_cost_metric(ctx->metric, ctx->Gpad, Su, n_sc, zst.as<float>(), ldzst, zsc.as<float>(), ldzsc, h_slots.data(),
+                               cost.as<float>(), ldc, &ms_gemm, ctx->device_id, stream)))
+        return rc;
+    std::vector<int32_t> colsol((size_t)N);
+    cyto_lap_info li;
+    double total = 0;
+    if ((rc = cyto_lap_f32((int)N, cost.as<float>(), ldc, 1, nullptr, colsol.data(), nullptr, nullptr, &total, &li, ctx->device_id, stream)))
+        return rc;
+    std::vector<int32_t> rowpos((size_t)N);
+    {
+        int64_t r = 0;
+        for (int k = 0; k < Su; k++) for (int64_t t = 0; t < h_slots[(size_t)k]; t++) rowpos[(size_t)r++] = h_pos[(size_t)k];
+    }
+    for (int c = 0; c < n_sc; c++) mapped_spot[c] = rowpos[(size_t)colsol[(size_t)c]];
+    if (total_cost) *total_cost = total;
+    if (info) {
+        memset(info, 0, sizeof *info);
+        info->ms_standardize = ms_gather;     // here: the two column gathers (the transforms ran once, in cyto_ctx_create)
+        info->ms_gemm = ms_gemm;
+        info->lap = li;
+        info->gemm_flops = 2.0 * ctx->Gpad * (double)Su * (double)n_sc;
     }
     return CYTO_OK;
 }

@@ -64,6 +64,66 @@ def assign_pearson(sc, st, slots, already_normalized=True, device_id=0, return_i
     return mapped
 
 
+class ExpressionContext:
+    """Both expression matrices uploaded and transformed once (standardised / ranked / plain float32 operands of the
+    metric), resident in HBM; every chunk of apply_linear_assignment gathers its columns out of them."""
+
+    def __init__(self, sc, st, already_normalized=True, device_id=0, distance_metric="Pearson_correlation"):
+        from .common import METRICS
+        if distance_metric not in METRICS:
+            raise ValueError(f"unknown distance_metric {distance_metric!r}")
+        sc = np.ascontiguousarray(sc, dtype=np.float64)
+        st = np.ascontiguousarray(st, dtype=np.float64)
+        if sc.ndim != 2 or st.ndim != 2:
+            raise ValueError("sc and st must be 2-D genes x columns matrices")
+        if sc.shape[0] != st.shape[0]:
+            raise ValueError("The two matrices v1 and v2 must have equal dimensions; "
+                             "ST and scRNA data must have the same genes")
+        self.G, self.C = sc.shape
+        self.S = st.shape[1]
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.lib().cyto_ctx_create(METRICS[distance_metric], self.G, self.C, self.S, sc.ctypes.data, st.ctypes.data,
+                                              int(already_normalized), device_id, ctypes.byref(self._h)))
+
+    def assign_chunk(self, index_sc, slots, index_st=None, return_info=False):
+        """Cells index_sc against spots index_st (None: all spots) with slots[k] cells for the k-th listed spot.
+        Returns mapped_st_index (np.int64, positions in the chunk's spot list) [, total, info]."""
+        if self._h is None:
+            raise RuntimeError("context was closed")
+        idx_sc = np.ascontiguousarray(index_sc, dtype=np.int64)
+        slots = np.ascontiguousarray(slots, dtype=np.int64)
+        idx_st = None if index_st is None else np.ascontiguousarray(index_st, dtype=np.int64)
+        nst = self.S if idx_st is None else len(idx_st)
+        if len(slots) != nst:
+            raise ValueError("one slot count per listed spot is required")
+        mapped = np.empty(len(idx_sc), np.int64)
+        total = ctypes.c_double()
+        info = _lib.AssignInfo()
+        _lib.check(_lib.lib().cyto_ctx_assign_chunk(self._h, idx_sc.ctypes.data, len(idx_sc),
+                                                    None if idx_st is None else idx_st.ctypes.data, nst, slots.ctypes.data,
+                                                    mapped.ctypes.data, ctypes.byref(total), ctypes.byref(info)))
+        if return_info:
+            return mapped, total.value, info
+        return mapped
+
+    def close(self):
+        if self._h is not None:
+            _lib.lib().cyto_ctx_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def solve_linear_assignment_problem(scRNA_norm_data, st_norm_data, cell_number_to_node_assignment,
                                     solver_method, solver, seed, distance_metric, process_idx=None, device_id=0):
     """cytospace.py:304-351.  Returns (mapped_st_index: list[int] of length C, process_idx).
@@ -113,26 +173,20 @@ def assign_chunks(scRNA_norm, st_norm, cell_number_to_node_assignment, index_sc_
     from concurrent.futures import ThreadPoolExecutor
     n_chunks = len(index_sc_list)
     owner = schedule_chunks([len(ix) for ix in index_sc_list], world_size)
-    jobs = {}
-    for idx in range(n_chunks):
-        if owner[idx] != rank:
-            continue
-        sc = scRNA_norm[:, index_sc_list[idx]]
-        if index_st_list is not None:
-            st = st_norm[:, index_st_list[idx]]
-            slots = np.asarray(cell_number_to_node_assignment)[index_st_list[idx]]
-        elif subsampled_slots_list is not None:
-            st = st_norm
-            slots = subsampled_slots_list[idx]
-        else:
-            st = st_norm
-            slots = cell_number_to_node_assignment
-        jobs[idx] = (sc, st, slots)
+    mine = [idx for idx in range(n_chunks) if owner[idx] == rank]
+    slots_all = np.asarray(cell_number_to_node_assignment)
     # the sequential part of one solve occupies one workgroup: run this rank's chunks side by side
-    # (ctypes releases the GIL; every call uses its own HIP stream)
-    with ThreadPoolExecutor(max_workers=max(1, min(max_concurrent, max(1, len(jobs))))) as ex:
-        futs = {idx: ex.submit(assign_pearson, sc, st, slots, True, device_id) for idx, (sc, st, slots) in jobs.items()}
-        return {idx: f.result() for idx, f in futs.items()}
+    # (ctypes releases the GIL; every call uses its own HIP stream); the matrices are uploaded once
+    with ExpressionContext(scRNA_norm, st_norm, True, device_id) as ctx:
+        def one(idx):
+            if index_st_list is not None:
+                return ctx.assign_chunk(index_sc_list[idx], slots_all[index_st_list[idx]], index_st_list[idx])
+            if subsampled_slots_list is not None:
+                return ctx.assign_chunk(index_sc_list[idx], subsampled_slots_list[idx])
+            return ctx.assign_chunk(index_sc_list[idx], slots_all)
+
+        with ThreadPoolExecutor(max_workers=max(1, min(max_concurrent, max(1, len(mine))))) as ex:
+            return dict(zip(mine, ex.map(one, mine)))
 
 
 def apply_linear_assignment(scRNA_data, st_data, coordinates_data, cell_number_to_node_assignment,
@@ -169,19 +223,15 @@ def apply_linear_assignment(scRNA_data, st_data, coordinates_data, cell_number_t
     owner = schedule_chunks([len(index_sc_list[idx]) for idx in range(n_chunks)], world_size)
     mine = [idx for idx in range(n_chunks) if owner[idx] == rank]
 
-    def one(idx):
-        if index_st_list is not None:
-            st_sel = st_norm_np[:, index_st_list[idx]]
-            slots = slots_all[index_st_list[idx]]
-        else:
-            st_sel = st_norm_np
-            slots = np.asarray(subsampled_cell_number_to_node_assignment_list[idx])
-        mapped = assign_pearson(scRNA_norm_np[:, index_sc_list[idx]], st_sel, slots, True, device_id,
-                                distance_metric=distance_metric)
-        return idx, mapped
+    # both matrices go to the device once; a chunk gathers its columns there (spots without cells are skipped)
+    with ExpressionContext(scRNA_norm_np, st_norm_np, True, device_id, distance_metric) as ctx:
+        def one(idx):
+            if index_st_list is not None:
+                return idx, ctx.assign_chunk(index_sc_list[idx], slots_all[index_st_list[idx]], index_st_list[idx])
+            return idx, ctx.assign_chunk(index_sc_list[idx], subsampled_cell_number_to_node_assignment_list[idx])
 
-    with ThreadPoolExecutor(max_workers=max(1, min(len(mine) or 1, int(number_of_processors)))) as ex:
-        results = list(ex.map(one, mine))
+        with ThreadPoolExecutor(max_workers=max(1, min(len(mine) or 1, int(number_of_processors)))) as ex:
+            results = list(ex.map(one, mine))
     assigned_locations_list, cell_ids_selected_list = [], []
     for idx, mapped in results:
         loc = coordinates_data.iloc[index_st_list[idx]].iloc[mapped] if index_st_list is not None \

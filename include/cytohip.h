@@ -158,6 +158,20 @@ int cyto_assign_metric(int metric, int G, int C, int S, const double *sc, const 
                        cyto_assign_info *info, int device_id);
 
 
+/* ---- A8, the multi-chunk seam: apply_linear_assignment (cytospace/cytospace.py:354-469) normalises the two
+ * matrices once and submits one solve_linear_assignment_problem per chunk, each with a column subset of the
+ * scRNA matrix and either a column subset of the ST matrix (--single-cell, :434-435) or the full ST matrix with
+ * per-chunk slot counts (--sampling-sub-spots, :438-439).  Here the matrices are uploaded and transformed once
+ * into a device-resident context; a chunk gathers its columns out of it (spots with slots == 0 are not
+ * contracted).  mapped_spot[c] = position in the chunk's spot list, as the reference's per-chunk result.
+ * cyto_ctx_assign_chunk may be called concurrently from several host threads on one context. */
+typedef struct cyto_expr_ctx cyto_expr_ctx;
+int cyto_ctx_create(int metric, int G, int C, int S, const double *sc, const double *st, int already_normalized,
+                    int device_id, cyto_expr_ctx **out);
+int cyto_ctx_assign_chunk(cyto_expr_ctx *ctx, const int64_t *idx_sc, int n_sc, const int64_t *idx_st, int n_st,
+                          const int64_t *slots, int64_t *mapped_spot, double *total_cost, cyto_assign_info *info);
+void cyto_ctx_destroy(cyto_expr_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -226,3 +226,30 @@ def test_gv11_apply_linear_assignment_chunked_modes(mode):
                                            idx_sc, rank=r, world_size=2, **kw) for r in range(2)]
     got2 = {(int(c[1:]), int(r), int(k)) for loc2, ids2 in parts for c, (r, k) in zip(ids2, loc2.to_numpy())}
     assert got2 == want
+
+
+@pytest.mark.parametrize("metric", ["Pearson_correlation", "Spearman_correlation", "Euclidean"])
+def test_expression_context_chunks_equal_per_chunk_uploads(metric):
+    # multi-chunk seam: transform once + device-side column gathers == uploading and transforming every chunk
+    rng = np.random.default_rng(17)
+    G, S, C = 90, 24, 60
+    sc = ocost.normalize_data(rng.poisson(2.0, (G, C)).astype(np.float64))
+    st = ocost.normalize_data(rng.poisson(8.0, (G, S)).astype(np.float64))
+    with gcyto.ExpressionContext(sc, st, True, 0, metric) as ctx:
+        # (a) a subset of cells against a subset of spots, with spots that receive no cell
+        idx_sc = rng.permutation(C)[:20]
+        idx_st = rng.permutation(S)[:9]
+        slots = np.array([3, 0, 5, 2, 0, 4, 1, 0, 5])
+        got, total, info = ctx.assign_chunk(idx_sc, slots, idx_st, return_info=True)
+        want, total2, _ = gcyto.assign_pearson(sc[:, idx_sc], st[:, idx_st], slots, return_info=True, distance_metric=metric)
+        assert np.array_equal(got, want) and total == total2
+        assert np.array_equal(np.bincount(got, minlength=len(slots)), slots)
+        assert info.gemm_flops == 2.0 * 96 * 6 * 20          # only the 6 spots with cells are contracted (Gpad = 96)
+        # (b) all spots, per-chunk slot counts
+        idx_sc = np.arange(10, 58)
+        slots = np.full(S, 2)
+        assert np.array_equal(ctx.assign_chunk(idx_sc, slots), gcyto.assign_pearson(sc[:, idx_sc], st, slots, distance_metric=metric))
+        with pytest.raises(ValueError):
+            ctx.assign_chunk(idx_sc, np.full(S, 3))            # not square
+        with pytest.raises(ValueError):
+            ctx.assign_chunk(np.array([0, 1, C]), np.array([3] + [0] * (S - 1)))   # cell index out of range
