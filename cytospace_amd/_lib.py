@@ -29,7 +29,7 @@ class LapInfo(ctypes.Structure):
             "hbm_row_reads", "dense_refreshes")] + [("ms_arr", ctypes.c_double), ("ms_aug", ctypes.c_double),
                                                         ("aug_scans_skipped", ctypes.c_int64),
                                                         ("row_groups", ctypes.c_int64), ("aug_dense_scans", ctypes.c_int64),
-                                                        ("aug_sparse_inits", ctypes.c_int64)]
+                                                        ("aug_sparse_inits", ctypes.c_int64), ("aug_handover", ctypes.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -1003,6 +1003,7 @@ struct Chain2Args {
     int ngroups;
     int gmode;           // 0: no duplicate rows; 1: per-group state in LDS; 2: in global memory
     int auxlds;          // augmentation: cassign (f32) + colgroup (u16) per column also in LDS
+    int aug_start;       // jv_aug2: first free row to augment (> 0: continues after jv_aug_lazy gave up)
 };
 
 // L2-coherent (agent-scope, relaxed) accesses to global state
@@ -1517,6 +1518,12 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug2(Chain2Args a) {
     // per-column auxiliaries (assigned cost, owner's row group) in LDS when they fit (a.auxlds)
     float *s_ca = nullptr;
     uint16_t *s_cg = nullptr;
+    if (a.aug_start > 0 && gmode) {
+        // continuing after jv_aug_lazy, which keeps no per-column group array: rebuild it from the assignment
+        int32_t *colgroup = a.iws + 6 * (int64_t)n;
+        for (int c = tid; c < n; c += BLOCK2) { const int32_t r = gcolsol[c]; colgroup[c] = r >= 0 ? a.rowgid[r] : 0; }
+        __syncthreads();
+    }
     if (a.auxlds) {
         const size_t off = (size_t)npad * 6 + (gmode == 1 ? (size_t)a.ngroups * 8 : 0);
         s_ca = reinterpret_cast<float *>(dyn_lds + ((off + 15) & ~(size_t)15));
@@ -1527,8 +1534,14 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug2(Chain2Args a) {
     __syncthreads();
     const int numfree = *reinterpret_cast<const int *>(a.misc + 128);
     long long c_relax = 0, c_hops = 0, c_augs = 0, c_skipped = 0;
+    long long rows0 = 0, base0 = 0;
+    if (a.aug_start > 0) {   // carry the counters of the searches jv_aug_lazy completed
+        const long long *cn = reinterpret_cast<const long long *>(a.misc + 16);
+        c_relax = cn[C_AUG_RELAX]; c_hops = cn[C_HOPS]; c_augs = cn[C_AUGS]; c_skipped = cn[C2_AUG_SKIPPED];
+        rows0 = cn[C_ROWS_READ]; base0 = c_augs + c_relax - c_skipped;
+    }
     int err = 0;
-    for (int f = 0; f < numfree && !err; f++) {
+    for (int f = a.aug_start; f < numfree && !err; f++) {
         const int freerow = __builtin_amdgcn_readfirstlane(ld_i32(freerows + f));
         err = chain_augment<CH, LDS_STATE>(n, ld, cost, gv, sumvd, cassign, rowsol, gcolsol, pred, s_v, s_cs, freerow, validm, s,
                                            par, c_relax, c_hops, c_skipped, gmode, a.rowgid, a.iws + 6 * (int64_t)n, hb, hs, f + 1, s_ca, s_cg);
@@ -1562,7 +1575,8 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug2(Chain2Args a) {
         *reinterpret_cast<double *>(a.misc + 8) = t;
         long long *counters = reinterpret_cast<long long *>(a.misc + 16);
         counters[C_AUG_INIT] = c_augs; counters[C_AUG_RELAX] = c_relax; counters[C_AUGS] = c_augs; counters[C_HOPS] = c_hops;
-        counters[C_ROWS_READ] = counters[C2_DENSE_REFRESH] + c_augs + c_relax - c_skipped;
+        counters[C_ROWS_READ] = a.aug_start > 0 ? rows0 + (c_augs + c_relax - c_skipped - base0)
+                                                : counters[C2_DENSE_REFRESH] + c_augs + c_relax - c_skipped;
         counters[C2_AUG_SKIPPED] = c_skipped;
         *reinterpret_cast<int *>(a.misc + 4) = err;
     }
@@ -2152,6 +2166,7 @@ struct LazyArgs {
     float *g_hbest; int32_t *g_hstamp;
     char *misc;
     int ngroups, gmode;
+    int may_bail;        // a dense kernel can take over: give up when the cache certificates keep failing
 };
 struct LazyCmd { int op, row, step, stamp; float h; };
 enum { LZ_DENSE = 1, LZ_EXIT = 2, LZ_ERR = 3, LZ_INIT_DENSE = 4 };
@@ -2275,6 +2290,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
     float curmin = 0.0f, icv = 0.0f;
     uint32_t icc = COLSENT;
     int level = 0, nscan = 0, ntouch = 0;
+    bool bail = false;
     // software pipeline over searches: id of the free row after next, cache row of the next one
     int id_next = -1, id1_saved = -1;
     uint32_t ncc = COLSENT;
@@ -2291,7 +2307,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
             bool post = false;
             while (!post) {
                 if (!insearch) {
-                    if (f >= numfree || err) { if (lane == 0) cmd.op = err ? LZ_ERR : LZ_EXIT; break; }
+                    if (f >= numfree || err || bail) { if (lane == 0) cmd.op = err ? LZ_ERR : LZ_EXIT; break; }
                     LZ_STAMP2(0)
                     // (freerow, ncc, ncv) were requested during the previous search; request the next ones now
                     const uint32_t cc = ncc;
@@ -2437,6 +2453,9 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                         f++;
                         freerow = id1_saved;
                         insearch = false;
+                        // instances whose searches run deeper than the caches reach (>= 25 % full-row scans) are
+                        // faster on the register-resident dense kernel: hand the remaining free rows over
+                        if (a.may_bail && c_relax >= 8192 && c_dense * 4 >= c_relax) bail = true;
                         break;
                     }
                     const int i = __builtin_amdgcn_readfirstlane(st_csget<LDS_STATE>(s_cs, a.colsol, jp));
@@ -2657,6 +2676,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
     double part = 0.0;
     for (int i = tid; i < n; i += BLOCK2) {
         const int j = ld_i32(a.rowsol + i);
+        if (j < 0) continue;              // still free: the kernel gave up and the dense kernel finishes (and redoes this)
         const float cij = cost[(int64_t)i * ld + j];
         const float vj = ld_f32(gv + j);
         a.gu[i] = cij - vj;
@@ -2676,6 +2696,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
         counters[C2_AUG_SKIPPED] = c_skipped;
         counters[C2_AUG_DENSE] = c_dense;
         counters[C2_AUG_SPARSE_INIT] = c_sparse;
+        *reinterpret_cast<int *>(a.misc + 136) = f;          // searches completed (== numfree unless the kernel gave up)
         *reinterpret_cast<int *>(a.misc + 4) = err;
 #ifdef LZ_PROF
         long long *pp = reinterpret_cast<long long *>(a.misc + 152);
@@ -2725,14 +2746,32 @@ static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_c
             hipLaunchKernelGGL((build_row_caches<CH>), dim3(cache_grid), dim3(BLOCK2), 0, stream, args.n, args.ld, args.cost,
                                (const float *)args.fws, args.cache_col, args.cache_val);
         CYTO_HIP(hipGetLastError());
+        LazyArgs la = lz.args;
+        la.may_bail = (LDS_STATE && !getenv("CYTO_AUG")) ? 1 : 0;     // the dense jv_aug2<CH, true> can take over
         if (lz.lds_state) {
             CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jv_aug_lazy<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lz.shm));
-            hipLaunchKernelGGL(jv_aug_lazy<true>, dim3(1), dim3(BLOCK2), lz.shm, stream, lz.args);
+            hipLaunchKernelGGL(jv_aug_lazy<true>, dim3(1), dim3(BLOCK2), lz.shm, stream, la);
         } else {
             CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jv_aug_lazy<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lz.shm));
-            hipLaunchKernelGGL(jv_aug_lazy<false>, dim3(1), dim3(BLOCK2), lz.shm, stream, lz.args);
+            hipLaunchKernelGGL(jv_aug_lazy<false>, dim3(1), dim3(BLOCK2), lz.shm, stream, la);
         }
         CYTO_HIP(hipGetLastError());
+        if constexpr (LDS_STATE) {
+            if (la.may_bail) {
+                // did it give up?  (misc + 128: number of free rows, misc + 136: searches completed)
+                int h[3] = {0, 0, 0};
+                CYTO_HIP(hipMemcpyAsync(h, args.misc + 128, sizeof h, hipMemcpyDeviceToHost, stream));
+                CYTO_HIP(hipStreamSynchronize(stream));
+                if (getenv("CYTO_DEBUG_HANDOVER")) fprintf(stderr, "[handover] numfree=%d done=%d\n", h[0], h[2]);
+                if (h[2] < h[0] && !getenv("CYTO_DEBUG_NO_CONT")) {
+                    aug_args.aug_start = h[2];
+                    auto kaug = jv_aug2<CH, LDS_STATE>;
+                    CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kaug), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_aug));
+                    hipLaunchKernelGGL(kaug, dim3(1), dim3(BLOCK2), shmem_aug, stream, aug_args);
+                    CYTO_HIP(hipGetLastError());
+                }
+            }
+        }
         return CYTO_OK;
     }
     if (coop) {
@@ -2875,6 +2914,7 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
     CYTO_HIP(hipEventRecord(e1b, stream));
     const int64_t per = (int64_t)VW * BLOCK;
     DevBuf b_ccol, b_cval, b_ghb, b_ghs, b_coop, b_cghb, b_cghs;
+    bool lazy_used = false;
     bool fast = false;
     if constexpr (std::is_same<T, float>::value) {
         // float32 fast path: per-row top-K caches + single-wave cached chain steps
@@ -2890,7 +2930,7 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
             c2.cache_col = b_ccol.as<uint32_t>(); c2.cache_val = b_cval.as<float>(); c2.misc = b_misc.as<char>();
             // duplicate-row skip: per-group state in LDS when it fits beside v (4 B) and colsol (2 B) per column
             c2.rowgid = b_gid.as<int32_t>(); c2.ngroups = h_ngroups; c2.gmode = 0; c2.g_hbest = nullptr; c2.g_hstamp = nullptr;
-            c2.auxlds = 0;
+            c2.auxlds = 0; c2.aug_start = 0;
             // ---- cache-certified augmentation (CYTO_AUG=lazy) ----
             LazyPlan lz; memset(&lz, 0, sizeof lz);
             DevBuf b_lzhb, b_lzhs;
@@ -2903,6 +2943,7 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
                     const size_t npad6 = (((size_t)((n + 3) & ~3) * 6) + 15) & ~(size_t)15, nb24 = (size_t)((((n + 63) / 64) + 511) & ~511) * 8 + (size_t)((n + 63) / 64) * 24 + 16;
                     const size_t lds_budget = 160 * 1024 - 2048;       // static __shared__ of the kernel
                     lz.enabled = true;
+                    lazy_used = true;
                     lz.lds_state = n <= 65535 && !getenv("CYTO_FORCE_STREAM") && npad6 + nb24 <= lds_budget;
                     lz.shm = (lz.lds_state ? npad6 : 0) + nb24;
                     LazyArgs &la = lz.args;
@@ -3053,6 +3094,12 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
         info->aug_scans_skipped = fast ? h_counters[C2_AUG_SKIPPED] : 0;
         info->aug_dense_scans = fast ? h_counters[C2_AUG_DENSE] : 0;
         info->aug_sparse_inits = fast ? h_counters[C2_AUG_SPARSE_INIT] : 0;
+        info->aug_handover = -1;
+        if (fast && lazy_used) {
+            int h[3] = {0, 0, 0};
+            CYTO_HIP(hipMemcpy(h, b_misc.as<char>() + 128, sizeof h, hipMemcpyDeviceToHost));
+            if (h[2] < h[0]) info->aug_handover = h[2];
+        }
         info->row_groups = h_ngroups;
     }
     cleanup();

@@ -74,6 +74,8 @@ typedef struct {
     int64_t row_groups;      /* number of runs of bitwise identical consecutive rows (== n: none) */
     int64_t aug_dense_scans; /* augmentation scans that had to read the full cost row (cache certificate failed) */
     int64_t aug_sparse_inits; /* augmentations whose initial row scan was served from the row cache */
+    int64_t aug_handover;    /* -1, or the index of the search at which the cache-certified augmentation handed the
+                                remaining free rows to the dense kernel (its certificates kept failing) */
 } cyto_lap_info;
 
 int cyto_lap_f32(int n, const float *cost, int64_t ld, int cost_on_device,

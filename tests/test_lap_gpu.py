@@ -225,3 +225,20 @@ def test_cache_certified_augmentation_forced(monkeypatch):
     for n in (130, 1500):
         c = np.random.default_rng(n + 1).random((n, n)).astype(np.float32)
         _check(c, np.float32)
+
+
+def test_augmentation_handover_to_dense_kernel_on_deep_searches():
+    # few cell types, many near-equal columns: searches run deeper than the 63-column caches reach, the
+    # cache-certified augmentation gives up (>= 25 % full-row scans) and the dense kernel finishes; bit-identical
+    rng = np.random.default_rng(5)
+    n, types = 5400, 6
+    prof = rng.normal(size=(types, 64)).astype(np.float32)
+    rows = prof[rng.integers(0, types, n)] + 0.05 * rng.normal(size=(n, 64)).astype(np.float32)
+    cols = prof[rng.integers(0, types, n)] + 0.05 * rng.normal(size=(n, 64)).astype(np.float32)
+    c = -(rows @ cols.T).astype(np.float32)
+    g = lap_solve(c, np.float32, return_info=True)
+    o = jv_oracle(c, np.float32)
+    for k in ("rowsol", "colsol", "u", "v"):
+        assert np.array_equal(g[k], o[k]), k
+    assert g["info"].scans_aug_relax == o["stats"].scans_aug_relax and g["info"].augmentations == o["stats"].augmentations
+    assert g["info"].aug_handover >= 0

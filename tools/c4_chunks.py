@@ -29,3 +29,7 @@ print(f"context (H2D + normalise + standardise, once): {t1-t0:.2f}s; {len(index_
       f"=> {C/(t2-t0):.0f} assignments/s end to end, {C/(t2-t1):.0f}/s for the chunk phase; bincount==slots: {ok}")
 print(f"per chunk: gather {np.mean(gath):.1f} ms, GEMM {np.mean(gemm_ms):.1f} ms (spots with cells: ~{int(np.mean([(s_>0).sum() for s_ in sub]))}), "
       f"LAP {np.mean(lap_ms):.1f} ms")
+li = res[0][2].lap
+print("chunk 0 LAP: arr %.0f ms (%d RT + %d ARR scans, %d dense refreshes), aug %.0f ms (%d scans, %d skipped, %d full-row, %d searches, %d sparse inits), free rows %d/%d/%d, handover at search %d" % (
+    li.ms_arr, li.scans_redtransfer, li.scans_arr, li.dense_refreshes, li.ms_aug, li.scans_aug_relax, li.aug_scans_skipped, li.aug_dense_scans,
+    li.augmentations, li.aug_sparse_inits, li.free_after_colred, li.free_after_arr1, li.free_after_arr2, li.aug_handover))
