@@ -2453,9 +2453,9 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                         f++;
                         freerow = id1_saved;
                         insearch = false;
-                        // instances whose searches run deeper than the caches reach (>= 25 % full-row scans) are
+                        // instances whose searches run deeper than the caches reach (>= 10 % full-row scans) are
                         // faster on the register-resident dense kernel: hand the remaining free rows over
-                        if (a.may_bail && c_relax >= 8192 && c_dense * 4 >= c_relax) bail = true;
+                        if (a.may_bail && c_relax >= 4096 && c_dense * 10 >= c_relax) bail = true;
                         break;
                     }
                     const int i = __builtin_amdgcn_readfirstlane(st_csget<LDS_STATE>(s_cs, a.colsol, jp));

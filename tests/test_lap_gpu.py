@@ -229,7 +229,7 @@ def test_cache_certified_augmentation_forced(monkeypatch):
 
 def test_augmentation_handover_to_dense_kernel_on_deep_searches():
     # few cell types, many near-equal columns: searches run deeper than the 63-column caches reach, the
-    # cache-certified augmentation gives up (>= 25 % full-row scans) and the dense kernel finishes; bit-identical
+    # cache-certified augmentation gives up (>= 10 % full-row scans) and the dense kernel finishes; bit-identical
     rng = np.random.default_rng(5)
     n, types = 5400, 6
     prof = rng.normal(size=(types, 64)).astype(np.float32)
