@@ -2614,15 +2614,20 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                 continue;
             }
             // ================= dense scan of row cmd.row (certificate failed): whole workgroup =================
+            // Only a relaxation to a value <= T (the threshold when the scan starts; T only decreases) can be observed,
+            // so the per-column words are touched for those columns only; a 64-column block none of whose columns
+            // matters is skipped altogether, one that is met for the first time in this search is initialised here.
             {
                 const int i = cmd.row, step = cmd.step;
                 const float h = cmd.h;
+                const float T0 = ord2f(s_T);
                 const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<float *>(cost + (int64_t)i * ld), 0, (int)(ld * 4), 0x00020000);
                 float tl2 = INFINITY;
                 for (int q0 = 0; q0 < nquad; q0 += BLOCK2) {
                     const int q = q0 + tid;
-                    uint64_t bk = KEYMAX;
+                    uint32_t o2s[4] = {0, 0, 0, 0};
+                    uint32_t okm = 0, um = 0;
                     if (q < nquad) {
                         const u32x4_t xr = __builtin_amdgcn_raw_buffer_load_b128(rr, q * 16, 0, 0);
                         float4 vv;
@@ -2631,29 +2636,62 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                             const u32x4_t vr = __builtin_amdgcn_raw_buffer_load_b128(rv, q * 16, 0, 0x10);
                             vv = make_float4(__uint_as_float(vr.x), __uint_as_float(vr.y), __uint_as_float(vr.z), __uint_as_float(vr.w));
                         }
-                        const uint32_t um = (s_un[q >> 3] >> ((q & 7) * 4)) & 0xFu;
+                        um = (s_un[q >> 3] >> ((q & 7) * 4)) & 0xFu;
                         const uint32_t sm = (s_sc[q >> 3] >> ((q & 7) * 4)) & 0xFu;
-                        const bool fresh = s_ep[q >> 4] == stamp;
                         const float xs[4] = {__uint_as_float(xr.x), __uint_as_float(xr.y), __uint_as_float(xr.z), __uint_as_float(xr.w)};
                         const float vs[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
                             const int c = q * 4 + e;
-                            if (c < n && !((sm >> e) & 1u)) {
-                                uint64_t dkc = fresh ? ld_u64(a.dkey + c) : LZ_INFKEY;
-                                const float v2 = (xs[e] - vs[e]) - h;
-                                const uint32_t o2 = f2ord(v2);
-                                bool wr = !fresh;
-                                if (o2 < (uint32_t)(dkc >> 32)) { dkc = ((uint64_t)o2 << 32) | (uint32_t)step; wr = true; }
-                                if (wr) st_u64(a.dkey + c, dkc);
-                                const bool un = (um >> e) & 1u;
-                                bk = umin64(bk, (dkc & 0xFFFFFFFF00000000ull) | (un ? 0u : 0x80000000u) | (uint32_t)c);
-                                if (un) tl2 = fminf(tl2, ord2f((uint32_t)(dkc >> 32)));
+                            const float v2 = (xs[e] - vs[e]) - h;
+                            o2s[e] = f2ord(v2);
+                            if (c < n && !((sm >> e) & 1u) && !(v2 > T0)) {
+                                okm |= 1u << e;
+                                if ((um >> e) & 1u) tl2 = fminf(tl2, v2);
                             }
                         }
                     }
-                    bk = min64_row_allreduce(bk);
-                    if ((lane & 15) == 0 && q < nquad) { bmin[q >> 4] = bk; s_ep[q >> 4] = stamp; }
+                    // does any column of my block (16 lanes = 64 columns) matter?
+                    const uint64_t hitm = __ballot(okm != 0);
+                    if ((hitm >> (lane & 48)) & 0xFFFFull) {
+                        const int b = q >> 4;
+                        const bool fresh = q < nquad && s_ep[b] == stamp;
+                        const bool first = q < nquad && !fresh;
+                        uint64_t bk = KEYMAX;
+                        if (fresh) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                if ((okm >> e) & 1u) {
+                                    const int c = q * 4 + e;
+                                    const uint64_t dkc = ld_u64(a.dkey + c);
+                                    if (o2s[e] < (uint32_t)(dkc >> 32)) {
+                                        st_u64(a.dkey + c, ((uint64_t)o2s[e] << 32) | (uint32_t)step);
+                                        bk = umin64(bk, ((uint64_t)o2s[e] << 32) | (((um >> e) & 1u) ? 0u : 0x80000000u) | (uint32_t)c);
+                                    }
+                                }
+                            }
+                        } else if (first) {
+                            uint64_t dq[4];
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const int c = q * 4 + e;
+                                dq[e] = LZ_INFKEY;
+                                if ((okm >> e) & 1u) {
+                                    dq[e] = ((uint64_t)o2s[e] << 32) | (uint32_t)step;
+                                    bk = umin64(bk, ((uint64_t)o2s[e] << 32) | (((um >> e) & 1u) ? 0u : 0x80000000u) | (uint32_t)c);
+                                }
+                            }
+                            const u32x4_t w0 = {(uint32_t)dq[0], (uint32_t)(dq[0] >> 32), (uint32_t)dq[1], (uint32_t)(dq[1] >> 32)};
+                            const u32x4_t w1 = {(uint32_t)dq[2], (uint32_t)(dq[2] >> 32), (uint32_t)dq[3], (uint32_t)(dq[3] >> 32)};
+                            __builtin_amdgcn_raw_buffer_store_b128(w0, rdk, q * 32, 0, 0x10);
+                            __builtin_amdgcn_raw_buffer_store_b128(w1, rdk, q * 32 + 16, 0, 0x10);
+                        }
+                        bk = min64_row_allreduce(bk);
+                        if ((lane & 15) == 0 && q < nquad) {
+                            if (bk != KEYMAX) lds_min_u64(bmin + b, bk);
+                            s_ep[b] = stamp;
+                        }
+                    }
                 }
                 {
                     const uint32_t t2 = wg_min_u32(f2ord(tl2), s, par);
