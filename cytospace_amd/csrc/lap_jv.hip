@@ -2194,9 +2194,9 @@ __device__ __forceinline__ void gl_min_u64(uint64_t *p, uint64_t x) {
 constexpr uint64_t LZ_INFKEY = 0xFFFFFFFF00000000ull;   // "no distance yet": any real d wins the unsigned min
 // Before a column's word is used in this search its block of 64 words must hold this search's values:
 // blocks are reset lazily (all 64 words = "no distance") the first time a search touches them.
-__device__ __forceinline__ void lz_touch_blocks(bool act, int myblk, uint64_t *dkey, int32_t *s_ep, int32_t *s_tl, int &ntouch,
-                                                int stamp, int npad, int lane) {
-    uint64_t todo = __ballot(act && s_ep[myblk] != stamp);
+__device__ __forceinline__ void lz_touch_blocks(bool act, int myblk, int myepoch, uint64_t *dkey, int32_t *s_ep, int32_t *s_tl,
+                                                int &ntouch, int stamp, int npad, int lane) {
+    uint64_t todo = __ballot(act && myepoch != stamp);
     while (todo) {
         const int l = __builtin_ctzll(todo);
         const int b = (int)readlane32((uint32_t)myblk, l);
@@ -2289,7 +2289,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
     bool insearch = false, have = false, dense_used = false, isparse = false;
     float curmin = 0.0f, icv = 0.0f;
     uint32_t icc = COLSENT;
-    int level = 0, nscan = 0, ntouch = 0;
+    int level = 0, nscan = 0, ntouch = 0, nexc = 0;   // nexc: register copy of s_nexc (it only changes at a search's end)
     bool bail = false;
     // software pipeline over searches: id of the free row after next, cache row of the next one
     int id_next = -1, id1_saved = -1;
@@ -2330,7 +2330,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                     const uint32_t odd = valid ? f2ord(dd) : 0xFFFFFFFFu;
                     const uint32_t t0 = wave_min_u32(un ? odd : 0xFFFFFFFFu);
                     const float floor_f = __uint_as_float(readlane32(__float_as_uint(cv), KCU));
-                    const bool cert0 = s_nexc == 0 && t0 != 0xFFFFFFFFu && floor_f > ord2f(t0);
+                    const bool cert0 = nexc == 0 && t0 != 0xFFFFFFFFu && floor_f > ord2f(t0);
                     if (cert0 && wave_min_u32(odd) == t0) {
                         // ---- single-edge search: the smallest distance of the whole row belongs to an unassigned
                         // column (the oracle's first pick ends the search at once: no scan, no price update);
@@ -2358,7 +2358,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                     }
                     if (cert0) {
                         const bool act = valid && !(dd > ord2f(t0));
-                        lz_touch_blocks(act, j >> 6, a.dkey, s_ep, s_tl, ntouch, stamp, npad, lane);
+                        lz_touch_blocks(act, j >> 6, s_ep[j >> 6], a.dkey, s_ep, s_tl, ntouch, stamp, npad, lane);
                         if (act) {
                             const uint32_t od = f2ord(dd);
                             st_u64(a.dkey + j, (uint64_t)od << 32);                 // step 0 = the free row
@@ -2415,7 +2415,8 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                                 }
                             }
                         }
-                        if (s_nexc > LZ_MAXEXC) err = CYTO_ERR_INTERNAL;
+                        nexc = s_nexc;
+                        if (nexc > LZ_MAXEXC) err = CYTO_ERR_INTERNAL;
                         // c[freerow][endofpath] is in the sparse init's cache row when the path is a single edge
                         float cie0 = 0.0f;
                         bool have_cie0 = false;
@@ -2521,13 +2522,16 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                     {
                         const bool valid = lane < KCU && cc != COLSENT;
                         const int j = valid ? (int)cc : 0;
+                        // one round of LDS gathers: price, scanned / unassigned words, the block's search stamp
                         const float vj = st_vget<LDS_STATE>(s_v, gv, j);
+                        const uint32_t scw = s_sc[j >> 5], unw = s_un[j >> 5];
+                        const int32_t epj = s_ep[j >> 6];
                         const float v2 = (cv - vj) - h;
-                        const bool scn = (s_sc[j >> 5] >> (j & 31)) & 1u;
+                        const bool scn = (scw >> (j & 31)) & 1u;
                         const bool act = valid && !scn && !(v2 > T);
-                        lz_touch_blocks(act, j >> 6, a.dkey, s_ep, s_tl, ntouch, stamp, npad, lane);
+                        lz_touch_blocks(act, j >> 6, epj, a.dkey, s_ep, s_tl, ntouch, stamp, npad, lane);
                         if (act) {
-                            const bool un = (s_un[j >> 5] >> (j & 31)) & 1u;
+                            const bool un = (unw >> (j & 31)) & 1u;
                             const uint32_t o2 = f2ord(v2);
                             gl_min_u64(a.dkey + j, ((uint64_t)o2 << 32) | (uint32_t)step);
                             lds_min_u64(bmin + (j >> 6), ((uint64_t)o2 << 32) | (un ? 0u : 0x80000000u) | (uint32_t)j);
@@ -2535,14 +2539,13 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                         }
                     }
                     LZ_STAMP(4)
-                    const int nexc = s_nexc;
                     if (nexc > 0) {
                         const bool ev = lane < nexc;
                         const int j = ev ? s_exc[lane] : 0;
                         const float vj = st_vget<LDS_STATE>(s_v, gv, j);
                         const float v2 = ev ? (cost[(int64_t)i * ld + j] - vj) - h : 0.0f;
                         const bool scn = (s_sc[j >> 5] >> (j & 31)) & 1u;
-                        lz_touch_blocks(ev && !scn, j >> 6, a.dkey, s_ep, s_tl, ntouch, stamp, npad, lane);
+                        lz_touch_blocks(ev && !scn, j >> 6, s_ep[j >> 6], a.dkey, s_ep, s_tl, ntouch, stamp, npad, lane);
                         if (ev && !scn) {
                             const bool un = (s_un[j >> 5] >> (j & 31)) & 1u;
                             const uint32_t o2 = f2ord(v2);
