@@ -241,3 +241,69 @@ def apply_linear_assignment(scRNA_data, st_data, coordinates_data, cell_number_t
     if not results:
         return coordinates_data.iloc[[]], cell_ids[[]]
     return pd.concat(assigned_locations_list), np.concatenate(cell_ids_selected_list, axis=0)
+
+
+# ---- upstream of the chunk fan-out: the per-spot cell counts, the per-type cell numbers and the
+# cell sampler whose output apply_linear_assignment consumes.  Host code like the reference's; the one heavy step of
+# the first (normalize_data over the whole ST matrix) runs on the device. ----
+
+def estimate_cell_number_RNA_reads(st_data, mean_cell_numbers, device_id=0):
+    """cytospace/cytospace.py:116-134.  Cells per spot from a straight line through (min, 0 or 1) and
+    (mean, mean_cell_numbers) of the per-spot sums of the normalised expression; truncated to int."""
+    from . import common
+    reads = common.normalize_data(st_data.values.astype(float), device_id).sum(axis=0, dtype=float)
+    lo, mid = reads.min(), reads.mean()
+    line = np.poly1d(np.polyfit(np.array([lo, mid]), np.array([1 if lo > 0 else 0, mean_cell_numbers]), 1))
+    return line(reads).astype(int)
+
+
+def get_cell_type_fraction(number_of_cells, cell_type_fraction_data):
+    """cytospace/cytospace.py:137-147.  Fractions (1 x types) -> integer cell numbers (types x 1): truncate
+    fraction * number_of_cells, then give the shortfall to the FIRST cell type."""
+    numbers = cell_type_fraction_data.transpose()
+    numbers.iloc[:, 0] = (numbers.values * number_of_cells).astype(int)[:, 0]
+    numbers.loc[numbers.index[0], numbers.columns[0]] += number_of_cells - sum(numbers.iloc[:, 0])
+    return numbers
+
+
+def sample_single_cells(scRNA_data, cell_type_data, cell_type_numbers_int, sampling_method, seed):
+    """cytospace/cytospace.py:212-301.  Draw, per cell type and in the order of cell_type_numbers_int.index, as many
+    cells as that type needs.  Enough cells: python `random.sample` without replacement; too few: every cell once plus
+    `np.random.choice` with replacement ("duplicates") or synthetic cells whose genes are drawn independently from
+    the type's cells ("place_holders").  Both generators are seeded with `seed` first, and are consumed in the
+    reference's order, so the same seed reproduces the reference's sample."""
+    import random
+    import pandas as pd
+    if sampling_method not in ("duplicates", "place_holders"):
+        raise ValueError("Invalid sampling_method provided")
+    np.random.seed(seed)
+    random.seed(seed)
+    labels = cell_type_data.values[:, 0]
+    ids = scRNA_data.columns.values
+    picked, blocks, names = [], [], []
+    for cell_type in cell_type_numbers_int.index.values:
+        members = np.nonzero(labels == cell_type)[0].tolist()
+        if not members:
+            raise ValueError(f"Cell type {cell_type} in the ST dataset is not available in the scRNA-seq dataset.")
+        want = cell_type_numbers_int.loc[cell_type].iloc[0]
+        short = want - len(members)
+        if short <= 0:
+            chosen = random.sample(members, want)
+            if sampling_method == "duplicates":
+                picked.append(chosen)
+            else:
+                names.append(ids[chosen]); blocks.append(scRNA_data.iloc[:, chosen].to_numpy())
+        elif sampling_method == "duplicates":
+            picked.append(np.concatenate([members, np.random.choice(members, short)], axis=0))
+        else:
+            own = scRNA_data.iloc[:, members].to_numpy()
+            np.random.choice(members, short)          # (the reference draws and discards this)
+            fake = np.zeros((own.shape[0], short))
+            for k in range(short):
+                fake[:, k] = [np.random.choice(own[g, :]) for g in range(own.shape[0])]
+            names.append(np.array(ids[members]))
+            names.append(np.array([cell_type.replace('TYPE_', 'CELL_') + '_new_' + str(k + 1) for k in range(short)]))
+            blocks.append(own); blocks.append(fake)
+    if sampling_method == "place_holders":
+        return pd.DataFrame(np.concatenate(blocks, axis=1), index=scRNA_data.index, columns=np.concatenate(names, axis=0))
+    return scRNA_data.iloc[:, np.concatenate(picked, axis=0).astype(int)]

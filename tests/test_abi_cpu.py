@@ -120,3 +120,30 @@ def test_chunk_sharding_world_size_2_gloo(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29517", str(script), ROOT],
                        capture_output=True, text=True, timeout=280, env=env)
     assert "GLOO_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_gv7_upstream_sampler_and_type_numbers_match_the_reference():
+    # host-side functions upstream of apply_linear_assignment (cytospace.py:137-147, 212-301) vs arrays captured from
+    # the reference: integer cell numbers per type, and the seeded cell sampler in both of its modes
+    import pandas as pd
+    from cytospace_amd import cytospace as gcyto
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gv7_upstream.npz"))
+    frac_df = pd.DataFrame(d["fractions"], index=["Fraction"], columns=["TYPE_A", "TYPE_B", "TYPE_C"])
+    for total in (101, 7):
+        got = gcyto.get_cell_type_fraction(total, frac_df.copy())
+        assert list(got.index) == ["TYPE_A", "TYPE_B", "TYPE_C"] and int(got.values.sum()) == total
+        assert np.array_equal(got.values[:, 0].astype(np.int64), d[f"numbers_{total}"])
+    sc = d["sc_counts"]
+    G, C = sc.shape
+    sc_df = pd.DataFrame(sc, index=[f"g{i}" for i in range(G)], columns=[f"CELL_{i}" for i in range(C)])
+    ct_df = pd.DataFrame(d["sc_labels"], index=sc_df.columns, columns=["CellType"])
+    need = pd.DataFrame(d["need"], index=["TYPE_A", "TYPE_B", "TYPE_C"], columns=["Fraction"])
+    for seed in (1, 4):
+        dup = gcyto.sample_single_cells(sc_df, ct_df, need, "duplicates", seed)
+        assert np.array_equal(np.array([int(x.split("_")[1]) for x in dup.columns]), d[f"dup_s{seed}_cells"])
+        ph = gcyto.sample_single_cells(sc_df, ct_df, need, "place_holders", seed)
+        assert list(ph.columns) == list(d[f"ph_s{seed}_names"]) and np.array_equal(ph.to_numpy(), d[f"ph_s{seed}_values"])
+    with pytest.raises(ValueError):
+        gcyto.sample_single_cells(sc_df, ct_df, need, "bootstrap", 1)
+    with pytest.raises(ValueError):
+        gcyto.sample_single_cells(sc_df, ct_df, pd.DataFrame([3], index=["TYPE_Z"], columns=["Fraction"]), "duplicates", 1)

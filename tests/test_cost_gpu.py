@@ -253,3 +253,13 @@ def test_expression_context_chunks_equal_per_chunk_uploads(metric):
             ctx.assign_chunk(idx_sc, np.full(S, 3))            # not square
         with pytest.raises(ValueError):
             ctx.assign_chunk(np.array([0, 1, C]), np.array([3] + [0] * (S - 1)))   # cell index out of range
+
+
+def test_gv7_cells_per_spot_estimate():
+    # estimate_cell_number_RNA_reads (cytospace.py:116-134) with the normalisation on the device
+    import pandas as pd
+    d = load("gv7_upstream.npz")
+    st = d["st_counts"]
+    st_df = pd.DataFrame(st, index=[f"g{i}" for i in range(st.shape[0])], columns=[f"s{i}" for i in range(st.shape[1])])
+    for mean in (5, 20):
+        assert np.array_equal(gcyto.estimate_cell_number_RNA_reads(st_df, mean), d[f"cells_per_spot_mean{mean}"])
