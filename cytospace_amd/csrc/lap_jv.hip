@@ -1227,9 +1227,13 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
 
 enum { PH_RT = 0, PH_ARR = 1, PH_AUG = 2 };
 
-template <int CH, bool LDS_STATE>
+// CS_LDS (only meaningful with !LDS_STATE, n <= 65535): the prices are too many for LDS but colsol (u16) still fits;
+// the chain then never stores colsol to global memory (on gfx9 a load is not returned before the stores issued
+// ahead of it are acknowledged, so every global store in the step delays the next step's gathers).
+template <int CH, bool LDS_STATE, bool CS_LDS = false>
 __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
     constexpr int NC = CH * 4;
+    constexpr bool CSL = LDS_STATE || CS_LDS;     // colsol lives in LDS
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     __shared__ Scratch2 s;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1244,16 +1248,16 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
     int32_t *freerows = a.iws + 3 * (int64_t)n, *rtrows = a.iws + 4 * (int64_t)n, *pred = a.iws + 5 * (int64_t)n;
     const int npad = (n + 3) & ~3;
     float *s_v = reinterpret_cast<float *>(dyn_lds);
-    uint16_t *s_cs = reinterpret_cast<uint16_t *>(dyn_lds + (size_t)npad * 4);
+    uint16_t *s_cs = reinterpret_cast<uint16_t *>(dyn_lds + (LDS_STATE ? (size_t)npad * 4 : 0));
     int par = 0;
 
     uint64_t validm = 0;
 #pragma unroll
     for (int sl = 0; sl < NC; sl++) if (SLOT_COL(sl) < n) validm |= (1ull << sl);
 
-    if constexpr (LDS_STATE) {
+    if constexpr (CSL) {
         for (int c = tid; c < npad; c += BLOCK2) {
-            s_v[c] = c < n ? gv[c] : 0.0f;
+            if constexpr (LDS_STATE) s_v[c] = c < n ? gv[c] : 0.0f;
             const int32_t cs = c < n ? gcolsol[c] : -1;
             s_cs[c] = cs < 0 ? (uint16_t)0xFFFFu : (uint16_t)cs;
         }
@@ -1365,8 +1369,8 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
                         j1 = (int)(uint32_t)gd.m1; j2 = (int)(uint32_t)gd.m2;
                         cj1 = a.cost[(int64_t)i * a.ld + j1]; cj2 = a.cost[(int64_t)i * a.ld + j2];
                         vj1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(st_vget<LDS_STATE>(s_v, gv, j1))));
-                        i0 = __builtin_amdgcn_readfirstlane(st_csget<LDS_STATE>(s_cs, gcolsol, j1));
-                        i02 = __builtin_amdgcn_readfirstlane(st_csget<LDS_STATE>(s_cs, gcolsol, j2));
+                        i0 = __builtin_amdgcn_readfirstlane(st_csget<CSL>(s_cs, gcolsol, j1));
+                        i02 = __builtin_amdgcn_readfirstlane(st_csget<CSL>(s_cs, gcolsol, j2));
                     } else {
                         uint32_t col;
                         float cv;
@@ -1377,7 +1381,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
                         }
                         const bool valid = col != COLSENT;
                         const float vj = st_vget<LDS_STATE>(s_v, gv, valid ? (int)col : 0);
-                        const int32_t csj = st_csget<LDS_STATE>(s_cs, gcolsol, valid ? (int)col : 0);
+                        const int32_t csj = st_csget<CSL>(s_cs, gcolsol, valid ? (int)col : 0);
                         const float F = __uint_as_float(readlane32(__float_as_uint(cv), KCU));
                         const uint32_t ord = valid ? f2ord(cv - vj) : 0xFFFFFFFFu;
                         // minimum, its lane (ties: lowest column), then the minimum of the rest
@@ -1429,7 +1433,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
                     // rowsol is not read during ARR and equals the inverse of colsol: it is rebuilt after the chain
                     if (lane == 0) {
                         if (lowers) st_vset<LDS_STATE>(s_v, gv, j1, vnew);
-                        st_csset<LDS_STATE>(s_cs, gcolsol, jj, i);
+                        st_csset<CSL>(s_cs, gcolsol, jj, i);
                     }
                     if (__builtin_expect(i0f >= 0 && lowers && c_arr < arr_budget, 1)) { cur_i = i0f; continue; }   // chain goes on
                     if (i0f >= 0) {
@@ -1460,8 +1464,9 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
     int32_t *colgroup = a.iws + 6 * (int64_t)n;
     __syncthreads();
     for (int c = tid; c < n; c += BLOCK2) {
-        const int32_t r = st_csget<LDS_STATE>(s_cs, gcolsol, c);
-        if constexpr (LDS_STATE) { gv[c] = s_v[c]; gcolsol[c] = r; }
+        const int32_t r = st_csget<CSL>(s_cs, gcolsol, c);
+        if constexpr (LDS_STATE) gv[c] = s_v[c];
+        if constexpr (CSL) gcolsol[c] = r;
         if (r >= 0) {
             rowsol[r] = c;
             cassign[c] = cost[(int64_t)r * ld + c];                 // c[colsol[j]][j] for the augmentation kernel
@@ -2760,12 +2765,14 @@ static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_c
     CoopArgs ca = plan.args;
     const size_t coop_shm = plan.shm;
     const int npad = (args.n + 3) & ~3;
-    const size_t shmem = LDS_STATE ? (((size_t)npad * 6 + 15) / 16) * 16 : 16;
+    const bool cs_lds = !LDS_STATE && args.n <= 65535;
+    const size_t shmem = LDS_STATE ? (((size_t)npad * 6 + 15) / 16) * 16 : (cs_lds ? (((size_t)npad * 2 + 15) / 16) * 16 : 16);
     const size_t base_aug = (((LDS_STATE ? (size_t)npad * 6 : 0) + (args.gmode == 1 ? (size_t)args.ngroups * 8 : 0) + 15) / 16) * 16;
     Chain2Args aug_args = args;
     aug_args.auxlds = (LDS_STATE && args.ngroups < 65536 && base_aug + (size_t)npad * 6 + 4096 <= 160 * 1024) ? 1 : 0;
     const size_t shmem_aug = base_aug + (aug_args.auxlds ? (size_t)npad * 6 : 0) + 32;
-    auto kern = jv_chain2<CH, LDS_STATE>;
+    void (*kern)(Chain2Args) = jv_chain2<CH, LDS_STATE, false>;
+    if constexpr (!LDS_STATE) { if (cs_lds) kern = jv_chain2<CH, false, true>; }
     CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     if constexpr (CH == 0)
         hipLaunchKernelGGL(build_row_caches_stream, dim3(cache_grid), dim3(BLOCK2), 0, stream, args.n, args.ld, args.cost,
