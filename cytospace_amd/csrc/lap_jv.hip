@@ -2219,8 +2219,10 @@ __device__ __forceinline__ uint64_t wave_lexmin_u64(uint64_t k) {
     const uint32_t l = wave_min_u32(hi == m ? lo : 0xFFFFFFFFu);
     return ((uint64_t)m << 32) | l;
 }
-template <bool LDS_STATE>
+// LDS_STATE: prices and colsol in LDS; CS_LDS (with !LDS_STATE, n <= 65535): colsol (u16) in LDS, prices in L2
+template <bool LDS_STATE, bool CS_LDS = false>
 __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
+    constexpr bool CSL = LDS_STATE || CS_LDS;
 #ifdef LZ_PROF
     long long prof[6] = {0, 0, 0, 0, 0, 0}, profn[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
     long long prof2[4] = {0, 0, 0, 0}, tlast2 = 0;
@@ -2245,6 +2247,9 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
         s_v = reinterpret_cast<float *>(dyn_lds);
         s_cs = reinterpret_cast<uint16_t *>(dyn_lds + (size_t)npad * 4);
         off = ((size_t)npad * 6 + 15) & ~(size_t)15;
+    } else if constexpr (CS_LDS) {
+        s_cs = reinterpret_cast<uint16_t *>(dyn_lds);
+        off = ((size_t)npad * 2 + 15) & ~(size_t)15;
     }
     const int nbp = (nb + 511) & ~511;               // padded with KEYMAX: the pick reads 8 keys per lane, unpredicated
     uint64_t *bmin = reinterpret_cast<uint64_t *>(dyn_lds + off); off += (size_t)nbp * 8;
@@ -2262,9 +2267,9 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
         for (int g = tid; g < a.ngroups; g += BLOCK2) hs[g] = 0;
     }
     int par = 0;
-    if constexpr (LDS_STATE) {
+    if constexpr (CSL) {
         for (int c = tid; c < npad; c += BLOCK2) {
-            s_v[c] = c < n ? gv[c] : 0.0f;
+            if constexpr (LDS_STATE) s_v[c] = c < n ? gv[c] : 0.0f;
             const int32_t cs = c < n ? a.colsol[c] : -1;
             s_cs[c] = cs < 0 ? (uint16_t)0xFFFFu : (uint16_t)cs;
         }
@@ -2349,7 +2354,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                         const int ep = (int)readlane32(cc, le);
                         const float cie = __uint_as_float(readlane32(__float_as_uint(cv), le));
                         if (lane == 0) {
-                            st_csset<LDS_STATE>(s_cs, a.colsol, ep, freerow);
+                            st_csset<CSL>(s_cs, a.colsol, ep, freerow);
                             st_f32(a.cassign + ep, cie);
                             st_i32(a.rowsol + freerow, ep);
                             s_un[ep >> 5] &= ~(1u << (ep & 31));
@@ -2435,7 +2440,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                             const int st0 = nscan == 0 ? 0 : (int32_t)(uint32_t)ld_u64(a.dkey + ep);
                             int i = st0 == 0 ? freerow : ld_i32(a.srow + st0);
                             for (;;) {
-                                st_csset<LDS_STATE>(s_cs, a.colsol, ep, i);
+                                st_csset<CSL>(s_cs, a.colsol, ep, i);
                                 st_f32(a.cassign + ep, (have_cie0 && hops == 0) ? cie0 : cost[(int64_t)i * ld + ep]);
                                 const int j1 = ep;
                                 if (i != freerow) ep = ld_i32(a.rowsol + i);      // (the free row owns no column)
@@ -2464,7 +2469,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                         if (a.may_bail && c_relax >= 4096 && c_dense * 10 >= c_relax) bail = true;
                         break;
                     }
-                    const int i = __builtin_amdgcn_readfirstlane(st_csget<LDS_STATE>(s_cs, a.colsol, jp));
+                    const int i = __builtin_amdgcn_readfirstlane(st_csget<CSL>(s_cs, a.colsol, jp));
                     const float vjp = st_vget<LDS_STATE>(s_v, gv, jp);
                     const int step = nscan + 1;
                     const int blk = jp >> 6;
@@ -2711,9 +2716,9 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
         }
     }
     // ---- write back prices and colsol, then duals u and the total ----
-    if constexpr (LDS_STATE) {
+    if constexpr (CSL) {
         for (int c = tid; c < n; c += BLOCK2) {
-            gv[c] = s_v[c];
+            if constexpr (LDS_STATE) gv[c] = s_v[c];
             const uint16_t cs = s_cs[c];
             a.colsol[c] = cs == 0xFFFFu ? -1 : (int32_t)cs;
         }
@@ -2757,7 +2762,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
 // host side
 // ------------------------------------------------------------------------------------------
 struct CoopPlan { bool enabled; CoopArgs args; size_t shm; };
-struct LazyPlan { bool enabled, lds_state; LazyArgs args; size_t shm; };
+struct LazyPlan { bool enabled, lds_state, cs_lds; LazyArgs args; size_t shm; };
 template <int CH, bool LDS_STATE>
 static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_cache_done, hipEvent_t ev_arr_done, hipStream_t stream,
                          const CoopPlan &plan, const LazyPlan &lz) {
@@ -2799,6 +2804,9 @@ static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_c
         if (lz.lds_state) {
             CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jv_aug_lazy<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lz.shm));
             hipLaunchKernelGGL(jv_aug_lazy<true>, dim3(1), dim3(BLOCK2), lz.shm, stream, la);
+        } else if (lz.cs_lds) {
+            CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jv_aug_lazy<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lz.shm));
+            hipLaunchKernelGGL((jv_aug_lazy<false, true>), dim3(1), dim3(BLOCK2), lz.shm, stream, la);
         } else {
             CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jv_aug_lazy<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lz.shm));
             hipLaunchKernelGGL(jv_aug_lazy<false>, dim3(1), dim3(BLOCK2), lz.shm, stream, la);
@@ -2993,7 +3001,9 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
                     lz.enabled = true;
                     lazy_used = true;
                     lz.lds_state = n <= 65535 && !getenv("CYTO_FORCE_STREAM") && npad6 + nb24 <= lds_budget;
-                    lz.shm = (lz.lds_state ? npad6 : 0) + nb24;
+                    const size_t npad2 = (((size_t)((n + 3) & ~3) * 2) + 15) & ~(size_t)15;
+                    lz.cs_lds = !lz.lds_state && n <= 65535 && npad2 + nb24 <= lds_budget;
+                    lz.shm = (lz.lds_state ? npad6 : (lz.cs_lds ? npad2 : 0)) + nb24;
                     LazyArgs &la = lz.args;
                     la.n = n; la.ld = dld; la.cost = dcost; la.gv = d_v; la.gu = d_u; la.sumvd = d_v + 2 * (int64_t)n;
                     la.cassign = d_v + 3 * (int64_t)n; la.dkey = reinterpret_cast<uint64_t *>(d_v + 4 * (int64_t)n);
