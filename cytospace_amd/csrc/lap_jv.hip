@@ -312,6 +312,8 @@ template <typename T> struct ChainArgs {
     double *total;       // [1] out
     long long *counters; // [C_NCOUNTERS] out
     int *status;         // [1] out (0 ok)
+    T *dwork;            // [n] scratch (jv_chain_stream: distances)
+    int32_t *lvl;        // [n] scratch (jv_chain_stream: level at which a column was scanned; 0 = not scanned)
 };
 
 // agent-scope relaxed accesses: served by L2, never by the scalar cache or a stale L1 line
@@ -601,6 +603,228 @@ __global__ __launch_bounds__(BLOCK) void jv_chain(ChainArgs<T> a) {
         *a.status = err;
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// The same chain with every per-column quantity (prices, distances, predecessors, scan levels) in L2-resident
+// global memory instead of VGPRs: jv_chain<double, CH> spills badly beyond CH = 2 (1024 threads leave 128 VGPRs
+// per lane), this variant has no per-lane arrays at all and takes any n.  Column c is only ever touched by thread
+// (c / VW) % BLOCK, so plain loads and stores in program order are all the ordering the per-column arrays need.
+// A row scan = one coalesced sweep of the cost row (HBM) and of the price vector (L2).  Same arithmetic, same
+// tie-breaking, same step budget as jv_chain / the oracle.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
+    using V = typename VecOf<T>::type;
+    constexpr int VW = VecOf<T>::W;
+    __shared__ RedScratch<T> red;
+    const int tid = threadIdx.x;
+    const int n = a.n;
+    const int64_t ld = a.ld;
+    const T *__restrict__ cost = a.cost;
+    T *v = a.v, *d = a.dwork;
+    int32_t *lvl = a.lvl, *pred = a.pred;
+    int par = 0;
+    const T INF = (T)INFINITY;
+    const int nq = (n + VW - 1) / VW;                  // vector chunks per row (rows and v are VW-aligned and padded)
+    const V *vp = reinterpret_cast<const V *>(v);
+
+    long long c_rt = 0, c_arr = 0, c_auginit = 0, c_augrelax = 0, c_augs = 0, c_hops = 0, c_free_a1 = 0;
+    int numfree = 0, nrt = 0;
+    {
+        const int R = (n + BLOCK - 1) / BLOCK;
+        const int r0 = min(n, tid * R), r1 = min(n, r0 + R);
+        int f = 0, g = 0;
+        for (int i = r0; i < r1; i++) { const int mt = a.matches[i]; f += (mt == 0); g += (mt == 1); }
+        int of = wg_exscan(f, red, par, &numfree);
+        int og = wg_exscan(g, red, par, &nrt);
+        for (int i = r0; i < r1; i++) {
+            const int mt = a.matches[i];
+            if (mt == 0) st_i32(a.freerows + of++, i);
+            else if (mt == 1) st_i32(a.rtrows + og++, i);
+        }
+    }
+    __syncthreads();
+    const long long c_free_cr = numfree;
+
+    // ---- REDUCTION TRANSFER ----
+    if (n > 1) {
+        for (int k = 0; k < nrt; k++) {
+            const int i = ld_i32(a.rtrows + k);
+            const int j1 = ld_i32(a.rowsol + i);
+            const V *rp = reinterpret_cast<const V *>(cost + (int64_t)i * ld);
+            Min1<T> loc; loc.u = INF; loc.k = 0; loc.a = 0;
+            for (int q = tid; q < nq; q += BLOCK) {
+                const V x = rp[q], vv = vp[q];
+#pragma unroll
+                for (int e = 0; e < VW; e++) {
+                    const int c = q * VW + e;
+                    if (c < n && c != j1) { const T h = vec_get<T>(x, e) - vec_get<T>(vv, e); if (h < loc.u) loc.u = h; }
+                }
+            }
+            const Min1<T> g = wg_min1(loc, red, par);
+            if (((j1 / VW) % BLOCK) == tid) v[j1] = v[j1] - g.u;
+            c_rt++;
+        }
+    }
+
+    // ---- AUGMENTING ROW REDUCTION, two sweeps ----
+    const long long arr_budget = 1000ll * n + 1000000ll;   // == JV_ARR_BUDGET(n) of the oracle
+    for (int sweep = 0; sweep < 2; sweep++) {
+        int k = 0;
+        const int prev = numfree;
+        numfree = 0;
+        int carry = -1;
+        while (carry >= 0 || k < prev) {
+            if (c_arr >= arr_budget) {
+                if (carry >= 0) { if (tid == 0) st_i32(a.freerows + numfree, carry); numfree++; carry = -1; }
+                while (k < prev) { const int r = ld_i32(a.freerows + k); k++; if (tid == 0) st_i32(a.freerows + numfree, r); numfree++; }
+                break;
+            }
+            int i;
+            if (carry >= 0) { i = carry; carry = -1; }
+            else { i = ld_i32(a.freerows + k); k++; }
+            const V *rp = reinterpret_cast<const V *>(cost + (int64_t)i * ld);
+            Top2<T> loc; loc.u1 = INF; loc.k1 = 0xFFFFFFFFu; loc.a1 = 0; loc.u2 = INF; loc.k2 = 0xFFFFFFFFu;
+            for (int q = tid; q < nq; q += BLOCK) {
+                const V x = rp[q], vv = vp[q];
+#pragma unroll
+                for (int e = 0; e < VW; e++) {
+                    const int c = q * VW + e;
+                    if (c < n) top2_push(loc, vec_get<T>(x, e) - vec_get<T>(vv, e), (uint32_t)c, vec_get<T>(vv, e));
+                }
+            }
+            const Top2<T> g = wg_top2(loc, red, par);
+            c_arr++;
+            int j1 = (int)g.k1;
+            const int j2 = (int)g.k2;
+            int i0 = ld_i32(a.colsol + j1);
+            const T vj1 = g.a1;
+            const T vnew = vj1 - (g.u2 - g.u1);
+            const bool lowers = vnew < vj1;
+            if (lowers) { if (((j1 / VW) % BLOCK) == tid) v[j1] = vnew; }
+            else if (i0 >= 0) { j1 = j2; i0 = ld_i32(a.colsol + j2); }
+            __syncthreads();  // every wave has read colsol for this step before it changes
+            if (tid == 0) { st_i32(a.rowsol + i, j1); st_i32(a.colsol + j1, i); }
+            if (i0 >= 0) {
+                if (lowers) carry = i0;
+                else { if (tid == 0) st_i32(a.freerows + numfree, i0); numfree++; }
+            }
+            __syncthreads();  // the colsol store is visible (L2) before the next step reads it
+        }
+        __syncthreads();
+        if (sweep == 0) c_free_a1 = numfree;
+    }
+    const long long c_free_a2 = numfree;
+
+    // ---- AUGMENTATION: relaxation and the search for the next pick share one sweep ----
+    int err = 0;
+    for (int f = 0; f < numfree && !err; f++) {
+        const int freerow = ld_i32(a.freerows + f);
+        Min1<T> loc; loc.u = INF; loc.k = 0xFFFFFFFFu; loc.a = 0;
+        {
+            const V *rp = reinterpret_cast<const V *>(cost + (int64_t)freerow * ld);
+            for (int q = tid; q < nq; q += BLOCK) {
+                const V x = rp[q], vv = vp[q];
+#pragma unroll
+                for (int e = 0; e < VW; e++) {
+                    const int c = q * VW + e;
+                    if (c < n) {
+                        const T dd = vec_get<T>(x, e) - vec_get<T>(vv, e);
+                        d[c] = dd; pred[c] = freerow; lvl[c] = 0;
+                        const uint32_t key = (uint32_t)c | (ld_i32(a.colsol + c) >= 0 ? 0x80000000u : 0u);
+                        if (lex_less(dd, key, loc.u, loc.k)) { loc.u = dd; loc.k = key; loc.a = vec_get<T>(vv, e); }
+                    }
+                }
+            }
+            c_auginit++;
+        }
+        bool have = false;
+        T curmin = 0;
+        int endofpath = -1, level = 0;
+        for (;;) {
+            const Min1<T> g = wg_min1(loc, red, par);
+            if (g.k == 0xFFFFFFFFu) { err = CYTO_ERR_INTERNAL; break; }
+            const int jp = (int)(g.k & 0x7FFFFFFFu);
+            if (!have || g.u != curmin) { level++; curmin = g.u; have = true; }
+            if (!(g.k & 0x80000000u)) { endofpath = jp; break; }
+            if (((jp / VW) % BLOCK) == tid) lvl[jp] = level;                 // scanned (its d keeps the value at the pick)
+            const int i = ld_i32(a.colsol + jp);
+            const T cip = cost[(int64_t)i * ld + jp];
+            const T h = (cip - g.a) - curmin;
+            const V *rp = reinterpret_cast<const V *>(cost + (int64_t)i * ld);
+            loc.u = INF; loc.k = 0xFFFFFFFFu; loc.a = 0;
+            for (int q = tid; q < nq; q += BLOCK) {
+                const V x = rp[q], vv = vp[q];
+#pragma unroll
+                for (int e = 0; e < VW; e++) {
+                    const int c = q * VW + e;
+                    if (c < n && lvl[c] == 0) {
+                        const T v2 = (vec_get<T>(x, e) - vec_get<T>(vv, e)) - h;
+                        T dc = d[c];
+                        if (v2 < dc) { dc = v2; d[c] = v2; pred[c] = i; }
+                        const uint32_t key = (uint32_t)c | (ld_i32(a.colsol + c) >= 0 ? 0x80000000u : 0u);
+                        if (lex_less(dc, key, loc.u, loc.k)) { loc.u = dc; loc.k = key; loc.a = vec_get<T>(vv, e); }
+                    }
+                }
+            }
+            c_augrelax++;
+        }
+        if (err) break;
+        // price update: columns scanned at an earlier level than the final one
+        for (int q = tid; q < nq; q += BLOCK) {
+#pragma unroll
+            for (int e = 0; e < VW; e++) {
+                const int c = q * VW + e;
+                if (c < n) { const int lv = lvl[c]; if (lv != 0 && lv < level) v[c] = (v[c] + d[c]) - curmin; }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();  // pred / price stores of all waves are complete (and, via L2, visible)
+        if (tid == 0) {
+            int ep = endofpath, i;
+            do {
+                i = ld_i32(pred + ep);
+                st_i32(a.colsol + ep, i);
+                const int j1 = ep;
+                ep = ld_i32(a.rowsol + i);
+                st_i32(a.rowsol + i, j1);
+                c_hops++;
+            } while (i != freerow);
+        }
+        c_augs++;
+        __syncthreads();
+    }
+
+    // ---- duals u and the total ----
+    __threadfence_block();
+    __syncthreads();
+    double part = 0.0;
+    if (!err) {
+        for (int i = tid; i < n; i += BLOCK) {
+            const int j = ld_i32(a.rowsol + i);
+            const T cij = cost[(int64_t)i * ld + j];
+            const T vj = __hip_atomic_load(a.v + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.u[i] = cij - vj;
+            part += (double)cij;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+    __shared__ double s_sum[NW];
+    if ((tid & 63) == 0) s_sum[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < NW; w++) t += s_sum[w];
+        *a.total = t;
+        a.counters[C_RT] = c_rt; a.counters[C_ARR] = c_arr; a.counters[C_AUG_INIT] = c_auginit;
+        a.counters[C_AUG_RELAX] = c_augrelax; a.counters[C_AUGS] = c_augs; a.counters[C_HOPS] = c_hops;
+        a.counters[C_FREE_CR] = c_free_cr; a.counters[C_FREE_A1] = c_free_a1; a.counters[C_FREE_A2] = c_free_a2;
+        a.counters[C_ROWS_READ] = c_rt + c_arr + c_auginit + c_augrelax;
+        *a.status = err;
+    }
+}
+
 
 
 // ==========================================================================================
@@ -2881,8 +3105,8 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
                      T *u, T *v, double *total, cyto_lap_info *info, int device_id, void *stream_) {
     constexpr int VW = VecOf<T>::W;
     if (n <= 0 || !cost || ld < n) return CYTO_ERR_BAD_ARG;
-    // float32: the cached-chain path takes any n up to FAST_NMAX; float64: the generic kernel's register budget
-    const int64_t cap = std::is_same<T, float>::value ? (int64_t)FAST_NMAX : (int64_t)16 * VW * BLOCK;
+    // both precisions take any n up to FAST_NMAX (float32: cached chain; float64: streaming generic chain)
+    const int64_t cap = (int64_t)FAST_NMAX;
     if (n > cap) return CYTO_ERR_UNSUPPORTED;
     int rc = select_device(device_id);
     if (rc) return rc;
@@ -2962,6 +3186,7 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
     ca.rowsol = d_rowsol; ca.colsol = d_colsol; ca.matches = d_matches;
     ca.freerows = d_free; ca.rtrows = d_rt; ca.pred = d_pred;
     ca.total = d_total; ca.counters = d_counters; ca.status = d_status;
+    ca.dwork = d_v + 4 * (size_t)n; ca.lvl = d_rowsol + 7 * (size_t)n;
 
     hipEvent_t e1b, e1c, e1d;
     CYTO_HIP(hipEventCreate(&e1b));
@@ -3101,10 +3326,16 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
     } else {
         CYTO_HIP(hipEventRecord(e1c, stream));
         CYTO_HIP(hipEventRecord(e1d, stream));
-        if (n <= 2 * per) rc = launch_chain<T, 2, true>(ca, stream);
-        else if (n <= 5 * per) rc = launch_chain<T, 5, true>(ca, stream);
-        else if (n <= 8 * per) rc = launch_chain<T, 8, true>(ca, stream);
-        else rc = launch_chain<T, 16, false>(ca, stream);
+        if constexpr (!std::is_same<T, float>::value) {
+            // float64: register-resident chain while it does not spill (n <= 4096), else everything streams from L2
+            if (n <= 2 * per && !getenv("CYTO_FORCE_STREAM")) rc = launch_chain<T, 2, true>(ca, stream);
+            else {
+                hipLaunchKernelGGL(jv_chain_stream<T>, dim3(1), dim3(BLOCK), 0, stream, ca);
+                rc = hipGetLastError() == hipSuccess ? CYTO_OK : CYTO_ERR_HIP;
+            }
+        } else {
+            rc = CYTO_ERR_UNSUPPORTED;      // (float32 always takes the cached-chain path above)
+        }
     }
     if (rc) { cleanup(); (void)hipEventDestroy(e1b); (void)hipEventDestroy(e1c); (void)hipEventDestroy(e1d); return rc; }
     CYTO_HIP(hipEventRecord(e2, stream));
