@@ -2525,6 +2525,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
     uint32_t icc = COLSENT;
     int level = 0, nscan = 0, ntouch = 0, nexc = 0;   // nexc: register copy of s_nexc (it only changes at a search's end)
     bool bail = false;
+    long long w_relax0 = 0, w_dense0 = 0;           // start of the current hand-over window
     // software pipeline over searches: id of the free row after next, cache row of the next one
     int id_next = -1, id1_saved = -1;
     uint32_t ncc = COLSENT;
@@ -2690,7 +2691,11 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                         insearch = false;
                         // instances whose searches run deeper than the caches reach (>= 10 % full-row scans) are
                         // faster on the register-resident dense kernel: hand the remaining free rows over
-                        if (a.may_bail && c_relax >= 4096 && c_dense * 10 >= c_relax) bail = true;
+                        // (judged on windows of >= 8192 scans, so that a dense-heavy start alone does not decide)
+                        if (a.may_bail && c_relax - w_relax0 >= 8192) {
+                            if ((c_dense - w_dense0) * 10 >= c_relax - w_relax0) bail = true;
+                            w_relax0 = c_relax; w_dense0 = c_dense;
+                        }
                         break;
                     }
                     const int i = __builtin_amdgcn_readfirstlane(st_csget<CSL>(s_cs, a.colsol, jp));
