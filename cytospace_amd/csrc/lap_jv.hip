@@ -1460,6 +1460,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
     constexpr bool CSL = LDS_STATE || CS_LDS;     // colsol lives in LDS
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     __shared__ Scratch2 s;
+    __shared__ int32_t s_app[64];          // staged appends to the next sweep's free-row list (wave 0)
     const int tid = threadIdx.x, lane = tid & 63;
     // provably wave-uniform wave id: the wave-0 state machine below then lives in SGPRs with scalar branches
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1516,6 +1517,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
     if (phase == PH_ARR) numfree = 0;
     bool have_dense = false;
     K2 gd; gd.m1 = KEYMAX; gd.m2 = KEYMAX;
+    int napp = 0;                           // entries staged in s_app since the last flush
 
     for (;;) {
         if (wave == 0) {
@@ -1531,6 +1533,8 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
                         if (c_arr >= arr_budget && (carry >= 0 || k < prev)) {
                             // step budget exhausted (see oracle/jv_oracle_impl.h): hand the waiting rows
                             // to the augmentation phase, the displaced row first, then the list order
+                            if (lane < (napp & 63)) st_i32(freerows + numfree - (napp & 63) + lane, s_app[lane]);
+                            napp = 0;
                             if (carry >= 0) { if (lane == 0) st_i32(freerows + numfree, carry); numfree++; carry = -1; }
                             while (k < prev) {
                                 const int r = __builtin_amdgcn_readfirstlane(ld_i32(freerows + k)); k++;
@@ -1541,8 +1545,16 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
                         }
                         if (carry >= 0) { cur_i = carry; carry = -1; }
                         else if (k < prev) { cur_i = __builtin_amdgcn_readfirstlane(ld_i32(freerows + k)); k++; }
-                        else if (sweep == 0) { c_free_a1 = numfree; sweep = 1; k = 0; prev = numfree; numfree = 0; continue; }
-                        else { c_free_a2 = numfree; phase = PH_AUG; k = 0; continue; }
+                        else if (sweep == 0) {
+                            if (lane < (napp & 63)) st_i32(freerows + numfree - (napp & 63) + lane, s_app[lane]);   // flush the staged tail
+                            napp = 0;
+                            c_free_a1 = numfree; sweep = 1; k = 0; prev = numfree; numfree = 0; continue;
+                        }
+                        else {
+                            if (lane < (napp & 63)) st_i32(freerows + numfree - (napp & 63) + lane, s_app[lane]);
+                            napp = 0;
+                            c_free_a2 = numfree; phase = PH_AUG; k = 0; continue;
+                        }
                     } else {
                         // RT and ARR are done: the augmentation runs in its own kernel (jv_aug2)
                         if (lane == 0) { s.cmd_op = OP_EXIT; s.cmd_row = 0; }
@@ -1662,7 +1674,13 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
                     if (__builtin_expect(i0f >= 0 && lowers && c_arr < arr_budget, 1)) { cur_i = i0f; continue; }   // chain goes on
                     if (i0f >= 0) {
                         if (lowers) carry = i0f;       // budget reached: the slow path flushes it
-                        else { if (lane == 0) st_i32(freerows + numfree, i0f); numfree++; }
+                        else {
+                            // the next sweep's list is staged in LDS and written 64 entries at a time: a global store in
+                            // every step would hold back the next step's loads until it is acknowledged
+                            if (lane == 0) s_app[napp & 63] = i0f;
+                            napp++; numfree++;
+                            if ((napp & 63) == 0) st_i32(freerows + numfree - 64 + lane, s_app[lane]);
+                        }
                     }
                     break;
                 }
