@@ -2393,7 +2393,7 @@ __global__ __launch_bounds__(BLOCK3) void jv_finish_duals(int n, int64_t ld, con
 //
 // State: one 64-bit word per column in L2-resident global memory, (ordered d << 32) | step of the scan
 // that set it (unsigned min == "strictly smaller d wins, the earlier scan on equal d", i.e. the oracle's
-// `v2 < d` rule; pred is recovered as the row of that step); 0 once the column is scanned.  The pick
+// `v2 < d` rule; pred is recovered as the row of that step); never written again once the column is scanned.  The pick
 // structure is in LDS: for each block of 64 columns the smallest (d, assigned?, column) key.  A cached
 // step runs on wave 0 alone: LDS min over the block keys, three independent loads (cache row, the picked
 // column's block for its new minimum, c[i][jp]), <= 63 fire-and-forget 64-bit atomic mins + LDS mins.
@@ -2406,7 +2406,7 @@ struct LazyArgs {
     const float *cost;
     float *gv, *gu, *sumvd, *cassign;
     uint64_t *dkey;                                   // [n]
-    int32_t *rowsol, *colsol, *freerows, *predstep, *srow, *slist, *slevel;   // [n] each (srow: [n+1])
+    int32_t *rowsol, *colsol, *freerows, *srow, *slist, *slevel;   // [n] each (srow: [n+1])
     const int32_t *rowgid;
     const uint32_t *cache_col;
     const float *cache_val;
@@ -2474,6 +2474,10 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
     __shared__ LazyCmd cmd;
     __shared__ int s_nexc;
     __shared__ uint32_t s_T;          // ordered key of T (wave 0 lowers it with LDS atomic mins)
+    // the per-scan records of the current search (column, level, v + d, row) are staged here and written to the
+    // global lists 64 at a time: every global store in a step holds back the next step's loads until it is acknowledged
+    __shared__ int32_t s_ljp[64], s_llv[64], s_lrw[64];
+    __shared__ float s_lsv[64];
     __shared__ int s_exc[LZ_MAXEXC];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2656,11 +2660,18 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                         // ======== end of the search (wave 0 alone): price update, path flip, clean-up ========
                         LZ_STAMP2(2)
                         const int endofpath = jp;
+                        {
+                            const int rem = nscan & 63, base = nscan - rem;
+                            if (lane < rem) {
+                                st_i32(a.slist + base + lane, s_ljp[lane]); st_i32(a.slevel + base + lane, s_llv[lane]);
+                                st_f32(a.sumvd + base + lane, s_lsv[lane]); st_i32(a.srow + 1 + base + lane, s_lrw[lane]);
+                            }
+                        }
                         for (int k2 = lane; k2 < nscan; k2 += 64) {
                             if (ld_i32(a.slevel + k2) < level) {
                                 const int j = ld_i32(a.slist + k2);
                                 const float vold = st_vget<LDS_STATE>(s_v, gv, j);
-                                const float vnew = ld_f32(a.sumvd + j) - curmin;
+                                const float vnew = ld_f32(a.sumvd + k2) - curmin;
                                 st_vset<LDS_STATE>(s_v, gv, j, vnew);
                                 if (vnew > vold) {   // rounding pushed a price UP: column j leaves the cache certificates
                                     const int e = atomicAdd(&s_nexc, 1);
@@ -2690,7 +2701,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                                 st_i32(a.rowsol + i, j1);
                                 hops++;
                                 if (i == freerow) break;
-                                const int stp = ld_i32(a.predstep + ep);
+                                const int stp = (int32_t)(uint32_t)ld_u64(a.dkey + ep);
                                 i = stp == 0 ? freerow : ld_i32(a.srow + stp);
                             }
                             s_un[endofpath >> 5] &= ~(1u << (endofpath & 31));
@@ -2730,8 +2741,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                     const float cv = ld_f32(a.cache_val + (int64_t)i * KC + lane);
                     // retire column jp
                     if (lane == 0) {
-                        st_i32(a.slist + nscan, jp); st_i32(a.slevel + nscan, level); st_f32(a.sumvd + jp, vjp + dmin);
-                        st_i32(a.srow + step, i);
+                        s_ljp[nscan & 63] = jp; s_llv[nscan & 63] = level; s_lsv[nscan & 63] = vjp + dmin; s_lrw[nscan & 63] = i;
                         atomicOr(&s_sc[jp >> 5], 1u << (jp & 31));
                     }
                     const uint32_t scw = s_sc[blk * 2 + (lane >> 5)], unw = s_un[blk * 2 + (lane >> 5)];
@@ -2739,7 +2749,8 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                     LZ_STAMP(2)
                     const float cip = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(cip_raw)));
                     const float h = (cip - vjp) - curmin;
-                    if (jb == jp) { st_i32(a.predstep + jp, (int32_t)(uint32_t)dk); st_u64(a.dkey + jp, 0ull); }
+                    // (the word of a scanned column is never written again -- every writer tests the scanned bit -- so it
+                    // keeps the step that set its distance: that is its predecessor for the path flip)
                     bool skip = false;
                     if (gmode) {
                         const int g = __builtin_amdgcn_readfirstlane(g_raw);
@@ -2766,6 +2777,11 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                     }
                     nscan++;
                     c_relax++;
+                    if ((nscan & 63) == 0) {
+                        const int base = nscan - 64;
+                        st_i32(a.slist + base + lane, s_ljp[lane]); st_i32(a.slevel + base + lane, s_llv[lane]);
+                        st_f32(a.sumvd + base + lane, s_lsv[lane]); st_i32(a.srow + 1 + base + lane, s_lrw[lane]);
+                    }
                     LZ_STAMP(3)
                     if (skip) { c_skipped++; continue; }
                     const float floor_i = __uint_as_float(readlane32(__float_as_uint(cv), KCU));
@@ -3255,7 +3271,7 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
                     LazyArgs &la = lz.args;
                     la.n = n; la.ld = dld; la.cost = dcost; la.gv = d_v; la.gu = d_u; la.sumvd = d_v + 2 * (int64_t)n;
                     la.cassign = d_v + 3 * (int64_t)n; la.dkey = reinterpret_cast<uint64_t *>(d_v + 4 * (int64_t)n);
-                    la.rowsol = d_rowsol; la.colsol = d_colsol; la.freerows = d_free; la.predstep = d_rowsol + 5 * (int64_t)n;
+                    la.rowsol = d_rowsol; la.colsol = d_colsol; la.freerows = d_free;
                     la.srow = d_rowsol + 6 * (int64_t)n;      // [n+1]: runs into the next slot, which the lazy path does not use
                     la.slist = d_rowsol + 8 * (int64_t)n; la.slevel = d_rowsol + 9 * (int64_t)n;
                     la.rowgid = b_gid.as<int32_t>(); la.cache_col = b_ccol.as<uint32_t>(); la.cache_val = b_cval.as<float>();
