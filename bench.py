@@ -137,7 +137,7 @@ def main():
     achieved = dom_bytes / (dom[2] * 1e-3) / 1e9
     traffic = None
     try:   # HBM bytes from the separate rocprofv3 --pmc pass committed under profiles/ (same n, same instance)
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01d_pmc_traffic_n20000.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_traffic_n20000.json")))
         if pm.get("n") == n:
             key = [k for k in pm["kernels"] if k.startswith(dom[0] + "<")]
             if key:
