@@ -2414,6 +2414,7 @@ struct LazyArgs {
     char *misc;
     int ngroups, gmode;
     int may_bail;        // a dense kernel can take over: give up when the cache certificates keep failing
+    int debug_exc;       // tests: pretend the first debug_exc columns had a price rounded upwards (exception list)
 };
 struct LazyCmd { int op, row, step, stamp; float h; };
 enum { LZ_DENSE = 1, LZ_EXIT = 2, LZ_ERR = 3, LZ_INIT_DENSE = 4 };
@@ -2525,7 +2526,8 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
         for (int b = 0; b < 32; b++) { const int c = w * 32 + b; if (c < n && a.colsol[c] < 0) m |= (1u << b); }
         s_un[w] = m;
     }
-    if (tid == 0) s_nexc = 0;
+    if (tid == 0) s_nexc = a.debug_exc;
+    if (tid < LZ_MAXEXC) s_exc[tid] = tid < n ? tid : 0;
     for (int b = tid; b < nb; b += BLOCK2) s_ep[b] = 0;
     long long c_sparse = 0;
     // between searches: every block minimum is "empty", no column is marked scanned
@@ -2545,8 +2547,9 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
     bool insearch = false, have = false, dense_used = false, isparse = false;
     float curmin = 0.0f, icv = 0.0f;
     uint32_t icc = COLSENT;
-    int level = 0, nscan = 0, ntouch = 0, nexc = 0;   // nexc: register copy of s_nexc (it only changes at a search's end)
-    bool bail = false;
+    int level = 0, nscan = 0, ntouch = 0;
+    int nexc = a.debug_exc > LZ_MAXEXC ? LZ_MAXEXC : a.debug_exc;   // register copy of s_nexc (it only changes at a search's end)
+    bool bail = false, no_cert = a.debug_exc > LZ_MAXEXC;
     long long w_relax0 = 0, w_dense0 = 0;           // start of the current hand-over window
     // software pipeline over searches: id of the free row after next, cache row of the next one
     int id_next = -1, id1_saved = -1;
@@ -2587,7 +2590,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                     const uint32_t odd = valid ? f2ord(dd) : 0xFFFFFFFFu;
                     const uint32_t t0 = wave_min_u32(un ? odd : 0xFFFFFFFFu);
                     const float floor_f = __uint_as_float(readlane32(__float_as_uint(cv), KCU));
-                    const bool cert0 = nexc == 0 && t0 != 0xFFFFFFFFu && floor_f > ord2f(t0);
+                    const bool cert0 = !no_cert && nexc == 0 && t0 != 0xFFFFFFFFu && floor_f > ord2f(t0);
                     if (cert0 && wave_min_u32(odd) == t0) {
                         // ---- single-edge search: the smallest distance of the whole row belongs to an unassigned
                         // column (the oracle's first pick ends the search at once: no scan, no price update);
@@ -2680,7 +2683,9 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                             }
                         }
                         nexc = s_nexc;
-                        if (nexc > LZ_MAXEXC) err = CYTO_ERR_INTERNAL;
+                        // more such columns than the list holds: the certificates are abandoned for the rest of the solve
+                        // (every scan reads its full row; still exact, just slow) -- or the dense kernel takes over
+                        if (nexc > LZ_MAXEXC) { nexc = LZ_MAXEXC; no_cert = true; if (a.may_bail) bail = true; }
                         // c[freerow][endofpath] is in the sparse init's cache row when the path is a single edge
                         float cie0 = 0.0f;
                         bool have_cie0 = false;
@@ -2786,7 +2791,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                     if (skip) { c_skipped++; continue; }
                     const float floor_i = __uint_as_float(readlane32(__float_as_uint(cv), KCU));
                     const float T = ord2f(s_T);
-                    if (!((floor_i - h) > T)) {
+                    if (no_cert || !((floor_i - h) > T)) {
                         if (lane == 0) { cmd.op = LZ_DENSE; cmd.row = i; cmd.step = step; cmd.h = h; cmd.stamp = stamp; }
                         dense_used = true; post = true;
                         break;
@@ -3064,6 +3069,7 @@ static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_c
         CYTO_HIP(hipGetLastError());
         LazyArgs la = lz.args;
         la.may_bail = (LDS_STATE && !getenv("CYTO_AUG")) ? 1 : 0;     // the dense jv_aug2<CH, true> can take over
+        la.debug_exc = getenv("CYTO_DEBUG_EXC") ? atoi(getenv("CYTO_DEBUG_EXC")) : 0;
         if (lz.lds_state) {
             CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jv_aug_lazy<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lz.shm));
             hipLaunchKernelGGL(jv_aug_lazy<true>, dim3(1), dim3(BLOCK2), lz.shm, stream, la);

@@ -242,3 +242,17 @@ def test_augmentation_handover_to_dense_kernel_on_deep_searches():
         assert np.array_equal(g[k], o[k]), k
     assert g["info"].scans_aug_relax == o["stats"].scans_aug_relax and g["info"].augmentations == o["stats"].augmentations
     assert g["info"].aug_handover >= 0
+
+
+@pytest.mark.parametrize("k", ["5", "100"])
+def test_exception_columns_of_the_cache_certified_augmentation(monkeypatch, k):
+    # a price that a rounding pushed UP takes its column out of the cache certificates: such columns are relaxed
+    # explicitly in every cached step (k = 5), and when the list overflows the certificates are abandoned (k = 100:
+    # every scan reads its row).  CYTO_DEBUG_EXC pretends the first k columns are such columns; results stay exact.
+    monkeypatch.setenv("CYTO_AUG", "lazy")
+    monkeypatch.setenv("CYTO_DEBUG_EXC", k)
+    for n in (300, 2300):
+        c = np.random.default_rng(n + 7).random((n, n)).astype(np.float32)
+        _check(c, np.float32)
+    base = -(np.random.default_rng(9).random((200, 1000)) ** 3).astype(np.float32)
+    _check(np.repeat(base, 5, axis=0), np.float32)
