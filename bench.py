@@ -179,7 +179,8 @@ def main():
         "value": round(value, 1), "unit": "assignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{n}x{n} dense uniform float32 cost resident in HBM, JV HIP solver (BASELINE.json configs[1])",
+        "config": {"workload": f"{n}x{n} dense uniform float32 cost resident in HBM, JV HIP solver "
+                               + ("(BASELINE.json configs[1])" if n == 20000 else "(size given with --n; BASELINE.json configs[1] is 20000)"),
                    "n": n, "lap_per_gpu": 1, "parallelism": f"independent LAPs x{world}"},
         "parity": {"bit_exact_vs_cpu_oracle_n3000": parity_small, "full_size_permutation": perm_ok,
                    "full_size_total_1e-5": bool(total_ok), "full_size_dual_feasible": dual_ok,
