@@ -151,6 +151,39 @@ def solve_linear_assignment_problem(scRNA_norm_data, st_norm_data, cell_number_t
     raise ValueError("Invalid solver_method provided")
 
 
+class _RankContext:
+    """ExpressionContext over only the columns this rank's chunks touch (one process per GPU: a rank neither uploads nor
+    transforms the columns of other ranks' chunks), with the chunk index lists remapped accordingly."""
+
+    def __init__(self, sc, st, mine, index_sc_list, index_st_list, device_id, distance_metric):
+        sc = np.asarray(sc)
+        st = np.asarray(st)
+        self._sc_cols = self._st_cols = None
+        if mine and len(mine) < len(index_sc_list):
+            cols = np.unique(np.concatenate([np.asarray(index_sc_list[i]) for i in mine]))
+            if len(cols) < sc.shape[1]:
+                self._sc_cols, sc = cols, sc[:, cols]
+            if index_st_list is not None:
+                cols = np.unique(np.concatenate([np.asarray(index_st_list[i]) for i in mine]))
+                if len(cols) < st.shape[1]:
+                    self._st_cols, st = cols, st[:, cols]
+        self.ctx = ExpressionContext(sc, st, True, device_id, distance_metric)
+
+    def assign_chunk(self, index_sc, slots, index_st=None):
+        index_sc = np.asarray(index_sc)
+        if self._sc_cols is not None:
+            index_sc = np.searchsorted(self._sc_cols, index_sc)
+        if index_st is not None and self._st_cols is not None:
+            index_st = np.searchsorted(self._st_cols, np.asarray(index_st))
+        return self.ctx.assign_chunk(index_sc, slots, index_st)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.ctx.close()
+
+
 def schedule_chunks(sizes, n_devices):
     """Longest-processing-time-first placement of independent sub-LAPs on devices (cost ~ n^2.5)."""
     order = np.argsort([-float(s) ** 2.5 for s in sizes], kind="stable")
@@ -177,7 +210,7 @@ def assign_chunks(scRNA_norm, st_norm, cell_number_to_node_assignment, index_sc_
     slots_all = np.asarray(cell_number_to_node_assignment)
     # the sequential part of one solve occupies one workgroup: run this rank's chunks side by side
     # (ctypes releases the GIL; every call uses its own HIP stream); the matrices are uploaded once
-    with ExpressionContext(scRNA_norm, st_norm, True, device_id) as ctx:
+    with _RankContext(scRNA_norm, st_norm, mine, index_sc_list, index_st_list, device_id, "Pearson_correlation") as ctx:
         def one(idx):
             if index_st_list is not None:
                 return ctx.assign_chunk(index_sc_list[idx], slots_all[index_st_list[idx]], index_st_list[idx])
@@ -224,7 +257,7 @@ def apply_linear_assignment(scRNA_data, st_data, coordinates_data, cell_number_t
     mine = [idx for idx in range(n_chunks) if owner[idx] == rank]
 
     # both matrices go to the device once; a chunk gathers its columns there (spots without cells are skipped)
-    with ExpressionContext(scRNA_norm_np, st_norm_np, True, device_id, distance_metric) as ctx:
+    with _RankContext(scRNA_norm_np, st_norm_np, mine, index_sc_list, index_st_list, device_id, distance_metric) as ctx:
         def one(idx):
             if index_st_list is not None:
                 return idx, ctx.assign_chunk(index_sc_list[idx], slots_all[index_st_list[idx]], index_st_list[idx])
