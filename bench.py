@@ -37,7 +37,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=20000, help="LAP size (default: BASELINE.json configs[1])")
-    ap.add_argument("--cpu-n", type=int, default=16000, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-n", type=int, default=0,
+                    help="size of the bounded CPU-baseline sample (0: min(n, 20000); when it equals n the very same "
+                         "instance is used and the GPU result is compared bit for bit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -162,15 +164,23 @@ def main():
     }
 
     cpu = None
+    full_size_bit_exact = None
     if not args.no_cpu_baseline and world == 1:
-        cn = args.cpu_n
-        cc = make_cost(cn, cn)
+        cn = args.cpu_n if args.cpu_n > 0 else min(n, 20000)
+        same = cn == n
+        cc = cost if same else make_cost(cn, cn)
         t1 = time.perf_counter()
         oc = jv_oracle(cc, np.float32)
         dt = time.perf_counter() - t1
+        if same:   # the workload itself: the GPU result must be the oracle's, bit for bit
+            full_size_bit_exact = bool(all(np.array_equal(res[k], oc[k]) for k in ("rowsol", "colsol", "u", "v"))
+                                       and info.row_scans == oc["stats"].row_scans)
+            if not full_size_bit_exact:
+                raise SystemExit("full-size parity failed: HIP solver differs from the CPU oracle on the bench instance")
         cpu = {"value": round(cn / dt, 1), "unit": "assignments/s", "cores": 1, "kind": "port",
-               "sample": f"oracle/jv_oracle.c (C port of JV, -O3 -mavx2, 1 thread; lapjv wheel unavailable) on a "
-                         f"{cn}x{cn} uniform instance of the same generator: {dt:.1f} s, {oc['stats'].row_scans} row scans "
+               "sample": f"oracle/jv_oracle.c (C port of JV, -O3 -mavx2, 1 thread; lapjv wheel unavailable) on "
+                         + ("the bench instance itself" if same else "a smaller instance of the same generator")
+                         + f" ({cn}x{cn} uniform): {dt:.1f} s, {oc['stats'].row_scans} row scans "
                          f"({4.0 * cn * oc['stats'].row_scans / dt / 1e9:.1f} GB/s algorithmic); assignments/s falls with n",
                "cpu_model": _cpu_model(), "host_cores": os.cpu_count()}
 
@@ -182,7 +192,8 @@ def main():
         "config": {"workload": f"{n}x{n} dense uniform float32 cost resident in HBM, JV HIP solver "
                                + ("(BASELINE.json configs[1])" if n == 20000 else "(size given with --n; BASELINE.json configs[1] is 20000)"),
                    "n": n, "lap_per_gpu": 1, "parallelism": f"independent LAPs x{world}"},
-        "parity": {"bit_exact_vs_cpu_oracle_n3000": parity_small, "full_size_permutation": perm_ok,
+        "parity": {"bit_exact_vs_cpu_oracle_n3000": parity_small, "full_size_bit_exact_vs_cpu_oracle": full_size_bit_exact,
+                   "full_size_permutation": perm_ok,
                    "full_size_total_1e-5": bool(total_ok), "full_size_dual_feasible": dual_ok,
                    "note": "oracle = C restatement of JV; the lapjv wheel is not available in this image"},
         "roofline": roofline,
