@@ -147,3 +147,26 @@ def test_gv7_upstream_sampler_and_type_numbers_match_the_reference():
         gcyto.sample_single_cells(sc_df, ct_df, need, "bootstrap", 1)
     with pytest.raises(ValueError):
         gcyto.sample_single_cells(sc_df, ct_df, pd.DataFrame([3], index=["TYPE_Z"], columns=["Fraction"]), "duplicates", 1)
+
+
+def test_c_abi_argument_validation_needs_no_device():
+    # the entry points validate their arguments before they touch HIP: status codes only, no device required
+    from cytospace_amd import _lib
+    L = _lib.lib()
+    BAD = 1   # CYTO_ERR_BAD_ARG
+    x = np.zeros((4, 4), np.float64)
+    assert L.cyto_lap_f32(0, None, 0, 0, None, None, None, None, None, None, 0, None) == BAD
+    assert L.cyto_lap_f32(4, x.ctypes.data, 3, 0, None, None, None, None, None, None, 0, None) == BAD      # ld < n
+    assert L.cyto_transform(7, 4, 4, x.ctypes.data, 4, 1, 0, 1, x.ctypes.data, 4, 4, 0, None) == BAD       # unknown transform
+    assert L.cyto_transform(0, 4, 4, x.ctypes.data, 2, 1, 0, 1, x.ctypes.data, 4, 4, 0, None) == BAD       # ldx < C
+    slots = np.ones(4, np.int64)
+    assert L.cyto_cost_metric(5, 32, 4, 4, x.ctypes.data, 128, x.ctypes.data, 128, slots.ctypes.data, x.ctypes.data, 4, None, 0, None) == BAD
+    assert L.cyto_assign_metric(9, 4, 4, 4, x.ctypes.data, x.ctypes.data, slots.ctypes.data, 1, slots.ctypes.data, None, None, 0) == BAD
+    bad_slots = np.array([1, 1, 1, 2], np.int64)                                                            # sum != C
+    assert L.cyto_assign_metric(0, 4, 4, 4, x.ctypes.data, x.ctypes.data, bad_slots.ctypes.data, 1, slots.ctypes.data, None, None, 0) == BAD
+    h = ctypes.c_void_p()
+    assert L.cyto_ctx_create(3, 4, 4, 4, x.ctypes.data, x.ctypes.data, 1, 0, ctypes.byref(h)) == BAD      # unknown metric
+    assert L.cyto_ctx_create(0, 4, 0, 4, x.ctypes.data, x.ctypes.data, 1, 0, ctypes.byref(h)) == BAD      # empty matrix
+    assert L.cyto_ctx_assign_chunk(None, slots.ctypes.data, 4, None, 0, slots.ctypes.data, slots.ctypes.data, None, None) == BAD
+    L.cyto_ctx_destroy(None)                                                                                # no-op
+    assert L.cyto_strerror(1).decode() != ""
