@@ -256,3 +256,21 @@ def test_exception_columns_of_the_cache_certified_augmentation(monkeypatch, k):
         _check(c, np.float32)
     base = -(np.random.default_rng(9).random((200, 1000)) ** 3).astype(np.float32)
     _check(np.repeat(base, 5, axis=0), np.float32)
+
+
+def test_full_size_properties_bench_config():
+    # BASELINE.json configs[1] (20000 x 20000 dense): size-independent properties of an optimal assignment -- a
+    # permutation, rowsol/colsol mutually inverse, dual feasibility u_i + v_j <= c_ij with equality on the assignment
+    # (complementary slackness certifies optimality), total == sum of the assigned costs.  (bench.py additionally compares
+    # this instance with the CPU oracle bit for bit; that takes the oracle 14 s.)
+    n = 20000
+    c = np.random.default_rng(n).random((n, n)).astype(np.float32)
+    g = lap_solve(c, np.float32, return_info=True)
+    rowsol, colsol = g["rowsol"], g["colsol"]
+    assert np.array_equal(np.sort(colsol), np.arange(n)) and np.array_equal(rowsol[colsol], np.arange(n))
+    tot = float(c[np.arange(n), rowsol].astype(np.float64).sum())
+    assert abs(tot - g["total"]) <= 1e-5 * max(1.0, abs(tot))
+    rows = np.random.default_rng(1).choice(n, 1024, replace=False)
+    red = c[rows].astype(np.float64) - g["u"][rows].astype(np.float64)[:, None] - g["v"].astype(np.float64)[None, :]
+    assert red.min() > -1e-5 and np.abs(red[np.arange(len(rows)), rowsol[rows]]).max() < 1e-5
+    assert g["info"].aug_dense_scans < 0.05 * g["info"].scans_aug_relax      # the augmentation ran from the row caches
