@@ -83,6 +83,8 @@ def lib():
         L.cyto_ctx_create.argtypes = [i32, i32, i32, i32, vp, vp, i32, i32, ctypes.POINTER(vp)]
         L.cyto_ctx_assign_chunk.argtypes = [vp, vp, i32, vp, i32, vp, vp, dp, ctypes.POINTER(AssignInfo)]
         L.cyto_ctx_destroy.argtypes = [vp]
+        L.cyto_assign_metric_typed.argtypes = [i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, dp, ctypes.POINTER(AssignInfo), i32]
+        L.cyto_ctx_create_typed.argtypes = [i32, i32, i32, i32, vp, vp, i32, i32, i32, ctypes.POINTER(vp)]
         L.cyto_ctx_destroy.restype = None
         L.cyto_assign_pearson.argtypes = [i32, i32, i32, vp, vp, vp, i32, vp, dp, ctypes.POINTER(AssignInfo), i32]
         L.cyto_lap_batch_f32.argtypes = [i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32]

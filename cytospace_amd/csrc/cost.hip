@@ -520,8 +520,8 @@ int cyto_cost_metric(int metric, int Gpad, int S, int C, const float *zst, int64
 // JV solve on the device, mapped_spot[c] = spot of the LAP row given to cell c.
 // sc: G x C, st: G x S (host, row-major, float64 like the reference's arrays).  sum(slots) must be C.
 // The 1e-16 perturbation of cytospace.py:325-327 is not applied: it is a no-op in float32.
-int cyto_assign_metric(int metric, int G, int C, int S, const double *sc, const double *st, const int64_t *slots, int already_normalized,
-                       int64_t *mapped_spot, double *total_cost, cyto_assign_info *info, int device_id) {
+int cyto_assign_metric_typed(int metric, int G, int C, int S, const void *sc, const void *st, int x_is_f64, const int64_t *slots,
+                             int already_normalized, int64_t *mapped_spot, double *total_cost, cyto_assign_info *info, int device_id) {
     if (metric < CYTO_METRIC_PEARSON || metric > CYTO_METRIC_EUCLIDEAN) return CYTO_ERR_BAD_ARG;
     const int transform = metric == CYTO_METRIC_PEARSON ? CYTO_TRANSFORM_STANDARDIZE
                         : metric == CYTO_METRIC_SPEARMAN ? CYTO_TRANSFORM_RANK : CYTO_TRANSFORM_RAW;
@@ -545,8 +545,8 @@ int cyto_assign_metric(int metric, int G, int C, int S, const double *sc, const 
     CYTO_HIP(hipEventCreate(&e0));
     CYTO_HIP(hipEventCreate(&e1));
     CYTO_HIP(hipEventRecord(e0, stream));
-    if ((rc = cyto_transform(transform, G, S, st, S, 1, 0, already_normalized, zst.as<float>(), ldzst, Gpad, device_id, stream))) return rc;
-    if ((rc = cyto_transform(transform, G, C, sc, C, 1, 0, already_normalized, zsc.as<float>(), ldzsc, Gpad, device_id, stream))) return rc;
+    if ((rc = cyto_transform(transform, G, S, st, S, x_is_f64, 0, already_normalized, zst.as<float>(), ldzst, Gpad, device_id, stream))) return rc;
+    if ((rc = cyto_transform(transform, G, C, sc, C, x_is_f64, 0, already_normalized, zsc.as<float>(), ldzsc, Gpad, device_id, stream))) return rc;
     CYTO_HIP(hipEventRecord(e1, stream));
     CYTO_HIP(hipEventSynchronize(e1));
     float ms_std = 0;
@@ -588,8 +588,8 @@ struct cyto_expr_ctx {
     DevBuf zsc, zst;
 };
 
-int cyto_ctx_create(int metric, int G, int C, int S, const double *sc, const double *st, int already_normalized, int device_id,
-                    cyto_expr_ctx **out) {
+int cyto_ctx_create_typed(int metric, int G, int C, int S, const void *sc, const void *st, int x_is_f64, int already_normalized,
+                          int device_id, cyto_expr_ctx **out) {
     if (!out || G <= 0 || C <= 0 || S <= 0 || !sc || !st) return CYTO_ERR_BAD_ARG;
     if (metric < CYTO_METRIC_PEARSON || metric > CYTO_METRIC_EUCLIDEAN) return CYTO_ERR_BAD_ARG;
     int rc = select_device(device_id);
@@ -601,8 +601,8 @@ int cyto_ctx_create(int metric, int G, int C, int S, const double *sc, const dou
     const int transform = metric == CYTO_METRIC_PEARSON ? CYTO_TRANSFORM_STANDARDIZE
                         : metric == CYTO_METRIC_SPEARMAN ? CYTO_TRANSFORM_RANK : CYTO_TRANSFORM_RAW;
     if ((rc = ctx->zsc.alloc((size_t)ctx->Gpad * ctx->ldsc * 4)) || (rc = ctx->zst.alloc((size_t)ctx->Gpad * ctx->ldst * 4)) ||
-        (rc = cyto_transform(transform, G, S, st, S, 1, 0, already_normalized, ctx->zst.as<float>(), ctx->ldst, ctx->Gpad, device_id, nullptr)) ||
-        (rc = cyto_transform(transform, G, C, sc, C, 1, 0, already_normalized, ctx->zsc.as<float>(), ctx->ldsc, ctx->Gpad, device_id, nullptr))) {
+        (rc = cyto_transform(transform, G, S, st, S, x_is_f64, 0, already_normalized, ctx->zst.as<float>(), ctx->ldst, ctx->Gpad, device_id, nullptr)) ||
+        (rc = cyto_transform(transform, G, C, sc, C, x_is_f64, 0, already_normalized, ctx->zsc.as<float>(), ctx->ldsc, ctx->Gpad, device_id, nullptr))) {
         delete ctx;
         return rc;
     }
@@ -700,6 +700,16 @@ int cyto_ctx_assign_chunk(cyto_expr_ctx *ctx, const int64_t *idx_sc, int n_sc, c
 int cyto_assign_pearson(int G, int C, int S, const double *sc, const double *st, const int64_t *slots, int already_normalized,
                         int64_t *mapped_spot, double *total_cost, cyto_assign_info *info, int device_id) {
     return cyto_assign_metric(CYTO_METRIC_PEARSON, G, C, S, sc, st, slots, already_normalized, mapped_spot, total_cost, info, device_id);
+}
+
+int cyto_assign_metric(int metric, int G, int C, int S, const double *sc, const double *st, const int64_t *slots, int already_normalized,
+                       int64_t *mapped_spot, double *total_cost, cyto_assign_info *info, int device_id) {
+    return cyto_assign_metric_typed(metric, G, C, S, sc, st, 1, slots, already_normalized, mapped_spot, total_cost, info, device_id);
+}
+
+int cyto_ctx_create(int metric, int G, int C, int S, const double *sc, const double *st, int already_normalized, int device_id,
+                    cyto_expr_ctx **out) {
+    return cyto_ctx_create_typed(metric, G, C, S, sc, st, 1, already_normalized, device_id, out);
 }
 
 }  // extern "C"

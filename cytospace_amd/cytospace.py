@@ -35,19 +35,27 @@ def partition_indices(indices, split_by_category_list=None, split_by_interval_in
     return np.array_split(indices, sorted(cuts)[1:-1])
 
 
+def _pair(sc, st):
+    """Both matrices C-contiguous and of ONE dtype: float32 if both are float32 already (half the upload), else float64
+    (the dtype of the reference's arrays)."""
+    sc = np.asarray(sc)
+    st = np.asarray(st)
+    if sc.ndim != 2 or st.ndim != 2:
+        raise ValueError("sc and st must be 2-D genes x columns matrices")
+    if sc.shape[0] != st.shape[0]:
+        raise ValueError("The two matrices v1 and v2 must have equal dimensions; "
+                         "ST and scRNA data must have the same genes")
+    dt = np.float32 if (sc.dtype == np.float32 and st.dtype == np.float32) else np.float64
+    return np.ascontiguousarray(sc, dtype=dt), np.ascontiguousarray(st, dtype=dt), int(dt == np.float64)
+
+
 def assign_pearson(sc, st, slots, already_normalized=True, device_id=0, return_info=False,
                    distance_metric="Pearson_correlation"):
     """Fused chunk solve on one GPU: returns mapped_st_index (np.int64[C]) [, total, info]."""
     from .common import METRICS
     if distance_metric not in METRICS:
         raise ValueError(f"unknown distance_metric {distance_metric!r}")
-    sc = np.ascontiguousarray(sc, dtype=np.float64)
-    st = np.ascontiguousarray(st, dtype=np.float64)
-    if sc.ndim != 2 or st.ndim != 2:
-        raise ValueError("sc and st must be 2-D genes x columns matrices")
-    if sc.shape[0] != st.shape[0]:
-        raise ValueError("The two matrices v1 and v2 must have equal dimensions; "
-                         "ST and scRNA data must have the same genes")
+    sc, st, is64 = _pair(sc, st)
     slots = np.ascontiguousarray(slots, dtype=np.int64)
     G, C = sc.shape
     S = st.shape[1]
@@ -56,9 +64,9 @@ def assign_pearson(sc, st, slots, already_normalized=True, device_id=0, return_i
     mapped = np.empty(C, np.int64)
     total = ctypes.c_double()
     info = _lib.AssignInfo()
-    _lib.check(_lib.lib().cyto_assign_metric(METRICS[distance_metric], G, C, S, sc.ctypes.data, st.ctypes.data,
-                                             slots.ctypes.data, int(already_normalized), mapped.ctypes.data,
-                                             ctypes.byref(total), ctypes.byref(info), device_id))
+    _lib.check(_lib.lib().cyto_assign_metric_typed(METRICS[distance_metric], G, C, S, sc.ctypes.data, st.ctypes.data, is64,
+                                                   slots.ctypes.data, int(already_normalized), mapped.ctypes.data,
+                                                   ctypes.byref(total), ctypes.byref(info), device_id))
     if return_info:
         return mapped, total.value, info
     return mapped
@@ -72,18 +80,13 @@ class ExpressionContext:
         from .common import METRICS
         if distance_metric not in METRICS:
             raise ValueError(f"unknown distance_metric {distance_metric!r}")
-        sc = np.ascontiguousarray(sc, dtype=np.float64)
-        st = np.ascontiguousarray(st, dtype=np.float64)
-        if sc.ndim != 2 or st.ndim != 2:
-            raise ValueError("sc and st must be 2-D genes x columns matrices")
-        if sc.shape[0] != st.shape[0]:
-            raise ValueError("The two matrices v1 and v2 must have equal dimensions; "
-                             "ST and scRNA data must have the same genes")
+        sc, st, is64 = _pair(sc, st)
         self.G, self.C = sc.shape
         self.S = st.shape[1]
         self._h = ctypes.c_void_p()
-        _lib.check(_lib.lib().cyto_ctx_create(METRICS[distance_metric], self.G, self.C, self.S, sc.ctypes.data, st.ctypes.data,
-                                              int(already_normalized), device_id, ctypes.byref(self._h)))
+        _lib.check(_lib.lib().cyto_ctx_create_typed(METRICS[distance_metric], self.G, self.C, self.S, sc.ctypes.data,
+                                                    st.ctypes.data, is64, int(already_normalized), device_id,
+                                                    ctypes.byref(self._h)))
 
     def assign_chunk(self, index_sc, slots, index_st=None, return_info=False):
         """Cells index_sc against spots index_st (None: all spots) with slots[k] cells for the k-th listed spot.

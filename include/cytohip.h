@@ -174,6 +174,14 @@ int cyto_ctx_assign_chunk(cyto_expr_ctx *ctx, const int64_t *idx_sc, int n_sc, c
                           const int64_t *slots, int64_t *mapped_spot, double *total_cost, cyto_assign_info *info);
 void cyto_ctx_destroy(cyto_expr_ctx *ctx);
 
+/* The same two entry points for float32 host matrices (x_is_f64 = 0): half the host-to-device traffic, identical
+ * results for data that is exactly representable in float32 (raw counts); the reference's own arrays are float64. */
+int cyto_assign_metric_typed(int metric, int G, int C, int S, const void *sc, const void *st, int x_is_f64,
+                             const int64_t *slots, int already_normalized, int64_t *mapped_spot, double *total_cost,
+                             cyto_assign_info *info, int device_id);
+int cyto_ctx_create_typed(int metric, int G, int C, int S, const void *sc, const void *st, int x_is_f64,
+                          int already_normalized, int device_id, cyto_expr_ctx **out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -263,3 +263,22 @@ def test_gv7_cells_per_spot_estimate():
     st_df = pd.DataFrame(st, index=[f"g{i}" for i in range(st.shape[0])], columns=[f"s{i}" for i in range(st.shape[1])])
     for mean in (5, 20):
         assert np.array_equal(gcyto.estimate_cell_number_RNA_reads(st_df, mean), d[f"cells_per_spot_mean{mean}"])
+
+
+def test_float32_inputs_give_the_float64_results():
+    # raw counts are exact in float32: uploading them as float32 (half the traffic) must not change anything
+    rng = np.random.default_rng(23)
+    G, S, k = 150, 20, 3
+    sc = rng.poisson(2.0, (G, S * k)).astype(np.float64)
+    st = rng.poisson(7.0, (G, S)).astype(np.float64)
+    slots = np.full(S, k)
+    for metric in ("Pearson_correlation", "Spearman_correlation", "Euclidean"):
+        m64, t64, _ = gcyto.assign_pearson(sc, st, slots, already_normalized=False, return_info=True, distance_metric=metric)
+        m32, t32, _ = gcyto.assign_pearson(sc.astype(np.float32), st.astype(np.float32), slots, already_normalized=False,
+                                           return_info=True, distance_metric=metric)
+        assert np.array_equal(m64, m32) and t64 == t32
+    with gcyto.ExpressionContext(sc.astype(np.float32), st.astype(np.float32), already_normalized=False) as c32, \
+         gcyto.ExpressionContext(sc, st, already_normalized=False) as c64:
+        idx = np.arange(0, 30)
+        sl = np.array([3] * 10 + [0] * 10)
+        assert np.array_equal(c32.assign_chunk(idx, sl), c64.assign_chunk(idx, sl))
