@@ -1468,9 +1468,8 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
     const int64_t ld = a.ld;
     const float *__restrict__ cost = a.cost;
     float *gv = a.fws;
-    float *sumvd = a.fws + 2 * (int64_t)n;
     int32_t *rowsol = a.iws, *gcolsol = a.iws + n, *matches = a.iws + 2 * (int64_t)n;
-    int32_t *freerows = a.iws + 3 * (int64_t)n, *rtrows = a.iws + 4 * (int64_t)n, *pred = a.iws + 5 * (int64_t)n;
+    int32_t *freerows = a.iws + 3 * (int64_t)n, *rtrows = a.iws + 4 * (int64_t)n;
     const int npad = (n + 3) & ~3;
     float *s_v = reinterpret_cast<float *>(dyn_lds);
     uint16_t *s_cs = reinterpret_cast<uint16_t *>(dyn_lds + (LDS_STATE ? (size_t)npad * 4 : 0));
@@ -1508,7 +1507,6 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
     float delta = 0.0f;
     int c_rt = 0, c_arr = 0, c_dense = 0;
     int c_free_cr = numfree, c_free_a1 = 0, c_free_a2 = 0;
-    int err = 0;
 
     const int arr_budget = 1000 * n + 1000000;   // == JV_ARR_BUDGET(n) of the oracle (fits: n <= FAST_NMAX)
     // chain state (meaningful in wave 0 only; uniform there)
