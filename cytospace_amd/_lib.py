@@ -74,6 +74,8 @@ def lib():
             getattr(L, name).argtypes = [i32, vp, i64, i32, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(LapInfo), i32, vp]
         dp = ctypes.POINTER(ctypes.c_double)
+        L.cyto_lap_f32_from_f64.argtypes = [i32, vp, i64, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_double),
+                                            ctypes.POINTER(LapInfo), i32, vp]
         L.cyto_normalize_data.argtypes = [i32, i32, vp, i64, i32, vp, i64, i32]
         L.cyto_standardize.argtypes = [i32, i32, vp, i64, i32, i32, i32, vp, i64, i32, i32, vp]
         L.cyto_cost_pearson.argtypes = [i32, i32, i32, vp, i64, vp, i64, vp, vp, i64, dp, i32, vp]

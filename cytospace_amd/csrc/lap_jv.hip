@@ -3441,9 +3441,38 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
     return h_status ? CYTO_ERR_INTERNAL : CYTO_OK;
 }
 
+// float64 -> float32 of a row-major matrix (the cast numpy's astype(float32) performs: round to nearest even)
+__global__ __launch_bounds__(256) void narrow_f64_to_f32(int n, int64_t lds_, const double *__restrict__ src, int64_t ldd,
+                                                         float *__restrict__ dst) {
+    const int64_t row = blockIdx.y;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) dst[row * ldd + c] = (float)src[row * lds_ + c];
+}
+
 }  // namespace cyto
 
 extern "C" {
+
+// The call the reference makes, `lapjv(cost_scaled)` with a float64 numpy array solved in float32
+// (linear_assignment_solvers.py:38): the matrix goes to the device as it is and is narrowed there, instead of a
+// float64 -> float32 pass over 8 n^2 bytes on the host first.
+int cyto_lap_f32_from_f64(int n, const double *cost_host, int64_t ld, int32_t *rowsol, int32_t *colsol, float *u, float *v,
+                          double *total, cyto_lap_info *info, int device_id, void *stream_) {
+    if (n <= 0 || !cost_host || ld < n) return CYTO_ERR_BAD_ARG;
+    int rc = cyto::select_device(device_id);
+    if (rc) return rc;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const int64_t ldd = ((int64_t)n + 3) & ~(int64_t)3;
+    cyto::DevBuf d64, d32;
+    if ((rc = d64.alloc((size_t)n * n * sizeof(double))) || (rc = d32.alloc((size_t)n * ldd * sizeof(float)))) return rc;
+    CYTO_HIP(hipMemcpy2DAsync(d64.p, (size_t)n * sizeof(double), cost_host, (size_t)ld * sizeof(double), (size_t)n * sizeof(double), n,
+                              hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(cyto::narrow_f64_to_f32, dim3((n + 255) / 256 > 64 ? 64 : (n + 255) / 256, n), dim3(256), 0, stream, n, (int64_t)n,
+                       d64.as<double>(), ldd, d32.as<float>());
+    CYTO_HIP(hipGetLastError());
+    CYTO_HIP(hipStreamSynchronize(stream));
+    (void)hipFree(d64.p); d64.p = nullptr;                  // the float64 copy is not needed during the solve
+    return cyto::lap_solve<float>(n, d32.as<float>(), ldd, 1, rowsol, colsol, u, v, total, info, device_id, stream_);
+}
 
 int cyto_lap_f32(int n, const float *cost, int64_t ld, int cost_on_device, int32_t *rowsol, int32_t *colsol,
                  float *u, float *v, double *total, cyto_lap_info *info, int device_id, void *stream) {

@@ -25,8 +25,13 @@ def lap_solve(cost, dtype=np.float32, device_id=0, return_info=False, device_ptr
     L = _lib.lib()
     if dtype not in (np.float32, np.float64):
         raise TypeError("dtype must be numpy.float32 or numpy.float64")
+    narrow_on_device = False
     if device_ptr is None:
-        c = np.ascontiguousarray(cost, dtype=dtype)
+        c = np.asarray(cost)
+        # the reference hands lapjv a float64 array that is solved in float32: narrow it on the device
+        narrow_on_device = dtype == np.float32 and c.dtype == np.float64 and c.ndim == 2 and c.flags.c_contiguous
+        if not narrow_on_device:
+            c = np.ascontiguousarray(c, dtype=dtype)
         if c.ndim != 2 or c.shape[0] != c.shape[1]:
             raise ValueError("cost must be a square 2-D matrix")
         n = c.shape[0]
@@ -45,9 +50,13 @@ def lap_solve(cost, dtype=np.float32, device_id=0, return_info=False, device_ptr
     v = np.empty(n, dtype)
     total = ctypes.c_double()
     info = _lib.LapInfo()
-    fn = L.cyto_lap_f32 if dtype == np.float32 else L.cyto_lap_f64
-    st = fn(n, ptr, ld, on_device, rowsol.ctypes.data, colsol.ctypes.data, u.ctypes.data, v.ctypes.data,
-            ctypes.byref(total), ctypes.byref(info), device_id, None)
+    if narrow_on_device:
+        st = L.cyto_lap_f32_from_f64(n, ptr, ld, rowsol.ctypes.data, colsol.ctypes.data, u.ctypes.data, v.ctypes.data,
+                                     ctypes.byref(total), ctypes.byref(info), device_id, None)
+    else:
+        fn = L.cyto_lap_f32 if dtype == np.float32 else L.cyto_lap_f64
+        st = fn(n, ptr, ld, on_device, rowsol.ctypes.data, colsol.ctypes.data, u.ctypes.data, v.ctypes.data,
+                ctypes.byref(total), ctypes.byref(info), device_id, None)
     _lib.check(st)
     out = dict(rowsol=rowsol, colsol=colsol, u=u, v=v, total=total.value)
     if return_info:

@@ -85,6 +85,11 @@ int cyto_lap_f64(int n, const double *cost, int64_t ld, int cost_on_device,
                  int32_t *rowsol, int32_t *colsol, double *u, double *v, double *total,
                  cyto_lap_info *info, int device_id, void *stream);
 
+/* `lapjv(cost_scaled)` as the reference calls it (linear_assignment_solvers.py:38): a float64 HOST matrix solved in
+ * float32.  The matrix is uploaded as it is and narrowed on the device (same rounding as numpy's astype(float32)). */
+int cyto_lap_f32_from_f64(int n, const double *cost_host, int64_t ld, int32_t *rowsol, int32_t *colsol,
+                          float *u, float *v, double *total, cyto_lap_info *info, int device_id, void *stream);
+
 /* ---- A8 (one GPU): nb independent LAPs solved concurrently.  Replaces the per-chunk worker processes of
  * apply_linear_assignment (cytospace/cytospace.py:430-451) for the solver-only seam: the sequential
  * chain of one solve occupies one workgroup, so chunks run side by side (one HIP stream each).

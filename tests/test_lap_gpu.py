@@ -274,3 +274,18 @@ def test_full_size_properties_bench_config():
     red = c[rows].astype(np.float64) - g["u"][rows].astype(np.float64)[:, None] - g["v"].astype(np.float64)[None, :]
     assert red.min() > -1e-5 and np.abs(red[np.arange(len(rows)), rowsol[rows]]).max() < 1e-5
     assert g["info"].aug_dense_scans < 0.05 * g["info"].scans_aug_relax      # the augmentation ran from the row caches
+
+
+def test_float64_host_matrix_is_narrowed_on_the_device():
+    # the reference calls lapjv(cost_scaled) with a float64 array that is solved in float32: same answer as casting first
+    from cytospace_amd.lap import lapjv_hip
+    for n in (1, 7, 130, 2500):
+        c64 = np.random.default_rng(n).random((n, n)) * 3.0 - 1.0
+        row, col, (tot, u, v) = lapjv_hip(c64)
+        ref = lap_solve(c64.astype(np.float32), np.float32)
+        assert np.array_equal(row, ref["rowsol"]) and np.array_equal(col, ref["colsol"])
+        assert np.array_equal(u, ref["u"]) and np.array_equal(v, ref["v"]) and tot == ref["total"]
+    with pytest.raises(ValueError):
+        lapjv_hip(np.array([[1.0, np.nan], [0.0, 1.0]]))
+    with pytest.raises(ValueError):
+        lapjv_hip(np.array([[1e300, 0.0], [0.0, 1.0]]))        # overflows to inf in float32, like astype(float32)
