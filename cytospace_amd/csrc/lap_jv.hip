@@ -1020,6 +1020,32 @@ __device__ __forceinline__ float fmin_raw(float a, float b) {
     return r;
 }
 
+// The <= 63 entries of a rebuilt cache row are sorted by column (wave 0, bitonic network on 64 lanes; slot 63 keeps the
+// floor): lane order is then column order, so "lowest column among equal reduced costs" -- the oracle's tie-break, and
+// on CytoSPACE's duplicated spot rows ties at a reduced cost of exactly 0 are the rule -- is the lowest lane of a ballot
+// instead of one more wave reduction per tie.
+__device__ __forceinline__ void sort_cache_row(uint32_t *__restrict__ ccol, float *__restrict__ cval, float tau) {
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    uint32_t key = lane < KCU ? ccol[lane] : COLSENT;
+    float val = lane < KCU ? cval[lane] : 0.0f;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t pk = __shfl_xor(key, j);
+            const float pv = __shfl_xor(val, j);
+            const bool take_min = ((lane & j) == 0) == ((lane & k) == 0);
+            const bool sw = take_min ? (pk < key) : (pk > key);
+            key = sw ? pk : key; val = sw ? pv : val;
+        }
+    }
+    // unused slots and the floor slot all carry COLSENT and end up last, in no particular order: restore their values
+    if (key == COLSENT) val = 0.0f;
+    if (lane == KCU) { key = COLSENT; val = tau; }
+    ccol[lane] = key; cval[lane] = val;
+}
+
 // Full scan of row i by the whole workgroup: exact two smallest keys of (c[i][j]-v[j], j) over all
 // columns, plus a rebuilt cache for the row.  vreg = current prices of this thread's columns.
 // delta adapts the cache threshold tau = umin + delta so that KCU/2..KCU columns qualify.
@@ -1101,6 +1127,7 @@ __device__ __forceinline__ K2 refresh_row(int i, int n, int64_t ld, const float 
     if (tid == KCU) { ccol[KCU] = COLSENT; cval[KCU] = tau; }
 #undef HVAL
     __syncthreads();  // the rebuilt cache is complete before anyone may read it
+    sort_cache_row(ccol, cval, tau);
     return g;
 }
 
@@ -1199,6 +1226,7 @@ __device__ __forceinline__ K2 refresh_row_stream(int i, int n, int64_t ld, const
     if (tid >= cnt && tid < KCU) { ccol[tid] = COLSENT; cval[tid] = 0.0f; }
     if (tid == KCU) { ccol[KCU] = COLSENT; cval[KCU] = tau; }
     __syncthreads();
+    sort_cache_row(ccol, cval, tau);
     return g;
 }
 
@@ -1621,11 +1649,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
                         // minimum, its lane (ties: lowest column), then the minimum of the rest
                         const uint32_t o1 = wave_min_u32(ord);
                         const uint64_t m1 = __ballot(ord == o1);
-                        int l1 = __builtin_ctzll(m1);
-                        if (__builtin_expect((m1 & (m1 - 1)) != 0, 0)) {
-                            const uint32_t cmin = wave_min_u32(ord == o1 ? col : 0xFFFFFFFFu);
-                            l1 = __builtin_ctzll(__ballot(col == cmin));
-                        }
+                        const int l1 = __builtin_ctzll(m1);     // cache rows are sorted by column: lowest lane = lowest column
                         // the current owner of the best column is (almost always) the next row of the chain
                         pf_row = (int)readlane32((uint32_t)csj, l1);
                         if (pf_row >= 0) {
@@ -1647,11 +1671,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
                         i0 = (int)readlane32((uint32_t)csj, l1);
                         if (__builtin_expect(!((vj1 - (usub - umin)) < vj1) && i0 >= 0, 0)) {
                             const uint64_t m2 = __ballot(ord == o2 && lane != l1);
-                            int l2 = __builtin_ctzll(m2);
-                            if (m2 & (m2 - 1)) {
-                                const uint32_t cmin2 = wave_min_u32((ord == o2 && lane != l1) ? col : 0xFFFFFFFFu);
-                                l2 = __builtin_ctzll(__ballot(col == cmin2));
-                            }
+                            const int l2 = __builtin_ctzll(m2);
                             j2 = (int)readlane32(col, l2);
                             cj2 = __uint_as_float(readlane32(__float_as_uint(cv), l2));
                             i02 = (int)readlane32((uint32_t)csj, l2);
@@ -2594,11 +2614,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                         // column (the oracle's first pick ends the search at once: no scan, no price update);
                         // nothing of the pick structure is touched ----
                         const uint64_t me = __ballot(un && odd == t0);
-                        int le = __builtin_ctzll(me);
-                        if (me & (me - 1)) {    // several unassigned columns tie: the lowest column (reduction outside any divergent branch)
-                            const uint32_t cmin = wave_min_u32((un && odd == t0) ? cc : 0xFFFFFFFFu);
-                            le = __builtin_ctzll(__ballot(un && odd == t0 && cc == cmin));
-                        }
+                        const int le = __builtin_ctzll(me);   // (cache rows are sorted by column: lowest lane = lowest column)
                         const int ep = (int)readlane32(cc, le);
                         const float cie = __uint_as_float(readlane32(__float_as_uint(cv), le));
                         if (lane == 0) {
