@@ -2592,11 +2592,6 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                     const float cv = ncv;
                     const int id1 = __builtin_amdgcn_readfirstlane(id_next);
                     id1_saved = id1;
-                    if (id1 >= 0) {
-                        ncc = ld_u32(a.cache_col + (int64_t)id1 * KC + lane);
-                        ncv = ld_f32(a.cache_val + (int64_t)id1 * KC + lane);
-                    }
-                    id_next = f + 2 < numfree ? ld_i32(a.freerows + f + 2) : -1;
                     stamp = f + 1;
                     have = false; curmin = 0.0f; level = 0; nscan = 0; ntouch = 0; dense_used = false; insearch = true;
                     // ---- certified sparse init: if the free row's cache floor is above the distance of an
@@ -2607,6 +2602,13 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
                     const bool un = valid && ((s_un[j >> 5] >> (j & 31)) & 1u);
                     const uint32_t odd = valid ? f2ord(dd) : 0xFFFFFFFFu;
                     const uint32_t t0 = wave_min_u32(un ? odd : 0xFFFFFFFFu);
+                    // only now the requests for the next search (loads return in issue order: issued before the price gather
+                    // above, these cache-row loads from HBM would have held it back)
+                    if (id1 >= 0) {
+                        ncc = ld_u32(a.cache_col + (int64_t)id1 * KC + lane);
+                        ncv = ld_f32(a.cache_val + (int64_t)id1 * KC + lane);
+                    }
+                    id_next = f + 2 < numfree ? ld_i32(a.freerows + f + 2) : -1;
                     const float floor_f = __uint_as_float(readlane32(__float_as_uint(cv), KCU));
                     const bool cert0 = !no_cert && nexc == 0 && t0 != 0xFFFFFFFFu && floor_f > ord2f(t0);
                     if (cert0 && wave_min_u32(odd) == t0) {
