@@ -10,6 +10,14 @@ the augmentation kernel).  With N GPUs every rank solves its own, differently se
 reference shards independent sub-LAPs across workers: cytospace.py:430-451; no data-path collective),
 so scaling is "weak" and value = N * n / max-over-ranks time.
 
+Besides the headline (`value`, on configs[1]) the same JSON line carries, at N = 1, the other single-GPU
+workloads the north star names (skip them with --no-extras):
+  "n50000"    the 50 000 x 50 000 uniform LAP (ms, assignments/s, colsol compared with the committed oracle golden)
+  "c3"        configs[2] end to end: 20 000 genes x 50 000 cells x 5 000 spots, normalise + standardise, fp32-MFMA cost
+              GEMM (its own "roofline" against the 157.3 TFLOP/s f32 matrix peak), LAP; wall time includes the H2D copies
+  "c4_chunks" K concurrent 10 000-cell --sampling-sub-spots chunk LAPs (configs[3]'s unit of work) on one GPU, with the
+              CPU oracle run on all host cores beside it (core count stated)
+
 torch is used only for the rendezvous (barrier + max over ranks); the product never imports it.
 """
 import argparse
@@ -24,6 +32,155 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3   # same guide: dense fp32 matrix (v_mfma_f32_32x32x2_f32) peak
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def extra_n50000(dev):
+    """The north star's 50 000 x 50 000 LAP, resident in HBM; the answer is compared with the oracle's (golden file)."""
+    from cytospace_amd.lap import lap_solve
+    from tools import instances
+    n = 50000
+    t = time.perf_counter()
+    buf = instances.blocks_to_device(instances.uniform_cost_blocks(n), n, dev)
+    t_gen = time.perf_counter() - t
+    lap_solve(None, np.float32, device_id=dev, device_ptr=buf.ptr, n=n, ld=n)          # warm-up
+    t = time.perf_counter()
+    r = lap_solve(None, np.float32, device_id=dev, return_info=True, device_ptr=buf.ptr, n=n, ld=n)
+    wall = time.perf_counter() - t
+    buf.free()
+    i = r["info"]
+    out = {"n": n, "ms_per_solve": round(wall * 1e3, 1), "assignments_per_s": round(n / wall, 1),
+           "kernel_ms": {"colred": round(i.ms_colred, 2), "row_caches": round(i.ms_cache, 2), "jv_chain2": round(i.ms_arr, 1),
+                         "jv_aug_lazy": round(i.ms_aug, 1)},
+           "row_scans": int(i.row_scans), "algorithmic_GBs": round(4.0 * n * i.row_scans / wall / 1e9, 1),
+           "hbm_frac_algorithmic": round(4.0 * n * i.row_scans / wall / 1e9 / HBM_PEAK_GBS, 5),
+           "instance_seconds": round(t_gen, 1)}
+    gpath = os.path.join(ROOT, "tests", "golden", "large_u50000.npz")
+    if os.path.exists(gpath):
+        d = np.load(gpath)
+        ok = bool(np.array_equal(r["colsol"], d["colsol"]) and _sha(r["u"]) == str(d["u_sha256"]) and _sha(r["v"]) == str(d["v_sha256"]))
+        out["bit_exact_vs_oracle_golden"] = ok
+        if not ok:
+            raise SystemExit("n50000: HIP result differs from tests/golden/large_u50000.npz")
+    else:
+        out["bit_exact_vs_oracle_golden"] = None
+    return out
+
+
+def extra_c3(dev):
+    """BASELINE configs[2]: 50k cells x 5k spots x 20k genes, fused on one GPU (raw float32 counts in, spots out)."""
+    from cytospace_amd.cytospace import assign_pearson
+    from tools import instances
+    G, C, S = 20000, 50000, 5000
+    t = time.perf_counter()
+    sc, st, slots = instances.synth_expression(G, C, S, seed=1)
+    t_gen = time.perf_counter() - t
+    assign_pearson(sc, st, slots, already_normalized=False, device_id=dev)                # warm-up
+    t = time.perf_counter()
+    mapped, total, info = assign_pearson(sc, st, slots, already_normalized=False, device_id=dev, return_info=True)
+    wall = time.perf_counter() - t
+    ok = bool(np.array_equal(np.bincount(mapped, minlength=S), slots))
+    if not ok:
+        raise SystemExit("c3: bincount(mapped) != slots")
+    tf = info.gemm_flops / (info.ms_gemm * 1e-3) / 1e12
+    kern = info.ms_standardize + info.ms_gemm + info.lap.ms_total
+    return {"workload": f"{G} genes x {C} cells x {S} spots (10 slots each), float32 counts -> spots",
+            "wall_ms_incl_h2d": round(wall * 1e3, 1), "assignments_per_s_wall": round(C / wall, 1),
+            "kernel_ms": {"standardize_incl_h2d": round(info.ms_standardize, 1), "pearson_gemm": round(info.ms_gemm, 2),
+                          "lap": round(info.lap.ms_total, 1), "sum": round(kern, 1)},
+            "assignments_per_s_kernels": round(C / (kern * 1e-3), 1),
+            "roofline": {"bound": "mfma", "kernel": "pearson_gemm", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF,
+                         "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "flops_per_launch": info.gemm_flops},
+            "lap_row_scans": int(info.lap.row_scans), "bincount_equals_slots": ok, "instance_seconds": round(t_gen, 1)}
+
+
+def _usable_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def extra_c4_chunks(dev, K, distinct=4, cpu_n=5000, cpu_threads=64):
+    """K concurrent sub-spot chunk LAPs (10 000 cells each) on one GPU; beside it the CPU oracle on the host's cores
+    (BASELINE.md section 3 item 2), on a BOUNDED sample: chunks of cpu_n cells (a 10 000-cell chunk takes the oracle
+    minutes when every core runs one; assignments/s falls with n, so the smaller sample flatters the CPU)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from cytospace_amd import _lib
+    from cytospace_amd.lap import lap_solve_batch_device
+    from oracle.jv import jv_oracle
+    from tools import instances
+    n = 10000
+    t = time.perf_counter()
+    costs = [instances.c4_chunk_cost(n, seed=4 + k)[0] for k in range(distinct)]
+    small = [instances.c4_chunk_cost(cpu_n, seed=40 + k)[0] for k in range(distinct)]
+    t_gen = time.perf_counter() - t
+    bufs = [_lib.DeviceBuffer.from_numpy(costs[k % distinct], dev) for k in range(K)]
+    lap_solve_batch_device([b.ptr for b in bufs[:1]], [n], device_id=dev, max_concurrent=1)     # warm-up (block cache, code objects)
+    t = time.perf_counter()
+    one = lap_solve_batch_device([bufs[0].ptr], [n], device_id=dev, max_concurrent=1, return_info=True)[0]
+    wall1 = time.perf_counter() - t
+    t = time.perf_counter()
+    res = lap_solve_batch_device([b.ptr for b in bufs], [n] * K, device_id=dev, max_concurrent=K, return_info=True)
+    wall = time.perf_counter() - t
+    for b in bufs:
+        b.free()
+    exact = None
+    gpath = os.path.join(ROOT, "tests", "golden", "large_c4s10000.npz")
+    if os.path.exists(gpath):            # instance 0 (seed 4) is the golden instance: every copy of it must match the oracle's answer
+        d = np.load(gpath)
+        exact = all(np.array_equal(res[k]["colsol"], d["colsol"]) and _sha(res[k]["v"]) == str(d["v_sha256"])
+                    for k in range(0, K, distinct))
+        if not exact:
+            raise SystemExit("c4_chunks: HIP result differs from tests/golden/large_c4s10000.npz")
+    same = all(np.array_equal(res[k]["colsol"], res[k % distinct]["colsol"]) for k in range(K))
+    if not same:
+        raise SystemExit("c4_chunks: copies of one instance solved concurrently gave different answers")
+    # ---- CPU: the oracle, one thread alone, then T threads at once (ctypes releases the GIL), one chunk each ----
+    cores = _usable_cores()
+    T = max(1, min(cores, cpu_threads))
+    t = time.perf_counter()
+    o1 = jv_oracle(small[0], np.float32)
+    cpu1 = time.perf_counter() - t
+    t = time.perf_counter()
+    with ThreadPoolExecutor(T) as ex:
+        ora = list(ex.map(lambda k: jv_oracle(small[k % distinct], np.float32), range(T)))
+    cpu_wall = time.perf_counter() - t
+    bs = [_lib.DeviceBuffer.from_numpy(small[k], dev) for k in range(distinct)]
+    rs = lap_solve_batch_device([b.ptr for b in bs], [cpu_n] * distinct, device_id=dev, max_concurrent=distinct, return_info=True)
+    for b in bs:
+        b.free()
+    small_exact = all(np.array_equal(rs[k]["colsol"], ora[k]["colsol"]) and np.array_equal(rs[k]["v"], ora[k]["v"])
+                      for k in range(min(distinct, T)))
+    if not small_exact or not np.array_equal(o1["colsol"], ora[0]["colsol"]):
+        raise SystemExit("c4_chunks: HIP result differs from the CPU oracle on the CPU sample")
+    i0 = one["info"]
+    return {"workload": f"{K} concurrent {n} x {n} sub-spot chunk LAPs ({distinct} distinct seeded instances), cost resident in HBM",
+            "chunks": K, "wall_s": round(wall, 2), "assignments_per_s": round(K * n / wall, 1),
+            "one_chunk_alone": {"wall_s": round(wall1, 2), "assignments_per_s": round(n / wall1, 1), "kernel_ms": round(i0.ms_total, 1),
+                                "jv_chain2_ms": round(i0.ms_arr, 1), "augmentation_ms": round(i0.ms_aug, 1),
+                                "row_scans": int(i0.row_scans), "aug_scans": int(i0.scans_aug_relax),
+                                "aug_full_row_scans": int(i0.aug_dense_scans), "handover_at_search": int(i0.aug_handover),
+                                "us_per_aug_scan": round(i0.ms_aug * 1e3 / max(1, i0.scans_aug_relax), 3)},
+            "bit_exact_vs_oracle_golden": exact, "copies_identical": same,
+            "cpu_baseline": {"value": round(T * cpu_n / cpu_wall, 1), "unit": "assignments/s", "cores": T, "kind": "port",
+                             "usable_cores": cores, "host_cores": os.cpu_count(),
+                             "one_thread_alone": round(cpu_n / cpu1, 1),
+                             "sample": f"oracle/jv_oracle.c on sub-spot chunks of {cpu_n} cells (same generator): one thread alone {cpu1:.1f} s; "
+                                       f"{T} threads at once, one chunk each, {cpu_wall:.1f} s; the HIP path solves the same {distinct} "
+                                       f"instances bit-identically ({rs[0]['info'].ms_total:.0f} ms of kernels each)",
+                             "cpu_model": _cpu_model()},
+            "instance_seconds": round(t_gen, 1)}
 
 
 def make_cost(n, seed):
@@ -41,6 +198,9 @@ def main():
                     help="size of the bounded CPU-baseline sample (0: min(n, 20000); when it equals n the very same "
                          "instance is used and the GPU result is compared bit for bit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no n50000 / c3 / c4_chunks)")
+    ap.add_argument("--c4-chunks", type=int, default=32, help="concurrent chunk LAPs in the c4_chunks leg")
+    ap.add_argument("--pmc-tag", default="r02", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -138,8 +298,12 @@ def main():
     dom_bytes = 4.0 * n * dom[1]
     achieved = dom_bytes / (dom[2] * 1e-3) / 1e9
     traffic = None
+    traffic_source = None
     try:   # HBM bytes from the separate rocprofv3 --pmc pass committed under profiles/ (same n, same instance)
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_traffic_n20000.json")))
+        traffic_source = f"profiles/{args.pmc_tag}_pmc_traffic_n{n}.json"
+        if not os.path.exists(os.path.join(ROOT, traffic_source)):
+            traffic_source = f"profiles/r01e_pmc_traffic_n{n}.json"
+        pm = json.load(open(os.path.join(ROOT, traffic_source)))
         if pm.get("n") == n:
             key = [k for k in pm["kernels"] if k.startswith(dom[0] + "<")]
             if key:
@@ -150,6 +314,8 @@ def main():
     roofline = {
         "bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "traffic_source": (traffic_source + " (separate rocprofv3 --pmc pass of this command, PMC, half-factor calibrated; "
+                                            "not re-measured in this run)") if traffic is not None else None,
         "algorithmic_bytes_per_launch": dom_bytes, "row_scans_per_launch": int(dom[1]), "kernel_ms_avg": round(dom[2], 3),
         "other_kernels": {
             "jv_chain2": {"ms": round(arr_ms, 3), "row_scans": int(arr_scans), "algorithmic_GBs": round(4.0 * n * arr_scans / (arr_ms * 1e-3) / 1e9, 2)},
@@ -186,6 +352,7 @@ def main():
 
     out = {
         "metric": "cell-to-spot assignments/sec on NxN synthetic cost; bit-exact vs lapjv",
+        "metric_note": "bit-exact vs the in-tree CPU JV oracle (== scipy on uniqueness-certified instances); the lapjv wheel is not in this image",
         "value": round(value, 1), "unit": "assignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
@@ -199,6 +366,10 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
+    if world == 1 and not args.no_extras:
+        out["n50000"] = extra_n50000(dev)
+        out["c3"] = extra_c3(dev)
+        out["c4_chunks"] = extra_c4_chunks(dev, args.c4_chunks)
     print(json.dumps(out))
 
 

@@ -40,6 +40,12 @@ class LapInfo(ctypes.Structure):
                    + self.scans_aug_init + self.scans_aug_relax)
 
 
+class LapOpts(ctypes.Structure):
+    """cyto_lap_opts (include/cytohip.h): kernel-selection options; results never depend on them."""
+    _fields_ = [("chain_variant", ctypes.c_int32), ("augmentation", ctypes.c_int32), ("no_handover", ctypes.c_int32),
+                ("inject_exceptions", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
+
+
 class AssignInfo(ctypes.Structure):
     _fields_ = [("ms_standardize", ctypes.c_double), ("ms_gemm", ctypes.c_double), ("gemm_flops", ctypes.c_double),
                 ("lap", LapInfo)]
@@ -73,6 +79,12 @@ def lib():
         for name in ("cyto_lap_f32", "cyto_lap_f64"):
             getattr(L, name).argtypes = [i32, vp, i64, i32, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(LapInfo), i32, vp]
+        for name in ("cyto_lap_f32_opts", "cyto_lap_f64_opts"):
+            getattr(L, name).argtypes = [i32, vp, i64, i32, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_double),
+                                         ctypes.POINTER(LapInfo), i32, vp, ctypes.POINTER(LapOpts)]
+            getattr(L, name).restype = ctypes.c_int
+        L.cyto_trim_device_cache.argtypes = [i32]
+        L.cyto_trim_device_cache.restype = ctypes.c_int
         dp = ctypes.POINTER(ctypes.c_double)
         L.cyto_lap_f32_from_f64.argtypes = [i32, vp, i64, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(LapInfo), i32, vp]

@@ -3,19 +3,19 @@
 //
 // CytoSPACE splits large inputs into independent square sub-LAPs ("chunks") and ships each to a worker
 // process (/root/reference/cytospace/cytospace.py:430-451).  On the GPU the sequential part of one solve
-// occupies ONE workgroup (one CU of 256), so chunks are solved concurrently: one host thread + one HIP
-// stream per chunk in flight; the streaming kernels (column reduction, row-cache build, cost GEMM) of
-// different chunks interleave on the rest of the chip.
+// occupies ONE workgroup (one CU of 256), so the chunks of a batch go through every chain phase TOGETHER: one launch with
+// a workgroup per chunk (lap_jv.hip: lap_solve_f32_batch), up to 256 chains running side by side on the 256 CUs.
 #include "cyto_common.h"
 #include <rccl/rccl.h>
-#include <atomic>
-#include <thread>
+#include <algorithm>
+#include <map>
 #include <vector>
 
 extern "C" {
 
 // Solve nb independent LAPs.  Arrays of per-problem pointers/sizes; outputs may be NULL like in
-// cyto_lap_f32.  max_concurrent <= 0 picks min(nb, 32).  Returns the first non-zero status (all
+// cyto_lap_f32.  Problems of equal size share their launches; max_concurrent bounds how many are in flight at once (each
+// holds its workspace, ~2.6 KB per row): <= 0 picks min(nb, 256), one chain per CU.  Returns the first non-zero status (all
 // problems are attempted); status_out[b] (optional) receives each problem's status.
 int cyto_lap_batch_f32(int nb, const int *n, const float *const *cost, const int64_t *ld, int cost_on_device,
                        int32_t *const *rowsol, int32_t *const *colsol, float *const *u, float *const *v, double *total,
@@ -24,27 +24,43 @@ int cyto_lap_batch_f32(int nb, const int *n, const float *const *cost, const int
     if (nb == 0) return CYTO_OK;
     int rc = cyto::select_device(device_id);
     if (rc) return rc;
-    int conc = max_concurrent > 0 ? max_concurrent : 32;
-    if (conc > nb) conc = nb;
-    std::atomic<int> next(0);
+    const int conc = std::max(1, std::min(nb, max_concurrent > 0 ? max_concurrent : 256));
+    cyto::StreamGuard guard;
+    CYTO_HIP(hipStreamCreateWithFlags(&guard.s, hipStreamNonBlocking));
+    guard.own = true;
     std::vector<int> st((size_t)nb, CYTO_OK);
-    auto worker = [&]() {
-        if (hipSetDevice(device_id) != hipSuccess) return;
-        hipStream_t stream = nullptr;
-        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) stream = nullptr;
-        for (;;) {
-            const int b = next.fetch_add(1);
-            if (b >= nb) break;
-            cyto::tl_single_cu_only = 1;
-            st[(size_t)b] = cyto_lap_f32(n[b], cost[b], ld[b], cost_on_device, rowsol ? rowsol[b] : nullptr,
-                                         colsol ? colsol[b] : nullptr, u ? u[b] : nullptr, v ? v[b] : nullptr,
-                                         total ? &total[b] : nullptr, info ? &info[b] : nullptr, device_id, stream);
+    std::map<int, std::vector<int>> by_n;                 // size -> problems, in input order
+    for (int b = 0; b < nb; b++) {
+        if (n[b] <= 0 || !cost[b] || ld[b] < n[b]) st[(size_t)b] = CYTO_ERR_BAD_ARG;
+        else by_n[n[b]].push_back(b);
+    }
+    for (auto &kv : by_n) {
+        const std::vector<int> &ids = kv.second;
+        for (size_t lo = 0; lo < ids.size(); lo += (size_t)conc) {
+            const int cnt = (int)std::min(ids.size() - lo, (size_t)conc);
+            std::vector<const float *> c((size_t)cnt);
+            std::vector<int64_t> l((size_t)cnt);
+            std::vector<int32_t *> rs((size_t)cnt), cs((size_t)cnt);
+            std::vector<float *> uu((size_t)cnt), vv((size_t)cnt);
+            std::vector<double> tot((size_t)cnt);
+            std::vector<cyto_lap_info> inf((size_t)cnt);
+            std::vector<int> stat((size_t)cnt, CYTO_OK);
+            for (int k = 0; k < cnt; k++) {
+                const int b = ids[lo + (size_t)k];
+                c[(size_t)k] = cost[b]; l[(size_t)k] = ld[b];
+                rs[(size_t)k] = rowsol ? rowsol[b] : nullptr; cs[(size_t)k] = colsol ? colsol[b] : nullptr;
+                uu[(size_t)k] = u ? u[b] : nullptr; vv[(size_t)k] = v ? v[b] : nullptr;
+            }
+            const int brc = cyto::lap_batch_same_n(kv.first, cnt, c.data(), l.data(), cost_on_device, rs.data(), cs.data(), uu.data(), vv.data(),
+                                                   tot.data(), inf.data(), stat.data(), device_id, guard.s);
+            for (int k = 0; k < cnt; k++) {
+                const int b = ids[lo + (size_t)k];
+                st[(size_t)b] = brc ? brc : stat[(size_t)k];
+                if (total) total[b] = tot[(size_t)k];
+                if (info) info[b] = inf[(size_t)k];
+            }
         }
-        if (stream) (void)hipStreamDestroy(stream);
-    };
-    std::vector<std::thread> pool;
-    for (int t = 0; t < conc; t++) pool.emplace_back(worker);
-    for (auto &t : pool) t.join();
+    }
     int first = CYTO_OK;
     for (int b = 0; b < nb; b++) {
         if (status_out) status_out[b] = st[(size_t)b];

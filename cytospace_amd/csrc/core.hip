@@ -1,5 +1,9 @@
 // core.hip -- status strings, device selection and memory plumbing of the C ABI (include/cytohip.h).
 #include "cyto_common.h"
+#include <map>
+#include <mutex>
+#include <set>
+#include <vector>
 
 namespace cyto {
 
@@ -21,9 +25,106 @@ int select_device(int device_id) {
     return CYTO_OK;
 }
 
+// ---- device block cache ----
+namespace {
+struct Block { void *p; size_t bytes; };
+struct DeviceCache {
+    std::multimap<size_t, void *> free_blocks;     // size -> block
+    std::map<void *, size_t> live;                 // every block this cache handed out (or holds): its size
+};
+std::mutex g_cache_mutex;
+std::map<int, DeviceCache> g_cache;                // by device
+
+size_t round_size(size_t b) {
+    // 256-byte granules below 1 MiB, 1/8-octave steps above: a slightly larger n finds the block of the last solve
+    if (b <= (1u << 20)) return (b + 255) & ~(size_t)255;
+    size_t step = (size_t)1 << 17;
+    while ((step << 4) < b) step <<= 1;
+    return (b + step - 1) / step * step;
+}
+
+void trim_locked(DeviceCache &c) {
+    for (auto &kv : c.free_blocks) { c.live.erase(kv.second); (void)hipFree(kv.second); }
+    c.free_blocks.clear();
+}
+}  // namespace
+
+void *cache_alloc(size_t bytes, int *status) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { *status = CYTO_ERR_HIP; return nullptr; }
+    const size_t want = round_size(bytes);
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mutex);
+        DeviceCache &c = g_cache[dev];
+        auto it = c.free_blocks.lower_bound(want);
+        // best fit, but never a block more than 25 % larger than asked for (a 10 GB block must not serve a 1 MB request)
+        if (it != c.free_blocks.end() && it->first <= want + want / 4 + 4096) {
+            void *p = it->second;
+            c.free_blocks.erase(it);
+            *status = CYTO_OK;
+            return p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipErrorOutOfMemory) {                 // give the cached blocks back and try once more
+        (void)hipGetLastError();
+        { std::lock_guard<std::mutex> lk(g_cache_mutex); trim_locked(g_cache[dev]); }
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) {
+        set_hip_error(e, "hipMalloc");
+        *status = e == hipErrorOutOfMemory ? CYTO_ERR_NOMEM : CYTO_ERR_HIP;
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_cache_mutex);
+    g_cache[dev].live[p] = want;
+    *status = CYTO_OK;
+    return p;
+}
+
+void cache_release(void *p, hipStream_t used_on) {
+    if (!p) return;
+    // normal returns have synchronised their stream already (the query is then a cheap "yes"); error returns may not have
+    if (hipStreamQuery(used_on) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(used_on); }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_cache_mutex);
+    for (auto &kv : g_cache) {                      // the owning device's cache (normally the current device)
+        auto it = kv.second.live.find(p);
+        if (it != kv.second.live.end()) { kv.second.free_blocks.emplace(it->second, p); return; }
+    }
+    (void)hipFree(p);                               // not ours (cannot happen)
+}
+
+int set_max_dynamic_lds(const void *kernel) {
+    static std::mutex m;
+    static std::set<const void *> done;
+    std::lock_guard<std::mutex> lk(m);
+    if (done.count(kernel)) return CYTO_OK;
+    // the CU has 160 KB; what the kernel declares statically comes off the dynamic allowance
+    hipFuncAttributes fa;
+    CYTO_HIP(hipFuncGetAttributes(&fa, kernel));
+    const int dyn = 160 * 1024 - (int)((fa.sharedSizeBytes + 255) & ~(size_t)255);
+    if (dyn < LDS_DYNAMIC_MAX) return CYTO_ERR_INTERNAL;      // a kernel's static LDS outgrew the 2 KB the planners leave for it
+    CYTO_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+    done.insert(kernel);
+    return CYTO_OK;
+}
+
 }  // namespace cyto
 
 extern "C" {
+
+int cyto_trim_device_cache(int device_id) {
+    int rc = cyto::select_device(device_id);
+    if (rc) return rc;
+    CYTO_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(cyto::g_cache_mutex);
+    auto it = cyto::g_cache.find(device_id);
+    if (it != cyto::g_cache.end()) cyto::trim_locked(it->second);
+    return CYTO_OK;
+}
 
 const char *cyto_strerror(int status) {
     switch (status) {

@@ -247,13 +247,18 @@ __global__ __launch_bounds__(256) void pearson_gemm(int Gpad, int S, int C, cons
     const int m0 = tm * BM, n0 = tn * BN;
     const int wm = wave >> 1, wn = wave & 1;
 
-    f32x16 acc[2][2];
+    // Two-level accumulation: the matrix cores add into `acc` for FOLD k-tiles (512 genes), then `acc` is folded into
+    // `sum` with ordinary round-to-nearest adds and cleared.  One running fp32 sum over 20 000 genes (config c3) drifts by
+    // ~1e-5 (measured against the float64 reference, biased towards zero); partial sums of 512 genes are 40x smaller, so
+    // their rounding steps are too, and the 40 folds add ~1e-7.
+    constexpr int FOLD = 16;
+    f32x16 acc[2][2], sum[2][2];
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int b = 0; b < 2; b++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+            for (int r = 0; r < 16; r++) { acc[a][b][r] = 0.0f; sum[a][b][r] = 0.0f; }
 
     // staging: 4 float4 per thread per operand per k-tile, register-staged double buffering:
     // the global loads of tile t+1 are issued before the MFMAs of tile t and written to the other LDS
@@ -299,6 +304,16 @@ __global__ __launch_bounds__(256) void pearson_gemm(int Gpad, int S, int C, cons
             __builtin_amdgcn_sched_barrier(0);
             a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
+        if ((kt % FOLD) == FOLD - 1 || kt + 1 == nk) {
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    sum[a][b] += acc[a][b];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+                }
+        }
         if (kt + 1 < nk) { LSTORE(buf ^ 1) }
         __syncthreads();
     }
@@ -316,8 +331,8 @@ __global__ __launch_bounds__(256) void pearson_gemm(int Gpad, int S, int C, cons
                 const int s = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (s < S && c < C) {
                     float val;
-                    if constexpr (EPI == 0) val = -acc[a][b][r];
-                    else { const double d2 = na[s] + nb[c] - 2.0 * (double)acc[a][b][r]; val = (float)sqrt(d2 > 0.0 ? d2 : 0.0); }
+                    if constexpr (EPI == 0) val = -sum[a][b][r];
+                    else { const double d2 = na[s] + nb[c] - 2.0 * (double)sum[a][b][r]; val = (float)sqrt(d2 > 0.0 ? d2 : 0.0); }
                     const int r0 = rowstart[s], r1 = rowstart[s + 1];
                     for (int row = r0; row < r1; row++) cost[(int64_t)row * ldc + c] = val;
                 }
@@ -352,7 +367,7 @@ static int standardize_dev(int G, int C, const TIn *dx, int64_t ldx, int already
         if (G > 32 * 1024) return CYTO_ERR_UNSUPPORTED;
         DevBuf ranks;
         int rc2;
-        if ((rc2 = ranks.alloc((size_t)G * C * sizeof(float)))) return rc2;
+        if ((rc2 = ranks.alloc((size_t)G * C * sizeof(float), stream))) return rc2;
         const int m = (G + 1023) / 1024;
         float *rp = ranks.as<float>();
         if (m <= 4) hipLaunchKernelGGL((rank_columns<TIn, 4>), dim3(C), dim3(1024), 0, stream, G, C, dx, ldx, rp, (int64_t)C);
@@ -366,9 +381,9 @@ static int standardize_dev(int G, int C, const TIn *dx, int64_t ldx, int already
     const int nblk = (G + GB - 1) / GB;
     DevBuf part1, part2, colsum, mean, inv;
     int rc;
-    if ((rc = part1.alloc((size_t)nblk * C * sizeof(double))) || (rc = part2.alloc((size_t)nblk * C * sizeof(double))) ||
-        (rc = colsum.alloc((size_t)C * sizeof(double))) || (rc = mean.alloc((size_t)C * sizeof(double))) ||
-        (rc = inv.alloc((size_t)C * sizeof(double))))
+    if ((rc = part1.alloc((size_t)nblk * C * sizeof(double), stream)) || (rc = part2.alloc((size_t)nblk * C * sizeof(double), stream)) ||
+        (rc = colsum.alloc((size_t)C * sizeof(double), stream)) || (rc = mean.alloc((size_t)C * sizeof(double), stream)) ||
+        (rc = inv.alloc((size_t)C * sizeof(double), stream)))
         return rc;
     const dim3 grid((C + 255) / 256, nblk), blk(256);
     const dim3 g1((C + 255) / 256);
@@ -430,7 +445,7 @@ int cyto_transform(int transform, int G, int C, const void *x, int64_t ldx, int 
     const void *src = x;
     int64_t sld = ldx;
     if (!x_on_device) {
-        if ((rc = dx.alloc((size_t)G * C * esz))) return rc;
+        if ((rc = dx.alloc((size_t)G * C * esz, stream))) return rc;
         CYTO_HIP(hipMemcpy2DAsync(dx.p, (size_t)C * esz, x, (size_t)ldx * esz, (size_t)C * esz, G, hipMemcpyHostToDevice, stream));
         src = dx.p;
         sld = C;
@@ -466,18 +481,18 @@ static int cost_gemm(int euclid, int Gpad, int S, int C, const float *zst, int64
     }
     rowstart[S] = (int)acc;
     DevBuf drs;
-    if ((rc = drs.alloc(((size_t)S + 1) * sizeof(int)))) return rc;
+    if ((rc = drs.alloc(((size_t)S + 1) * sizeof(int), stream))) return rc;
     CYTO_HIP(hipMemcpyAsync(drs.p, rowstart.data(), ((size_t)S + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
     const int tiles_m = (S + BM - 1) / BM, tiles_n = (C + BN - 1) / BN;
-    hipEvent_t e0, e1;
-    CYTO_HIP(hipEventCreate(&e0));
-    CYTO_HIP(hipEventCreate(&e1));
+    Events<2> ev;
+    if ((rc = ev.create())) return rc;
+    const hipEvent_t e0 = ev[0], e1 = ev[1];
     DevBuf na, nb, part;
     if (euclid) {
         // squared column norms of the float32 operands, in float64
         const int nblk = Gpad / GB + (Gpad % GB ? 1 : 0);
         const int Cmax = S > C ? S : C;
-        if ((rc = na.alloc((size_t)S * 8)) || (rc = nb.alloc((size_t)C * 8)) || (rc = part.alloc((size_t)nblk * Cmax * 8))) return rc;
+        if ((rc = na.alloc((size_t)S * 8, stream)) || (rc = nb.alloc((size_t)C * 8, stream)) || (rc = part.alloc((size_t)nblk * Cmax * 8, stream))) return rc;
         hipLaunchKernelGGL(colsq_partial, dim3((S + 255) / 256, nblk), dim3(256), 0, stream, Gpad, S, zst, ldzst, part.as<double>());
         hipLaunchKernelGGL(col_finish_sum, dim3((S + 255) / 256), dim3(256), 0, stream, S, nblk, part.as<double>(), na.as<double>());
         hipLaunchKernelGGL(colsq_partial, dim3((C + 255) / 256, nblk), dim3(256), 0, stream, Gpad, C, zsc, ldzsc, part.as<double>());
@@ -496,8 +511,6 @@ static int cost_gemm(int euclid, int Gpad, int S, int C, const float *zst, int64
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
     if (gemm_ms) *gemm_ms = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return CYTO_OK;
 }
 
@@ -533,17 +546,19 @@ int cyto_assign_metric_typed(int metric, int G, int C, int S, const void *sc, co
     if (rc) return rc;
     const int Gpad = (int)round_up(G, BK);
     const int64_t ldzst = round_up(S, BM), ldzsc = round_up(C, BN), ldc = round_up(C, 4);
-    DevBuf zst, zsc, cost;
-    if ((rc = zst.alloc((size_t)Gpad * ldzst * 4)) || (rc = zsc.alloc((size_t)Gpad * ldzsc * 4)) ||
-        (rc = cost.alloc((size_t)N * ldc * 4)))
-        return rc;
     // a private stream, so that several host threads can run chunks concurrently on one GPU
-    hipStream_t stream = nullptr;
-    CYTO_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { if (s) (void)hipStreamDestroy(s); } } guard{stream};
-    hipEvent_t e0, e1;
-    CYTO_HIP(hipEventCreate(&e0));
-    CYTO_HIP(hipEventCreate(&e1));
+    // (declared before the buffers: they go back to the block cache while their stream still exists)
+    StreamGuard guard;
+    CYTO_HIP(hipStreamCreateWithFlags(&guard.s, hipStreamNonBlocking));
+    guard.own = true;
+    const hipStream_t stream = guard.s;
+    Events<2> ev;
+    if ((rc = ev.create())) return rc;
+    const hipEvent_t e0 = ev[0], e1 = ev[1];
+    DevBuf zst, zsc, cost;
+    if ((rc = zst.alloc((size_t)Gpad * ldzst * 4, stream)) || (rc = zsc.alloc((size_t)Gpad * ldzsc * 4, stream)) ||
+        (rc = cost.alloc((size_t)N * ldc * 4, stream)))
+        return rc;
     CYTO_HIP(hipEventRecord(e0, stream));
     if ((rc = cyto_transform(transform, G, S, st, S, x_is_f64, 0, already_normalized, zst.as<float>(), ldzst, Gpad, device_id, stream))) return rc;
     if ((rc = cyto_transform(transform, G, C, sc, C, x_is_f64, 0, already_normalized, zsc.as<float>(), ldzsc, Gpad, device_id, stream))) return rc;
@@ -551,8 +566,6 @@ int cyto_assign_metric_typed(int metric, int G, int C, int S, const void *sc, co
     CYTO_HIP(hipEventSynchronize(e1));
     float ms_std = 0;
     (void)hipEventElapsedTime(&ms_std, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     double ms_gemm = 0;
     if ((rc = cyto_cost_metric(metric, Gpad, S, C, zst.as<float>(), ldzst, zsc.as<float>(), ldzsc, slots, cost.as<float>(), ldc,
                                &ms_gemm, device_id, stream)))
@@ -644,16 +657,17 @@ int cyto_ctx_assign_chunk(cyto_expr_ctx *ctx, const int64_t *idx_sc, int n_sc, c
     }
     const int Su = (int)h_st.size();
     const int64_t ldzst = round_up(Su, BM), ldzsc = round_up(n_sc, BN), ldc = round_up(n_sc, 4);
+    StreamGuard guard;
+    CYTO_HIP(hipStreamCreateWithFlags(&guard.s, hipStreamNonBlocking));
+    guard.own = true;
+    const hipStream_t stream = guard.s;
+    Events<2> ev;
+    if ((rc = ev.create())) return rc;
+    const hipEvent_t e0 = ev[0], e1 = ev[1];
     DevBuf zst, zsc, cost, dsc, dst;
-    if ((rc = zst.alloc((size_t)ctx->Gpad * ldzst * 4)) || (rc = zsc.alloc((size_t)ctx->Gpad * ldzsc * 4)) ||
-        (rc = cost.alloc((size_t)N * ldc * 4)) || (rc = dsc.alloc((size_t)n_sc * 4)) || (rc = dst.alloc((size_t)Su * 4)))
+    if ((rc = zst.alloc((size_t)ctx->Gpad * ldzst * 4, stream)) || (rc = zsc.alloc((size_t)ctx->Gpad * ldzsc * 4, stream)) ||
+        (rc = cost.alloc((size_t)N * ldc * 4, stream)) || (rc = dsc.alloc((size_t)n_sc * 4, stream)) || (rc = dst.alloc((size_t)Su * 4, stream)))
         return rc;
-    hipStream_t stream = nullptr;
-    CYTO_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { if (s) (void)hipStreamDestroy(s); } } guard{stream};
-    hipEvent_t e0, e1;
-    CYTO_HIP(hipEventCreate(&e0));
-    CYTO_HIP(hipEventCreate(&e1));
     CYTO_HIP(hipEventRecord(e0, stream));
     CYTO_HIP(hipMemcpyAsync(dsc.p, h_sc.data(), (size_t)n_sc * 4, hipMemcpyHostToDevice, stream));
     CYTO_HIP(hipMemcpyAsync(dst.p, h_st.data(), (size_t)Su * 4, hipMemcpyHostToDevice, stream));
@@ -669,8 +683,6 @@ int cyto_ctx_assign_chunk(cyto_expr_ctx *ctx, const int64_t *idx_sc, int n_sc, c
     CYTO_HIP(hipEventSynchronize(e1));
     float ms_gather = 0;
     (void)hipEventElapsedTime(&ms_gather, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     double ms_gemm = 0;
     if ((rc = cyto_cost_metric(ctx->metric, ctx->Gpad, Su, n_sc, zst.as<float>(), ldzst, zsc.as<float>(), ldzsc, h_slots.data(),
                                cost.as<float>(), ldc, &ms_gemm, ctx->device_id, stream)))

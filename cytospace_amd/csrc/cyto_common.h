@@ -19,20 +19,62 @@ void set_hip_error(hipError_t e, const char *what);
         }                                                    \
     } while (0)
 
-// RAII device buffer (hipFree on scope exit) -- host-side convenience only.
+// Device memory comes from a per-device cache of blocks (core.hip): a solve takes its ~15 work buffers from blocks that
+// earlier solves returned, so the steady state has no hipMalloc / hipFree at all -- hipFree synchronises the whole device,
+// which serialised the chunk solves that run side by side on their own streams.  A block is handed back only when the
+// stream it was used on has drained (checked with hipStreamQuery, waited for on error paths), so a new owner on another
+// stream never races with work still in flight.  cyto_trim_device_cache() gives everything back to the runtime.
+void *cache_alloc(size_t bytes, int *status);
+void cache_release(void *p, hipStream_t used_on);
+
+// RAII device buffer -- host-side convenience only.
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) {
-        CYTO_HIP(hipMalloc(&p, bytes ? bytes : 16));
-        return CYTO_OK;
+    hipStream_t stream = nullptr;          // the stream the buffer is used on (for the drain check at release)
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { reset(); }
+    void reset() { if (p) cache_release(p, stream); p = nullptr; }
+    int alloc(size_t bytes, hipStream_t used_on = nullptr) {
+        reset();
+        int st = CYTO_OK;
+        stream = used_on;
+        p = cache_alloc(bytes ? bytes : 16, &st);
+        return st;
     }
     template <typename U> U *as() const { return reinterpret_cast<U *>(p); }
 };
 
+// RAII events (timing brackets of one call); destroyed on every return path.
+template <int N> struct Events {
+    hipEvent_t e[N] = {};
+    int made = 0;
+    ~Events() { for (int i = 0; i < made; i++) (void)hipEventDestroy(e[i]); }
+    int create() {
+        for (; made < N; made++) CYTO_HIP(hipEventCreate(&e[made]));
+        return CYTO_OK;
+    }
+    hipEvent_t operator[](int i) const { return e[i]; }
+};
+
+// A private non-blocking stream for one call when the caller gave none.
+struct StreamGuard {
+    hipStream_t s = nullptr;
+    bool own = false;
+    ~StreamGuard() { if (own && s) (void)hipStreamDestroy(s); }
+};
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-symbol, process-wide setting: set it ONCE per kernel to the most
+// the CU offers (160 KB minus the kernel's static LDS) instead of before every launch with a size that depends on n
+// (two host threads launching different sizes of the same kernel would race).
+constexpr int LDS_DYNAMIC_MAX = 160 * 1024 - 2048;
+int set_max_dynamic_lds(const void *kernel);
+
 int select_device(int device_id);
 
-// set by callers that run several solves concurrently on one GPU (cyto_lap_batch_f32): the cooperative
-// augmentation spins on its peers and must not compete with other cooperative launches for CUs
-extern thread_local int tl_single_cu_only;
+// lap_jv.hip: float32 problems of ONE size solved as a batch (one launch per chain phase, a workgroup per problem)
+int lap_batch_same_n(int n, int nb, const float *const *cost, const int64_t *ld, int cost_on_device, int32_t *const *rowsol,
+                     int32_t *const *colsol, float *const *u, float *const *v, double *total, cyto_lap_info *info, int *status,
+                     int device_id, hipStream_t stream);
 }  // namespace cyto

@@ -17,8 +17,8 @@
 //       One persistent 512-thread workgroup; a scan is served from the row's cache by wave 0 alone whenever the
 //       cache certifies its top-2, otherwise the workgroup re-scans the row (refresh_row / refresh_row_stream).
 //   jv_aug_lazy<LDS_STATE> (n > 5120) : AUGMENTATION with cache-certified scans and sparse search initialisation.
-//   jv_aug2<CH, LDS_STATE> (n <= 5120), jv_aug_stream, jv_aug_coop : dense augmentation kernels (register /
-//       L2-resident / multi-CU column state); the last two are kept for comparison (CYTO_AUG=stream|coop).
+//   jv_aug2<CH, LDS_STATE> (n <= 5120, and taking over from jv_aug_lazy on deep searches) : dense augmentation,
+//       per-column search state in registers.
 //   jv_chain<T, CH> : the generic dense chain (1024 threads) -- float64 only.
 //
 // Compile with -ffp-contract=off (build.py does): the arithmetic is subtract/compare only,
@@ -26,12 +26,13 @@
 #include "cyto_common.h"
 #include <math.h>
 #include <type_traits>
+#include <vector>
+#include <algorithm>
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
 namespace cyto {
-thread_local int tl_single_cu_only = 0;
 
 constexpr int BLOCK = 1024;
 constexpr int NW = BLOCK / 64;
@@ -315,6 +316,11 @@ template <typename T> struct ChainArgs {
     T *dwork;            // [n] scratch (jv_chain_stream: distances)
     int32_t *lvl;        // [n] scratch (jv_chain_stream: level at which a column was scanned; 0 = not scanned)
 };
+
+// The persistent chain kernels run one workgroup per PROBLEM: a batch of independent chunk LAPs is one launch with
+// grid = batch size (consecutive workgroups land on consecutive XCDs, so the chains spread over the whole chip), each
+// workgroup reading its own argument block.  One stream per chunk instead tops out at ~32 concurrent kernels
+// (measured: 64 chunks on 64 streams took 3x as long as 32) and every 1-workgroup grid starts on XCD 0.
 
 // agent-scope relaxed accesses: served by L2, never by the scalar cache or a stale L1 line
 __device__ __forceinline__ int32_t ld_i32(const int32_t *p) {
@@ -936,6 +942,8 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// a wave's candidate for the next pick of the dense augmentation, with everything the step needs once it wins
+struct __attribute__((aligned(16))) PickRec { uint64_t key; int32_t row; float h; float vjp; int32_t g; int32_t skip; int32_t pad; };
 struct Scratch2 {
     uint64_t m1[2][NW2], m2[2][NW2];
     int cnt[2][NW2];
@@ -1003,14 +1011,14 @@ struct CachePtrs {
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 // One cost row through a bounds-checked buffer descriptor: lane `tid` gets 16 bytes of every
 // 8 KiB chunk (a wave reads 1 KiB contiguous); bytes past the row pitch read as 0, so no branches.
-template <int CH>
+template <int CH, int BS = BLOCK2>
 __device__ __forceinline__ void load_row4(const float *__restrict__ cost, int64_t ld, int i, int n, int tid, float4 (&x)[CH]) {
     (void)n;
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(cost + (int64_t)i * ld), 0, (int)(ld * 4), 0x00020000);
 #pragma unroll
     for (int m = 0; m < CH; m++) {
-        const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, m * BLOCK2 * 16, 0);
+        const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, m * BS * 16, 0);
         x[m] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
     }
 }
@@ -1279,11 +1287,11 @@ template <bool LDS_STATE> __device__ __forceinline__ void st_csset(uint16_t *s_c
     if constexpr (LDS_STATE) s_cs[j] = (uint16_t)i; else st_i32(gcs + j, i);
 }
 
-template <int CH, bool LDS_STATE>
+template <int CH, bool LDS_STATE, int BS = BLOCK2>
 __device__ __forceinline__ void load_vreg(const float *s_v, const float *gv, int n, int tid, float (&vreg)[CH * 4]) {
 #pragma unroll
     for (int m = 0; m < CH; m++) {
-        const int q = m * BLOCK2 + tid;
+        const int q = m * BS + tid;
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q * 4 < n) {
             if constexpr (LDS_STATE) t = *reinterpret_cast<const float4 *>(s_v + q * 4);
@@ -1299,181 +1307,339 @@ __device__ __forceinline__ void load_vreg(const float *s_v, const float *gv, int
     }
 }
 
+template <int NWV = NW2>
 __device__ __forceinline__ uint32_t wg_min_u32(uint32_t x, Scratch2 &s, int &par) {
     const uint32_t w0 = wave_min_u32(x);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t *buf = reinterpret_cast<uint32_t *>(&s.cnt[par][0]);
     if (lane == 0) buf[w] = w0;
     lds_barrier();
-    uint32_t r = buf[lane & (NW2 - 1)];
+    uint32_t r = buf[lane & (NWV - 1)];
     r = row_min_u32(r);
     par ^= 1;
     return readlane32(r, 0);
 }
 
+// -DCYTO_AUG_PROF (tools/prof_aug_step.sh): s_memtime stamps of wave 0 inside a dense augmentation step
+#ifdef CYTO_AUG_PROF
+__device__ long long g_aug_prof[16];
+#define AP_DECL long long ap_[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ap_t_ = 0;
+#define AP_START ap_t_ = (long long)__builtin_amdgcn_s_memtime();
+#define AP_STAMP(k) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long now_ = (long long)__builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ap_[k] += now_ - ap_t_; ap_t_ = now_; }
+#define AP_WAITVM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define AP_FLUSH if (threadIdx.x == 0) { for (int k_ = 0; k_ < 14; k_++) g_aug_prof[k_] += ap_[k_]; g_aug_prof[15] += 1; }
+#else
+#define AP_DECL
+#define AP_START
+#define AP_STAMP(k)
+#define AP_WAITVM
+#define AP_FLUSH
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float fmin3_raw(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // One augmentation (all threads, uniform control): dense Dijkstra search from `freerow`, price
 // update, path flip.  Same pick rule as the oracle: lexicographic minimum of (d, assigned?, column)
 // over the unscanned columns.  Per column the owning lane keeps, in VGPRs, the distance d (+inf
-// once the column is scanned), the price vm (-inf once scanned: every later relaxation of that
-// column is then a no-op) and the predecessor row; relax + running minimum are 6 VALU operations
-// per column.  The arg-min is found in two steps: the minimum value first (one 32-bit all-reduce
+// once the column is scanned) and the price vm (-inf once scanned: every later relaxation of that
+// column is then a no-op).  The arg-min is found in two steps: the minimum value first (one 32-bit all-reduce
 // on order-preserving keys), then the column among the few lanes that hold that value.
-template <int CH, bool LDS_STATE>
-__device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__restrict__ cost, float *gv, float *sumvd,
-                                             float *cassign, int32_t *rowsol, int32_t *gcolsol, int32_t *pred, float *s_v,
-                                             uint16_t *s_cs, int freerow, uint64_t validm, Scratch2 &s, int &par,
+//
+// A step's cost on one CU is (a) the round trip of the picked row and (b) the VALU work of relaxing n columns, so
+// the relaxation is as lean as the oracle's arithmetic allows: per PAIR of columns two packed subtractions
+// (v_pk_add_f32 with negated operands: fl(fl(c - v) - h), the oracle's two roundings), per column one v_min_f32,
+// per four columns two v_min3_f32 for the running minimum -- 2.5 VALU operations per column.
+// No predecessor is tracked while relaxing (it cost a compare and two selects per column).  The oracle's pred[j] is the
+// FIRST scan, in scan order and with the free row's initial scan before all others, whose candidate equals the final
+// d[j] (a later equal candidate never replaces it: updates are strict); so every scan logs (row, h), every retired
+// column logs the distance it was scanned at, and the <= ~40 columns of the augmenting path find their predecessors
+// afterwards by re-evaluating the logged candidates for that one column (reconstruct_pred).
+template <int CH, bool LDS_STATE, int BS>
+__device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__restrict__ cost, float *gv, float2 *sd,
+                                             float *cassign, int32_t *rowsol, int32_t *gcolsol, int32_t *slog_row, float *slog_h,
+                                             float *s_v, uint16_t *s_cs, int freerow, uint64_t validm, Scratch2 &s, int &par,
                                              long long &c_relax, long long &c_hops, long long &c_skipped, int gmode,
                                              const int32_t *rowgid, int32_t *colgroup, float *hb, int32_t *hs, int stamp, float *s_ca,
-                                             uint16_t *s_cg) {
+                                             uint16_t *s_cg, PickRec (*rec)[NW2]) {
     constexpr int NC = CH * 4;
+    constexpr int NWV = BS / 64;
+#undef SLOT_COL
+#define SLOT_COL(sl) ((((sl) / 4) * BS + tid) * 4 + ((sl) % 4))
     const int tid = threadIdx.x;
-    float vm[NC], dreg[NC], cm[CH];
-    int32_t preg[NC];
-    load_vreg<CH, LDS_STATE>(s_v, gv, n, tid, vm);
+    // Column state as two register VECTORS: a slot that is only known at run time, but is the same for the whole wave
+    // (the retired column's, the picked column's), is then read or written with indirect register addressing
+    // (s_set_gpr_idx / v_movrel: a handful of instructions) instead of a compare-and-select per slot.  The hardware indexes
+    // at most 32 registers that way; beyond (NC > 32) the select chains remain.
+    typedef float fvec __attribute__((ext_vector_type(NC)));
+    constexpr bool VEC = NC <= 32;
+    fvec vmV, dV;
+    float cm[CH];
+    // LDS views with their address space spelled out: through plain (generic) pointers that may also be null or point to
+    // global memory the compiler emits FLAT loads, which take the long way round (measured: ~1000 cycles for the four
+    // look-ups of a step)
+    typedef __attribute__((address_space(3))) float lds_f32;
+    typedef __attribute__((address_space(3))) uint16_t lds_u16;
+    typedef __attribute__((address_space(3))) int32_t lds_i32;
+    lds_f32 *const l_v = (lds_f32 *)s_v;
+    lds_u16 *const l_cs = (lds_u16 *)s_cs;
+    lds_f32 *const l_ca = (lds_f32 *)s_ca;
+    lds_u16 *const l_cg = (lds_u16 *)s_cg;
+    lds_f32 *const l_hb = (lds_f32 *)hb;
+    lds_i32 *const l_hs = (lds_i32 *)hs;
+#define VM(sl) vmV[sl]
+#define DR(sl) dV[sl]
+    {
+        float v0[NC];
+        load_vreg<CH, LDS_STATE, BS>(s_v, gv, n, tid, v0);
+#pragma unroll
+        for (int sl = 0; sl < NC; sl++) VM(sl) = v0[sl];
+    }
     uint64_t assignedm = 0, scannedm = 0, readym = 0;
 #pragma unroll
     for (int sl = 0; sl < NC; sl++)
         if (((validm >> sl) & 1) && st_csget<LDS_STATE>(s_cs, gcolsol, SLOT_COL(sl)) >= 0) assignedm |= (1ull << sl);
     {
         float4 x[CH];
-        load_row4<CH>(cost, ld, freerow, n, tid, x);
+        load_row4<CH, BS>(cost, ld, freerow, n, tid, x);
 #pragma unroll
         for (int sl = 0; sl < NC; sl++) {
             const bool ok = (validm >> sl) & 1;
-            dreg[sl] = ok ? vec_get<float>(x[sl / 4], sl % 4) - vm[sl] : INFINITY;
-            vm[sl] = ok ? vm[sl] : -INFINITY;
-            preg[sl] = freerow;
+            DR(sl) = ok ? vec_get<float>(x[sl / 4], sl % 4) - VM(sl) : INFINITY;
+            VM(sl) = ok ? VM(sl) : -INFINITY;
         }
     }
 #pragma unroll
-    for (int m = 0; m < CH; m++)
-        cm[m] = fmin_raw(fmin_raw(dreg[m * 4], dreg[m * 4 + 1]), fmin_raw(dreg[m * 4 + 2], dreg[m * 4 + 3]));
+    for (int m = 0; m < CH; m++) cm[m] = fmin_raw(fmin3_raw(DR(m * 4), DR(m * 4 + 1), DR(m * 4 + 2)), DR(m * 4 + 3));
     bool have = false;
     float curmin = 0.0f;
     int endofpath = -1;
-    int pend_g = -1;
-    float pend_h = 0.0f;
+    int nlog = 0;            // scans logged so far in this search (uniform)
+    const int lane = tid & 63, wave = tid >> 6;
+    AP_DECL
+    AP_START
     for (;;) {
-        // pick: smallest d; among equal d an unassigned column first, then the lowest column
+        // ---- pick: smallest d; among equal d an unassigned column first, then the lowest column.  ONE workgroup
+        // exchange per step: every wave reduces its own columns to a candidate (value, then column among the lanes that
+        // hold that value: two DPP all-reduces, no barrier), looks up what the step needs if that candidate wins (owner
+        // row, its offset h, the duplicate-row skip test: independent broadcast LDS reads) and posts the record; after the
+        // barrier every wave reduces the eight 64-bit keys and reads the winner's record. ----
         float lm = cm[0];
 #pragma unroll
         for (int m = 1; m < CH; m++) lm = fmin_raw(lm, cm[m]);
-        const uint32_t omin = wg_min_u32(f2ord(lm), s, par);
-        const float dmin = ord2f(omin);
-        if (pend_g >= 0) {   // every wave is past the barrier above, i.e. done reading the group state of the last step
-            if (tid == 0) {
-                if (gmode == 1) { hb[pend_g] = pend_h; hs[pend_g] = stamp; }
-                else { st_f32(hb + pend_g, pend_h); st_i32(hs + pend_g, stamp); }
-            }
-            pend_g = -1;
-        }
+        const uint32_t wmin = wave_min_u32(f2ord(lm));
+        const float dminw = ord2f(wmin);
+        AP_STAMP(8)
         uint32_t lk = 0xFFFFFFFFu;
-        if (lm == dmin) {
+        const uint64_t holders = __ballot(lm == dminw && dminw < INFINITY);
+        if (VEC && __builtin_popcountll(holders) == 1) {
+            // the usual case: ONE lane of the wave holds the minimum.  Its group of four (found with CH compares) is
+            // broadcast, the four slots are fetched with indirect addressing, the holder picks among them.
+            int mg = CH - 1;
+#pragma unroll
+            for (int m = CH - 2; m >= 0; m--) mg = cm[m] == dminw ? m : mg;     // first group that holds the value
+            const int hl = (int)__builtin_ctzll(holders);
+            const int mgu = __builtin_amdgcn_readlane(mg, hl);                   // wave-uniform
+            if (lm == dminw) {
+#pragma unroll
+                for (int e = 3; e >= 0; e--) {
+                    const int sl = mgu * 4 + e;
+                    const float de = dV[sl];
+                    const uint32_t key = (uint32_t)(((mgu * BS + tid) << 2) + e) | (uint32_t)((assignedm >> sl) & 1) << 31;
+                    lk = de == dminw ? umin32(lk, key) : lk;
+                }
+            }
+        } else if (lm == dminw && dminw < INFINITY) {
 #pragma unroll
             for (int m = 0; m < CH; m++) {
-                if (cm[m] == dmin) {
+                if (cm[m] == dminw) {
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const int sl = m * 4 + e;
-                        if (dreg[sl] == dmin)
+                        if (DR(sl) == dminw)
                             lk = umin32(lk, (uint32_t)SLOT_COL(sl) | (((assignedm >> sl) & 1) ? 0x80000000u : 0u));
                     }
                 }
             }
         }
-        const uint32_t g = wg_min_u32(lk, s, par);
+        AP_STAMP(9)
+        const uint32_t wlk = wave_min_u32(lk);
+        AP_STAMP(10)
+        {
+            int32_t iw = -1, gw = 0, skipw = 0;
+            float hw = 0.0f, vjpw = 0.0f;
+            if (wlk != 0xFFFFFFFFu && (wlk & 0x80000000u)) {          // (wave-uniform) an assigned column: its owner row
+                const int jpw = (int)(wlk & 0x7FFFFFFFu);
+                const float cipw = s_ca ? l_ca[jpw] : ld_f32(cassign + jpw);   // c[i][jp]
+                gw = gmode ? (s_cg ? (int)l_cg[jpw] : ld_i32(colgroup + jpw)) : 0;
+                if constexpr (LDS_STATE) { const uint16_t c16 = l_cs[jpw]; iw = c16 == 0xFFFFu ? -1 : (int32_t)c16; vjpw = l_v[jpw]; }
+                else { iw = ld_i32(gcolsol + jpw); vjpw = ld_f32(gv + jpw); }
+                hw = (cipw - vjpw) - dminw;
+                // Exact skip for duplicated rows: if a bitwise identical row was already scanned in THIS search with an
+                // offset hb >= h, every relaxation through row i is a no-op: fl(x - h) >= fl(x - hb) >= d[j] for every
+                // unscanned column (prices do not change during a search and d only decreases).  The column is retired
+                // exactly as usual, only the row read and the relaxation sweep are elided.
+                if (gmode) {
+                    float hbv; int hsv;
+                    if (gmode == 1) { hbv = l_hb[gw]; hsv = l_hs[gw]; }
+                    else { hbv = ld_f32(hb + gw); hsv = ld_i32(hs + gw); }
+                    skipw = ((hsv == stamp) && (hw <= hbv)) ? 1 : 0;
+                }
+            }
+            AP_STAMP(11)
+            if (lane == 0) {
+                PickRec r;
+                r.key = ((uint64_t)wmin << 32) | wlk; r.row = iw; r.h = hw; r.vjp = vjpw; r.g = gw; r.skip = skipw; r.pad = 0;
+                rec[par][wave] = r;
+            }
+        }
+        lds_barrier();
+        AP_STAMP(12)
+        uint64_t k8 = rec[par][lane & (NWV - 1)].key;
+        uint64_t kmin = k8;
+        kmin = umin64(kmin, dpp64<0xB1>(kmin)); kmin = umin64(kmin, dpp64<0x4E>(kmin));
+        if constexpr (NWV > 4) kmin = umin64(kmin, dpp64<0x141>(kmin));
+        kmin = readlane64(kmin, 0);
+        const int wstar = (int)__builtin_ctzll(__ballot(k8 == kmin)) & (NWV - 1);     // keys of distinct waves are distinct columns
+        const PickRec rw = rec[par][wstar];
+        par ^= 1;
+        AP_STAMP(0)
+        const float dmin = ord2f((uint32_t)(kmin >> 32));
+        const uint32_t g = (uint32_t)kmin;
         if (g == 0xFFFFFFFFu || !(dmin < INFINITY)) return CYTO_ERR_INTERNAL;
         const int jp = (int)(g & 0x7FFFFFFFu);
         if (!have || dmin != curmin) { readym |= scannedm; curmin = dmin; have = true; }
         if (!(g & 0x80000000u)) { endofpath = jp; break; }
-        // three independent loads as soon as the pick is known: owner row (LDS), its cost at jp and its
-        // duplicate-row group (L2)
-        const float cip_raw = s_ca ? s_ca[jp] : ld_f32(cassign + jp);   // c[i][jp]
-        const int g_raw = gmode ? (s_cg ? (int)s_cg[jp] : ld_i32(colgroup + jp)) : 0;
-        const int i = __builtin_amdgcn_readfirstlane(st_csget<LDS_STATE>(s_cs, gcolsol, jp));
-        const float cip = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(cip_raw)));
-        const float vjp = st_vget<LDS_STATE>(s_v, gv, jp);
-        const float h = (cip - vjp) - curmin;
-        // Exact skip for duplicated rows: if a bitwise identical row was already scanned in THIS search with an
-        // offset hb >= h, every relaxation through row i is a no-op: fl(x - h) >= fl(x - hb) >= d[j] for every
-        // unscanned column (prices do not change during a search and d only decreases).  The column is retired
-        // exactly as usual, only the row read and the compare sweep are elided.
-        bool skip = false;
-        if (gmode) {
-            const int g = __builtin_amdgcn_readfirstlane(g_raw);
-            float hbv; int hsv;
-            if (gmode == 1) { hbv = hb[g]; hsv = hs[g]; }
-            else { hbv = ld_f32(hb + g); hsv = ld_i32(hs + g); }
-            skip = (hsv == stamp) && (h <= hbv);
-            // the new best offset of the group is published after the next barrier (all waves have read by then)
-            if (!skip) { pend_g = g; pend_h = h; }
+        const int i = __builtin_amdgcn_readfirstlane(rw.row);
+        const float h = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rw.h)));
+        const float vjp = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rw.vjp)));
+        const bool skip = __builtin_amdgcn_readfirstlane(rw.skip) != 0;
+        if (gmode && !skip && lane == 0) {
+            // the group's new best offset.  Every wave posts the same value: its own later look-ups (program order) see it
+            // without another barrier, whichever wave is first
+            const int grp = rw.g;
+            if (gmode == 1) { l_hb[grp] = h; l_hs[grp] = stamp; }
+            else { st_f32(hb + grp, h); st_i32(hs + grp, stamp); }
         }
+        AP_STAMP(1)
         float4 x[CH];
-        if (!skip) load_row4<CH>(cost, ld, i, n, tid, x);
-        {   // retire column jp: remember v+d for the price update, mask the column out
+        if (!skip) {
+            load_row4<CH, BS>(cost, ld, i, n, tid, x);
+            // scan log (after the loads in program order: a store does not hold them up); one store instruction of the last wave
+            if (tid >= BS - 2) {
+                if (tid == BS - 2) st_i32(slog_row + nlog, i);
+                else st_f32(slog_h + nlog, h);
+            }
+            nlog++;
+        }
+        AP_STAMP(2)
+        {   // retire column jp: remember v+d (price update) and d (predecessor search), mask the column out.
+            // The slot is wave-uniform: a scalar branch per slot instead of two selects per slot.
             const int q = jp >> 2;
-            const int sj = (q / BLOCK2) * 4 + (jp & 3);   // uniform
-            const bool own = (q % BLOCK2) == tid;
-            if (own) { scannedm |= (1ull << sj); sumvd[jp] = vjp + dmin; }
-            // (runs while the row loads are in flight; sj is wave-uniform, `own` selects one lane)
+            const int sj = (q / BS) * 4 + (jp & 3);   // uniform
+            const bool own = (q % BS) == tid;
+            if (own) { scannedm |= (1ull << sj); sd[jp] = make_float2(vjp + dmin, dmin); }
+            if constexpr (VEC) {   // sj is wave-uniform: indirect register addressing
+                const float vo = vmV[sj], dq = dV[sj];
+                vmV[sj] = own ? -INFINITY : vo;
+                dV[sj] = own ? INFINITY : dq;
+            } else {
 #pragma unroll
-            for (int sl = 0; sl < NC; sl++) {
-                const bool hit = own && (sl == sj);
-                vm[sl] = hit ? -INFINITY : vm[sl];
-                dreg[sl] = hit ? INFINITY : dreg[sl];
+                for (int sl = 0; sl < NC; sl++) {
+                    const bool hit = own && (sl == sj);
+                    VM(sl) = hit ? -INFINITY : VM(sl);
+                    DR(sl) = hit ? INFINITY : DR(sl);
+                }
             }
         }
+        AP_STAMP(3)
         if (skip) {
 #pragma unroll
-            for (int m = 0; m < CH; m++)
-                cm[m] = fmin_raw(fmin_raw(dreg[m * 4], dreg[m * 4 + 1]), fmin_raw(dreg[m * 4 + 2], dreg[m * 4 + 3]));
+            for (int m = 0; m < CH; m++) cm[m] = fmin_raw(fmin3_raw(DR(m * 4), DR(m * 4 + 1), DR(m * 4 + 2)), DR(m * 4 + 3));
             c_relax++;
             c_skipped++;
+            AP_STAMP(6)
             continue;
         }
+        AP_WAITVM
+        AP_STAMP(4)
+        const f32x2 hh = {h, h};
 #pragma unroll
         for (int m = 0; m < CH; m++) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int sl = m * 4 + e;
-                const float v2 = (vec_get<float>(x[m], e) - vm[sl]) - h;
-                const bool upd = v2 < dreg[sl];
-                dreg[sl] = upd ? v2 : dreg[sl];
-                preg[sl] = upd ? i : preg[sl];
-            }
-            cm[m] = fmin_raw(fmin_raw(dreg[m * 4], dreg[m * 4 + 1]), fmin_raw(dreg[m * 4 + 2], dreg[m * 4 + 3]));
+            const f32x2 x01 = {x[m].x, x[m].y}, x23 = {x[m].z, x[m].w};
+            const f32x2 v01 = {vmV[4 * m], vmV[4 * m + 1]}, v23 = {vmV[4 * m + 2], vmV[4 * m + 3]};
+            const f32x2 a = (x01 - v01) - hh, b = (x23 - v23) - hh;
+            dV[4 * m] = fmin_raw(dV[4 * m], a[0]);
+            dV[4 * m + 1] = fmin_raw(dV[4 * m + 1], a[1]);
+            dV[4 * m + 2] = fmin_raw(dV[4 * m + 2], b[0]);
+            dV[4 * m + 3] = fmin_raw(dV[4 * m + 3], b[1]);
+            cm[m] = fmin_raw(fmin3_raw(dV[4 * m], dV[4 * m + 1], dV[4 * m + 2]), dV[4 * m + 3]);
             SCHED_FENCE();
         }
         c_relax++;
+        AP_STAMP(5)
     }
-    // price update (columns scanned at an earlier level than the final one) and pred hand-off
-#pragma unroll
-    for (int sl = 0; sl < NC; sl++)
-        if ((readym >> sl) & 1) st_vset<LDS_STATE>(s_v, gv, SLOT_COL(sl), sumvd[SLOT_COL(sl)] - curmin);
+    // ---- the augmenting path, from the end column back to the free row (prices are still the search's prices) ----
+    __syncthreads();   // the scan log and the retired columns' records are complete
+    AP_START
     {
-        const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(pred, 0, n * 4, 0x00020000);
+        int ep = endofpath;
+        float dep = curmin;                                   // the end column's distance is the final minimum
+        for (;;) {
+            const float vep = st_vget<LDS_STATE>(s_v, gv, ep);
+            // candidates in the oracle's order: entry 0 = the free row's initial scan (offset 0: fl(x - 0) = x), entry k + 1
+            // = logged scan k.  Up to 8 gathers of c[row][ep] in flight per lane: one pass for <= 4095 scans.
+            uint32_t first = 0xFFFFFFFFu;
+            float cfirst = 0.0f;
+            for (int e0 = 0; e0 <= nlog; e0 += 8 * BS) {
+                float cv[8], hv[8];
 #pragma unroll
-        for (int m = 0; m < CH; m++) {
-            const u32x4_t t = {(uint32_t)preg[m * 4], (uint32_t)preg[m * 4 + 1], (uint32_t)preg[m * 4 + 2], (uint32_t)preg[m * 4 + 3]};
-            __builtin_amdgcn_raw_buffer_store_b128(t, pr, tid * 16, m * BLOCK2 * 16, 0);
+                for (int t = 0; t < 8; t++) {
+                    const int e = e0 + t * BS + tid;
+                    const bool in = e >= 1 && e <= nlog;
+                    const int row = in ? ld_i32(slog_row + e - 1) : freerow;
+                    hv[t] = in ? ld_f32(slog_h + e - 1) : 0.0f;
+                    cv[t] = cost[(int64_t)row * ld + ep];
+                }
+#pragma unroll
+                for (int t = 7; t >= 0; t--) {
+                    const int e = e0 + t * BS + tid;
+                    if (e <= nlog && ((cv[t] - vep) - hv[t]) == dep) { first = umin32(first, (uint32_t)e); if (first == (uint32_t)e) cfirst = cv[t]; }
+                }
+                if (__syncthreads_or(first != 0xFFFFFFFFu)) break;   // a match in this pass precedes every later entry
+            }
+            const uint32_t f = wg_min_u32<NWV>(first, s, par);
+            if (f == 0xFFFFFFFFu) return CYTO_ERR_INTERNAL;
+            const int i = f == 0u ? freerow : __builtin_amdgcn_readfirstlane(ld_i32(slog_row + (int)f - 1));
+            const int nxt = __builtin_amdgcn_readfirstlane(ld_i32(rowsol + i));
+            __builtin_amdgcn_s_barrier();                     // every wave holds the old rowsol[i] before it is overwritten
+            if (first == f) {                                 // the lane that evaluated the winning entry holds c[i][ep]
+                st_csset<LDS_STATE>(s_cs, gcolsol, ep, i);
+                if (s_ca) s_ca[ep] = cfirst; else st_f32(cassign + ep, cfirst);
+                if (gmode) { const int gi = rowgid[i]; if (s_cg) s_cg[ep] = (uint16_t)gi; else st_i32(colgroup + ep, gi); }
+                st_i32(rowsol + i, ep);
+            }
+            c_hops++;
+            if (i == freerow) break;
+            ep = nxt;
+            dep = ld_f32(&sd[ep].y);                          // the distance this (scanned) column was retired at
         }
     }
-    __syncthreads();  // pred stores and price updates of all waves are complete
-    if (tid == 0) {
-        int ep = endofpath, i;
-        do {
-            i = ld_i32(pred + ep);
-            st_csset<LDS_STATE>(s_cs, gcolsol, ep, i);
-            const float cie = cost[(int64_t)i * ld + ep];
-            if (s_ca) s_ca[ep] = cie; else st_f32(cassign + ep, cie);
-            if (gmode) { const int gi = rowgid[i]; if (s_cg) s_cg[ep] = (uint16_t)gi; else st_i32(colgroup + ep, gi); }
-            const int j1 = ep;
-            ep = ld_i32(rowsol + i);
-            st_i32(rowsol + i, j1);
-            c_hops++;
-        } while (i != freerow);
-    }
+    // price update: columns scanned at an earlier level than the final one.  (LDS prices: every lane updates its own
+    // columns, nobody reads another lane's before the barrier below.)
+#pragma unroll
+    for (int sl = 0; sl < NC; sl++)
+        if ((readym >> sl) & 1) st_vset<LDS_STATE>(s_v, gv, SLOT_COL(sl), ld_f32(&sd[SLOT_COL(sl)].x) - curmin);
     __syncthreads();
+    AP_STAMP(7)
+    AP_FLUSH
+#undef VM
+#undef DR
+#undef SLOT_COL
+#define SLOT_COL(sl) ((((sl) / 4) * BLOCK2 + tid) * 4 + ((sl) % 4))
     return 0;
 }
 
@@ -1483,7 +1649,8 @@ enum { PH_RT = 0, PH_ARR = 1, PH_AUG = 2 };
 // the chain then never stores colsol to global memory (on gfx9 a load is not returned before the stores issued
 // ahead of it are acknowledged, so every global store in the step delays the next step's gathers).
 template <int CH, bool LDS_STATE, bool CS_LDS = false>
-__global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
+__global__ __launch_bounds__(BLOCK2) void jv_chain2(const Chain2Args *__restrict__ batch) {
+    const Chain2Args a = batch[blockIdx.x];      // one workgroup per problem of the batch
     constexpr int NC = CH * 4;
     constexpr bool CSL = LDS_STATE || CS_LDS;     // colsol lives in LDS
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
@@ -1743,19 +1910,28 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(Chain2Args a) {
 }
 
 // AUGMENTATION + duals + total: one persistent workgroup, all lanes active (see chain_augment).
-template <int CH, bool LDS_STATE>
-__global__ __launch_bounds__(BLOCK2) void jv_aug2(Chain2Args a) {
+// (BS is a parameter because a 256-thread variant -- one wave per SIMD, twice the columns per lane -- was measured: not faster,
+// a lone wave per SIMD exposes the latency of every dependent instruction.)
+template <int CH, bool LDS_STATE, int BS = BLOCK2>
+__global__ __launch_bounds__(BS) void jv_aug2(const Chain2Args *__restrict__ batch) {
+    const Chain2Args a = batch[blockIdx.x];      // one workgroup per problem of the batch
+#undef SLOT_COL
+#define SLOT_COL(sl) ((((sl) / 4) * BS + tid) * 4 + ((sl) % 4))
     constexpr int NC = CH * 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     __shared__ Scratch2 s;
+    __shared__ PickRec s_rec[2][NW2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = a.n;
     const int64_t ld = a.ld;
     const float *__restrict__ cost = a.cost;
     float *gv = a.fws;
-    float *sumvd = a.fws + 2 * (int64_t)n;
+    // per retired column (v + d, d) of the current search: the 2n floats behind cassign (jv_aug_lazy's distance words,
+    // dead once this kernel runs); scan log: rows in the old predecessor slot, offsets in the old sumvd slot
+    float2 *sd = reinterpret_cast<float2 *>(a.fws + 4 * (int64_t)n);
+    float *slog_h = a.fws + 2 * (int64_t)n;
     int32_t *rowsol = a.iws, *gcolsol = a.iws + n;
-    int32_t *freerows = a.iws + 3 * (int64_t)n, *pred = a.iws + 5 * (int64_t)n;
+    int32_t *freerows = a.iws + 3 * (int64_t)n, *slog_row = a.iws + 5 * (int64_t)n;
     const int npad = (n + 3) & ~3;
     float *s_v = reinterpret_cast<float *>(dyn_lds);
     uint16_t *s_cs = reinterpret_cast<uint16_t *>(dyn_lds + (size_t)npad * 4);
@@ -1764,7 +1940,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug2(Chain2Args a) {
 #pragma unroll
     for (int sl = 0; sl < NC; sl++) if (SLOT_COL(sl) < n) validm |= (1ull << sl);
     if constexpr (LDS_STATE) {
-        for (int c = tid; c < npad; c += BLOCK2) {
+        for (int c = tid; c < npad; c += BS) {
             s_v[c] = c < n ? gv[c] : 0.0f;
             const int32_t cs = c < n ? gcolsol[c] : -1;
             s_cs[c] = cs < 0 ? (uint16_t)0xFFFFu : (uint16_t)cs;
@@ -1777,7 +1953,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug2(Chain2Args a) {
     if (gmode == 1) {
         hb = reinterpret_cast<float *>(dyn_lds + (size_t)npad * 6);
         hs = reinterpret_cast<int32_t *>(dyn_lds + (size_t)npad * 6 + (size_t)a.ngroups * 4);
-        for (int g = tid; g < a.ngroups; g += BLOCK2) hs[g] = 0;
+        for (int g = tid; g < a.ngroups; g += BS) hs[g] = 0;
     }
     float *cassign = a.fws + 3 * (int64_t)n;
     // per-column auxiliaries (assigned cost, owner's row group) in LDS when they fit (a.auxlds)
@@ -1786,7 +1962,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug2(Chain2Args a) {
     if (a.aug_start > 0 && gmode) {
         // continuing after jv_aug_lazy, which keeps no per-column group array: rebuild it from the assignment
         int32_t *colgroup = a.iws + 6 * (int64_t)n;
-        for (int c = tid; c < n; c += BLOCK2) { const int32_t r = gcolsol[c]; colgroup[c] = r >= 0 ? a.rowgid[r] : 0; }
+        for (int c = tid; c < n; c += BS) { const int32_t r = gcolsol[c]; colgroup[c] = r >= 0 ? a.rowgid[r] : 0; }
         __syncthreads();
     }
     if (a.auxlds) {
@@ -1794,7 +1970,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug2(Chain2Args a) {
         s_ca = reinterpret_cast<float *>(dyn_lds + ((off + 15) & ~(size_t)15));
         s_cg = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(s_ca) + (size_t)npad * 4);
         const int32_t *colgroup = a.iws + 6 * (int64_t)n;
-        for (int c = tid; c < n; c += BLOCK2) { s_ca[c] = cassign[c]; s_cg[c] = (uint16_t)(gmode ? colgroup[c] : 0); }
+        for (int c = tid; c < n; c += BS) { s_ca[c] = cassign[c]; s_cg[c] = (uint16_t)(gmode ? colgroup[c] : 0); }
     }
     __syncthreads();
     const int numfree = *reinterpret_cast<const int *>(a.misc + 128);
@@ -1808,13 +1984,13 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug2(Chain2Args a) {
     int err = 0;
     for (int f = a.aug_start; f < numfree && !err; f++) {
         const int freerow = __builtin_amdgcn_readfirstlane(ld_i32(freerows + f));
-        err = chain_augment<CH, LDS_STATE>(n, ld, cost, gv, sumvd, cassign, rowsol, gcolsol, pred, s_v, s_cs, freerow, validm, s,
-                                           par, c_relax, c_hops, c_skipped, gmode, a.rowgid, a.iws + 6 * (int64_t)n, hb, hs, f + 1, s_ca, s_cg);
+        err = chain_augment<CH, LDS_STATE, BS>(n, ld, cost, gv, sd, cassign, rowsol, gcolsol, slog_row, slog_h, s_v, s_cs, freerow, validm, s,
+                                           par, c_relax, c_hops, c_skipped, gmode, a.rowgid, a.iws + 6 * (int64_t)n, hb, hs, f + 1, s_ca, s_cg, s_rec);
         c_augs++;
     }
     // ---- write back prices and colsol, then duals u and the total ----
     if constexpr (LDS_STATE) {
-        for (int c = tid; c < n; c += BLOCK2) {
+        for (int c = tid; c < n; c += BS) {
             gv[c] = s_v[c];
             const uint16_t cs = s_cs[c];
             gcolsol[c] = cs == 0xFFFFu ? -1 : (int32_t)cs;
@@ -1823,7 +1999,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug2(Chain2Args a) {
     __syncthreads();
     float *gu = a.fws + n;
     double part = 0.0;
-    for (int i = tid; i < n; i += BLOCK2) {
+    for (int i = tid; i < n; i += BS) {
         const int j = ld_i32(rowsol + i);
         const float cij = cost[(int64_t)i * ld + j];
         const float vj = ld_f32(gv + j);
@@ -1836,7 +2012,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug2(Chain2Args a) {
     __syncthreads();
     if (tid == 0) {
         double t = 0.0;
-        for (int w = 0; w < NW2; w++) t += s.sum[w];
+        for (int w = 0; w < BS / 64; w++) t += s.sum[w];
         *reinterpret_cast<double *>(a.misc + 8) = t;
         long long *counters = reinterpret_cast<long long *>(a.misc + 16);
         counters[C_AUG_INIT] = c_augs; counters[C_AUG_RELAX] = c_relax; counters[C_AUGS] = c_augs; counters[C_HOPS] = c_hops;
@@ -1847,555 +2023,13 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug2(Chain2Args a) {
     }
 }
 #undef SLOT_COL
+#define SLOT_COL(sl) ((((sl) / 4) * BLOCK2 + tid) * 4 + ((sl) % 4))
+#undef SLOT_COL
 
 // ------------------------------------------------------------------------------------------
-// Streaming augmentation for large n (prices/distances do not fit the register+LDS budget of jv_aug2).
-// Same search, same pick rule, same results; every per-column quantity lives in (L2-resident) global
-// memory and each step is two coalesced sweeps by 1024 threads:
-//   sweep A  relax through the picked row (cost row from HBM; vwork, d, pred from L2) fused with the
-//            running minimum of d (lowest column on ties: columns are visited in ascending order per lane)
-//   sweep B  the (few) still unassigned columns: an unassigned column whose d equals the minimum wins
-// vwork is the price vector with scanned columns masked to -inf (their relaxation becomes a no-op).
-// ------------------------------------------------------------------------------------------
-constexpr int BLOCK3 = 1024;
 constexpr int FAST_NMAX = 1 << 18;   // float32 cached-chain path (index arithmetic is 32-bit in bytes per row)
-constexpr int NW3 = BLOCK3 / 64;
-
-struct AugStreamArgs {
-    int n;
-    int64_t ld;
-    const float *cost;
-    float *gv, *gu, *sumvd, *cassign, *vwork, *d;     // [n] each
-    int32_t *rowsol, *colsol, *freerows, *pred, *colgroup, *ulist, *slist, *slevel;   // [n] each
-    const int32_t *rowgid;
-    float *g_hbest; int32_t *g_hstamp;                 // gmode 2
-    char *misc;
-    int ngroups, gmode;
-};
-
-__device__ __forceinline__ uint64_t wg3_min64(uint64_t x, uint64_t *buf /* [2][NW3] */, int &par) {
-    x = min64_wave_allreduce(x);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) buf[par * NW3 + w] = x;
-    lds_barrier();                       // LDS hand-off only: no wait for this wave's global stores
-    uint64_t r = buf[par * NW3 + (lane & (NW3 - 1))];
-    r = min64_row_allreduce(r);
-    par ^= 1;
-    return readlane64(r, 0);
-}
-
-// Ownership rule that makes the sweeps barrier-free: column c is read and written ONLY by lane
-// ((c >> 2) % BLOCK3) during a search (d, vwork, pred), so program order of that lane is all the ordering
-// needed; the unassigned-column bitmap and the per-group offsets live in LDS.
-__global__ __launch_bounds__(BLOCK3) void jv_aug_stream(AugStreamArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    __shared__ uint64_t s_red[2 * NW3];
-    __shared__ double s_sum[NW3];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = a.n;
-    const int64_t ld = a.ld;
-    const float *__restrict__ cost = a.cost;
-    const int nqfull = n >> 2;                         // float4 chunks completely inside [0, n)
-    const int nwords = (n + 31) >> 5;
-    int par = 0;
-    const int gmode = a.gmode;
-    uint32_t *s_un = reinterpret_cast<uint32_t *>(dyn_lds);               // bit c set: column c unassigned
-    float *hb = a.g_hbest;
-    int32_t *hs = a.g_hstamp;
-    if (gmode == 1) {
-        hb = reinterpret_cast<float *>(dyn_lds + (size_t)nwords * 4);
-        hs = reinterpret_cast<int32_t *>(dyn_lds + (size_t)nwords * 4 + (size_t)a.ngroups * 4);
-        for (int g = tid; g < a.ngroups; g += BLOCK3) hs[g] = 0;
-    }
-    for (int w = tid; w < nwords; w += BLOCK3) {
-        uint32_t m = 0;
-        for (int b = 0; b < 32; b++) { const int c = w * 32 + b; if (c < n && a.colsol[c] < 0) m |= (1u << b); }
-        s_un[w] = m;
-    }
-    __syncthreads();
-    const int numfree = *reinterpret_cast<const int *>(a.misc + 128);
-    long long c_relax = 0, c_hops = 0, c_augs = 0, c_skipped = 0;
-    int err = 0;
-    const float4 *vp = reinterpret_cast<const float4 *>(a.vwork);
-    float4 *dp = reinterpret_cast<float4 *>(a.d);
-
-    for (int f = 0; f < numfree && !err; f++) {
-        const int freerow = a.freerows[f];
-        const int stamp = f + 1;
-        // running minima of this lane: over all its columns, and over its unassigned columns
-        float bestv = INFINITY, bestu = INFINITY;
-        int bestc = -1, bestuc = -1;
-#define TRACK(dd, c, ubit)                                         \
-    { if ((dd) < bestv) { bestv = (dd); bestc = (c); }             \
-      if ((ubit) && (dd) < bestu) { bestu = (dd); bestuc = (c); } }
-        // ---- initialise d = c[freerow] - v, pred = freerow, vwork = v ----
-        {
-            const float *rowp = cost + (int64_t)freerow * ld;
-            for (int q = tid; q * 4 < n; q += BLOCK3) {
-                const uint32_t um = s_un[q >> 3] >> ((q & 7) * 4);
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int c = q * 4 + e;
-                    if (c < n) {
-                        const float vv = a.gv[c];
-                        const float dd = rowp[c] - vv;
-                        a.d[c] = dd; a.pred[c] = freerow; a.vwork[c] = vv;
-                        TRACK(dd, c, (um >> e) & 1u)
-                    }
-                }
-            }
-        }
-        bool have = false;
-        float curmin = 0.0f;
-        int endofpath = -1, level = 0, nscan = 0;
-        int pend_g = -1;
-        float pend_h = 0.0f;
-        for (;;) {
-            // ---- pick: smallest d, an unassigned column first among equals, then the lowest column ----
-            uint64_t key = KEYMAX;
-            if (bestc >= 0) {
-                if (bestuc >= 0 && bestu == bestv) key = mkkey(bestu, (uint32_t)bestuc);
-                else key = mkkey(bestv, (uint32_t)bestc | 0x80000000u);
-                // (a lane's overall best may be unassigned with bestu == bestv: handled by the first branch)
-            }
-            const uint64_t g = wg3_min64(key, s_red, par);
-            const float dmin = key_val(g);
-            if (g == KEYMAX || !(dmin < INFINITY)) { err = CYTO_ERR_INTERNAL; break; }
-            if (pend_g >= 0) {
-                if (tid == 0) { if (gmode == 1) { hb[pend_g] = pend_h; hs[pend_g] = stamp; } else { st_f32(hb + pend_g, pend_h); st_i32(hs + pend_g, stamp); } }
-                pend_g = -1;
-            }
-            const int jp = (int)((uint32_t)g & 0x7FFFFFFFu);
-            if (!have || dmin != curmin) { level++; curmin = dmin; have = true; }
-            if (!((uint32_t)g & 0x80000000u)) { endofpath = jp; break; }
-            // ---- scan column jp through its row ----
-            const int i = a.colsol[jp];
-            const float cip = a.cassign[jp];
-            const float vjp = a.gv[jp];
-            const float h = (cip - vjp) - curmin;
-            bool skip = false;
-            if (gmode) {
-                const int gq = a.colgroup[jp];
-                float hbv; int hsv;
-                if (gmode == 1) { hbv = hb[gq]; hsv = hs[gq]; } else { hbv = ld_f32(hb + gq); hsv = ld_i32(hs + gq); }
-                skip = (hsv == stamp) && (h <= hbv);
-                if (!skip) { pend_g = gq; pend_h = h; }
-            }
-            if (tid == 0) { a.sumvd[jp] = vjp + dmin; a.slist[nscan] = jp; a.slevel[nscan] = level; }
-            nscan++;
-            if (((jp >> 2) % BLOCK3) == tid) { a.d[jp] = INFINITY; a.vwork[jp] = -INFINITY; }   // the owner masks it
-            bestv = INFINITY; bestu = INFINITY; bestc = -1; bestuc = -1;
-            if (!skip) {
-                const float4 *rp = reinterpret_cast<const float4 *>(cost + (int64_t)i * ld);
-                // batches of 4 chunks per lane: all 12 loads are issued before the first use
-                for (int q0 = tid; q0 < nqfull; q0 += 4 * BLOCK3) {
-                    float4 x[4], vv[4], dd[4];
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const int q = q0 + t * BLOCK3;
-                        if (q < nqfull) { x[t] = rp[q]; vv[t] = vp[q]; dd[t] = dp[q]; }
-                    }
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const int q = q0 + t * BLOCK3;
-                        if (q < nqfull) {
-                            const int c0 = q * 4;
-                            const uint32_t um = s_un[q >> 3] >> ((q & 7) * 4);
-                            const float v0 = (x[t].x - vv[t].x) - h, v1 = (x[t].y - vv[t].y) - h;
-                            const float v2 = (x[t].z - vv[t].z) - h, v3 = (x[t].w - vv[t].w) - h;
-                            const bool u0 = v0 < dd[t].x, u1 = v1 < dd[t].y, u2 = v2 < dd[t].z, u3 = v3 < dd[t].w;
-                            if (u0 | u1 | u2 | u3) {
-                                dd[t].x = u0 ? v0 : dd[t].x; dd[t].y = u1 ? v1 : dd[t].y;
-                                dd[t].z = u2 ? v2 : dd[t].z; dd[t].w = u3 ? v3 : dd[t].w;
-                                dp[q] = dd[t];
-                                if (u0) a.pred[c0] = i;
-                                if (u1) a.pred[c0 + 1] = i;
-                                if (u2) a.pred[c0 + 2] = i;
-                                if (u3) a.pred[c0 + 3] = i;
-                            }
-                            TRACK(dd[t].x, c0, um & 1u)
-                            TRACK(dd[t].y, c0 + 1, (um >> 1) & 1u)
-                            TRACK(dd[t].z, c0 + 2, (um >> 2) & 1u)
-                            TRACK(dd[t].w, c0 + 3, (um >> 3) & 1u)
-                        }
-                    }
-                }
-                if (tid == (nqfull % BLOCK3)) {       // ragged tail (n % 4 columns) belongs to the lane that owns chunk nqfull
-                    for (int c = nqfull * 4; c < n; c++) {
-                        const float v2 = (cost[(int64_t)i * ld + c] - a.vwork[c]) - h;
-                        float dd = a.d[c];
-                        if (v2 < dd) { dd = v2; a.d[c] = v2; a.pred[c] = i; }
-                        TRACK(dd, c, (s_un[c >> 5] >> (c & 31)) & 1u)
-                    }
-                }
-            } else {
-                for (int q = tid; q < nqfull; q += BLOCK3) {
-                    const float4 dd = dp[q];
-                    const int c0 = q * 4;
-                    const uint32_t um = s_un[q >> 3] >> ((q & 7) * 4);
-                    TRACK(dd.x, c0, um & 1u)
-                    TRACK(dd.y, c0 + 1, (um >> 1) & 1u)
-                    TRACK(dd.z, c0 + 2, (um >> 2) & 1u)
-                    TRACK(dd.w, c0 + 3, (um >> 3) & 1u)
-                }
-                if (tid == (nqfull % BLOCK3)) {
-                    for (int c = nqfull * 4; c < n; c++) { const float dd = a.d[c]; TRACK(dd, c, (s_un[c >> 5] >> (c & 31)) & 1u) }
-                }
-                c_skipped++;
-            }
-            c_relax++;
-        }
-#undef TRACK
-        if (err) break;
-        // ---- price update: columns scanned at an earlier level than the final one ----
-        __syncthreads();
-        for (int k = tid; k < nscan; k += BLOCK3)
-            if (a.slevel[k] < level) { const int j = a.slist[k]; a.gv[j] = a.sumvd[j] - curmin; }
-        __syncthreads();
-        if (tid == 0) {
-            int ep = endofpath, i;
-            do {
-                i = a.pred[ep];
-                a.colsol[ep] = i;
-                a.cassign[ep] = cost[(int64_t)i * ld + ep];
-                if (gmode) a.colgroup[ep] = a.rowgid[i];
-                const int j1 = ep;
-                ep = a.rowsol[i];
-                a.rowsol[i] = j1;
-                c_hops++;
-            } while (i != freerow);
-            s_un[endofpath >> 5] &= ~(1u << (endofpath & 31));     // no longer unassigned
-        }
-        c_augs++;
-        __syncthreads();
-    }
-    // ---- duals u and the total ----
-    double part = 0.0;
-    for (int i = tid; i < n; i += BLOCK3) {
-        const int j = a.rowsol[i];
-        const float cij = cost[(int64_t)i * ld + j];
-        a.gu[i] = cij - a.gv[j];
-        part += (double)cij;
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
-    if (lane == 0) s_sum[wave] = part;
-    __syncthreads();
-    if (tid == 0) {
-        double t = 0.0;
-        for (int w = 0; w < NW3; w++) t += s_sum[w];
-        *reinterpret_cast<double *>(a.misc + 8) = t;
-        long long *counters = reinterpret_cast<long long *>(a.misc + 16);
-        counters[C_AUG_INIT] = c_augs; counters[C_AUG_RELAX] = c_relax; counters[C_AUGS] = c_augs; counters[C_HOPS] = c_hops;
-        counters[C_ROWS_READ] = counters[C2_DENSE_REFRESH] + c_augs + c_relax - c_skipped;
-        counters[C2_AUG_SKIPPED] = c_skipped;
-        *reinterpret_cast<int *>(a.misc + 4) = err;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Cooperative augmentation: W single-wave workers on W compute units, each owning a contiguous slice of
-// 4*QW columns (d, masked price, pred, colsol, ... in its own LDS).  A row scan is split W ways, so the
-// per-step HBM fetch is n/W columns per CU instead of n.  The replicated control state (level, curmin,
-// duplicate-row table, path walk) is kept identical on every worker by ONE all-to-all exchange per step:
-// every worker publishes its local candidate as a data-tagged record {key, hp, row, group} (agent-scope
-// 8-byte stores, double-buffered by round parity) and polls the W records; the winner is the 64-bit
-// minimum, exactly the oracle's lexicographic (d, assigned?, column) pick.  A worker can be at most one
-// round ahead of the slowest one, so two record buffers suffice; spins are bounded (abort flag).
-// Workers are launched as blocks b with b % stride == 0 (stride 8: all on one XCD -> one shared L2).
-// ------------------------------------------------------------------------------------------
-struct CoopArgs {
-    int n;
-    int64_t ld;
-    const float *cost;
-    float *gv, *cassign;
-    int32_t *rowsol, *colsol, *freerows, *colgroup;
-    const int32_t *rowgid;
-    float *g_hbest; int32_t *g_hstamp;     // gmode 2: [W][ngroups] private tables in global memory
-    char *misc;
-    uint64_t *slots;                       // [2][64][4]
-    int *abort_flag;
-    int ngroups, gmode;
-    int W, stride, QW;
-};
-constexpr uint32_t COOP_KEYLO_MAX = 0xFFFFFF00u;
 __device__ __forceinline__ uint64_t ld_u64(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_u64(uint64_t *p, uint64_t x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-struct CoopRec { uint64_t a, b, c; };
-// publish my record for round t and collect everybody's; returns the winning record (uniform), false on abort
-__device__ __forceinline__ bool coop_exchange(const CoopArgs &a, int w, int lane, uint32_t t, uint64_t ka, uint64_t kb, uint64_t kc,
-                                              CoopRec &win, uint64_t &second_a) {
-    const uint32_t tag = t & 0xFFu;
-    uint64_t *my = a.slots + ((size_t)(t & 1u) * 64 + w) * 4;
-    if (lane == 0) { st_u64(my + 1, kb | tag); st_u64(my + 2, kc | tag); st_u64(my, ka | tag); }
-    const uint64_t *peer = a.slots + ((size_t)(t & 1u) * 64 + lane) * 4;
-    uint64_t pa = ((uint64_t)0xFFFFFFFFu << 32) | COOP_KEYLO_MAX | tag, pb = tag, pc = tag;
-    const long long spin0 = wall_clock64();
-    int it = 0;
-    for (;;) {
-        bool ok = true;
-        if (lane < a.W) {
-            pa = ld_u64(peer); pb = ld_u64(peer + 1); pc = ld_u64(peer + 2);
-            ok = ((uint32_t)pa & 0xFFu) == tag && ((uint32_t)pb & 0xFFu) == tag && ((uint32_t)pc & 0xFFu) == tag;
-        }
-        if (__ballot(ok) == ~0ull) break;
-        if ((++it & 255) == 0) {
-            if (wall_clock64() - spin0 > 200000000LL) { if (lane == 0) atomicExch(a.abort_flag, 1); return false; }   // 2 s
-            if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-        }
-    }
-    K2 k; k.m1 = pa; k.m2 = KEYMAX;
-    k = k2_wave_allreduce(k);
-    const int wl = __builtin_ctzll(__ballot(pa == k.m1));
-    win.a = k.m1;
-    win.b = readlane64(pb, wl);
-    win.c = readlane64(pc, wl);
-    second_a = k.m2;
-    return true;
-}
-
-__global__ __launch_bounds__(64) void jv_aug_coop(CoopArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    if (blockIdx.x % a.stride) return;
-    const int w = blockIdx.x / a.stride;
-    if (w >= a.W) return;
-    const int lane = threadIdx.x;
-    const int n = a.n;
-    const int64_t ld = a.ld;
-    const float *__restrict__ cost = a.cost;
-    const int C = 4 * a.QW;                              // columns per worker (LDS arrays are this long)
-    const int c_lo = min(n, w * C);
-    const int ncols = max(0, min(n, c_lo + C) - c_lo);
-    const int nq = (ncols + 3) >> 2;                     // quads that hold at least one valid column
-    float *s_d = reinterpret_cast<float *>(dyn_lds);
-    float *s_vw = s_d + C, *s_v = s_vw + C, *s_sumvd = s_v + C, *s_ca = s_sumvd + C;
-    int32_t *s_pred = reinterpret_cast<int32_t *>(s_ca + C), *s_cs = s_pred + C, *s_lvl = s_cs + C, *s_cg = s_lvl + C;
-    uint32_t *s_un = reinterpret_cast<uint32_t *>(s_cg + C);   // [(C+31)/32]   bit k: local column k unassigned
-    const int nwords = (C + 31) >> 5;
-    const int gmode = a.gmode;
-    float *hb = nullptr; int32_t *hs = nullptr;
-    if (gmode == 1) { hb = reinterpret_cast<float *>(s_un + nwords); hs = reinterpret_cast<int32_t *>(hb + a.ngroups); }
-    else if (gmode == 2) { hb = a.g_hbest + (size_t)w * a.ngroups; hs = a.g_hstamp + (size_t)w * a.ngroups; }
-    if (gmode == 1) for (int g = lane; g < a.ngroups; g += 64) hs[g] = 0;
-    if (gmode == 2) for (int g = lane; g < a.ngroups; g += 64) st_i32(hs + g, 0);
-    for (int k = lane; k < C; k += 64) {
-        const int c = c_lo + k;
-        const bool valid = k < ncols;
-        s_v[k] = valid ? a.gv[c] : 0.0f;
-        s_cs[k] = valid ? a.colsol[c] : 0;
-        s_ca[k] = valid ? a.cassign[c] : 0.0f;
-        s_cg[k] = (valid && gmode) ? a.colgroup[c] : 0;
-        s_lvl[k] = 0; s_d[k] = INFINITY; s_vw[k] = -INFINITY; s_sumvd[k] = 0.0f; s_pred[k] = -1;
-    }
-    __syncthreads();
-    for (int wd = lane; wd < nwords; wd += 64) {
-        uint32_t m = 0;
-        for (int b = 0; b < 32; b++) { const int k = wd * 32 + b; if (k < ncols && s_cs[k] < 0) m |= (1u << b); }
-        s_un[wd] = m;
-    }
-    __syncthreads();
-    const int numfree = *reinterpret_cast<const int *>(a.misc + 128);
-    long long c_relax = 0, c_hops = 0, c_augs = 0, c_skipped = 0;
-    int err = 0;
-    uint32_t t = 0;                                      // exchange round (identical on every worker)
-
-#define COOP_TRACK(dd, kk, ubit)                                    \
-    { if ((dd) < bestv) { bestv = (dd); bestk = (kk); }             \
-      if ((ubit) && (dd) < bestu) { bestu = (dd); bestuk = (kk); } }
-
-    for (int f = 0; f < numfree && !err; f++) {
-        const int freerow = a.freerows[f];
-        const int stamp = f + 1;
-        float bestv = INFINITY, bestu = INFINITY;
-        int bestk = -1, bestuk = -1;
-        // ---- d = c[freerow] - v, pred = freerow, vwork = v (my slice) ----
-        {
-            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float *>(cost + (int64_t)freerow * ld), 0, (int)(ld * 4), 0x00020000);
-            for (int q = lane; q < nq; q += 64) {
-                const u32x4_t xr = __builtin_amdgcn_raw_buffer_load_b128(rr, (c_lo + q * 4) * 4, 0, 0);
-                const float xs[4] = {__uint_as_float(xr.x), __uint_as_float(xr.y), __uint_as_float(xr.z), __uint_as_float(xr.w)};
-                const uint32_t um = s_un[q >> 3] >> ((q & 7) * 4);
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int k = q * 4 + e;
-                    if (k < ncols) {
-                        const float vv = s_v[k];
-                        const float dd = xs[e] - vv;
-                        s_d[k] = dd; s_pred[k] = freerow; s_vw[k] = vv;
-                        COOP_TRACK(dd, k, (um >> e) & 1u)
-                    }
-                }
-            }
-        }
-        bool have = false;
-        float curmin = 0.0f;
-        int endofpath = -1, level = 0;
-        for (;;) {
-            // ---- my candidate: smallest d, an unassigned column first among equals, then the lowest column ----
-            uint64_t key = KEYMAX;
-            if (bestk >= 0) {
-                if (bestuk >= 0 && bestu == bestv) key = mkkey(bestu, (uint32_t)(c_lo + bestuk) << 8);
-                else key = mkkey(bestv, ((uint32_t)(c_lo + bestk) << 8) | 0x80000000u);
-            }
-            key = min64_wave_allreduce(key);
-            uint64_t ka = ((uint64_t)0xFFFFFFFFu << 32) | COOP_KEYLO_MAX, kb = 0, kc = 0;
-            if (key != KEYMAX) {
-                ka = key;
-                if ((uint32_t)key & 0x80000000u) {
-                    const int kl = (int)(((uint32_t)key & 0x7FFFFFFFu) >> 8) - c_lo;
-                    const float hp = s_ca[kl] - s_v[kl];
-                    kb = ((uint64_t)__float_as_uint(hp) << 32) | ((uint32_t)s_cs[kl] << 8);
-                    kc = (uint64_t)(uint32_t)s_cg[kl] << 32;
-                }
-            }
-            CoopRec win; uint64_t second;
-            if (!coop_exchange(a, w, lane, t, ka, kb, kc, win, second)) { err = CYTO_ERR_INTERNAL; break; }
-            t++;
-            const float dmin = key_val(win.a);
-            if ((win.a >> 32) == 0xFFFFFFFFull || !(dmin < INFINITY)) { err = CYTO_ERR_INTERNAL; break; }
-            const int jp = (int)(((uint32_t)win.a & 0x7FFFFFFFu) >> 8);
-            if (!have || dmin != curmin) { level++; curmin = dmin; have = true; }
-            if (!((uint32_t)win.a & 0x80000000u)) { endofpath = jp; break; }
-            // ---- scan column jp through its row ----
-            const int i = (int)((uint32_t)win.b >> 8);
-            const float hp = __uint_as_float((uint32_t)(win.b >> 32));
-            const float h = hp - curmin;
-            bool skip = false;
-            if (gmode) {
-                const int gq = (int)(uint32_t)(win.c >> 32);
-                float hbv; int hsv;
-                if (gmode == 1) { hbv = hb[gq]; hsv = hs[gq]; } else { hbv = ld_f32(hb + gq); hsv = ld_i32(hs + gq); }
-                skip = (hsv == stamp) && (h <= hbv);
-                if (!skip && lane == 0) {
-                    if (gmode == 1) { hb[gq] = h; hs[gq] = stamp; } else { st_f32(hb + gq, h); st_i32(hs + gq, stamp); }
-                }
-            }
-            if (jp >= c_lo && jp < c_lo + ncols && lane == 0) {     // the owner retires it
-                const int kl = jp - c_lo;
-                s_lvl[kl] = level; s_sumvd[kl] = s_v[kl] + dmin; s_d[kl] = INFINITY; s_vw[kl] = -INFINITY;
-            }
-            bestv = INFINITY; bestu = INFINITY; bestk = -1; bestuk = -1;
-            if (!skip) {
-                const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<float *>(cost + (int64_t)i * ld), 0, (int)(ld * 4), 0x00020000);
-                for (int q0 = lane; q0 < nq; q0 += 64 * 8) {
-                    u32x4_t xr[8];
-#pragma unroll
-                    for (int b = 0; b < 8; b++) xr[b] = __builtin_amdgcn_raw_buffer_load_b128(rr, (c_lo + (q0 + b * 64) * 4) * 4, 0, 0);
-#pragma unroll
-                    for (int b = 0; b < 8; b++) {
-                        const int q = q0 + b * 64;
-                        if (q < nq) {
-                            const int k0 = q * 4;
-                            const float4 vv = *reinterpret_cast<const float4 *>(s_vw + k0);
-                            float4 dd = *reinterpret_cast<const float4 *>(s_d + k0);
-                            const uint32_t um = s_un[q >> 3] >> ((q & 7) * 4);
-                            const float v0 = (__uint_as_float(xr[b].x) - vv.x) - h, v1 = (__uint_as_float(xr[b].y) - vv.y) - h;
-                            const float v2 = (__uint_as_float(xr[b].z) - vv.z) - h, v3 = (__uint_as_float(xr[b].w) - vv.w) - h;
-                            const bool u0 = v0 < dd.x, u1 = v1 < dd.y, u2 = v2 < dd.z, u3 = v3 < dd.w;
-                            if (u0 | u1 | u2 | u3) {
-                                dd.x = u0 ? v0 : dd.x; dd.y = u1 ? v1 : dd.y; dd.z = u2 ? v2 : dd.z; dd.w = u3 ? v3 : dd.w;
-                                *reinterpret_cast<float4 *>(s_d + k0) = dd;
-                                if (u0) s_pred[k0] = i;
-                                if (u1) s_pred[k0 + 1] = i;
-                                if (u2) s_pred[k0 + 2] = i;
-                                if (u3) s_pred[k0 + 3] = i;
-                            }
-                            COOP_TRACK(dd.x, k0, um & 1u)
-                            COOP_TRACK(dd.y, k0 + 1, (um >> 1) & 1u)
-                            COOP_TRACK(dd.z, k0 + 2, (um >> 2) & 1u)
-                            COOP_TRACK(dd.w, k0 + 3, (um >> 3) & 1u)
-                        }
-                    }
-                }
-            } else {
-                for (int q = lane; q < nq; q += 64) {
-                    const int k0 = q * 4;
-                    const float4 dd = *reinterpret_cast<const float4 *>(s_d + k0);
-                    const uint32_t um = s_un[q >> 3] >> ((q & 7) * 4);
-                    COOP_TRACK(dd.x, k0, um & 1u)
-                    COOP_TRACK(dd.y, k0 + 1, (um >> 1) & 1u)
-                    COOP_TRACK(dd.z, k0 + 2, (um >> 2) & 1u)
-                    COOP_TRACK(dd.w, k0 + 3, (um >> 3) & 1u)
-                }
-                c_skipped++;
-            }
-            c_relax++;
-        }
-        if (err) break;
-        // ---- price update: my columns scanned at an earlier level than the final one ----
-        for (int k = lane; k < ncols; k += 64) {
-            const int lv = s_lvl[k];
-            if (lv != 0) { if (lv < level) s_v[k] = s_sumvd[k] - curmin; s_lvl[k] = 0; }
-        }
-        // ---- flip the alternating path: one exchange round per hop, driven by the owner of the column ----
-        int ep = endofpath;
-        for (;;) {
-            uint64_t ka = ((uint64_t)0xFFFFFFFFu << 32) | COOP_KEYLO_MAX, kb = 0, kc = 0;
-            if (ep >= c_lo && ep < c_lo + ncols) {
-                const int kl = ep - c_lo;
-                const int i = s_pred[kl];
-                int nxt = 0;
-                if (lane == 0) {
-                    s_cs[kl] = i;
-                    s_ca[kl] = cost[(int64_t)i * ld + ep];
-                    if (gmode) s_cg[kl] = a.rowgid[i];
-                    s_un[kl >> 5] &= ~(1u << (kl & 31));
-                    nxt = ld_i32(a.rowsol + i);
-                    st_i32(a.rowsol + i, ep);
-                }
-                nxt = __builtin_amdgcn_readfirstlane(nxt);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                ka = 0;
-                kb = ((uint64_t)(uint32_t)nxt << 32) | ((uint32_t)i << 8);
-            }
-            CoopRec win; uint64_t second;
-            if (!coop_exchange(a, w, lane, t, ka, kb, kc, win, second)) { err = CYTO_ERR_INTERNAL; break; }
-            t++;
-            if ((win.a >> 32) != 0) { err = CYTO_ERR_INTERNAL; break; }
-            const int i = (int)((uint32_t)win.b >> 8);
-            ep = (int)(uint32_t)(win.b >> 32);
-            c_hops++;
-            if (i == freerow) break;
-        }
-        c_augs++;
-    }
-#undef COOP_TRACK
-    // ---- write my slice of the prices and the column assignment back ----
-    for (int k = lane; k < ncols; k += 64) { a.gv[c_lo + k] = s_v[k]; a.colsol[c_lo + k] = s_cs[k]; }
-    if (w == 0 && lane == 0) {
-        long long *counters = reinterpret_cast<long long *>(a.misc + 16);
-        counters[C_AUG_INIT] = c_augs; counters[C_AUG_RELAX] = c_relax; counters[C_AUGS] = c_augs; counters[C_HOPS] = c_hops;
-        counters[C_ROWS_READ] = counters[C2_DENSE_REFRESH] + c_augs + c_relax - c_skipped;
-        counters[C2_AUG_SKIPPED] = c_skipped;
-    }
-    if (err && lane == 0) *reinterpret_cast<int *>(a.misc + 4) = err;
-}
-
-// duals u and the total after the cooperative augmentation (needs every worker's write-back: own launch)
-__global__ __launch_bounds__(BLOCK3) void jv_finish_duals(int n, int64_t ld, const float *__restrict__ cost, const float *__restrict__ gv,
-                                                         float *__restrict__ gu, const int32_t *__restrict__ rowsol, char *misc) {
-    __shared__ double s_sum[NW3];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double part = 0.0;
-    for (int i = tid; i < n; i += BLOCK3) {
-        const int j = rowsol[i];
-        const float cij = cost[(int64_t)i * ld + j];
-        gu[i] = cij - gv[j];
-        part += (double)cij;
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
-    if (lane == 0) s_sum[wave] = part;
-    __syncthreads();
-    if (tid == 0) {
-        double tt = 0.0;
-        for (int w = 0; w < NW3; w++) tt += s_sum[w];
-        *reinterpret_cast<double *>(misc + 8) = tt;
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // Cache-certified augmentation ("lazy" Dijkstra): the row caches also serve the augmentation.
@@ -2482,7 +2116,8 @@ __device__ __forceinline__ uint64_t wave_lexmin_u64(uint64_t k) {
 }
 // LDS_STATE: prices and colsol in LDS; CS_LDS (with !LDS_STATE, n <= 65535): colsol (u16) in LDS, prices in L2
 template <bool LDS_STATE, bool CS_LDS = false>
-__global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
+__global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(const LazyArgs *__restrict__ batch) {
+    const LazyArgs a = batch[blockIdx.x];        // one workgroup per problem of the batch
     constexpr bool CSL = LDS_STATE || CS_LDS;
 #ifdef LZ_PROF
     long long prof[6] = {0, 0, 0, 0, 0, 0}, profn[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
@@ -3045,390 +2680,445 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(LazyArgs a) {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-struct CoopPlan { bool enabled; CoopArgs args; size_t shm; };
-struct LazyPlan { bool enabled, lds_state, cs_lds; LazyArgs args; size_t shm; };
-template <int CH, bool LDS_STATE>
-static int launch_chain2(const Chain2Args &args, int cache_grid, hipEvent_t ev_cache_done, hipEvent_t ev_arr_done, hipStream_t stream,
-                         const CoopPlan &plan, const LazyPlan &lz) {
-    const bool coop = plan.enabled;
-    CoopArgs ca = plan.args;
-    const size_t coop_shm = plan.shm;
-    const int npad = (args.n + 3) & ~3;
-    const bool cs_lds = !LDS_STATE && args.n <= 65535;
-    const size_t shmem = LDS_STATE ? (((size_t)npad * 6 + 15) / 16) * 16 : (cs_lds ? (((size_t)npad * 2 + 15) / 16) * 16 : 16);
-    const size_t base_aug = (((LDS_STATE ? (size_t)npad * 6 : 0) + (args.gmode == 1 ? (size_t)args.ngroups * 8 : 0) + 15) / 16) * 16;
-    Chain2Args aug_args = args;
-    aug_args.auxlds = (LDS_STATE && args.ngroups < 65536 && base_aug + (size_t)npad * 6 + 4096 <= 160 * 1024) ? 1 : 0;
-    const size_t shmem_aug = base_aug + (aug_args.auxlds ? (size_t)npad * 6 : 0) + 32;
-    void (*kern)(Chain2Args) = jv_chain2<CH, LDS_STATE, false>;
-    if constexpr (!LDS_STATE) { if (cs_lds) kern = jv_chain2<CH, false, true>; }
-    CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    if constexpr (CH == 0)
-        hipLaunchKernelGGL(build_row_caches_stream, dim3(cache_grid), dim3(BLOCK2), 0, stream, args.n, args.ld, args.cost,
-                           (const float *)args.fws, args.cache_col, args.cache_val);
-    else
-        hipLaunchKernelGGL((build_row_caches<CH>), dim3(cache_grid), dim3(BLOCK2), 0, stream, args.n, args.ld, args.cost,
-                           (const float *)args.fws, args.cache_col, args.cache_val);
-    CYTO_HIP(hipGetLastError());
-    CYTO_HIP(hipEventRecord(ev_cache_done, stream));
-    hipLaunchKernelGGL(kern, dim3(1), dim3(BLOCK2), shmem, stream, args);
-    CYTO_HIP(hipGetLastError());
-    CYTO_HIP(hipEventRecord(ev_arr_done, stream));
-    if (lz.enabled) {
-        // fresh caches (floors against the prices the augmentation starts from), then the cache-certified search
-        if constexpr (CH == 0)
-            hipLaunchKernelGGL(build_row_caches_stream, dim3(cache_grid), dim3(BLOCK2), 0, stream, args.n, args.ld, args.cost,
-                               (const float *)args.fws, args.cache_col, args.cache_val);
-        else
-            hipLaunchKernelGGL((build_row_caches<CH>), dim3(cache_grid), dim3(BLOCK2), 0, stream, args.n, args.ld, args.cost,
-                               (const float *)args.fws, args.cache_col, args.cache_val);
-        CYTO_HIP(hipGetLastError());
-        LazyArgs la = lz.args;
-        la.may_bail = (LDS_STATE && !getenv("CYTO_AUG")) ? 1 : 0;     // the dense jv_aug2<CH, true> can take over
-        la.debug_exc = getenv("CYTO_DEBUG_EXC") ? atoi(getenv("CYTO_DEBUG_EXC")) : 0;
-        if (lz.lds_state) {
-            CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jv_aug_lazy<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lz.shm));
-            hipLaunchKernelGGL(jv_aug_lazy<true>, dim3(1), dim3(BLOCK2), lz.shm, stream, la);
-        } else if (lz.cs_lds) {
-            CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jv_aug_lazy<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lz.shm));
-            hipLaunchKernelGGL((jv_aug_lazy<false, true>), dim3(1), dim3(BLOCK2), lz.shm, stream, la);
-        } else {
-            CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jv_aug_lazy<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lz.shm));
-            hipLaunchKernelGGL(jv_aug_lazy<false>, dim3(1), dim3(BLOCK2), lz.shm, stream, la);
-        }
-        CYTO_HIP(hipGetLastError());
-        if constexpr (LDS_STATE) {
-            if (la.may_bail) {
-                // did it give up?  (misc + 128: number of free rows, misc + 136: searches completed)
-                int h[3] = {0, 0, 0};
-                CYTO_HIP(hipMemcpyAsync(h, args.misc + 128, sizeof h, hipMemcpyDeviceToHost, stream));
-                CYTO_HIP(hipStreamSynchronize(stream));
-                if (getenv("CYTO_DEBUG_HANDOVER")) fprintf(stderr, "[handover] numfree=%d done=%d\n", h[0], h[2]);
-                if (h[2] < h[0] && !getenv("CYTO_DEBUG_NO_CONT")) {
-                    aug_args.aug_start = h[2];
-                    auto kaug = jv_aug2<CH, LDS_STATE>;
-                    CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kaug), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_aug));
-                    hipLaunchKernelGGL(kaug, dim3(1), dim3(BLOCK2), shmem_aug, stream, aug_args);
-                    CYTO_HIP(hipGetLastError());
-                }
-            }
-        }
-        return CYTO_OK;
-    }
-    if (coop) {
-        CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jv_aug_coop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_shm));
-    }
-    if constexpr (LDS_STATE) {
-      if (!coop) {
-        auto kaug = jv_aug2<CH, LDS_STATE>;
-        CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kaug), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_aug));
-        hipLaunchKernelGGL(kaug, dim3(1), dim3(BLOCK2), shmem_aug, stream, aug_args);
-      }
-    }
-    if (LDS_STATE && !coop) {
-    } else if (coop) {
-        hipLaunchKernelGGL(jv_aug_coop, dim3(ca.W * ca.stride), dim3(64), coop_shm, stream, ca);
-        CYTO_HIP(hipGetLastError());
-        hipLaunchKernelGGL(jv_finish_duals, dim3(1), dim3(BLOCK3), 0, stream, args.n, args.ld, args.cost, (const float *)args.fws,
-                           args.fws + args.n, (const int32_t *)args.iws, args.misc);
-    } else {
-        // large n: streaming augmentation (per-column state in L2-resident global memory)
-        const int n = args.n;
-        AugStreamArgs sa;
-        sa.n = n; sa.ld = args.ld; sa.cost = args.cost;
-        sa.gv = args.fws; sa.gu = args.fws + n; sa.sumvd = args.fws + 2 * (int64_t)n; sa.cassign = args.fws + 3 * (int64_t)n;
-        sa.vwork = args.fws + 4 * (int64_t)n; sa.d = args.fws + 5 * (int64_t)n;
-        sa.rowsol = args.iws; sa.colsol = args.iws + n; sa.freerows = args.iws + 3 * (int64_t)n; sa.pred = args.iws + 5 * (int64_t)n;
-        sa.colgroup = args.iws + 6 * (int64_t)n; sa.ulist = args.iws + 7 * (int64_t)n; sa.slist = args.iws + 8 * (int64_t)n;
-        sa.slevel = args.iws + 9 * (int64_t)n;
-        sa.rowgid = args.rowgid; sa.g_hbest = args.g_hbest; sa.g_hstamp = args.g_hstamp; sa.misc = args.misc;
-        sa.ngroups = args.ngroups; sa.gmode = args.gmode;
-        const size_t shm = (size_t)((n + 31) / 32) * 4 + (args.gmode == 1 ? (size_t)args.ngroups * 8 : 0) + 32;
-        CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jv_aug_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        hipLaunchKernelGGL(jv_aug_stream, dim3(1), dim3(BLOCK3), shm, stream, sa);
-    }
-    CYTO_HIP(hipGetLastError());
+static const cyto_lap_opts k_default_opts = {0, 0, 0, 0, {0, 0, 0, 0}};
+
+static int check_opts(const cyto_lap_opts &o) {
+    if (o.chain_variant < 0 || o.chain_variant > 2 || o.augmentation < 0 || o.augmentation > 2 || o.inject_exceptions < 0 ||
+        o.no_handover < 0 || o.no_handover > 1)
+        return CYTO_ERR_BAD_ARG;
+    for (int k = 0; k < 4; k++) if (o.reserved[k]) return CYTO_ERR_BAD_ARG;
     return CYTO_OK;
 }
 
+// ---- float32: one problem of a batch (all problems of a batch have the same n) ----
+struct F32Job {
+    // in
+    const float *cost = nullptr; int64_t ld = 0; int cost_on_device = 0;
+    // out (host pointers, may be null)
+    int32_t *rowsol = nullptr, *colsol = nullptr; float *u = nullptr, *v = nullptr; double *total = nullptr; cyto_lap_info *info = nullptr;
+    int status = CYTO_OK;
+    // device state
+    DevBuf staged, b_fws, b_iws, b_imin, b_pmin, b_parg, b_misc, b_same, b_gid, b_ccol, b_cval, b_ghb, b_ghs, b_lzhb, b_lzhs;
+    const float *dcost = nullptr; int64_t dld = 0;
+    int h_nonfinite = 0, h_ngroups = 0, h_hand[3] = {0, 0, 0};
+    Chain2Args c2; LazyArgs la;
+    size_t shm_lazy = 0, shm_aug = 0;
+    bool alive() const { return status == CYTO_OK; }
+};
+
+struct F32Plan {            // what depends on n (and the options) only: identical for every problem of the batch
+    int n, colblocks, rowblocks, rows_per_block, cache_grid;
+    bool force_l2, lds_variant, lazy, lz_lds_state, lz_cs_lds;
+    size_t shm_chain, lz_base_shm;
+};
+
+template <int CH, bool LDS_STATE>
+static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_t stream, hipEvent_t ev_cache_done,
+                        hipEvent_t ev_arr_done, DevBuf &d_c2, DevBuf &d_la) {
+    const int n = pl.n;
+    std::vector<int> live;
+    for (int b = 0; b < (int)jobs.size(); b++) if (jobs[b].alive()) live.push_back(b);
+    const int nl = (int)live.size();
+    if (!nl) return CYTO_OK;
+    int rc;
+    const bool cs_lds = !LDS_STATE && n <= 65535;
+    void (*kern)(const Chain2Args *) = jv_chain2<CH, LDS_STATE, false>;
+    if constexpr (!LDS_STATE) { if (cs_lds) kern = jv_chain2<CH, false, true>; }
+    auto build_caches = [&]() -> int {
+        for (int b : live) {
+            const Chain2Args &a = jobs[b].c2;
+            if constexpr (CH == 0)
+                hipLaunchKernelGGL(build_row_caches_stream, dim3(pl.cache_grid), dim3(BLOCK2), 0, stream, n, a.ld, a.cost,
+                                   (const float *)a.fws, a.cache_col, a.cache_val);
+            else
+                hipLaunchKernelGGL((build_row_caches<CH>), dim3(pl.cache_grid), dim3(BLOCK2), 0, stream, n, a.ld, a.cost,
+                                   (const float *)a.fws, a.cache_col, a.cache_val);
+        }
+        CYTO_HIP(hipGetLastError());
+        return CYTO_OK;
+    };
+    // argument blocks of the batch, in `live` order
+    std::vector<Chain2Args> h_c2((size_t)nl);
+    std::vector<LazyArgs> h_la((size_t)nl);
+    size_t shm_aug = 0, shm_lazy = 0;
+    for (int k = 0; k < nl; k++) {
+        F32Job &j = jobs[live[k]];
+        h_c2[k] = j.c2; h_la[k] = j.la;
+        if (!LDS_STATE) h_la[k].may_bail = 0;                        // only the dense jv_aug2<CH, true> can take over
+        shm_aug = std::max(shm_aug, j.shm_aug); shm_lazy = std::max(shm_lazy, j.shm_lazy);
+    }
+    if ((rc = d_c2.alloc(sizeof(Chain2Args) * nl, stream)) || (rc = d_la.alloc(sizeof(LazyArgs) * nl, stream))) return rc;
+    CYTO_HIP(hipMemcpyAsync(d_c2.p, h_c2.data(), sizeof(Chain2Args) * nl, hipMemcpyHostToDevice, stream));
+    CYTO_HIP(hipMemcpyAsync(d_la.p, h_la.data(), sizeof(LazyArgs) * nl, hipMemcpyHostToDevice, stream));
+
+    if ((rc = build_caches())) return rc;
+    CYTO_HIP(hipEventRecord(ev_cache_done, stream));
+    if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern)))) return rc;
+    if (pl.shm_chain > (size_t)LDS_DYNAMIC_MAX || shm_aug > (size_t)LDS_DYNAMIC_MAX || shm_lazy > (size_t)LDS_DYNAMIC_MAX) return CYTO_ERR_INTERNAL;
+    hipLaunchKernelGGL(kern, dim3(nl), dim3(BLOCK2), pl.shm_chain, stream, d_c2.as<Chain2Args>());
+    CYTO_HIP(hipGetLastError());
+    CYTO_HIP(hipEventRecord(ev_arr_done, stream));
+    auto launch_dense = [&](const Chain2Args *d_args, int count) -> int {
+        if constexpr (LDS_STATE) {
+            void (*ka)(const Chain2Args *) = jv_aug2<CH, true, BLOCK2>;
+            int r2 = set_max_dynamic_lds(reinterpret_cast<const void *>(ka));
+            if (r2) return r2;
+            hipLaunchKernelGGL(ka, dim3(count), dim3(BLOCK2), shm_aug, stream, d_args);
+            CYTO_HIP(hipGetLastError());
+            return CYTO_OK;
+        } else {
+            (void)d_args; (void)count;
+            return CYTO_ERR_INTERNAL;     // (beyond the LDS-resident sizes the cache-certified search is always used)
+        }
+    };
+    if (!pl.lazy) return launch_dense(d_c2.as<Chain2Args>(), nl);
+
+    // fresh caches (floors against the prices the augmentation starts from), then the cache-certified search
+    if ((rc = build_caches())) return rc;
+    void (*lk)(const LazyArgs *) = pl.lz_lds_state ? jv_aug_lazy<true> : (pl.lz_cs_lds ? jv_aug_lazy<false, true> : jv_aug_lazy<false>);
+    if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(lk)))) return rc;
+    hipLaunchKernelGGL(lk, dim3(nl), dim3(BLOCK2), shm_lazy, stream, d_la.as<LazyArgs>());
+    CYTO_HIP(hipGetLastError());
+    if constexpr (LDS_STATE) {
+        // which searches gave up?  (misc + 128: number of free rows, misc + 136: searches completed)
+        bool any_bail = false;
+        for (int k = 0; k < nl; k++) any_bail |= h_la[k].may_bail != 0;
+        if (any_bail) {
+            for (int k = 0; k < nl; k++)
+                CYTO_HIP(hipMemcpyAsync(jobs[live[k]].h_hand, jobs[live[k]].c2.misc + 128, sizeof(int) * 3, hipMemcpyDeviceToHost, stream));
+            CYTO_HIP(hipStreamSynchronize(stream));
+            std::vector<Chain2Args> cont;
+            for (int k = 0; k < nl; k++) {
+                const F32Job &j = jobs[live[k]];
+                if (h_la[k].may_bail && j.h_hand[2] < j.h_hand[0]) { Chain2Args a = h_c2[k]; a.aug_start = j.h_hand[2]; cont.push_back(a); }
+            }
+            if (!cont.empty()) {
+                // (the first nl blocks of d_c2 are no longer read: jv_chain2 has finished)
+                CYTO_HIP(hipMemcpyAsync(d_c2.p, cont.data(), sizeof(Chain2Args) * cont.size(), hipMemcpyHostToDevice, stream));
+                if ((rc = launch_dense(d_c2.as<Chain2Args>(), (int)cont.size()))) return rc;
+                CYTO_HIP(hipStreamSynchronize(stream));     // `cont` is read by the copy until here
+            }
+        }
+    }
+    return CYTO_OK;
+}
+
+// All problems have the same n.  jobs[b].status carries per-problem failures (non-finite costs, solver status); the
+// return value reports failures of the batch as a whole (allocation, HIP).
+static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, hipStream_t stream, const cyto_lap_opts &opts) {
+    const int nb = (int)jobs.size();
+    if (nb == 0) return CYTO_OK;
+    if (n <= 0) return CYTO_ERR_BAD_ARG;
+    if (n > FAST_NMAX) return CYTO_ERR_UNSUPPORTED;
+    int rc = check_opts(opts);
+    if (rc) return rc;
+    if ((rc = select_device(device_id))) return rc;
+    Events<6> ev;                                   // destroyed on every return path
+    if ((rc = ev.create())) return rc;
+    const hipEvent_t e0 = ev[0], e1 = ev[1], e1b = ev[2], e1c = ev[3], e1d = ev[4], e2 = ev[5];
+
+    F32Plan pl;
+    pl.n = n;
+    pl.colblocks = (n + 256 * 4 - 1) / (256 * 4);
+    pl.rowblocks = (2048 + pl.colblocks - 1) / pl.colblocks;
+    pl.rowblocks = max(1, min(pl.rowblocks, (n + 15) / 16));
+    pl.rows_per_block = (n + pl.rowblocks - 1) / pl.rowblocks;
+    pl.rowblocks = (n + pl.rows_per_block - 1) / pl.rows_per_block;
+    pl.cache_grid = max(1, min(n, 1024));
+    const int per2 = 4 * BLOCK2;
+    // which chain variant: by size, or the large-n variants forced at a small n (opts.chain_variant; the test-suite
+    // runs them on instances the CPU oracle solves in a second)
+    pl.force_l2 = opts.chain_variant != 0;
+    pl.lds_variant = !pl.force_l2 && n <= 13 * per2;
+    // cache-certified augmentation: the default above 5120 columns (measured cross-over with the register-resident dense
+    // search on uniform and duplicated-row instances), the only one beyond 26 624
+    pl.lazy = opts.augmentation == 2 || !pl.lds_variant || (opts.augmentation == 0 && n > 5120);
+    const int npad = (n + 3) & ~3;
+    const size_t npad6 = (((size_t)npad * 6) + 15) & ~(size_t)15, npad2 = (((size_t)npad * 2) + 15) & ~(size_t)15;
+    const size_t nb24 = (size_t)((((n + 63) / 64) + 511) & ~511) * 8 + (size_t)((n + 63) / 64) * 24 + 16;
+    const size_t lds_budget = LDS_DYNAMIC_MAX;
+    pl.lz_lds_state = n <= 65535 && !pl.force_l2 && npad6 + nb24 <= lds_budget;
+    pl.lz_cs_lds = !pl.lz_lds_state && n <= 65535 && npad2 + nb24 <= lds_budget;
+    pl.lz_base_shm = (pl.lz_lds_state ? npad6 : (pl.lz_cs_lds ? npad2 : 0)) + nb24;
+    const bool cs_lds_chain = !pl.lds_variant && n <= 65535;
+    pl.shm_chain = pl.lds_variant ? (((size_t)npad * 6 + 15) / 16) * 16 : (cs_lds_chain ? (((size_t)npad * 2 + 15) / 16) * 16 : 16);
+
+    const size_t nT = (size_t)n * sizeof(float), nI = (size_t)n * sizeof(int32_t);
+    // ---- stage 1 (every problem, back to back on the stream: full-chip streaming kernels): column reduction, row groups ----
+    CYTO_HIP(hipEventRecord(e0, stream));
+    for (F32Job &j : jobs) {
+        if (!j.cost || j.ld < n) { j.status = CYTO_ERR_BAD_ARG; continue; }
+        // the kernels want 16-byte aligned rows: pitch a multiple of 4 elements
+        j.dcost = j.cost; j.dld = j.ld;
+        const bool aligned = j.cost_on_device && (j.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(j.cost) & 15) == 0);
+        if (!aligned) {
+            j.dld = ((int64_t)n + 3) / 4 * 4;
+            if ((rc = j.staged.alloc((size_t)n * j.dld * sizeof(float), stream))) return rc;
+            CYTO_HIP(hipMemcpy2DAsync(j.staged.p, j.dld * sizeof(float), j.cost, j.ld * sizeof(float), (size_t)n * sizeof(float), n,
+                                      j.cost_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+            j.dcost = j.staged.as<float>();
+        }
+        // workspace (blocks of the device cache: no hipMalloc / hipFree once a size has been seen)
+        if ((rc = j.b_fws.alloc(6 * nT + 64, stream)) || (rc = j.b_iws.alloc(10 * nI + 64, stream)) || (rc = j.b_imin.alloc(nI, stream)) ||
+            (rc = j.b_pmin.alloc((size_t)pl.rowblocks * nT, stream)) || (rc = j.b_parg.alloc((size_t)pl.rowblocks * nI, stream)) ||
+            (rc = j.b_misc.alloc(256, stream)) || (rc = j.b_same.alloc(nI, stream)) || (rc = j.b_gid.alloc(nI, stream)) ||
+            (rc = j.b_ccol.alloc((size_t)n * KC * sizeof(uint32_t), stream)) || (rc = j.b_cval.alloc((size_t)n * KC * sizeof(float), stream)))
+            return rc;
+        // float workspace: v | u | ... ; int workspace: rowsol | colsol | matches | freerows | rtrows | pred | ...
+        float *d_v = j.b_fws.as<float>();
+        int32_t *d_rowsol = j.b_iws.as<int32_t>(), *d_colsol = d_rowsol + n, *d_matches = d_rowsol + 2 * (size_t)n;
+        // misc: [0] nonfinite flag (int), [1] chain status (int), [8..16) total (double), [16..) counters, [144] ngroups
+        CYTO_HIP(hipMemsetAsync(j.b_misc.p, 0, 256, stream));
+        CYTO_HIP(hipMemsetAsync(d_rowsol, 0xFF, nI, stream));
+        CYTO_HIP(hipMemsetAsync(d_matches, 0, nI, stream));
+        hipLaunchKernelGGL(colred_partial<float>, dim3(pl.colblocks, pl.rowblocks), dim3(256), 0, stream, n, j.dld, j.dcost, pl.rows_per_block,
+                           j.b_pmin.as<float>(), j.b_parg.as<int32_t>(), j.b_misc.as<int>());
+        hipLaunchKernelGGL(colred_finish<float>, dim3((n + 255) / 256), dim3(256), 0, stream, n, pl.rowblocks, j.b_pmin.as<float>(),
+                           j.b_parg.as<int32_t>(), d_v, j.b_imin.as<int32_t>(), d_rowsol, d_matches);
+        hipLaunchKernelGGL(colred_assign, dim3((n + 255) / 256), dim3(256), 0, stream, n, j.b_imin.as<int32_t>(), d_rowsol, d_colsol);
+    }
+    CYTO_HIP(hipGetLastError());
+    CYTO_HIP(hipEventRecord(e1, stream));
+    // duplicate-row groups: runs of bitwise identical consecutive rows
+    const bool want_groups = n >= 2;
+    for (F32Job &j : jobs) {
+        if (!j.alive()) continue;
+        j.h_ngroups = n;
+        if (want_groups) {
+            hipLaunchKernelGGL(rows_same_as_prev<float>, dim3(min(n, 2048)), dim3(256), 0, stream, n, j.dld, j.dcost, j.b_same.as<int32_t>());
+            hipLaunchKernelGGL(rows_group_ids, dim3(1), dim3(1024), 0, stream, n, j.b_same.as<int32_t>(), j.b_gid.as<int32_t>(),
+                               j.b_misc.as<int>() + 36);   // misc + 144
+        }
+        // a non-finite cost makes every later comparison meaningless: that problem stops before the chain
+        CYTO_HIP(hipMemcpyAsync(&j.h_nonfinite, j.b_misc.as<int>(), sizeof(int), hipMemcpyDeviceToHost, stream));
+        if (want_groups) CYTO_HIP(hipMemcpyAsync(&j.h_ngroups, j.b_misc.as<int>() + 36, sizeof(int), hipMemcpyDeviceToHost, stream));
+    }
+    CYTO_HIP(hipGetLastError());
+    CYTO_HIP(hipStreamSynchronize(stream));
+    CYTO_HIP(hipEventRecord(e1b, stream));
+
+    // ---- stage 2: per-problem argument blocks ----
+    for (F32Job &j : jobs) {
+        if (!j.alive()) continue;
+        if (j.h_nonfinite) { j.status = CYTO_ERR_NONFINITE; continue; }
+        float *d_v = j.b_fws.as<float>(), *d_u = d_v + n;
+        int32_t *d_rowsol = j.b_iws.as<int32_t>(), *d_colsol = d_rowsol + n, *d_free = d_rowsol + 3 * (size_t)n;
+        const int ng = j.h_ngroups;
+        Chain2Args &c2 = j.c2;
+        c2.n = n; c2.ld = j.dld; c2.cost = j.dcost; c2.fws = d_v; c2.iws = d_rowsol;
+        c2.cache_col = j.b_ccol.as<uint32_t>(); c2.cache_val = j.b_cval.as<float>(); c2.misc = j.b_misc.as<char>();
+        // duplicate-row skip: per-group state in LDS when it fits beside v (4 B) and colsol (2 B) per column
+        c2.rowgid = j.b_gid.as<int32_t>(); c2.ngroups = ng; c2.gmode = 0; c2.g_hbest = nullptr; c2.g_hstamp = nullptr;
+        c2.auxlds = 0; c2.aug_start = 0;
+        LazyArgs &la = j.la;
+        memset(&la, 0, sizeof la);
+        j.shm_lazy = pl.lz_base_shm;
+        if (pl.lazy) {
+            la.n = n; la.ld = j.dld; la.cost = j.dcost; la.gv = d_v; la.gu = d_u; la.sumvd = d_v + 2 * (int64_t)n;
+            la.cassign = d_v + 3 * (int64_t)n; la.dkey = reinterpret_cast<uint64_t *>(d_v + 4 * (int64_t)n);
+            la.rowsol = d_rowsol; la.colsol = d_colsol; la.freerows = d_free;
+            la.srow = d_rowsol + 6 * (int64_t)n;      // [n+1]: runs into the next slot, which the lazy path does not use
+            la.slist = d_rowsol + 8 * (int64_t)n; la.slevel = d_rowsol + 9 * (int64_t)n;
+            la.rowgid = j.b_gid.as<int32_t>(); la.cache_col = j.b_ccol.as<uint32_t>(); la.cache_val = j.b_cval.as<float>();
+            la.misc = j.b_misc.as<char>(); la.ngroups = ng; la.gmode = 0; la.g_hbest = nullptr; la.g_hstamp = nullptr;
+            la.may_bail = opts.no_handover ? 0 : 1;   // (launch_batch clears it where no dense kernel can take over)
+            la.debug_exc = opts.inject_exceptions;
+            if (want_groups && ng < n) {
+                if (j.shm_lazy + (size_t)ng * 8 <= lds_budget) { la.gmode = 1; j.shm_lazy += (size_t)ng * 8; }
+                else {
+                    la.gmode = 2;
+                    if ((rc = j.b_lzhb.alloc((size_t)ng * 4, stream)) || (rc = j.b_lzhs.alloc((size_t)ng * 4, stream))) return rc;
+                    CYTO_HIP(hipMemsetAsync(j.b_lzhs.p, 0, (size_t)ng * 4, stream));
+                    la.g_hbest = j.b_lzhb.as<float>(); la.g_hstamp = j.b_lzhs.as<int32_t>();
+                }
+            }
+        }
+        if (want_groups && ng < n) {
+            // LDS beside the group state: v (4 B) + colsol (2 B) per column on the LDS-resident path
+            const size_t lds_state = pl.lds_variant ? (size_t)npad * 6 : (size_t)((n + 31) / 32) * 4;
+            if (lds_state + (size_t)ng * 8 + 8192 <= 160 * 1024) c2.gmode = 1;
+            else {
+                c2.gmode = 2;
+                if ((rc = j.b_ghb.alloc((size_t)ng * 4, stream)) || (rc = j.b_ghs.alloc((size_t)ng * 4, stream))) return rc;
+                CYTO_HIP(hipMemsetAsync(j.b_ghs.p, 0, (size_t)ng * 4, stream));
+                c2.g_hbest = j.b_ghb.as<float>(); c2.g_hstamp = j.b_ghs.as<int32_t>();
+            }
+        }
+        // dense augmentation: its LDS (prices, colsol, per-group state, and the per-column auxiliaries when they fit)
+        const size_t base_aug = (((pl.lds_variant ? (size_t)npad * 6 : 0) + (c2.gmode == 1 ? (size_t)ng * 8 : 0) + 15) / 16) * 16;
+        c2.auxlds = (pl.lds_variant && ng < 65536 && base_aug + (size_t)npad * 6 + 4096 <= 160 * 1024) ? 1 : 0;
+        j.shm_aug = base_aug + (c2.auxlds ? (size_t)npad * 6 : 0) + 32;
+    }
+
+    // ---- stage 3: the chains, one launch per phase for the whole batch ----
+    DevBuf d_c2, d_la;
+    if (opts.chain_variant == 2) rc = launch_batch<0, false>(pl, jobs, stream, e1c, e1d, d_c2, d_la);
+    else if (pl.force_l2 && n <= 5 * per2) rc = launch_batch<5, false>(pl, jobs, stream, e1c, e1d, d_c2, d_la);
+    else if (pl.force_l2 && n <= 16 * per2) rc = launch_batch<16, false>(pl, jobs, stream, e1c, e1d, d_c2, d_la);
+    else if (pl.force_l2) rc = launch_batch<0, false>(pl, jobs, stream, e1c, e1d, d_c2, d_la);
+    else if (n <= 2 * per2) rc = launch_batch<2, true>(pl, jobs, stream, e1c, e1d, d_c2, d_la);
+    else if (n <= 5 * per2) rc = launch_batch<5, true>(pl, jobs, stream, e1c, e1d, d_c2, d_la);
+    else if (n <= 10 * per2) rc = launch_batch<10, true>(pl, jobs, stream, e1c, e1d, d_c2, d_la);
+    else if (n <= 13 * per2) rc = launch_batch<13, true>(pl, jobs, stream, e1c, e1d, d_c2, d_la);
+    else if (n <= 16 * per2) rc = launch_batch<16, false>(pl, jobs, stream, e1c, e1d, d_c2, d_la);
+    else rc = launch_batch<0, false>(pl, jobs, stream, e1c, e1d, d_c2, d_la);   // streaming dense refresh, any n
+    if (rc) return rc;
+    CYTO_HIP(hipEventRecord(e2, stream));
+    CYTO_HIP(hipStreamSynchronize(stream));
+
+    // ---- results ----
+    float ms_colred = 0, ms_cache = 0, ms_chain = 0, ms_arr = 0, ms_aug = 0;
+    bool any_alive = false;
+    for (const F32Job &j : jobs) any_alive |= j.alive();
+    (void)hipEventElapsedTime(&ms_colred, e0, e1);
+    if (any_alive) {
+        (void)hipEventElapsedTime(&ms_cache, e1b, e1c); (void)hipEventElapsedTime(&ms_chain, e1c, e2);
+        (void)hipEventElapsedTime(&ms_arr, e1c, e1d); (void)hipEventElapsedTime(&ms_aug, e1d, e2);
+    }
+    for (F32Job &j : jobs) {
+        if (!j.alive()) continue;
+        int h_status = 0;
+        long long h_counters[C3_NCOUNTERS] = {0};
+        int32_t *d_rowsol = j.b_iws.as<int32_t>();
+        float *d_v = j.b_fws.as<float>();
+        CYTO_HIP(hipMemcpy(&h_status, j.b_misc.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost));
+        CYTO_HIP(hipMemcpy(h_counters, j.b_misc.as<char>() + 16, sizeof(h_counters), hipMemcpyDeviceToHost));
+        if (j.rowsol) CYTO_HIP(hipMemcpy(j.rowsol, d_rowsol, nI, hipMemcpyDeviceToHost));
+        if (j.colsol) CYTO_HIP(hipMemcpy(j.colsol, d_rowsol + n, nI, hipMemcpyDeviceToHost));
+        if (j.u) CYTO_HIP(hipMemcpy(j.u, d_v + n, nT, hipMemcpyDeviceToHost));
+        if (j.v) CYTO_HIP(hipMemcpy(j.v, d_v, nT, hipMemcpyDeviceToHost));
+        if (j.total) CYTO_HIP(hipMemcpy(j.total, j.b_misc.as<char>() + 8, sizeof(double), hipMemcpyDeviceToHost));
+        if (j.info) {
+            cyto_lap_info *info = j.info;
+            memset(info, 0, sizeof *info);
+            // (kernel times of a batch are those of the whole batch: its problems share every launch)
+            info->ms_colred = ms_colred; info->ms_cache = ms_cache; info->ms_chain = ms_chain; info->ms_arr = ms_arr; info->ms_aug = ms_aug;
+            info->ms_total = info->ms_colred + info->ms_cache + info->ms_chain;
+            info->scans_colred = n;
+            info->scans_redtransfer = h_counters[C_RT];
+            info->scans_arr = h_counters[C_ARR];
+            info->scans_aug_init = h_counters[C_AUG_INIT];
+            info->scans_aug_relax = h_counters[C_AUG_RELAX];
+            info->augmentations = h_counters[C_AUGS];
+            info->path_hops = h_counters[C_HOPS];
+            info->free_after_colred = h_counters[C_FREE_CR];
+            info->free_after_arr1 = h_counters[C_FREE_A1];
+            info->free_after_arr2 = h_counters[C_FREE_A2];
+            info->hbm_row_reads = 2 * (int64_t)n + h_counters[C_ROWS_READ];
+            info->dense_refreshes = h_counters[C2_DENSE_REFRESH];
+            info->aug_scans_skipped = h_counters[C2_AUG_SKIPPED];
+            info->aug_dense_scans = h_counters[C2_AUG_DENSE];
+            info->aug_sparse_inits = h_counters[C2_AUG_SPARSE_INIT];
+            info->aug_handover = -1;
+            if (pl.lazy) {
+                int h[3] = {0, 0, 0};
+                CYTO_HIP(hipMemcpy(h, j.b_misc.as<char>() + 128, sizeof h, hipMemcpyDeviceToHost));
+                if (h[2] < h[0]) info->aug_handover = h[2];
+            }
+            info->row_groups = j.h_ngroups;
+        }
+        if (h_status) j.status = CYTO_ERR_INTERNAL;
+    }
+    return CYTO_OK;
+}
+
+// ---- float64 (the force_doubles / lapjv_compat precision): the generic chain, one problem ----
 template <typename T, int CH, bool LDSCS>
 static int launch_chain(const ChainArgs<T> &args, hipStream_t stream) {
     const size_t shmem = LDSCS ? (((size_t)args.n * sizeof(int32_t) + 15) / 16) * 16 : 16;
     auto kern = jv_chain<T, CH, LDSCS>;
-    CYTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern));
+    if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(1), dim3(BLOCK), shmem, stream, args);
     CYTO_HIP(hipGetLastError());
     return CYTO_OK;
 }
 
-template <typename T>
-static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32_t *rowsol, int32_t *colsol,
-                     T *u, T *v, double *total, cyto_lap_info *info, int device_id, void *stream_) {
+static int lap_solve_f64(int n, const double *cost, int64_t ld, int cost_on_device, int32_t *rowsol, int32_t *colsol,
+                         double *u, double *v, double *total, cyto_lap_info *info, int device_id, hipStream_t stream,
+                         const cyto_lap_opts &opts) {
+    typedef double T;
     constexpr int VW = VecOf<T>::W;
     if (n <= 0 || !cost || ld < n) return CYTO_ERR_BAD_ARG;
-    // both precisions take any n up to FAST_NMAX (float32: cached chain; float64: streaming generic chain)
-    const int64_t cap = (int64_t)FAST_NMAX;
-    if (n > cap) return CYTO_ERR_UNSUPPORTED;
-    int rc = select_device(device_id);
+    int rc = check_opts(opts);
     if (rc) return rc;
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-
-    // the kernels want 16-byte aligned rows: pitch a multiple of VW elements
+    if (n > FAST_NMAX) return CYTO_ERR_UNSUPPORTED;
+    if ((rc = select_device(device_id))) return rc;
+    Events<3> ev;
+    if ((rc = ev.create())) return rc;
+    const hipEvent_t e0 = ev[0], e1 = ev[1], e2 = ev[2];
     DevBuf staged;
     const T *dcost = cost;
     int64_t dld = ld;
     const bool aligned = cost_on_device && (ld % VW == 0) && ((reinterpret_cast<uintptr_t>(cost) & 15) == 0);
     if (!aligned) {
         dld = ((int64_t)n + VW - 1) / VW * VW;
-        if ((rc = staged.alloc((size_t)n * dld * sizeof(T)))) return rc;
+        if ((rc = staged.alloc((size_t)n * dld * sizeof(T), stream))) return rc;
         CYTO_HIP(hipMemcpy2DAsync(staged.p, dld * sizeof(T), cost, ld * sizeof(T), (size_t)n * sizeof(T), n,
                                   cost_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
         dcost = staged.as<T>();
     }
-
-    // workspace
     const int colblocks = (n + 256 * VW - 1) / (256 * VW);
     int rowblocks = (2048 + colblocks - 1) / colblocks;
     rowblocks = max(1, min(rowblocks, (n + 15) / 16));
     const int rows_per_block = (n + rowblocks - 1) / rowblocks;
     rowblocks = (n + rows_per_block - 1) / rows_per_block;
-
     DevBuf b_fws, b_iws, b_imin, b_pmin, b_parg, b_misc;
     const size_t nT = (size_t)n * sizeof(T), nI = (size_t)n * sizeof(int32_t);
-    if ((rc = b_fws.alloc(6 * nT + 64)) || (rc = b_iws.alloc(10 * nI + 64)) || (rc = b_imin.alloc(nI)) ||
-        (rc = b_pmin.alloc((size_t)rowblocks * nT)) || (rc = b_parg.alloc((size_t)rowblocks * nI)) || (rc = b_misc.alloc(256)))
+    if ((rc = b_fws.alloc(6 * nT + 64, stream)) || (rc = b_iws.alloc(10 * nI + 64, stream)) || (rc = b_imin.alloc(nI, stream)) ||
+        (rc = b_pmin.alloc((size_t)rowblocks * nT, stream)) || (rc = b_parg.alloc((size_t)rowblocks * nI, stream)) ||
+        (rc = b_misc.alloc(256, stream)))
         return rc;
-    // float workspace: v | u ; int workspace: rowsol | colsol | matches | freerows | rtrows | pred
     T *d_v = b_fws.as<T>(), *d_u = b_fws.as<T>() + n;
     int32_t *d_rowsol = b_iws.as<int32_t>(), *d_colsol = d_rowsol + n, *d_matches = d_rowsol + 2 * (size_t)n;
-    int32_t *d_free = d_rowsol + 3 * (size_t)n, *d_rt = d_rowsol + 4 * (size_t)n, *d_pred = d_rowsol + 5 * (size_t)n;
-    // misc: [0] nonfinite flag (int), [1] chain status (int), [8..16) total (double), [16..) counters
     int *d_nonfinite = b_misc.as<int>();
-    int *d_status = b_misc.as<int>() + 1;
-    double *d_total = reinterpret_cast<double *>(b_misc.as<char>() + 8);
-    long long *d_counters = reinterpret_cast<long long *>(b_misc.as<char>() + 16);
     CYTO_HIP(hipMemsetAsync(b_misc.p, 0, 256, stream));
     CYTO_HIP(hipMemsetAsync(d_rowsol, 0xFF, nI, stream));
     CYTO_HIP(hipMemsetAsync(d_matches, 0, nI, stream));
-
-    hipEvent_t e0, e1, e2;
-    CYTO_HIP(hipEventCreate(&e0));
-    CYTO_HIP(hipEventCreate(&e1));
-    CYTO_HIP(hipEventCreate(&e2));
-    auto cleanup = [&]() { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); };
-
     CYTO_HIP(hipEventRecord(e0, stream));
     hipLaunchKernelGGL(colred_partial<T>, dim3(colblocks, rowblocks), dim3(256), 0, stream, n, dld, dcost, rows_per_block,
                        b_pmin.as<T>(), b_parg.as<int32_t>(), d_nonfinite);
     hipLaunchKernelGGL(colred_finish<T>, dim3((n + 255) / 256), dim3(256), 0, stream, n, rowblocks, b_pmin.as<T>(),
                        b_parg.as<int32_t>(), d_v, b_imin.as<int32_t>(), d_rowsol, d_matches);
-    hipLaunchKernelGGL(colred_assign, dim3((n + 255) / 256), dim3(256), 0, stream, n, b_imin.as<int32_t>(),
-                       d_rowsol, d_colsol);
+    hipLaunchKernelGGL(colred_assign, dim3((n + 255) / 256), dim3(256), 0, stream, n, b_imin.as<int32_t>(), d_rowsol, d_colsol);
     CYTO_HIP(hipEventRecord(e1, stream));
-
-    // duplicate-row groups (float32 fast path only): runs of bitwise identical consecutive rows
-    DevBuf b_same, b_gid;
-    int *d_ngroups = b_misc.as<int>() + 36;   // misc + 144
-    const bool want_groups = std::is_same<T, float>::value && n <= FAST_NMAX && n >= 2;
-    if (want_groups) {
-        if ((rc = b_same.alloc(nI)) || (rc = b_gid.alloc(nI))) { cleanup(); return rc; }
-        hipLaunchKernelGGL(rows_same_as_prev<T>, dim3(min(n, 2048)), dim3(256), 0, stream, n, dld, dcost, b_same.as<int32_t>());
-        hipLaunchKernelGGL(rows_group_ids, dim3(1), dim3(1024), 0, stream, n, b_same.as<int32_t>(), b_gid.as<int32_t>(), d_ngroups);
-    }
-    // a non-finite cost makes every later comparison meaningless: stop before the chain
-    int h_nonfinite = 0, h_ngroups = n;
+    int h_nonfinite = 0;
     CYTO_HIP(hipMemcpyAsync(&h_nonfinite, d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, stream));
-    if (want_groups) CYTO_HIP(hipMemcpyAsync(&h_ngroups, d_ngroups, sizeof(int), hipMemcpyDeviceToHost, stream));
     CYTO_HIP(hipStreamSynchronize(stream));
-    if (h_nonfinite) { cleanup(); return CYTO_ERR_NONFINITE; }
-
+    if (h_nonfinite) return CYTO_ERR_NONFINITE;
     ChainArgs<T> ca;
     ca.n = n; ca.ld = dld; ca.cost = dcost; ca.v = d_v; ca.u = d_u;
     ca.rowsol = d_rowsol; ca.colsol = d_colsol; ca.matches = d_matches;
-    ca.freerows = d_free; ca.rtrows = d_rt; ca.pred = d_pred;
-    ca.total = d_total; ca.counters = d_counters; ca.status = d_status;
+    ca.freerows = d_rowsol + 3 * (size_t)n; ca.rtrows = d_rowsol + 4 * (size_t)n; ca.pred = d_rowsol + 5 * (size_t)n;
+    ca.total = reinterpret_cast<double *>(b_misc.as<char>() + 8);
+    ca.counters = reinterpret_cast<long long *>(b_misc.as<char>() + 16);
+    ca.status = b_misc.as<int>() + 1;
     ca.dwork = d_v + 4 * (size_t)n; ca.lvl = d_rowsol + 7 * (size_t)n;
-
-    hipEvent_t e1b, e1c, e1d;
-    CYTO_HIP(hipEventCreate(&e1b));
-    CYTO_HIP(hipEventCreate(&e1c));
-    CYTO_HIP(hipEventCreate(&e1d));
-    CYTO_HIP(hipEventRecord(e1b, stream));
+    // register-resident chain while it does not spill (n <= 4096), else everything streams from L2
     const int64_t per = (int64_t)VW * BLOCK;
-    DevBuf b_ccol, b_cval, b_ghb, b_ghs, b_coop, b_cghb, b_cghs;
-    bool lazy_used = false;
-    bool fast = false;
-    if constexpr (std::is_same<T, float>::value) {
-        // float32 fast path: per-row top-K caches + single-wave cached chain steps
-        fast = n <= FAST_NMAX;
+    if (n <= 2 * per && opts.chain_variant == 0) rc = launch_chain<T, 2, true>(ca, stream);
+    else {
+        hipLaunchKernelGGL(jv_chain_stream<T>, dim3(1), dim3(BLOCK), 0, stream, ca);
+        rc = hipGetLastError() == hipSuccess ? CYTO_OK : CYTO_ERR_HIP;
     }
-    if (fast) {
-        if constexpr (std::is_same<T, float>::value) {
-            if ((rc = b_ccol.alloc((size_t)n * KC * sizeof(uint32_t))) || (rc = b_cval.alloc((size_t)n * KC * sizeof(float)))) {
-                cleanup(); return rc;
-            }
-            Chain2Args c2;
-            c2.n = n; c2.ld = dld; c2.cost = dcost; c2.fws = d_v; c2.iws = d_rowsol;
-            c2.cache_col = b_ccol.as<uint32_t>(); c2.cache_val = b_cval.as<float>(); c2.misc = b_misc.as<char>();
-            // duplicate-row skip: per-group state in LDS when it fits beside v (4 B) and colsol (2 B) per column
-            c2.rowgid = b_gid.as<int32_t>(); c2.ngroups = h_ngroups; c2.gmode = 0; c2.g_hbest = nullptr; c2.g_hstamp = nullptr;
-            c2.auxlds = 0; c2.aug_start = 0;
-            // ---- cache-certified augmentation (CYTO_AUG=lazy) ----
-            LazyPlan lz; memset(&lz, 0, sizeof lz);
-            DevBuf b_lzhb, b_lzhs;
-            {
-                // default for n > 5120 (measured cross-over with the register-resident dense search, uniform and
-                // duplicated-row instances); CYTO_AUG=lazy forces it at any size, CYTO_AUG=single|stream|coop selects
-                // the older kernels
-                const char *e = getenv("CYTO_AUG");
-                if (e ? strcmp(e, "lazy") == 0 : n > 5120) {
-                    const size_t npad6 = (((size_t)((n + 3) & ~3) * 6) + 15) & ~(size_t)15, nb24 = (size_t)((((n + 63) / 64) + 511) & ~511) * 8 + (size_t)((n + 63) / 64) * 24 + 16;
-                    const size_t lds_budget = 160 * 1024 - 2048;       // static __shared__ of the kernel
-                    lz.enabled = true;
-                    lazy_used = true;
-                    lz.lds_state = n <= 65535 && !getenv("CYTO_FORCE_STREAM") && npad6 + nb24 <= lds_budget;
-                    const size_t npad2 = (((size_t)((n + 3) & ~3) * 2) + 15) & ~(size_t)15;
-                    lz.cs_lds = !lz.lds_state && n <= 65535 && npad2 + nb24 <= lds_budget;
-                    lz.shm = (lz.lds_state ? npad6 : (lz.cs_lds ? npad2 : 0)) + nb24;
-                    LazyArgs &la = lz.args;
-                    la.n = n; la.ld = dld; la.cost = dcost; la.gv = d_v; la.gu = d_u; la.sumvd = d_v + 2 * (int64_t)n;
-                    la.cassign = d_v + 3 * (int64_t)n; la.dkey = reinterpret_cast<uint64_t *>(d_v + 4 * (int64_t)n);
-                    la.rowsol = d_rowsol; la.colsol = d_colsol; la.freerows = d_free;
-                    la.srow = d_rowsol + 6 * (int64_t)n;      // [n+1]: runs into the next slot, which the lazy path does not use
-                    la.slist = d_rowsol + 8 * (int64_t)n; la.slevel = d_rowsol + 9 * (int64_t)n;
-                    la.rowgid = b_gid.as<int32_t>(); la.cache_col = b_ccol.as<uint32_t>(); la.cache_val = b_cval.as<float>();
-                    la.misc = b_misc.as<char>(); la.ngroups = h_ngroups; la.gmode = 0; la.g_hbest = nullptr; la.g_hstamp = nullptr;
-                    if (want_groups && h_ngroups < n) {
-                        if (lz.shm + (size_t)h_ngroups * 8 <= lds_budget) { la.gmode = 1; lz.shm += (size_t)h_ngroups * 8; }
-                        else {
-                            la.gmode = 2;
-                            if ((rc = b_lzhb.alloc((size_t)h_ngroups * 4)) || (rc = b_lzhs.alloc((size_t)h_ngroups * 4))) { cleanup(); return rc; }
-                            CYTO_HIP(hipMemsetAsync(b_lzhs.p, 0, (size_t)h_ngroups * 4, stream));
-                            la.g_hbest = b_lzhb.as<float>(); la.g_hstamp = b_lzhs.as<int32_t>();
-                        }
-                    }
-                }
-            }
-            if (want_groups && h_ngroups < n) {
-                // LDS beside the group state: v (4 B) + colsol (2 B) per column on the LDS-resident path,
-                // the unassigned-column bitmap on the streaming path
-                const size_t lds_state = (n <= 13 * 4 * BLOCK2 && !getenv("CYTO_FORCE_STREAM")) ? (size_t)((n + 3) & ~3) * 6
-                                                                                               : (size_t)((n + 31) / 32) * 4;
-                if (lds_state + (size_t)h_ngroups * 8 + 8192 <= 160 * 1024) c2.gmode = 1;
-                else {
-                    c2.gmode = 2;
-                    if ((rc = b_ghb.alloc((size_t)h_ngroups * 4)) || (rc = b_ghs.alloc((size_t)h_ngroups * 4))) { cleanup(); return rc; }
-                    CYTO_HIP(hipMemsetAsync(b_ghs.p, 0, (size_t)h_ngroups * 4, stream));
-                    c2.g_hbest = b_ghb.as<float>(); c2.g_hstamp = b_ghs.as<int32_t>();
-                }
-            }
-            // ---- augmentation kernel choice: cooperative (W workers on W CUs) above a size threshold ----
-            CoopPlan plan; memset(&plan, 0, sizeof plan);
-            {
-                const char *e = getenv("CYTO_AUG");
-                const char *emin = getenv("CYTO_COOP_MIN_N");
-                const int coop_min_n = emin ? atoi(emin) : 0;   // opt-in: CYTO_AUG=coop or CYTO_COOP_MIN_N=<n>
-                const bool want = !tl_single_cu_only && ((e && strcmp(e, "coop") == 0) || (emin && n >= coop_min_n));
-                if (want) {
-                    const char *ew = getenv("CYTO_COOP_W"), *es = getenv("CYTO_COOP_STRIDE");
-                    int W = ew ? max(1, min(64, atoi(ew))) : 16;
-                    const int stride = es ? max(1, atoi(es)) : 8;
-                    const int nquad = (n + 3) / 4;
-                    const size_t lds_max = 150 * 1024;
-                    size_t shm = 0; int QW = 0;
-                    for (;;) {
-                        QW = (nquad + W - 1) / W;
-                        const size_t C = (size_t)4 * QW;
-                        shm = C * 36 + ((C + 31) / 32) * 4 + 64;
-                        if (shm <= lds_max || W >= 64) break;
-                        W = min(64, W * 2);
-                    }
-                    if (shm <= lds_max) {
-                        CoopArgs &ca = plan.args;
-                        ca.n = n; ca.ld = dld; ca.cost = dcost; ca.gv = d_v; ca.cassign = d_v + 3 * (int64_t)n;
-                        ca.rowsol = d_rowsol; ca.colsol = d_colsol; ca.freerows = d_free; ca.colgroup = d_rowsol + 6 * (int64_t)n;
-                        ca.rowgid = b_gid.as<int32_t>(); ca.misc = b_misc.as<char>();
-                        ca.ngroups = h_ngroups; ca.gmode = 0; ca.g_hbest = nullptr; ca.g_hstamp = nullptr;
-                        ca.W = W; ca.stride = stride; ca.QW = QW;
-                        if (c2.gmode) {
-                            if (shm + (size_t)h_ngroups * 8 <= lds_max + 6 * 1024) { ca.gmode = 1; shm += (size_t)h_ngroups * 8; }
-                            else {
-                                ca.gmode = 2;
-                                if ((rc = b_cghb.alloc((size_t)W * h_ngroups * 4)) || (rc = b_cghs.alloc((size_t)W * h_ngroups * 4))) { cleanup(); return rc; }
-                                ca.g_hbest = b_cghb.as<float>(); ca.g_hstamp = b_cghs.as<int32_t>();
-                            }
-                        }
-                        if ((rc = b_coop.alloc(4096 + 64))) { cleanup(); return rc; }
-                        CYTO_HIP(hipMemsetAsync(b_coop.p, 0xFF, 4096, stream));
-                        CYTO_HIP(hipMemsetAsync(b_coop.as<char>() + 4096, 0, 64, stream));
-                        ca.slots = b_coop.as<uint64_t>(); ca.abort_flag = reinterpret_cast<int *>(b_coop.as<char>() + 4096);
-                        plan.shm = shm; plan.enabled = true;
-                    }
-                }
-            }
-            const int cache_grid = max(1, min(n, 1024));
-            const int per2 = 4 * BLOCK2;
-            // CYTO_FORCE_STREAM=1 (tests): take the large-n code path (state in global memory, streaming
-            // augmentation) at any size
-            const bool force_stream = getenv("CYTO_FORCE_STREAM") != nullptr;
-            // (=2: also the streaming dense refresh used beyond 32768 columns)
-            const bool force_refresh_stream = force_stream && strcmp(getenv("CYTO_FORCE_STREAM"), "2") == 0;
-            if (force_refresh_stream) rc = launch_chain2<0, false>(c2, cache_grid, e1c, e1d, stream, plan, lz);
-            else if (force_stream && n <= 5 * per2) rc = launch_chain2<5, false>(c2, cache_grid, e1c, e1d, stream, plan, lz);
-            else if (force_stream && n <= 16 * per2) rc = launch_chain2<16, false>(c2, cache_grid, e1c, e1d, stream, plan, lz);
-            else if (force_stream) rc = launch_chain2<0, false>(c2, cache_grid, e1c, e1d, stream, plan, lz);
-            else if (n <= 2 * per2) rc = launch_chain2<2, true>(c2, cache_grid, e1c, e1d, stream, plan, lz);
-            else if (n <= 5 * per2) rc = launch_chain2<5, true>(c2, cache_grid, e1c, e1d, stream, plan, lz);
-            else if (n <= 10 * per2) rc = launch_chain2<10, true>(c2, cache_grid, e1c, e1d, stream, plan, lz);
-            else if (n <= 13 * per2) rc = launch_chain2<13, true>(c2, cache_grid, e1c, e1d, stream, plan, lz);
-            else if (n <= 16 * per2) rc = launch_chain2<16, false>(c2, cache_grid, e1c, e1d, stream, plan, lz);
-            else rc = launch_chain2<0, false>(c2, cache_grid, e1c, e1d, stream, plan, lz);   // streaming dense refresh, any n
-        }
-    } else {
-        CYTO_HIP(hipEventRecord(e1c, stream));
-        CYTO_HIP(hipEventRecord(e1d, stream));
-        if constexpr (!std::is_same<T, float>::value) {
-            // float64: register-resident chain while it does not spill (n <= 4096), else everything streams from L2
-            if (n <= 2 * per && !getenv("CYTO_FORCE_STREAM")) rc = launch_chain<T, 2, true>(ca, stream);
-            else {
-                hipLaunchKernelGGL(jv_chain_stream<T>, dim3(1), dim3(BLOCK), 0, stream, ca);
-                rc = hipGetLastError() == hipSuccess ? CYTO_OK : CYTO_ERR_HIP;
-            }
-        } else {
-            rc = CYTO_ERR_UNSUPPORTED;      // (float32 always takes the cached-chain path above)
-        }
-    }
-    if (rc) { cleanup(); (void)hipEventDestroy(e1b); (void)hipEventDestroy(e1c); (void)hipEventDestroy(e1d); return rc; }
+    if (rc) return rc;
     CYTO_HIP(hipEventRecord(e2, stream));
     CYTO_HIP(hipStreamSynchronize(stream));
-
     int h_status = 0;
-    long long h_counters[C3_NCOUNTERS] = {0};
-    CYTO_HIP(hipMemcpy(&h_status, d_status, sizeof(int), hipMemcpyDeviceToHost));
-    CYTO_HIP(hipMemcpy(h_counters, d_counters, sizeof(h_counters), hipMemcpyDeviceToHost));
-#ifdef LZ_PROF
-    {
-        long long pp[12];
-        CYTO_HIP(hipMemcpy(pp, b_misc.as<char>() + 152, sizeof pp, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[lazy prof] cycles:");
-        fprintf(stderr, " per search (n=%lld): gap+start %lld init %lld steps %lld end %lld;", pp[6], pp[0], pp[1], pp[2], pp[3]);
-        for (int k = 4; k < 6; k++) fprintf(stderr, " seg%d %.0f/step (n=%lld)", k, pp[6 + k] ? (double)pp[k] / pp[6 + k] : 0.0, pp[6 + k]);
-        fprintf(stderr, "\n");
-    }
-#endif
+    long long h_counters[C_NCOUNTERS] = {0};
+    CYTO_HIP(hipMemcpy(&h_status, ca.status, sizeof(int), hipMemcpyDeviceToHost));
+    CYTO_HIP(hipMemcpy(h_counters, ca.counters, sizeof(h_counters), hipMemcpyDeviceToHost));
     if (rowsol) CYTO_HIP(hipMemcpy(rowsol, d_rowsol, nI, hipMemcpyDeviceToHost));
     if (colsol) CYTO_HIP(hipMemcpy(colsol, d_colsol, nI, hipMemcpyDeviceToHost));
     if (u) CYTO_HIP(hipMemcpy(u, d_u, nT, hipMemcpyDeviceToHost));
     if (v) CYTO_HIP(hipMemcpy(v, d_v, nT, hipMemcpyDeviceToHost));
-    if (total) CYTO_HIP(hipMemcpy(total, d_total, sizeof(double), hipMemcpyDeviceToHost));
+    if (total) CYTO_HIP(hipMemcpy(total, ca.total, sizeof(double), hipMemcpyDeviceToHost));
     if (info) {
         memset(info, 0, sizeof *info);
         float ms = 0;
         (void)hipEventElapsedTime(&ms, e0, e1); info->ms_colred = ms;
-        (void)hipEventElapsedTime(&ms, e1b, e1c); info->ms_cache = ms;
-        (void)hipEventElapsedTime(&ms, e1c, e2); info->ms_chain = ms;
-        if (fast) { (void)hipEventElapsedTime(&ms, e1c, e1d); info->ms_arr = ms; (void)hipEventElapsedTime(&ms, e1d, e2); info->ms_aug = ms; }
-        info->ms_total = info->ms_colred + info->ms_cache + info->ms_chain;
+        (void)hipEventElapsedTime(&ms, e1, e2); info->ms_chain = ms;
+        info->ms_total = info->ms_colred + info->ms_chain;
         info->scans_colred = n;
         info->scans_redtransfer = h_counters[C_RT];
         info->scans_arr = h_counters[C_ARR];
@@ -3439,31 +3129,48 @@ static int lap_solve(int n, const T *cost, int64_t ld, int cost_on_device, int32
         info->free_after_colred = h_counters[C_FREE_CR];
         info->free_after_arr1 = h_counters[C_FREE_A1];
         info->free_after_arr2 = h_counters[C_FREE_A2];
-        info->hbm_row_reads = n + (fast ? n : 0) + h_counters[C_ROWS_READ];
-        info->dense_refreshes = fast ? h_counters[C2_DENSE_REFRESH] : 0;
-        info->aug_scans_skipped = fast ? h_counters[C2_AUG_SKIPPED] : 0;
-        info->aug_dense_scans = fast ? h_counters[C2_AUG_DENSE] : 0;
-        info->aug_sparse_inits = fast ? h_counters[C2_AUG_SPARSE_INIT] : 0;
+        info->hbm_row_reads = n + h_counters[C_ROWS_READ];
         info->aug_handover = -1;
-        if (fast && lazy_used) {
-            int h[3] = {0, 0, 0};
-            CYTO_HIP(hipMemcpy(h, b_misc.as<char>() + 128, sizeof h, hipMemcpyDeviceToHost));
-            if (h[2] < h[0]) info->aug_handover = h[2];
-        }
-        info->row_groups = h_ngroups;
+        info->row_groups = n;
     }
-    cleanup();
-    (void)hipEventDestroy(e1b);
-    (void)hipEventDestroy(e1c);
-    (void)hipEventDestroy(e1d);
     return h_status ? CYTO_ERR_INTERNAL : CYTO_OK;
+}
+
+// one float32 problem = a batch of one
+static int lap_solve_f32(int n, const float *cost, int64_t ld, int cost_on_device, int32_t *rowsol, int32_t *colsol,
+                         float *u, float *v, double *total, cyto_lap_info *info, int device_id, hipStream_t stream,
+                         const cyto_lap_opts &opts) {
+    if (n <= 0 || !cost || ld < n) return CYTO_ERR_BAD_ARG;
+    std::vector<F32Job> jobs(1);
+    F32Job &j = jobs[0];
+    j.cost = cost; j.ld = ld; j.cost_on_device = cost_on_device;
+    j.rowsol = rowsol; j.colsol = colsol; j.u = u; j.v = v; j.total = total; j.info = info;
+    const int rc = lap_solve_f32_batch(n, jobs, device_id, stream, opts);
+    return rc ? rc : j.status;
+}
+
+// C ABI helper of cyto_lap_batch_f32 (batch.hip): problems of equal size go through the chains together
+int lap_batch_same_n(int n, int nb, const float *const *cost, const int64_t *ld, int cost_on_device, int32_t *const *rowsol,
+                     int32_t *const *colsol, float *const *u, float *const *v, double *total, cyto_lap_info *info, int *status,
+                     int device_id, hipStream_t stream) {
+    std::vector<F32Job> jobs((size_t)nb);
+    for (int b = 0; b < nb; b++) {
+        F32Job &j = jobs[(size_t)b];
+        j.cost = cost[b]; j.ld = ld[b]; j.cost_on_device = cost_on_device;
+        j.rowsol = rowsol ? rowsol[b] : nullptr; j.colsol = colsol ? colsol[b] : nullptr;
+        j.u = u ? u[b] : nullptr; j.v = v ? v[b] : nullptr;
+        j.total = total ? &total[b] : nullptr; j.info = info ? &info[b] : nullptr;
+    }
+    const int rc = lap_solve_f32_batch(n, jobs, device_id, stream, k_default_opts);
+    for (int b = 0; b < nb; b++) status[b] = rc ? rc : jobs[(size_t)b].status;
+    return rc;
 }
 
 // float64 -> float32 of a row-major matrix (the cast numpy's astype(float32) performs: round to nearest even)
 __global__ __launch_bounds__(256) void narrow_f64_to_f32(int n, int64_t lds_, const double *__restrict__ src, int64_t ldd,
                                                          float *__restrict__ dst) {
-    const int64_t row = blockIdx.y;
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) dst[row * ldd + c] = (float)src[row * lds_ + c];
+    for (int64_t row = blockIdx.y; row < n; row += gridDim.y)
+        for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) dst[row * ldd + c] = (float)src[row * lds_ + c];
 }
 
 }  // namespace cyto
@@ -3481,25 +3188,45 @@ int cyto_lap_f32_from_f64(int n, const double *cost_host, int64_t ld, int32_t *r
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const int64_t ldd = ((int64_t)n + 3) & ~(int64_t)3;
     cyto::DevBuf d64, d32;
-    if ((rc = d64.alloc((size_t)n * n * sizeof(double))) || (rc = d32.alloc((size_t)n * ldd * sizeof(float)))) return rc;
+    if ((rc = d64.alloc((size_t)n * n * sizeof(double), stream)) || (rc = d32.alloc((size_t)n * ldd * sizeof(float), stream))) return rc;
     CYTO_HIP(hipMemcpy2DAsync(d64.p, (size_t)n * sizeof(double), cost_host, (size_t)ld * sizeof(double), (size_t)n * sizeof(double), n,
                               hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(cyto::narrow_f64_to_f32, dim3((n + 255) / 256 > 64 ? 64 : (n + 255) / 256, n), dim3(256), 0, stream, n, (int64_t)n,
-                       d64.as<double>(), ldd, d32.as<float>());
+    hipLaunchKernelGGL(cyto::narrow_f64_to_f32, dim3((n + 255) / 256 > 64 ? 64 : (n + 255) / 256, n > 32768 ? 32768 : n), dim3(256), 0,
+                       stream, n, (int64_t)n, d64.as<double>(), ldd, d32.as<float>());
     CYTO_HIP(hipGetLastError());
     CYTO_HIP(hipStreamSynchronize(stream));
-    (void)hipFree(d64.p); d64.p = nullptr;                  // the float64 copy is not needed during the solve
-    return cyto::lap_solve<float>(n, d32.as<float>(), ldd, 1, rowsol, colsol, u, v, total, info, device_id, stream_);
+    d64.reset();                                           // the float64 copy is not needed during the solve
+    return cyto::lap_solve_f32(n, d32.as<float>(), ldd, 1, rowsol, colsol, u, v, total, info, device_id, stream, cyto::k_default_opts);
 }
 
 int cyto_lap_f32(int n, const float *cost, int64_t ld, int cost_on_device, int32_t *rowsol, int32_t *colsol,
                  float *u, float *v, double *total, cyto_lap_info *info, int device_id, void *stream) {
-    return cyto::lap_solve<float>(n, cost, ld, cost_on_device, rowsol, colsol, u, v, total, info, device_id, stream);
+    return cyto::lap_solve_f32(n, cost, ld, cost_on_device, rowsol, colsol, u, v, total, info, device_id, reinterpret_cast<hipStream_t>(stream), cyto::k_default_opts);
 }
 
 int cyto_lap_f64(int n, const double *cost, int64_t ld, int cost_on_device, int32_t *rowsol, int32_t *colsol,
                  double *u, double *v, double *total, cyto_lap_info *info, int device_id, void *stream) {
-    return cyto::lap_solve<double>(n, cost, ld, cost_on_device, rowsol, colsol, u, v, total, info, device_id, stream);
+    return cyto::lap_solve_f64(n, cost, ld, cost_on_device, rowsol, colsol, u, v, total, info, device_id, reinterpret_cast<hipStream_t>(stream), cyto::k_default_opts);
+}
+
+#ifdef CYTO_AUG_PROF
+// profiling build only (tools/prof_aug_step.py): read and clear the step-cycle accumulators of the dense augmentation
+int cyto_aug_prof_read(long long *out16) {
+    long long z[16] = {0};
+    CYTO_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(cyto::g_aug_prof), sizeof z));
+    CYTO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(cyto::g_aug_prof), z, sizeof z));
+    return CYTO_OK;
+}
+#endif
+
+int cyto_lap_f32_opts(int n, const float *cost, int64_t ld, int cost_on_device, int32_t *rowsol, int32_t *colsol,
+                      float *u, float *v, double *total, cyto_lap_info *info, int device_id, void *stream, const cyto_lap_opts *opts) {
+    return cyto::lap_solve_f32(n, cost, ld, cost_on_device, rowsol, colsol, u, v, total, info, device_id, reinterpret_cast<hipStream_t>(stream), opts ? *opts : cyto::k_default_opts);
+}
+
+int cyto_lap_f64_opts(int n, const double *cost, int64_t ld, int cost_on_device, int32_t *rowsol, int32_t *colsol,
+                      double *u, double *v, double *total, cyto_lap_info *info, int device_id, void *stream, const cyto_lap_opts *opts) {
+    return cyto::lap_solve_f64(n, cost, ld, cost_on_device, rowsol, colsol, u, v, total, info, device_id, reinterpret_cast<hipStream_t>(stream), opts ? *opts : cyto::k_default_opts);
 }
 
 }  // extern "C"

@@ -15,11 +15,13 @@ import numpy as np
 from . import _lib
 
 
-def lap_solve(cost, dtype=np.float32, device_id=0, return_info=False, device_ptr=None, n=None, ld=None):
+def lap_solve(cost, dtype=np.float32, device_id=0, return_info=False, device_ptr=None, n=None, ld=None, opts=None):
     """Solve a square LAP on the GPU.
 
     cost        2-D square array-like (host) -- cast to `dtype` -- or None with `device_ptr`
     device_ptr  int address of a device-resident row-major matrix (then give n and ld)
+    opts        None, or a dict of cyto_lap_opts fields (chain_variant, augmentation, no_handover, inject_exceptions):
+                kernel selection only, the results never depend on it
     Returns dict(rowsol, colsol, u, v, total[, info]).
     """
     L = _lib.lib()
@@ -50,7 +52,15 @@ def lap_solve(cost, dtype=np.float32, device_id=0, return_info=False, device_ptr
     v = np.empty(n, dtype)
     total = ctypes.c_double()
     info = _lib.LapInfo()
-    if narrow_on_device:
+    if opts:
+        o = _lib.LapOpts(**opts)
+        if narrow_on_device:
+            c = np.ascontiguousarray(c, dtype=dtype)
+            ptr = c.ctypes.data
+        fn = L.cyto_lap_f32_opts if dtype == np.float32 else L.cyto_lap_f64_opts
+        st = fn(n, ptr, ld, on_device, rowsol.ctypes.data, colsol.ctypes.data, u.ctypes.data, v.ctypes.data,
+                ctypes.byref(total), ctypes.byref(info), device_id, None, ctypes.byref(o))
+    elif narrow_on_device:
         st = L.cyto_lap_f32_from_f64(n, ptr, ld, rowsol.ctypes.data, colsol.ctypes.data, u.ctypes.data, v.ctypes.data,
                                      ctypes.byref(total), ctypes.byref(info), device_id, None)
     else:
@@ -99,6 +109,35 @@ def lap_solve_batch(costs, device_id=0, max_concurrent=0, return_info=False):
     infos = (_lib.LapInfo * nb)()
     status = (ctypes.c_int * nb)()
     st = L.cyto_lap_batch_f32(nb, ns, cptr, lds, 0, ptrs("rowsol"), ptrs("colsol"), ptrs("u"), ptrs("v"), totals, infos,
+                              status, max_concurrent, device_id)
+    _lib.check(st)
+    for b, o in enumerate(outs):
+        o["total"] = totals[b]
+        if return_info:
+            o["info"] = infos[b]
+    return outs
+
+
+def lap_solve_batch_device(device_ptrs, ns, lds=None, device_id=0, max_concurrent=0, return_info=False):
+    """lap_solve_batch for cost matrices that are already resident in HBM (row-major float32, ld elements per row)."""
+    L = _lib.lib()
+    nb = len(device_ptrs)
+    if nb == 0:
+        return []
+    lds = list(ns) if lds is None else list(lds)
+    n_arr = (ctypes.c_int * nb)(*[int(x) for x in ns])
+    ld_arr = (ctypes.c_int64 * nb)(*[int(x) for x in lds])
+    outs = [dict(rowsol=np.empty(n, np.int32), colsol=np.empty(n, np.int32), u=np.empty(n, np.float32),
+                 v=np.empty(n, np.float32)) for n in ns]
+
+    def ptrs(key):
+        return (ctypes.c_void_p * nb)(*[o[key].ctypes.data for o in outs])
+
+    cptr = (ctypes.c_void_p * nb)(*[int(p) for p in device_ptrs])
+    totals = (ctypes.c_double * nb)()
+    infos = (_lib.LapInfo * nb)()
+    status = (ctypes.c_int * nb)()
+    st = L.cyto_lap_batch_f32(nb, n_arr, cptr, ld_arr, 1, ptrs("rowsol"), ptrs("colsol"), ptrs("u"), ptrs("v"), totals, infos,
                               status, max_concurrent, device_id)
     _lib.check(st)
     for b, o in enumerate(outs):

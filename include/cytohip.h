@@ -26,7 +26,7 @@ enum {
     CYTO_ERR_INTERNAL = 4,      /* solver invariant violated */
     CYTO_ERR_HIP = 5,           /* a HIP runtime call failed; cyto_last_hip_error() has the text */
     CYTO_ERR_NO_DEVICE = 6,     /* no gfx950 device visible */
-    CYTO_ERR_UNSUPPORTED = 7,   /* size outside what this build supports (n > 65536 per LAP) */
+    CYTO_ERR_UNSUPPORTED = 7,   /* size outside what this build supports (n > 262144 per LAP) */
     CYTO_ERR_SHAPE = 8          /* gene counts differ; reference: ValueError, common/common.py:191-192 */
 };
 
@@ -42,6 +42,10 @@ int cyto_free(void *dptr, int device_id);
 int cyto_memcpy_h2d(void *dst, const void *src, size_t bytes, int device_id);
 int cyto_memcpy_d2h(void *dst, const void *src, size_t bytes, int device_id);
 int cyto_device_synchronize(int device_id);
+/* Work buffers of the solves are taken from a per-device cache of HBM blocks and go back to it afterwards (a steady
+ * stream of chunk solves performs no hipMalloc / hipFree: hipFree would synchronise the whole device and serialise the
+ * chunks that run side by side).  This returns every cached block to the runtime. */
+int cyto_trim_device_cache(int device_id);
 
 /* ---- A5: the LAP solve.  Replaces `_, y, _ = lapjv.lapjv(cost_scaled)`
  * (cytospace/linear_assignment_solvers/linear_assignment_solvers.py:34-40; solver imported
@@ -84,6 +88,26 @@ int cyto_lap_f32(int n, const float *cost, int64_t ld, int cost_on_device,
 int cyto_lap_f64(int n, const double *cost, int64_t ld, int cost_on_device,
                  int32_t *rowsol, int32_t *colsol, double *u, double *v, double *total,
                  cyto_lap_info *info, int device_id, void *stream);
+
+/* The same solves with explicit kernel-selection options.  Results never depend on them (every variant realises the same
+ * search, bit for bit); they exist so that the kernels the solver picks for n > 26 624 / 32 768 and the hand-over paths can
+ * be exercised on instances small enough for the CPU oracle (tests/test_lap_gpu.py).  NULL = the defaults. */
+typedef struct {
+    int32_t chain_variant;      /* 0: by size.  1: prices in L2 (u16 colsol in LDS), cached refresh -- what n > 26 624 uses.
+                                   2: streaming dense refresh -- what n > 32 768 uses.  float64: != 0 selects the streaming chain */
+    int32_t augmentation;       /* 0: by size (cache-certified search above 5 120 columns).  1: dense register-resident search
+                                   (n <= 26 624 only).  2: cache-certified search */
+    int32_t no_handover;        /* 1: the cache-certified search never hands deep searches over to the dense kernel */
+    int32_t inject_exceptions;  /* self-test of the rounding-exception list of the cache-certified search: treat the first k
+                                   columns as exception columns (k > 64 overflows the list: certificates are abandoned) */
+    int32_t reserved[4];        /* must be 0 */
+} cyto_lap_opts;
+int cyto_lap_f32_opts(int n, const float *cost, int64_t ld, int cost_on_device,
+                      int32_t *rowsol, int32_t *colsol, float *u, float *v, double *total,
+                      cyto_lap_info *info, int device_id, void *stream, const cyto_lap_opts *opts);
+int cyto_lap_f64_opts(int n, const double *cost, int64_t ld, int cost_on_device,
+                      int32_t *rowsol, int32_t *colsol, double *u, double *v, double *total,
+                      cyto_lap_info *info, int device_id, void *stream, const cyto_lap_opts *opts);
 
 /* `lapjv(cost_scaled)` as the reference calls it (linear_assignment_solvers.py:38): a float64 HOST matrix solved in
  * float32.  The matrix is uploaded as it is and narrowed on the device (same rounding as numpy's astype(float32)). */

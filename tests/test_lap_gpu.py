@@ -15,9 +15,9 @@ STAT_KEYS = ["scans_colred", "scans_redtransfer", "scans_arr", "scans_aug_init",
              "augmentations", "path_hops", "free_after_colred", "free_after_arr1", "free_after_arr2"]
 
 
-def _check(c, dtype):
+def _check(c, dtype, opts=None):
     o = jv_oracle(c, dtype)
-    g = lap_solve(c, dtype, return_info=True)
+    g = lap_solve(c, dtype, return_info=True, opts=opts)
     assert np.array_equal(g["rowsol"], o["rowsol"])
     assert np.array_equal(g["colsol"], o["colsol"])
     assert np.array_equal(g["v"], o["v"]), "dual prices v differ"
@@ -165,66 +165,59 @@ def test_duplicate_rows_skip_is_exact_and_deterministic(n, slots):
         assert g["info"].row_groups == n // slots and g["info"].aug_scans_skipped > 0
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_large_n_code_path_forced_at_small_n(monkeypatch, mode):
-    # CYTO_FORCE_STREAM routes any size through the large-n kernels (state in L2-resident global memory,
-    # streaming augmentation; "2": also the streaming dense refresh used beyond 32768 columns); they must
-    # be bit-identical too.  The real switch-overs are at n > 26624 and n > 32768.
-    monkeypatch.setenv("CYTO_FORCE_STREAM", mode)
+@pytest.mark.parametrize("mode", [1, 2])
+def test_large_n_code_path_forced_at_small_n(mode):
+    # cyto_lap_opts.chain_variant routes any size through the large-n kernels (prices in L2-resident global memory,
+    # u16 colsol in LDS, cache-certified augmentation without LDS state; 2: also the streaming dense refresh used beyond
+    # 32768 columns); they must be bit-identical too.  The real switch-overs are at n > 26624 and n > 32768, where
+    # tests/test_large_gpu.py runs them at true size against goldens.
+    opts = dict(chain_variant=mode)
     for n in (5, 64, 700, 2300):
         c = np.random.default_rng(n).random((n, n)).astype(np.float32)
-        _check(c, np.float32)
+        _check(c, np.float32, opts)
     rng = np.random.default_rng(8)
     base = -(rng.random((300, 1500)) ** 3).astype(np.float32)
     c = np.repeat(base, 5, axis=0)
-    g = lap_solve(c, np.float32, return_info=True)
-    _check(c, np.float32)
+    g = lap_solve(c, np.float32, return_info=True, opts=opts)
+    _check(c, np.float32, opts)
     assert g["info"].aug_scans_skipped > 0
     c = np.random.default_rng(3).integers(0, 10, (400, 400)).astype(np.float32)
-    _check(c, np.float32)
+    _check(c, np.float32, opts)
+    c = np.random.default_rng(12).random((900, 900))
+    _check(c, np.float64, opts)          # float64: the streaming chain at a size the register chain would take
 
 
-@pytest.mark.parametrize("W,stride", [("16", "8"), ("64", "1"), ("3", "8")])
-def test_cooperative_augmentation_forced(monkeypatch, W, stride):
-    # CYTO_AUG=coop routes the augmentation through the (opt-in) multi-CU cooperative kernel; W workers, placed on one XCD (stride 8) or round-robin over all XCDs (stride 1).
-    monkeypatch.setenv("CYTO_AUG", "coop")
-    monkeypatch.setenv("CYTO_COOP_W", W)
-    monkeypatch.setenv("CYTO_COOP_STRIDE", stride)
-    for n in (1, 2, 5, 64, 257, 700, 2300):
-        c = np.random.default_rng(n).random((n, n)).astype(np.float32)
-        _check(c, np.float32)
-    rng = np.random.default_rng(8)
-    base = -(rng.random((300, 1500)) ** 3).astype(np.float32)
-    c = np.repeat(base, 5, axis=0)
-    g = lap_solve(c, np.float32, return_info=True)
-    _check(c, np.float32)
-    assert g["info"].aug_scans_skipped > 0
-    c = np.random.default_rng(3).integers(0, 10, (400, 400)).astype(np.float32)
-    _check(c, np.float32)
-    monkeypatch.setenv("CYTO_FORCE_STREAM", "2")
-    c = np.random.default_rng(5).random((1500, 1500)).astype(np.float32)
-    _check(c, np.float32)
-
-
-def test_cache_certified_augmentation_forced(monkeypatch):
-    # CYTO_AUG=lazy: the augmentation relaxes only the cached columns of a row whenever the cache floor
+def test_cache_certified_augmentation_forced():
+    # augmentation=2: the augmentation relaxes only the cached columns of a row whenever the cache floor
     # certifies that no other column can matter; results must stay bit-identical to the oracle.
-    monkeypatch.setenv("CYTO_AUG", "lazy")
+    opts = dict(augmentation=2, no_handover=1)
     for n in (1, 2, 5, 64, 65, 257, 700, 2300, 5000):
         c = np.random.default_rng(n).random((n, n)).astype(np.float32)
-        _check(c, np.float32)
+        _check(c, np.float32, opts)
     rng = np.random.default_rng(8)
     base = -(rng.random((300, 1500)) ** 3).astype(np.float32)
     c = np.repeat(base, 5, axis=0)
-    g = lap_solve(c, np.float32, return_info=True)
-    _check(c, np.float32)
+    g = lap_solve(c, np.float32, return_info=True, opts=opts)
+    _check(c, np.float32, opts)
     assert g["info"].aug_scans_skipped > 0 and g["info"].aug_dense_scans < g["info"].scans_aug_relax
     c = np.random.default_rng(3).integers(0, 10, (400, 400)).astype(np.float32)
-    _check(c, np.float32)
-    monkeypatch.setenv("CYTO_FORCE_STREAM", "2")
+    _check(c, np.float32, opts)
     for n in (130, 1500):
         c = np.random.default_rng(n + 1).random((n, n)).astype(np.float32)
-        _check(c, np.float32)
+        _check(c, np.float32, dict(augmentation=2, no_handover=1, chain_variant=2))
+
+
+def test_dense_augmentation_forced_above_its_default_range():
+    # augmentation=1: the register-resident dense search at a size where the cache-certified one is the default
+    c = np.random.default_rng(6100).random((6100, 6100)).astype(np.float32)
+    _check(c, np.float32, dict(augmentation=1))
+
+
+def test_bad_options_are_rejected():
+    c = np.random.default_rng(1).random((8, 8)).astype(np.float32)
+    for bad in (dict(chain_variant=3), dict(augmentation=-1), dict(no_handover=2), dict(inject_exceptions=-5)):
+        with pytest.raises(ValueError):
+            lap_solve(c, np.float32, opts=bad)
 
 
 def test_augmentation_handover_to_dense_kernel_on_deep_searches():
@@ -244,18 +237,18 @@ def test_augmentation_handover_to_dense_kernel_on_deep_searches():
     assert g["info"].aug_handover >= 0
 
 
-@pytest.mark.parametrize("k", ["5", "100"])
-def test_exception_columns_of_the_cache_certified_augmentation(monkeypatch, k):
+@pytest.mark.parametrize("k", [5, 100])
+def test_exception_columns_of_the_cache_certified_augmentation(k):
     # a price that a rounding pushed UP takes its column out of the cache certificates: such columns are relaxed
     # explicitly in every cached step (k = 5), and when the list overflows the certificates are abandoned (k = 100:
-    # every scan reads its row).  CYTO_DEBUG_EXC pretends the first k columns are such columns; results stay exact.
-    monkeypatch.setenv("CYTO_AUG", "lazy")
-    monkeypatch.setenv("CYTO_DEBUG_EXC", k)
+    # every scan reads its row).  cyto_lap_opts.inject_exceptions pretends the first k columns are such columns; results stay exact.
+    opts = dict(augmentation=2, no_handover=1, inject_exceptions=k)
     for n in (300, 2300):
         c = np.random.default_rng(n + 7).random((n, n)).astype(np.float32)
-        _check(c, np.float32)
+        _check(c, np.float32, opts)
     base = -(np.random.default_rng(9).random((200, 1000)) ** 3).astype(np.float32)
-    _check(np.repeat(base, 5, axis=0), np.float32)
+    _check(np.repeat(base, 5, axis=0), np.float32, opts)
+    _check(np.repeat(base, 5, axis=0), np.float32, dict(augmentation=2, inject_exceptions=k))     # with the hand-over allowed
 
 
 def test_full_size_properties_bench_config():

@@ -1,0 +1,189 @@
+"""GPU parity at the TRUE sizes of BASELINE.json's single-GPU configs (c1, c2, c3 and one c4 chunk pair).
+
+The large LAPs are compared with tests/golden/large_*.npz: what the CPU JV oracle returned in the build container
+for the same seeded instance (tests/golden/make_golden_large.py; certified there by its duals, by scipy and by a
+one-ulp perturbation re-solve).  No oracle run at these sizes happens here (it would need minutes), and nothing of
+/root/reference is read.  Every call goes through the C ABI (ctypes).
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from cytospace_amd import _lib, common
+from cytospace_amd.cytospace import ExpressionContext, assign_pearson, solve_linear_assignment_problem
+from cytospace_amd.lap import lap_solve
+from cytospace_amd.linear_assignment_solvers import calculate_cost, call_solver, import_solver
+from oracle import cost as ocost
+from oracle.jv import jv_oracle
+from tools import instances
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+STAT_KEYS = ["scans_colred", "scans_redtransfer", "scans_arr", "scans_aug_init", "scans_aug_relax",
+             "augmentations", "path_hops", "free_after_colred", "free_after_arr1", "free_after_arr2"]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _golden(tag):
+    path = os.path.join(GOLD, f"large_{tag}.npz")
+    assert os.path.exists(path), f"{path} missing: run tests/golden/make_golden_large.py {tag}"
+    return np.load(path)
+
+
+def _compare_with_golden(tag, buf, n):
+    """HIP solve of the device-resident n x n matrix vs the oracle's stored answer: colsol element for element,
+    rowsol / u / v by sha256 (bit-exact without shipping 3 more arrays), the work counters, the total."""
+    d = _golden(tag)
+    assert int(d["n"]) == n
+    g = lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n)
+    assert np.array_equal(g["colsol"], d["colsol"]), f"{(g['colsol'] != d['colsol']).sum()} of {n} columns differ"
+    assert sha(g["rowsol"]) == str(d["rowsol_sha256"])
+    assert sha(g["v"]) == str(d["v_sha256"]), "dual prices v differ from the oracle's"
+    assert sha(g["u"]) == str(d["u_sha256"]), "duals u differ from the oracle's"
+    assert abs(g["total"] - float(d["total"])) <= 1e-5 * max(1.0, abs(float(d["total"])))   # BASELINE.json's tolerance
+    want = dict(zip([str(k) for k in d["stats_keys"]], d["stats_vals"].tolist()))
+    got = g["info"].as_dict()
+    for k in STAT_KEYS:
+        assert got[k] == want[k], (k, got[k], want[k])
+    assert bool(d["unique"]), "golden is not uniqueness-certified"
+    return g
+
+
+@pytest.mark.parametrize("n", [20000, 33000, 50000])
+def test_uniform_true_size(n):
+    """c2 (20 000) and the north star's 50 000: <10|13,true> / <16,false> / <0,false> chain variants, u16 colsol in LDS,
+    prices in L2, build_row_caches_stream -- at the sizes they are meant for."""
+    buf = instances.blocks_to_device(instances.uniform_cost_blocks(n), n)
+    try:
+        _compare_with_golden(f"u{n}", buf, n)
+    finally:
+        buf.free()
+
+
+def test_c3_shaped_lap_50000():
+    """c3's LAP shape: 5 000 spot rows x 10 slots against 50 000 cells (duplicate-row elision, sparse inits)."""
+    n = 50000
+    uniq, loc = instances.c3_shaped_unique(n)
+    buf = instances.blocks_to_device(instances.repeated_row_blocks(uniq, loc), n)
+    try:
+        g = _compare_with_golden(f"c3s{n}", buf, n)
+        assert np.array_equal(np.bincount(loc[g["colsol"]], minlength=n // 10), np.full(n // 10, 10))
+    finally:
+        buf.free()
+
+
+def test_c4_chunk_lap_10000():
+    """One --sampling-sub-spots chunk of c4: 10 000 cells of 10 types, deep searches (hand-over to the dense kernel)."""
+    n = 10000
+    cost, loc = instances.c4_chunk_cost(n)
+    buf = _lib.DeviceBuffer.from_numpy(cost)
+    try:
+        _compare_with_golden(f"c4s{n}", buf, n)
+    finally:
+        buf.free()
+
+
+# ---- c1: 1k cells x 1k spots x 2k genes through the plug-in surface (linear_assignment_solvers.py:11-69) ----
+
+def test_c1_plugin_surface():
+    G, C, S = 2000, 1000, 1000
+    sc, st, slots = instances.synth_expression(G, C, S, seed=11, dtype=np.float64)
+    scn, stn = common.normalize_data(sc), common.normalize_data(st)
+    np.testing.assert_allclose(scn, ocost.normalize_data(sc), rtol=1e-12, atol=1e-12)
+    solver = import_solver("lapjv_hip")
+    dist, loc = calculate_cost(scn, stn, slots, "lapjv_hip", "Pearson_correlation")
+    ref, ref_loc = ocost.calculate_cost(ocost.normalize_data(sc), ocost.normalize_data(st), slots)
+    assert np.array_equal(loc, ref_loc)
+    np.testing.assert_allclose(dist, ref, rtol=0, atol=2e-6)
+    y = call_solver(solver, "lapjv_hip", dist)
+    o = jv_oracle(dist, np.float32)
+    assert np.array_equal(y, o["colsol"])                       # same cost matrix: bit-exact vs the CPU oracle
+    mapped, idx = solve_linear_assignment_problem(scn, stn, slots, "lapjv_hip", solver, 1, "Pearson_correlation", process_idx=7)
+    assert idx == 7 and len(mapped) == C
+    assert np.array_equal(np.bincount(mapped, minlength=S), slots)
+    # the fused path and the split path agree; the total on the float64 reference cost is the optimum within 1e-5
+    cols = np.arange(C)
+    ro = jv_oracle(ref.astype(np.float32), np.float32)
+    best = ref[ro["colsol"], cols].sum()
+    mine = ref[np.asarray(mapped), cols].sum()      # slots == 1: the spot index is the row index
+    assert abs(mine - best) <= 1e-5 * max(1.0, abs(best))
+    assert np.array_equal(np.asarray(mapped), loc[y])
+
+
+# ---- c3 at full size: 50k cells x 5k spots x 20k genes, MFMA cost GEMM + LAP ----
+
+def test_c3_full_size_pipeline():
+    G, C, S = 20000, 50000, 5000
+    sc, st, slots = instances.synth_expression(G, C, S, seed=1)          # float32 counts (exact)
+    cost, N, ld, gemm_ms = common.pearson_cost_device(sc, st, slots, already_normalized=False)
+    try:
+        assert N == C and ld >= C
+        g = lap_solve(None, np.float32, return_info=True, device_ptr=cost.ptr, n=N, ld=ld)
+        # (1) a permutation, every spot filled exactly
+        assert np.array_equal(np.sort(g["colsol"]), np.arange(N))
+        assert np.array_equal(g["rowsol"][g["colsol"]], np.arange(N))
+        loc = np.repeat(np.arange(S), slots)
+        mapped = loc[g["colsol"]]
+        assert np.array_equal(np.bincount(mapped, minlength=S), slots)
+        # (2) on a sample of spots: the device cost rows against the float64 reference formula
+        #     (common.py:142-147, 190-199 restated in oracle/cost.py), and the optimality conditions ON THE REFERENCE COST
+        rs = np.random.default_rng(0).choice(S, 96, replace=False)
+        stn = ocost.normalize_data(st[:, rs].astype(np.float64))
+        ref = np.empty((len(rs), C))
+        for lo in range(0, C, 5000):            # cells are independent columns: block-wise keeps the float64 copy small
+            ref[:, lo:lo + 5000] = -ocost.matrix_correlation_pearson(ocost.normalize_data(sc[:, lo:lo + 5000].astype(np.float64)), stn)
+        first = np.concatenate([[0], np.cumsum(slots)[:-1]])
+        rows = np.empty((len(rs), ld), np.float32)
+        for k, s_ in enumerate(rs):
+            _lib.check(_lib.lib().cyto_memcpy_d2h(rows[k].ctypes.data, cost.ptr + int(first[s_]) * ld * 4, ld * 4, 0))
+        np.testing.assert_allclose(rows[:, :C], ref, rtol=0, atol=2e-6)
+        u, v = g["u"].astype(np.float64), g["v"].astype(np.float64)
+        for k, s_ in enumerate(rs):
+            for i in range(first[s_], first[s_] + slots[s_]):
+                red = ref[k] - u[i] - v
+                assert red.min() > -1e-5                          # dual feasible on the float64 reference cost
+                assert abs(red[g["rowsol"][i]]) < 1e-5            # complementary slackness
+        # (3) strong duality: the primal total equals the dual objective (within float32 rounding of 50 000 duals)
+        assert abs(g["total"] - (u.sum() + v.sum())) <= 1e-5 * max(1.0, abs(g["total"]))
+    finally:
+        cost.free()
+    # (4) the fused entry point (cyto_assign_metric_typed) gives the same spots and the same total
+    m2, tot2, info = assign_pearson(sc, st, slots, already_normalized=False, return_info=True)
+    assert np.array_equal(m2, mapped)
+    assert abs(tot2 - g["total"]) <= 1e-5 * max(1.0, abs(g["total"]))
+    assert info.gemm_flops == 2.0 * G * S * C
+
+
+# ---- c4-shaped: two --sampling-sub-spots chunks of 10 000 cells against 50 000 spots on one GPU ----
+
+def test_c4_two_chunks_of_10000():
+    G, C, S, chunk = 2000, 200000, 50000, 10000
+    sc, st, slots = instances.synth_expression(G, C, S, seed=2)
+    rng = np.random.default_rng(0)
+    slot_ids = rng.permutation(np.repeat(np.arange(S), slots))          # which spot every cell's slot belongs to
+    idx = [np.arange(k * chunk, (k + 1) * chunk) for k in range(2)]
+    sub = [np.bincount(slot_ids[ix], minlength=S) for ix in idx]       # per-chunk slot counts (cytospace.py:436-439)
+    used = np.unique(np.concatenate(idx))
+    sc_used = np.ascontiguousarray(sc[:, used])
+    from concurrent.futures import ThreadPoolExecutor
+    with ExpressionContext(sc_used, st, already_normalized=False) as ctx:
+        with ThreadPoolExecutor(2) as ex:
+            res = list(ex.map(lambda k: ctx.assign_chunk(np.searchsorted(used, idx[k]), sub[k], return_info=True), range(2)))
+    scn = ocost.normalize_data(sc_used.astype(np.float64))
+    stn = ocost.normalize_data(st.astype(np.float64))
+    for k, (mapped, total, info) in enumerate(res):
+        assert np.array_equal(np.bincount(mapped, minlength=S), sub[k])
+        spots = np.flatnonzero(sub[k])
+        ref = -ocost.matrix_correlation_pearson(scn[:, np.searchsorted(used, idx[k])], stn[:, spots])    # S_u x 10000 float64
+        pos = np.searchsorted(spots, mapped)
+        mine = ref[pos, np.arange(chunk)].sum()
+        o = jv_oracle(ref[np.repeat(np.arange(len(spots)), sub[k][spots])].astype(np.float32), np.float32)
+        best = float(o["total"])
+        assert abs(mine - best) <= 1e-5 * max(1.0, abs(best)), (k, mine, best)
+        assert abs(total - best) <= 1e-5 * max(1.0, abs(best))

@@ -140,3 +140,45 @@ def test_gv9_other_metrics_cost():
 def test_rank_columns_average_ties():
     v = np.array([[3.0, 0.0], [1.0, 0.0], [3.0, 5.0], [0.0, 0.0], [3.0, 5.0]])
     np.testing.assert_array_equal(ocost.rank_columns(v), np.array([[4.0, 2.0], [2.0, 2.0], [4.0, 4.5], [1.0, 2.0], [4.0, 4.5]]))
+
+
+# ---- the seeded instance generators behind the large goldens (tools/instances.py) are platform independent ----
+
+def test_instance_generators_are_pinned():
+    import hashlib
+    from tools import instances
+
+    def sha(a):
+        return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+    c, loc = instances.c4_chunk_cost(300, seed=4)
+    assert c.shape == (300, 300) and c.dtype == np.float32 and len(loc) == 300
+    c3, loc3 = instances.c3_shaped_cost(200, 10, seed=3)
+    assert np.array_equal(c3[0], c3[9]) and not np.array_equal(c3[9], c3[10])
+    u = instances.uniform_cost(257)
+    assert np.array_equal(u, np.random.default_rng(257).random((257, 257)).astype(np.float32))
+    pinned = {"c4": sha(c), "c3": sha(c3), "u": sha(u)}
+    assert pinned == {"c4": "617df22ab5811ead", "c3": "6a725449cb4d96a5", "u": "79dec35b4da37fe0"}, pinned
+
+
+@pytest.mark.parametrize("tag", ["u20000", "u33000", "u50000", "c3s50000", "c4s10000"])
+def test_large_goldens_are_certified(tag):
+    path = os.path.join(G, f"large_{tag}.npz")
+    assert os.path.exists(path), "run tests/golden/make_golden_large.py"
+    d = np.load(path)
+    n = int(d["n"])
+    assert np.array_equal(np.sort(d["colsol"]), np.arange(n))
+    assert bool(d["unique"])
+    mn, tight, gap = d["dual_certificate"]
+    assert mn >= -1e-6 and tight <= 1e-6 and abs(gap) <= 1e-6 * n
+    assert bool(d["scipy_checked"]) or bool(d["spot_level"])   # scipy may time out only on the 10x duplicated rows
+
+
+def test_small_typed_instances_oracle_vs_scipy():
+    # the typed (few cell types, deep searches) family at a size scipy solves in a second
+    from tools import instances
+    c, loc = instances.c4_chunk_cost(600, seed=9)
+    r = jv_oracle(c, np.float32)
+    ri, ci = linear_sum_assignment(c.astype(np.float64))
+    sp = np.empty(600, np.int64)
+    sp[ci] = ri
+    assert np.array_equal(loc[r["colsol"]], loc[sp])

@@ -1,0 +1,22 @@
+"""Throughput of K concurrent sub-spot chunk LAPs (10 000 cells each, c4/c5's unit of work) on ONE GPU, K = 1 ... 128."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from cytospace_amd import _lib
+from cytospace_amd.lap import lap_solve_batch_device
+from tools import instances
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+Ks = [int(x) for x in sys.argv[2:]] or [1, 8, 32, 64, 128]
+distinct = 4
+costs = [instances.c4_chunk_cost(n, seed=4 + k)[0] for k in range(distinct)]
+bufs = [_lib.DeviceBuffer.from_numpy(costs[k % distinct]) for k in range(max(Ks))]
+lap_solve_batch_device([bufs[0].ptr], [n], max_concurrent=1)
+ref = None
+for K in Ks:
+    t = time.perf_counter()
+    res = lap_solve_batch_device([b.ptr for b in bufs[:K]], [n] * K, max_concurrent=K, return_info=True)
+    wall = time.perf_counter() - t
+    ref = res[0]["colsol"] if ref is None else ref
+    ok = all(np.array_equal(res[k]["colsol"], res[k % distinct]["colsol"]) for k in range(K)) and np.array_equal(res[0]["colsol"], ref)
+    kms = [r["info"].ms_total for r in res]
+    print(f"K={K:4d}: wall {wall:7.2f} s  {K * n / wall:9.0f} assignments/s  per-chunk kernel ms min/mean/max {min(kms):.0f}/{np.mean(kms):.0f}/{max(kms):.0f}  identical={ok}", flush=True)
