@@ -17,6 +17,8 @@ workloads the north star names (skip them with --no-extras):
               GEMM (its own "roofline" against the 157.3 TFLOP/s f32 matrix peak), LAP; wall time includes the H2D copies
   "c4_chunks" K concurrent 10 000-cell --sampling-sub-spots chunk LAPs (configs[3]'s unit of work) on one GPU, with the
               CPU oracle run on all host cores beside it (core count stated)
+and, at every N, "c4_sharded": configs[3]'s structure with the path's one collective -- rank 0 transforms the ST matrix and
+broadcasts the operand over xGMI (RCCL), every rank uploads its own cells and solves its chunks in one batched call.
 
 torch is used only for the rendezvous (barrier + max over ranks); the product never imports it.
 """
@@ -125,7 +127,8 @@ def extra_c4_chunks(dev, K, distinct=4, cpu_n=5000, cpu_threads=64):
     costs = [instances.c4_chunk_cost(n, seed=4 + k)[0] for k in range(distinct)]
     small = [instances.c4_chunk_cost(cpu_n, seed=40 + k)[0] for k in range(distinct)]
     t_gen = time.perf_counter() - t
-    bufs = [_lib.DeviceBuffer.from_numpy(costs[k % distinct], dev) for k in range(K)]
+    bufs = [_lib.DeviceBuffer.from_numpy(costs[k], dev) for k in range(distinct)]
+    bufs += [bufs[k % distinct].clone() for k in range(distinct, K)]          # every chain reads its OWN copy (no shared cache lines)
     lap_solve_batch_device([b.ptr for b in bufs[:1]], [n], device_id=dev, max_concurrent=1)     # warm-up (block cache, code objects)
     t = time.perf_counter()
     one = lap_solve_batch_device([bufs[0].ptr], [n], device_id=dev, max_concurrent=1, return_info=True)[0]
@@ -165,7 +168,8 @@ def extra_c4_chunks(dev, K, distinct=4, cpu_n=5000, cpu_threads=64):
     if not small_exact or not np.array_equal(o1["colsol"], ora[0]["colsol"]):
         raise SystemExit("c4_chunks: HIP result differs from the CPU oracle on the CPU sample")
     i0 = one["info"]
-    return {"workload": f"{K} concurrent {n} x {n} sub-spot chunk LAPs ({distinct} distinct seeded instances), cost resident in HBM",
+    return {"workload": f"{K} concurrent {n} x {n} sub-spot chunk LAPs ({distinct} distinct seeded instances, every chain on its own copy), "
+                        "cost resident in HBM, ONE launch per chain phase with a workgroup per chunk",
             "chunks": K, "wall_s": round(wall, 2), "assignments_per_s": round(K * n / wall, 1),
             "one_chunk_alone": {"wall_s": round(wall1, 2), "assignments_per_s": round(n / wall1, 1), "kernel_ms": round(i0.ms_total, 1),
                                 "jv_chain2_ms": round(i0.ms_arr, 1), "augmentation_ms": round(i0.ms_aug, 1),
@@ -181,6 +185,71 @@ def extra_c4_chunks(dev, K, distinct=4, cpu_n=5000, cpu_threads=64):
                                        f"instances bit-identically ({rs[0]['info'].ms_total:.0f} ms of kernels each)",
                              "cpu_model": _cpu_model()},
             "instance_seconds": round(t_gen, 1)}
+
+
+def extra_c4_sharded(dev, rank, world, dist, chunks_per_rank, G=5000, S=50000, chunk=10000):
+    """BASELINE configs[3]'s structure on N GPUs (weak scaling: chunks_per_rank chunks of 10 000 cells per GPU against
+    50 000 spots): rank 0 transforms the ST matrix and broadcasts the float32 operand over xGMI (RCCL; the one collective of
+    the path), every rank uploads only its own cells as raw counts and solves its chunks in one batched call."""
+    from cytospace_amd import _lib
+    from cytospace_amd.cytospace import ExpressionContext
+    K = 10
+    g = np.random.default_rng(5)                                   # shared by all ranks: gene means, type multipliers
+    m = g.lognormal(0.0, 1.5, G).astype(np.float32)
+    mult = g.lognormal(0.0, 0.75, (K, G)).astype(np.float32)
+    t = time.perf_counter()
+    r = np.random.default_rng(1000 + rank)
+    C = chunks_per_rank * chunk
+    sc = np.empty((G, C), np.float32)
+    for lo in range(0, C, 5000):
+        ty = r.integers(0, K, 5000)
+        sc[:, lo:lo + 5000] = r.poisson(0.3 * m[:, None] * mult[ty].T)
+    st = None
+    if rank == 0:                                                  # a spot: four cells' worth of counts (only the root holds ST)
+        st = np.empty((G, S), np.float32)
+        for lo in range(0, S, 5000):
+            ty = g.integers(0, K, (4, 5000))
+            st[:, lo:lo + 5000] = g.poisson(0.3 * m[:, None] * (mult[ty[0]] + mult[ty[1]] + mult[ty[2]] + mult[ty[3]]).T)
+    subs = [np.bincount(r.integers(0, S, chunk), minlength=S) for _ in range(chunks_per_rank)]    # sub-spot slot counts
+    t_gen = time.perf_counter() - t
+    # communicator: the 128-byte id travels through the launcher's own channel
+    uid = [_lib.Communicator.unique_id() if rank == 0 else None]
+    if dist is not None:
+        dist.broadcast_object_list(uid, src=0)
+    comm = _lib.Communicator(uid[0], rank, world, device_id=dev)
+
+    def sync():
+        _lib.check(_lib.lib().cyto_device_synchronize(dev))
+        if dist is not None:
+            dist.barrier()
+
+    sync()
+    t0 = time.perf_counter()
+    with ExpressionContext(sc, st, False, dev, comm=comm, n_spots=S) as ctx:
+        t1 = time.perf_counter()
+        res = ctx.assign_chunks([(np.arange(k * chunk, (k + 1) * chunk), subs[k]) for k in range(chunks_per_rank)],
+                                return_info=True)
+        bcast_ms = ctx.bcast_ms
+    sync()
+    el = time.perf_counter() - t0
+    ok = all(np.array_equal(np.bincount(mp, minlength=S), subs[k]) for k, (mp, _, _) in enumerate(res))
+    if not ok:
+        raise SystemExit("c4_sharded: bincount(mapped) != the chunk's slot counts")
+    comm.close()
+    if dist is not None:
+        import torch
+        tt = torch.tensor([el], dtype=torch.float64, device="cuda" if torch.cuda.is_available() else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    i0 = res[0][2]
+    return {"workload": f"{world} GPU(s) x {chunks_per_rank} sub-spot chunks of {chunk} cells against {S} spots, {G} genes: "
+                        "ST transformed on rank 0 + RCCL broadcast, per-rank raw-count upload, batched chunk solves",
+            "assignments_per_s": round(world * C / el, 1), "seconds": round(el, 2), "scaling": "weak",
+            "context_s_rank0": round(t1 - t0, 3), "bcast_ms_rank0": None if bcast_ms is None else round(bcast_ms, 3),
+            "bcast_bytes": int(-(-G // 32) * 32) * int(-(-S // 128) * 128) * 4,
+            "chunk0": {"gather_ms": round(i0.ms_standardize, 2), "gemm_ms": round(i0.ms_gemm, 2), "spots_with_cells": int((subs[0] > 0).sum()),
+                       "lap_batch_kernel_ms": round(i0.lap.ms_total, 1), "lap_row_scans": int(i0.lap.row_scans)},
+            "bincount_equals_slots": ok, "instance_seconds_rank0": round(t_gen, 1)}
 
 
 def make_cost(n, seed):
@@ -199,7 +268,8 @@ def main():
                          "instance is used and the GPU result is compared bit for bit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no n50000 / c3 / c4_chunks)")
-    ap.add_argument("--c4-chunks", type=int, default=32, help="concurrent chunk LAPs in the c4_chunks leg")
+    ap.add_argument("--c4-chunks", type=int, default=256, help="concurrent chunk LAPs in the c4_chunks leg (256 = one chain per CU; 400 MB each)")
+    ap.add_argument("--c4-rank-chunks", type=int, default=8, help="chunks per rank in the c4_sharded leg")
     ap.add_argument("--pmc-tag", default="r02", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
     args = ap.parse_args()
 
@@ -280,6 +350,9 @@ def main():
         raise SystemExit(f"full-size property check failed: perm={perm_ok} total={total_ok} dual={dual_ok}")
     buf.free()
 
+    sharded = None
+    if not args.no_extras:
+        sharded = extra_c4_sharded(dev, rank, world, dist, args.c4_rank_chunks)      # every rank takes part
     if rank != 0:
         return
     ms_per_step = elapsed * 1e3 / args.steps
@@ -366,6 +439,8 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
+    if sharded is not None:
+        out["c4_sharded"] = sharded
     if world == 1 and not args.no_extras:
         out["n50000"] = extra_n50000(dev)
         out["c3"] = extra_c3(dev)

@@ -51,6 +51,13 @@ class AssignInfo(ctypes.Structure):
                 ("lap", LapInfo)]
 
 
+class Chunk(ctypes.Structure):
+    """cyto_chunk (include/cytohip.h)."""
+    _fields_ = [("idx_sc", ctypes.c_void_p), ("n_sc", ctypes.c_int32), ("idx_st", ctypes.c_void_p), ("n_st", ctypes.c_int32),
+                ("slots", ctypes.c_void_p), ("mapped_spot", ctypes.c_void_p), ("total_cost", ctypes.c_double),
+                ("status", ctypes.c_int32), ("info", AssignInfo)]
+
+
 def lib():
     """Return the loaded library (loading it on first use in this process)."""
     global _lib
@@ -100,6 +107,12 @@ def lib():
         L.cyto_assign_metric_typed.argtypes = [i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, dp, ctypes.POINTER(AssignInfo), i32]
         L.cyto_ctx_create_typed.argtypes = [i32, i32, i32, i32, vp, vp, i32, i32, i32, ctypes.POINTER(vp)]
         L.cyto_ctx_destroy.restype = None
+        L.cyto_ctx_create_shared.argtypes = [i32, i32, i32, i32, vp, vp, i32, i32, vp, i32, i32, i32, ctypes.POINTER(vp), dp]
+        L.cyto_ctx_create_shared.restype = ctypes.c_int
+        L.cyto_ctx_assign_chunks.argtypes = [vp, i32, ctypes.POINTER(Chunk), i32]
+        L.cyto_ctx_assign_chunks.restype = ctypes.c_int
+        L.cyto_memcpy_d2d.argtypes = [vp, vp, ctypes.c_size_t, i32]
+        L.cyto_memcpy_d2d.restype = ctypes.c_int
         L.cyto_assign_pearson.argtypes = [i32, i32, i32, vp, vp, vp, i32, vp, dp, ctypes.POINTER(AssignInfo), i32]
         L.cyto_lap_batch_f32.argtypes = [i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32]
         L.cyto_comm_unique_id.argtypes = [ctypes.c_char_p]
@@ -152,6 +165,12 @@ class DeviceBuffer:
         check(lib().cyto_memcpy_h2d(buf.ptr, arr.ctypes.data, arr.nbytes, device_id))
         return buf
 
+    def clone(self):
+        """A device-to-device copy (same device)."""
+        out = DeviceBuffer(self.nbytes, self.device_id)
+        check(lib().cyto_memcpy_d2d(out.ptr, self.ptr, self.nbytes, self.device_id))
+        return out
+
     def to_numpy(self, shape, dtype):
         import numpy as np
         out = np.empty(shape, dtype)
@@ -167,5 +186,37 @@ class DeviceBuffer:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+class Communicator:
+    """RCCL communicator of a one-process-per-GPU job (C ABI: cyto_comm_*).  The 128-byte unique id is made on rank 0
+    (`Communicator.unique_id()`) and handed to the other ranks by the launcher (torch.distributed, MPI, a file ...)."""
+
+    def __init__(self, unique_id, rank, nranks, device_id=0):
+        self.rank, self.nranks, self.device_id = int(rank), int(nranks), int(device_id)
+        self._h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        check(lib().cyto_comm_init(buf, self.rank, self.nranks, self.device_id, ctypes.byref(self._h)))
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        check(lib().cyto_comm_unique_id(buf))
+        return buf.raw
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            lib().cyto_comm_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass

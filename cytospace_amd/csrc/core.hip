@@ -193,6 +193,14 @@ int cyto_memcpy_d2h(void *dst, const void *src, size_t bytes, int device_id) {
     return CYTO_OK;
 }
 
+int cyto_memcpy_d2d(void *dst, const void *src, size_t bytes, int device_id) {
+    if (!dst || !src) return CYTO_ERR_BAD_ARG;
+    int rc = cyto::select_device(device_id);
+    if (rc) return rc;
+    CYTO_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+    return CYTO_OK;
+}
+
 int cyto_device_synchronize(int device_id) {
     int rc = cyto::select_device(device_id);
     if (rc) return rc;

@@ -24,6 +24,7 @@
 //                       writes each spot row to its slots[s] consecutive LAP rows.
 #include "cyto_common.h"
 #include <math.h>
+#include <algorithm>
 #include <vector>
 #include <new>
 #include <string.h>
@@ -228,22 +229,34 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // EPI 0: cost = -dot (Pearson / Spearman on standardised operands);
 // EPI 1: cost = sqrt(|a|^2 + |b|^2 - 2 dot) (Euclidean; squared norms in float64, sum and root in float64)
 template <int EPI>
-__global__ __launch_bounds__(256) void pearson_gemm(int Gpad, int S, int C, const float *__restrict__ A, int64_t lda,
+__global__ __launch_bounds__(256, 2) void pearson_gemm(int Gpad, int S, int C, const float *__restrict__ A, int64_t lda,
                                                     const float *__restrict__ B, int64_t ldb,
                                                     const int *__restrict__ rowstart, float *__restrict__ cost, int64_t ldc,
-                                                    int tiles_n, const double *__restrict__ na, const double *__restrict__ nb) {
+                                                    int tiles_n, const double *__restrict__ na, const double *__restrict__ nb, int tiles_m) {
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware tile order: consecutive workgroup ids land on different XCDs (private L2s), so give
-    // each XCD a contiguous band of tiles that share operand panels
+    // XCD-aware tile order: consecutive workgroup ids land on different XCDs (private L2s), so every XCD gets a contiguous
+    // band of the tile sequence; inside the band tiles are walked in SUPER x SUPER blocks, so the ~64 workgroups an XCD runs
+    // at a time share 8 spot panels and 8 cell panels in its L2 (row-major order: 1 spot panel + 64 cell panels, four
+    // times the operand traffic per flop).
     const int nwg = gridDim.x;
     int wg = blockIdx.x;
     {
         const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = wg / tiles_n, tn = wg % tiles_n;
+    constexpr int SUPER = 8;
+    int tm, tn;
+    {
+        const int band = SUPER * tiles_n;                 // tiles in a full band of SUPER tile rows
+        const int bi = wg / band, rem = wg - bi * band;
+        const int rows_here = min(SUPER, tiles_m - bi * SUPER);
+        const int cb = rem / (rows_here * SUPER), rem2 = rem - cb * rows_here * SUPER;
+        const int cols_here = min(SUPER, tiles_n - cb * SUPER);
+        tm = bi * SUPER + rem2 / cols_here;
+        tn = cb * SUPER + rem2 % cols_here;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -264,20 +277,21 @@ __global__ __launch_bounds__(256) void pearson_gemm(int Gpad, int S, int C, cons
     // the global loads of tile t+1 are issued before the MFMAs of tile t and written to the other LDS
     // buffer afterwards; inside a tile the A/B fragments of step kk+2 are read from LDS before the four
     // MFMAs of step kk are issued (explicit register ping-pong), so LDS latency hides under the matrix pipe.
-    float4 ra[4], rb[4];
+    // (eight named registers, not two arrays: inside these macros the unroll pragma was not honoured, the arrays were
+    //  indexed dynamically and ended up in scratch and in an LDS-promoted alloca -- 16 KB more LDS per block and a round trip
+    //  through memory for every staged tile)
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     const int st_k = tid >> 5, st_c = (tid & 31) * 4;   // this thread's row / column inside a staging pass
     const float *gA = A + (int64_t)st_k * lda + m0 + st_c;
     const float *gB = B + (int64_t)st_k * ldb + n0 + st_c;
+#define GL1(r, g, ld_, k0, t) r = *reinterpret_cast<const float4 *>(g + (int64_t)((k0) + (t) * 8) * ld_);
 #define GLOAD(k0)                                                                                   \
-    _Pragma("unroll") for (int t = 0; t < 4; t++) {                                                 \
-        ra[t] = *reinterpret_cast<const float4 *>(gA + (int64_t)((k0) + t * 8) * lda);              \
-        rb[t] = *reinterpret_cast<const float4 *>(gB + (int64_t)((k0) + t * 8) * ldb);              \
-    }
+    GL1(ra0, gA, lda, k0, 0) GL1(ra1, gA, lda, k0, 1) GL1(ra2, gA, lda, k0, 2) GL1(ra3, gA, lda, k0, 3)      \
+    GL1(rb0, gB, ldb, k0, 0) GL1(rb1, gB, ldb, k0, 1) GL1(rb2, gB, ldb, k0, 2) GL1(rb3, gB, ldb, k0, 3)
+#define LS1(Xs, buf, t, r) *reinterpret_cast<float4 *>(&Xs[buf][st_k + (t) * 8][st_c]) = r;
 #define LSTORE(buf)                                                                                 \
-    _Pragma("unroll") for (int t = 0; t < 4; t++) {                                                 \
-        *reinterpret_cast<float4 *>(&As[buf][st_k + t * 8][st_c]) = ra[t];                          \
-        *reinterpret_cast<float4 *>(&Bs[buf][st_k + t * 8][st_c]) = rb[t];                          \
-    }
+    LS1(As, buf, 0, ra0) LS1(As, buf, 1, ra1) LS1(As, buf, 2, ra2) LS1(As, buf, 3, ra3)                        \
+    LS1(Bs, buf, 0, rb0) LS1(Bs, buf, 1, rb1) LS1(Bs, buf, 2, rb2) LS1(Bs, buf, 3, rb3)
     const int nk = Gpad / BK;
     GLOAD(0)
     LSTORE(0)
@@ -319,6 +333,8 @@ __global__ __launch_bounds__(256) void pearson_gemm(int Gpad, int S, int C, cons
     }
 #undef GLOAD
 #undef LSTORE
+#undef GL1
+#undef LS1
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
@@ -501,10 +517,10 @@ static int cost_gemm(int euclid, int Gpad, int S, int C, const float *zst, int64
     CYTO_HIP(hipEventRecord(e0, stream));
     if (euclid)
         hipLaunchKernelGGL(pearson_gemm<1>, dim3(tiles_m * tiles_n), dim3(256), 0, stream, Gpad, S, C, zst, ldzst, zsc, ldzsc,
-                           drs.as<int>(), cost_dev, ldc, tiles_n, na.as<double>(), nb.as<double>());
+                           drs.as<int>(), cost_dev, ldc, tiles_n, na.as<double>(), nb.as<double>(), tiles_m);
     else
         hipLaunchKernelGGL(pearson_gemm<0>, dim3(tiles_m * tiles_n), dim3(256), 0, stream, Gpad, S, C, zst, ldzst, zsc, ldzsc,
-                           drs.as<int>(), cost_dev, ldc, tiles_n, (const double *)nullptr, (const double *)nullptr);
+                           drs.as<int>(), cost_dev, ldc, tiles_n, (const double *)nullptr, (const double *)nullptr, tiles_m);
     CYTO_HIP(hipGetLastError());
     CYTO_HIP(hipEventRecord(e1, stream));
     CYTO_HIP(hipStreamSynchronize(stream));
@@ -601,10 +617,16 @@ struct cyto_expr_ctx {
     DevBuf zsc, zst;
 };
 
-int cyto_ctx_create_typed(int metric, int G, int C, int S, const void *sc, const void *st, int x_is_f64, int already_normalized,
-                          int device_id, cyto_expr_ctx **out) {
-    if (!out || G <= 0 || C <= 0 || S <= 0 || !sc || !st) return CYTO_ERR_BAD_ARG;
+// comm == NULL: this process transforms both matrices itself.  comm != NULL (one process per GPU): only `root` holds the
+// ST matrix; it transforms it once and the float32 operand goes to the other ranks with ONE ncclBroadcast over xGMI -- the
+// only collective of the path (the reference pickles the whole ST matrix to every worker: cytospace.py:438, 446-451).
+// sc always holds THIS rank's cells only.
+static int ctx_create_impl(int metric, int G, int C, int S, const void *sc, const void *st, int x_is_f64, int already_normalized,
+                           void *comm, int root, int rank, int device_id, cyto_expr_ctx **out, double *bcast_ms) {
+    if (!out || G <= 0 || C <= 0 || S <= 0 || !sc) return CYTO_ERR_BAD_ARG;
     if (metric < CYTO_METRIC_PEARSON || metric > CYTO_METRIC_EUCLIDEAN) return CYTO_ERR_BAD_ARG;
+    const bool have_st = !comm || rank == root;
+    if (have_st && !st) return CYTO_ERR_BAD_ARG;
     int rc = select_device(device_id);
     if (rc) return rc;
     cyto_expr_ctx *ctx = new (std::nothrow) cyto_expr_ctx();
@@ -613,14 +635,38 @@ int cyto_ctx_create_typed(int metric, int G, int C, int S, const void *sc, const
     ctx->ldsc = round_up(C, BN); ctx->ldst = round_up(S, BM);
     const int transform = metric == CYTO_METRIC_PEARSON ? CYTO_TRANSFORM_STANDARDIZE
                         : metric == CYTO_METRIC_SPEARMAN ? CYTO_TRANSFORM_RANK : CYTO_TRANSFORM_RAW;
-    if ((rc = ctx->zsc.alloc((size_t)ctx->Gpad * ctx->ldsc * 4)) || (rc = ctx->zst.alloc((size_t)ctx->Gpad * ctx->ldst * 4)) ||
-        (rc = cyto_transform(transform, G, S, st, S, x_is_f64, 0, already_normalized, ctx->zst.as<float>(), ctx->ldst, ctx->Gpad, device_id, nullptr)) ||
-        (rc = cyto_transform(transform, G, C, sc, C, x_is_f64, 0, already_normalized, ctx->zsc.as<float>(), ctx->ldsc, ctx->Gpad, device_id, nullptr))) {
-        delete ctx;
-        return rc;
+    const size_t nst = (size_t)ctx->Gpad * ctx->ldst;
+    if ((rc = ctx->zsc.alloc((size_t)ctx->Gpad * ctx->ldsc * 4)) || (rc = ctx->zst.alloc(nst * 4))) { delete ctx; return rc; }
+    if (have_st)
+        rc = cyto_transform(transform, G, S, st, S, x_is_f64, 0, already_normalized, ctx->zst.as<float>(), ctx->ldst, ctx->Gpad, device_id, nullptr);
+    if (!rc && comm) {
+        Events<2> ev;
+        if (!(rc = ev.create())) {
+            (void)hipEventRecord(ev[0], nullptr);
+            rc = cyto_comm_bcast_f32(comm, ctx->zst.as<float>(), nst, root, device_id, nullptr);
+            (void)hipEventRecord(ev[1], nullptr);
+            if (!rc && hipEventSynchronize(ev[1]) != hipSuccess) rc = CYTO_ERR_HIP;
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
+            if (bcast_ms) *bcast_ms = ms;
+        }
     }
+    if (!rc) rc = cyto_transform(transform, G, C, sc, C, x_is_f64, 0, already_normalized, ctx->zsc.as<float>(), ctx->ldsc, ctx->Gpad, device_id, nullptr);
+    if (rc) { delete ctx; return rc; }
     *out = ctx;
     return CYTO_OK;
+}
+
+int cyto_ctx_create_typed(int metric, int G, int C, int S, const void *sc, const void *st, int x_is_f64, int already_normalized,
+                          int device_id, cyto_expr_ctx **out) {
+    if (!st) return CYTO_ERR_BAD_ARG;
+    return ctx_create_impl(metric, G, C, S, sc, st, x_is_f64, already_normalized, nullptr, 0, 0, device_id, out, nullptr);
+}
+
+int cyto_ctx_create_shared(int metric, int G, int C, int S, const void *sc, const void *st, int x_is_f64, int already_normalized,
+                           void *comm, int root, int rank, int device_id, cyto_expr_ctx **out, double *bcast_ms) {
+    if (!comm) return CYTO_ERR_BAD_ARG;
+    return ctx_create_impl(metric, G, C, S, sc, st, x_is_f64, already_normalized, comm, root, rank, device_id, out, bcast_ms);
 }
 
 void cyto_ctx_destroy(cyto_expr_ctx *ctx) {
@@ -707,6 +753,128 @@ int cyto_ctx_assign_chunk(cyto_expr_ctx *ctx, const int64_t *idx_sc, int n_sc, c
         info->gemm_flops = 2.0 * ctx->Gpad * (double)Su * (double)n_sc;
     }
     return CYTO_OK;
+}
+
+// Every chunk of this rank in ONE call: per chunk the two column gathers and the cost GEMM (back to back on one stream,
+// the gathered operands are reused), then the LAPs of all chunks TOGETHER -- one workgroup per chunk in every chain phase
+// (cyto_lap_batch_f32), so a rank's chunks run on as many CUs side by side.  Replaces the per-chunk worker processes of
+// apply_linear_assignment (cytospace/cytospace.py:430-467).  chunks[k].status reports per-chunk failures.
+int cyto_ctx_assign_chunks(cyto_expr_ctx *ctx, int nchunks, cyto_chunk *chunks, int max_concurrent) {
+    if (!ctx || nchunks < 0 || (nchunks > 0 && !chunks)) return CYTO_ERR_BAD_ARG;
+    if (nchunks == 0) return CYTO_OK;
+    int rc = select_device(ctx->device_id);
+    if (rc) return rc;
+    const int conc = std::max(1, std::min(nchunks, max_concurrent > 0 ? max_concurrent : 64));
+    StreamGuard guard;
+    CYTO_HIP(hipStreamCreateWithFlags(&guard.s, hipStreamNonBlocking));
+    guard.own = true;
+    const hipStream_t stream = guard.s;
+    Events<3> ev;
+    if ((rc = ev.create())) return rc;
+    struct Prep {
+        std::vector<int32_t> h_st, h_pos, h_sc;
+        std::vector<int64_t> h_slots;
+        int64_t N = 0; int Su = 0; int64_t ldc = 0;
+        DevBuf cost;
+        std::vector<int32_t> colsol;
+        float ms_gather = 0, ms_gemm = 0;
+    };
+    int first = CYTO_OK;
+    for (int lo = 0; lo < nchunks; lo += conc) {
+        const int cnt = std::min(conc, nchunks - lo);
+        std::vector<Prep> pp((size_t)cnt);
+        DevBuf zst, zsc, dsc, dst;                    // gathered operands, reused by the chunks of this round
+        size_t cap_st = 0, cap_sc = 0, cap_isc = 0, cap_ist = 0;
+        for (int k = 0; k < cnt; k++) {
+            cyto_chunk &ch = chunks[lo + k];
+            Prep &p = pp[(size_t)k];
+            ch.status = CYTO_OK; ch.total_cost = 0.0;
+            memset(&ch.info, 0, sizeof ch.info);
+            const int nst = ch.idx_st ? ch.n_st : ctx->S;
+            if (!ch.idx_sc || ch.n_sc <= 0 || !ch.slots || !ch.mapped_spot || nst <= 0) { ch.status = CYTO_ERR_BAD_ARG; continue; }
+            for (int t = 0; t < nst && ch.status == CYTO_OK; t++) {
+                if (ch.slots[t] < 0) { ch.status = CYTO_ERR_BAD_ARG; break; }
+                const int64_t s_ = ch.idx_st ? ch.idx_st[t] : t;
+                if (s_ < 0 || s_ >= ctx->S) { ch.status = CYTO_ERR_BAD_ARG; break; }
+                if (ch.slots[t] > 0) { p.h_st.push_back((int32_t)s_); p.h_pos.push_back(t); p.h_slots.push_back(ch.slots[t]); p.N += ch.slots[t]; }
+            }
+            if (ch.status == CYTO_OK && p.N != ch.n_sc) ch.status = CYTO_ERR_BAD_ARG;          // the LAP must be square
+            p.h_sc.resize((size_t)std::max(ch.n_sc, 0));
+            for (int c = 0; c < ch.n_sc && ch.status == CYTO_OK; c++) {
+                if (ch.idx_sc[c] < 0 || ch.idx_sc[c] >= ctx->C) { ch.status = CYTO_ERR_BAD_ARG; break; }
+                p.h_sc[(size_t)c] = (int32_t)ch.idx_sc[c];
+            }
+            if (ch.status != CYTO_OK) continue;
+            p.Su = (int)p.h_st.size();
+            const int n_sc = ch.n_sc;
+            const int64_t ldzst = round_up(p.Su, BM), ldzsc = round_up(n_sc, BN);
+            p.ldc = round_up(n_sc, 4);
+            const size_t need_st = (size_t)ctx->Gpad * ldzst * 4, need_sc = (size_t)ctx->Gpad * ldzsc * 4;
+            // (a larger operand than any before: the stream is drained first, the old block goes back to the cache)
+            if (need_st > cap_st) { CYTO_HIP(hipStreamSynchronize(stream)); if ((rc = zst.alloc(need_st, stream))) return rc; cap_st = need_st; }
+            if (need_sc > cap_sc) { CYTO_HIP(hipStreamSynchronize(stream)); if ((rc = zsc.alloc(need_sc, stream))) return rc; cap_sc = need_sc; }
+            if ((size_t)n_sc * 4 > cap_isc) { CYTO_HIP(hipStreamSynchronize(stream)); if ((rc = dsc.alloc((size_t)n_sc * 4, stream))) return rc; cap_isc = (size_t)n_sc * 4; }
+            if ((size_t)p.Su * 4 > cap_ist) { CYTO_HIP(hipStreamSynchronize(stream)); if ((rc = dst.alloc((size_t)p.Su * 4, stream))) return rc; cap_ist = (size_t)p.Su * 4; }
+            if ((rc = p.cost.alloc((size_t)p.N * p.ldc * 4, stream))) return rc;
+            CYTO_HIP(hipEventRecord(ev[0], stream));
+            CYTO_HIP(hipMemcpyAsync(dsc.p, p.h_sc.data(), (size_t)n_sc * 4, hipMemcpyHostToDevice, stream));
+            CYTO_HIP(hipMemcpyAsync(dst.p, p.h_st.data(), (size_t)p.Su * 4, hipMemcpyHostToDevice, stream));
+            CYTO_HIP(hipMemsetAsync(zst.p, 0, need_st, stream));
+            CYTO_HIP(hipMemsetAsync(zsc.p, 0, need_sc, stream));
+            const int nblk = (ctx->Gpad + GB - 1) / GB;
+            hipLaunchKernelGGL(gather_columns, dim3((p.Su + 255) / 256, nblk), dim3(256), 0, stream, ctx->Gpad, p.Su, ctx->zst.as<float>(),
+                               ctx->ldst, dst.as<int32_t>(), zst.as<float>(), ldzst);
+            hipLaunchKernelGGL(gather_columns, dim3((n_sc + 255) / 256, nblk), dim3(256), 0, stream, ctx->Gpad, n_sc, ctx->zsc.as<float>(),
+                               ctx->ldsc, dsc.as<int32_t>(), zsc.as<float>(), ldzsc);
+            CYTO_HIP(hipGetLastError());
+            CYTO_HIP(hipEventRecord(ev[1], stream));
+            double ms_gemm = 0;
+            // (cost_gemm synchronises the stream: the host index vectors and the operands are free again afterwards)
+            if ((rc = cyto_cost_metric(ctx->metric, ctx->Gpad, p.Su, n_sc, zst.as<float>(), ldzst, zsc.as<float>(), ldzsc, p.h_slots.data(),
+                                       p.cost.as<float>(), p.ldc, &ms_gemm, ctx->device_id, stream)))
+                return rc;
+            (void)hipEventElapsedTime(&p.ms_gather, ev[0], ev[1]);
+            p.ms_gemm = (float)ms_gemm;
+            p.colsol.resize((size_t)p.N);
+        }
+        // the LAPs of this round, together
+        std::vector<int> ids;
+        for (int k = 0; k < cnt; k++) if (chunks[lo + k].status == CYTO_OK) ids.push_back(k);
+        const int nl = (int)ids.size();
+        if (nl) {
+            std::vector<int> nn((size_t)nl), stat((size_t)nl, CYTO_OK);
+            std::vector<const float *> cst((size_t)nl);
+            std::vector<int64_t> lds_((size_t)nl);
+            std::vector<int32_t *> cs((size_t)nl);
+            std::vector<double> tot((size_t)nl);
+            std::vector<cyto_lap_info> li((size_t)nl);
+            for (int q = 0; q < nl; q++) {
+                Prep &p = pp[(size_t)ids[(size_t)q]];
+                nn[(size_t)q] = (int)p.N; cst[(size_t)q] = p.cost.as<float>(); lds_[(size_t)q] = p.ldc; cs[(size_t)q] = p.colsol.data();
+            }
+            (void)cyto_lap_batch_f32(nl, nn.data(), cst.data(), lds_.data(), 1, nullptr, cs.data(), nullptr, nullptr, tot.data(), li.data(),
+                                     stat.data(), nl, ctx->device_id);
+            for (int q = 0; q < nl; q++) {
+                const int k = ids[(size_t)q];
+                cyto_chunk &ch = chunks[lo + k];
+                Prep &p = pp[(size_t)k];
+                ch.status = stat[(size_t)q];
+                if (ch.status != CYTO_OK) continue;
+                // location_repeat[y] (cytospace.py:331): LAP row -> position in the chunk's spot list
+                std::vector<int32_t> rowpos((size_t)p.N);
+                int64_t r = 0;
+                for (int t = 0; t < p.Su; t++) for (int64_t e = 0; e < p.h_slots[(size_t)t]; e++) rowpos[(size_t)r++] = p.h_pos[(size_t)t];
+                for (int c = 0; c < ch.n_sc; c++) ch.mapped_spot[c] = rowpos[(size_t)p.colsol[(size_t)c]];
+                ch.total_cost = tot[(size_t)q];
+                ch.info.ms_standardize = p.ms_gather;     // here: the two column gathers (the transforms ran once, at context creation)
+                ch.info.ms_gemm = p.ms_gemm;
+                ch.info.lap = li[(size_t)q];
+                ch.info.gemm_flops = 2.0 * ctx->Gpad * (double)p.Su * (double)ch.n_sc;
+            }
+        }
+        for (int k = 0; k < cnt; k++) if (!first && chunks[lo + k].status) first = chunks[lo + k].status;
+    }
+    return first;
 }
 
 int cyto_assign_pearson(int G, int C, int S, const double *sc, const double *st, const int64_t *slots, int already_normalized,

@@ -3,8 +3,9 @@
 
 `solve_linear_assignment_problem` keeps the reference's signature; with solver_method == "lapjv_hip"
 the whole chunk (cost build + LAP) stays on the GPU (C ABI: cyto_assign_pearson).
-`assign_chunks` is the multi-chunk seam: independent square sub-LAPs, one GPU each, no data-path
-collective (the chunks are independent; cytospace.py:430-451 ships them to a process pool).
+`assign_chunks` is the multi-chunk seam: independent square sub-LAPs, all chunks of a rank solved together (a workgroup
+per chunk); across ranks (one process per GPU) the only collective is the broadcast of the transformed ST operand
+(cytospace.py:430-451 ships the whole ST matrix to every worker of a process pool).
 """
 import ctypes
 import time
@@ -76,17 +77,80 @@ class ExpressionContext:
     """Both expression matrices uploaded and transformed once (standardised / ranked / plain float32 operands of the
     metric), resident in HBM; every chunk of apply_linear_assignment gathers its columns out of them."""
 
-    def __init__(self, sc, st, already_normalized=True, device_id=0, distance_metric="Pearson_correlation"):
+    def __init__(self, sc, st, already_normalized=True, device_id=0, distance_metric="Pearson_correlation",
+                 comm=None, root=0, n_spots=None):
+        """comm (a _lib.Communicator, one process per GPU): only rank `root` passes the ST matrix (`st`; the others may pass
+        None with n_spots); root transforms it once and the float32 operand reaches the other ranks with one RCCL broadcast.
+        `sc` holds THIS rank's cells only."""
         from .common import METRICS
         if distance_metric not in METRICS:
             raise ValueError(f"unknown distance_metric {distance_metric!r}")
-        sc, st, is64 = _pair(sc, st)
-        self.G, self.C = sc.shape
-        self.S = st.shape[1]
+        self.bcast_ms = None
         self._h = ctypes.c_void_p()
-        _lib.check(_lib.lib().cyto_ctx_create_typed(METRICS[distance_metric], self.G, self.C, self.S, sc.ctypes.data,
-                                                    st.ctypes.data, is64, int(already_normalized), device_id,
-                                                    ctypes.byref(self._h)))
+        if comm is None:
+            sc, st, is64 = _pair(sc, st)
+            self.G, self.C = sc.shape
+            self.S = st.shape[1]
+            _lib.check(_lib.lib().cyto_ctx_create_typed(METRICS[distance_metric], self.G, self.C, self.S, sc.ctypes.data,
+                                                        st.ctypes.data, is64, int(already_normalized), device_id,
+                                                        ctypes.byref(self._h)))
+            return
+        sc = np.asarray(sc)
+        have_st = st is not None
+        if comm.rank == root and not have_st:
+            raise ValueError("the root rank must pass the ST matrix")
+        if have_st:
+            sc, st, is64 = _pair(sc, st)
+            n_spots = st.shape[1]
+        else:
+            if n_spots is None:
+                raise ValueError("n_spots is required on ranks that do not hold the ST matrix")
+            is64 = int(sc.dtype != np.float32)
+            sc = np.ascontiguousarray(sc, dtype=np.float64 if is64 else np.float32)
+        self.G, self.C = sc.shape
+        self.S = int(n_spots)
+        ms = ctypes.c_double()
+        _lib.check(_lib.lib().cyto_ctx_create_shared(METRICS[distance_metric], self.G, self.C, self.S, sc.ctypes.data,
+                                                     st.ctypes.data if have_st else None, is64, int(already_normalized),
+                                                     comm.handle, int(root), comm.rank, device_id, ctypes.byref(self._h),
+                                                     ctypes.byref(ms)))
+        self.bcast_ms = ms.value
+
+    def assign_chunks(self, chunks, max_concurrent=0, return_info=False):
+        """All chunks of this rank in one call (C ABI: cyto_ctx_assign_chunks): per chunk the gathers and the cost GEMM, then
+        every chunk's LAP together, a workgroup per chunk.  chunks: list of (index_sc, slots[, index_st]).
+        Returns a list of mapped_st_index arrays (or (mapped, total, info) tuples)."""
+        if self._h is None:
+            raise RuntimeError("context was closed")
+        nb = len(chunks)
+        if nb == 0:
+            return []
+        arr = (_lib.Chunk * nb)()
+        keep = []
+        for k, ch in enumerate(chunks):
+            idx_sc = np.ascontiguousarray(ch[0], dtype=np.int64)
+            slots = np.ascontiguousarray(ch[1], dtype=np.int64)
+            idx_st = None if len(ch) < 3 or ch[2] is None else np.ascontiguousarray(ch[2], dtype=np.int64)
+            nst = self.S if idx_st is None else len(idx_st)
+            if len(slots) != nst:
+                raise ValueError("one slot count per listed spot is required")
+            mapped = np.empty(len(idx_sc), np.int64)
+            keep.append((idx_sc, slots, idx_st, mapped))
+            arr[k].idx_sc, arr[k].n_sc = idx_sc.ctypes.data, len(idx_sc)
+            arr[k].idx_st, arr[k].n_st = (None if idx_st is None else idx_st.ctypes.data), nst
+            arr[k].slots, arr[k].mapped_spot = slots.ctypes.data, mapped.ctypes.data
+        st = _lib.lib().cyto_ctx_assign_chunks(self._h, nb, arr, int(max_concurrent))
+        for k in range(nb):
+            _lib.check(arr[k].status)
+        _lib.check(st)
+        if return_info:
+            infos = []
+            for k in range(nb):
+                inf = _lib.AssignInfo()
+                ctypes.memmove(ctypes.byref(inf), ctypes.byref(arr[k].info), ctypes.sizeof(inf))
+                infos.append(inf)
+            return [(keep[k][3], arr[k].total_cost, infos[k]) for k in range(nb)]
+        return [keep[k][3] for k in range(nb)]
 
     def assign_chunk(self, index_sc, slots, index_st=None, return_info=False):
         """Cells index_sc against spots index_st (None: all spots) with slots[k] cells for the k-th listed spot.
@@ -154,37 +218,70 @@ def solve_linear_assignment_problem(scRNA_norm_data, st_norm_data, cell_number_t
     raise ValueError("Invalid solver_method provided")
 
 
+def _counts_matrix(a):
+    """A genes x columns count matrix as the narrowest dtype that holds it exactly: float32 when every value survives the
+    cast (raw counts do: half the PCIe traffic), else float64 (the reference's dtype)."""
+    a = np.asarray(a)
+    if a.dtype == np.float32:
+        return np.ascontiguousarray(a)
+    if a.dtype.kind in "iub":
+        if a.size == 0 or np.abs(a).max() < (1 << 24):
+            return np.ascontiguousarray(a, dtype=np.float32)
+        return np.ascontiguousarray(a, dtype=np.float64)
+    a64 = np.ascontiguousarray(a, dtype=np.float64)
+    a32 = a64.astype(np.float32)
+    return a32 if np.array_equal(a32, a64, equal_nan=True) else a64
+
+
 class _RankContext:
     """ExpressionContext over only the columns this rank's chunks touch (one process per GPU: a rank neither uploads nor
-    transforms the columns of other ranks' chunks), with the chunk index lists remapped accordingly."""
+    transforms the cells of other ranks' chunks), with the chunk index lists remapped accordingly.  With a communicator the
+    ST matrix is transformed on rank 0 only and broadcast (ExpressionContext, comm=...); every rank then keeps ALL spots."""
 
-    def __init__(self, sc, st, mine, index_sc_list, index_st_list, device_id, distance_metric):
+    def __init__(self, sc, st, mine, index_sc_list, index_st_list, device_id, distance_metric, already_normalized=True,
+                 comm=None, n_spots=None):
         sc = np.asarray(sc)
-        st = np.asarray(st)
         self._sc_cols = self._st_cols = None
+        self.ctx = None
+        if not mine and comm is None:
+            return                                    # nothing to solve on this rank: no upload, no transform
         if mine and len(mine) < len(index_sc_list):
             cols = np.unique(np.concatenate([np.asarray(index_sc_list[i]) for i in mine]))
             if len(cols) < sc.shape[1]:
                 self._sc_cols, sc = cols, sc[:, cols]
-            if index_st_list is not None:
+            if index_st_list is not None and comm is None:
+                st = np.asarray(st)
                 cols = np.unique(np.concatenate([np.asarray(index_st_list[i]) for i in mine]))
                 if len(cols) < st.shape[1]:
                     self._st_cols, st = cols, st[:, cols]
-        self.ctx = ExpressionContext(sc, st, True, device_id, distance_metric)
+        elif not mine:
+            sc = sc[:, :1]                            # (takes part in the broadcast only)
+        self.ctx = ExpressionContext(sc, st, already_normalized, device_id, distance_metric, comm=comm, n_spots=n_spots)
 
-    def assign_chunk(self, index_sc, slots, index_st=None):
+    def remap(self, index_sc, index_st=None):
         index_sc = np.asarray(index_sc)
         if self._sc_cols is not None:
             index_sc = np.searchsorted(self._sc_cols, index_sc)
         if index_st is not None and self._st_cols is not None:
             index_st = np.searchsorted(self._st_cols, np.asarray(index_st))
-        return self.ctx.assign_chunk(index_sc, slots, index_st)
+        return index_sc, index_st
+
+    def assign_chunks(self, chunks, max_concurrent=0):
+        """chunks: list of (index_sc, slots, index_st or None) in ORIGINAL column numbering."""
+        if not chunks:
+            return []
+        out = []
+        for index_sc, slots, index_st in chunks:
+            isc, ist = self.remap(index_sc, index_st)
+            out.append((isc, slots, ist))
+        return self.ctx.assign_chunks(out, max_concurrent)
 
     def __enter__(self):
         return self
 
     def __exit__(self, *exc):
-        self.ctx.close()
+        if self.ctx is not None:
+            self.ctx.close()
 
 
 def schedule_chunks(sizes, n_devices):
@@ -199,82 +296,80 @@ def schedule_chunks(sizes, n_devices):
     return owner
 
 
-def assign_chunks(scRNA_norm, st_norm, cell_number_to_node_assignment, index_sc_list, index_st_list=None,
-                  subsampled_slots_list=None, rank=0, world_size=1, device_id=0, max_concurrent=8):
+def assign_chunks(scRNA, st, cell_number_to_node_assignment, index_sc_list, index_st_list=None,
+                  subsampled_slots_list=None, rank=0, world_size=1, device_id=0, max_concurrent=0,
+                  distance_metric="Pearson_correlation", already_normalized=True, comm=None):
     """The chunk fan-out of apply_linear_assignment (cytospace.py:405-467) for one rank of a
-    one-process-per-GPU job: this rank solves the chunks the LPT schedule gives it and returns
-    {chunk index: mapped_st_index}.  Inputs are already normalised numpy arrays (genes x cells/spots)."""
+    one-process-per-GPU job: this rank solves the chunks the LPT schedule gives it -- all of them in one batched call, a
+    workgroup per chunk in every chain phase -- and returns {chunk index: mapped_st_index}.
+    scRNA / st: genes x cells / genes x spots numpy arrays, normalised (already_normalized=True, as the reference hands them
+    to its workers) or raw counts (False: normalised on the device).  comm: a _lib.Communicator; then only rank 0 needs `st`
+    (the others may pass None) and its transformed operand is broadcast over xGMI."""
     if (index_st_list is not None) and (subsampled_slots_list is not None):
         raise ValueError("index_st_list and subsampled_cell_number_to_node_assignment_list cannot both be specified")
-    from concurrent.futures import ThreadPoolExecutor
     n_chunks = len(index_sc_list)
     owner = schedule_chunks([len(ix) for ix in index_sc_list], world_size)
     mine = [idx for idx in range(n_chunks) if owner[idx] == rank]
-    slots_all = np.asarray(cell_number_to_node_assignment)
-    # the sequential part of one solve occupies one workgroup: run this rank's chunks side by side
-    # (ctypes releases the GIL; every call uses its own HIP stream); the matrices are uploaded once
-    with _RankContext(scRNA_norm, st_norm, mine, index_sc_list, index_st_list, device_id, "Pearson_correlation") as ctx:
-        def one(idx):
+    slots_all = None if cell_number_to_node_assignment is None else np.asarray(cell_number_to_node_assignment)
+    n_spots = np.asarray(st).shape[1] if st is not None else (len(slots_all) if slots_all is not None
+                                                              else len(subsampled_slots_list[0]))
+    with _RankContext(scRNA, st, mine, index_sc_list, index_st_list, device_id, distance_metric, already_normalized,
+                      comm=comm, n_spots=n_spots) as ctx:
+        chunks = []
+        for idx in mine:
             if index_st_list is not None:
-                return ctx.assign_chunk(index_sc_list[idx], slots_all[index_st_list[idx]], index_st_list[idx])
-            if subsampled_slots_list is not None:
-                return ctx.assign_chunk(index_sc_list[idx], subsampled_slots_list[idx])
-            return ctx.assign_chunk(index_sc_list[idx], slots_all)
-
-        with ThreadPoolExecutor(max_workers=max(1, min(max_concurrent, max(1, len(mine))))) as ex:
-            return dict(zip(mine, ex.map(one, mine)))
+                chunks.append((index_sc_list[idx], slots_all[np.asarray(index_st_list[idx])], index_st_list[idx]))
+            elif subsampled_slots_list is not None:
+                chunks.append((index_sc_list[idx], subsampled_slots_list[idx], None))
+            else:
+                chunks.append((index_sc_list[idx], slots_all, None))
+        return dict(zip(mine, ctx.assign_chunks(chunks, max_concurrent)))
 
 
 def apply_linear_assignment(scRNA_data, st_data, coordinates_data, cell_number_to_node_assignment,
                             solver_method, solver, seed, distance_metric, number_of_processors,
                             index_sc_list, index_st_list=None, subsampled_cell_number_to_node_assignment_list=None,
-                            rank=0, world_size=1, device_id=0):
+                            rank=0, world_size=1, device_id=0, comm=None):
     """cytospace/cytospace.py:354-469 with the reference's arguments (pandas DataFrames as read by read_data):
     normalise once, solve every chunk, map the assigned spot indices to coordinates.
 
     Returns (assigned_locations: pd.DataFrame, cell_ids_selected: np.ndarray); the nth cell id is mapped to the
-    nth row of assigned_locations.  The reference forks one process per chunk (number_of_processors bounds the
-    pool); here `number_of_processors` bounds the chunks solved side by side on this rank's GPU, and with
-    world_size > 1 (one process per GPU) each rank returns the chunks the LPT schedule gives it, in chunk order
-    (the reference concatenates in completion order: compare as a set of (cell, spot) pairs)."""
+    nth row of assigned_locations.  The count matrices go to the GPU ONCE, as raw counts (float32 when exact), and are
+    normalised and transformed there (common.py:142-147 on the device); nothing normalised comes back to the host.
+    The reference forks one process per chunk; here all chunks of a rank go through the solver together, a workgroup per
+    chunk (`number_of_processors` bounds how many are in flight).  With world_size > 1 (one process per GPU) each rank
+    returns the chunks the LPT schedule gives it, in chunk order (the reference concatenates in completion order: compare
+    as a set of (cell, spot) pairs); with `comm` only rank 0's ST matrix is used and its operand is broadcast."""
     import pandas as pd
-    from . import common
     if (index_st_list is not None) and (subsampled_cell_number_to_node_assignment_list is not None):
         raise ValueError("index_st_list and subsampled_cell_number_to_node_assignment_list cannot both be specified")
     if solver_method != "lapjv_hip":
         raise ValueError("apply_linear_assignment of this package drives the lapjv_hip solver")
-    scRNA_norm_np = common.normalize_data(scRNA_data.to_numpy(), device_id)
-    st_norm_np = common.normalize_data(st_data.to_numpy(), device_id)
+    sc_counts = _counts_matrix(scRNA_data.to_numpy())
+    st_counts = _counts_matrix(st_data.to_numpy()) if st_data is not None else None
     cell_ids = scRNA_data.columns.values
     slots_all = np.asarray(cell_number_to_node_assignment)
     if (index_st_list is None) and (subsampled_cell_number_to_node_assignment_list is None):
-        mapped_st_index, _ = solve_linear_assignment_problem(
-            scRNA_norm_np[:, index_sc_list[0]], st_norm_np, slots_all, solver_method, solver, seed, distance_metric,
-            device_id=device_id)
-        return coordinates_data.iloc[mapped_st_index], cell_ids[index_sc_list[0]]
-    num_iters = len(index_st_list) if index_st_list is not None else len(subsampled_cell_number_to_node_assignment_list)
-    print(f"Number of required processors: {num_iters}")
-    n_chunks = num_iters
-    from concurrent.futures import ThreadPoolExecutor
-    owner = schedule_chunks([len(index_sc_list[idx]) for idx in range(n_chunks)], world_size)
-    mine = [idx for idx in range(n_chunks) if owner[idx] == rank]
-
-    # both matrices go to the device once; a chunk gathers its columns there (spots without cells are skipped)
-    with _RankContext(scRNA_norm_np, st_norm_np, mine, index_sc_list, index_st_list, device_id, distance_metric) as ctx:
-        def one(idx):
-            if index_st_list is not None:
-                return idx, ctx.assign_chunk(index_sc_list[idx], slots_all[index_st_list[idx]], index_st_list[idx])
-            return idx, ctx.assign_chunk(index_sc_list[idx], subsampled_cell_number_to_node_assignment_list[idx])
-
-        with ThreadPoolExecutor(max_workers=max(1, min(len(mine) or 1, int(number_of_processors)))) as ex:
-            results = list(ex.map(one, mine))
+        print('Solving linear assignment problem ...')
+        t0 = time.perf_counter()
+        mapped = assign_pearson(sc_counts[:, index_sc_list[0]], st_counts, slots_all, already_normalized=False,
+                                device_id=device_id, distance_metric=distance_metric)
+        print(f"Time to solve linear assignment problem: {round(time.perf_counter() - t0, 2)} seconds")
+        return coordinates_data.iloc[mapped.tolist()], cell_ids[index_sc_list[0]]
+    n_chunks = len(index_st_list) if index_st_list is not None else len(subsampled_cell_number_to_node_assignment_list)
+    print(f"Number of required processors: {n_chunks}")
+    res = assign_chunks(sc_counts, st_counts, slots_all, index_sc_list, index_st_list,
+                        subsampled_cell_number_to_node_assignment_list, rank=rank, world_size=world_size,
+                        device_id=device_id, max_concurrent=int(number_of_processors), distance_metric=distance_metric,
+                        already_normalized=False, comm=comm)
     assigned_locations_list, cell_ids_selected_list = [], []
-    for idx, mapped in results:
+    for idx in sorted(res):
+        mapped = res[idx]
         loc = coordinates_data.iloc[index_st_list[idx]].iloc[mapped] if index_st_list is not None \
             else coordinates_data.iloc[mapped]
         assigned_locations_list.append(loc)
         cell_ids_selected_list.append(cell_ids[index_sc_list[idx]])
-    if not results:
+    if not res:
         return coordinates_data.iloc[[]], cell_ids[[]]
     return pd.concat(assigned_locations_list), np.concatenate(cell_ids_selected_list, axis=0)
 

@@ -41,6 +41,7 @@ int cyto_malloc(void **dptr, size_t bytes, int device_id);
 int cyto_free(void *dptr, int device_id);
 int cyto_memcpy_h2d(void *dst, const void *src, size_t bytes, int device_id);
 int cyto_memcpy_d2h(void *dst, const void *src, size_t bytes, int device_id);
+int cyto_memcpy_d2d(void *dst, const void *src, size_t bytes, int device_id);
 int cyto_device_synchronize(int device_id);
 /* Work buffers of the solves are taken from a per-device cache of HBM blocks and go back to it afterwards (a steady
  * stream of chunk solves performs no hipMalloc / hipFree: hipFree would synchronise the whole device and serialise the
@@ -202,6 +203,28 @@ int cyto_ctx_create(int metric, int G, int C, int S, const double *sc, const dou
 int cyto_ctx_assign_chunk(cyto_expr_ctx *ctx, const int64_t *idx_sc, int n_sc, const int64_t *idx_st, int n_st,
                           const int64_t *slots, int64_t *mapped_spot, double *total_cost, cyto_assign_info *info);
 void cyto_ctx_destroy(cyto_expr_ctx *ctx);
+
+/* One process per GPU (cytospace.py:430-451 forks one worker per chunk and pickles the whole ST matrix to each): only rank
+ * `root` holds the ST matrix; it transforms it once and the float32 operand reaches the other ranks with ONE broadcast over
+ * xGMI (comm from cyto_comm_init; RCCL) -- the only collective of the path.  sc / C are THIS rank's cells only (raw counts
+ * with already_normalized = 0: nothing normalised ever crosses PCIe twice).  st may be NULL on ranks != root.
+ * bcast_ms (optional): HIP-event time of the broadcast. */
+int cyto_ctx_create_shared(int metric, int G, int C, int S, const void *sc, const void *st, int x_is_f64, int already_normalized,
+                           void *comm, int root, int rank, int device_id, cyto_expr_ctx **out, double *bcast_ms);
+
+/* Every chunk of a rank in one call: per chunk the column gathers and the cost GEMM, then ALL the chunks' LAPs together (a
+ * workgroup per chunk in every chain phase: cyto_lap_batch_f32).  Fields as cyto_ctx_assign_chunk's arguments; status, total_cost
+ * and info are outputs.  max_concurrent bounds the chunks whose cost matrices exist at once (<= 0: min(nchunks, 64)). */
+typedef struct {
+    const int64_t *idx_sc; int32_t n_sc;
+    const int64_t *idx_st; int32_t n_st;          /* NULL / ignored: all S spots */
+    const int64_t *slots;
+    int64_t *mapped_spot;                          /* out, n_sc entries */
+    double total_cost;                             /* out */
+    int32_t status;                                /* out */
+    cyto_assign_info info;                         /* out */
+} cyto_chunk;
+int cyto_ctx_assign_chunks(cyto_expr_ctx *ctx, int nchunks, cyto_chunk *chunks, int max_concurrent);
 
 /* The same two entry points for float32 host matrices (x_is_f64 = 0): half the host-to-device traffic, identical
  * results for data that is exactly representable in float32 (raw counts); the reference's own arrays are float64. */

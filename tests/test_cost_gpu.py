@@ -228,6 +228,62 @@ def test_gv11_apply_linear_assignment_chunked_modes(mode):
     assert got2 == want
 
 
+def _gv11_ss():
+    d = load("gv11_apply_linear_assignment.npz")
+    idx_sc = np.split(d["ss_idx_sc"], np.cumsum(d["ss_idx_sc_lens"])[:-1])
+    return d, idx_sc
+
+
+def test_broadcast_context_single_rank_equals_local_transform():
+    # the collective of the path (RCCL broadcast of the transformed ST operand) with a 1-rank communicator on this GPU:
+    # same answers as the context that transforms ST itself; raw counts in (normalised on the device)
+    from cytospace_amd import _lib
+    d, idx_sc = _gv11_ss()
+    sc, st = d["ss_counts"].astype(np.float32), d["ss_st_counts"].astype(np.float32)
+    subs = list(d["ss_sub"])
+    comm = _lib.Communicator(_lib.Communicator.unique_id(), 0, 1)
+    try:
+        with gcyto.ExpressionContext(sc, st, False, 0, comm=comm) as shared, gcyto.ExpressionContext(sc, st, False, 0) as local:
+            assert shared.bcast_ms is not None and shared.bcast_ms >= 0.0
+            a = shared.assign_chunks([(ix, subs[k]) for k, ix in enumerate(idx_sc)])
+            b = local.assign_chunks([(ix, subs[k]) for k, ix in enumerate(idx_sc)])
+            one = [local.assign_chunk(ix, subs[k]) for k, ix in enumerate(idx_sc)]        # one chunk at a time
+        for x, y, z in zip(a, b, one):
+            assert np.array_equal(x, y) and np.array_equal(x, z)
+        r = gcyto.assign_chunks(sc, st, d["ss_slots"], idx_sc, subsampled_slots_list=subs, already_normalized=False, comm=comm)
+        assert all(np.array_equal(r[k], a[k]) for k in range(len(idx_sc)))
+    finally:
+        comm.close()
+
+
+def test_two_ranks_broadcast_and_disjoint_chunks(tmp_path):
+    # one process per GPU: rank 0 transforms ST and broadcasts it, rank 1 never sees the ST matrix; the ranks solve disjoint
+    # chunks whose union is the reference's own result (gv11).  Needs two devices (the driver's multi-GPU node).
+    import subprocess
+    import sys
+    from cytospace_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    d, idx_sc = _gv11_ss()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_two_rank_worker.py")
+    idf = str(tmp_path / "uid.bin")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", idf, str(tmp_path / f"out{r}.npz")]) for r in range(2)]
+    for p_ in procs:
+        assert p_.wait(timeout=300) == 0
+    got = {}
+    for r in range(2):
+        o = np.load(str(tmp_path / f"out{r}.npz"))
+        for k in o["chunks"]:
+            assert int(k) not in got
+            got[int(k)] = o[f"m{int(k)}"]
+    assert sorted(got) == list(range(len(idx_sc)))
+    S = d["ss_st_counts"].shape[1]
+    ncol = 4
+    pairs = {(int(c), int(sp) // ncol, int(sp) % ncol) for k, ix in enumerate(idx_sc) for c, sp in zip(ix, got[k])}
+    want = {(int(c), int(r), int(k)) for c, (r, k) in zip(d["ss_out_cell"], d["ss_out_rowcol"])}
+    assert pairs == want and S > 0
+
+
 @pytest.mark.parametrize("metric", ["Pearson_correlation", "Spearman_correlation", "Euclidean"])
 def test_expression_context_chunks_equal_per_chunk_uploads(metric):
     # multi-chunk seam: transform once + device-side column gathers == uploading and transforming every chunk
