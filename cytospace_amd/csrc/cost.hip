@@ -260,11 +260,13 @@ __global__ __launch_bounds__(256, 2) void pearson_gemm(int Gpad, int S, int C, c
     const int m0 = tm * BM, n0 = tn * BN;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // Two-level accumulation: the matrix cores add into `acc` for FOLD k-tiles (512 genes), then `acc` is folded into
-    // `sum` with ordinary round-to-nearest adds and cleared.  One running fp32 sum over 20 000 genes (config c3) drifts by
-    // ~1e-5 (measured against the float64 reference, biased towards zero); partial sums of 512 genes are 40x smaller, so
-    // their rounding steps are too, and the 40 folds add ~1e-7.
-    constexpr int FOLD = 16;
+    // Two-level accumulation: the matrix cores add into `acc` for FOLD k-tiles (32 genes each), then `acc` is folded into
+    // `sum` with ordinary round-to-nearest adds and cleared.  The MFMA accumulate truncates: one running fp32 sum over
+    // 20 000 genes (config c3) ended ~1e-5 below the float64 reference (up to 7e-5), always towards zero; partial sums of 32
+    // genes are ~600x smaller, so are their truncation steps.  Measured at c3 size with FOLD = 1: every entry within 2e-6
+    // (FOLD = 8: 21 of 4.8 M entries above, FOLD = 16: up to 3e-6 on correlations near 1); the 64 extra adds per tile hide
+    // under the 64 MFMAs (122 TFLOP/s either way).
+    constexpr int FOLD = 1;
     f32x16 acc[2][2], sum[2][2];
 #pragma unroll
     for (int a = 0; a < 2; a++)
