@@ -166,16 +166,18 @@ __device__ __forceinline__ uint64_t d2ord(double x) {
     const uint64_t b = (uint64_t)__double_as_longlong(x + 0.0);          // +0.0: -0 -> +0
     return b ^ ((b >> 63) ? ~0ull : 0x8000000000000000ull);
 }
+// A launch ranks the values own0 <= g < own0 + MOWN * 1024 of every column (against the WHOLE column): unfiltered 10x gene
+// sets (33 538 or 36 601 genes) take two launches.
 template <typename TIn, int MOWN>
 __global__ __launch_bounds__(1024) void rank_columns(int G, int C, const TIn *__restrict__ x, int64_t ldx,
-                                                     float *__restrict__ r, int64_t ldr) {
+                                                     float *__restrict__ r, int64_t ldr, int own0) {
     __shared__ uint64_t sk[RANK_CHUNK];
     const int c = blockIdx.x, tid = threadIdx.x;
     uint64_t own[MOWN];
     int lt[MOWN], eq[MOWN];
 #pragma unroll
     for (int e = 0; e < MOWN; e++) {
-        const int g = tid + e * 1024;
+        const int g = own0 + tid + e * 1024;
         own[e] = g < G ? d2ord(clean<TIn>(x[(int64_t)g * ldx + c])) : 0ull;
         lt[e] = 0; eq[e] = 0;
     }
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(1024) void rank_columns(int G, int C, const TIn *__
         }
 #pragma unroll
         for (int e = 0; e < MOWN; e++) {
-            if (tid + e * 1024 < G) {
+            if (own0 + tid + e * 1024 < G) {
                 const uint64_t key = own[e];
                 int lo = 0, hi = 0;
 #pragma unroll
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(1024) void rank_columns(int G, int C, const TIn *__
     }
 #pragma unroll
     for (int e = 0; e < MOWN; e++) {
-        const int g = tid + e * 1024;
+        const int g = own0 + tid + e * 1024;
         if (g < G) r[(int64_t)g * ldr + c] = (float)((double)lt[e] + 0.5 * (double)(eq[e] + 1));
     }
 }
@@ -382,17 +384,19 @@ static int standardize_dev(int G, int C, const TIn *dx, int64_t ldx, int already
                            int64_t ldy, hipStream_t stream, int transform = 0) {
     if (transform == 1) {
         // ranks into a float32 matrix, then the usual standardisation of that matrix
-        if (G > 32 * 1024) return CYTO_ERR_UNSUPPORTED;
+        if (G >= (1 << 24)) return CYTO_ERR_UNSUPPORTED;      // ranks are stored as float32: exact up to 2^24 values per column
         DevBuf ranks;
         int rc2;
         if ((rc2 = ranks.alloc((size_t)G * C * sizeof(float), stream))) return rc2;
-        const int m = (G + 1023) / 1024;
         float *rp = ranks.as<float>();
-        if (m <= 4) hipLaunchKernelGGL((rank_columns<TIn, 4>), dim3(C), dim3(1024), 0, stream, G, C, dx, ldx, rp, (int64_t)C);
-        else if (m <= 8) hipLaunchKernelGGL((rank_columns<TIn, 8>), dim3(C), dim3(1024), 0, stream, G, C, dx, ldx, rp, (int64_t)C);
-        else if (m <= 16) hipLaunchKernelGGL((rank_columns<TIn, 16>), dim3(C), dim3(1024), 0, stream, G, C, dx, ldx, rp, (int64_t)C);
-        else if (m <= 24) hipLaunchKernelGGL((rank_columns<TIn, 24>), dim3(C), dim3(1024), 0, stream, G, C, dx, ldx, rp, (int64_t)C);
-        else hipLaunchKernelGGL((rank_columns<TIn, 32>), dim3(C), dim3(1024), 0, stream, G, C, dx, ldx, rp, (int64_t)C);
+        for (int own0 = 0; own0 < G; own0 += 32 * 1024) {
+            const int m = (min(G - own0, 32 * 1024) + 1023) / 1024;
+            if (m <= 4) hipLaunchKernelGGL((rank_columns<TIn, 4>), dim3(C), dim3(1024), 0, stream, G, C, dx, ldx, rp, (int64_t)C, own0);
+            else if (m <= 8) hipLaunchKernelGGL((rank_columns<TIn, 8>), dim3(C), dim3(1024), 0, stream, G, C, dx, ldx, rp, (int64_t)C, own0);
+            else if (m <= 16) hipLaunchKernelGGL((rank_columns<TIn, 16>), dim3(C), dim3(1024), 0, stream, G, C, dx, ldx, rp, (int64_t)C, own0);
+            else if (m <= 24) hipLaunchKernelGGL((rank_columns<TIn, 24>), dim3(C), dim3(1024), 0, stream, G, C, dx, ldx, rp, (int64_t)C, own0);
+            else hipLaunchKernelGGL((rank_columns<TIn, 32>), dim3(C), dim3(1024), 0, stream, G, C, dx, ldx, rp, (int64_t)C, own0);
+        }
         CYTO_HIP(hipGetLastError());
         return standardize_dev<float>(G, C, rp, C, 1, z, ldz, nullptr, 0, stream, 0);
     }

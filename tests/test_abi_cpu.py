@@ -170,3 +170,47 @@ def test_c_abi_argument_validation_needs_no_device():
     assert L.cyto_ctx_assign_chunk(None, slots.ctypes.data, 4, None, 0, slots.ctypes.data, slots.ctypes.data, None, None) == BAD
     L.cyto_ctx_destroy(None)                                                                                # no-op
     assert L.cyto_strerror(1).decode() != ""
+
+
+# ---- the output writers against files the reference itself wrote (tests/golden/gv12_outputs.npz) ----
+
+def _gv12_toy(method):
+    import pandas as pd
+    rng = np.random.default_rng(12)
+    G, C, S = 7, 14, 6
+    genes = [f"GENE_g{i}" for i in range(G)]
+    cells = [f"CELL_c{i}" for i in range(C)]
+    types_ = ["TYPE_B", "TYPE_T", "TYPE_Mono"]
+    ctd = pd.DataFrame({"CellType": [types_[i % 3] for i in range(C)]}, index=cells)
+    expr = pd.DataFrame(rng.poisson(2.0, (G, C)), index=genes, columns=cells)
+    coords = pd.DataFrame({"row": np.arange(S) // 3, "col": np.arange(S) % 3}, index=[f"SPOT_s{i}" for i in range(S)])
+    picked = [cells[i] for i in (3, 0, 7, 7, 12, 5, 9, 1, 3, 13, 2)]
+    if method == "place_holders":
+        extra = [f"CELL_{t[5:]}_new_{k + 1}" for k, t in enumerate(["TYPE_B", "TYPE_Mono"])]
+        for e in extra:
+            expr[e] = rng.poisson(2.0, G)
+        picked = picked[:9] + extra
+    spots = [coords.index[i] for i in (0, 0, 1, 3, 3, 3, 4, 1, 0, 4, 3)]
+    return picked, expr, coords.loc[spots], ctd, coords
+
+
+@pytest.mark.parametrize("method", ["duplicates", "place_holders"])
+@pytest.mark.parametrize("single", [False, True])
+def test_gv12_output_files_equal_the_references(method, single, tmp_path):
+    from cytospace_amd.post_processing import save_results, save_unassigned_locations
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gv12_outputs.npz"))
+    picked, expr, assigned, ctd, coords = _gv12_toy(method)
+    save_results(str(tmp_path), "p_", np.array(picked), expr, assigned, ctd, method, single)
+    assert save_unassigned_locations(str(tmp_path), "p_", coords.index, assigned, coords) == 2
+    tag = f"{method}_{'sc' if single else 'spot'}"
+    want = {k.split("::", 1)[1]: bytes(gold[k].tobytes()) for k in gold.files if k.startswith(tag + "::")}
+    got = {}
+    for root, _, files in os.walk(str(tmp_path)):
+        for f in files:
+            got[os.path.relpath(os.path.join(root, f), str(tmp_path))] = open(os.path.join(root, f), "rb").read()
+    assert sorted(got) == sorted(want)
+
+    def norm(name, b):          # scipy's MatrixMarket header carries no date, but be robust to comment lines
+        return b"\n".join(l for l in b.split(b"\n") if not (name.endswith(".mtx") and l.startswith(b"%") and not l.startswith(b"%%")))
+    for name in want:
+        assert norm(name, got[name]) == norm(name, want[name]), name

@@ -228,6 +228,22 @@ def test_gv11_apply_linear_assignment_chunked_modes(mode):
     assert got2 == want
 
 
+@pytest.mark.parametrize("G", [9000, 20000, 36601])
+def test_spearman_ranks_many_genes(G):
+    # unfiltered 10x gene sets have 33 538 / 36 601 genes: several sorted chunks per column (G > 8 192), every MOWN variant,
+    # and two launches beyond 32 768 genes.  Against pandas' rank() (average ties, 1-based), heavy ties included.
+    import pandas as pd
+    rng = np.random.default_rng(G)
+    x = rng.poisson(0.7, (G, 5)).astype(np.float64)             # mostly 0 / 1 / 2: long tie runs
+    x[:, 3] = rng.random(G)                                      # one column without ties
+    x[:, 4] = np.round(rng.normal(size=G), 2)
+    z = gcommon.StandardizedMatrix(x, True, 0, "Spearman_correlation").to_numpy()
+    want = pd.DataFrame(x).rank().to_numpy()
+    want = (want - want.mean(0)) / (want.std(0) * np.sqrt(G))    # the operand holds the standardised ranks
+    np.testing.assert_allclose(z, want, rtol=0, atol=2e-7)
+    np.testing.assert_array_equal(ocost.rank_columns(x), pd.DataFrame(x).rank().to_numpy())
+
+
 def _gv11_ss():
     d = load("gv11_apply_linear_assignment.npz")
     idx_sc = np.split(d["ss_idx_sc"], np.cumsum(d["ss_idx_sc_lens"])[:-1])
