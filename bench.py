@@ -270,8 +270,14 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no n50000 / c3 / c4_chunks)")
     ap.add_argument("--c4-chunks", type=int, default=256, help="concurrent chunk LAPs in the c4_chunks leg (256 = one chain per CU; 400 MB each)")
     ap.add_argument("--c4-rank-chunks", type=int, default=8, help="chunks per rank in the c4_sharded leg")
-    ap.add_argument("--pmc-tag", default="r02", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
+    ap.add_argument("--pmc-tag", default="r02a", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
     args = ap.parse_args()
+
+    # ONE JSON line on stdout: everything else this process (or a library under it: RCCL prints a version banner through C
+    # stdio) writes to file descriptor 1 goes to stderr instead; the line itself is written to the saved descriptor.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -445,7 +451,8 @@ def main():
         out["n50000"] = extra_n50000(dev)
         out["c3"] = extra_c3(dev)
         out["c4_chunks"] = extra_c4_chunks(dev, args.c4_chunks)
-    print(json.dumps(out))
+    json_out.write(json.dumps(out) + "\n")
+    json_out.flush()
 
 
 def _cpu_model():

@@ -51,6 +51,11 @@ class AssignInfo(ctypes.Structure):
                 ("lap", LapInfo)]
 
 
+class Matrix(ctypes.Structure):
+    """cyto_matrix (include/cytohip.h): a dense genes x columns array on the host or on the device."""
+    _fields_ = [("data", ctypes.c_void_p), ("ld", ctypes.c_int64), ("is_f64", ctypes.c_int32), ("on_device", ctypes.c_int32)]
+
+
 class Chunk(ctypes.Structure):
     """cyto_chunk (include/cytohip.h)."""
     _fields_ = [("idx_sc", ctypes.c_void_p), ("n_sc", ctypes.c_int32), ("idx_st", ctypes.c_void_p), ("n_st", ctypes.c_int32),
@@ -109,6 +114,11 @@ def lib():
         L.cyto_ctx_destroy.restype = None
         L.cyto_ctx_create_shared.argtypes = [i32, i32, i32, i32, vp, vp, i32, i32, vp, i32, i32, i32, ctypes.POINTER(vp), dp]
         L.cyto_ctx_create_shared.restype = ctypes.c_int
+        L.cyto_ctx_create_ex.argtypes = [i32, i32, ctypes.POINTER(Matrix), i32, ctypes.POINTER(Matrix), i32, i32, vp, i32, i32, i32,
+                                         ctypes.POINTER(vp), dp]
+        L.cyto_ctx_create_ex.restype = ctypes.c_int
+        L.cyto_csc_to_dense_f32.argtypes = [i32, i32, i64, vp, vp, vp, vp, i64, i32, vp]
+        L.cyto_csc_to_dense_f32.restype = ctypes.c_int
         L.cyto_ctx_assign_chunks.argtypes = [vp, i32, ctypes.POINTER(Chunk), i32]
         L.cyto_ctx_assign_chunks.restype = ctypes.c_int
         L.cyto_memcpy_d2d.argtypes = [vp, vp, ctypes.c_size_t, i32]

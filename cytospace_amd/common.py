@@ -34,6 +34,84 @@ def normalize_data(data, device_id=0):
 METRICS = {"Pearson_correlation": 0, "Spearman_correlation": 1, "Euclidean": 2}   # CYTO_METRIC_*
 
 
+def is_sparse(x):
+    try:
+        import scipy.sparse as sp
+    except ImportError:
+        return False
+    return sp.issparse(x)
+
+
+def sparse_to_device(x, device_id=0):
+    """A scipy.sparse genes x columns count matrix -> dense float32 G x ld matrix in HBM (C ABI: cyto_csc_to_dense_f32): only the
+    non-zeros cross PCIe and the expansion runs on the device.  The reference densifies on the host
+    (`pd.DataFrame.sparse.from_spmatrix(...).sparse.to_dense()`, cytospace/common/common.py:57).
+    Returns (DeviceBuffer, G, C, ld).  Values must be exact in float32 (counts are)."""
+    csc = x.tocsc()
+    csc.sum_duplicates()
+    G, C = csc.shape
+    vals = np.ascontiguousarray(csc.data, dtype=np.float32)
+    if not np.array_equal(vals.astype(csc.data.dtype, copy=False), csc.data):
+        raise ValueError("sparse values are not exactly representable in float32; pass a dense float64 matrix instead")
+    colptr = np.ascontiguousarray(csc.indptr, dtype=np.int64)
+    rowidx = np.ascontiguousarray(csc.indices, dtype=np.int32)
+    ld = -(-C // 4) * 4
+    buf = _lib.DeviceBuffer(max(G, 1) * ld * 4, device_id)
+    _lib.check(_lib.lib().cyto_csc_to_dense_f32(G, C, len(vals), colptr.ctypes.data, rowidx.ctypes.data if len(vals) else None,
+                                                vals.ctypes.data if len(vals) else None, buf.ptr, ld, device_id, None))
+    return buf, G, C, ld
+
+
+def read_file(file_path, keep_sparse=True):
+    """cytospace/common/common.py:16-82.  A MatrixMarket file (.mtx / .mtx.gz, genes x cells, with genes|features and
+    cells|barcodes lists beside it) or a delimited text table (.csv: ','; otherwise tab) with gene ids in the first column.
+    Returns a pandas DataFrame like the reference -- except that, with keep_sparse, a MatrixMarket input stays sparse
+    (a DataFrame of pandas sparse columns, `df.sparse.to_coo()` recovers the matrix): ExpressionContext uploads it as non-zeros."""
+    import os
+    import pandas as pd
+    if file_path.endswith(".mtx") or file_path.endswith(".mtx.gz"):
+        import scipy.io
+        if not os.path.isfile(file_path):
+            raise IOError("Cannot locate file: {}".format(file_path))
+        base = os.path.dirname(file_path) + os.path.sep
+
+        def find(names):
+            for name in names:
+                for ext in (".tsv", ".csv", ".tsv.gz", ".csv.gz"):
+                    if os.path.isfile(f"{base}{name}{ext}"):
+                        return f"{base}{name}{ext}", ext
+            raise IOError(f"Required files not found for base path: {base}")
+        gpath, gext = find(["genes", "features"])
+        cpath, cext = find(["cells", "barcodes"])
+        genes = pd.read_csv(gpath, sep="\t" if ".tsv" in gext else ",", header=None).iloc[:, 0].to_numpy()
+        cells = pd.read_csv(cpath, sep="\t" if ".tsv" in cext else ",", header=None).iloc[:, 0].to_numpy()
+        m = scipy.io.mmread(file_path)
+        if m.shape != (len(genes), len(cells)):
+            raise IOError("The dimensions of the provided sparse matrix does not match the corresponding gene and cell lists. "
+                          f"Please check the following files: {gpath}, {cpath}.")
+        df = pd.DataFrame.sparse.from_spmatrix(m, index=genes, columns=cells)
+        return df if keep_sparse else df.sparse.to_dense()
+    sep = "," if file_path.lower().endswith(".csv") else "\t"
+    return pd.read_csv(file_path, sep=sep, header=0, index_col=0)
+
+
+def downsample(data_df, target_count):
+    """cytospace/common/common.py:149-173.  Every cell (column) with more than target_count transcripts is reduced to
+    target_count draws WITH replacement from its transcripts (np.random.choice over the expanded gene list, legacy
+    RandomState: same draws as the reference for the same np.random.seed); other cells are kept.  Host code."""
+    import pandas as pd
+    index = data_df.index
+    values = data_df.to_numpy()
+    out = np.array(values, copy=True)
+    for c in range(values.shape[1]):
+        col = values[:, c]
+        if col.sum() <= target_count:
+            continue
+        picked = np.random.choice(np.repeat(np.arange(len(index)), col), target_count)
+        out[:, c] = np.bincount(picked, minlength=len(index))
+    return pd.DataFrame(out, index=index, columns=data_df.columns)
+
+
 class StandardizedMatrix:
     """A gene x column matrix as the float32 GEMM operand of a metric, zero padded, resident in HBM:
     standardised values (Pearson), standardised average-tie ranks (Spearman) or the plain values (Euclidean)."""

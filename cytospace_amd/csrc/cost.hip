@@ -371,6 +371,19 @@ __global__ __launch_bounds__(256) void gather_columns(int Gpad, int nsel, const 
     for (int g = g0; g < g1; g++) out[(int64_t)g * ldo + c] = z[(int64_t)g * ldz + src];
 }
 
+// Sparse counts -> dense: one thread per stored entry (binary search of its column in colptr); the dense matrix was zeroed.
+__global__ __launch_bounds__(256) void csc_scatter(int C, int64_t nnz, const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx,
+                                                   const float *__restrict__ vals, float *__restrict__ dense, int64_t ld, int G,
+                                                   int *__restrict__ bad) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nnz) return;
+    int lo = 0, hi = C;                           // largest c with colptr[c] <= e
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (colptr[mid] <= e) lo = mid; else hi = mid; }
+    const int g = rowidx[e];
+    if (g < 0 || g >= G) { *bad = 1; return; }
+    dense[(int64_t)g * ld + lo] = vals[e];
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -627,12 +640,13 @@ struct cyto_expr_ctx {
 // ST matrix; it transforms it once and the float32 operand goes to the other ranks with ONE ncclBroadcast over xGMI -- the
 // only collective of the path (the reference pickles the whole ST matrix to every worker: cytospace.py:438, 446-451).
 // sc always holds THIS rank's cells only.
-static int ctx_create_impl(int metric, int G, int C, int S, const void *sc, const void *st, int x_is_f64, int already_normalized,
+static int ctx_create_impl(int metric, int G, int C, int S, const void *sc, int64_t ldsc_in, int sc_is_f64, int sc_on_device,
+                           const void *st, int64_t ldst_in, int st_is_f64, int st_on_device, int already_normalized,
                            void *comm, int root, int rank, int device_id, cyto_expr_ctx **out, double *bcast_ms) {
-    if (!out || G <= 0 || C <= 0 || S <= 0 || !sc) return CYTO_ERR_BAD_ARG;
+    if (!out || G <= 0 || C <= 0 || S <= 0 || !sc || ldsc_in < C) return CYTO_ERR_BAD_ARG;
     if (metric < CYTO_METRIC_PEARSON || metric > CYTO_METRIC_EUCLIDEAN) return CYTO_ERR_BAD_ARG;
     const bool have_st = !comm || rank == root;
-    if (have_st && !st) return CYTO_ERR_BAD_ARG;
+    if (have_st && (!st || ldst_in < S)) return CYTO_ERR_BAD_ARG;
     int rc = select_device(device_id);
     if (rc) return rc;
     cyto_expr_ctx *ctx = new (std::nothrow) cyto_expr_ctx();
@@ -644,7 +658,8 @@ static int ctx_create_impl(int metric, int G, int C, int S, const void *sc, cons
     const size_t nst = (size_t)ctx->Gpad * ctx->ldst;
     if ((rc = ctx->zsc.alloc((size_t)ctx->Gpad * ctx->ldsc * 4)) || (rc = ctx->zst.alloc(nst * 4))) { delete ctx; return rc; }
     if (have_st)
-        rc = cyto_transform(transform, G, S, st, S, x_is_f64, 0, already_normalized, ctx->zst.as<float>(), ctx->ldst, ctx->Gpad, device_id, nullptr);
+        rc = cyto_transform(transform, G, S, st, ldst_in, st_is_f64, st_on_device, already_normalized, ctx->zst.as<float>(), ctx->ldst,
+                            ctx->Gpad, device_id, nullptr);
     if (!rc && comm) {
         Events<2> ev;
         if (!(rc = ev.create())) {
@@ -657,7 +672,8 @@ static int ctx_create_impl(int metric, int G, int C, int S, const void *sc, cons
             if (bcast_ms) *bcast_ms = ms;
         }
     }
-    if (!rc) rc = cyto_transform(transform, G, C, sc, C, x_is_f64, 0, already_normalized, ctx->zsc.as<float>(), ctx->ldsc, ctx->Gpad, device_id, nullptr);
+    if (!rc) rc = cyto_transform(transform, G, C, sc, ldsc_in, sc_is_f64, sc_on_device, already_normalized, ctx->zsc.as<float>(), ctx->ldsc,
+                                 ctx->Gpad, device_id, nullptr);
     if (rc) { delete ctx; return rc; }
     *out = ctx;
     return CYTO_OK;
@@ -666,13 +682,51 @@ static int ctx_create_impl(int metric, int G, int C, int S, const void *sc, cons
 int cyto_ctx_create_typed(int metric, int G, int C, int S, const void *sc, const void *st, int x_is_f64, int already_normalized,
                           int device_id, cyto_expr_ctx **out) {
     if (!st) return CYTO_ERR_BAD_ARG;
-    return ctx_create_impl(metric, G, C, S, sc, st, x_is_f64, already_normalized, nullptr, 0, 0, device_id, out, nullptr);
+    return ctx_create_impl(metric, G, C, S, sc, C, x_is_f64, 0, st, S, x_is_f64, 0, already_normalized, nullptr, 0, 0, device_id, out, nullptr);
 }
 
 int cyto_ctx_create_shared(int metric, int G, int C, int S, const void *sc, const void *st, int x_is_f64, int already_normalized,
                            void *comm, int root, int rank, int device_id, cyto_expr_ctx **out, double *bcast_ms) {
     if (!comm) return CYTO_ERR_BAD_ARG;
-    return ctx_create_impl(metric, G, C, S, sc, st, x_is_f64, already_normalized, comm, root, rank, device_id, out, bcast_ms);
+    return ctx_create_impl(metric, G, C, S, sc, C, x_is_f64, 0, st, S, x_is_f64, 0, already_normalized, comm, root, rank, device_id, out, bcast_ms);
+}
+
+int cyto_ctx_create_ex(int metric, int G, const cyto_matrix *sc, int C, const cyto_matrix *st, int S, int already_normalized,
+                       void *comm, int root, int rank, int device_id, cyto_expr_ctx **out, double *bcast_ms) {
+    if (!sc) return CYTO_ERR_BAD_ARG;
+    return ctx_create_impl(metric, G, C, S, sc->data, sc->ld, sc->is_f64, sc->on_device, st ? st->data : nullptr, st ? st->ld : 0,
+                           st ? st->is_f64 : 0, st ? st->on_device : 0, already_normalized, comm, root, rank, device_id, out, bcast_ms);
+}
+
+// sparse counts (what scipy.io.mmread of a 10x matrix.mtx holds, common/common.py:49) go to the device AS
+// non-zeros and are expanded there; the reference densifies on the host (common.py:57) and ships the dense matrix.
+int cyto_csc_to_dense_f32(int G, int C, int64_t nnz, const int64_t *colptr, const int32_t *rowidx, const float *vals,
+                          float *dense_dev, int64_t ld, int device_id, void *stream_) {
+    if (G <= 0 || C <= 0 || nnz < 0 || !colptr || (nnz > 0 && (!rowidx || !vals)) || !dense_dev || ld < C) return CYTO_ERR_BAD_ARG;
+    if (colptr[0] != 0 || colptr[C] != nnz) return CYTO_ERR_BAD_ARG;
+    for (int c = 0; c < C; c++) if (colptr[c + 1] < colptr[c]) return CYTO_ERR_BAD_ARG;
+    int rc = select_device(device_id);
+    if (rc) return rc;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    DevBuf dptr, didx, dval, dbad;
+    if ((rc = dptr.alloc(((size_t)C + 1) * 8, stream)) || (rc = didx.alloc((size_t)nnz * 4, stream)) || (rc = dval.alloc((size_t)nnz * 4, stream)) ||
+        (rc = dbad.alloc(4, stream)))
+        return rc;
+    CYTO_HIP(hipMemcpyAsync(dptr.p, colptr, ((size_t)C + 1) * 8, hipMemcpyHostToDevice, stream));
+    if (nnz) {
+        CYTO_HIP(hipMemcpyAsync(didx.p, rowidx, (size_t)nnz * 4, hipMemcpyHostToDevice, stream));
+        CYTO_HIP(hipMemcpyAsync(dval.p, vals, (size_t)nnz * 4, hipMemcpyHostToDevice, stream));
+    }
+    CYTO_HIP(hipMemsetAsync(dbad.p, 0, 4, stream));
+    CYTO_HIP(hipMemsetAsync(dense_dev, 0, (size_t)G * ld * 4, stream));
+    if (nnz)
+        hipLaunchKernelGGL(csc_scatter, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, stream, C, nnz, dptr.as<int64_t>(), didx.as<int32_t>(),
+                           dval.as<float>(), dense_dev, ld, G, dbad.as<int>());
+    CYTO_HIP(hipGetLastError());
+    int bad = 0;
+    CYTO_HIP(hipMemcpyAsync(&bad, dbad.p, 4, hipMemcpyDeviceToHost, stream));
+    CYTO_HIP(hipStreamSynchronize(stream));
+    return bad ? CYTO_ERR_BAD_ARG : CYTO_OK;
 }
 
 void cyto_ctx_destroy(cyto_expr_ctx *ctx) {

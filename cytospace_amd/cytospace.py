@@ -87,6 +87,10 @@ class ExpressionContext:
             raise ValueError(f"unknown distance_metric {distance_metric!r}")
         self.bcast_ms = None
         self._h = ctypes.c_void_p()
+        from . import common as _common
+        if _common.is_sparse(sc) or (st is not None and _common.is_sparse(st)):
+            self._create_from_mixed(sc, st, already_normalized, device_id, METRICS[distance_metric], comm, root, n_spots)
+            return
         if comm is None:
             sc, st, is64 = _pair(sc, st)
             self.G, self.C = sc.shape
@@ -115,6 +119,44 @@ class ExpressionContext:
                                                      comm.handle, int(root), comm.rank, device_id, ctypes.byref(self._h),
                                                      ctypes.byref(ms)))
         self.bcast_ms = ms.value
+
+    def _create_from_mixed(self, sc, st, already_normalized, device_id, metric, comm, root, n_spots):
+        """Inputs of which at least one is a scipy.sparse matrix: sparse ones are uploaded as non-zeros and expanded on the
+        device (cyto_csc_to_dense_f32), dense ones go up as they are (C ABI: cyto_ctx_create_ex)."""
+        from . import common as _common
+        keep = []
+
+        def describe(x):
+            m = _lib.Matrix()
+            if _common.is_sparse(x):
+                buf, G, C, ld = _common.sparse_to_device(x, device_id)
+                keep.append(buf)
+                m.data, m.ld, m.is_f64, m.on_device = buf.ptr, ld, 0, 1
+                return m, G, C
+            a = np.asarray(x)
+            a = np.ascontiguousarray(a, dtype=np.float32 if a.dtype == np.float32 else np.float64)
+            keep.append(a)
+            m.data, m.ld, m.is_f64, m.on_device = a.ctypes.data, a.shape[1], int(a.dtype == np.float64), 0
+            return m, a.shape[0], a.shape[1]
+        msc, self.G, self.C = describe(sc)
+        mst = None
+        if st is not None:
+            mst, Gs, self.S = describe(st)
+            if Gs != self.G:
+                raise ValueError("The two matrices v1 and v2 must have equal dimensions; "
+                                 "ST and scRNA data must have the same genes")
+        else:
+            if comm is None or n_spots is None:
+                raise ValueError("the ST matrix (or, on non-root ranks of a communicator, n_spots) is required")
+            self.S = int(n_spots)
+        ms = ctypes.c_double()
+        _lib.check(_lib.lib().cyto_ctx_create_ex(metric, self.G, ctypes.byref(msc), self.C, ctypes.byref(mst) if mst is not None else None,
+                                                 self.S, int(already_normalized), comm.handle if comm is not None else None, int(root),
+                                                 comm.rank if comm is not None else 0, device_id, ctypes.byref(self._h), ctypes.byref(ms)))
+        self.bcast_ms = ms.value if comm is not None else None
+        for k in keep:
+            if isinstance(k, _lib.DeviceBuffer):
+                k.free()
 
     def assign_chunks(self, chunks, max_concurrent=0, return_info=False):
         """All chunks of this rank in one call (C ABI: cyto_ctx_assign_chunks): per chunk the gathers and the cost GEMM, then

@@ -212,6 +212,24 @@ void cyto_ctx_destroy(cyto_expr_ctx *ctx);
 int cyto_ctx_create_shared(int metric, int G, int C, int S, const void *sc, const void *st, int x_is_f64, int already_normalized,
                            void *comm, int root, int rank, int device_id, cyto_expr_ctx **out, double *bcast_ms);
 
+/* The general form: each matrix is a dense genes x columns array on the host or ALREADY ON THE DEVICE (e.g. expanded from sparse
+ * counts by cyto_csc_to_dense_f32), float32 or float64, with its own leading dimension.  comm == NULL: no broadcast. */
+typedef struct {
+    const void *data;
+    int64_t ld;              /* elements per row (>= number of columns) */
+    int32_t is_f64;          /* 1: float64, 0: float32 */
+    int32_t on_device;       /* 1: device pointer */
+} cyto_matrix;
+int cyto_ctx_create_ex(int metric, int G, const cyto_matrix *sc, int C, const cyto_matrix *st, int S, int already_normalized,
+                       void *comm, int root, int rank, int device_id, cyto_expr_ctx **out, double *bcast_ms);
+
+/* SURVEY 8(f) rank 2, device-side staging: sparse counts as the reference reads them from a 10x MatrixMarket file
+ * (scipy.io.mmread, cytospace/common/common.py:49; CSC: colptr[C + 1], rowidx[nnz], vals[nnz], host arrays) are uploaded as
+ * non-zeros and expanded into the dense float32 G x ld DEVICE matrix the transforms read (zero filled here).  The reference
+ * densifies on the host (common.py:57).  CYTO_ERR_BAD_ARG: malformed colptr or a row index outside [0, G). */
+int cyto_csc_to_dense_f32(int G, int C, int64_t nnz, const int64_t *colptr, const int32_t *rowidx, const float *vals,
+                          float *dense_dev, int64_t ld, int device_id, void *stream);
+
 /* Every chunk of a rank in one call: per chunk the column gathers and the cost GEMM, then ALL the chunks' LAPs together (a
  * workgroup per chunk in every chain phase: cyto_lap_batch_f32).  Fields as cyto_ctx_assign_chunk's arguments; status, total_cost
  * and info are outputs.  max_concurrent bounds the chunks whose cost matrices exist at once (<= 0: min(nchunks, 64)). */

@@ -214,3 +214,41 @@ def test_gv12_output_files_equal_the_references(method, single, tmp_path):
         return b"\n".join(l for l in b.split(b"\n") if not (name.endswith(".mtx") and l.startswith(b"%") and not l.startswith(b"%%")))
     for name in want:
         assert norm(name, got[name]) == norm(name, want[name]), name
+
+
+def test_gv13_downsample_equals_the_references():
+    # cytospace/common/common.py:149-173 (legacy RandomState draws): same seed, same counts as the reference produced
+    import pandas as pd
+    from cytospace_amd.common import downsample
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gv13_downsample.npz"))
+    df = pd.DataFrame(d["counts"], index=[f"GENE_{i}" for i in range(40)], columns=[f"CELL_{i}" for i in range(9)])
+    np.random.seed(int(d["seed"]))
+    out = downsample(df, int(d["target"]))
+    assert np.array_equal(out.to_numpy(), d["out"])
+    assert list(out.index) == list(df.index) and list(out.columns) == list(df.columns)
+
+
+def test_read_file_matrix_market_and_tables(tmp_path):
+    # cytospace/common/common.py:16-82: 10x-style directory (matrix.mtx + genes.tsv + barcodes.tsv) and delimited tables
+    import pandas as pd
+    import scipy.io
+    import scipy.sparse as sp
+    from cytospace_amd.common import read_file
+    rng = np.random.default_rng(2)
+    m = sp.random(12, 7, density=0.3, random_state=3, data_rvs=lambda k: rng.integers(1, 9, k)).tocoo()
+    scipy.io.mmwrite(str(tmp_path / "matrix.mtx"), m)
+    pd.Series([f"g{i}" for i in range(12)]).to_csv(tmp_path / "genes.tsv", sep="\t", header=False, index=False)
+    pd.Series([f"c{i}" for i in range(7)]).to_csv(tmp_path / "barcodes.tsv", sep="\t", header=False, index=False)
+    df = read_file(str(tmp_path / "matrix.mtx"))
+    assert df.shape == (12, 7) and list(df.index[:2]) == ["g0", "g1"] and list(df.columns[:2]) == ["c0", "c1"]
+    assert np.array_equal(df.sparse.to_coo().toarray(), m.toarray())
+    dense = read_file(str(tmp_path / "matrix.mtx"), keep_sparse=False)
+    assert np.array_equal(dense.to_numpy(), m.toarray())
+    t = pd.DataFrame(m.toarray(), index=[f"g{i}" for i in range(12)], columns=[f"c{i}" for i in range(7)])
+    t.to_csv(tmp_path / "t.csv")
+    t.to_csv(tmp_path / "t.txt", sep="\t")
+    for name in ("t.csv", "t.txt"):
+        back = read_file(str(tmp_path / name))
+        assert np.array_equal(back.to_numpy(), m.toarray()) and list(back.index) == list(t.index)
+    with pytest.raises(IOError):
+        read_file(str(tmp_path / "missing" / "matrix.mtx"))

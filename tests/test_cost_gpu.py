@@ -244,6 +244,31 @@ def test_spearman_ranks_many_genes(G):
     np.testing.assert_array_equal(ocost.rank_columns(x), pd.DataFrame(x).rank().to_numpy())
 
 
+def test_sparse_counts_are_expanded_on_the_device():
+    # sparse inputs (scipy.sparse, what scipy.io.mmread of a 10x matrix holds) go up as non-zeros and are
+    # expanded by cyto_csc_to_dense_f32; same assignments as the dense upload (raw counts, normalised on the device)
+    import scipy.sparse as sp
+    from cytospace_amd import _lib
+    d, idx_sc = _gv11_ss()
+    sc, st = d["ss_counts"].astype(np.float32), d["ss_st_counts"].astype(np.float32)
+    subs = list(d["ss_sub"])
+    chunks = [(ix, subs[k]) for k, ix in enumerate(idx_sc)]
+    with gcyto.ExpressionContext(sc, st, False, 0) as dense:
+        want = dense.assign_chunks(chunks)
+    for a, b in ((sp.coo_matrix(sc), sp.csr_matrix(st)), (sp.csc_matrix(sc), st)):
+        with gcyto.ExpressionContext(a, b, False, 0) as ctx:
+            got = ctx.assign_chunks(chunks)
+        assert all(np.array_equal(x, y) for x, y in zip(got, want))
+    buf, G, C, ld = gcommon.sparse_to_device(sp.csr_matrix(sc))
+    assert np.array_equal(buf.to_numpy((G, ld), np.float32)[:, :C], sc)
+    buf.free()
+    bad = sp.csc_matrix(sc)
+    bad.indices = bad.indices.copy()
+    bad.indices[0] = G + 5                                     # a row index outside the matrix: ValueError, not a wild write
+    with pytest.raises(ValueError):
+        gcommon.sparse_to_device(bad)
+
+
 def _gv11_ss():
     d = load("gv11_apply_linear_assignment.npz")
     idx_sc = np.split(d["ss_idx_sc"], np.cumsum(d["ss_idx_sc_lens"])[:-1])
