@@ -95,7 +95,7 @@ def test_gv8_duplicate_rows_spot_level():
     assert abs(r["total"] - float(d["dup_total"])) <= 1e-5
 
 
-@pytest.mark.parametrize("n", [5, 33, 128, 500, 1200])
+@pytest.mark.parametrize("n", [5, 33, 128, 500, 1200, 5000])
 def test_jv_oracle_vs_scipy_random(n):
     c = np.random.default_rng(1000 + n).random((n, n)).astype(np.float32)
     r = jv_oracle(c, np.float32)

@@ -1,15 +1,14 @@
 """Config c4 shape on ONE GPU: C cells x S spots in --sampling-sub-spots chunks of `chunk` cells; the
-matrices are uploaded/transformed once (ExpressionContext), chunks are solved side by side.
+matrices are uploaded/transformed once (ExpressionContext), all chunks go through the solver together (a workgroup per chunk).
 Usage: c4_chunks.py [G C S chunk concurrent]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from concurrent.futures import ThreadPoolExecutor
 from c3_pipeline import synth
 from cytospace_amd.cytospace import ExpressionContext, partition_indices
 
-G, C, S, chunk, conc = (int(x) for x in sys.argv[1:6]) if len(sys.argv) > 5 else (5000, 200000, 50000, 10000, 8)
+G, C, S, chunk, conc = (int(x) for x in sys.argv[1:6]) if len(sys.argv) > 5 else (5000, 200000, 50000, 10000, 64)
 t = time.time(); sc, st, slots = synth(G, C, S); print(f"synthetic G={G} C={C} S={S} in {time.time()-t:.1f}s", flush=True)
 sc = sc.astype(np.float64); st = st.astype(np.float64)
 index_sc = partition_indices(np.arange(C), split_by_interval_int=chunk, shuffle=False)
@@ -20,8 +19,7 @@ sub = [np.bincount(slot_ids[ix], minlength=S) for ix in index_sc]
 t0 = time.time()
 with ExpressionContext(sc, st, already_normalized=False) as ctx:
     t1 = time.time()
-    with ThreadPoolExecutor(conc) as ex:
-        res = list(ex.map(lambda k: ctx.assign_chunk(index_sc[k], sub[k], return_info=True), range(len(index_sc))))
+    res = ctx.assign_chunks([(index_sc[k], sub[k]) for k in range(len(index_sc))], max_concurrent=conc, return_info=True)
     t2 = time.time()
 ok = all(np.array_equal(np.bincount(m, minlength=S), s_) for (m, _, _), s_ in zip(res, sub))
 lap_ms = [i.lap.ms_total for _, _, i in res]; gemm_ms = [i.ms_gemm for _, _, i in res]; gath = [i.ms_standardize for _, _, i in res]
