@@ -95,6 +95,9 @@ def lib():
             getattr(L, name).argtypes = [i32, vp, i64, i32, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(LapInfo), i32, vp, ctypes.POINTER(LapOpts)]
             getattr(L, name).restype = ctypes.c_int
+        L.cyto_lap_f32_rowmap.argtypes = [i32, vp, i64, i32, i32, vp, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_double),
+                                          ctypes.POINTER(LapInfo), i32, vp, ctypes.POINTER(LapOpts)]
+        L.cyto_lap_f32_rowmap.restype = ctypes.c_int
         L.cyto_trim_device_cache.argtypes = [i32]
         L.cyto_trim_device_cache.restype = ctypes.c_int
         dp = ctypes.POINTER(ctypes.c_double)

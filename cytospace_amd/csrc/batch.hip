@@ -11,21 +11,18 @@
 #include <map>
 #include <vector>
 
-extern "C" {
+namespace cyto {
 
-// Solve nb independent LAPs.  Arrays of per-problem pointers/sizes; outputs may be NULL like in
-// cyto_lap_f32.  Problems of equal size share their launches; max_concurrent bounds how many are in flight at once (each
-// holds its workspace, ~2.6 KB per row): <= 0 picks min(nb, 256), one chain per CU.  Returns the first non-zero status (all
-// problems are attempted); status_out[b] (optional) receives each problem's status.
-int cyto_lap_batch_f32(int nb, const int *n, const float *const *cost, const int64_t *ld, int cost_on_device,
-                       int32_t *const *rowsol, int32_t *const *colsol, float *const *u, float *const *v, double *total,
-                       cyto_lap_info *info, int *status_out, int max_concurrent, int device_id) {
+// cyto_lap_batch_f32 with optional row maps (rowmap[b] != NULL: cost[b] holds nu[b] distinct rows, see cyto_lap_f32_rowmap)
+int lap_batch_any(int nb, const int *n, const float *const *cost, const int64_t *ld, int cost_on_device,
+                  const int32_t *const *rowmap, const int *nu, int32_t *const *rowsol, int32_t *const *colsol, float *const *u,
+                  float *const *v, double *total, cyto_lap_info *info, int *status_out, int max_concurrent, int device_id) {
     if (nb < 0 || (nb > 0 && (!n || !cost || !ld))) return CYTO_ERR_BAD_ARG;
     if (nb == 0) return CYTO_OK;
-    int rc = cyto::select_device(device_id);
+    int rc = select_device(device_id);
     if (rc) return rc;
     const int conc = std::max(1, std::min(nb, max_concurrent > 0 ? max_concurrent : 256));
-    cyto::StreamGuard guard;
+    StreamGuard guard;
     CYTO_HIP(hipStreamCreateWithFlags(&guard.s, hipStreamNonBlocking));
     guard.own = true;
     std::vector<int> st((size_t)nb, CYTO_OK);
@@ -44,15 +41,17 @@ int cyto_lap_batch_f32(int nb, const int *n, const float *const *cost, const int
             std::vector<float *> uu((size_t)cnt), vv((size_t)cnt);
             std::vector<double> tot((size_t)cnt);
             std::vector<cyto_lap_info> inf((size_t)cnt);
-            std::vector<int> stat((size_t)cnt, CYTO_OK);
+            std::vector<int> stat((size_t)cnt, CYTO_OK), nus((size_t)cnt, 0);
+            std::vector<const int32_t *> rm((size_t)cnt, nullptr);
             for (int k = 0; k < cnt; k++) {
                 const int b = ids[lo + (size_t)k];
                 c[(size_t)k] = cost[b]; l[(size_t)k] = ld[b];
                 rs[(size_t)k] = rowsol ? rowsol[b] : nullptr; cs[(size_t)k] = colsol ? colsol[b] : nullptr;
                 uu[(size_t)k] = u ? u[b] : nullptr; vv[(size_t)k] = v ? v[b] : nullptr;
+                if (rowmap && rowmap[b]) { rm[(size_t)k] = rowmap[b]; nus[(size_t)k] = nu ? nu[b] : 0; }
             }
-            const int brc = cyto::lap_batch_same_n(kv.first, cnt, c.data(), l.data(), cost_on_device, rs.data(), cs.data(), uu.data(), vv.data(),
-                                                   tot.data(), inf.data(), stat.data(), device_id, guard.s);
+            const int brc = lap_batch_same_n(kv.first, cnt, c.data(), l.data(), cost_on_device, rs.data(), cs.data(), uu.data(), vv.data(),
+                                             tot.data(), inf.data(), stat.data(), device_id, guard.s, rm.data(), nus.data());
             for (int k = 0; k < cnt; k++) {
                 const int b = ids[lo + (size_t)k];
                 st[(size_t)b] = brc ? brc : stat[(size_t)k];
@@ -67,6 +66,21 @@ int cyto_lap_batch_f32(int nb, const int *n, const float *const *cost, const int
         if (!first && st[(size_t)b]) first = st[(size_t)b];
     }
     return first;
+}
+
+}  // namespace cyto
+
+extern "C" {
+
+// Solve nb independent LAPs.  Arrays of per-problem pointers/sizes; outputs may be NULL like in
+// cyto_lap_f32.  Problems of equal size share their launches; max_concurrent bounds how many are in flight at once (each
+// holds its workspace, ~2.6 KB per row): <= 0 picks min(nb, 256), one chain per CU.  Returns the first non-zero status (all
+// problems are attempted); status_out[b] (optional) receives each problem's status.
+int cyto_lap_batch_f32(int nb, const int *n, const float *const *cost, const int64_t *ld, int cost_on_device,
+                       int32_t *const *rowsol, int32_t *const *colsol, float *const *u, float *const *v, double *total,
+                       cyto_lap_info *info, int *status_out, int max_concurrent, int device_id) {
+    return cyto::lap_batch_any(nb, n, cost, ld, cost_on_device, nullptr, nullptr, rowsol, colsol, u, v, total, info, status_out,
+                               max_concurrent, device_id);
 }
 
 // ---- RCCL (xGMI): the only collective on the path is the broadcast of the shared standardised ST

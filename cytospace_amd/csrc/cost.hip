@@ -590,9 +590,17 @@ int cyto_assign_metric_typed(int metric, int G, int C, int S, const void *sc, co
     Events<2> ev;
     if ((rc = ev.create())) return rc;
     const hipEvent_t e0 = ev[0], e1 = ev[1];
+    // Row indirection: the cost holds ONE row per spot (S x C); LAP row i reads the row of its spot through rowspot[]
+    // (calculate_cost materialises the repeats: linear_assignment_solvers.py:63-66 -- 10 GB instead of 1 GB at config c3).
+    std::vector<int32_t> rowspot((size_t)N);
+    {
+        int64_t r = 0;
+        for (int s = 0; s < S; s++) for (int64_t k = 0; k < slots[s]; k++) rowspot[(size_t)r++] = s;
+    }
+    std::vector<int64_t> ones((size_t)S, 1);
     DevBuf zst, zsc, cost;
     if ((rc = zst.alloc((size_t)Gpad * ldzst * 4, stream)) || (rc = zsc.alloc((size_t)Gpad * ldzsc * 4, stream)) ||
-        (rc = cost.alloc((size_t)N * ldc * 4, stream)))
+        (rc = cost.alloc((size_t)S * ldc * 4, stream)))
         return rc;
     CYTO_HIP(hipEventRecord(e0, stream));
     if ((rc = cyto_transform(transform, G, S, st, S, x_is_f64, 0, already_normalized, zst.as<float>(), ldzst, Gpad, device_id, stream))) return rc;
@@ -602,20 +610,19 @@ int cyto_assign_metric_typed(int metric, int G, int C, int S, const void *sc, co
     float ms_std = 0;
     (void)hipEventElapsedTime(&ms_std, e0, e1);
     double ms_gemm = 0;
-    if ((rc = cyto_cost_metric(metric, Gpad, S, C, zst.as<float>(), ldzst, zsc.as<float>(), ldzsc, slots, cost.as<float>(), ldc,
+    if ((rc = cyto_cost_metric(metric, Gpad, S, C, zst.as<float>(), ldzst, zsc.as<float>(), ldzsc, ones.data(), cost.as<float>(), ldc,
                                &ms_gemm, device_id, stream)))
         return rc;
     std::vector<int32_t> colsol((size_t)N);
     cyto_lap_info li;
     double total = 0;
-    if ((rc = cyto_lap_f32((int)N, cost.as<float>(), ldc, 1, nullptr, colsol.data(), nullptr, nullptr, &total, &li, device_id, stream)))
-        return rc;
+    bool identity = N == S;                              // every spot takes exactly one cell: row i IS spot i
+    for (int s = 0; s < S && identity; s++) identity = slots[s] == 1;
+    rc = identity ? cyto_lap_f32((int)N, cost.as<float>(), ldc, 1, nullptr, colsol.data(), nullptr, nullptr, &total, &li, device_id, stream)
+                  : cyto_lap_f32_rowmap((int)N, cost.as<float>(), ldc, S, 1, rowspot.data(), nullptr, colsol.data(), nullptr, nullptr, &total,
+                                        &li, device_id, stream, nullptr);
+    if (rc) return rc;
     // location_repeat[y] (cytospace.py:331): LAP row -> spot
-    std::vector<int32_t> rowspot((size_t)N);
-    {
-        int64_t r = 0;
-        for (int s = 0; s < S; s++) for (int64_t k = 0; k < slots[s]; k++) rowspot[(size_t)r++] = s;
-    }
     for (int64_t c = 0; c < C; c++) mapped_spot[c] = rowspot[(size_t)colsol[(size_t)c]];
     if (total_cost) *total_cost = total;
     if (info) {
@@ -739,80 +746,17 @@ void cyto_ctx_destroy(cyto_expr_ctx *ctx) {
 // listed spot; sum(slots) must be n_sc.  mapped_spot[c] = position in the chunk's spot list (what the reference's
 // solve_linear_assignment_problem returns for the chunk, cytospace.py:331-332).  Spots with slots == 0 are not
 // contracted at all.  Thread-safe on one context (private stream and buffers per call).
+int cyto_ctx_assign_chunks(cyto_expr_ctx *ctx, int nchunks, cyto_chunk *chunks, int max_concurrent);
 int cyto_ctx_assign_chunk(cyto_expr_ctx *ctx, const int64_t *idx_sc, int n_sc, const int64_t *idx_st, int n_st,
                           const int64_t *slots, int64_t *mapped_spot, double *total_cost, cyto_assign_info *info) {
     if (!ctx || !idx_sc || n_sc <= 0 || !slots || !mapped_spot) return CYTO_ERR_BAD_ARG;
-    const int nst = idx_st ? n_st : ctx->S;
-    if (nst <= 0) return CYTO_ERR_BAD_ARG;
-    int rc = select_device(ctx->device_id);
-    if (rc) return rc;
-    // the spots that actually receive cells
-    std::vector<int32_t> h_st, h_pos, h_sc((size_t)n_sc);
-    std::vector<int64_t> h_slots;
-    int64_t N = 0;
-    for (int k = 0; k < nst; k++) {
-        if (slots[k] < 0) return CYTO_ERR_BAD_ARG;
-        const int64_t s = idx_st ? idx_st[k] : k;
-        if (s < 0 || s >= ctx->S) return CYTO_ERR_BAD_ARG;
-        if (slots[k] > 0) { h_st.push_back((int32_t)s); h_pos.push_back(k); h_slots.push_back(slots[k]); N += slots[k]; }
-    }
-    if (N != n_sc) return CYTO_ERR_BAD_ARG;                 // the LAP must be square
-    for (int c = 0; c < n_sc; c++) {
-        if (idx_sc[c] < 0 || idx_sc[c] >= ctx->C) return CYTO_ERR_BAD_ARG;
-        h_sc[(size_t)c] = (int32_t)idx_sc[c];
-    }
-    const int Su = (int)h_st.size();
-    const int64_t ldzst = round_up(Su, BM), ldzsc = round_up(n_sc, BN), ldc = round_up(n_sc, 4);
-    StreamGuard guard;
-    CYTO_HIP(hipStreamCreateWithFlags(&guard.s, hipStreamNonBlocking));
-    guard.own = true;
-    const hipStream_t stream = guard.s;
-    Events<2> ev;
-    if ((rc = ev.create())) return rc;
-    const hipEvent_t e0 = ev[0], e1 = ev[1];
-    DevBuf zst, zsc, cost, dsc, dst;
-    if ((rc = zst.alloc((size_t)ctx->Gpad * ldzst * 4, stream)) || (rc = zsc.alloc((size_t)ctx->Gpad * ldzsc * 4, stream)) ||
-        (rc = cost.alloc((size_t)N * ldc * 4, stream)) || (rc = dsc.alloc((size_t)n_sc * 4, stream)) || (rc = dst.alloc((size_t)Su * 4, stream)))
-        return rc;
-    CYTO_HIP(hipEventRecord(e0, stream));
-    CYTO_HIP(hipMemcpyAsync(dsc.p, h_sc.data(), (size_t)n_sc * 4, hipMemcpyHostToDevice, stream));
-    CYTO_HIP(hipMemcpyAsync(dst.p, h_st.data(), (size_t)Su * 4, hipMemcpyHostToDevice, stream));
-    CYTO_HIP(hipMemsetAsync(zst.p, 0, (size_t)ctx->Gpad * ldzst * 4, stream));
-    CYTO_HIP(hipMemsetAsync(zsc.p, 0, (size_t)ctx->Gpad * ldzsc * 4, stream));
-    const int nblk = (ctx->Gpad + GB - 1) / GB;
-    hipLaunchKernelGGL(gather_columns, dim3((Su + 255) / 256, nblk), dim3(256), 0, stream, ctx->Gpad, Su, ctx->zst.as<float>(),
-                       ctx->ldst, dst.as<int32_t>(), zst.as<float>(), ldzst);
-    hipLaunchKernelGGL(gather_columns, dim3((n_sc + 255) / 256, nblk), dim3(256), 0, stream, ctx->Gpad, n_sc, ctx->zsc.as<float>(),
-                       ctx->ldsc, dsc.as<int32_t>(), zsc.as<float>(), ldzsc);
-    CYTO_HIP(hipGetLastError());
-    CYTO_HIP(hipEventRecord(e1, stream));
-    CYTO_HIP(hipEventSynchronize(e1));
-    float ms_gather = 0;
-    (void)hipEventElapsedTime(&ms_gather, e0, e1);
-    double ms_gemm = 0;
-    if ((rc = cyto_cost_metric(ctx->metric, ctx->Gpad, Su, n_sc, zst.as<float>(), ldzst, zsc.as<float>(), ldzsc, h_slots.data(),
-                               cost.as<float>(), ldc, &ms_gemm, ctx->device_id, stream)))
-        return rc;
-    std::vector<int32_t> colsol((size_t)N);
-    cyto_lap_info li;
-    double total = 0;
-    if ((rc = cyto_lap_f32((int)N, cost.as<float>(), ldc, 1, nullptr, colsol.data(), nullptr, nullptr, &total, &li, ctx->device_id, stream)))
-        return rc;
-    std::vector<int32_t> rowpos((size_t)N);
-    {
-        int64_t r = 0;
-        for (int k = 0; k < Su; k++) for (int64_t t = 0; t < h_slots[(size_t)k]; t++) rowpos[(size_t)r++] = h_pos[(size_t)k];
-    }
-    for (int c = 0; c < n_sc; c++) mapped_spot[c] = rowpos[(size_t)colsol[(size_t)c]];
-    if (total_cost) *total_cost = total;
-    if (info) {
-        memset(info, 0, sizeof *info);
-        info->ms_standardize = ms_gather;     // here: the two column gathers (the transforms ran once, in cyto_ctx_create)
-        info->ms_gemm = ms_gemm;
-        info->lap = li;
-        info->gemm_flops = 2.0 * ctx->Gpad * (double)Su * (double)n_sc;
-    }
-    return CYTO_OK;
+    cyto_chunk ch;
+    memset(&ch, 0, sizeof ch);
+    ch.idx_sc = idx_sc; ch.n_sc = n_sc; ch.idx_st = idx_st; ch.n_st = n_st; ch.slots = slots; ch.mapped_spot = mapped_spot;
+    const int rc = cyto_ctx_assign_chunks(ctx, 1, &ch, 1);       // a batch of one (thread-safe: private stream and buffers per call)
+    if (total_cost) *total_cost = ch.total_cost;
+    if (info) *info = ch.info;
+    return rc ? rc : ch.status;
 }
 
 // Every chunk of this rank in ONE call: per chunk the two column gathers and the cost GEMM (back to back on one stream,
@@ -835,8 +779,10 @@ int cyto_ctx_assign_chunks(cyto_expr_ctx *ctx, int nchunks, cyto_chunk *chunks, 
         std::vector<int32_t> h_st, h_pos, h_sc;
         std::vector<int64_t> h_slots;
         int64_t N = 0; int Su = 0; int64_t ldc = 0;
-        DevBuf cost;
-        std::vector<int32_t> colsol;
+        DevBuf cost;                                  // one row per spot that receives cells (Su x ldc)
+        std::vector<int32_t> colsol, rowpos_u;        // rowpos_u[i] = stored row (= index into h_st) of LAP row i
+        std::vector<int64_t> ones;
+        bool identity = true;
         float ms_gather = 0, ms_gemm = 0;
     };
     int first = CYTO_OK;
@@ -875,7 +821,16 @@ int cyto_ctx_assign_chunks(cyto_expr_ctx *ctx, int nchunks, cyto_chunk *chunks, 
             if (need_sc > cap_sc) { CYTO_HIP(hipStreamSynchronize(stream)); if ((rc = zsc.alloc(need_sc, stream))) return rc; cap_sc = need_sc; }
             if ((size_t)n_sc * 4 > cap_isc) { CYTO_HIP(hipStreamSynchronize(stream)); if ((rc = dsc.alloc((size_t)n_sc * 4, stream))) return rc; cap_isc = (size_t)n_sc * 4; }
             if ((size_t)p.Su * 4 > cap_ist) { CYTO_HIP(hipStreamSynchronize(stream)); if ((rc = dst.alloc((size_t)p.Su * 4, stream))) return rc; cap_ist = (size_t)p.Su * 4; }
-            if ((rc = p.cost.alloc((size_t)p.N * p.ldc * 4, stream))) return rc;
+            if ((rc = p.cost.alloc((size_t)p.Su * p.ldc * 4, stream))) return rc;
+            p.ones.assign((size_t)p.Su, 1);
+            p.rowpos_u.resize((size_t)p.N);
+            {
+                int64_t r = 0;
+                for (int t = 0; t < p.Su; t++) {
+                    p.identity = p.identity && p.h_slots[(size_t)t] == 1;
+                    for (int64_t e = 0; e < p.h_slots[(size_t)t]; e++) p.rowpos_u[(size_t)r++] = t;
+                }
+            }
             CYTO_HIP(hipEventRecord(ev[0], stream));
             CYTO_HIP(hipMemcpyAsync(dsc.p, p.h_sc.data(), (size_t)n_sc * 4, hipMemcpyHostToDevice, stream));
             CYTO_HIP(hipMemcpyAsync(dst.p, p.h_st.data(), (size_t)p.Su * 4, hipMemcpyHostToDevice, stream));
@@ -890,7 +845,7 @@ int cyto_ctx_assign_chunks(cyto_expr_ctx *ctx, int nchunks, cyto_chunk *chunks, 
             CYTO_HIP(hipEventRecord(ev[1], stream));
             double ms_gemm = 0;
             // (cost_gemm synchronises the stream: the host index vectors and the operands are free again afterwards)
-            if ((rc = cyto_cost_metric(ctx->metric, ctx->Gpad, p.Su, n_sc, zst.as<float>(), ldzst, zsc.as<float>(), ldzsc, p.h_slots.data(),
+            if ((rc = cyto_cost_metric(ctx->metric, ctx->Gpad, p.Su, n_sc, zst.as<float>(), ldzst, zsc.as<float>(), ldzsc, p.ones.data(),
                                        p.cost.as<float>(), p.ldc, &ms_gemm, ctx->device_id, stream)))
                 return rc;
             (void)hipEventElapsedTime(&p.ms_gather, ev[0], ev[1]);
@@ -902,7 +857,8 @@ int cyto_ctx_assign_chunks(cyto_expr_ctx *ctx, int nchunks, cyto_chunk *chunks, 
         for (int k = 0; k < cnt; k++) if (chunks[lo + k].status == CYTO_OK) ids.push_back(k);
         const int nl = (int)ids.size();
         if (nl) {
-            std::vector<int> nn((size_t)nl), stat((size_t)nl, CYTO_OK);
+            std::vector<int> nn((size_t)nl), stat((size_t)nl, CYTO_OK), nus((size_t)nl, 0);
+            std::vector<const int32_t *> rmaps((size_t)nl, nullptr);
             std::vector<const float *> cst((size_t)nl);
             std::vector<int64_t> lds_((size_t)nl);
             std::vector<int32_t *> cs((size_t)nl);
@@ -911,9 +867,10 @@ int cyto_ctx_assign_chunks(cyto_expr_ctx *ctx, int nchunks, cyto_chunk *chunks, 
             for (int q = 0; q < nl; q++) {
                 Prep &p = pp[(size_t)ids[(size_t)q]];
                 nn[(size_t)q] = (int)p.N; cst[(size_t)q] = p.cost.as<float>(); lds_[(size_t)q] = p.ldc; cs[(size_t)q] = p.colsol.data();
+                if (!p.identity) { rmaps[(size_t)q] = p.rowpos_u.data(); nus[(size_t)q] = p.Su; }
             }
-            (void)cyto_lap_batch_f32(nl, nn.data(), cst.data(), lds_.data(), 1, nullptr, cs.data(), nullptr, nullptr, tot.data(), li.data(),
-                                     stat.data(), nl, ctx->device_id);
+            (void)lap_batch_any(nl, nn.data(), cst.data(), lds_.data(), 1, rmaps.data(), nus.data(), nullptr, cs.data(), nullptr, nullptr,
+                                tot.data(), li.data(), stat.data(), nl, ctx->device_id);
             for (int q = 0; q < nl; q++) {
                 const int k = ids[(size_t)q];
                 cyto_chunk &ch = chunks[lo + k];
@@ -921,10 +878,7 @@ int cyto_ctx_assign_chunks(cyto_expr_ctx *ctx, int nchunks, cyto_chunk *chunks, 
                 ch.status = stat[(size_t)q];
                 if (ch.status != CYTO_OK) continue;
                 // location_repeat[y] (cytospace.py:331): LAP row -> position in the chunk's spot list
-                std::vector<int32_t> rowpos((size_t)p.N);
-                int64_t r = 0;
-                for (int t = 0; t < p.Su; t++) for (int64_t e = 0; e < p.h_slots[(size_t)t]; e++) rowpos[(size_t)r++] = p.h_pos[(size_t)t];
-                for (int c = 0; c < ch.n_sc; c++) ch.mapped_spot[c] = rowpos[(size_t)p.colsol[(size_t)c]];
+                for (int c = 0; c < ch.n_sc; c++) ch.mapped_spot[c] = p.h_pos[(size_t)p.rowpos_u[(size_t)p.colsol[(size_t)c]]];
                 ch.total_cost = tot[(size_t)q];
                 ch.info.ms_standardize = p.ms_gather;     // here: the two column gathers (the transforms ran once, at context creation)
                 ch.info.ms_gemm = p.ms_gemm;

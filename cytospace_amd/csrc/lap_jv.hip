@@ -44,6 +44,15 @@ template <typename T> struct VecOf;
 template <> struct VecOf<float> { using type = float4; static constexpr int W = 4; };
 template <> struct VecOf<double> { using type = double2; static constexpr int W = 2; };
 
+// Row indirection (first half): CytoSPACE repeats every spot row slots[s] times
+// (linear_assignment_solvers.py:63-66).  With a row map the cost holds every DISTINCT row once (S_u x C) and LAP row i reads
+// row rowmap[i]; without one (nullptr) row i is row i.  RBASE gives callees that compute `base + i * ld` themselves a base that
+// lands on the mapped row.
+__device__ __forceinline__ int64_t row_off(const int32_t *__restrict__ rowmap, int i, int64_t ld) {
+    return (int64_t)(rowmap ? rowmap[i] : i) * ld;
+}
+#define RBASE(cost_, rowmap_, i_, ld_) ((cost_) + (row_off((rowmap_), (i_), (ld_)) - (int64_t)(i_) * (ld_)))
+
 template <typename T> __device__ __forceinline__ T vec_get(const typename VecOf<T>::type &x, int e);
 template <> __device__ __forceinline__ float vec_get<float>(const float4 &x, int e) {
     return e == 0 ? x.x : e == 1 ? x.y : e == 2 ? x.z : x.w;
@@ -62,32 +71,36 @@ __device__ __forceinline__ bool memcmp_neq(double a, double b) { return __double
 template <typename T>
 __global__ __launch_bounds__(256) void colred_partial(int n, int64_t ld, const T *__restrict__ cost,
                                                       int rows_per_block, T *__restrict__ pmin,
-                                                      int32_t *__restrict__ parg, int *__restrict__ nonfinite) {
+                                                      int32_t *__restrict__ parg, int *__restrict__ nonfinite,
+                                                      int nrows, const int32_t *__restrict__ ulist,
+                                                      const int32_t *__restrict__ ufirst) {
+    // nrows rows are swept (n without a row map).  With one: the k-th DISTINCT row that is in use is row ulist[k] of the
+    // cost and stands for the LAP rows starting at ufirst[k] (ascending in k) -- the lowest of them is what a tie keeps.
     using V = typename VecOf<T>::type;
     constexpr int VW = VecOf<T>::W;
     const int q = blockIdx.x * 256 + threadIdx.x;  // vector-column index
     const int col0 = q * VW;
     const int r0 = blockIdx.y * rows_per_block;
-    const int r1 = min(n, r0 + rows_per_block);
+    const int r1 = min(nrows, r0 + rows_per_block);
     if (col0 >= n) return;
     T mn[VW];
     int32_t arg[VW];
     bool bad = false;
 #pragma unroll
-    for (int e = 0; e < VW; e++) { mn[e] = (T)INFINITY; arg[e] = r0; }
-    const V *p = reinterpret_cast<const V *>(cost + (int64_t)r0 * ld) + q;
+    for (int e = 0; e < VW; e++) { mn[e] = (T)INFINITY; arg[e] = ufirst ? ufirst[min(r0, nrows - 1)] : r0; }
     const int64_t stride = ld / VW;
 #pragma unroll 4
     for (int r = r0; r < r1; r++) {
-        const V x = *p;
-        p += stride;
+        const V x = *(reinterpret_cast<const V *>(cost + (int64_t)(ulist ? ulist[r] : r) * ld) + q);
+        const int32_t rid = ufirst ? ufirst[r] : r;
 #pragma unroll
         for (int e = 0; e < VW; e++) {
             const T xe = vec_get<T>(x, e);
             if (col0 + e < n) bad |= !__builtin_isfinite(xe);
-            if (xe < mn[e]) { mn[e] = xe; arg[e] = r; }
+            if (xe < mn[e]) { mn[e] = xe; arg[e] = rid; }
         }
     }
+    (void)stride;
 #pragma unroll
     for (int e = 0; e < VW; e++) {
         if (col0 + e < n) {
@@ -133,6 +146,12 @@ __global__ void colred_assign(int n, const int32_t *__restrict__ imin, const int
 // distinct rows cost one chunk, identical rows one full read).  Used by the augmentation to skip
 // scans that provably change nothing (see chain_augment).
 // ------------------------------------------------------------------------------------------
+// with a row map: consecutive LAP rows that read the same stored row
+__global__ __launch_bounds__(256) void rows_same_from_map(int n, const int32_t *__restrict__ rowmap, int32_t *__restrict__ same_prev) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) same_prev[i] = (i > 0 && rowmap[i] == rowmap[i - 1]) ? 1 : 0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void rows_same_as_prev(int n, int64_t ld, const T *__restrict__ cost, int32_t *__restrict__ same_prev) {
     using V = typename VecOf<T>::type;
@@ -1143,7 +1162,7 @@ __device__ __forceinline__ K2 refresh_row(int i, int n, int64_t ld, const float 
 template <int CH>
 __global__ __launch_bounds__(BLOCK2) void build_row_caches(int n, int64_t ld, const float *__restrict__ cost,
                                                           const float *__restrict__ v, uint32_t *__restrict__ cache_col,
-                                                          float *__restrict__ cache_val) {
+                                                          float *__restrict__ cache_val, const int32_t *__restrict__ rowmap) {
     constexpr int NC = CH * 4;
     __shared__ Scratch2 s;
     const int tid = threadIdx.x;
@@ -1158,7 +1177,7 @@ __global__ __launch_bounds__(BLOCK2) void build_row_caches(int n, int64_t ld, co
     }
     float delta = 0.0f;
     for (int i = blockIdx.x; i < n; i += gridDim.x)
-        (void)refresh_row<CH>(i, n, ld, cost, vreg, validm, cache_col, cache_val, delta, s, par);
+        (void)refresh_row<CH>(i, n, ld, RBASE(cost, rowmap, i, ld), vreg, validm, cache_col, cache_val, delta, s, par);
 }
 
 // Streaming variant of refresh_row for large n: no per-lane arrays.  The row and the prices come through
@@ -1240,12 +1259,12 @@ __device__ __forceinline__ K2 refresh_row_stream(int i, int n, int64_t ld, const
 
 __global__ __launch_bounds__(BLOCK2) void build_row_caches_stream(int n, int64_t ld, const float *__restrict__ cost,
                                                                  const float *v, uint32_t *__restrict__ cache_col,
-                                                                 float *__restrict__ cache_val) {
+                                                                 float *__restrict__ cache_val, const int32_t *__restrict__ rowmap) {
     __shared__ Scratch2 s;
     int par = 0;
     float delta = 0.0f;
     for (int i = blockIdx.x; i < n; i += gridDim.x)
-        (void)refresh_row_stream<0>(i, n, ld, cost, v, cache_col, cache_val, delta, s, par);
+        (void)refresh_row_stream<0>(i, n, ld, RBASE(cost, rowmap, i, ld), v, cache_col, cache_val, delta, s, par);
 }
 
 struct Chain2Args {
@@ -1258,6 +1277,7 @@ struct Chain2Args {
     float *cache_val;    // [n][KC]
     char *misc;          // +8: double total; +16: long long counters[]; +4: int status
     int32_t *rowgid;     // [n] duplicate-row group of every row (consecutive identical rows share an id)
+    const int32_t *rowmap; // [n] stored row of every LAP row, or nullptr (row i is stored row i)
     float *g_hbest;      // [ngroups] scratch for gmode 2
     int32_t *g_hstamp;   // [ngroups] scratch for gmode 2 (zeroed)
     int ngroups;
@@ -1364,7 +1384,7 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
                                              float *s_v, uint16_t *s_cs, int freerow, uint64_t validm, Scratch2 &s, int &par,
                                              long long &c_relax, long long &c_hops, long long &c_skipped, int gmode,
                                              const int32_t *rowgid, int32_t *colgroup, float *hb, int32_t *hs, int stamp, float *s_ca,
-                                             uint16_t *s_cg, PickRec (*rec)[NW2]) {
+                                             uint16_t *s_cg, PickRec (*rec)[NW2], const int32_t *__restrict__ rowmap) {
     constexpr int NC = CH * 4;
     constexpr int NWV = BS / 64;
 #undef SLOT_COL
@@ -1404,7 +1424,7 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
         if (((validm >> sl) & 1) && st_csget<LDS_STATE>(s_cs, gcolsol, SLOT_COL(sl)) >= 0) assignedm |= (1ull << sl);
     {
         float4 x[CH];
-        load_row4<CH, BS>(cost, ld, freerow, n, tid, x);
+        load_row4<CH, BS>(RBASE(cost, rowmap, freerow, ld), ld, freerow, n, tid, x);
 #pragma unroll
         for (int sl = 0; sl < NC; sl++) {
             const bool ok = (validm >> sl) & 1;
@@ -1527,7 +1547,7 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
         AP_STAMP(1)
         float4 x[CH];
         if (!skip) {
-            load_row4<CH, BS>(cost, ld, i, n, tid, x);
+            load_row4<CH, BS>(RBASE(cost, rowmap, i, ld), ld, i, n, tid, x);
             // scan log (after the loads in program order: a store does not hold them up); one store instruction of the last wave
             if (tid >= BS - 2) {
                 if (tid == BS - 2) st_i32(slog_row + nlog, i);
@@ -1602,7 +1622,7 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
                     const bool in = e >= 1 && e <= nlog;
                     const int row = in ? ld_i32(slog_row + e - 1) : freerow;
                     hv[t] = in ? ld_f32(slog_h + e - 1) : 0.0f;
-                    cv[t] = cost[(int64_t)row * ld + ep];
+                    cv[t] = cost[row_off(rowmap, row, ld) + ep];
                 }
 #pragma unroll
                 for (int t = 7; t >= 0; t--) {
@@ -1796,7 +1816,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(const Chain2Args *__restrict
                         have_dense = false;
                         umin = key_val(gd.m1); usub = key_val(gd.m2);
                         j1 = (int)(uint32_t)gd.m1; j2 = (int)(uint32_t)gd.m2;
-                        cj1 = a.cost[(int64_t)i * a.ld + j1]; cj2 = a.cost[(int64_t)i * a.ld + j2];
+                        cj1 = a.cost[row_off(a.rowmap, i, a.ld) + j1]; cj2 = a.cost[row_off(a.rowmap, i, a.ld) + j2];
                         vj1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(st_vget<LDS_STATE>(s_v, gv, j1))));
                         i0 = __builtin_amdgcn_readfirstlane(st_csget<CSL>(s_cs, gcolsol, j1));
                         i02 = __builtin_amdgcn_readfirstlane(st_csget<CSL>(s_cs, gcolsol, j2));
@@ -1876,12 +1896,12 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(const Chain2Args *__restrict
         const int op = s.cmd_op, row = s.cmd_row;
         if (op == OP_EXIT) break;
         if constexpr (CH == 0) {
-            gd = refresh_row_stream<0x10>(row, n, ld, cost, gv, a.cache_col, a.cache_val, delta, s, par);
+            gd = refresh_row_stream<0x10>(row, n, ld, RBASE(cost, a.rowmap, row, ld), gv, a.cache_col, a.cache_val, delta, s, par);
             have_dense = true;
         } else {
             float vreg[NC > 0 ? NC : 1];
             load_vreg<CH, LDS_STATE>(s_v, gv, n, tid, vreg);
-            gd = refresh_row<CH>(row, n, ld, cost, vreg, validm, a.cache_col, a.cache_val, delta, s, par);
+            gd = refresh_row<CH>(row, n, ld, RBASE(cost, a.rowmap, row, ld), vreg, validm, a.cache_col, a.cache_val, delta, s, par);
             have_dense = true;
         }
     }
@@ -1896,7 +1916,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(const Chain2Args *__restrict
         if constexpr (CSL) gcolsol[c] = r;
         if (r >= 0) {
             rowsol[r] = c;
-            cassign[c] = cost[(int64_t)r * ld + c];                 // c[colsol[j]][j] for the augmentation kernel
+            cassign[c] = cost[row_off(a.rowmap, r, ld) + c];          // c[colsol[j]][j] for the augmentation kernel
             colgroup[c] = a.gmode ? a.rowgid[r] : 0;               // duplicate-row group of the row that owns column c
         }
     }
@@ -1985,7 +2005,7 @@ __global__ __launch_bounds__(BS) void jv_aug2(const Chain2Args *__restrict__ bat
     for (int f = a.aug_start; f < numfree && !err; f++) {
         const int freerow = __builtin_amdgcn_readfirstlane(ld_i32(freerows + f));
         err = chain_augment<CH, LDS_STATE, BS>(n, ld, cost, gv, sd, cassign, rowsol, gcolsol, slog_row, slog_h, s_v, s_cs, freerow, validm, s,
-                                           par, c_relax, c_hops, c_skipped, gmode, a.rowgid, a.iws + 6 * (int64_t)n, hb, hs, f + 1, s_ca, s_cg, s_rec);
+                                           par, c_relax, c_hops, c_skipped, gmode, a.rowgid, a.iws + 6 * (int64_t)n, hb, hs, f + 1, s_ca, s_cg, s_rec, a.rowmap);
         c_augs++;
     }
     // ---- write back prices and colsol, then duals u and the total ----
@@ -2001,7 +2021,7 @@ __global__ __launch_bounds__(BS) void jv_aug2(const Chain2Args *__restrict__ bat
     double part = 0.0;
     for (int i = tid; i < n; i += BS) {
         const int j = ld_i32(rowsol + i);
-        const float cij = cost[(int64_t)i * ld + j];
+        const float cij = cost[row_off(a.rowmap, i, ld) + j];
         const float vj = ld_f32(gv + j);
         gu[i] = cij - vj;
         part += (double)cij;
@@ -2060,6 +2080,7 @@ struct LazyArgs {
     uint64_t *dkey;                                   // [n]
     int32_t *rowsol, *colsol, *freerows, *srow, *slist, *slevel;   // [n] each (srow: [n+1])
     const int32_t *rowgid;
+    const int32_t *rowmap;                            // [n] stored row of every LAP row, or nullptr
     const uint32_t *cache_col;
     const float *cache_val;
     float *g_hbest; int32_t *g_hstamp;
@@ -2351,7 +2372,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(const LazyArgs *__restrict
                             int i = st0 == 0 ? freerow : ld_i32(a.srow + st0);
                             for (;;) {
                                 st_csset<CSL>(s_cs, a.colsol, ep, i);
-                                st_f32(a.cassign + ep, (have_cie0 && hops == 0) ? cie0 : cost[(int64_t)i * ld + ep]);
+                                st_f32(a.cassign + ep, (have_cie0 && hops == 0) ? cie0 : cost[row_off(a.rowmap, i, ld) + ep]);
                                 const int j1 = ep;
                                 if (i != freerow) ep = ld_i32(a.rowsol + i);      // (the free row owns no column)
                                 st_i32(a.rowsol + i, j1);
@@ -2472,7 +2493,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(const LazyArgs *__restrict
                         const bool ev = lane < nexc;
                         const int j = ev ? s_exc[lane] : 0;
                         const float vj = st_vget<LDS_STATE>(s_v, gv, j);
-                        const float v2 = ev ? (cost[(int64_t)i * ld + j] - vj) - h : 0.0f;
+                        const float v2 = ev ? (cost[row_off(a.rowmap, i, ld) + j] - vj) - h : 0.0f;
                         const bool scn = (s_sc[j >> 5] >> (j & 31)) & 1u;
                         lz_touch_blocks(ev && !scn, j >> 6, s_ep[j >> 6], a.dkey, s_ep, s_tl, ntouch, stamp, npad, lane);
                         if (ev && !scn) {
@@ -2499,7 +2520,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(const LazyArgs *__restrict
                         float tl = INFINITY;
                 {
                     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-                        const_cast<float *>(cost + (int64_t)freerow * ld), 0, (int)(ld * 4), 0x00020000);
+                        const_cast<float *>(cost + row_off(a.rowmap, freerow, ld)), 0, (int)(ld * 4), 0x00020000);
                     for (int q0 = 0; q0 < nquad; q0 += BLOCK2) {
                         const int q = q0 + tid;
                         uint64_t bk = KEYMAX;
@@ -2554,7 +2575,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(const LazyArgs *__restrict
                 const float h = cmd.h;
                 const float T0 = ord2f(s_T);
                 const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<float *>(cost + (int64_t)i * ld), 0, (int)(ld * 4), 0x00020000);
+                    const_cast<float *>(cost + row_off(a.rowmap, i, ld)), 0, (int)(ld * 4), 0x00020000);
                 float tl2 = INFINITY;
                 for (int q0 = 0; q0 < nquad; q0 += BLOCK2) {
                     const int q = q0 + tid;
@@ -2647,7 +2668,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(const LazyArgs *__restrict
     for (int i = tid; i < n; i += BLOCK2) {
         const int j = ld_i32(a.rowsol + i);
         if (j < 0) continue;              // still free: the kernel gave up and the dense kernel finishes (and redoes this)
-        const float cij = cost[(int64_t)i * ld + j];
+        const float cij = cost[row_off(a.rowmap, i, ld) + j];
         const float vj = ld_f32(gv + j);
         a.gu[i] = cij - vj;
         part += (double)cij;
@@ -2694,11 +2715,14 @@ static int check_opts(const cyto_lap_opts &o) {
 struct F32Job {
     // in
     const float *cost = nullptr; int64_t ld = 0; int cost_on_device = 0;
+    const int32_t *rowmap_host = nullptr; int nu = 0;   // optional row map: LAP row i reads stored row rowmap[i] (nu stored rows)
     // out (host pointers, may be null)
     int32_t *rowsol = nullptr, *colsol = nullptr; float *u = nullptr, *v = nullptr; double *total = nullptr; cyto_lap_info *info = nullptr;
     int status = CYTO_OK;
     // device state
     DevBuf staged, b_fws, b_iws, b_imin, b_pmin, b_parg, b_misc, b_same, b_gid, b_ccol, b_cval, b_ghb, b_ghs, b_lzhb, b_lzhs;
+    DevBuf b_rowmap, b_ulist, b_ufirst;
+    int nused = 0;
     const float *dcost = nullptr; int64_t dld = 0;
     int h_nonfinite = 0, h_ngroups = 0, h_hand[3] = {0, 0, 0};
     Chain2Args c2; LazyArgs la;
@@ -2729,10 +2753,10 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             const Chain2Args &a = jobs[b].c2;
             if constexpr (CH == 0)
                 hipLaunchKernelGGL(build_row_caches_stream, dim3(pl.cache_grid), dim3(BLOCK2), 0, stream, n, a.ld, a.cost,
-                                   (const float *)a.fws, a.cache_col, a.cache_val);
+                                   (const float *)a.fws, a.cache_col, a.cache_val, a.rowmap);
             else
                 hipLaunchKernelGGL((build_row_caches<CH>), dim3(pl.cache_grid), dim3(BLOCK2), 0, stream, n, a.ld, a.cost,
-                                   (const float *)a.fws, a.cache_col, a.cache_val);
+                                   (const float *)a.fws, a.cache_col, a.cache_val, a.rowmap);
         }
         CYTO_HIP(hipGetLastError());
         return CYTO_OK;
@@ -2848,15 +2872,38 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
     CYTO_HIP(hipEventRecord(e0, stream));
     for (F32Job &j : jobs) {
         if (!j.cost || j.ld < n) { j.status = CYTO_ERR_BAD_ARG; continue; }
+        // optional row map: validated on the host (non-decreasing: duplicated spot rows are contiguous, as np.repeat makes
+        // them), the distinct rows in use and the first LAP row of each go to the device with it
+        const int nstored = j.rowmap_host ? j.nu : n;
+        std::vector<int32_t> ulist, ufirst;
+        if (j.rowmap_host) {
+            if (j.nu <= 0) { j.status = CYTO_ERR_BAD_ARG; continue; }
+            bool ok = true;
+            for (int i = 0; i < n && ok; i++) {
+                const int32_t r = j.rowmap_host[i];
+                ok = r >= 0 && r < j.nu && (i == 0 || r >= j.rowmap_host[i - 1]);
+                if (ok && (i == 0 || r != j.rowmap_host[i - 1])) { ulist.push_back(r); ufirst.push_back(i); }
+            }
+            if (!ok) { j.status = CYTO_ERR_BAD_ARG; continue; }
+            j.nused = (int)ulist.size();
+        }
         // the kernels want 16-byte aligned rows: pitch a multiple of 4 elements
         j.dcost = j.cost; j.dld = j.ld;
         const bool aligned = j.cost_on_device && (j.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(j.cost) & 15) == 0);
         if (!aligned) {
             j.dld = ((int64_t)n + 3) / 4 * 4;
-            if ((rc = j.staged.alloc((size_t)n * j.dld * sizeof(float), stream))) return rc;
-            CYTO_HIP(hipMemcpy2DAsync(j.staged.p, j.dld * sizeof(float), j.cost, j.ld * sizeof(float), (size_t)n * sizeof(float), n,
+            if ((rc = j.staged.alloc((size_t)nstored * j.dld * sizeof(float), stream))) return rc;
+            CYTO_HIP(hipMemcpy2DAsync(j.staged.p, j.dld * sizeof(float), j.cost, j.ld * sizeof(float), (size_t)n * sizeof(float), nstored,
                                       j.cost_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
             j.dcost = j.staged.as<float>();
+        }
+        if (j.rowmap_host) {
+            if ((rc = j.b_rowmap.alloc(nI, stream)) || (rc = j.b_ulist.alloc((size_t)j.nused * 4, stream)) || (rc = j.b_ufirst.alloc((size_t)j.nused * 4, stream)))
+                return rc;
+            CYTO_HIP(hipMemcpyAsync(j.b_rowmap.p, j.rowmap_host, nI, hipMemcpyHostToDevice, stream));
+            CYTO_HIP(hipMemcpyAsync(j.b_ulist.p, ulist.data(), (size_t)j.nused * 4, hipMemcpyHostToDevice, stream));
+            CYTO_HIP(hipMemcpyAsync(j.b_ufirst.p, ufirst.data(), (size_t)j.nused * 4, hipMemcpyHostToDevice, stream));
+            CYTO_HIP(hipStreamSynchronize(stream));       // ulist / ufirst are locals
         }
         // workspace (blocks of the device cache: no hipMalloc / hipFree once a size has been seen)
         if ((rc = j.b_fws.alloc(6 * nT + 64, stream)) || (rc = j.b_iws.alloc(10 * nI + 64, stream)) || (rc = j.b_imin.alloc(nI, stream)) ||
@@ -2871,10 +2918,17 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
         CYTO_HIP(hipMemsetAsync(j.b_misc.p, 0, 256, stream));
         CYTO_HIP(hipMemsetAsync(d_rowsol, 0xFF, nI, stream));
         CYTO_HIP(hipMemsetAsync(d_matches, 0, nI, stream));
-        hipLaunchKernelGGL(colred_partial<float>, dim3(pl.colblocks, pl.rowblocks), dim3(256), 0, stream, n, j.dld, j.dcost, pl.rows_per_block,
-                           j.b_pmin.as<float>(), j.b_parg.as<int32_t>(), j.b_misc.as<int>());
-        hipLaunchKernelGGL(colred_finish<float>, dim3((n + 255) / 256), dim3(256), 0, stream, n, pl.rowblocks, j.b_pmin.as<float>(),
-                           j.b_parg.as<int32_t>(), d_v, j.b_imin.as<int32_t>(), d_rowsol, d_matches);
+        {   // the column minima need every DISTINCT row once: with a row map only the stored rows in use are swept
+            const int nrows = j.rowmap_host ? j.nused : n;
+            const int rpb = j.rowmap_host ? (nrows + pl.rowblocks - 1) / pl.rowblocks : pl.rows_per_block;
+            const int rblocks = j.rowmap_host ? (nrows + rpb - 1) / rpb : pl.rowblocks;
+            hipLaunchKernelGGL(colred_partial<float>, dim3(pl.colblocks, rblocks), dim3(256), 0, stream, n, j.dld, j.dcost, rpb,
+                               j.b_pmin.as<float>(), j.b_parg.as<int32_t>(), j.b_misc.as<int>(), nrows,
+                               j.rowmap_host ? j.b_ulist.as<int32_t>() : (const int32_t *)nullptr,
+                               j.rowmap_host ? j.b_ufirst.as<int32_t>() : (const int32_t *)nullptr);
+            hipLaunchKernelGGL(colred_finish<float>, dim3((n + 255) / 256), dim3(256), 0, stream, n, rblocks, j.b_pmin.as<float>(),
+                               j.b_parg.as<int32_t>(), d_v, j.b_imin.as<int32_t>(), d_rowsol, d_matches);
+        }
         hipLaunchKernelGGL(colred_assign, dim3((n + 255) / 256), dim3(256), 0, stream, n, j.b_imin.as<int32_t>(), d_rowsol, d_colsol);
     }
     CYTO_HIP(hipGetLastError());
@@ -2885,7 +2939,10 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
         if (!j.alive()) continue;
         j.h_ngroups = n;
         if (want_groups) {
-            hipLaunchKernelGGL(rows_same_as_prev<float>, dim3(min(n, 2048)), dim3(256), 0, stream, n, j.dld, j.dcost, j.b_same.as<int32_t>());
+            if (j.rowmap_host)
+                hipLaunchKernelGGL(rows_same_from_map, dim3((n + 255) / 256), dim3(256), 0, stream, n, j.b_rowmap.as<int32_t>(), j.b_same.as<int32_t>());
+            else
+                hipLaunchKernelGGL(rows_same_as_prev<float>, dim3(min(n, 2048)), dim3(256), 0, stream, n, j.dld, j.dcost, j.b_same.as<int32_t>());
             hipLaunchKernelGGL(rows_group_ids, dim3(1), dim3(1024), 0, stream, n, j.b_same.as<int32_t>(), j.b_gid.as<int32_t>(),
                                j.b_misc.as<int>() + 36);   // misc + 144
         }
@@ -2910,6 +2967,7 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
         // duplicate-row skip: per-group state in LDS when it fits beside v (4 B) and colsol (2 B) per column
         c2.rowgid = j.b_gid.as<int32_t>(); c2.ngroups = ng; c2.gmode = 0; c2.g_hbest = nullptr; c2.g_hstamp = nullptr;
         c2.auxlds = 0; c2.aug_start = 0;
+        c2.rowmap = j.rowmap_host ? j.b_rowmap.as<int32_t>() : nullptr;
         LazyArgs &la = j.la;
         memset(&la, 0, sizeof la);
         j.shm_lazy = pl.lz_base_shm;
@@ -2920,6 +2978,7 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
             la.srow = d_rowsol + 6 * (int64_t)n;      // [n+1]: runs into the next slot, which the lazy path does not use
             la.slist = d_rowsol + 8 * (int64_t)n; la.slevel = d_rowsol + 9 * (int64_t)n;
             la.rowgid = j.b_gid.as<int32_t>(); la.cache_col = j.b_ccol.as<uint32_t>(); la.cache_val = j.b_cval.as<float>();
+            la.rowmap = j.rowmap_host ? j.b_rowmap.as<int32_t>() : nullptr;
             la.misc = j.b_misc.as<char>(); la.ngroups = ng; la.gmode = 0; la.g_hbest = nullptr; la.g_hstamp = nullptr;
             la.may_bail = opts.no_handover ? 0 : 1;   // (launch_batch clears it where no dense kernel can take over)
             la.debug_exc = opts.inject_exceptions;
@@ -3077,7 +3136,7 @@ static int lap_solve_f64(int n, const double *cost, int64_t ld, int cost_on_devi
     CYTO_HIP(hipMemsetAsync(d_matches, 0, nI, stream));
     CYTO_HIP(hipEventRecord(e0, stream));
     hipLaunchKernelGGL(colred_partial<T>, dim3(colblocks, rowblocks), dim3(256), 0, stream, n, dld, dcost, rows_per_block,
-                       b_pmin.as<T>(), b_parg.as<int32_t>(), d_nonfinite);
+                       b_pmin.as<T>(), b_parg.as<int32_t>(), d_nonfinite, n, (const int32_t *)nullptr, (const int32_t *)nullptr);
     hipLaunchKernelGGL(colred_finish<T>, dim3((n + 255) / 256), dim3(256), 0, stream, n, rowblocks, b_pmin.as<T>(),
                        b_parg.as<int32_t>(), d_v, b_imin.as<int32_t>(), d_rowsol, d_matches);
     hipLaunchKernelGGL(colred_assign, dim3((n + 255) / 256), dim3(256), 0, stream, n, b_imin.as<int32_t>(), d_rowsol, d_colsol);
@@ -3152,11 +3211,12 @@ static int lap_solve_f32(int n, const float *cost, int64_t ld, int cost_on_devic
 // C ABI helper of cyto_lap_batch_f32 (batch.hip): problems of equal size go through the chains together
 int lap_batch_same_n(int n, int nb, const float *const *cost, const int64_t *ld, int cost_on_device, int32_t *const *rowsol,
                      int32_t *const *colsol, float *const *u, float *const *v, double *total, cyto_lap_info *info, int *status,
-                     int device_id, hipStream_t stream) {
+                     int device_id, hipStream_t stream, const int32_t *const *rowmap, const int *nu) {
     std::vector<F32Job> jobs((size_t)nb);
     for (int b = 0; b < nb; b++) {
         F32Job &j = jobs[(size_t)b];
         j.cost = cost[b]; j.ld = ld[b]; j.cost_on_device = cost_on_device;
+        if (rowmap && rowmap[b]) { j.rowmap_host = rowmap[b]; j.nu = nu ? nu[b] : 0; }
         j.rowsol = rowsol ? rowsol[b] : nullptr; j.colsol = colsol ? colsol[b] : nullptr;
         j.u = u ? u[b] : nullptr; j.v = v ? v[b] : nullptr;
         j.total = total ? &total[b] : nullptr; j.info = info ? &info[b] : nullptr;
@@ -3218,6 +3278,18 @@ int cyto_aug_prof_read(long long *out16) {
     return CYTO_OK;
 }
 #endif
+
+int cyto_lap_f32_rowmap(int n, const float *cost_rows, int64_t ld, int nu, int cost_on_device, const int32_t *rowmap,
+                        int32_t *rowsol, int32_t *colsol, float *u, float *v, double *total, cyto_lap_info *info, int device_id,
+                        void *stream, const cyto_lap_opts *opts) {
+    if (n <= 0 || !cost_rows || ld < n || !rowmap || nu <= 0) return CYTO_ERR_BAD_ARG;
+    std::vector<cyto::F32Job> jobs(1);
+    cyto::F32Job &j = jobs[0];
+    j.cost = cost_rows; j.ld = ld; j.cost_on_device = cost_on_device; j.rowmap_host = rowmap; j.nu = nu;
+    j.rowsol = rowsol; j.colsol = colsol; j.u = u; j.v = v; j.total = total; j.info = info;
+    const int rc = cyto::lap_solve_f32_batch(n, jobs, device_id, reinterpret_cast<hipStream_t>(stream), opts ? *opts : cyto::k_default_opts);
+    return rc ? rc : j.status;
+}
 
 int cyto_lap_f32_opts(int n, const float *cost, int64_t ld, int cost_on_device, int32_t *rowsol, int32_t *colsol,
                       float *u, float *v, double *total, cyto_lap_info *info, int device_id, void *stream, const cyto_lap_opts *opts) {

@@ -15,6 +15,38 @@ import numpy as np
 from . import _lib
 
 
+def lap_solve_rows(rows, rowmap, device_id=0, return_info=False, device_ptr=None, nu=None, ld=None, opts=None):
+    """Solve the LAP whose row i is stored row rowmap[i] (C ABI: cyto_lap_f32_rowmap): `rows` holds every DISTINCT cost row
+    once (nu x n, float32; or a device pointer with nu and ld), rowmap is what np.repeat(arange(nu), slots) gives.
+    Same result, bit for bit, as lap_solve(rows[rowmap])."""
+    L = _lib.lib()
+    rowmap = np.ascontiguousarray(rowmap, dtype=np.int32)
+    n = len(rowmap)
+    if device_ptr is None:
+        c = np.ascontiguousarray(rows, dtype=np.float32)
+        if c.ndim != 2 or c.shape[1] != n:
+            raise ValueError("rows must be nu x n with n = len(rowmap)")
+        nu, ld, ptr, on_device = c.shape[0], n, c.ctypes.data, 0
+    else:
+        if nu is None:
+            raise ValueError("nu is required with device_ptr")
+        ld = n if ld is None else ld
+        ptr, on_device = int(device_ptr), 1
+    rowsol, colsol = np.empty(n, np.int32), np.empty(n, np.int32)
+    u, v = np.empty(n, np.float32), np.empty(n, np.float32)
+    total = ctypes.c_double()
+    info = _lib.LapInfo()
+    o = _lib.LapOpts(**opts) if opts else None
+    st = L.cyto_lap_f32_rowmap(n, ptr, ld, int(nu), on_device, rowmap.ctypes.data, rowsol.ctypes.data, colsol.ctypes.data,
+                               u.ctypes.data, v.ctypes.data, ctypes.byref(total), ctypes.byref(info), device_id, None,
+                               ctypes.byref(o) if o is not None else None)
+    _lib.check(st)
+    out = dict(rowsol=rowsol, colsol=colsol, u=u, v=v, total=total.value)
+    if return_info:
+        out["info"] = info
+    return out
+
+
 def lap_solve(cost, dtype=np.float32, device_id=0, return_info=False, device_ptr=None, n=None, ld=None, opts=None):
     """Solve a square LAP on the GPU.
 

@@ -110,6 +110,14 @@ int cyto_lap_f64_opts(int n, const double *cost, int64_t ld, int cost_on_device,
                       int32_t *rowsol, int32_t *colsol, double *u, double *v, double *total,
                       cyto_lap_info *info, int device_id, void *stream, const cyto_lap_opts *opts);
 
+/* Row indirection (first half).  calculate_cost repeats every spot row slots[s] times
+ * (linear_assignment_solvers.py:63-66: `cost[location_repeat, :]`); here the cost holds every DISTINCT row once (nu x ld) and
+ * rowmap[i] (host, n entries, non-decreasing like np.repeat's output, values in [0, nu)) names the stored row of LAP row i --
+ * 10x less memory and streaming traffic at config c3.  Results are bit-identical to solving the materialised n x n matrix. */
+int cyto_lap_f32_rowmap(int n, const float *cost_rows, int64_t ld, int nu, int cost_on_device, const int32_t *rowmap,
+                        int32_t *rowsol, int32_t *colsol, float *u, float *v, double *total,
+                        cyto_lap_info *info, int device_id, void *stream, const cyto_lap_opts *opts);
+
 /* `lapjv(cost_scaled)` as the reference calls it (linear_assignment_solvers.py:38): a float64 HOST matrix solved in
  * float32.  The matrix is uploaded as it is and narrowed on the device (same rounding as numpy's astype(float32)). */
 int cyto_lap_f32_from_f64(int n, const double *cost_host, int64_t ld, int32_t *rowsol, int32_t *colsol,

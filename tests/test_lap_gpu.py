@@ -4,7 +4,7 @@ import os
 import numpy as np
 import pytest
 
-from cytospace_amd.lap import lap_solve, lapjv_hip
+from cytospace_amd.lap import lap_solve, lap_solve_rows, lapjv_hip
 from oracle.jv import jv_oracle
 
 pytestmark = pytest.mark.gpu
@@ -282,3 +282,37 @@ def test_float64_host_matrix_is_narrowed_on_the_device():
         lapjv_hip(np.array([[1.0, np.nan], [0.0, 1.0]]))
     with pytest.raises(ValueError):
         lapjv_hip(np.array([[1e300, 0.0], [0.0, 1.0]]))        # overflows to inf in float32, like astype(float32)
+
+
+# ---- SURVEY 8f rank 3 (first half): row indirection -- the cost holds every distinct spot row once ----
+
+@pytest.mark.parametrize("opts", [None, dict(chain_variant=1), dict(chain_variant=2), dict(augmentation=1), dict(augmentation=2, no_handover=1)])
+def test_row_map_equals_the_materialised_matrix(opts):
+    # cyto_lap_f32_rowmap(rows, np.repeat(arange(S), slots)) == cyto_lap_f32(rows[rowmap]) == the oracle, bit for bit,
+    # with equal slots, ragged slots, stored rows nobody uses (slots == 0) and a single spot
+    rng = np.random.default_rng(31)
+    cases = []
+    for S, slots in ((12, np.full(12, 5)), (300, rng.integers(0, 6, 300)), (1, np.array([7])), (500, np.full(500, 4)),
+                     (900, np.where(rng.random(900) < 0.3, 0, rng.integers(1, 4, 900)))):
+        n = int(slots.sum())
+        rows = -(rng.random((S, n)) ** 3).astype(np.float32)
+        cases.append((rows, np.repeat(np.arange(S), slots).astype(np.int32)))
+    for rows, rowmap in cases:
+        full = rows[rowmap]
+        a = lap_solve_rows(rows, rowmap, return_info=True, opts=opts)
+        b = lap_solve(full, np.float32, return_info=True, opts=opts)
+        o = jv_oracle(full, np.float32)
+        for k in ("rowsol", "colsol", "u", "v"):
+            assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], o[k]), k
+        assert a["total"] == b["total"]
+        for k in STAT_KEYS:
+            assert a["info"].as_dict()[k] == o["stats"].as_dict()[k], k
+
+
+def test_row_map_argument_validation():
+    rows = np.random.default_rng(1).random((3, 6)).astype(np.float32)
+    for bad in ([0, 0, 1, 1, 2, 3], [0, 1, 0, 1, 2, 2], [-1, 0, 0, 1, 1, 2]):        # out of range, not monotone, negative
+        with pytest.raises(ValueError):
+            lap_solve_rows(rows, np.array(bad, np.int32))
+    with pytest.raises(ValueError):
+        lap_solve_rows(rows, np.array([0, 0, 1, 1, 2], np.int32))                    # n != number of columns

@@ -13,7 +13,7 @@ import pytest
 
 from cytospace_amd import _lib, common
 from cytospace_amd.cytospace import ExpressionContext, assign_pearson, solve_linear_assignment_problem
-from cytospace_amd.lap import lap_solve
+from cytospace_amd.lap import lap_solve, lap_solve_rows
 from cytospace_amd.linear_assignment_solvers import calculate_cost, call_solver, import_solver
 from oracle import cost as ocost
 from oracle.jv import jv_oracle
@@ -36,12 +36,12 @@ def _golden(tag):
     return np.load(path)
 
 
-def _compare_with_golden(tag, buf, n):
+def _compare_with_golden(tag, buf, n, solve=None):
     """HIP solve of the device-resident n x n matrix vs the oracle's stored answer: colsol element for element,
     rowsol / u / v by sha256 (bit-exact without shipping 3 more arrays), the work counters, the total."""
     d = _golden(tag)
     assert int(d["n"]) == n
-    g = lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n)
+    g = solve() if solve else lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n)
     assert np.array_equal(g["colsol"], d["colsol"]), f"{(g['colsol'] != d['colsol']).sum()} of {n} columns differ"
     assert sha(g["rowsol"]) == str(d["rowsol_sha256"])
     assert sha(g["v"]) == str(d["v_sha256"]), "dual prices v differ from the oracle's"
@@ -74,6 +74,19 @@ def test_c3_shaped_lap_50000():
     try:
         g = _compare_with_golden(f"c3s{n}", buf, n)
         assert np.array_equal(np.bincount(loc[g["colsol"]], minlength=n // 10), np.full(n // 10, 10))
+    finally:
+        buf.free()
+
+
+def test_c3_shaped_lap_50000_through_the_row_map():
+    """The same LAP with the cost stored as its 5 000 distinct rows (1 GB instead of 10 GB) + location_repeat as the row map
+    (cyto_lap_f32_rowmap): the oracle's answer for the materialised matrix, bit for bit."""
+    n = 50000
+    uniq, loc = instances.c3_shaped_unique(n)
+    buf = _lib.DeviceBuffer.from_numpy(uniq)
+    try:
+        _compare_with_golden(f"c3s{n}", None, n, solve=lambda: lap_solve_rows(None, loc, return_info=True, device_ptr=buf.ptr,
+                                                                              nu=len(uniq), ld=n))
     finally:
         buf.free()
 
