@@ -12,6 +12,7 @@ so scaling is "weak" and value = N * n / max-over-ranks time.
 
 Besides the headline (`value`, on configs[1]) the same JSON line carries, at N = 1, the other single-GPU
 workloads the north star names (skip them with --no-extras):
+  "c2_batch"  32 copies of the headline instance solved together (one launch per chain phase, a workgroup per problem)
   "n50000"    the 50 000 x 50 000 uniform LAP (ms, assignments/s, colsol compared with the committed oracle golden)
   "c3"        configs[2] end to end: 20 000 genes x 50 000 cells x 5 000 spots, normalise + standardise, fp32-MFMA cost
               GEMM (its own "roofline" against the 157.3 TFLOP/s f32 matrix peak), LAP; wall time includes the H2D copies
@@ -99,6 +100,26 @@ def extra_c3(dev):
             "roofline": {"bound": "mfma", "kernel": "pearson_gemm", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF,
                          "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "flops_per_launch": info.gemm_flops},
             "lap_row_scans": int(info.lap.row_scans), "bincount_equals_slots": ok, "instance_seconds": round(t_gen, 1)}
+
+
+def extra_c2_batch(dev, cost_buf, n, B=32):
+    """B independent instances of the headline workload solved together (one launch per chain phase, a workgroup per problem):
+    what the chip delivers on configs[1]-sized problems when there is more than one of them (CytoSPACE's chunked modes)."""
+    from cytospace_amd.lap import lap_solve_batch_device
+    bufs = [cost_buf] + [cost_buf.clone() for _ in range(B - 1)]       # every chain reads its own copy
+    lap_solve_batch_device([bufs[0].ptr], [n], device_id=dev, max_concurrent=1)
+    t = time.perf_counter()
+    res = lap_solve_batch_device([b.ptr for b in bufs], [n] * B, device_id=dev, max_concurrent=B, return_info=True)
+    wall = time.perf_counter() - t
+    for b in bufs[1:]:
+        b.free()
+    same = all(np.array_equal(r["colsol"], res[0]["colsol"]) and np.array_equal(r["v"], res[0]["v"]) for r in res)
+    if not same:
+        raise SystemExit("c2_batch: copies of one instance solved together gave different answers")
+    i = res[0]["info"]
+    return {"workload": f"{B} copies of the headline instance ({n} x {n}) solved together, each on its own copy of the matrix",
+            "wall_s": round(wall, 3), "assignments_per_s": round(B * n / wall, 1), "batch_kernel_ms": round(i.ms_total, 1),
+            "jv_chain2_ms": round(i.ms_arr, 1), "jv_aug_lazy_ms": round(i.ms_aug, 1), "copies_identical": same}, res[0]
 
 
 def _usable_cores():
@@ -354,6 +375,11 @@ def main():
     dual_ok = bool(red.min() > -1e-5 and np.abs(red[np.arange(len(rs)), rowsol[rs]]).max() < 1e-5)
     if not (perm_ok and total_ok and dual_ok):
         raise SystemExit(f"full-size property check failed: perm={perm_ok} total={total_ok} dual={dual_ok}")
+    c2_batch = None
+    if world == 1 and not args.no_extras:
+        c2_batch, r0 = extra_c2_batch(dev, buf, n)
+        if not (np.array_equal(r0["colsol"], colsol) and np.array_equal(r0["v"], res["v"])):
+            raise SystemExit("c2_batch: the batched solve differs from the single solve")
     buf.free()
 
     sharded = None
@@ -445,6 +471,8 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
+    if c2_batch is not None:
+        out["c2_batch"] = c2_batch
     if sharded is not None:
         out["c4_sharded"] = sharded
     if world == 1 and not args.no_extras:

@@ -1267,24 +1267,36 @@ __global__ __launch_bounds__(BLOCK2) void build_row_caches_stream(int n, int64_t
         (void)refresh_row_stream<0>(i, n, ld, RBASE(cost, rowmap, i, ld), v, cache_col, cache_val, delta, s, par);
 }
 
-struct Chain2Args {
-    int n;
-    int64_t ld;
-    const float *cost;
-    float *fws;          // float workspace: v[n] | u[n] | sumvd[n] | cassign[n] (= c[colsol[j]][j])
-    int32_t *iws;        // int workspace: rowsol | colsol | matches | freerows | rtrows | pred | colgroup   (n each)
-    uint32_t *cache_col; // [n][KC]
-    float *cache_val;    // [n][KC]
-    char *misc;          // +8: double total; +16: long long counters[]; +4: int status
-    int32_t *rowgid;     // [n] duplicate-row group of every row (consecutive identical rows share an id)
-    const int32_t *rowmap; // [n] stored row of every LAP row, or nullptr (row i is stored row i)
-    float *g_hbest;      // [ngroups] scratch for gmode 2
-    int32_t *g_hstamp;   // [ngroups] scratch for gmode 2 (zeroed)
-    int ngroups;
-    int gmode;           // 0: no duplicate rows; 1: per-group state in LDS; 2: in global memory
-    int auxlds;          // augmentation: cassign (f32) + colgroup (u16) per column also in LDS
-    int aug_start;       // jv_aug2: first free row to augment (> 0: continues after jv_aug_lazy gave up)
-};
+// Argument block of one problem (kernels get an array of them: one workgroup per problem).  Fields through an X-macro because
+// the kernels read the block through a mirror struct whose pointers are typed as GLOBAL (LOAD_ARGS): pointers that are loaded from
+// memory are generic to the compiler, and every access through them would be a FLAT instruction instead of a global one.
+//   fws        float workspace: v[n] | u[n] | sumvd[n] | cassign[n] (= c[colsol[j]][j]) | 2n more
+//   iws        int workspace: rowsol | colsol | matches | freerows | rtrows | pred | colgroup | ...   (n each)
+//   cache_*    [n][KC] row caches;  misc: +8 double total; +16 long long counters[]; +4 int status
+//   rowgid     [n] duplicate-row group of every row (consecutive identical rows share an id)
+//   rowmap     [n] stored row of every LAP row, or nullptr (row i is stored row i)
+//   g_hbest / g_hstamp   [ngroups] scratch for gmode 2 (stamps zeroed)
+//   gmode      0: no duplicate rows; 1: per-group state in LDS; 2: in global memory
+//   auxlds     augmentation: cassign (f32) + colgroup (u16) per column also in LDS
+//   aug_start  jv_aug2: first free row to augment (> 0: continues after jv_aug_lazy gave up)
+#define CHAIN2_FIELDS(P, S)                                                                                             \
+    S(int, n) S(int64_t, ld) P(const float, cost) P(float, fws) P(int32_t, iws) P(uint32_t, cache_col) P(float, cache_val)   \
+    P(char, misc) P(int32_t, rowgid) P(const int32_t, rowmap) P(float, g_hbest) P(int32_t, g_hstamp)                        \
+    S(int, ngroups) S(int, gmode) S(int, auxlds) S(int, aug_start)
+#define F_PTR(T, name) T *name;
+#define F_GPTR(T, name) __attribute__((address_space(1))) T *name;
+#define F_VAL(T, name) T name;
+#define F_COPY_PTR(T, name) a.name = (T *)g.name;
+#define F_COPY_VAL(T, name) a.name = g.name;
+struct Chain2Args { CHAIN2_FIELDS(F_PTR, F_VAL) };
+struct Chain2ArgsG { CHAIN2_FIELDS(F_GPTR, F_VAL) };
+static_assert(sizeof(Chain2Args) == sizeof(Chain2ArgsG), "mirror layout");
+__device__ __forceinline__ Chain2Args load_args(const Chain2Args *__restrict__ batch) {
+    const Chain2ArgsG g = reinterpret_cast<const Chain2ArgsG *>(batch)[blockIdx.x];
+    Chain2Args a;
+    CHAIN2_FIELDS(F_COPY_PTR, F_COPY_VAL)
+    return a;
+}
 
 // L2-coherent (agent-scope, relaxed) accesses to global state
 __device__ __forceinline__ float ld_f32(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1410,6 +1422,8 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
     lds_u16 *const l_cg = (lds_u16 *)s_cg;
     lds_f32 *const l_hb = (lds_f32 *)hb;
     lds_i32 *const l_hs = (lds_i32 *)hs;
+    typedef __attribute__((address_space(3))) PickRec lds_rec;
+    lds_rec *const l_rec = (lds_rec *)&rec[0][0];          // [2][NW2]
 #define VM(sl) vmV[sl]
 #define DR(sl) dV[sl]
     {
@@ -1511,20 +1525,21 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
             }
             AP_STAMP(11)
             if (lane == 0) {
-                PickRec r;
-                r.key = ((uint64_t)wmin << 32) | wlk; r.row = iw; r.h = hw; r.vjp = vjpw; r.g = gw; r.skip = skipw; r.pad = 0;
-                rec[par][wave] = r;
+                lds_rec *const dst = l_rec + par * NW2 + wave;
+                dst->key = ((uint64_t)wmin << 32) | wlk; dst->row = iw; dst->h = hw; dst->vjp = vjpw; dst->g = gw; dst->skip = skipw;
             }
         }
         lds_barrier();
         AP_STAMP(12)
-        uint64_t k8 = rec[par][lane & (NWV - 1)].key;
+        uint64_t k8 = l_rec[par * NW2 + (lane & (NWV - 1))].key;
         uint64_t kmin = k8;
         kmin = umin64(kmin, dpp64<0xB1>(kmin)); kmin = umin64(kmin, dpp64<0x4E>(kmin));
         if constexpr (NWV > 4) kmin = umin64(kmin, dpp64<0x141>(kmin));
         kmin = readlane64(kmin, 0);
         const int wstar = (int)__builtin_ctzll(__ballot(k8 == kmin)) & (NWV - 1);     // keys of distinct waves are distinct columns
-        const PickRec rw = rec[par][wstar];
+        const lds_rec *const win = l_rec + par * NW2 + wstar;
+        const int32_t rw_row = win->row, rw_g = win->g, rw_skip = win->skip;
+        const float rw_h = win->h, rw_vjp = win->vjp;
         par ^= 1;
         AP_STAMP(0)
         const float dmin = ord2f((uint32_t)(kmin >> 32));
@@ -1533,14 +1548,14 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
         const int jp = (int)(g & 0x7FFFFFFFu);
         if (!have || dmin != curmin) { readym |= scannedm; curmin = dmin; have = true; }
         if (!(g & 0x80000000u)) { endofpath = jp; break; }
-        const int i = __builtin_amdgcn_readfirstlane(rw.row);
-        const float h = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rw.h)));
-        const float vjp = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rw.vjp)));
-        const bool skip = __builtin_amdgcn_readfirstlane(rw.skip) != 0;
+        const int i = __builtin_amdgcn_readfirstlane(rw_row);
+        const float h = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rw_h)));
+        const float vjp = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rw_vjp)));
+        const bool skip = __builtin_amdgcn_readfirstlane(rw_skip) != 0;
         if (gmode && !skip && lane == 0) {
             // the group's new best offset.  Every wave posts the same value: its own later look-ups (program order) see it
             // without another barrier, whichever wave is first
-            const int grp = rw.g;
+            const int grp = rw_g;
             if (gmode == 1) { l_hb[grp] = h; l_hs[grp] = stamp; }
             else { st_f32(hb + grp, h); st_i32(hs + grp, stamp); }
         }
@@ -1670,7 +1685,7 @@ enum { PH_RT = 0, PH_ARR = 1, PH_AUG = 2 };
 // ahead of it are acknowledged, so every global store in the step delays the next step's gathers).
 template <int CH, bool LDS_STATE, bool CS_LDS = false>
 __global__ __launch_bounds__(BLOCK2) void jv_chain2(const Chain2Args *__restrict__ batch) {
-    const Chain2Args a = batch[blockIdx.x];      // one workgroup per problem of the batch
+    const Chain2Args a = load_args(batch);       // one workgroup per problem of the batch
     constexpr int NC = CH * 4;
     constexpr bool CSL = LDS_STATE || CS_LDS;     // colsol lives in LDS
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
@@ -1934,7 +1949,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(const Chain2Args *__restrict
 // a lone wave per SIMD exposes the latency of every dependent instruction.)
 template <int CH, bool LDS_STATE, int BS = BLOCK2>
 __global__ __launch_bounds__(BS) void jv_aug2(const Chain2Args *__restrict__ batch) {
-    const Chain2Args a = batch[blockIdx.x];      // one workgroup per problem of the batch
+    const Chain2Args a = load_args(batch);       // one workgroup per problem of the batch
 #undef SLOT_COL
 #define SLOT_COL(sl) ((((sl) / 4) * BS + tid) * 4 + ((sl) % 4))
     constexpr int NC = CH * 4;
@@ -2072,23 +2087,23 @@ __device__ __forceinline__ void st_u64(uint64_t *p, uint64_t x) { __hip_atomic_s
 // Columns whose price ROSE by rounding in a price update (possible only by an ulp when v+d crosses a
 // binade) are kept in an exception list and relaxed explicitly in every cached step.
 // ------------------------------------------------------------------------------------------
-struct LazyArgs {
-    int n;
-    int64_t ld;
-    const float *cost;
-    float *gv, *gu, *sumvd, *cassign;
-    uint64_t *dkey;                                   // [n]
-    int32_t *rowsol, *colsol, *freerows, *srow, *slist, *slevel;   // [n] each (srow: [n+1])
-    const int32_t *rowgid;
-    const int32_t *rowmap;                            // [n] stored row of every LAP row, or nullptr
-    const uint32_t *cache_col;
-    const float *cache_val;
-    float *g_hbest; int32_t *g_hstamp;
-    char *misc;
-    int ngroups, gmode;
-    int may_bail;        // a dense kernel can take over: give up when the cache certificates keep failing
-    int debug_exc;       // tests: pretend the first debug_exc columns had a price rounded upwards (exception list)
-};
+//   srow: [n+1]; dkey: [n] 64-bit distance words; rowgid / rowmap as in Chain2Args
+//   may_bail   a dense kernel can take over: give up when the cache certificates keep failing
+//   debug_exc  tests: pretend the first debug_exc columns had a price rounded upwards (exception list)
+#define LAZY_FIELDS(P, S)                                                                                                \
+    S(int, n) S(int64_t, ld) P(const float, cost) P(float, gv) P(float, gu) P(float, sumvd) P(float, cassign) P(uint64_t, dkey) \
+    P(int32_t, rowsol) P(int32_t, colsol) P(int32_t, freerows) P(int32_t, srow) P(int32_t, slist) P(int32_t, slevel)          \
+    P(const int32_t, rowgid) P(const int32_t, rowmap) P(const uint32_t, cache_col) P(const float, cache_val)                  \
+    P(float, g_hbest) P(int32_t, g_hstamp) P(char, misc) S(int, ngroups) S(int, gmode) S(int, may_bail) S(int, debug_exc)
+struct LazyArgs { LAZY_FIELDS(F_PTR, F_VAL) };
+struct LazyArgsG { LAZY_FIELDS(F_GPTR, F_VAL) };
+static_assert(sizeof(LazyArgs) == sizeof(LazyArgsG), "mirror layout");
+__device__ __forceinline__ LazyArgs load_args(const LazyArgs *__restrict__ batch) {
+    const LazyArgsG g = reinterpret_cast<const LazyArgsG *>(batch)[blockIdx.x];
+    LazyArgs a;
+    LAZY_FIELDS(F_COPY_PTR, F_COPY_VAL)
+    return a;
+}
 struct LazyCmd { int op, row, step, stamp; float h; };
 enum { LZ_DENSE = 1, LZ_EXIT = 2, LZ_ERR = 3, LZ_INIT_DENSE = 4 };
 enum { C2_AUG_DENSE = C2_NCOUNTERS, C2_AUG_SPARSE_INIT, C3_NCOUNTERS };
@@ -2138,7 +2153,7 @@ __device__ __forceinline__ uint64_t wave_lexmin_u64(uint64_t k) {
 // LDS_STATE: prices and colsol in LDS; CS_LDS (with !LDS_STATE, n <= 65535): colsol (u16) in LDS, prices in L2
 template <bool LDS_STATE, bool CS_LDS = false>
 __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(const LazyArgs *__restrict__ batch) {
-    const LazyArgs a = batch[blockIdx.x];        // one workgroup per problem of the batch
+    const LazyArgs a = load_args(batch);         // one workgroup per problem of the batch
     constexpr bool CSL = LDS_STATE || CS_LDS;
 #ifdef LZ_PROF
     long long prof[6] = {0, 0, 0, 0, 0, 0}, profn[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
