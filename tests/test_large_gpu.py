@@ -200,3 +200,27 @@ def test_c4_two_chunks_of_10000():
         best = float(o["total"])
         assert abs(mine - best) <= 1e-5 * max(1.0, abs(best)), (k, mine, best)
         assert abs(total - best) <= 1e-5 * max(1.0, abs(best))
+
+
+# ---- c5-shaped: --single-cell chunks (slots == 1, every chunk against its own subset of the spots; cytospace.py:598-640) ----
+
+def test_c5_shaped_single_cell_chunks():
+    G, C, S, chunk = 1500, 15000, 15000, 5000
+    sc, st, slots = instances.synth_expression(G, C, S, seed=5)          # slots == 1 everywhere: one cell per spot
+    assert (slots == 1).all()
+    rng = np.random.default_rng(1)
+    cells, spots = rng.permutation(C), rng.permutation(S)
+    idx_sc = [np.sort(cells[k * chunk:(k + 1) * chunk]) for k in range(3)]
+    idx_st = [np.sort(spots[k * chunk:(k + 1) * chunk]) for k in range(3)]
+    with ExpressionContext(sc, st, already_normalized=False) as ctx:
+        res = ctx.assign_chunks([(idx_sc[k], np.ones(chunk, np.int64), idx_st[k]) for k in range(3)], return_info=True)
+    stn = ocost.normalize_data(st.astype(np.float64))
+    scn = ocost.normalize_data(sc.astype(np.float64))
+    for k, (mapped, total, info) in enumerate(res):
+        assert np.array_equal(np.sort(mapped), np.arange(chunk))          # positions in the chunk's spot list: a permutation
+        ref = -ocost.matrix_correlation_pearson(scn[:, idx_sc[k]], stn[:, idx_st[k]])     # chunk spots x chunk cells, float64
+        o = jv_oracle(ref.astype(np.float32), np.float32)
+        best = float(ref[o["colsol"], np.arange(chunk)].sum())
+        mine = float(ref[mapped, np.arange(chunk)].sum())
+        assert abs(mine - best) <= 1e-5 * max(1.0, abs(best)), (k, mine, best)
+        assert info.lap.row_groups == chunk                                # no duplicated rows in single-cell mode
