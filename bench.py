@@ -208,10 +208,12 @@ def extra_c4_chunks(dev, K, distinct=4, cpu_n=5000, cpu_threads=64):
             "instance_seconds": round(t_gen, 1)}
 
 
-def extra_c4_sharded(dev, rank, world, dist, chunks_per_rank, G=5000, S=50000, chunk=10000):
+def extra_c4_sharded(dev, rank, world, dist, chunks_per_rank, G=5000, S=50000, chunk=10000, cell_sets=8):
     """BASELINE configs[3]'s structure on N GPUs (weak scaling: chunks_per_rank chunks of 10 000 cells per GPU against
     50 000 spots): rank 0 transforms the ST matrix and broadcasts the float32 operand over xGMI (RCCL; the one collective of
-    the path), every rank uploads only its own cells as raw counts and solves its chunks in one batched call."""
+    the path), every rank uploads only its own cells as raw counts and solves its chunks in one batched call.
+    (Synthetic: a rank draws cell_sets x 10 000 cells; chunk k uses cell set k % cell_sets with its own sub-spot slot draw,
+    so 64 chunks need the expression of 80 000 cells, not 640 000.)"""
     from cytospace_amd import _lib
     from cytospace_amd.cytospace import ExpressionContext
     K = 10
@@ -220,7 +222,8 @@ def extra_c4_sharded(dev, rank, world, dist, chunks_per_rank, G=5000, S=50000, c
     mult = g.lognormal(0.0, 0.75, (K, G)).astype(np.float32)
     t = time.perf_counter()
     r = np.random.default_rng(1000 + rank)
-    C = chunks_per_rank * chunk
+    cell_sets = max(1, min(cell_sets, chunks_per_rank))
+    C = cell_sets * chunk
     sc = np.empty((G, C), np.float32)
     for lo in range(0, C, 5000):
         ty = r.integers(0, K, 5000)
@@ -248,8 +251,8 @@ def extra_c4_sharded(dev, rank, world, dist, chunks_per_rank, G=5000, S=50000, c
     t0 = time.perf_counter()
     with ExpressionContext(sc, st, False, dev, comm=comm, n_spots=S) as ctx:
         t1 = time.perf_counter()
-        res = ctx.assign_chunks([(np.arange(k * chunk, (k + 1) * chunk), subs[k]) for k in range(chunks_per_rank)],
-                                return_info=True)
+        res = ctx.assign_chunks([(np.arange((k % cell_sets) * chunk, (k % cell_sets + 1) * chunk), subs[k])
+                                 for k in range(chunks_per_rank)], max_concurrent=chunks_per_rank, return_info=True)
         bcast_ms = ctx.bcast_ms
     sync()
     el = time.perf_counter() - t0
@@ -265,7 +268,8 @@ def extra_c4_sharded(dev, rank, world, dist, chunks_per_rank, G=5000, S=50000, c
     i0 = res[0][2]
     return {"workload": f"{world} GPU(s) x {chunks_per_rank} sub-spot chunks of {chunk} cells against {S} spots, {G} genes: "
                         "ST transformed on rank 0 + RCCL broadcast, per-rank raw-count upload, batched chunk solves",
-            "assignments_per_s": round(world * C / el, 1), "seconds": round(el, 2), "scaling": "weak",
+            "assignments_per_s": round(world * chunks_per_rank * chunk / el, 1), "seconds": round(el, 2), "scaling": "weak",
+            "cost_build_ms_per_rank": round(sum(r[2].ms_standardize + r[2].ms_gemm for r in res), 1),
             "context_s_rank0": round(t1 - t0, 3), "bcast_ms_rank0": None if bcast_ms is None else round(bcast_ms, 3),
             "bcast_bytes": int(-(-G // 32) * 32) * int(-(-S // 128) * 128) * 4,
             "chunk0": {"gather_ms": round(i0.ms_standardize, 2), "gemm_ms": round(i0.ms_gemm, 2), "spots_with_cells": int((subs[0] > 0).sum()),
@@ -290,7 +294,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no n50000 / c3 / c4_chunks)")
     ap.add_argument("--c4-chunks", type=int, default=256, help="concurrent chunk LAPs in the c4_chunks leg (256 = one chain per CU; 400 MB each)")
-    ap.add_argument("--c4-rank-chunks", type=int, default=8, help="chunks per rank in the c4_sharded leg")
+    ap.add_argument("--c4-rank-chunks", type=int, default=64, help="chunks per rank in the c4_sharded leg")
     ap.add_argument("--pmc-tag", default="r02b", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
     args = ap.parse_args()
 
