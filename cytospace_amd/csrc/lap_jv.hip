@@ -919,7 +919,8 @@ __device__ __forceinline__ uint32_t row_min_u32(uint32_t x) {
     x = umin32(x, dpp32<0x141>(x)); x = umin32(x, dpp32<0x140>(x));
     return x;
 }
-// all lanes active; result is wave-uniform (scalar)
+// all lanes active; result is wave-uniform (scalar).  (Combining the four row minima with the gfx9 cross-row DPP controls
+// row_bcast:15 / row_bcast:31 and one read-lane instead of four read-lanes + scalar mins was measured: 2 % slower.)
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
     x = row_min_u32(x);
     return umin32(umin32(readlane32(x, 0), readlane32(x, 16)), umin32(readlane32(x, 32), readlane32(x, 48)));
@@ -1680,6 +1681,26 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
 
 enum { PH_RT = 0, PH_ARR = 1, PH_AUG = 2 };
 
+// -DCYTO_ARR_PROF (tools/prof_arr_step.py): s_memtime stamps inside a cached ARR step (the loop runs on wave 0 alone)
+#ifdef CYTO_ARR_PROF
+__device__ long long g_arr_prof[16];
+#define RP_DECL long long rp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rp_t_ = 0, rp_n_ = 0;
+#define RP_START rp_t_ = (long long)__builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#define RP_STAMP(k) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); rp_[k] += now_ - rp_t_; rp_t_ = now_; }
+#define RP_WAITVM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define RP_WAITLDS asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#define RP_COUNT rp_n_++;
+#define RP_FLUSH if (threadIdx.x == 0) { for (int k_ = 0; k_ < 8; k_++) g_arr_prof[k_] = rp_[k_]; g_arr_prof[8] = rp_n_; }
+#else
+#define RP_DECL
+#define RP_START
+#define RP_STAMP(k)
+#define RP_WAITVM
+#define RP_WAITLDS
+#define RP_COUNT
+#define RP_FLUSH
+#endif
+
 // CS_LDS (only meaningful with !LDS_STATE, n <= 65535): the prices are too many for LDS but colsol (u16) still fits;
 // the chain then never stores colsol to global memory (on gfx9 a load is not returned before the stores issued
 // ahead of it are acknowledged, so every global store in the step delays the next step's gathers).
@@ -1746,6 +1767,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(const Chain2Args *__restrict
     bool have_dense = false;
     K2 gd; gd.m1 = KEYMAX; gd.m2 = KEYMAX;
     int napp = 0;                           // entries staged in s_app since the last flush
+    RP_DECL
 
     for (;;) {
         if (wave == 0) {
@@ -1823,6 +1845,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(const Chain2Args *__restrict
                 int pf_row = -1;
                 uint32_t pf_col = 0;
                 float pf_cv = 0.0f;
+                RP_START
                 for (;;) {
                     const int i = cur_i;
                     float umin, usub, vj1, cj1 = 0.0f, cj2 = 0.0f;
@@ -1843,11 +1866,15 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(const Chain2Args *__restrict
                             col = ld_u32(a.cache_col + (int64_t)i * KC + lane);
                             cv = ld_f32(a.cache_val + (int64_t)i * KC + lane);
                         }
+                        RP_WAITVM
+                        RP_STAMP(0)                                              // wait for the row's cache (L2)
                         const bool valid = col != COLSENT;
                         const float vj = st_vget<LDS_STATE>(s_v, gv, valid ? (int)col : 0);
                         const int32_t csj = st_csget<CSL>(s_cs, gcolsol, valid ? (int)col : 0);
                         const float F = __uint_as_float(readlane32(__float_as_uint(cv), KCU));
                         const uint32_t ord = valid ? f2ord(cv - vj) : 0xFFFFFFFFu;
+                        RP_WAITLDS
+                        RP_STAMP(1)                                              // LDS gathers of v and colsol
                         // minimum, its lane (ties: lowest column), then the minimum of the rest
                         const uint32_t o1 = wave_min_u32(ord);
                         const uint64_t m1 = __ballot(ord == o1);
@@ -1858,6 +1885,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(const Chain2Args *__restrict
                             pf_col = ld_u32(a.cache_col + (int64_t)pf_row * KC + lane);
                             pf_cv = ld_f32(a.cache_val + (int64_t)pf_row * KC + lane);
                         }
+                        RP_STAMP(2)                                              // first reduction, lane of the minimum, prefetch issue
                         const uint32_t o2 = wave_min_u32(lane == l1 ? 0xFFFFFFFFu : ord);
                         usub = ord2f(o2);
                         if (__builtin_expect(!(usub < F), 0)) {
@@ -1880,6 +1908,8 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(const Chain2Args *__restrict
                         }
                     }
                     c_arr++;
+                    RP_STAMP(3)                                                  // second reduction, read-lanes
+                    RP_COUNT
                     const float vnew = vj1 - (usub - umin);
                     const bool lowers = vnew < vj1;
                     const bool swap = !lowers && i0 >= 0;
@@ -1891,6 +1921,8 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(const Chain2Args *__restrict
                         if (lowers) st_vset<LDS_STATE>(s_v, gv, j1, vnew);
                         st_csset<CSL>(s_cs, gcolsol, jj, i);
                     }
+                    RP_WAITLDS
+                    RP_STAMP(4)                                                  // price / colsol update
                     if (__builtin_expect(i0f >= 0 && lowers && c_arr < arr_budget, 1)) { cur_i = i0f; continue; }   // chain goes on
                     if (i0f >= 0) {
                         if (lowers) carry = i0f;       // budget reached: the slow path flushes it
@@ -1942,6 +1974,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(const Chain2Args *__restrict
         counters[C2_DENSE_REFRESH] = c_dense;
         *reinterpret_cast<int *>(a.misc + 128) = numfree;
     }
+    RP_FLUSH
 }
 
 // AUGMENTATION + duals + total: one persistent workgroup, all lanes active (see chain_augment).
@@ -3283,6 +3316,14 @@ int cyto_lap_f64(int n, const double *cost, int64_t ld, int cost_on_device, int3
                  double *u, double *v, double *total, cyto_lap_info *info, int device_id, void *stream) {
     return cyto::lap_solve_f64(n, cost, ld, cost_on_device, rowsol, colsol, u, v, total, info, device_id, reinterpret_cast<hipStream_t>(stream), cyto::k_default_opts);
 }
+
+#ifdef CYTO_ARR_PROF
+// profiling build only (tools/prof_arr_step.py): the step-cycle accumulators of the last jv_chain2 launch
+int cyto_arr_prof_read(long long *out16) {
+    CYTO_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(cyto::g_arr_prof), sizeof(long long) * 16));
+    return CYTO_OK;
+}
+#endif
 
 #ifdef CYTO_AUG_PROF
 // profiling build only (tools/prof_aug_step.py): read and clear the step-cycle accumulators of the dense augmentation
