@@ -1391,7 +1391,10 @@ __device__ __forceinline__ float fmin3_raw(float a, float b, float c) {
 // d[j] (a later equal candidate never replaces it: updates are strict); so every scan logs (row, h), every retired
 // column logs the distance it was scanned at, and the <= ~40 columns of the augmenting path find their predecessors
 // afterwards by re-evaluating the logged candidates for that one column (reconstruct_pred).
-template <int CH, bool LDS_STATE, int BS>
+// LEAN (the usual configuration: the per-column auxiliaries and the duplicate-row group state are in LDS): the pick's look-ups
+// are plain LDS reads with no global-memory alternative compiled in -- the alternatives cost a branch each and a
+// `s_waitcnt vmcnt(0)` at every join.
+template <int CH, bool LDS_STATE, int BS, bool LEAN>
 __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__restrict__ cost, float *gv, float2 *sd,
                                              float *cassign, int32_t *rowsol, int32_t *gcolsol, int32_t *slog_row, float *slog_h,
                                              float *s_v, uint16_t *s_cs, int freerow, uint64_t validm, Scratch2 &s, int &par,
@@ -1508,8 +1511,9 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
             float hw = 0.0f, vjpw = 0.0f;
             if (wlk != 0xFFFFFFFFu && (wlk & 0x80000000u)) {          // (wave-uniform) an assigned column: its owner row
                 const int jpw = (int)(wlk & 0x7FFFFFFFu);
-                const float cipw = s_ca ? l_ca[jpw] : ld_f32(cassign + jpw);   // c[i][jp]
-                gw = gmode ? (s_cg ? (int)l_cg[jpw] : ld_i32(colgroup + jpw)) : 0;
+                float cipw;                                                     // c[i][jp]
+                if constexpr (LEAN) { cipw = l_ca[jpw]; gw = (int)l_cg[jpw]; }
+                else { cipw = s_ca ? l_ca[jpw] : ld_f32(cassign + jpw); gw = gmode ? (s_cg ? (int)l_cg[jpw] : ld_i32(colgroup + jpw)) : 0; }
                 if constexpr (LDS_STATE) { const uint16_t c16 = l_cs[jpw]; iw = c16 == 0xFFFFu ? -1 : (int32_t)c16; vjpw = l_v[jpw]; }
                 else { iw = ld_i32(gcolsol + jpw); vjpw = ld_f32(gv + jpw); }
                 hw = (cipw - vjpw) - dminw;
@@ -1519,7 +1523,7 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
                 // exactly as usual, only the row read and the relaxation sweep are elided.
                 if (gmode) {
                     float hbv; int hsv;
-                    if (gmode == 1) { hbv = l_hb[gw]; hsv = l_hs[gw]; }
+                    if (LEAN || gmode == 1) { hbv = l_hb[gw]; hsv = l_hs[gw]; }
                     else { hbv = ld_f32(hb + gw); hsv = ld_i32(hs + gw); }
                     skipw = ((hsv == stamp) && (hw <= hbv)) ? 1 : 0;
                 }
@@ -1557,7 +1561,7 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
             // the group's new best offset.  Every wave posts the same value: its own later look-ups (program order) see it
             // without another barrier, whichever wave is first
             const int grp = rw_g;
-            if (gmode == 1) { l_hb[grp] = h; l_hs[grp] = stamp; }
+            if (LEAN || gmode == 1) { l_hb[grp] = h; l_hs[grp] = stamp; }
             else { st_f32(hb + grp, h); st_i32(hs + grp, stamp); }
         }
         AP_STAMP(1)
@@ -1654,8 +1658,8 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
             __builtin_amdgcn_s_barrier();                     // every wave holds the old rowsol[i] before it is overwritten
             if (first == f) {                                 // the lane that evaluated the winning entry holds c[i][ep]
                 st_csset<LDS_STATE>(s_cs, gcolsol, ep, i);
-                if (s_ca) s_ca[ep] = cfirst; else st_f32(cassign + ep, cfirst);
-                if (gmode) { const int gi = rowgid[i]; if (s_cg) s_cg[ep] = (uint16_t)gi; else st_i32(colgroup + ep, gi); }
+                if (LEAN || s_ca) l_ca[ep] = cfirst; else st_f32(cassign + ep, cfirst);
+                if (gmode) { const int gi = rowgid[i]; if (LEAN || s_cg) l_cg[ep] = (uint16_t)gi; else st_i32(colgroup + ep, gi); }
                 st_i32(rowsol + i, ep);
             }
             c_hops++;
@@ -2052,8 +2056,14 @@ __global__ __launch_bounds__(BS) void jv_aug2(const Chain2Args *__restrict__ bat
     int err = 0;
     for (int f = a.aug_start; f < numfree && !err; f++) {
         const int freerow = __builtin_amdgcn_readfirstlane(ld_i32(freerows + f));
-        err = chain_augment<CH, LDS_STATE, BS>(n, ld, cost, gv, sd, cassign, rowsol, gcolsol, slog_row, slog_h, s_v, s_cs, freerow, validm, s,
-                                           par, c_relax, c_hops, c_skipped, gmode, a.rowgid, a.iws + 6 * (int64_t)n, hb, hs, f + 1, s_ca, s_cg, s_rec, a.rowmap);
+        if (LDS_STATE && a.auxlds && gmode != 2)
+            err = chain_augment<CH, LDS_STATE, BS, true>(n, ld, cost, gv, sd, cassign, rowsol, gcolsol, slog_row, slog_h, s_v, s_cs, freerow, validm,
+                                                         s, par, c_relax, c_hops, c_skipped, gmode, a.rowgid, a.iws + 6 * (int64_t)n, hb, hs, f + 1,
+                                                         s_ca, s_cg, s_rec, a.rowmap);
+        else
+            err = chain_augment<CH, LDS_STATE, BS, false>(n, ld, cost, gv, sd, cassign, rowsol, gcolsol, slog_row, slog_h, s_v, s_cs, freerow, validm,
+                                                          s, par, c_relax, c_hops, c_skipped, gmode, a.rowgid, a.iws + 6 * (int64_t)n, hb, hs, f + 1,
+                                                          s_ca, s_cg, s_rec, a.rowmap);
         c_augs++;
     }
     // ---- write back prices and colsol, then duals u and the total ----
