@@ -13,3 +13,5 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc -o wri
 mkdir -p $OUT/gemm_pmc
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/gemm_pmc -o gemm -- python $R/tools/gemm_only.py > $OUT/gemm_pmc/gemm.log 2>&1
 find $OUT -name "*.csv" | head -30
+# wave-stall reasons and LDS bank conflicts of the same GEMM (second PMC pass: the SQ block has 8 counters)
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/gemm_pmc -o gemm_stall -- python $R/tools/gemm_only.py > $OUT/gemm_pmc/gemm_stall.log 2>&1
