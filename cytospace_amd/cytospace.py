@@ -13,7 +13,7 @@ import time
 import numpy as np
 
 from . import _lib
-from .linear_assignment_solvers import calculate_cost, call_solver
+from .linear_assignment_solvers import calculate_cost, call_solver, match_solution
 
 
 def partition_indices(indices, split_by_category_list=None, split_by_interval_int=None, shuffle=True):
@@ -257,6 +257,18 @@ def solve_linear_assignment_problem(scRNA_norm_data, st_norm_data, cell_number_t
         assignment = call_solver(solver, solver_method, cost_scaled)
         print(f"Time to solve linear assignment problem: {round(time.perf_counter() - t0, 2)} seconds")
         return np.transpose(location_repeat[assignment]).tolist(), process_idx
+    if solver_method == 'lap_CSPR':
+        # cytospace.py:334-347: integerised cost 10^6 d + 10 rand + 1 (legacy RandomState stream), workers = cells
+        distance_repeat, location_repeat = calculate_cost(scRNA_norm_data, st_norm_data, cell_number_to_node_assignment,
+                                                          solver_method, distance_metric)
+        print('Solving linear assignment problem ...')
+        np.random.seed(seed)
+        cost_scaled = 10**6 * distance_repeat.astype(np.float64) + 10 * np.random.rand(*distance_repeat.shape) + 1
+        cost_scaled_int = np.transpose(cost_scaled).astype(int)
+        t0 = time.perf_counter()
+        assignment = match_solution(cost_scaled_int)
+        print(f"Time to solve linear assignment problem: {round(time.perf_counter() - t0, 2)} seconds")
+        return location_repeat[assignment[:, 0].astype(int)].tolist(), process_idx
     raise ValueError("Invalid solver_method provided")
 
 

@@ -269,6 +269,33 @@ def test_sparse_counts_are_expanded_on_the_device():
         gcommon.sparse_to_device(bad)
 
 
+def test_lap_cspr_branch_integerised_cost():
+    # cytospace.py:334-347 + linear_assignment_solvers.py:72-96: cost 10^6 d + 10 rand + 1 truncated to integers, workers =
+    # cells; OR-tools is not available, the exact integer optimum comes from scipy on the same integer matrix
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(21)
+    G, S, k = 150, 25, 4
+    sc = ocost.normalize_data(rng.poisson(3.0, (G, S * k)).astype(np.float64))
+    st = ocost.normalize_data(rng.poisson(9.0, (G, S)).astype(np.float64))
+    slots = np.full(S, k, np.int64)
+    mapped, idx = gcyto.solve_linear_assignment_problem(sc, st, slots, "lap_CSPR", None, 3, "Pearson_correlation", process_idx=2)
+    assert idx == 2 and np.array_equal(np.bincount(mapped, minlength=S), slots)
+    dist, loc = gsolvers.calculate_cost(sc, st, slots, "lap_CSPR", "Pearson_correlation")
+    np.random.seed(3)
+    ci = np.transpose(10**6 * dist.astype(np.float64) + 10 * np.random.rand(*dist.shape) + 1).astype(int)
+    mat = gsolvers.match_solution(ci.tolist())
+    r, c = linear_sum_assignment(ci)
+    assert int(mat[:, 1].sum()) == int(ci[r, c].sum())                       # an optimum of the integer problem
+    assert np.array_equal(np.sort(mat[:, 0]), np.arange(S * k))
+    assert np.array_equal(np.asarray(mapped), loc[mat[:, 0].astype(int)])
+    # zero-cost arcs are never used (the reference does not add them), non-square input is rejected
+    z = np.array([[0, 5, 9], [4, 0, 7], [8, 6, 0]])
+    m = gsolvers.match_solution(z)
+    assert np.all(z[np.arange(3), m[:, 0].astype(int)] != 0) and int(m[:, 1].sum()) == 9 + 4 + 6
+    with pytest.raises(ValueError):
+        gsolvers.match_solution(np.ones((2, 3), int))
+
+
 def _gv11_ss():
     d = load("gv11_apply_linear_assignment.npz")
     idx_sc = np.split(d["ss_idx_sc"], np.cumsum(d["ss_idx_sc_lens"])[:-1])
