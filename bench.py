@@ -18,6 +18,7 @@ workloads the north star names (skip them with --no-extras):
               GEMM (its own "roofline" against the 157.3 TFLOP/s f32 matrix peak), LAP; wall time includes the H2D copies
   "c4_chunks" K concurrent 10 000-cell --sampling-sub-spots chunk LAPs (configs[3]'s unit of work) on one GPU, with the
               CPU oracle run on all host cores beside it (core count stated)
+  "c5_chunks" configs[4]'s 50 single-cell-mode chunks (10 000 cells x 10 000 single-cell spots) in one batched call on one GPU
 and, at every N, "c4_sharded": configs[3]'s structure with the path's one collective -- rank 0 transforms the ST matrix and
 broadcasts the operand over xGMI (RCCL), every rank uploads its own cells and solves its chunks in one batched call.
 
@@ -208,6 +209,66 @@ def extra_c4_chunks(dev, K, distinct=4, cpu_n=5000, cpu_threads=64):
             "instance_seconds": round(t_gen, 1)}
 
 
+def extra_c5_chunks(dev, K=50, G=500, chunk=10000, sets=8, cpu_n=10000, cpu_threads=64):
+    """BASELINE configs[4]'s LAP work on ONE GPU: --single-cell mode partitions 500 000 cells x 500 000 single-cell spots into
+    50 chunks of <= 10 000 cells against <= 10 000 spots (cytospace.py:441-451; every slot count 1, no duplicated rows); here
+    all K chunks go through ONE batched context call (gather + fp32-MFMA cost build per chunk, then every LAP together).
+    (Synthetic, Xenium-like: a G-gene panel; `sets` x 10 000 cells and spots are drawn, chunk k pairs cell set k % sets with spot
+    set k // sets.)  CPU beside it: the oracle's LAP on the cost matrices of cpu_n-cell chunks (cost built by the GPU: numpy
+    needs 8 s per chunk for it), one chunk per thread."""
+    from concurrent.futures import ThreadPoolExecutor
+    from cytospace_amd import common
+    from cytospace_amd.cytospace import ExpressionContext
+    from cytospace_amd.lap import lap_solve
+    from oracle.jv import jv_oracle
+    from tools import instances
+    t = time.perf_counter()
+    sc, st = instances.single_cell_expression(G, sets * chunk, sets * chunk, seed=5)
+    t_gen = time.perf_counter() - t
+    ones = np.ones(chunk, np.int64)
+    work = [(np.arange((k % sets) * chunk, (k % sets + 1) * chunk), ones,
+             np.arange(((k // sets) % sets) * chunk, ((k // sets) % sets + 1) * chunk)) for k in range(K)]
+    t0 = time.perf_counter()
+    with ExpressionContext(sc, st, already_normalized=False, device_id=dev) as ctx:
+        ctx.assign_chunks(work[:1], max_concurrent=1)                                      # warm-up
+        t1 = time.perf_counter()
+        res = ctx.assign_chunks(work, max_concurrent=K, return_info=True)
+        wall = time.perf_counter() - t1
+    if not all(np.array_equal(np.sort(m), np.arange(chunk)) for m, _, _ in res):
+        raise SystemExit("c5_chunks: a chunk's mapping is not a permutation of its spots")
+    # ---- CPU sample: cpu_n-cell chunks, LAP only, same cost matrices on both sides (bit-exact comparison) ----
+    distinct = 2
+    costs = []
+    for k in range(distinct):
+        cb, N, ld, _ = common.pearson_cost_device(sc[:, k * cpu_n:(k + 1) * cpu_n], st[:, k * cpu_n:(k + 1) * cpu_n],
+                                                  np.ones(cpu_n, np.int64), dev, already_normalized=False)
+        costs.append(np.ascontiguousarray(cb.to_numpy((N, ld), np.float32)[:, :cpu_n]))
+        cb.free()
+    cores = _usable_cores()
+    T = max(1, min(cores, cpu_threads))
+    t = time.perf_counter()
+    with ThreadPoolExecutor(T) as ex:
+        ora = list(ex.map(lambda k: jv_oracle(costs[k % distinct], np.float32), range(T)))
+    cpu_wall = time.perf_counter() - t
+    gp = [lap_solve(costs[k], np.float32, device_id=dev, return_info=True) for k in range(distinct)]
+    if not all(np.array_equal(gp[k]["colsol"], ora[k]["colsol"]) and np.array_equal(gp[k]["v"], ora[k]["v"]) for k in range(min(distinct, T))):
+        raise SystemExit("c5_chunks: HIP result differs from the CPU oracle on the CPU sample")
+    i0 = res[0][2]
+    return {"workload": f"{K} single-cell-mode chunks ({chunk} cells x {chunk} single-cell spots, {G}-gene panel; configs[4] = 50 such chunks) "
+                        "through one batched context call on one GPU: per-chunk gather + MFMA cost build, then every LAP together",
+            "chunks": K, "wall_s": round(wall, 2), "assignments_per_s": round(K * chunk / wall, 1),
+            "context_s": round(t1 - t0, 2), "cost_build_ms_total": round(sum(r[2].ms_standardize + r[2].ms_gemm for r in res), 1),
+            "chunk0": {"lap_batch_kernel_ms": round(i0.lap.ms_total, 1), "jv_chain2_ms": round(i0.lap.ms_arr, 1),
+                       "augmentation_ms": round(i0.lap.ms_aug, 1), "row_scans": int(i0.lap.row_scans),
+                       "aug_scans": int(i0.lap.scans_aug_relax), "searches": int(i0.lap.augmentations)},
+            "cpu_baseline": {"value": round(T * cpu_n / cpu_wall, 1), "unit": "assignments/s", "cores": T, "kind": "port",
+                             "usable_cores": cores,
+                             "sample": f"oracle/jv_oracle.c (LAP only) on the cost matrices of {cpu_n}-cell single-cell chunks, {T} threads at once, "
+                                       f"one chunk each, {cpu_wall:.1f} s; the HIP solver gives bit-identical results on the same matrices "
+                                       f"({gp[0]['info'].ms_total:.0f} ms of kernels each)"},
+            "instance_seconds": round(t_gen, 1)}
+
+
 def extra_c4_sharded(dev, rank, world, dist, chunks_per_rank, G=5000, S=50000, chunk=10000, cell_sets=8):
     """BASELINE configs[3]'s structure on N GPUs (weak scaling: chunks_per_rank chunks of 10 000 cells per GPU against
     50 000 spots): rank 0 transforms the ST matrix and broadcasts the float32 operand over xGMI (RCCL; the one collective of
@@ -292,7 +353,7 @@ def main():
                     help="size of the bounded CPU-baseline sample (0: min(n, 20000); when it equals n the very same "
                          "instance is used and the GPU result is compared bit for bit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no n50000 / c3 / c4_chunks)")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no n50000 / c3 / c4_chunks / c5_chunks)")
     ap.add_argument("--c4-chunks", type=int, default=256, help="concurrent chunk LAPs in the c4_chunks leg (256 = one chain per CU; 400 MB each)")
     ap.add_argument("--c4-rank-chunks", type=int, default=64, help="chunks per rank in the c4_sharded leg")
     ap.add_argument("--pmc-tag", default="r02b", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
@@ -483,6 +544,7 @@ def main():
         out["n50000"] = extra_n50000(dev)
         out["c3"] = extra_c3(dev)
         out["c4_chunks"] = extra_c4_chunks(dev, args.c4_chunks)
+        out["c5_chunks"] = extra_c5_chunks(dev)
     json_out.write(json.dumps(out) + "\n")
     json_out.flush()
 

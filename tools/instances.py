@@ -158,3 +158,20 @@ def synth_expression(G, C, S, seed=1, K=10, dtype=np.float32):
         st[lo:hi][:, nz] = np.add.reduceat(blk, starts[nz], axis=1)
     del spot_of
     return sc, st, slots
+
+
+def single_cell_expression(G, C, S, seed=5, K=10, depth_st=0.6, dtype=np.float32):
+    """Single-cell-resolution ST (BASELINE configs[4]: every spot holds ONE cell, and its cells are not the scRNA cells): the same
+    gene means and cell-type multipliers as synth_expression, scRNA counts Poisson(0.3 m mult[type]), spot counts
+    Poisson(depth_st * 0.3 m mult[type']) for independently drawn types.  Returns (sc G x C, st G x S)."""
+    rng = np.random.default_rng(seed)
+    m = rng.lognormal(0.0, 1.5, G).astype(np.float32)
+    mult = rng.lognormal(0.0, 0.75, (K, G)).astype(np.float32)
+    sc = np.empty((G, C), dtype)
+    st = np.empty((G, S), dtype)
+    for out, n, depth in ((sc, C, 1.0), (st, S, depth_st)):
+        for lo in range(0, n, 5000):
+            hi = min(n, lo + 5000)
+            ty = rng.integers(0, K, hi - lo)
+            out[:, lo:hi] = rng.poisson(depth * 0.3 * m[:, None] * mult[ty].T)
+    return sc, st
