@@ -268,7 +268,6 @@ __global__ __launch_bounds__(256, 2) void pearson_gemm(int Gpad, int S, int C, c
     // genes are ~600x smaller, so are their truncation steps.  Measured at c3 size with FOLD = 1: every entry within 2e-6
     // (FOLD = 8: 21 of 4.8 M entries above, FOLD = 16: up to 3e-6 on correlations near 1); the 64 extra adds per tile hide
     // under the 64 MFMAs (122 TFLOP/s either way).
-    constexpr int FOLD = 1;
     f32x16 acc[2][2], sum[2][2];
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -286,12 +285,20 @@ __global__ __launch_bounds__(256, 2) void pearson_gemm(int Gpad, int S, int C, c
     //  through memory for every staged tile)
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     const int st_k = tid >> 5, st_c = (tid & 31) * 4;   // this thread's row / column inside a staging pass
-    const float *gA = A + (int64_t)st_k * lda + m0 + st_c;
-    const float *gB = B + (int64_t)st_k * ldb + n0 + st_c;
-#define GL1(r, g, ld_, k0, t) r = *reinterpret_cast<const float4 *>(g + (int64_t)((k0) + (t) * 8) * ld_);
+    // buffer loads: the descriptor's base is the (scalar) start of the tile's 32-row slab, the four passes are scalar
+    // offsets, the thread's place in the slab is ONE loop-invariant register -- no vector address arithmetic per tile
+    const uint32_t voA = (uint32_t)(((int64_t)st_k * lda + m0 + st_c) * 4), voB = (uint32_t)(((int64_t)st_k * ldb + n0 + st_c) * 4);
+    const uint32_t passA = (uint32_t)(8 * lda * 4), passB = (uint32_t)(8 * ldb * 4);
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+#define GL1(r, rs, vo, pass, t) { const u32x4_t t_ = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (t) * pass, 0);                  \
+                                  r = make_float4(__uint_as_float(t_.x), __uint_as_float(t_.y), __uint_as_float(t_.z), __uint_as_float(t_.w)); }
 #define GLOAD(k0)                                                                                   \
-    GL1(ra0, gA, lda, k0, 0) GL1(ra1, gA, lda, k0, 1) GL1(ra2, gA, lda, k0, 2) GL1(ra3, gA, lda, k0, 3)      \
-    GL1(rb0, gB, ldb, k0, 0) GL1(rb1, gB, ldb, k0, 1) GL1(rb2, gB, ldb, k0, 2) GL1(rb3, gB, ldb, k0, 3)
+    {                                                                                               \
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A + (int64_t)(k0) * lda), 0, 0x7FFFFFFF, 0x00020000); \
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B + (int64_t)(k0) * ldb), 0, 0x7FFFFFFF, 0x00020000); \
+        GL1(ra0, rsA, voA, passA, 0) GL1(ra1, rsA, voA, passA, 1) GL1(ra2, rsA, voA, passA, 2) GL1(ra3, rsA, voA, passA, 3) \
+        GL1(rb0, rsB, voB, passB, 0) GL1(rb1, rsB, voB, passB, 1) GL1(rb2, rsB, voB, passB, 2) GL1(rb3, rsB, voB, passB, 3) \
+    }
 #define LS1(Xs, buf, t, r) *reinterpret_cast<float4 *>(&Xs[buf][st_k + (t) * 8][st_c]) = r;
 #define LSTORE(buf)                                                                                 \
     LS1(As, buf, 0, ra0) LS1(As, buf, 1, ra1) LS1(As, buf, 2, ra2) LS1(As, buf, 3, ra3)                        \
@@ -302,39 +309,80 @@ __global__ __launch_bounds__(256, 2) void pearson_gemm(int Gpad, int S, int C, c
     __syncthreads();
     const int li = lane & 31, lk = lane >> 5;
     const int ao = wm * 64 + li, bo = wn * 64 + li;
-    for (int kt = 0; kt < nk; kt++) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) { GLOAD((kt + 1) * BK) }
-        float a0 = As[buf][lk][ao], a1 = As[buf][lk][ao + 32];
-        float b0 = Bs[buf][lk][bo], b1 = Bs[buf][lk][bo + 32];
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-            if (kk + 2 < BK) {
-                na0 = As[buf][kk + 2 + lk][ao]; na1 = As[buf][kk + 2 + lk][ao + 32];
-                nb0 = Bs[buf][kk + 2 + lk][bo]; nb1 = Bs[buf][kk + 2 + lk][bo + 32];
-            }
-            __builtin_amdgcn_sched_barrier(0);   // keep the reads of step kk+2 ahead of the MFMAs of step kk
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
-        }
-        if ((kt % FOLD) == FOLD - 1 || kt + 1 == nk) {
-#pragma unroll
-            for (int a = 0; a < 2; a++)
-#pragma unroll
-                for (int b = 0; b < 2; b++) {
-                    sum[a][b] += acc[a][b];
-#pragma unroll
-                    for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
-                }
-        }
-        if (kt + 1 < nk) { LSTORE(buf ^ 1) }
-        __syncthreads();
+    // LDS fragment reads as ds_read2st64_b32 (inline asm: the compiler pairs a0/a1 into ds_read2_b32, whose 8-bit offsets
+    // need a vector add per read): base = one loop-invariant per-lane register, the two offsets (units of 256 bytes) select
+    // the buffer and the k-steps kk and kk + 2.  The waits for these reads are explicit (the compiler does not see them):
+    // LDS operations retire in order, so "at most the four reads just issued are outstanding" covers the pair before.
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    const uint32_t pa0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)&As[0][lk][ao], pa1 = pa0 + 128;
+    const uint32_t pb0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)&Bs[0][lk][bo], pb1 = pb0 + 128;
+#define DSR(dst, base, o0) asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(base), "n"(o0), "n"((o0) + 4));
+#define FRAGS(BUF, kk, A0, A1, B0, B1) DSR(A0, pa0, (BUF) * 64 + (kk) * 2) DSR(A1, pa1, (BUF) * 64 + (kk) * 2)                   \
+                                       DSR(B0, pb0, (BUF) * 64 + (kk) * 2) DSR(B1, pb1, (BUF) * 64 + (kk) * 2)
+#define WAITF(n, A0, A1, B0, B1) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(A0), "+v"(A1), "+v"(B0), "+v"(B1));
+#define MFMA4(a0_, a1_, b0_, b1_)                                                                             \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b0_, acc[0][0], 0, 0, 0);                           \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b1_, acc[0][1], 0, 0, 0);                           \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b0_, acc[1][0], 0, 0, 0);                           \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b1_, acc[1][1], 0, 0, 0);
+    // the first step of a tile: every accumulator is folded into its sum right before the MFMA that restarts it from zero
+    // (C = 0, in place: the packed adds of one accumulator issue in the shadow of the previous accumulator's MFMA)
+#define RESTART(A, a_, b_) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(A) : "v"(a_), "v"(b_));
+#define MFMA4_FOLD(a0_, a1_, b0_, b1_)                                                                        \
+    sum[0][0] += acc[0][0]; __builtin_amdgcn_sched_barrier(0); RESTART(acc[0][0], a0_, b0_) __builtin_amdgcn_sched_barrier(0); \
+    sum[0][1] += acc[0][1]; __builtin_amdgcn_sched_barrier(0); RESTART(acc[0][1], a0_, b1_) __builtin_amdgcn_sched_barrier(0); \
+    sum[1][0] += acc[1][0]; __builtin_amdgcn_sched_barrier(0); RESTART(acc[1][0], a1_, b0_) __builtin_amdgcn_sched_barrier(0); \
+    sum[1][1] += acc[1][1]; __builtin_amdgcn_sched_barrier(0); RESTART(acc[1][1], a1_, b1_) __builtin_amdgcn_sched_barrier(0);
+    // pair p of a tile: steps kk = 4p (x) and 4p + 2 (y) from the registers of set CUR; the reads of pair p + 1 go to set NXT
+#define PAIR(BUF, p, CA0, CA1, CB0, CB1, NA0, NA1, NB0, NB1, STORES)                                          \
+    if ((p) < 7) { FRAGS(BUF, 4 * (p) + 4, NA0, NA1, NB0, NB1) WAITF(4, CA0, CA1, CB0, CB1) }                 \
+    else { WAITF(0, CA0, CA1, CB0, CB1) }                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    MFMA4(CA0.x, CA1.x, CB0.x, CB1.x)                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    STORES                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    MFMA4(CA0.y, CA1.y, CB0.y, CB1.y)                                                                         \
+    __builtin_amdgcn_sched_barrier(0);
+    // the staged tile goes to the other buffer two 16-byte stores per pair over the second half of the tile: a burst of eight
+    // at the end held up the other waves' fragment reads (tools/dbg/mfma_peak.hip: -5 %)
+#define TILE(BUF)                                                                                             \
+    {                                                                                                         \
+        f32x2v xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1;                                                        \
+        const bool more = kt + 1 < nk;                                                                        \
+        FRAGS(BUF, 0, xa0, xa1, xb0, xb1)                                                                     \
+        if (more) { GLOAD((kt + 1) * BK) }                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        PAIR(BUF, 0, xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1, )                                                \
+        PAIR(BUF, 1, ya0, ya1, yb0, yb1, xa0, xa1, xb0, xb1, )                                                \
+        PAIR(BUF, 2, xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1, )                                                \
+        PAIR(BUF, 3, ya0, ya1, yb0, yb1, xa0, xa1, xb0, xb1, if (more) { LS1(As, (BUF) ^ 1, 0, ra0) LS1(As, (BUF) ^ 1, 1, ra1) }) \
+        PAIR(BUF, 4, xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1, if (more) { LS1(As, (BUF) ^ 1, 2, ra2) LS1(As, (BUF) ^ 1, 3, ra3) }) \
+        PAIR(BUF, 5, ya0, ya1, yb0, yb1, xa0, xa1, xb0, xb1, if (more) { LS1(Bs, (BUF) ^ 1, 0, rb0) LS1(Bs, (BUF) ^ 1, 1, rb1) }) \
+        PAIR(BUF, 6, xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1, if (more) { LS1(Bs, (BUF) ^ 1, 2, rb2) LS1(Bs, (BUF) ^ 1, 3, rb3) }) \
+        PAIR(BUF, 7, ya0, ya1, yb0, yb1, xa0, xa1, xb0, xb1, )                                                \
+        _Pragma("unroll") for (int a = 0; a < 2; a++)                                                         \
+            _Pragma("unroll") for (int b = 0; b < 2; b++) {                                                   \
+                sum[a][b] += acc[a][b];                                                                       \
+                _Pragma("unroll") for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;                           \
+            }                                                                                                 \
+        __syncthreads();                                                                                      \
+        kt++;                                                                                                 \
     }
+    int kt = 0;
+    while (kt + 1 < nk) {
+        TILE(0)
+        TILE(1)
+    }
+    if (kt < nk) TILE(0)
+#undef DSR
+#undef FRAGS
+#undef WAITF
+#undef MFMA4
+#undef RESTART
+#undef MFMA4_FOLD
+#undef PAIR
+#undef TILE
 #undef GLOAD
 #undef LSTORE
 #undef GL1
