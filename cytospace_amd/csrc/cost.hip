@@ -226,6 +226,9 @@ __global__ __launch_bounds__(1024) void rank_columns(int G, int C, const TIn *__
 // Block tile 128 (spots) x 128 (cells) x 32 (genes), 4 waves, each wave 64x64 = 2x2 MFMA tiles.
 // ------------------------------------------------------------------------------------------
 constexpr int BM = 128, BN = 128, BK = 32;
+#ifndef GEMM_FOLD
+#define GEMM_FOLD 2
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // EPI 0: cost = -dot (Pearson / Spearman on standardised operands);
@@ -263,11 +266,13 @@ __global__ __launch_bounds__(256, 2) void pearson_gemm(int Gpad, int S, int C, c
     const int wm = wave >> 1, wn = wave & 1;
 
     // Two-level accumulation: the matrix cores add into `acc` for FOLD k-tiles (32 genes each), then `acc` is folded into
-    // `sum` with ordinary round-to-nearest adds and cleared.  The MFMA accumulate truncates: one running fp32 sum over
-    // 20 000 genes (config c3) ended ~1e-5 below the float64 reference (up to 7e-5), always towards zero; partial sums of 32
-    // genes are ~600x smaller, so are their truncation steps.  Measured at c3 size with FOLD = 1: every entry within 2e-6
-    // (FOLD = 8: 21 of 4.8 M entries above, FOLD = 16: up to 3e-6 on correlations near 1); the 64 extra adds per tile hide
-    // under the 64 MFMAs (122 TFLOP/s either way).
+    // `sum` with ordinary round-to-nearest adds and restarted from zero (C = 0 in the next tile's first MFMAs).  The MFMA
+    // accumulate truncates: one running fp32 sum over 20 000 genes (config c3) ended ~1e-5 below the float64 reference (up to
+    // 7e-5), always towards zero; partial sums of 32 genes are ~600x smaller, so are their truncation steps.  Measured at c3
+    // size with FOLD = 1: every entry within 2e-6 (FOLD = 8: 21 of 4.8 M entries above, FOLD = 16: up to 3e-6 on
+    // correlations near 1).  The 32 packed adds per fold are not free: every VALU instruction costs the matrix pipe 4-8 cycles.
+    constexpr int FOLD = GEMM_FOLD;
+    static_assert(FOLD == 1 || FOLD == 2, "the tile loop is unrolled by two");
     f32x16 acc[2][2], sum[2][2];
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -325,18 +330,10 @@ __global__ __launch_bounds__(256, 2) void pearson_gemm(int Gpad, int S, int C, c
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b1_, acc[0][1], 0, 0, 0);                           \
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b0_, acc[1][0], 0, 0, 0);                           \
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b1_, acc[1][1], 0, 0, 0);
-    // the first step of a tile: every accumulator is folded into its sum right before the MFMA that restarts it from zero
-    // (C = 0, in place: the packed adds of one accumulator issue in the shadow of the previous accumulator's MFMA)
-#define RESTART(A, a_, b_) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(A) : "v"(a_), "v"(b_));
-#define MFMA4_FOLD(a0_, a1_, b0_, b1_)                                                                        \
-    sum[0][0] += acc[0][0]; __builtin_amdgcn_sched_barrier(0); RESTART(acc[0][0], a0_, b0_) __builtin_amdgcn_sched_barrier(0); \
-    sum[0][1] += acc[0][1]; __builtin_amdgcn_sched_barrier(0); RESTART(acc[0][1], a0_, b1_) __builtin_amdgcn_sched_barrier(0); \
-    sum[1][0] += acc[1][0]; __builtin_amdgcn_sched_barrier(0); RESTART(acc[1][0], a1_, b0_) __builtin_amdgcn_sched_barrier(0); \
-    sum[1][1] += acc[1][1]; __builtin_amdgcn_sched_barrier(0); RESTART(acc[1][1], a1_, b1_) __builtin_amdgcn_sched_barrier(0);
     // pair p of a tile: steps kk = 4p (x) and 4p + 2 (y) from the registers of set CUR; the reads of pair p + 1 go to set NXT
 #define PAIR(BUF, p, CA0, CA1, CB0, CB1, NA0, NA1, NB0, NB1, STORES)                                          \
-    if ((p) < 7) { FRAGS(BUF, 4 * (p) + 4, NA0, NA1, NB0, NB1) WAITF(4, CA0, CA1, CB0, CB1) }                 \
-    else { WAITF(0, CA0, CA1, CB0, CB1) }                                                                     \
+    if ((p) < 7) { FRAGS(BUF, 4 * (p) + 4, NA0, NA1, NB0, NB1) }                                              \
+    WAITF(4, CA0, CA1, CB0, CB1)                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
     MFMA4(CA0.x, CA1.x, CB0.x, CB1.x)                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
@@ -344,15 +341,16 @@ __global__ __launch_bounds__(256, 2) void pearson_gemm(int Gpad, int S, int C, c
     __builtin_amdgcn_sched_barrier(0);                                                                        \
     MFMA4(CA0.y, CA1.y, CB0.y, CB1.y)                                                                         \
     __builtin_amdgcn_sched_barrier(0);
-    // the staged tile goes to the other buffer two 16-byte stores per pair over the second half of the tile: a burst of eight
-    // at the end held up the other waves' fragment reads (tools/dbg/mfma_peak.hip: -5 %)
-#define TILE(BUF)                                                                                             \
+    // One tile out of buffer BUF (compile-time: the loop is unrolled over the two buffers).  On entry set x holds the
+    // fragments of its first pair and the global loads of tile kt + 1 are in flight.  The staged tile goes to the other buffer
+    // two 16-byte stores per pair over pairs 3-6 (a burst of eight at the end held up the other waves' fragment reads,
+    // tools/dbg/mfma_peak.hip: -5 %).  The workgroup barrier sits BEFORE the last pair: by then every read of this buffer
+    // has been issued (pair 7's fragments during pair 6) and is complete (the barrier's lgkmcnt(0)), and the stores of tile
+    // kt + 1 are done -- so the next tile's first fragments and the loads of tile kt + 2 are requested right after the
+    // barrier and arrive behind the eight MFMAs of pair 7: no gap in the MFMA stream at the tile boundary.
+#define TILE(BUF, FOLDNOW)                                                                                    \
     {                                                                                                         \
-        f32x2v xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1;                                                        \
         const bool more = kt + 1 < nk;                                                                        \
-        FRAGS(BUF, 0, xa0, xa1, xb0, xb1)                                                                     \
-        if (more) { GLOAD((kt + 1) * BK) }                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
         PAIR(BUF, 0, xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1, )                                                \
         PAIR(BUF, 1, ya0, ya1, yb0, yb1, xa0, xa1, xb0, xb1, )                                                \
         PAIR(BUF, 2, xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1, )                                                \
@@ -360,27 +358,33 @@ __global__ __launch_bounds__(256, 2) void pearson_gemm(int Gpad, int S, int C, c
         PAIR(BUF, 4, xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1, if (more) { LS1(As, (BUF) ^ 1, 2, ra2) LS1(As, (BUF) ^ 1, 3, ra3) }) \
         PAIR(BUF, 5, ya0, ya1, yb0, yb1, xa0, xa1, xb0, xb1, if (more) { LS1(Bs, (BUF) ^ 1, 0, rb0) LS1(Bs, (BUF) ^ 1, 1, rb1) }) \
         PAIR(BUF, 6, xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1, if (more) { LS1(Bs, (BUF) ^ 1, 2, rb2) LS1(Bs, (BUF) ^ 1, 3, rb3) }) \
-        PAIR(BUF, 7, ya0, ya1, yb0, yb1, xa0, xa1, xb0, xb1, )                                                \
-        _Pragma("unroll") for (int a = 0; a < 2; a++)                                                         \
-            _Pragma("unroll") for (int b = 0; b < 2; b++) {                                                   \
-                sum[a][b] += acc[a][b];                                                                       \
-                _Pragma("unroll") for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;                           \
-            }                                                                                                 \
         __syncthreads();                                                                                      \
+        if (more) { FRAGS((BUF) ^ 1, 0, xa0, xa1, xb0, xb1) }                                                 \
+        if (kt + 2 < nk) { GLOAD((kt + 2) * BK) }                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        PAIR(BUF, 7, ya0, ya1, yb0, yb1, xa0, xa1, xb0, xb1, )                                                \
+        if (FOLDNOW || !more) {                                                                               \
+            _Pragma("unroll") for (int a = 0; a < 2; a++)                                                     \
+                _Pragma("unroll") for (int b = 0; b < 2; b++) {                                               \
+                    sum[a][b] += acc[a][b];                                                                   \
+                    _Pragma("unroll") for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;                       \
+                }                                                                                             \
+        }                                                                                                     \
         kt++;                                                                                                 \
     }
+    f32x2v xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1;
     int kt = 0;
+    FRAGS(0, 0, xa0, xa1, xb0, xb1)
+    if (nk > 1) { GLOAD(BK) }
     while (kt + 1 < nk) {
-        TILE(0)
-        TILE(1)
+        TILE(0, FOLD == 1)
+        TILE(1, true)
     }
-    if (kt < nk) TILE(0)
+    if (kt < nk) TILE(0, true)
 #undef DSR
 #undef FRAGS
 #undef WAITF
 #undef MFMA4
-#undef RESTART
-#undef MFMA4_FOLD
 #undef PAIR
 #undef TILE
 #undef GLOAD
