@@ -222,8 +222,15 @@ __global__ __launch_bounds__(1024) void rank_columns(int G, int C, const TIn *__
 // ------------------------------------------------------------------------------------------
 // cost[r][c] = - sum_g zst[g][s] * zsc[g][c]   for every LAP row r of spot s
 // TN GEMM: both operands are stored gene-major, so a k-slice of either tile is a contiguous row
-// segment (coalesced 16-B global loads, conflict-free ds_read_b32 fragment reads).
-// Block tile 128 (spots) x 128 (cells) x 32 (genes), 4 waves, each wave 64x64 = 2x2 MFMA tiles.
+// segment (coalesced 16-byte loads straight into LDS, conflict-free fragment reads).
+// Block tile 128 (spots) x 128 (cells) x 32 (genes), 4 waves, each wave 64x64 = 2x2 MFMA tiles, two workgroups per CU.
+//
+// WHAT BOUNDS THE TILE LOOP (tools/dbg/mfma_peak.hip): the matrix pipe sustains 99 % of its peak with this MFMA sequence and
+// these LDS fragment reads, but every VALU instruction issued among the MFMAs costs it 4-8 cycles.  The first version of
+// this kernel spent 34 LDS-address adds, 32 packed adds (fold), ~16 global-address computations and a burst of eight
+// ds_write_b128 per 32-gene tile and reached 79 % (124 TFLOP/s at c3 size).  Now the loop needs (almost) no VALU work:
+// LDS fragments by ds_read2st64_b32 (one loop-invariant per-lane base + immediates), operands by buffer loads straight
+// into LDS (scalar row offsets), the fold every second tile -- 140 TFLOP/s = 89 %.
 // ------------------------------------------------------------------------------------------
 constexpr int BM = 128, BN = 128, BK = 32;
 #ifndef GEMM_FOLD
@@ -281,36 +288,30 @@ __global__ __launch_bounds__(256, 2) void pearson_gemm(int Gpad, int S, int C, c
 #pragma unroll
             for (int r = 0; r < 16; r++) { acc[a][b][r] = 0.0f; sum[a][b][r] = 0.0f; }
 
-    // staging: 4 float4 per thread per operand per k-tile, register-staged double buffering:
-    // the global loads of tile t+1 are issued before the MFMAs of tile t and written to the other LDS
-    // buffer afterwards; inside a tile the A/B fragments of step kk+2 are read from LDS before the four
-    // MFMAs of step kk are issued (explicit register ping-pong), so LDS latency hides under the matrix pipe.
-    // (eight named registers, not two arrays: inside these macros the unroll pragma was not honoured, the arrays were
-    //  indexed dynamically and ended up in scratch and in an LDS-promoted alloca -- 16 KB more LDS per block and a round trip
-    //  through memory for every staged tile)
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    // staging: direct-to-LDS buffer loads (buffer_load_dwordx4 ... lds), double buffered.  The descriptor's base is the
+    // (scalar) start of the tile's 32-row slab, the four passes are scalar offsets, the thread's place in the slab is ONE
+    // loop-invariant register -- no vector address arithmetic per tile.  Lane l of a wave writes 16 bytes at M0 + 16 l,
+    // i.e. a wave fills the two 128-float k-rows 2w + 8t, 2w + 8t + 1 of the tile; no staging registers, no ds_write.
+    // (Round 1-2 staged through eight float4 registers and eight ds_write_b128: same speed once the stores were spread over the
+    //  tile, but 90 more VGPRs.)
     const int st_k = tid >> 5, st_c = (tid & 31) * 4;   // this thread's row / column inside a staging pass
-    // buffer loads: the descriptor's base is the (scalar) start of the tile's 32-row slab, the four passes are scalar
-    // offsets, the thread's place in the slab is ONE loop-invariant register -- no vector address arithmetic per tile
     const uint32_t voA = (uint32_t)(((int64_t)st_k * lda + m0 + st_c) * 4), voB = (uint32_t)(((int64_t)st_k * ldb + n0 + st_c) * 4);
     const uint32_t passA = (uint32_t)(8 * lda * 4), passB = (uint32_t)(8 * ldb * 4);
-    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-#define GL1(r, rs, vo, pass, t) { const u32x4_t t_ = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (t) * pass, 0);                  \
-                                  r = make_float4(__uint_as_float(t_.x), __uint_as_float(t_.y), __uint_as_float(t_.z), __uint_as_float(t_.w)); }
-#define GLOAD(k0)                                                                                   \
+    const int nk = Gpad / BK;
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+#define DL1(Xs, BUF, rs, vo, pass, t) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)&Xs[BUF][2 * wave_s + 8 * (t)][0], 16, vo, (t) * pass, 0, 0);
+#define DLOAD(k0, BUF)                                                                              \
     {                                                                                               \
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A + (int64_t)(k0) * lda), 0, 0x7FFFFFFF, 0x00020000); \
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B + (int64_t)(k0) * ldb), 0, 0x7FFFFFFF, 0x00020000); \
-        GL1(ra0, rsA, voA, passA, 0) GL1(ra1, rsA, voA, passA, 1) GL1(ra2, rsA, voA, passA, 2) GL1(ra3, rsA, voA, passA, 3) \
-        GL1(rb0, rsB, voB, passB, 0) GL1(rb1, rsB, voB, passB, 1) GL1(rb2, rsB, voB, passB, 2) GL1(rb3, rsB, voB, passB, 3) \
+        DL1(As, BUF, rsA, voA, passA, 0) DL1(As, BUF, rsA, voA, passA, 1) DL1(As, BUF, rsA, voA, passA, 2) DL1(As, BUF, rsA, voA, passA, 3) \
+        DL1(Bs, BUF, rsB, voB, passB, 0) DL1(Bs, BUF, rsB, voB, passB, 1) DL1(Bs, BUF, rsB, voB, passB, 2) DL1(Bs, BUF, rsB, voB, passB, 3) \
     }
-#define LS1(Xs, buf, t, r) *reinterpret_cast<float4 *>(&Xs[buf][st_k + (t) * 8][st_c]) = r;
-#define LSTORE(buf)                                                                                 \
-    LS1(As, buf, 0, ra0) LS1(As, buf, 1, ra1) LS1(As, buf, 2, ra2) LS1(As, buf, 3, ra3)                        \
-    LS1(Bs, buf, 0, rb0) LS1(Bs, buf, 1, rb1) LS1(Bs, buf, 2, rb2) LS1(Bs, buf, 3, rb3)
-    const int nk = Gpad / BK;
-    GLOAD(0)
-    LSTORE(0)
+    // the loads' arrival in LDS is awaited explicitly (vmcnt): the fragment reads below are inline asm the compiler cannot see
+#define DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DLOAD(0, 0)
+    DMA_WAIT()
     __syncthreads();
     const int li = lane & 31, lk = lane >> 5;
     const int ao = wm * 64 + li, bo = wn * 64 + li;
@@ -331,38 +332,36 @@ __global__ __launch_bounds__(256, 2) void pearson_gemm(int Gpad, int S, int C, c
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b0_, acc[1][0], 0, 0, 0);                           \
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b1_, acc[1][1], 0, 0, 0);
     // pair p of a tile: steps kk = 4p (x) and 4p + 2 (y) from the registers of set CUR; the reads of pair p + 1 go to set NXT
-#define PAIR(BUF, p, CA0, CA1, CB0, CB1, NA0, NA1, NB0, NB1, STORES)                                          \
+#define PAIR(BUF, p, CA0, CA1, CB0, CB1, NA0, NA1, NB0, NB1)                                                  \
     if ((p) < 7) { FRAGS(BUF, 4 * (p) + 4, NA0, NA1, NB0, NB1) }                                              \
     WAITF(4, CA0, CA1, CB0, CB1)                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
     MFMA4(CA0.x, CA1.x, CB0.x, CB1.x)                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
-    STORES                                                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                        \
     MFMA4(CA0.y, CA1.y, CB0.y, CB1.y)                                                                         \
     __builtin_amdgcn_sched_barrier(0);
     // One tile out of buffer BUF (compile-time: the loop is unrolled over the two buffers).  On entry set x holds the
-    // fragments of its first pair and the global loads of tile kt + 1 are in flight.  The staged tile goes to the other buffer
-    // two 16-byte stores per pair over pairs 3-6 (a burst of eight at the end held up the other waves' fragment reads,
-    // tools/dbg/mfma_peak.hip: -5 %).  The workgroup barrier sits BEFORE the last pair: by then every read of this buffer
-    // has been issued (pair 7's fragments during pair 6) and is complete (the barrier's lgkmcnt(0)), and the stores of tile
-    // kt + 1 are done -- so the next tile's first fragments and the loads of tile kt + 2 are requested right after the
-    // barrier and arrive behind the eight MFMAs of pair 7: no gap in the MFMA stream at the tile boundary.
+    // fragments of its first pair and the direct-to-LDS loads of tile kt + 1 are in flight into the other buffer.  The
+    // workgroup barrier sits BEFORE the last pair: by then every read of this buffer has been issued (pair 7's fragments
+    // during pair 6) and is complete (the barrier's lgkmcnt(0)), and tile kt + 1 has landed (vmcnt(0)) -- so the next tile's
+    // first fragments are requested right after the barrier and arrive behind the eight MFMAs of pair 7, and the loads of
+    // tile kt + 2 can already overwrite THIS tile's buffer.
 #define TILE(BUF, FOLDNOW)                                                                                    \
     {                                                                                                         \
         const bool more = kt + 1 < nk;                                                                        \
-        PAIR(BUF, 0, xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1, )                                                \
-        PAIR(BUF, 1, ya0, ya1, yb0, yb1, xa0, xa1, xb0, xb1, )                                                \
-        PAIR(BUF, 2, xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1, )                                                \
-        PAIR(BUF, 3, ya0, ya1, yb0, yb1, xa0, xa1, xb0, xb1, if (more) { LS1(As, (BUF) ^ 1, 0, ra0) LS1(As, (BUF) ^ 1, 1, ra1) }) \
-        PAIR(BUF, 4, xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1, if (more) { LS1(As, (BUF) ^ 1, 2, ra2) LS1(As, (BUF) ^ 1, 3, ra3) }) \
-        PAIR(BUF, 5, ya0, ya1, yb0, yb1, xa0, xa1, xb0, xb1, if (more) { LS1(Bs, (BUF) ^ 1, 0, rb0) LS1(Bs, (BUF) ^ 1, 1, rb1) }) \
-        PAIR(BUF, 6, xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1, if (more) { LS1(Bs, (BUF) ^ 1, 2, rb2) LS1(Bs, (BUF) ^ 1, 3, rb3) }) \
+        PAIR(BUF, 0, xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1)                                                  \
+        PAIR(BUF, 1, ya0, ya1, yb0, yb1, xa0, xa1, xb0, xb1)                                                  \
+        PAIR(BUF, 2, xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1)                                                  \
+        PAIR(BUF, 3, ya0, ya1, yb0, yb1, xa0, xa1, xb0, xb1)                                                  \
+        PAIR(BUF, 4, xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1)                                                  \
+        PAIR(BUF, 5, ya0, ya1, yb0, yb1, xa0, xa1, xb0, xb1)                                                  \
+        PAIR(BUF, 6, xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1)                                                  \
+        DMA_WAIT()                                                                                            \
         __syncthreads();                                                                                      \
         if (more) { FRAGS((BUF) ^ 1, 0, xa0, xa1, xb0, xb1) }                                                 \
-        if (kt + 2 < nk) { GLOAD((kt + 2) * BK) }                                                             \
+        if (kt + 2 < nk) { DLOAD((kt + 2) * BK, BUF) }                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
-        PAIR(BUF, 7, ya0, ya1, yb0, yb1, xa0, xa1, xb0, xb1, )                                                \
+        PAIR(BUF, 7, ya0, ya1, yb0, yb1, xa0, xa1, xb0, xb1)                                                  \
         if (FOLDNOW || !more) {                                                                               \
             _Pragma("unroll") for (int a = 0; a < 2; a++)                                                     \
                 _Pragma("unroll") for (int b = 0; b < 2; b++) {                                               \
@@ -375,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void pearson_gemm(int Gpad, int S, int C, c
     f32x2v xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1;
     int kt = 0;
     FRAGS(0, 0, xa0, xa1, xb0, xb1)
-    if (nk > 1) { GLOAD(BK) }
+    if (nk > 1) { DLOAD(BK, 1) }
     while (kt + 1 < nk) {
         TILE(0, FOLD == 1)
         TILE(1, true)
@@ -387,14 +386,22 @@ __global__ __launch_bounds__(256, 2) void pearson_gemm(int Gpad, int S, int C, c
 #undef MFMA4
 #undef PAIR
 #undef TILE
-#undef GLOAD
-#undef LSTORE
-#undef GL1
-#undef LS1
+#undef DL1
+#undef DLOAD
+#undef DMA_WAIT
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // rowstart == nullptr: every slot count is 1, row = spot (the unique-row storage and single-cell mode).  Otherwise the
+    // 16 row ranges of an accumulator are fetched together first (one round trip, not sixteen dependent ones).
 #pragma unroll
     for (int a = 0; a < 2; a++) {
+        int r0s[16], r1s[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int s = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            r0s[r] = s; r1s[r] = s + 1;
+            if (rowstart && s < S) { r0s[r] = rowstart[s]; r1s[r] = rowstart[s + 1]; }
+        }
 #pragma unroll
         for (int b = 0; b < 2; b++) {
             const int c = n0 + wn * 64 + b * 32 + li;
@@ -405,8 +412,8 @@ __global__ __launch_bounds__(256, 2) void pearson_gemm(int Gpad, int S, int C, c
                     float val;
                     if constexpr (EPI == 0) val = -sum[a][b][r];
                     else { const double d2 = na[s] + nb[c] - 2.0 * (double)sum[a][b][r]; val = (float)sqrt(d2 > 0.0 ? d2 : 0.0); }
-                    const int r0 = rowstart[s], r1 = rowstart[s + 1];
-                    for (int row = r0; row < r1; row++) cost[(int64_t)row * ldc + c] = val;
+                    if (!rowstart) cost[(int64_t)s * ldc + c] = val;
+                    else for (int row = r0s[r]; row < r1s[r]; row++) cost[(int64_t)row * ldc + c] = val;
                 }
             }
         }
@@ -560,16 +567,20 @@ static int cost_gemm(int euclid, int Gpad, int S, int C, const float *zst, int64
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     std::vector<int> rowstart((size_t)S + 1);
     int64_t acc = 0;
+    bool identity = true;                                  // every slot count 1 (unique-row storage, single-cell mode): row = spot
     for (int s = 0; s < S; s++) {
         if (slots[s] < 0) return CYTO_ERR_BAD_ARG;
         rowstart[s] = (int)acc;
         acc += slots[s];
+        identity = identity && slots[s] == 1;
         if (acc > 0x7FFFFFFF) return CYTO_ERR_UNSUPPORTED;
     }
     rowstart[S] = (int)acc;
     DevBuf drs;
-    if ((rc = drs.alloc(((size_t)S + 1) * sizeof(int), stream))) return rc;
-    CYTO_HIP(hipMemcpyAsync(drs.p, rowstart.data(), ((size_t)S + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
+    if (!identity) {
+        if ((rc = drs.alloc(((size_t)S + 1) * sizeof(int), stream))) return rc;
+        CYTO_HIP(hipMemcpyAsync(drs.p, rowstart.data(), ((size_t)S + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
+    }
     const int tiles_m = (S + BM - 1) / BM, tiles_n = (C + BN - 1) / BN;
     Events<2> ev;
     if ((rc = ev.create())) return rc;
