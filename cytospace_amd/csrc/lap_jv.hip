@@ -2159,7 +2159,9 @@ __device__ __forceinline__ void gl_min_u64(uint64_t *p, uint64_t x) {
     (void)__hip_atomic_fetch_min(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// -DLZ_PROF (tools/prof_lazy_step.py): s_memtime stamps of wave 0 inside a cache-certified augmentation step
 #ifdef LZ_PROF
+__device__ long long g_lz_prof[24];
 #define LZ_STAMP(k) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)"); \
                       if ((k) > 0) prof[k] += now_ - tlast; else if (tlast) prof[0] += 0; tlast = now_; profn[k]++; }
 #define LZ_WAITVM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2545,6 +2547,9 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(const LazyArgs *__restrict
                             lds_min_u64(bmin + (j >> 6), ((uint64_t)o2 << 32) | (un ? 0u : 0x80000000u) | (uint32_t)j);
                             if (un) atomicMin(&s_T, o2);
                         }
+#ifdef LZ_PROF
+                        prof2[1] += __builtin_popcountll(__ballot(act));
+#endif
                     }
                     LZ_STAMP(4)
                     if (nexc > 0) {
@@ -2748,10 +2753,9 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(const LazyArgs *__restrict
         *reinterpret_cast<int *>(a.misc + 136) = f;          // searches completed (== numfree unless the kernel gave up)
         *reinterpret_cast<int *>(a.misc + 4) = err;
 #ifdef LZ_PROF
-        long long *pp = reinterpret_cast<long long *>(a.misc + 152);
-        for (int k = 0; k < 6; k++) { pp[k] = prof[k]; pp[6 + k] = profn[k]; }
-        for (int k = 0; k < 4; k++) pp[k] = prof2[k] / (c_augs ? c_augs : 1);
-        pp[6] = c_augs;
+        for (int k = 0; k < 6; k++) { g_lz_prof[k] = prof[k]; g_lz_prof[6 + k] = profn[k]; }
+        for (int k = 0; k < 4; k++) g_lz_prof[12 + k] = prof2[k];
+        g_lz_prof[16] = c_augs; g_lz_prof[17] = c_relax; g_lz_prof[18] = c_dense; g_lz_prof[19] = c_sparse;
 #endif
     }
 }
@@ -3331,6 +3335,14 @@ int cyto_lap_f64(int n, const double *cost, int64_t ld, int cost_on_device, int3
 // profiling build only (tools/prof_arr_step.py): the step-cycle accumulators of the last jv_chain2 launch
 int cyto_arr_prof_read(long long *out16) {
     CYTO_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(cyto::g_arr_prof), sizeof(long long) * 16));
+    return CYTO_OK;
+}
+#endif
+
+#ifdef LZ_PROF
+// profiling build only (tools/prof_lazy_step.py): the step-cycle accumulators of the last jv_aug_lazy launch
+int cyto_lz_prof_read(long long *out24) {
+    CYTO_HIP(hipMemcpyFromSymbol(out24, HIP_SYMBOL(cyto::g_lz_prof), sizeof(long long) * 24));
     return CYTO_OK;
 }
 #endif
