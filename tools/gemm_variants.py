@@ -3,7 +3,7 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from cytospace_amd import build as B
-VARIANTS = {"dma": [], "regs": ["-DGEMM_DMA=0"]}
+VARIANTS = {"fold2": [], "fold1": ["-DGEMM_FOLD=1"]}      # name -> extra hipcc flags (GEMM_FOLD: k-tiles per fold)
 names = [a for a in sys.argv[1:] if not a.startswith("--")] or list(VARIANTS)
 if "--run-one" in sys.argv:
     from cytospace_amd import _lib
