@@ -51,7 +51,7 @@ def test_gv3_calculate_cost_rows_and_slots():
             assert np.array_equal(dist[r], dist[r - 1])
 
 
-@pytest.mark.parametrize("G,S,C", [(33, 5, 7), (200, 130, 260), (1000, 257, 513)])
+@pytest.mark.parametrize("G,S,C", [(20, 3, 4), (33, 5, 7), (90, 129, 131), (200, 130, 260), (1000, 257, 513)])      # 1, 2, 3, 7, 32 k-tiles
 def test_cost_vs_numpy_odd_shapes(G, S, C):
     rng = np.random.default_rng(G + S + C)
     sc = rng.poisson(3.0, (G, C)).astype(np.float64)
