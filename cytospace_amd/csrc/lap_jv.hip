@@ -334,6 +334,8 @@ template <typename T> struct ChainArgs {
     int *status;         // [1] out (0 ok)
     T *dwork;            // [n] scratch (jv_chain_stream: distances)
     int32_t *lvl;        // [n] scratch (jv_chain_stream: level at which a column was scanned; 0 = not scanned)
+    const uint32_t *cache_col;   // [n x 64] jv_chain_stream: row caches (build_row_caches_wide), or nullptr
+    const T *cache_val;          // [n x 64]
 };
 
 // The persistent chain kernels run one workgroup per PROBLEM: a batch of independent chunk LAPs is one launch with
@@ -348,6 +350,8 @@ __device__ __forceinline__ int32_t ld_i32(const int32_t *p) {
 __device__ __forceinline__ void st_i32(int32_t *p, int32_t x) {
     __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+template <typename T> __device__ __forceinline__ T ld_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <typename T, int CH, bool COLSOL_LDS>
 __global__ __launch_bounds__(BLOCK) void jv_chain(ChainArgs<T> a) {
@@ -630,6 +634,83 @@ __global__ __launch_bounds__(BLOCK) void jv_chain(ChainArgs<T> a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Row caches for jv_chain_stream (the float64 chain beyond n = 4 096): the idea of the float32 fast path below -- prices
+// only decrease during REDUCTION TRANSFER and AUGMENTING ROW REDUCTION, so the (at most) 63 columns of a row with the
+// smallest reduced costs at build time, together with the 64th smallest reduced cost F (the floor), stay a certificate:
+// a later scan whose second-smallest recomputed cached value is < F has found the row's exact lexicographic top-2 --
+// in its simplest form.  One workgroup per row; the 64th smallest of the n order-preserving 64-bit keys is found bit by
+// bit (64 counting passes over the row, which stays in L2), then the columns below it are written in column order with
+// their raw costs.  Slot 63 holds the floor.
+// ------------------------------------------------------------------------------------------
+constexpr int WC_KC = 64;                          // slots per row; slot 63 = { sentinel, floor }
+constexpr uint32_t WC_SENT = 0xFFFFFFFFu;
+template <typename T> __device__ __forceinline__ uint64_t wide_ord(T h);
+template <> __device__ __forceinline__ uint64_t wide_ord<double>(double h) {
+    const uint64_t b = (uint64_t)__double_as_longlong(h + 0.0);
+    return b ^ ((uint64_t)((int64_t)b >> 63) | 0x8000000000000000ull);
+}
+template <> __device__ __forceinline__ uint64_t wide_ord<float>(float h) {
+    const uint32_t b = __float_as_uint(h + 0.0f);
+    return (uint64_t)(b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u)) << 32;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void build_row_caches_wide(int n, int64_t ld, const T *__restrict__ cost, const T *__restrict__ v,
+                                                             uint32_t *__restrict__ cache_col, T *__restrict__ cache_val) {
+    __shared__ int s_cnt[2][4];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = blockIdx.x;
+    const T *row = cost + (int64_t)i * ld;
+    uint64_t K = 0;
+    int par = 0;
+    if (n >= WC_KC) {
+        for (int b = 63; b >= 0; b--) {
+            const uint64_t cand = K | (1ull << b);
+            int c = 0;
+            for (int j = tid; j < n; j += 256) c += wide_ord<T>(row[j] - v[j]) < cand;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+            if (lane == 0) s_cnt[par][w] = c;
+            __syncthreads();
+            const int tot = s_cnt[par][0] + s_cnt[par][1] + s_cnt[par][2] + s_cnt[par][3];
+            par ^= 1;
+            if (tot < WC_KC) K = cand;             // fewer than 64 keys below cand: the 64th smallest is >= cand
+        }
+    } else K = ~0ull;                              // fewer than 64 columns: all of them are cached, the floor is +inf
+    // K is now the 64th smallest key: at most 63 keys are strictly below it, and its value is the floor
+    if (tid == 0) { s_base = 0; if (n < WC_KC) cache_val[(int64_t)i * WC_KC + WC_KC - 1] = (T)INFINITY; }
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + tid;
+        const T c = j < n ? row[j] : (T)0;
+        const T h = j < n ? c - v[j] : (T)0;
+        const uint64_t key = j < n ? wide_ord<T>(h) : ~0ull;
+        const bool sel = j < n && key < K;
+        if (j < n && n >= WC_KC && key == K) cache_val[(int64_t)i * WC_KC + WC_KC - 1] = h;   // (equal keys = equal values)
+        const uint64_t m = __ballot(sel);
+        if (lane == 0) s_cnt[par][w] = __builtin_popcountll(m);
+        __syncthreads();
+        int off = s_base;
+        for (int ww = 0; ww < w; ww++) off += s_cnt[par][ww];
+        const int tot = s_cnt[par][0] + s_cnt[par][1] + s_cnt[par][2] + s_cnt[par][3];
+        if (sel) {
+            const int pos = off + __builtin_popcountll(m & ((1ull << lane) - 1));
+            cache_col[(int64_t)i * WC_KC + pos] = (uint32_t)j;
+            cache_val[(int64_t)i * WC_KC + pos] = c;
+        }
+        __syncthreads();
+        if (tid == 0) s_base = off + tot;          // (thread 0 is in wave 0: its off is the running base)
+        par ^= 1;
+        __syncthreads();
+    }
+    const int used = s_base;
+    for (int p = used + tid; p < WC_KC; p += 256) {
+        cache_col[(int64_t)i * WC_KC + p] = WC_SENT;
+        if (p < WC_KC - 1) cache_val[(int64_t)i * WC_KC + p] = (T)0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // The same chain with every per-column quantity (prices, distances, predecessors, scan levels) in L2-resident
 // global memory instead of VGPRs: jv_chain<double, CH> spills badly beyond CH = 2 (1024 threads leave 128 VGPRs
 // per lane), this variant has no per-lane arrays at all and takes any n.  Column c is only ever touched by thread
@@ -642,6 +723,8 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
     using V = typename VecOf<T>::type;
     constexpr int VW = VecOf<T>::W;
     __shared__ RedScratch<T> red;
+    __shared__ int s_run[4];
+    __shared__ long long s_run_arr;
     const int tid = threadIdx.x;
     const int n = a.n;
     const int64_t ld = a.ld;
@@ -653,7 +736,8 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
     const int nq = (n + VW - 1) / VW;                  // vector chunks per row (rows and v are VW-aligned and padded)
     const V *vp = reinterpret_cast<const V *>(v);
 
-    long long c_rt = 0, c_arr = 0, c_auginit = 0, c_augrelax = 0, c_augs = 0, c_hops = 0, c_free_a1 = 0;
+    long long c_rt = 0, c_arr = 0, c_auginit = 0, c_augrelax = 0, c_augs = 0, c_hops = 0, c_free_a1 = 0, c_dense = 0;
+    const int lane = tid & 63;
     int numfree = 0, nrt = 0;
     {
         const int R = (n + BLOCK - 1) / BLOCK;
@@ -676,18 +760,36 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
         for (int k = 0; k < nrt; k++) {
             const int i = ld_i32(a.rtrows + k);
             const int j1 = ld_i32(a.rowsol + i);
-            const V *rp = reinterpret_cast<const V *>(cost + (int64_t)i * ld);
-            Min1<T> loc; loc.u = INF; loc.k = 0; loc.a = 0;
-            for (int q = tid; q < nq; q += BLOCK) {
-                const V x = rp[q], vv = vp[q];
+            T mn = INF;
+            bool certified = false;
+            if (a.cache_col) {
+                // cached scan, by every wave for itself (same loads, same result: no exchange needed)
+                const uint32_t col = a.cache_col[(int64_t)i * WC_KC + lane];
+                const T cv = a.cache_val[(int64_t)i * WC_KC + lane];
+                const T F = __shfl(cv, WC_KC - 1);
+                T h = INF;
+                if (col != WC_SENT && (int)col != j1) h = cv - ld_agent(v + col);
 #pragma unroll
-                for (int e = 0; e < VW; e++) {
-                    const int c = q * VW + e;
-                    if (c < n && c != j1) { const T h = vec_get<T>(x, e) - vec_get<T>(vv, e); if (h < loc.u) loc.u = h; }
-                }
+                for (int off = 32; off >= 1; off >>= 1) { const T o = __shfl_xor(h, off); h = o < h ? o : h; }
+                mn = h;
+                certified = mn < F;                    // every column outside the cache is still >= F
             }
-            const Min1<T> g = wg_min1(loc, red, par);
-            if (((j1 / VW) % BLOCK) == tid) v[j1] = v[j1] - g.u;
+            if (!certified) {
+                const V *rp = reinterpret_cast<const V *>(cost + (int64_t)i * ld);
+                Min1<T> loc; loc.u = INF; loc.k = 0; loc.a = 0;
+                for (int q = tid; q < nq; q += BLOCK) {
+                    const V x = rp[q], vv = vp[q];
+#pragma unroll
+                    for (int e = 0; e < VW; e++) {
+                        const int c = q * VW + e;
+                        if (c < n && c != j1) { const T h = vec_get<T>(x, e) - vec_get<T>(vv, e); if (h < loc.u) loc.u = h; }
+                    }
+                }
+                mn = wg_min1(loc, red, par).u;
+                c_dense++;
+            }
+            if (((j1 / VW) % BLOCK) == tid) v[j1] = v[j1] - mn;
+            if (a.cache_col) __syncthreads();          // the new price has reached L2 (the barrier waits for the store) before any wave gathers it
             c_rt++;
         }
     }
@@ -700,25 +802,90 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
         numfree = 0;
         int carry = -1;
         while (carry >= 0 || k < prev) {
-            if (c_arr >= arr_budget) {
+            int pend = -1;
+            if (a.cache_col) {
+                // ---- wave 0 alone follows the displacement chains while the row caches certify its scans: no barrier, no
+                // other wave involved.  Lane = cache entry: the row's cache (requested as soon as the previous step knew the
+                // next row), one round of gathers (price and owner of every cached column), the top-2 by wave shuffles,
+                // the step's stores from lane 0 (agent scope: the wave's own later gathers see them, in L2).  It stops at the
+                // first row whose cache does not certify its top-2 (that row is then scanned by the whole workgroup, below),
+                // at the end of the sweep's list, or at the step budget. ----
+                if (tid < 64) {
+                    int pf_row = -1;
+                    uint32_t pf_col = WC_SENT;
+                    T pf_cv = 0;
+                    while ((carry >= 0 || k < prev) && c_arr < arr_budget) {
+                        const bool from_carry = carry >= 0;
+                        const int i = from_carry ? carry : ld_i32(a.freerows + k);
+                        uint32_t col; T cv;
+                        if (pf_row == i) { col = pf_col; cv = pf_cv; }
+                        else { col = ld_agent(a.cache_col + (int64_t)i * WC_KC + lane); cv = ld_agent(a.cache_val + (int64_t)i * WC_KC + lane); }
+                        const T F = __shfl(cv, WC_KC - 1);
+                        const bool valid = col != WC_SENT;
+                        const T vj = ld_agent(v + (valid ? col : 0u));
+                        const int32_t csj = ld_i32(a.colsol + (valid ? col : 0u));
+                        Top2<T> g;
+                        g.u1 = INF; g.k1 = 0xFFFFFFFFu; g.a1 = 0; g.u2 = INF; g.k2 = 0xFFFFFFFFu;
+                        if (valid) { g.u1 = cv - vj; g.k1 = col; g.a1 = vj; }
+#pragma unroll
+                        for (int off = 32; off >= 1; off >>= 1) top2_merge(g, top2_shfl_xor(g, off));
+                        if (from_carry) carry = -1; else k++;                 // the row is taken, certified or not
+                        if (!(g.u2 < F)) { pend = i; break; }                 // (u2 < F: (u1, k1), (u2, k2) are the row's exact top-2)
+                        c_arr++;
+                        int j1 = (int)g.k1;
+                        const int j2 = (int)g.k2;
+                        const int l1 = __builtin_ctzll(__ballot(valid && col == g.k1)), l2 = __builtin_ctzll(__ballot(valid && col == g.k2) | (1ull << 63));
+                        int i0 = __shfl(csj, l1);
+                        const T vj1 = g.a1;
+                        const T vnew = vj1 - (g.u2 - g.u1);
+                        const bool lowers = vnew < vj1;
+                        if (!lowers && i0 >= 0) { j1 = j2; i0 = __shfl(csj, l2); }
+                        if (i0 >= 0 && lowers) {                              // the chain goes on with row i0: request its cache now
+                            pf_row = i0;
+                            pf_col = ld_agent(a.cache_col + (int64_t)i0 * WC_KC + lane);
+                            pf_cv = ld_agent(a.cache_val + (int64_t)i0 * WC_KC + lane);
+                        }
+                        if (lane == 0) {
+                            if (lowers) __hip_atomic_store(v + (int)g.k1, vnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            st_i32(a.rowsol + i, j1); st_i32(a.colsol + j1, i);
+                            if (i0 >= 0 && !lowers) st_i32(a.freerows + numfree, i0);
+                        }
+                        if (i0 >= 0) { if (lowers) carry = i0; else numfree++; }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // the stores have reached L2
+                    if (lane == 0) { s_run[0] = k; s_run[1] = carry; s_run[2] = numfree; s_run[3] = pend; s_run_arr = c_arr; }
+                }
+                __syncthreads();
+                k = s_run[0]; carry = s_run[1]; numfree = s_run[2]; pend = s_run[3]; c_arr = s_run_arr;
+                __syncthreads();                                             // (s_run is rewritten by the next run)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // wave 0's prices: drop what this CU's L1 holds
+                if (pend < 0 && c_arr < arr_budget) continue;                // the sweep's list is exhausted
+            }
+            if (pend < 0 && c_arr >= arr_budget) {
                 if (carry >= 0) { if (tid == 0) st_i32(a.freerows + numfree, carry); numfree++; carry = -1; }
                 while (k < prev) { const int r = ld_i32(a.freerows + k); k++; if (tid == 0) st_i32(a.freerows + numfree, r); numfree++; }
                 break;
             }
             int i;
-            if (carry >= 0) { i = carry; carry = -1; }
+            if (pend >= 0) i = pend;
+            else if (carry >= 0) { i = carry; carry = -1; }
             else { i = ld_i32(a.freerows + k); k++; }
-            const V *rp = reinterpret_cast<const V *>(cost + (int64_t)i * ld);
-            Top2<T> loc; loc.u1 = INF; loc.k1 = 0xFFFFFFFFu; loc.a1 = 0; loc.u2 = INF; loc.k2 = 0xFFFFFFFFu;
-            for (int q = tid; q < nq; q += BLOCK) {
-                const V x = rp[q], vv = vp[q];
+            Top2<T> g;
+            const bool certified = false;
+            if (!certified) {
+                const V *rp = reinterpret_cast<const V *>(cost + (int64_t)i * ld);
+                Top2<T> loc; loc.u1 = INF; loc.k1 = 0xFFFFFFFFu; loc.a1 = 0; loc.u2 = INF; loc.k2 = 0xFFFFFFFFu;
+                for (int q = tid; q < nq; q += BLOCK) {
+                    const V x = rp[q], vv = vp[q];
 #pragma unroll
-                for (int e = 0; e < VW; e++) {
-                    const int c = q * VW + e;
-                    if (c < n) top2_push(loc, vec_get<T>(x, e) - vec_get<T>(vv, e), (uint32_t)c, vec_get<T>(vv, e));
+                    for (int e = 0; e < VW; e++) {
+                        const int c = q * VW + e;
+                        if (c < n) top2_push(loc, vec_get<T>(x, e) - vec_get<T>(vv, e), (uint32_t)c, vec_get<T>(vv, e));
+                    }
                 }
+                g = wg_top2(loc, red, par);
+                c_dense++;
             }
-            const Top2<T> g = wg_top2(loc, red, par);
             c_arr++;
             int j1 = (int)g.k1;
             const int j2 = (int)g.k2;
@@ -740,6 +907,7 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
         if (sweep == 0) c_free_a1 = numfree;
     }
     const long long c_free_a2 = numfree;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 
     // ---- AUGMENTATION: relaxation and the search for the next pick share one sweep ----
     int err = 0;
@@ -845,7 +1013,7 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
         a.counters[C_RT] = c_rt; a.counters[C_ARR] = c_arr; a.counters[C_AUG_INIT] = c_auginit;
         a.counters[C_AUG_RELAX] = c_augrelax; a.counters[C_AUGS] = c_augs; a.counters[C_HOPS] = c_hops;
         a.counters[C_FREE_CR] = c_free_cr; a.counters[C_FREE_A1] = c_free_a1; a.counters[C_FREE_A2] = c_free_a2;
-        a.counters[C_ROWS_READ] = c_rt + c_arr + c_auginit + c_augrelax;
+        a.counters[C_ROWS_READ] = (a.cache_col ? c_dense : c_rt + c_arr) + c_auginit + c_augrelax;
         *a.status = err;
     }
 }
@@ -3215,10 +3383,19 @@ static int lap_solve_f64(int n, const double *cost, int64_t ld, int cost_on_devi
     ca.counters = reinterpret_cast<long long *>(b_misc.as<char>() + 16);
     ca.status = b_misc.as<int>() + 1;
     ca.dwork = d_v + 4 * (size_t)n; ca.lvl = d_rowsol + 7 * (size_t)n;
-    // register-resident chain while it does not spill (n <= 4096), else everything streams from L2
+    ca.cache_col = nullptr; ca.cache_val = nullptr;
+    // register-resident chain while it does not spill (n <= 4096), else everything streams from L2 -- with row caches
+    // against the post-column-reduction prices for REDUCTION TRANSFER and AUGMENTING ROW REDUCTION
+    // (opts.chain_variant == 2: without them, every scan reads its row)
     const int64_t per = (int64_t)VW * BLOCK;
+    DevBuf b_ccol, b_cval;
     if (n <= 2 * per && opts.chain_variant == 0) rc = launch_chain<T, 2, true>(ca, stream);
     else {
+        if (opts.chain_variant != 2) {
+            if ((rc = b_ccol.alloc((size_t)n * WC_KC * sizeof(uint32_t), stream)) || (rc = b_cval.alloc((size_t)n * WC_KC * sizeof(T), stream))) return rc;
+            hipLaunchKernelGGL(build_row_caches_wide<T>, dim3(n), dim3(256), 0, stream, n, dld, dcost, d_v, b_ccol.as<uint32_t>(), b_cval.as<T>());
+            ca.cache_col = b_ccol.as<uint32_t>(); ca.cache_val = b_cval.as<T>();
+        }
         hipLaunchKernelGGL(jv_chain_stream<T>, dim3(1), dim3(BLOCK), 0, stream, ca);
         rc = hipGetLastError() == hipSuccess ? CYTO_OK : CYTO_ERR_HIP;
     }

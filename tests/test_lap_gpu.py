@@ -316,3 +316,28 @@ def test_row_map_argument_validation():
             lap_solve_rows(rows, np.array(bad, np.int32))
     with pytest.raises(ValueError):
         lap_solve_rows(rows, np.array([0, 0, 1, 1, 2], np.int32))                    # n != number of columns
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_float64_streaming_chain_with_and_without_row_caches(variant):
+    # float64 beyond n = 4096 runs jv_chain_stream; chain_variant 1 = with the 63-column row caches for reduction transfer and
+    # augmenting row reduction (the default there), 2 = every scan reads its row.  Forced here at sizes the oracle solves quickly.
+    opts = dict(chain_variant=variant)
+    for n in (2, 5, 63, 64, 65, 300, 1500):
+        c = np.random.default_rng(n).random((n, n))
+        _check(c, np.float64, opts)
+    c = np.random.default_rng(5).integers(0, 10, (400, 400)).astype(np.float64)      # heavy ties: the floor ties with cached values
+    _check(c, np.float64, opts)
+    rng = np.random.default_rng(8)
+    c = np.repeat(-(rng.random((100, 500)) ** 3), 5, axis=0)                           # duplicated rows
+    _check(c, np.float64, opts)
+    c = c + 1e-16 * np.random.RandomState(1).rand(*c.shape)                            # CytoSPACE's perturbation (cytospace.py:325-327)
+    _check(c, np.float64, opts)
+
+
+def test_float64_default_path_above_4096():
+    n = 4500
+    c = np.random.default_rng(n).random((n, n))
+    g = lap_solve(c, np.float64, return_info=True)
+    _check(c, np.float64)
+    assert g["info"].hbm_row_reads < g["info"].scans_redtransfer + g["info"].scans_arr      # most scans were served by the caches
