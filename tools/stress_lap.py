@@ -26,6 +26,10 @@ def make(kind, n, rng):
     raise ValueError(kind)
 
 if __name__ == "__main__":
+    f64 = "--f64" in sys.argv                 # float64 through the streaming chain with row caches (chain_variant 1) at any size
+    sys.argv = [a for a in sys.argv if a != "--f64"]
+    dt = np.float64 if f64 else np.float32
+    opts = dict(chain_variant=1) if f64 else None
     seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 36
     lo, hi = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (5200, 8200)
@@ -36,10 +40,11 @@ if __name__ == "__main__":
         rng = np.random.default_rng(1000 + s)
         kind = kinds[s % len(kinds)]; n = int(rng.integers(lo, hi))
         c = make(kind, n, rng)
-        g = lap_solve(c, np.float32, return_info=True); o = jv_oracle(c, np.float32)
+        if f64: c = c.astype(np.float64) + (1e-16 * rng.random(c.shape) if s % 2 else 0.0)
+        g = lap_solve(c, dt, return_info=True, opts=opts); o = jv_oracle(c, dt)
         ok = all(np.array_equal(g[k], o[k]) for k in ("rowsol", "colsol", "u", "v")) and g["info"].row_scans == o["stats"].row_scans
         i = g["info"]
-        print(f"{s:3d} {kind:9s} n={n}: {'ok ' if ok else 'MISMATCH'} aug scans {i.scans_aug_relax} dense {i.aug_dense_scans} sparse {i.aug_sparse_inits}/{i.augmentations} "
+        print(f"{s:3d} {kind:9s} n={n}: {'ok ' if ok else 'MISMATCH'} rows read {i.hbm_row_reads} of {i.row_scans} scans, aug scans {i.scans_aug_relax} dense {i.aug_dense_scans} sparse {i.aug_sparse_inits}/{i.augmentations} "
               f"handover {i.aug_handover} arr refresh {i.dense_refreshes} {i.ms_total:.0f} ms", flush=True)
         bad += (not ok)
     print(f"{count} instances, {bad} mismatches, {time.time()-t0:.0f}s")
