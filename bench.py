@@ -193,6 +193,9 @@ def extra_c4_chunks(dev, K, distinct=4, cpu_n=5000, cpu_threads=64):
     return {"workload": f"{K} concurrent {n} x {n} sub-spot chunk LAPs ({distinct} distinct seeded instances, every chain on its own copy), "
                         "cost resident in HBM, ONE launch per chain phase with a workgroup per chunk",
             "chunks": K, "wall_s": round(wall, 2), "assignments_per_s": round(K * n / wall, 1),
+            # what the 256 chains together draw from HBM: every full-row scan reads its 4 n bytes (the cached scans read none)
+            "hbm_rows_read": int(sum(r["info"].hbm_row_reads for r in res)),
+            "hbm_GBs_rows_read": round(sum(r["info"].hbm_row_reads for r in res) * 4.0 * n / wall / 1e9, 1),
             "one_chunk_alone": {"wall_s": round(wall1, 2), "assignments_per_s": round(n / wall1, 1), "kernel_ms": round(i0.ms_total, 1),
                                 "jv_chain2_ms": round(i0.ms_arr, 1), "augmentation_ms": round(i0.ms_aug, 1),
                                 "row_scans": int(i0.row_scans), "aug_scans": int(i0.scans_aug_relax),
