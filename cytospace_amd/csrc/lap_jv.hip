@@ -633,6 +633,9 @@ __global__ __launch_bounds__(BLOCK) void jv_chain(ChainArgs<T> a) {
     }
 }
 
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x);       // (defined with the float32 fast path below)
+__device__ __forceinline__ uint64_t wave_lexmin_u64(uint64_t k);
+
 // ------------------------------------------------------------------------------------------
 // Row caches for jv_chain_stream (the float64 chain beyond n = 4 096): the idea of the float32 fast path below -- prices
 // only decrease during REDUCTION TRANSFER and AUGMENTING ROW REDUCTION, so the (at most) 63 columns of a row with the
@@ -725,6 +728,13 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
     __shared__ RedScratch<T> red;
     __shared__ int s_run[4];
     __shared__ long long s_run_arr;
+    // with the row caches (n <= 65 535): colsol lives in LDS as u16 during REDUCTION TRANSFER / AUGMENTING ROW REDUCTION -- the cached
+    // step then gathers the owners from LDS and stores nothing but a lowered price to global memory (a load is only returned
+    // after the stores issued before it are acknowledged)
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_cs[];
+    uint16_t *const s_cs16 = reinterpret_cast<uint16_t *>(dyn_cs);
+    const bool csl = a.cache_col != nullptr && a.n <= 65535;
+#define CS_GET(j) (csl ? (s_cs16[j] == 0xFFFFu ? -1 : (int32_t)s_cs16[j]) : ld_i32(a.colsol + (j)))
     const int tid = threadIdx.x;
     const int n = a.n;
     const int64_t ld = a.ld;
@@ -752,6 +762,7 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
             else if (mt == 1) st_i32(a.rtrows + og++, i);
         }
     }
+    if (csl) for (int c = tid; c < n; c += BLOCK) { const int32_t r = a.colsol[c]; s_cs16[c] = r < 0 ? (uint16_t)0xFFFFu : (uint16_t)r; }
     __syncthreads();
     const long long c_free_cr = numfree;
 
@@ -823,31 +834,37 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
                         const T F = __shfl(cv, WC_KC - 1);
                         const bool valid = col != WC_SENT;
                         const T vj = ld_agent(v + (valid ? col : 0u));
-                        const int32_t csj = ld_i32(a.colsol + (valid ? col : 0u));
-                        Top2<T> g;
-                        g.u1 = INF; g.k1 = 0xFFFFFFFFu; g.a1 = 0; g.u2 = INF; g.k2 = 0xFFFFFFFFu;
-                        if (valid) { g.u1 = cv - vj; g.k1 = col; g.a1 = vj; }
-#pragma unroll
-                        for (int off = 32; off >= 1; off >>= 1) top2_merge(g, top2_shfl_xor(g, off));
-                        if (from_carry) carry = -1; else k++;                 // the row is taken, certified or not
-                        if (!(g.u2 < F)) { pend = i; break; }                 // (u2 < F: (u1, k1), (u2, k2) are the row's exact top-2)
-                        c_arr++;
-                        int j1 = (int)g.k1;
-                        const int j2 = (int)g.k2;
-                        const int l1 = __builtin_ctzll(__ballot(valid && col == g.k1)), l2 = __builtin_ctzll(__ballot(valid && col == g.k2) | (1ull << 63));
+                        const int32_t csj = CS_GET(valid ? col : 0u);
+                        // the smallest reduced cost and its lane (cache rows are sorted by column: the lowest lane is the lowest
+                        // column), then the smallest of the rest: reductions on order-preserving 64-bit keys, as in the float32 chain
+                        const T h = valid ? cv - vj : INF;
+                        const uint64_t kh = valid ? wide_ord<T>(h) : ~0ull;
+                        const uint64_t m1 = wave_lexmin_u64(kh);
+                        const int l1 = __builtin_ctzll(__ballot(kh == m1) | (1ull << 63));
                         int i0 = __shfl(csj, l1);
-                        const T vj1 = g.a1;
-                        const T vnew = vj1 - (g.u2 - g.u1);
-                        const bool lowers = vnew < vj1;
-                        if (!lowers && i0 >= 0) { j1 = j2; i0 = __shfl(csj, l2); }
-                        if (i0 >= 0 && lowers) {                              // the chain goes on with row i0: request its cache now
+                        if (i0 >= 0 && m1 != ~0ull) {                         // (almost always) the next row of the chain: request its cache now
                             pf_row = i0;
                             pf_col = ld_agent(a.cache_col + (int64_t)i0 * WC_KC + lane);
                             pf_cv = ld_agent(a.cache_val + (int64_t)i0 * WC_KC + lane);
                         }
+                        const uint64_t kh2 = lane == l1 ? ~0ull : kh;
+                        const uint64_t m2 = wave_lexmin_u64(kh2);
+                        const int l2 = __builtin_ctzll(__ballot(kh2 == m2) | (1ull << 63));
+                        const T u1 = __shfl(h, l1), u2 = m2 == ~0ull ? INF : __shfl(h, l2);
+                        if (from_carry) carry = -1; else k++;                 // the row is taken, certified or not
+                        if (!(u2 < F)) { pend = i; break; }                   // (u2 < F: these are the row's exact lexicographic top-2)
+                        c_arr++;
+                        const int jfirst = (int)__shfl(col, l1);
+                        int j1 = jfirst;
+                        const int j2 = (int)__shfl(col, l2);
+                        const T vj1 = __shfl(vj, l1);
+                        const T vnew = vj1 - (u2 - u1);
+                        const bool lowers = vnew < vj1;
+                        if (!lowers && i0 >= 0) { j1 = j2; i0 = __shfl(csj, l2); }
                         if (lane == 0) {
-                            if (lowers) __hip_atomic_store(v + (int)g.k1, vnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            st_i32(a.rowsol + i, j1); st_i32(a.colsol + j1, i);
+                            if (lowers) __hip_atomic_store(v + jfirst, vnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            // (rowsol is not read during this phase and equals the inverse of colsol: rebuilt after it)
+                            if (csl) s_cs16[j1] = (uint16_t)i; else st_i32(a.colsol + j1, i);
                             if (i0 >= 0 && !lowers) st_i32(a.freerows + numfree, i0);
                         }
                         if (i0 >= 0) { if (lowers) carry = i0; else numfree++; }
@@ -889,14 +906,14 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
             c_arr++;
             int j1 = (int)g.k1;
             const int j2 = (int)g.k2;
-            int i0 = ld_i32(a.colsol + j1);
+            int i0 = CS_GET(j1);
             const T vj1 = g.a1;
             const T vnew = vj1 - (g.u2 - g.u1);
             const bool lowers = vnew < vj1;
             if (lowers) { if (((j1 / VW) % BLOCK) == tid) v[j1] = vnew; }
-            else if (i0 >= 0) { j1 = j2; i0 = ld_i32(a.colsol + j2); }
+            else if (i0 >= 0) { j1 = j2; i0 = CS_GET(j2); }
             __syncthreads();  // every wave has read colsol for this step before it changes
-            if (tid == 0) { st_i32(a.rowsol + i, j1); st_i32(a.colsol + j1, i); }
+            if (tid == 0) { if (csl) s_cs16[j1] = (uint16_t)i; else st_i32(a.colsol + j1, i); }
             if (i0 >= 0) {
                 if (lowers) carry = i0;
                 else { if (tid == 0) st_i32(a.freerows + numfree, i0); numfree++; }
@@ -907,7 +924,17 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
         if (sweep == 0) c_free_a1 = numfree;
     }
     const long long c_free_a2 = numfree;
+    // colsol back to global memory, rowsol = its inverse (ARR kept only colsol current)
+    __syncthreads();
+    for (int c = tid; c < n; c += BLOCK) {
+        const int32_t r = CS_GET(c);
+        if (csl) a.colsol[c] = r;
+        if (r >= 0) a.rowsol[r] = c;
+    }
+    __threadfence();
+    __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#undef CS_GET
 
     // ---- AUGMENTATION: relaxation and the search for the next pick share one sweep ----
     int err = 0;
@@ -3396,7 +3423,9 @@ static int lap_solve_f64(int n, const double *cost, int64_t ld, int cost_on_devi
             hipLaunchKernelGGL(build_row_caches_wide<T>, dim3(n), dim3(256), 0, stream, n, dld, dcost, d_v, b_ccol.as<uint32_t>(), b_cval.as<T>());
             ca.cache_col = b_ccol.as<uint32_t>(); ca.cache_val = b_cval.as<T>();
         }
-        hipLaunchKernelGGL(jv_chain_stream<T>, dim3(1), dim3(BLOCK), 0, stream, ca);
+        const size_t cs_lds = (ca.cache_col && n <= 65535) ? (((size_t)n * 2 + 15) / 16) * 16 : 16;
+        if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(jv_chain_stream<T>)))) return rc;
+        hipLaunchKernelGGL(jv_chain_stream<T>, dim3(1), dim3(BLOCK), cs_lds, stream, ca);
         rc = hipGetLastError() == hipSuccess ? CYTO_OK : CYTO_ERR_HIP;
     }
     if (rc) return rc;
