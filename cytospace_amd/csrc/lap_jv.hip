@@ -1158,7 +1158,7 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // a wave's candidate for the next pick of the dense augmentation, with everything the step needs once it wins
-struct __attribute__((aligned(16))) PickRec { uint64_t key; int32_t row; float h; float vjp; int32_t g; int32_t skip; int32_t pad; };
+struct __attribute__((aligned(16))) PickRec { uint64_t key; int32_t row; float h; float vjp; int32_t g; int32_t skip; int32_t srow; };   // srow: the stored row (row map applied)
 struct Scratch2 {
     uint64_t m1[2][NW2], m2[2][NW2];
     int cnt[2][NW2];
@@ -1702,7 +1702,7 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
         const uint32_t wlk = wave_min_u32(lk);
         AP_STAMP(10)
         {
-            int32_t iw = -1, gw = 0, skipw = 0;
+            int32_t iw = -1, gw = 0, skipw = 0, sroww = 0;
             float hw = 0.0f, vjpw = 0.0f;
             if (wlk != 0xFFFFFFFFu && (wlk & 0x80000000u)) {          // (wave-uniform) an assigned column: its owner row
                 const int jpw = (int)(wlk & 0x7FFFFFFFu);
@@ -1712,6 +1712,10 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
                 if constexpr (LDS_STATE) { const uint16_t c16 = l_cs[jpw]; iw = c16 == 0xFFFFu ? -1 : (int32_t)c16; vjpw = l_v[jpw]; }
                 else { iw = ld_i32(gcolsol + jpw); vjpw = ld_f32(gv + jpw); }
                 hw = (cipw - vjpw) - dminw;
+                // the stored row of the owner (row map): looked up here, by every wave for its own candidate and next to the LDS
+                // look-ups, not after the exchange -- there it was a dependent round trip to L2 in front of every row fetch
+                sroww = iw;
+                if (rowmap && iw >= 0) sroww = rowmap[__builtin_amdgcn_readfirstlane(iw)];
                 // Exact skip for duplicated rows: if a bitwise identical row was already scanned in THIS search with an
                 // offset hb >= h, every relaxation through row i is a no-op: fl(x - h) >= fl(x - hb) >= d[j] for every
                 // unscanned column (prices do not change during a search and d only decreases).  The column is retired
@@ -1726,7 +1730,7 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
             AP_STAMP(11)
             if (lane == 0) {
                 lds_rec *const dst = l_rec + par * NW2 + wave;
-                dst->key = ((uint64_t)wmin << 32) | wlk; dst->row = iw; dst->h = hw; dst->vjp = vjpw; dst->g = gw; dst->skip = skipw;
+                dst->key = ((uint64_t)wmin << 32) | wlk; dst->row = iw; dst->h = hw; dst->vjp = vjpw; dst->g = gw; dst->skip = skipw; dst->srow = sroww;
             }
         }
         lds_barrier();
@@ -1738,7 +1742,7 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
         kmin = readlane64(kmin, 0);
         const int wstar = (int)__builtin_ctzll(__ballot(k8 == kmin)) & (NWV - 1);     // keys of distinct waves are distinct columns
         const lds_rec *const win = l_rec + par * NW2 + wstar;
-        const int32_t rw_row = win->row, rw_g = win->g, rw_skip = win->skip;
+        const int32_t rw_row = win->row, rw_g = win->g, rw_skip = win->skip, rw_srow = win->srow;
         const float rw_h = win->h, rw_vjp = win->vjp;
         par ^= 1;
         AP_STAMP(0)
@@ -1762,7 +1766,8 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
         AP_STAMP(1)
         float4 x[CH];
         if (!skip) {
-            load_row4<CH, BS>(RBASE(cost, rowmap, i, ld), ld, i, n, tid, x);
+            const int srow = __builtin_amdgcn_readfirstlane(rw_srow);
+            load_row4<CH, BS>(cost + ((int64_t)srow - i) * ld, ld, i, n, tid, x);
             // scan log (after the loads in program order: a store does not hold them up); one store instruction of the last wave
             if (tid >= BS - 2) {
                 if (tid == BS - 2) st_i32(slog_row + nlog, i);
