@@ -453,6 +453,12 @@ def main():
     sharded = None
     if not args.no_extras:
         sharded = extra_c4_sharded(dev, rank, world, dist, args.c4_rank_chunks)      # every rank takes part
+    if dist is not None:                       # nothing collective happens after this point: leave the group together
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:                 # (a failed teardown must not cost the measured line)
+            print(f"process group teardown: {e}", file=sys.stderr)
     if rank != 0:
         return
     ms_per_step = elapsed * 1e3 / args.steps
