@@ -92,12 +92,12 @@ def extra_c3(dev):
     if not ok:
         raise SystemExit("c3: bincount(mapped) != slots")
     tf = info.gemm_flops / (info.ms_gemm * 1e-3) / 1e12
-    kern = info.ms_standardize + info.ms_gemm + info.lap.ms_total
+    # the cells go up in blocks of 8192 and block b's contraction runs while block b + 1 is copied and transformed, so the
+    # upload + transform time already contains all contractions but the last block's: the parts do not add up to the wall time
     return {"workload": f"{G} genes x {C} cells x {S} spots (10 slots each), float32 counts -> spots",
             "wall_ms_incl_h2d": round(wall * 1e3, 1), "assignments_per_s_wall": round(C / wall, 1),
-            "kernel_ms": {"standardize_incl_h2d": round(info.ms_standardize, 1), "pearson_gemm": round(info.ms_gemm, 2),
-                          "lap": round(info.lap.ms_total, 1), "sum": round(kern, 1)},
-            "assignments_per_s_kernels": round(C / (kern * 1e-3), 1),
+            "kernel_ms": {"upload_and_transform_with_the_gemm_blocks_inside": round(info.ms_standardize, 1),
+                          "pearson_gemm_blocks_sum": round(info.ms_gemm, 2), "lap": round(info.lap.ms_total, 1)},
             "roofline": {"bound": "mfma", "kernel": "pearson_gemm", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF,
                          "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "flops_per_launch": info.gemm_flops},
             "lap_row_scans": int(info.lap.row_scans), "bincount_equals_slots": ok, "instance_seconds": round(t_gen, 1)}

@@ -555,6 +555,14 @@ int cyto_standardize(int G, int C, const void *x, int64_t ldx, int x_is_f64, int
                           device_id, stream_);
 }
 
+// the -corr contraction, launch only (rowstart == nullptr: one cost row per spot)
+static void gemm_unique_rows_async(int Gpad, int S, int C, const float *zst, int64_t ldzst, const float *zsc, int64_t ldzsc,
+                                   const int *rowstart, float *cost_dev, int64_t ldc, hipStream_t stream) {
+    const int tiles_m = (S + BM - 1) / BM, tiles_n = (C + BN - 1) / BN;
+    hipLaunchKernelGGL(pearson_gemm<0>, dim3(tiles_m * tiles_n), dim3(256), 0, stream, Gpad, S, C, zst, ldzst, zsc, ldzsc,
+                       rowstart, cost_dev, ldc, tiles_n, (const double *)nullptr, (const double *)nullptr, tiles_m);
+}
+
 // A2+A3: cost = -corr, each spot row written to its slots[s] LAP rows (spot order).
 // zst: Gpad x ldzst, zsc: Gpad x ldzsc (device, zero padded: Gpad % 32 == 0, ld % 128 == 0).
 // cost: device, (sum slots) x ldc.  gemm_ms (optional): HIP-event time of the GEMM kernel.
@@ -601,8 +609,7 @@ static int cost_gemm(int euclid, int Gpad, int S, int C, const float *zst, int64
         hipLaunchKernelGGL(pearson_gemm<1>, dim3(tiles_m * tiles_n), dim3(256), 0, stream, Gpad, S, C, zst, ldzst, zsc, ldzsc,
                            drs.as<int>(), cost_dev, ldc, tiles_n, na.as<double>(), nb.as<double>(), tiles_m);
     else
-        hipLaunchKernelGGL(pearson_gemm<0>, dim3(tiles_m * tiles_n), dim3(256), 0, stream, Gpad, S, C, zst, ldzst, zsc, ldzsc,
-                           drs.as<int>(), cost_dev, ldc, tiles_n, (const double *)nullptr, (const double *)nullptr, tiles_m);
+        gemm_unique_rows_async(Gpad, S, C, zst, ldzst, zsc, ldzsc, identity ? nullptr : drs.as<int>(), cost_dev, ldc, stream);
     CYTO_HIP(hipGetLastError());
     CYTO_HIP(hipEventRecord(e1, stream));
     CYTO_HIP(hipStreamSynchronize(stream));
@@ -667,15 +674,53 @@ int cyto_assign_metric_typed(int metric, int G, int C, int S, const void *sc, co
         return rc;
     CYTO_HIP(hipEventRecord(e0, stream));
     if ((rc = cyto_transform(transform, G, S, st, S, x_is_f64, 0, already_normalized, zst.as<float>(), ldzst, Gpad, device_id, stream))) return rc;
-    if ((rc = cyto_transform(transform, G, C, sc, C, x_is_f64, 0, already_normalized, zsc.as<float>(), ldzsc, Gpad, device_id, stream))) return rc;
-    CYTO_HIP(hipEventRecord(e1, stream));
-    CYTO_HIP(hipEventSynchronize(e1));
     float ms_std = 0;
-    (void)hipEventElapsedTime(&ms_std, e0, e1);
     double ms_gemm = 0;
-    if ((rc = cyto_cost_metric(metric, Gpad, S, C, zst.as<float>(), ldzst, zsc.as<float>(), ldzsc, ones.data(), cost.as<float>(), ldc,
-                               &ms_gemm, device_id, stream)))
-        return rc;
+    constexpr int WBLK = 8192;                            // cells per block: 64 column tiles x 40 row tiles at c3 = five full rounds
+    if (metric != CYTO_METRIC_EUCLIDEAN && C > 2 * WBLK) {
+        // Large problems: the scRNA matrix goes up in blocks of cells, and the contraction of block b (its own stream) runs
+        // while block b + 1 is copied and transformed -- every transform is per cell (column), and a pitched copy out of
+        // pageable memory runs at the same 57 GB/s as a contiguous one (tools/dbg/h2d_2d_bench.hip).  At c3 the upload
+        // (70 ms) and the contraction (71 ms) then overlap instead of adding up.
+        // (Copying on a third stream with the transforms enqueued without a host wait was measured too: no faster -- while a
+        //  contraction runs the upload itself slows down from 57 to ~40 GB/s.)
+        StreamGuard gcomp;
+        CYTO_HIP(hipStreamCreateWithFlags(&gcomp.s, hipStreamNonBlocking));
+        gcomp.own = true;
+        const size_t esz = x_is_f64 ? 8 : 4;
+        DevBuf dx;
+        if ((rc = dx.alloc((size_t)G * WBLK * esz, stream))) return rc;
+        CYTO_HIP(hipMemsetAsync(zsc.p, 0, (size_t)Gpad * ldzsc * sizeof(float), stream));
+        const int nblocks = (C + WBLK - 1) / WBLK;
+        std::vector<hipEvent_t> evs((size_t)2 * nblocks, nullptr);     // per block: contraction begin / end
+        struct EvGuard { std::vector<hipEvent_t> &v; ~EvGuard() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); } } evguard{evs};
+        for (size_t k = 0; k < evs.size(); k++) CYTO_HIP(hipEventCreate(&evs[k]));
+        for (int b = 0; b < nblocks; b++) {
+            const int c0 = b * WBLK, w = std::min(WBLK, C - c0);
+            const char *src = reinterpret_cast<const char *>(sc) + (size_t)c0 * esz;
+            CYTO_HIP(hipMemcpy2DAsync(dx.p, (size_t)w * esz, src, (size_t)C * esz, (size_t)w * esz, G, hipMemcpyHostToDevice, stream));
+            if (x_is_f64) rc = standardize_dev<double>(G, w, dx.as<double>(), w, already_normalized, zsc.as<float>() + c0, ldzsc, nullptr, 0, stream, transform);
+            else rc = standardize_dev<float>(G, w, dx.as<float>(), w, already_normalized, zsc.as<float>() + c0, ldzsc, nullptr, 0, stream, transform);
+            if (rc) return rc;                            // (standardize_dev has waited for its kernels: block b's operand is complete)
+            CYTO_HIP(hipEventRecord(evs[2 * b], gcomp.s));
+            gemm_unique_rows_async(Gpad, S, w, zst.as<float>(), ldzst, zsc.as<float>() + c0, ldzsc, nullptr, cost.as<float>() + c0, ldc, gcomp.s);
+            CYTO_HIP(hipGetLastError());
+            CYTO_HIP(hipEventRecord(evs[2 * b + 1], gcomp.s));
+        }
+        CYTO_HIP(hipEventRecord(e1, stream));
+        CYTO_HIP(hipStreamSynchronize(gcomp.s));
+        CYTO_HIP(hipEventSynchronize(e1));
+        (void)hipEventElapsedTime(&ms_std, e0, e1);     // upload + transforms; the contractions of all blocks but the last ran inside it
+        for (int b = 0; b < nblocks; b++) { float ms = 0; (void)hipEventElapsedTime(&ms, evs[2 * b], evs[2 * b + 1]); ms_gemm += ms; }
+    } else {
+        if ((rc = cyto_transform(transform, G, C, sc, C, x_is_f64, 0, already_normalized, zsc.as<float>(), ldzsc, Gpad, device_id, stream))) return rc;
+        CYTO_HIP(hipEventRecord(e1, stream));
+        CYTO_HIP(hipEventSynchronize(e1));
+        (void)hipEventElapsedTime(&ms_std, e0, e1);
+        if ((rc = cyto_cost_metric(metric, Gpad, S, C, zst.as<float>(), ldzst, zsc.as<float>(), ldzsc, ones.data(), cost.as<float>(), ldc,
+                                   &ms_gemm, device_id, stream)))
+            return rc;
+    }
     std::vector<int32_t> colsol((size_t)N);
     cyto_lap_info li;
     double total = 0;
