@@ -359,7 +359,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no n50000 / c3 / c4_chunks / c5_chunks)")
     ap.add_argument("--c4-chunks", type=int, default=256, help="concurrent chunk LAPs in the c4_chunks leg (256 = one chain per CU; 400 MB each)")
     ap.add_argument("--c4-rank-chunks", type=int, default=64, help="chunks per rank in the c4_sharded leg")
-    ap.add_argument("--pmc-tag", default="r02c", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
+    ap.add_argument("--pmc-tag", default="r02d", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
     args = ap.parse_args()
 
     # ONE JSON line on stdout: everything else this process (or a library under it: RCCL prints a version banner through C
