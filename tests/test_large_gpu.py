@@ -224,3 +224,22 @@ def test_c5_shaped_single_cell_chunks():
         mine = float(ref[mapped, np.arange(chunk)].sum())
         assert abs(mine - best) <= 1e-5 * max(1.0, abs(best)), (k, mine, best)
         assert info.lap.row_groups == chunk                                # no duplicated rows in single-cell mode
+
+
+# ---- the fused path's block pipeline (more than 16 384 cells: upload + transform of block b + 1 next to the contraction of block b) ----
+
+@pytest.mark.parametrize("metric", ["Pearson_correlation", "Spearman_correlation"])
+def test_fused_block_pipeline_equals_the_split_path(metric):
+    G, C, S = 240, 17200, 1720                       # three blocks of cells (8192, 8192, 816)
+    sc, st, slots = instances.synth_expression(G, C, S, seed=11)
+    mapped, total, info = assign_pearson(sc, st, slots, already_normalized=False, return_info=True, distance_metric=metric)
+    assert np.array_equal(np.bincount(mapped, minlength=S), slots)
+    cost, N, ld, _ = common.pearson_cost_device(sc, st, np.ones(S, np.int64), already_normalized=False, metric=metric)
+    try:
+        rows = cost.to_numpy((S, ld), np.float32)[:, :C]
+    finally:
+        cost.free()
+    loc = np.repeat(np.arange(S), slots)
+    g = lap_solve_rows(rows, loc)                                        # the same unique rows, built in one piece
+    assert np.array_equal(loc[g["colsol"]], mapped)
+    assert abs(g["total"] - total) <= 1e-5 * max(1.0, abs(total))
