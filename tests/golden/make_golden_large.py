@@ -1,6 +1,6 @@
 """Goldens for the LARGE LAP instances (BASELINE configs c2/c3/c4 at true size), made in the build container.
 
-Run:  python tests/golden/make_golden_large.py [tag ...]      (tags: u20000 u33000 u50000 c3s50000 c4s10000)
+Run:  python tests/golden/make_golden_large.py [tag ...]      (tags: u20000 u24000 u30000 u33000 u50000 c3s50000 c4s10000)
 
 For every instance (generators: tools/instances.py, reproducible bit for bit on any machine) this stores what the
 CPU JV oracle (oracle/jv_oracle.c, float32) returns -- colsol (int32), the float64 re-summed total, sha256 of u and v,

@@ -55,10 +55,11 @@ def _compare_with_golden(tag, buf, n, solve=None):
     return g
 
 
-@pytest.mark.parametrize("n", [20000, 33000, 50000])
+@pytest.mark.parametrize("n", [20000, 24000, 30000, 33000, 50000])
 def test_uniform_true_size(n):
-    """c2 (20 000) and the north star's 50 000: <10|13,true> / <16,false> / <0,false> chain variants, u16 colsol in LDS,
-    prices in L2, build_row_caches_stream -- at the sizes they are meant for."""
+    """c2 (20 000) and the north star's 50 000, and one size inside every chain variant's own range: <10,true> (20 000),
+    <13,true> (24 000), <16,false> with u16 colsol in LDS and the prices in L2 (30 000), <0,false> with the streaming dense
+    refresh and build_row_caches_stream (33 000, 50 000)."""
     buf = instances.blocks_to_device(instances.uniform_cost_blocks(n), n)
     try:
         _compare_with_golden(f"u{n}", buf, n)
