@@ -336,6 +336,7 @@ template <typename T> struct ChainArgs {
     int32_t *lvl;        // [n] scratch (jv_chain_stream: level at which a column was scanned; 0 = not scanned)
     const uint32_t *cache_col;   // [n x 64] jv_chain_stream: row caches (build_row_caches_wide), or nullptr
     const T *cache_val;          // [n x 64]
+    int cs_lds;                  // jv_chain_stream: colsol as u16 in LDS during RT / ARR (n <= 65 535)
 };
 
 // The persistent chain kernels run one workgroup per PROBLEM: a batch of independent chunk LAPs is one launch with
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
     // after the stores issued before it are acknowledged)
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_cs[];
     uint16_t *const s_cs16 = reinterpret_cast<uint16_t *>(dyn_cs);
-    const bool csl = a.cache_col != nullptr && a.n <= 65535;
+    const bool csl = a.cs_lds != 0;
 #define CS_GET(j) (csl ? (s_cs16[j] == 0xFFFFu ? -1 : (int32_t)s_cs16[j]) : ld_i32(a.colsol + (j)))
     const int tid = threadIdx.x;
     const int n = a.n;
@@ -2966,7 +2967,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(const LazyArgs *__restrict
 static const cyto_lap_opts k_default_opts = {0, 0, 0, 0, {0, 0, 0, 0}};
 
 static int check_opts(const cyto_lap_opts &o) {
-    if (o.chain_variant < 0 || o.chain_variant > 2 || o.augmentation < 0 || o.augmentation > 2 || o.inject_exceptions < 0 ||
+    if (o.chain_variant < 0 || o.chain_variant > 3 || o.augmentation < 0 || o.augmentation > 2 || o.inject_exceptions < 0 ||
         o.no_handover < 0 || o.no_handover > 1)
         return CYTO_ERR_BAD_ARG;
     for (int k = 0; k < 4; k++) if (o.reserved[k]) return CYTO_ERR_BAD_ARG;
@@ -3097,6 +3098,7 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
     if (n <= 0) return CYTO_ERR_BAD_ARG;
     if (n > FAST_NMAX) return CYTO_ERR_UNSUPPORTED;
     int rc = check_opts(opts);
+    if (!rc && opts.chain_variant == 3) rc = CYTO_ERR_BAD_ARG;      // (3 exists for the float64 chain only)
     if (rc) return rc;
     if ((rc = select_device(device_id))) return rc;
     Events<6> ev;                                   // destroyed on every return path
@@ -3415,7 +3417,7 @@ static int lap_solve_f64(int n, const double *cost, int64_t ld, int cost_on_devi
     ca.counters = reinterpret_cast<long long *>(b_misc.as<char>() + 16);
     ca.status = b_misc.as<int>() + 1;
     ca.dwork = d_v + 4 * (size_t)n; ca.lvl = d_rowsol + 7 * (size_t)n;
-    ca.cache_col = nullptr; ca.cache_val = nullptr;
+    ca.cache_col = nullptr; ca.cache_val = nullptr; ca.cs_lds = 0;
     // register-resident chain while it does not spill (n <= 4096), else everything streams from L2 -- with row caches
     // against the post-column-reduction prices for REDUCTION TRANSFER and AUGMENTING ROW REDUCTION
     // (opts.chain_variant == 2: without them, every scan reads its row)
@@ -3428,7 +3430,9 @@ static int lap_solve_f64(int n, const double *cost, int64_t ld, int cost_on_devi
             hipLaunchKernelGGL(build_row_caches_wide<T>, dim3(n), dim3(256), 0, stream, n, dld, dcost, d_v, b_ccol.as<uint32_t>(), b_cval.as<T>());
             ca.cache_col = b_ccol.as<uint32_t>(); ca.cache_val = b_cval.as<T>();
         }
-        const size_t cs_lds = (ca.cache_col && n <= 65535) ? (((size_t)n * 2 + 15) / 16) * 16 : 16;
+        // (chain_variant 3: the caches with colsol in global memory -- what n > 65 535 uses -- forced for the test-suite)
+        ca.cs_lds = (ca.cache_col && n <= 65535 && opts.chain_variant != 3) ? 1 : 0;
+        const size_t cs_lds = ca.cs_lds ? (((size_t)n * 2 + 15) / 16) * 16 : 16;
         if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(jv_chain_stream<T>)))) return rc;
         hipLaunchKernelGGL(jv_chain_stream<T>, dim3(1), dim3(BLOCK), cs_lds, stream, ca);
         rc = hipGetLastError() == hipSuccess ? CYTO_OK : CYTO_ERR_HIP;

@@ -318,10 +318,11 @@ def test_row_map_argument_validation():
         lap_solve_rows(rows, np.array([0, 0, 1, 1, 2], np.int32))                    # n != number of columns
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_float64_streaming_chain_with_and_without_row_caches(variant):
     # float64 beyond n = 4096 runs jv_chain_stream; chain_variant 1 = with the 63-column row caches for reduction transfer and
-    # augmenting row reduction (the default there), 2 = every scan reads its row.  Forced here at sizes the oracle solves quickly.
+    # augmenting row reduction (the default there), 2 = every scan reads its row, 3 = the caches with colsol in global memory
+    # (what n > 65 535 uses).  Forced here at sizes the oracle solves quickly.
     opts = dict(chain_variant=variant)
     for n in (2, 5, 63, 64, 65, 300, 1500):
         c = np.random.default_rng(n).random((n, n))
