@@ -2995,7 +2995,7 @@ struct F32Job {
 
 struct F32Plan {            // what depends on n (and the options) only: identical for every problem of the batch
     int n, colblocks, rowblocks, rows_per_block, cache_grid;
-    bool force_l2, lds_variant, lazy, lz_lds_state, lz_cs_lds;
+    bool force_l2, lds_variant, lazy, lz_lds_state, lz_cs_lds, no_cs_lds;
     size_t shm_chain, lz_base_shm;
 };
 
@@ -3008,7 +3008,7 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
     const int nl = (int)live.size();
     if (!nl) return CYTO_OK;
     int rc;
-    const bool cs_lds = !LDS_STATE && n <= 65535;
+    const bool cs_lds = !LDS_STATE && n <= 65535 && !pl.no_cs_lds;
     void (*kern)(const Chain2Args *) = jv_chain2<CH, LDS_STATE, false>;
     if constexpr (!LDS_STATE) { if (cs_lds) kern = jv_chain2<CH, false, true>; }
     auto build_caches = [&]() -> int {
@@ -3098,7 +3098,6 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
     if (n <= 0) return CYTO_ERR_BAD_ARG;
     if (n > FAST_NMAX) return CYTO_ERR_UNSUPPORTED;
     int rc = check_opts(opts);
-    if (!rc && opts.chain_variant == 3) rc = CYTO_ERR_BAD_ARG;      // (3 exists for the float64 chain only)
     if (rc) return rc;
     if ((rc = select_device(device_id))) return rc;
     Events<6> ev;                                   // destroyed on every return path
@@ -3117,6 +3116,7 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
     // which chain variant: by size, or the large-n variants forced at a small n (opts.chain_variant; the test-suite
     // runs them on instances the CPU oracle solves in a second)
     pl.force_l2 = opts.chain_variant != 0;
+    pl.no_cs_lds = opts.chain_variant == 3;            // (3: as 2, with colsol in global memory too -- what n > 65 535 uses)
     pl.lds_variant = !pl.force_l2 && n <= 13 * per2;
     // cache-certified augmentation: the default above 5120 columns (measured cross-over with the register-resident dense
     // search on uniform and duplicated-row instances), the only one beyond 26 624
@@ -3126,9 +3126,9 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
     const size_t nb24 = (size_t)((((n + 63) / 64) + 511) & ~511) * 8 + (size_t)((n + 63) / 64) * 24 + 16;
     const size_t lds_budget = LDS_DYNAMIC_MAX;
     pl.lz_lds_state = n <= 65535 && !pl.force_l2 && npad6 + nb24 <= lds_budget;
-    pl.lz_cs_lds = !pl.lz_lds_state && n <= 65535 && npad2 + nb24 <= lds_budget;
+    pl.lz_cs_lds = !pl.lz_lds_state && n <= 65535 && !pl.no_cs_lds && npad2 + nb24 <= lds_budget;
     pl.lz_base_shm = (pl.lz_lds_state ? npad6 : (pl.lz_cs_lds ? npad2 : 0)) + nb24;
-    const bool cs_lds_chain = !pl.lds_variant && n <= 65535;
+    const bool cs_lds_chain = !pl.lds_variant && n <= 65535 && !pl.no_cs_lds;
     pl.shm_chain = pl.lds_variant ? (((size_t)npad * 6 + 15) / 16) * 16 : (cs_lds_chain ? (((size_t)npad * 2 + 15) / 16) * 16 : 16);
 
     const size_t nT = (size_t)n * sizeof(float), nI = (size_t)n * sizeof(int32_t);
@@ -3275,7 +3275,7 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
 
     // ---- stage 3: the chains, one launch per phase for the whole batch ----
     DevBuf d_c2, d_la;
-    if (opts.chain_variant == 2) rc = launch_batch<0, false>(pl, jobs, stream, e1c, e1d, d_c2, d_la);
+    if (opts.chain_variant >= 2) rc = launch_batch<0, false>(pl, jobs, stream, e1c, e1d, d_c2, d_la);
     else if (pl.force_l2 && n <= 5 * per2) rc = launch_batch<5, false>(pl, jobs, stream, e1c, e1d, d_c2, d_la);
     else if (pl.force_l2 && n <= 16 * per2) rc = launch_batch<16, false>(pl, jobs, stream, e1c, e1d, d_c2, d_la);
     else if (pl.force_l2) rc = launch_batch<0, false>(pl, jobs, stream, e1c, e1d, d_c2, d_la);

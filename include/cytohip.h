@@ -96,8 +96,8 @@ int cyto_lap_f64(int n, const double *cost, int64_t ld, int cost_on_device,
 typedef struct {
     int32_t chain_variant;      /* 0: by size.  1: prices in L2 (u16 colsol in LDS), cached refresh -- what n > 26 624 uses.
                                    2: streaming dense refresh -- what n > 32 768 uses.  float64: != 0 selects the streaming chain (what n > 4 096
-                                   uses), 1 with its row caches, 2 without (every scan reads its row), 3 (float64 only) with the caches but
-                                   colsol in global memory -- what n > 65 535 uses */
+                                   uses), 1 with its row caches, 2 without (every scan reads its row).  3: as 2 (float64: as 1) with colsol in
+                                   global memory too -- what n > 65 535 uses */
     int32_t augmentation;       /* 0: by size (cache-certified search above 5 120 columns).  1: dense register-resident search
                                    (n <= 26 624 only).  2: cache-certified search */
     int32_t no_handover;        /* 1: the cache-certified search never hands deep searches over to the dense kernel */

@@ -165,11 +165,11 @@ def test_duplicate_rows_skip_is_exact_and_deterministic(n, slots):
         assert g["info"].row_groups == n // slots and g["info"].aug_scans_skipped > 0
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_large_n_code_path_forced_at_small_n(mode):
     # cyto_lap_opts.chain_variant routes any size through the large-n kernels (prices in L2-resident global memory,
     # u16 colsol in LDS, cache-certified augmentation without LDS state; 2: also the streaming dense refresh used beyond
-    # 32768 columns); they must be bit-identical too.  The real switch-overs are at n > 26624 and n > 32768, where
+    # 32768 columns; 3: the same with colsol in global memory as well, what n > 65535 uses); they must be bit-identical too.  The real switch-overs are at n > 26624 and n > 32768, where
     # tests/test_large_gpu.py runs them at true size against goldens.
     opts = dict(chain_variant=mode)
     for n in (5, 64, 700, 2300):
@@ -215,7 +215,7 @@ def test_dense_augmentation_forced_above_its_default_range():
 
 def test_bad_options_are_rejected():
     c = np.random.default_rng(1).random((8, 8)).astype(np.float32)
-    for bad in (dict(chain_variant=3), dict(augmentation=-1), dict(no_handover=2), dict(inject_exceptions=-5)):
+    for bad in (dict(chain_variant=4), dict(augmentation=-1), dict(no_handover=2), dict(inject_exceptions=-5)):
         with pytest.raises(ValueError):
             lap_solve(c, np.float32, opts=bad)
 
@@ -286,7 +286,7 @@ def test_float64_host_matrix_is_narrowed_on_the_device():
 
 # ---- SURVEY 8f rank 3 (first half): row indirection -- the cost holds every distinct spot row once ----
 
-@pytest.mark.parametrize("opts", [None, dict(chain_variant=1), dict(chain_variant=2), dict(augmentation=1), dict(augmentation=2, no_handover=1)])
+@pytest.mark.parametrize("opts", [None, dict(chain_variant=1), dict(chain_variant=2), dict(chain_variant=3), dict(augmentation=1), dict(augmentation=2, no_handover=1)])
 def test_row_map_equals_the_materialised_matrix(opts):
     # cyto_lap_f32_rowmap(rows, np.repeat(arange(S), slots)) == cyto_lap_f32(rows[rowmap]) == the oracle, bit for bit,
     # with equal slots, ragged slots, stored rows nobody uses (slots == 0) and a single spot
