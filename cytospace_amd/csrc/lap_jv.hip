@@ -2964,13 +2964,14 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(const LazyArgs *__restrict
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-static const cyto_lap_opts k_default_opts = {0, 0, 0, 0, {0, 0, 0, 0}};
+static const cyto_lap_opts k_default_opts = {0, 0, 0, 0, 0, {0, 0, 0}};
 
 static int check_opts(const cyto_lap_opts &o) {
     if (o.chain_variant < 0 || o.chain_variant > 3 || o.augmentation < 0 || o.augmentation > 2 || o.inject_exceptions < 0 ||
         o.no_handover < 0 || o.no_handover > 1)
         return CYTO_ERR_BAD_ARG;
-    for (int k = 0; k < 4; k++) if (o.reserved[k]) return CYTO_ERR_BAD_ARG;
+    if (o.group_state_global < 0 || o.group_state_global > 1) return CYTO_ERR_BAD_ARG;
+    for (int k = 0; k < 3; k++) if (o.reserved[k]) return CYTO_ERR_BAD_ARG;
     return CYTO_OK;
 }
 
@@ -3247,7 +3248,7 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
             la.may_bail = opts.no_handover ? 0 : 1;   // (launch_batch clears it where no dense kernel can take over)
             la.debug_exc = opts.inject_exceptions;
             if (want_groups && ng < n) {
-                if (j.shm_lazy + (size_t)ng * 8 <= lds_budget) { la.gmode = 1; j.shm_lazy += (size_t)ng * 8; }
+                if (!opts.group_state_global && j.shm_lazy + (size_t)ng * 8 <= lds_budget) { la.gmode = 1; j.shm_lazy += (size_t)ng * 8; }
                 else {
                     la.gmode = 2;
                     if ((rc = j.b_lzhb.alloc((size_t)ng * 4, stream)) || (rc = j.b_lzhs.alloc((size_t)ng * 4, stream))) return rc;
@@ -3259,7 +3260,7 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
         if (want_groups && ng < n) {
             // LDS beside the group state: v (4 B) + colsol (2 B) per column on the LDS-resident path
             const size_t lds_state = pl.lds_variant ? (size_t)npad * 6 : (size_t)((n + 31) / 32) * 4;
-            if (lds_state + (size_t)ng * 8 + 8192 <= 160 * 1024) c2.gmode = 1;
+            if (!opts.group_state_global && lds_state + (size_t)ng * 8 + 8192 <= 160 * 1024) c2.gmode = 1;
             else {
                 c2.gmode = 2;
                 if ((rc = j.b_ghb.alloc((size_t)ng * 4, stream)) || (rc = j.b_ghs.alloc((size_t)ng * 4, stream))) return rc;

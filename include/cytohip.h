@@ -103,7 +103,9 @@ typedef struct {
     int32_t no_handover;        /* 1: the cache-certified search never hands deep searches over to the dense kernel */
     int32_t inject_exceptions;  /* self-test of the rounding-exception list of the cache-certified search: treat the first k
                                    columns as exception columns (k > 64 overflows the list: certificates are abandoned) */
-    int32_t reserved[4];        /* must be 0 */
+    int32_t group_state_global; /* 1: the duplicate-row group state (best offset / search stamp per row group) in global memory even
+                                   where it fits LDS -- what large problems with thousands of row groups use */
+    int32_t reserved[3];        /* must be 0 */
 } cyto_lap_opts;
 int cyto_lap_f32_opts(int n, const float *cost, int64_t ld, int cost_on_device,
                       int32_t *rowsol, int32_t *colsol, float *u, float *v, double *total,

@@ -215,7 +215,7 @@ def test_dense_augmentation_forced_above_its_default_range():
 
 def test_bad_options_are_rejected():
     c = np.random.default_rng(1).random((8, 8)).astype(np.float32)
-    for bad in (dict(chain_variant=4), dict(augmentation=-1), dict(no_handover=2), dict(inject_exceptions=-5)):
+    for bad in (dict(chain_variant=4), dict(group_state_global=2), dict(augmentation=-1), dict(no_handover=2), dict(inject_exceptions=-5)):
         with pytest.raises(ValueError):
             lap_solve(c, np.float32, opts=bad)
 
@@ -342,3 +342,17 @@ def test_float64_default_path_above_4096():
     g = lap_solve(c, np.float64, return_info=True)
     _check(c, np.float64)
     assert g["info"].hbm_row_reads < g["info"].scans_redtransfer + g["info"].scans_arr      # most scans were served by the caches
+
+
+@pytest.mark.parametrize("aug", [1, 2])
+def test_duplicate_row_group_state_in_global_memory(aug):
+    # large problems with thousands of row groups keep the groups' best offsets / search stamps in global memory (L2) instead
+    # of LDS; cyto_lap_opts.group_state_global forces that form at a size the oracle checks -- dense (1) and cache-certified (2)
+    rng = np.random.default_rng(21)
+    base = -(rng.random((360, 1800)) ** 3).astype(np.float32)
+    c = np.repeat(base, 5, axis=0)
+    opts = dict(augmentation=aug, no_handover=1, group_state_global=1)
+    g = lap_solve(c, np.float32, return_info=True, opts=opts)
+    _check(c, np.float32, opts)
+    assert g["info"].aug_scans_skipped > 0 and g["info"].row_groups == 360
+    _check(c, np.float32, dict(chain_variant=2, group_state_global=1))
