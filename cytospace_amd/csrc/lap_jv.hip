@@ -2964,14 +2964,14 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(const LazyArgs *__restrict
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-static const cyto_lap_opts k_default_opts = {0, 0, 0, 0, 0, {0, 0, 0}};
+static const cyto_lap_opts k_default_opts = {0, 0, 0, 0, 0, 0, {0, 0}};
 
 static int check_opts(const cyto_lap_opts &o) {
     if (o.chain_variant < 0 || o.chain_variant > 3 || o.augmentation < 0 || o.augmentation > 2 || o.inject_exceptions < 0 ||
         o.no_handover < 0 || o.no_handover > 1)
         return CYTO_ERR_BAD_ARG;
-    if (o.group_state_global < 0 || o.group_state_global > 1) return CYTO_ERR_BAD_ARG;
-    for (int k = 0; k < 3; k++) if (o.reserved[k]) return CYTO_ERR_BAD_ARG;
+    if (o.group_state_global < 0 || o.group_state_global > 1 || o.aux_state_global < 0 || o.aux_state_global > 1) return CYTO_ERR_BAD_ARG;
+    for (int k = 0; k < 2; k++) if (o.reserved[k]) return CYTO_ERR_BAD_ARG;
     return CYTO_OK;
 }
 
@@ -3270,7 +3270,7 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
         }
         // dense augmentation: its LDS (prices, colsol, per-group state, and the per-column auxiliaries when they fit)
         const size_t base_aug = (((pl.lds_variant ? (size_t)npad * 6 : 0) + (c2.gmode == 1 ? (size_t)ng * 8 : 0) + 15) / 16) * 16;
-        c2.auxlds = (pl.lds_variant && ng < 65536 && base_aug + (size_t)npad * 6 + 4096 <= 160 * 1024) ? 1 : 0;
+        c2.auxlds = (!opts.aux_state_global && pl.lds_variant && ng < 65536 && base_aug + (size_t)npad * 6 + 4096 <= 160 * 1024) ? 1 : 0;
         j.shm_aug = base_aug + (c2.auxlds ? (size_t)npad * 6 : 0) + 32;
     }
 

@@ -105,7 +105,9 @@ typedef struct {
                                    columns as exception columns (k > 64 overflows the list: certificates are abandoned) */
     int32_t group_state_global; /* 1: the duplicate-row group state (best offset / search stamp per row group) in global memory even
                                    where it fits LDS -- what large problems with thousands of row groups use */
-    int32_t reserved[3];        /* must be 0 */
+    int32_t aux_state_global;   /* 1: the dense augmentation's per-column auxiliaries (cost of the assigned entry, owner's row group) in
+                                   global memory even where they fit LDS -- what n > ~13 000 uses */
+    int32_t reserved[2];        /* must be 0 */
 } cyto_lap_opts;
 int cyto_lap_f32_opts(int n, const float *cost, int64_t ld, int cost_on_device,
                       int32_t *rowsol, int32_t *colsol, float *u, float *v, double *total,

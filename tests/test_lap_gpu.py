@@ -215,7 +215,7 @@ def test_dense_augmentation_forced_above_its_default_range():
 
 def test_bad_options_are_rejected():
     c = np.random.default_rng(1).random((8, 8)).astype(np.float32)
-    for bad in (dict(chain_variant=4), dict(group_state_global=2), dict(augmentation=-1), dict(no_handover=2), dict(inject_exceptions=-5)):
+    for bad in (dict(chain_variant=4), dict(group_state_global=2), dict(aux_state_global=-1), dict(augmentation=-1), dict(no_handover=2), dict(inject_exceptions=-5)):
         with pytest.raises(ValueError):
             lap_solve(c, np.float32, opts=bad)
 
@@ -356,3 +356,6 @@ def test_duplicate_row_group_state_in_global_memory(aug):
     _check(c, np.float32, opts)
     assert g["info"].aug_scans_skipped > 0 and g["info"].row_groups == 360
     _check(c, np.float32, dict(chain_variant=2, group_state_global=1))
+    # ... and the dense kernel's per-column auxiliaries in global memory as well (what it uses beyond ~13 000 columns)
+    _check(c, np.float32, dict(augmentation=1, aux_state_global=1, group_state_global=aug - 1))
+    _check(np.random.default_rng(4).random((700, 700)).astype(np.float32), np.float32, dict(augmentation=1, aux_state_global=1))
