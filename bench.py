@@ -359,6 +359,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no n50000 / c3 / c4_chunks / c5_chunks)")
     ap.add_argument("--c4-chunks", type=int, default=256, help="concurrent chunk LAPs in the c4_chunks leg (256 = one chain per CU; 400 MB each)")
     ap.add_argument("--c4-rank-chunks", type=int, default=64, help="chunks per rank in the c4_sharded leg")
+    ap.add_argument("--sharded-timeout", type=float, default=420.0, help="watchdog of the c4_sharded leg, seconds")
     ap.add_argument("--pmc-tag", default="r02d", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
     args = ap.parse_args()
 
@@ -450,16 +451,35 @@ def main():
             raise SystemExit("c2_batch: the batched solve differs from the single solve")
     buf.free()
 
-    sharded = None
+    sharded, sharded_stuck = None, False
     if not args.no_extras:
-        sharded = extra_c4_sharded(dev, rank, world, dist, args.c4_rank_chunks)      # every rank takes part
-    if dist is not None:                       # nothing collective happens after this point: leave the group together
+        # every rank takes part.  The headline above is already measured: a failure or a hang of this additional multi-rank leg
+        # (it cannot be exercised on the one-GPU development box beyond world size 1) must not cost the line, so it runs under a
+        # watchdog and reports what happened instead.
+        import threading
+        box = {}
+
+        def _leg():
+            try:
+                box["r"] = extra_c4_sharded(dev, rank, world, dist, args.c4_rank_chunks)
+            except BaseException as e:          # noqa: BLE001 (SystemExit from the leg's own gates included)
+                box["r"] = {"error": f"{type(e).__name__}: {e}"}
+
+        th = threading.Thread(target=_leg, daemon=True)
+        th.start()
+        th.join(args.sharded_timeout)
+        sharded_stuck = th.is_alive()
+        sharded = {"error": f"no result within {args.sharded_timeout} s"} if sharded_stuck else box.get("r")
+    failed = sharded_stuck or (isinstance(sharded, dict) and "error" in sharded)
+    if dist is not None and not failed:        # nothing collective happens after this point: leave the group together
         try:
             dist.barrier()
             dist.destroy_process_group()
         except Exception as e:                 # (a failed teardown must not cost the measured line)
             print(f"process group teardown: {e}", file=sys.stderr)
     if rank != 0:
+        if failed:
+            os._exit(0)                         # (a stuck collective would keep the interpreter from exiting)
         return
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * n * args.steps / elapsed
@@ -556,6 +576,8 @@ def main():
         out["c5_chunks"] = extra_c5_chunks(dev)
     json_out.write(json.dumps(out) + "\n")
     json_out.flush()
+    if sharded_stuck or (dist is not None and failed):
+        os._exit(0)                             # the line is out; a stuck collective must not keep the process alive
 
 
 def _cpu_model():
