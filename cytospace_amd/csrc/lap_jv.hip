@@ -337,6 +337,7 @@ template <typename T> struct ChainArgs {
     const uint32_t *cache_col;   // [n x 64] jv_chain_stream: row caches (build_row_caches_wide), or nullptr
     const T *cache_val;          // [n x 64]
     int cs_lds;                  // jv_chain_stream: colsol as u16 in LDS during RT / ARR (n <= 65 535)
+    int v_lds;                   // jv_chain_stream: the prices in LDS too during RT / ARR (with cs_lds, where both fit)
 };
 
 // The persistent chain kernels run one workgroup per PROBLEM: a batch of independent chunk LAPs is one launch with
@@ -733,8 +734,13 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
     // step then gathers the owners from LDS and stores nothing but a lowered price to global memory (a load is only returned
     // after the stores issued before it are acknowledged)
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_cs[];
-    uint16_t *const s_cs16 = reinterpret_cast<uint16_t *>(dyn_cs);
+    // ... and, where they fit beside it (a.v_lds: n <= ~15 800 in float64), the prices too: the cached step then touches global
+    // memory for the row's cache only
+    const bool vl = a.v_lds != 0;
+    T *const s_vT = reinterpret_cast<T *>(dyn_cs);
+    uint16_t *const s_cs16 = reinterpret_cast<uint16_t *>(dyn_cs + (vl ? (((size_t)a.n * sizeof(T) + 15) & ~(size_t)15) : 0));
     const bool csl = a.cs_lds != 0;
+#define V_GET(j) (vl ? s_vT[j] : ld_agent(v + (j)))
 #define CS_GET(j) (csl ? (s_cs16[j] == 0xFFFFu ? -1 : (int32_t)s_cs16[j]) : ld_i32(a.colsol + (j)))
     const int tid = threadIdx.x;
     const int n = a.n;
@@ -764,6 +770,7 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
         }
     }
     if (csl) for (int c = tid; c < n; c += BLOCK) { const int32_t r = a.colsol[c]; s_cs16[c] = r < 0 ? (uint16_t)0xFFFFu : (uint16_t)r; }
+    if (vl) for (int c = tid; c < n; c += BLOCK) s_vT[c] = v[c];
     __syncthreads();
     const long long c_free_cr = numfree;
 
@@ -780,7 +787,7 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
                 const T cv = a.cache_val[(int64_t)i * WC_KC + lane];
                 const T F = __shfl(cv, WC_KC - 1);
                 T h = INF;
-                if (col != WC_SENT && (int)col != j1) h = cv - ld_agent(v + col);
+                if (col != WC_SENT && (int)col != j1) h = cv - V_GET(col);
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) { const T o = __shfl_xor(h, off); h = o < h ? o : h; }
                 mn = h;
@@ -790,7 +797,7 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
                 const V *rp = reinterpret_cast<const V *>(cost + (int64_t)i * ld);
                 Min1<T> loc; loc.u = INF; loc.k = 0; loc.a = 0;
                 for (int q = tid; q < nq; q += BLOCK) {
-                    const V x = rp[q], vv = vp[q];
+                    const V x = rp[q], vv = vl ? reinterpret_cast<const V *>(s_vT)[q] : vp[q];
 #pragma unroll
                     for (int e = 0; e < VW; e++) {
                         const int c = q * VW + e;
@@ -800,7 +807,7 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
                 mn = wg_min1(loc, red, par).u;
                 c_dense++;
             }
-            if (((j1 / VW) % BLOCK) == tid) v[j1] = v[j1] - mn;
+            if (((j1 / VW) % BLOCK) == tid) { if (vl) s_vT[j1] = s_vT[j1] - mn; else v[j1] = v[j1] - mn; }
             if (a.cache_col) __syncthreads();          // the new price has reached L2 (the barrier waits for the store) before any wave gathers it
             c_rt++;
         }
@@ -834,7 +841,7 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
                         else { col = ld_agent(a.cache_col + (int64_t)i * WC_KC + lane); cv = ld_agent(a.cache_val + (int64_t)i * WC_KC + lane); }
                         const T F = __shfl(cv, WC_KC - 1);
                         const bool valid = col != WC_SENT;
-                        const T vj = ld_agent(v + (valid ? col : 0u));
+                        const T vj = V_GET(valid ? col : 0u);
                         const int32_t csj = CS_GET(valid ? col : 0u);
                         // the smallest reduced cost and its lane (cache rows are sorted by column: the lowest lane is the lowest
                         // column), then the smallest of the rest: reductions on order-preserving 64-bit keys, as in the float32 chain
@@ -863,7 +870,7 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
                         const bool lowers = vnew < vj1;
                         if (!lowers && i0 >= 0) { j1 = j2; i0 = __shfl(csj, l2); }
                         if (lane == 0) {
-                            if (lowers) __hip_atomic_store(v + jfirst, vnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (lowers) { if (vl) s_vT[jfirst] = vnew; else __hip_atomic_store(v + jfirst, vnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                             // (rowsol is not read during this phase and equals the inverse of colsol: rebuilt after it)
                             if (csl) s_cs16[j1] = (uint16_t)i; else st_i32(a.colsol + j1, i);
                             if (i0 >= 0 && !lowers) st_i32(a.freerows + numfree, i0);
@@ -894,7 +901,7 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
                 const V *rp = reinterpret_cast<const V *>(cost + (int64_t)i * ld);
                 Top2<T> loc; loc.u1 = INF; loc.k1 = 0xFFFFFFFFu; loc.a1 = 0; loc.u2 = INF; loc.k2 = 0xFFFFFFFFu;
                 for (int q = tid; q < nq; q += BLOCK) {
-                    const V x = rp[q], vv = vp[q];
+                    const V x = rp[q], vv = vl ? reinterpret_cast<const V *>(s_vT)[q] : vp[q];
 #pragma unroll
                     for (int e = 0; e < VW; e++) {
                         const int c = q * VW + e;
@@ -911,7 +918,7 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
             const T vj1 = g.a1;
             const T vnew = vj1 - (g.u2 - g.u1);
             const bool lowers = vnew < vj1;
-            if (lowers) { if (((j1 / VW) % BLOCK) == tid) v[j1] = vnew; }
+            if (lowers) { if (((j1 / VW) % BLOCK) == tid) { if (vl) s_vT[j1] = vnew; else v[j1] = vnew; } }
             else if (i0 >= 0) { j1 = j2; i0 = CS_GET(j2); }
             __syncthreads();  // every wave has read colsol for this step before it changes
             if (tid == 0) { if (csl) s_cs16[j1] = (uint16_t)i; else st_i32(a.colsol + j1, i); }
@@ -930,12 +937,14 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
     for (int c = tid; c < n; c += BLOCK) {
         const int32_t r = CS_GET(c);
         if (csl) a.colsol[c] = r;
+        if (vl) v[c] = s_vT[c];
         if (r >= 0) a.rowsol[r] = c;
     }
     __threadfence();
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #undef CS_GET
+#undef V_GET
 
     // ---- AUGMENTATION: relaxation and the search for the next pick share one sweep ----
     int err = 0;
@@ -3418,7 +3427,7 @@ static int lap_solve_f64(int n, const double *cost, int64_t ld, int cost_on_devi
     ca.counters = reinterpret_cast<long long *>(b_misc.as<char>() + 16);
     ca.status = b_misc.as<int>() + 1;
     ca.dwork = d_v + 4 * (size_t)n; ca.lvl = d_rowsol + 7 * (size_t)n;
-    ca.cache_col = nullptr; ca.cache_val = nullptr; ca.cs_lds = 0;
+    ca.cache_col = nullptr; ca.cache_val = nullptr; ca.cs_lds = 0; ca.v_lds = 0;
     // register-resident chain while it does not spill (n <= 4096), else everything streams from L2 -- with row caches
     // against the post-column-reduction prices for REDUCTION TRANSFER and AUGMENTING ROW REDUCTION
     // (opts.chain_variant == 2: without them, every scan reads its row)
@@ -3433,7 +3442,9 @@ static int lap_solve_f64(int n, const double *cost, int64_t ld, int cost_on_devi
         }
         // (chain_variant 3: the caches with colsol in global memory -- what n > 65 535 uses -- forced for the test-suite)
         ca.cs_lds = (ca.cache_col && n <= 65535 && opts.chain_variant != 3) ? 1 : 0;
-        const size_t cs_lds = ca.cs_lds ? (((size_t)n * 2 + 15) / 16) * 16 : 16;
+        const size_t vbytes = (((size_t)n * sizeof(T)) + 15) & ~(size_t)15, csbytes = (((size_t)n * 2 + 15) / 16) * 16;
+        ca.v_lds = (ca.cs_lds && vbytes + csbytes <= (size_t)LDS_DYNAMIC_MAX) ? 1 : 0;
+        const size_t cs_lds = ca.cs_lds ? csbytes + (ca.v_lds ? vbytes : 0) : 16;
         if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(jv_chain_stream<T>)))) return rc;
         hipLaunchKernelGGL(jv_chain_stream<T>, dim3(1), dim3(BLOCK), cs_lds, stream, ca);
         rc = hipGetLastError() == hipSuccess ? CYTO_OK : CYTO_ERR_HIP;
