@@ -29,7 +29,9 @@ class LapInfo(ctypes.Structure):
             "hbm_row_reads", "dense_refreshes")] + [("ms_arr", ctypes.c_double), ("ms_aug", ctypes.c_double),
                                                         ("aug_scans_skipped", ctypes.c_int64),
                                                         ("row_groups", ctypes.c_int64), ("aug_dense_scans", ctypes.c_int64),
-                                                        ("aug_sparse_inits", ctypes.c_int64), ("aug_handover", ctypes.c_int64)]
+                                                        ("aug_sparse_inits", ctypes.c_int64), ("aug_handover", ctypes.c_int64)] + \
+        [(k, ctypes.c_int64) for k in ("wide", "wide_rounds", "wide_retired", "wide_dense_arr", "wide_dense_aug", "wide_aug_rounds",
+                                       "wide_aug_settled", "wide_trivial", "wide_verify_passes")]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -43,7 +45,7 @@ class LapInfo(ctypes.Structure):
 class LapOpts(ctypes.Structure):
     """cyto_lap_opts (include/cytohip.h): kernel-selection options; results never depend on them."""
     _fields_ = [("chain_variant", ctypes.c_int32), ("augmentation", ctypes.c_int32), ("no_handover", ctypes.c_int32),
-                ("inject_exceptions", ctypes.c_int32), ("group_state_global", ctypes.c_int32), ("aux_state_global", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2)]
+                ("inject_exceptions", ctypes.c_int32), ("group_state_global", ctypes.c_int32), ("aux_state_global", ctypes.c_int32), ("mode", ctypes.c_int32), ("wide_rounds", ctypes.c_int32)]
 
 
 class AssignInfo(ctypes.Structure):

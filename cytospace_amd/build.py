@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcytohip.so")
-SOURCES = ["core.hip", "lap_jv.hip", "cost.hip", "batch.hip"]
+SOURCES = ["core.hip", "lap_jv.hip", "lap_wide.hip", "cost.hip", "batch.hip"]
 # -ffp-contract=off: the JV kernels must evaluate exactly the subtract/compare sequence of the
 # oracle (no FMA contraction, no re-association).  MFMA use in the cost kernels is explicit.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

@@ -68,6 +68,20 @@ int lap_batch_any(int nb, const int *n, const float *const *cost, const int64_t 
     return first;
 }
 
+// One int32 from `root` to every rank (the status word that precedes the operand broadcast: cost.hip, ctx_create_impl).
+int comm_bcast_status(void *comm, int *status, int root, int device_id) {
+    if (!comm || !status) return CYTO_ERR_BAD_ARG;
+    int rc = select_device(device_id);
+    if (rc) return rc;
+    DevBuf word;
+    if ((rc = word.alloc(16))) return rc;
+    CYTO_HIP(hipMemcpy(word.p, status, sizeof(int), hipMemcpyHostToDevice));
+    if (ncclBroadcast(word.p, word.p, 1, ncclInt32, root, reinterpret_cast<ncclComm_t>(comm), nullptr) != ncclSuccess) return CYTO_ERR_HIP;
+    CYTO_HIP(hipStreamSynchronize(nullptr));
+    CYTO_HIP(hipMemcpy(status, word.p, sizeof(int), hipMemcpyDeviceToHost));
+    return CYTO_OK;
+}
+
 }  // namespace cyto
 
 extern "C" {

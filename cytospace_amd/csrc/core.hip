@@ -35,6 +35,8 @@ struct DeviceCache {
 std::mutex g_cache_mutex;
 std::map<int, DeviceCache> g_cache;                // by device
 
+constexpr size_t k_keep_max = (size_t)1 << 30;    // larger blocks are not kept after the call that used them
+
 size_t round_size(size_t b) {
     // 256-byte granules below 1 MiB, 1/8-octave steps above: a slightly larger n finds the block of the last solve
     if (b <= (1u << 20)) return (b + 255) & ~(size_t)255;
@@ -89,26 +91,39 @@ void cache_release(void *p, hipStream_t used_on) {
     if (hipStreamQuery(used_on) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(used_on); }
     int dev = 0;
     (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lk(g_cache_mutex);
-    for (auto &kv : g_cache) {                      // the owning device's cache (normally the current device)
-        auto it = kv.second.live.find(p);
-        if (it != kv.second.live.end()) { kv.second.free_blocks.emplace(it->second, p); return; }
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mutex);
+        for (auto &kv : g_cache) {                  // the owning device's cache (normally the current device)
+            auto it = kv.second.live.find(p);
+            if (it == kv.second.live.end()) continue;
+            // blocks above 1 GiB (a materialised c3 cost matrix is 10 GB) go straight back to the runtime: the hipFree's
+            // device-wide synchronisation is nothing beside the solve that used such a block, and a resident 10 GB block
+            // nobody asked for starves the caller's own allocations
+            if (it->second > k_keep_max) { kv.second.live.erase(it); break; }
+            kv.second.free_blocks.emplace(it->second, p);
+            return;
+        }
     }
-    (void)hipFree(p);                               // not ours (cannot happen)
+    (void)hipFree(p);                               // a large block (or not ours: cannot happen); outside the lock
 }
 
 int set_max_dynamic_lds(const void *kernel) {
+    // hipFuncSetAttribute acts on the CURRENT device's copy of the kernel: remembered per (device, kernel), so a process
+    // that solves on device 0 and then on device 1 sets it on both
     static std::mutex m;
-    static std::set<const void *> done;
+    static std::set<std::pair<int, const void *>> done;
     std::lock_guard<std::mutex> lk(m);
-    if (done.count(kernel)) return CYTO_OK;
+    int dev = 0;
+    CYTO_HIP(hipGetDevice(&dev));
+    const std::pair<int, const void *> key(dev, kernel);
+    if (done.count(key)) return CYTO_OK;
     // the CU has 160 KB; what the kernel declares statically comes off the dynamic allowance
     hipFuncAttributes fa;
     CYTO_HIP(hipFuncGetAttributes(&fa, kernel));
     const int dyn = 160 * 1024 - (int)((fa.sharedSizeBytes + 255) & ~(size_t)255);
     if (dyn < LDS_DYNAMIC_MAX) return CYTO_ERR_INTERNAL;      // a kernel's static LDS outgrew the 2 KB the planners leave for it
     CYTO_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-    done.insert(kernel);
+    done.insert(key);
     return CYTO_OK;
 }
 
@@ -166,7 +181,19 @@ int cyto_malloc(void **dptr, size_t bytes, int device_id) {
     if (!dptr) return CYTO_ERR_BAD_ARG;
     int rc = cyto::select_device(device_id);
     if (rc) return rc;
-    CYTO_HIP(hipMalloc(dptr, bytes ? bytes : 16));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    if (e == hipErrorOutOfMemory) {                 // the solver's cached work blocks are reclaimable: give them back, retry
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+        { std::lock_guard<std::mutex> lk(cyto::g_cache_mutex); cyto::trim_locked(cyto::g_cache[device_id]); }
+        e = hipMalloc(dptr, bytes ? bytes : 16);
+    }
+    if (e != hipSuccess) {
+        *dptr = nullptr;
+        (void)hipGetLastError();
+        cyto::set_hip_error(e, "hipMalloc");
+        return e == hipErrorOutOfMemory ? CYTO_ERR_NOMEM : CYTO_ERR_HIP;
+    }
     return CYTO_OK;
 }
 

@@ -758,37 +758,68 @@ struct cyto_expr_ctx {
 static int ctx_create_impl(int metric, int G, int C, int S, const void *sc, int64_t ldsc_in, int sc_is_f64, int sc_on_device,
                            const void *st, int64_t ldst_in, int st_is_f64, int st_on_device, int already_normalized,
                            void *comm, int root, int rank, int device_id, cyto_expr_ctx **out, double *bcast_ms) {
-    if (!out || G <= 0 || C <= 0 || S <= 0 || !sc || ldsc_in < C) return CYTO_ERR_BAD_ARG;
-    if (metric < CYTO_METRIC_PEARSON || metric > CYTO_METRIC_EUCLIDEAN) return CYTO_ERR_BAD_ARG;
+    // With a communicator every rank MUST reach the collectives below whatever went wrong on it -- a rank that returned early
+    // would leave the others blocked inside ncclBroadcast.  So errors are collected in `rc`, the root's status travels first
+    // (one int32), and the operand follows only if the root succeeded: all ranks fail together, with the root's code.
+    int rc = CYTO_OK;
+    if (!out) return CYTO_ERR_BAD_ARG;                                       // (a caller bug on this rank alone: nothing to agree on)
+    *out = nullptr;
+    if (G <= 0 || C <= 0 || S <= 0 || !sc || ldsc_in < C) rc = CYTO_ERR_BAD_ARG;
+    if (metric < CYTO_METRIC_PEARSON || metric > CYTO_METRIC_EUCLIDEAN) rc = CYTO_ERR_BAD_ARG;
     const bool have_st = !comm || rank == root;
-    if (have_st && (!st || ldst_in < S)) return CYTO_ERR_BAD_ARG;
-    int rc = select_device(device_id);
-    if (rc) return rc;
-    cyto_expr_ctx *ctx = new (std::nothrow) cyto_expr_ctx();
-    if (!ctx) return CYTO_ERR_NOMEM;
-    ctx->metric = metric; ctx->G = G; ctx->Gpad = (int)round_up(G, BK); ctx->C = C; ctx->S = S; ctx->device_id = device_id;
-    ctx->ldsc = round_up(C, BN); ctx->ldst = round_up(S, BM);
+    if (have_st && (!st || ldst_in < S)) rc = CYTO_ERR_BAD_ARG;
+    if (!comm && rc) return rc;
+    int dev_rc = select_device(device_id);
+    if (dev_rc) return dev_rc;                                               // (no device: no communicator could have been made either)
+    cyto_expr_ctx *ctx = rc ? nullptr : new (std::nothrow) cyto_expr_ctx();
+    if (!rc && !ctx) rc = CYTO_ERR_NOMEM;
     const int transform = metric == CYTO_METRIC_PEARSON ? CYTO_TRANSFORM_STANDARDIZE
                         : metric == CYTO_METRIC_SPEARMAN ? CYTO_TRANSFORM_RANK : CYTO_TRANSFORM_RAW;
-    const size_t nst = (size_t)ctx->Gpad * ctx->ldst;
-    if ((rc = ctx->zsc.alloc((size_t)ctx->Gpad * ctx->ldsc * 4)) || (rc = ctx->zst.alloc(nst * 4))) { delete ctx; return rc; }
-    if (have_st)
+    size_t nst = 0;
+    if (!rc) {
+        ctx->metric = metric; ctx->G = G; ctx->Gpad = (int)round_up(G, BK); ctx->C = C; ctx->S = S; ctx->device_id = device_id;
+        ctx->ldsc = round_up(C, BN); ctx->ldst = round_up(S, BM);
+        nst = (size_t)ctx->Gpad * ctx->ldst;
+        if (!(rc = ctx->zsc.alloc((size_t)ctx->Gpad * ctx->ldsc * 4))) rc = ctx->zst.alloc(nst * 4);
+    }
+    auto transform_sc = [&]() {
+        if (!rc) rc = cyto_transform(transform, G, C, sc, ldsc_in, sc_is_f64, sc_on_device, already_normalized, ctx->zsc.as<float>(), ctx->ldsc,
+                                     ctx->Gpad, device_id, nullptr);
+    };
+    // ranks without the ST matrix transform their own cells FIRST: that work overlaps the root's ST transform instead of
+    // waiting behind the broadcast
+    if (comm && rank != root) transform_sc();
+    if (!rc && have_st)
         rc = cyto_transform(transform, G, S, st, ldst_in, st_is_f64, st_on_device, already_normalized, ctx->zst.as<float>(), ctx->ldst,
                             ctx->Gpad, device_id, nullptr);
-    if (!rc && comm) {
-        Events<2> ev;
-        if (!(rc = ev.create())) {
-            (void)hipEventRecord(ev[0], nullptr);
-            rc = cyto_comm_bcast_f32(comm, ctx->zst.as<float>(), nst, root, device_id, nullptr);
-            (void)hipEventRecord(ev[1], nullptr);
-            if (!rc && hipEventSynchronize(ev[1]) != hipSuccess) rc = CYTO_ERR_HIP;
-            float ms = 0;
-            (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
-            if (bcast_ms) *bcast_ms = ms;
+    if (comm) {
+        int root_rc = rc;                                                    // (only the root's value is sent)
+        const int brc = comm_bcast_status(comm, &root_rc, root, device_id);
+        if (brc) rc = rc ? rc : brc;
+        else if (root_rc) rc = rc ? rc : root_rc;                            // the root failed: nobody enters the data broadcast
+        else {
+            // every rank enters (one that failed locally receives into a scratch block so that the others are not left waiting)
+            DevBuf scratch;
+            float *dst = (!rc && ctx) ? ctx->zst.as<float>() : nullptr;
+            size_t count = nst;
+            if (!dst) {
+                count = (size_t)round_up(G > 0 ? G : 1, BK) * (size_t)round_up(S > 0 ? S : 1, BM);
+                if (!scratch.alloc(count * 4)) dst = scratch.as<float>();
+            }
+            Events<2> ev;
+            if (dst && !ev.create()) {
+                (void)hipEventRecord(ev[0], nullptr);
+                const int drc = cyto_comm_bcast_f32(comm, dst, count, root, device_id, nullptr);
+                (void)hipEventRecord(ev[1], nullptr);
+                if (!rc) rc = drc;
+                if (!rc && hipEventSynchronize(ev[1]) != hipSuccess) rc = CYTO_ERR_HIP;
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
+                if (bcast_ms) *bcast_ms = ms;
+            } else if (!rc) rc = CYTO_ERR_NOMEM;
         }
     }
-    if (!rc) rc = cyto_transform(transform, G, C, sc, ldsc_in, sc_is_f64, sc_on_device, already_normalized, ctx->zsc.as<float>(), ctx->ldsc,
-                                 ctx->Gpad, device_id, nullptr);
+    if (!comm || rank == root) transform_sc();
     if (rc) { delete ctx; return rc; }
     *out = ctx;
     return CYTO_OK;

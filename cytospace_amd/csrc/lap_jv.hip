@@ -24,6 +24,8 @@
 // Compile with -ffp-contract=off (build.py does): the arithmetic is subtract/compare only,
 // but nothing may be re-associated.
 #include "cyto_common.h"
+#include "lap_dev.h"
+#include "lap_wide.h"
 #include <math.h>
 #include <type_traits>
 #include <vector>
@@ -1077,95 +1079,8 @@ __global__ __launch_bounds__(BLOCK) void jv_chain_stream(ChainArgs<T> a) {
 // ==========================================================================================
 constexpr int BLOCK2 = 512;        // 8 waves: 256 VGPRs per lane for the column-resident state
 constexpr int NW2 = BLOCK2 / 64;
-constexpr int KC = 64;             // cache slots per row (one per lane of a wave)
-constexpr int KCU = 63;            // usable entries; slot 63 = { COLSENT, floor }
-constexpr uint64_t KEYMAX = ~0ull;
-constexpr uint32_t COLSENT = 0xFFFFFFFFu;
 enum { OP_EXIT = 0, OP_REFRESH = 1, OP_AUG = 2 };
 enum { C2_DENSE_REFRESH = C_NCOUNTERS, C2_AUG_SKIPPED, C2_NCOUNTERS };
-
-__device__ __forceinline__ uint32_t f2ord(float h) {
-    const uint32_t b = __float_as_uint(h + 0.0f);  // +0.0f: -0 -> +0 so that equal floats get equal keys
-    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(uint32_t o) {
-    return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
-}
-__device__ __forceinline__ uint64_t mkkey(float h, uint32_t lowbits) { return ((uint64_t)f2ord(h) << 32) | lowbits; }
-__device__ __forceinline__ float key_val(uint64_t k) { return ord2f((uint32_t)(k >> 32)); }
-__device__ __forceinline__ uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
-__device__ __forceinline__ uint64_t umax64(uint64_t a, uint64_t b) { return a < b ? b : a; }
-__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
-
-struct K2 { uint64_t m1, m2; };  // two smallest keys of a set of DISTINCT keys (or KEYMAX)
-__device__ __forceinline__ void k2_push(K2 &t, uint64_t k) {
-    const uint64_t lo = umin64(t.m1, k), hi = umax64(t.m1, k);
-    t.m1 = lo; t.m2 = umin64(t.m2, hi);
-}
-__device__ __forceinline__ void k2_merge(K2 &a, const K2 &b) {
-    const uint64_t lo = umin64(a.m1, b.m1), hi = umax64(a.m1, b.m1);
-    a.m2 = umin64(hi, umin64(a.m2, b.m2)); a.m1 = lo;
-}
-
-// DPP controls quad_perm[1,0,3,2] (0xB1), quad_perm[2,3,0,1] (0x4E), row_half_mirror (0x141),
-// row_mirror (0x140): a butterfly inside each 16-lane row (merged sets are disjoint at every step).
-template <int CTRL> __device__ __forceinline__ uint32_t dpp32(uint32_t x) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xF, 0xF, true);
-}
-template <int CTRL> __device__ __forceinline__ uint64_t dpp64(uint64_t x) {
-    return ((uint64_t)dpp32<CTRL>((uint32_t)(x >> 32)) << 32) | dpp32<CTRL>((uint32_t)x);
-}
-__device__ __forceinline__ uint32_t readlane32(uint32_t x, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, l); }
-__device__ __forceinline__ uint64_t readlane64(uint64_t x, int l) {
-    return ((uint64_t)readlane32((uint32_t)(x >> 32), l) << 32) | readlane32((uint32_t)x, l);
-}
-__device__ __forceinline__ uint32_t row_min_u32(uint32_t x) {
-    x = umin32(x, dpp32<0xB1>(x)); x = umin32(x, dpp32<0x4E>(x));
-    x = umin32(x, dpp32<0x141>(x)); x = umin32(x, dpp32<0x140>(x));
-    return x;
-}
-// all lanes active; result is wave-uniform (scalar).  (Combining the four row minima with the gfx9 cross-row DPP controls
-// row_bcast:15 / row_bcast:31 and one read-lane instead of four read-lanes + scalar mins was measured: 2 % slower.)
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
-    x = row_min_u32(x);
-    return umin32(umin32(readlane32(x, 0), readlane32(x, 16)), umin32(readlane32(x, 32), readlane32(x, 48)));
-}
-template <int CTRL> __device__ __forceinline__ void k2_step(K2 &t) {
-    K2 o; o.m1 = dpp64<CTRL>(t.m1); o.m2 = dpp64<CTRL>(t.m2);
-    k2_merge(t, o);
-}
-__device__ __forceinline__ void k2_row_allreduce(K2 &t) {
-    k2_step<0xB1>(t); k2_step<0x4E>(t); k2_step<0x141>(t); k2_step<0x140>(t);
-}
-__device__ __forceinline__ K2 k2_wave_allreduce(K2 t) {
-    k2_row_allreduce(t);
-    K2 r; r.m1 = readlane64(t.m1, 0); r.m2 = readlane64(t.m2, 0);
-#pragma unroll
-    for (int row = 1; row < 4; row++) {
-        K2 o; o.m1 = readlane64(t.m1, row * 16); o.m2 = readlane64(t.m2, row * 16);
-        k2_merge(r, o);
-    }
-    return r;
-}
-__device__ __forceinline__ uint64_t min64_row_allreduce(uint64_t x) {
-    x = umin64(x, dpp64<0xB1>(x)); x = umin64(x, dpp64<0x4E>(x));
-    x = umin64(x, dpp64<0x141>(x)); x = umin64(x, dpp64<0x140>(x));
-    return x;
-}
-__device__ __forceinline__ uint64_t min64_wave_allreduce(uint64_t x) {
-    x = min64_row_allreduce(x);
-    uint64_t r = readlane64(x, 0);
-#pragma unroll
-    for (int row = 1; row < 4; row++) r = umin64(r, readlane64(x, row * 16));
-    return r;
-}
-
-// Barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its outstanding global
-// stores/loads (a plain __syncthreads() carries s_waitcnt vmcnt(0): in the augmentation that made every
-// step wait for the owner lane's global store to be acknowledged by HBM).
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 // a wave's candidate for the next pick of the dense augmentation, with everything the step needs once it wins
 struct __attribute__((aligned(16))) PickRec { uint64_t key; int32_t row; float h; float vjp; int32_t g; int32_t skip; int32_t srow; };   // srow: the stored row (row map applied)
@@ -2973,14 +2888,14 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(const LazyArgs *__restrict
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-static const cyto_lap_opts k_default_opts = {0, 0, 0, 0, 0, 0, {0, 0}};
+static const cyto_lap_opts k_default_opts = {0, 0, 0, 0, 0, 0, 0, 0};
 
 static int check_opts(const cyto_lap_opts &o) {
     if (o.chain_variant < 0 || o.chain_variant > 3 || o.augmentation < 0 || o.augmentation > 2 || o.inject_exceptions < 0 ||
         o.no_handover < 0 || o.no_handover > 1)
         return CYTO_ERR_BAD_ARG;
     if (o.group_state_global < 0 || o.group_state_global > 1 || o.aux_state_global < 0 || o.aux_state_global > 1) return CYTO_ERR_BAD_ARG;
-    for (int k = 0; k < 2; k++) if (o.reserved[k]) return CYTO_ERR_BAD_ARG;
+    if (o.mode < 0 || o.mode > 2 || o.wide_rounds < -1) return CYTO_ERR_BAD_ARG;
     return CYTO_OK;
 }
 
@@ -2994,7 +2909,7 @@ struct F32Job {
     int status = CYTO_OK;
     // device state
     DevBuf staged, b_fws, b_iws, b_imin, b_pmin, b_parg, b_misc, b_same, b_gid, b_ccol, b_cval, b_ghb, b_ghs, b_lzhb, b_lzhs;
-    DevBuf b_rowmap, b_ulist, b_ufirst;
+    DevBuf b_rowmap, b_ulist, b_ufirst, b_wide;
     int nused = 0;
     const float *dcost = nullptr; int64_t dld = 0;
     int h_nonfinite = 0, h_ngroups = 0, h_hand[3] = {0, 0, 0};
@@ -3005,7 +2920,8 @@ struct F32Job {
 
 struct F32Plan {            // what depends on n (and the options) only: identical for every problem of the batch
     int n, colblocks, rowblocks, rows_per_block, cache_grid;
-    bool force_l2, lds_variant, lazy, lz_lds_state, lz_cs_lds, no_cs_lds;
+    bool force_l2, lds_variant, lazy, lz_lds_state, lz_cs_lds, no_cs_lds, wide;
+    long long wide_rounds;
     size_t shm_chain, lz_base_shm;
 };
 
@@ -3050,6 +2966,41 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
 
     if ((rc = build_caches())) return rc;
     CYTO_HIP(hipEventRecord(ev_cache_done, stream));
+    if (pl.wide) {
+        // the wide solver (lap_wide.hip): Jacobi reduction transfer, Jacobi rounds of row reduction, speculative shortest-path
+        // augmentation -- one launch per phase for the whole batch
+        const size_t nT = (size_t)n * sizeof(float);
+        std::vector<WideArgs> h_wa((size_t)nl);
+        for (int k = 0; k < nl; k++) {
+            F32Job &j = jobs[live[k]];
+            if ((rc = j.b_wide.alloc(4 * nT + 64, stream))) return rc;
+            const Chain2Args &c = j.c2;
+            WideArgs &wa = h_wa[k];
+            wa.n = n; wa.ld = c.ld; wa.cost = c.cost; wa.rowmap = c.rowmap;
+            wa.v = c.fws; wa.u = c.fws + n; wa.cassign = c.fws + 3 * (int64_t)n;
+            wa.label = reinterpret_cast<unsigned long long *>(c.fws + 4 * (int64_t)n);
+            wa.rowsol = c.iws; wa.colsol = c.iws + n; wa.matches = c.iws + 2 * (int64_t)n; wa.freerows = c.iws + 3 * (int64_t)n;
+            wa.act0 = c.iws + 4 * (int64_t)n; wa.act1 = c.iws + 5 * (int64_t)n; wa.touched = c.iws + 6 * (int64_t)n;
+            wa.slot_j = c.iws + 7 * (int64_t)n;
+            wa.bid = reinterpret_cast<unsigned long long *>(c.iws + 8 * (int64_t)n);
+            wa.slot_p = j.b_wide.as<float>(); wa.slot_c = wa.slot_p + n;
+            wa.cache_col = c.cache_col; wa.cache_val = c.cache_val; wa.misc = c.misc;
+            wa.max_rounds = pl.wide_rounds;
+            // the post-column-reduction prices: snapshot for the reduction transfer AND the raw cost of every owner entry
+            CYTO_HIP(hipMemcpyAsync(wa.cassign, wa.v, nT, hipMemcpyDeviceToDevice, stream));
+            CYTO_HIP(hipMemsetAsync(wa.label, 0xFF, 2 * nT, stream));
+            CYTO_HIP(hipMemsetAsync(wa.bid, 0xFF, 2 * nT, stream));
+        }
+        DevBuf d_wa;
+        if ((rc = d_wa.alloc(sizeof(WideArgs) * nl, stream))) return rc;
+        CYTO_HIP(hipMemcpyAsync(d_wa.p, h_wa.data(), sizeof(WideArgs) * nl, hipMemcpyHostToDevice, stream));
+        if ((rc = wide_launch_rt(d_wa.as<WideArgs>(), nl, n, stream)) || (rc = wide_launch_arr(d_wa.as<WideArgs>(), nl, n, stream))) return rc;
+        CYTO_HIP(hipEventRecord(ev_arr_done, stream));
+        if ((rc = build_caches())) return rc;                      // fresh floors against the prices the augmentation starts from
+        if ((rc = wide_launch_aug(d_wa.as<WideArgs>(), nl, n, stream))) return rc;
+        CYTO_HIP(hipStreamSynchronize(stream));                    // (d_wa is read by the kernels until here)
+        return CYTO_OK;
+    }
     if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern)))) return rc;
     if (pl.shm_chain > (size_t)LDS_DYNAMIC_MAX || shm_aug > (size_t)LDS_DYNAMIC_MAX || shm_lazy > (size_t)LDS_DYNAMIC_MAX) return CYTO_ERR_INTERNAL;
     hipLaunchKernelGGL(kern, dim3(nl), dim3(BLOCK2), pl.shm_chain, stream, d_c2.as<Chain2Args>());
@@ -3125,6 +3076,8 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
     const int per2 = 4 * BLOCK2;
     // which chain variant: by size, or the large-n variants forced at a small n (opts.chain_variant; the test-suite
     // runs them on instances the CPU oracle solves in a second)
+    pl.wide = opts.mode == 2;
+    pl.wide_rounds = opts.wide_rounds < 0 ? 0 : (opts.wide_rounds > 0 ? opts.wide_rounds : 4096 + (long long)n / 4);
     pl.force_l2 = opts.chain_variant != 0;
     pl.no_cs_lds = opts.chain_variant == 3;            // (3: as 2, with colsol in global memory too -- what n > 65 535 uses)
     pl.lds_variant = !pl.force_l2 && n <= 13 * per2;
@@ -3349,6 +3302,15 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
                 if (h[2] < h[0]) info->aug_handover = h[2];
             }
             info->row_groups = j.h_ngroups;
+            if (pl.wide) {
+                long long wc[WC_N] = {0};
+                CYTO_HIP(hipMemcpy(wc, j.b_misc.as<char>() + 160, sizeof wc, hipMemcpyDeviceToHost));
+                info->wide = 1;
+                info->wide_rounds = wc[WC_ROUNDS]; info->wide_retired = wc[WC_RETIRED]; info->wide_dense_arr = wc[WC_DENSE_ARR];
+                info->wide_dense_aug = wc[WC_DENSE_AUG]; info->wide_aug_rounds = wc[WC_AUG_ROUNDS]; info->wide_aug_settled = wc[WC_AUG_PROCESSED];
+                info->wide_trivial = wc[WC_TRIVIAL]; info->wide_verify_passes = wc[WC_VERIFY_PASSES];
+                info->aug_handover = -1;
+            }
         }
         if (h_status) j.status = CYTO_ERR_INTERNAL;
     }

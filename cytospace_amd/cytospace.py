@@ -101,14 +101,15 @@ class ExpressionContext:
             return
         sc = np.asarray(sc)
         have_st = st is not None
-        if comm.rank == root and not have_st:
-            raise ValueError("the root rank must pass the ST matrix")
         if have_st:
             sc, st, is64 = _pair(sc, st)
             n_spots = st.shape[1]
         else:
-            if n_spots is None:
+            # (a root without the ST matrix is NOT rejected here: the other ranks are already on their way into the
+            #  collective, so the call goes through and the library's status word fails every rank together)
+            if n_spots is None and comm.rank != root:
                 raise ValueError("n_spots is required on ranks that do not hold the ST matrix")
+            n_spots = 1 if n_spots is None else n_spots
             is64 = int(sc.dtype != np.float32)
             sc = np.ascontiguousarray(sc, dtype=np.float64 if is64 else np.float32)
         self.G, self.C = sc.shape

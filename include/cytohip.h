@@ -81,6 +81,16 @@ typedef struct {
     int64_t aug_sparse_inits; /* augmentations whose initial row scan was served from the row cache */
     int64_t aug_handover;    /* -1, or the index of the search at which the cache-certified augmentation handed the
                                 remaining free rows to the dense kernel (its certificates kept failing) */
+    /* wide solver (cyto_lap_opts.mode = 2) */
+    int64_t wide;                /* 1: solved by the wide solver */
+    int64_t wide_rounds;         /* Jacobi rounds of augmenting row reduction that ran */
+    int64_t wide_retired;        /* rows that left the rounds on a tie (handed to the augmentation) */
+    int64_t wide_dense_arr;      /* bids whose row cache could not certify the top-2 (full row read) */
+    int64_t wide_dense_aug;      /* augmentation: relaxations from the full cost row (cache certificate failed) */
+    int64_t wide_aug_rounds;     /* augmentation: rounds of the speculative search (16 columns settled per round at most) */
+    int64_t wide_aug_settled;    /* augmentation: columns settled, re-settlements after a label improved included */
+    int64_t wide_trivial;        /* augmentation: searches that ended at the free row's own best column */
+    int64_t wide_verify_passes;  /* augmentation: certificate passes (>= one per non-trivial search) */
 } cyto_lap_info;
 
 int cyto_lap_f32(int n, const float *cost, int64_t ld, int cost_on_device,
@@ -90,7 +100,7 @@ int cyto_lap_f64(int n, const double *cost, int64_t ld, int cost_on_device,
                  int32_t *rowsol, int32_t *colsol, double *u, double *v, double *total,
                  cyto_lap_info *info, int device_id, void *stream);
 
-/* The same solves with explicit kernel-selection options.  Results never depend on them (every variant realises the same
+/* The same solves with explicit kernel-selection options.  Within one `mode`, results never depend on them (every variant realises the same
  * search, bit for bit); they exist so that the kernels the solver picks for n > 26 624 / 32 768 and the hand-over paths can
  * be exercised on instances small enough for the CPU oracle (tests/test_lap_gpu.py).  NULL = the defaults. */
 typedef struct {
@@ -107,7 +117,12 @@ typedef struct {
                                    where it fits LDS -- what large problems with thousands of row groups use */
     int32_t aux_state_global;   /* 1: the dense augmentation's per-column auxiliaries (cost of the assigned entry, owner's row group) in
                                    global memory even where they fit LDS -- what n > ~13 000 uses */
-    int32_t reserved[2];        /* must be 0 */
+    int32_t mode;               /* 0: default.  1: the chain solver (classic Gauss-Seidel order: reduction transfer and augmenting row
+                                   reduction row after row, Dijkstra one column per step -- oracle/jv_oracle_impl.h, first half).
+                                   2: the wide solver (Jacobi reduction transfer, Jacobi rounds of row reduction, speculative
+                                   succ-clamped shortest paths -- same file, "WIDE MODE"; float32).  Both reach the same optimum;
+                                   the duals and, where the optimum is not unique, the particular optimal assignment differ */
+    int32_t wide_rounds;        /* wide solver: budget of row-reduction rounds.  0: 4096 + n / 4.  -1: none */
 } cyto_lap_opts;
 int cyto_lap_f32_opts(int n, const float *cost, int64_t ld, int cost_on_device,
                       int32_t *rowsol, int32_t *colsol, float *u, float *v, double *total,

@@ -73,3 +73,42 @@ def jv_oracle(cost, dtype=np.float32):
     if rc != 0:
         raise RuntimeError(f"jv_oracle failed with status {rc}")
     return dict(rowsol=rowsol, colsol=colsol, u=u, v=v, total=tot.value, total_T=tt.value, stats=st)
+
+
+class JVWideStats(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int64) for k in (
+        "scans_redtransfer", "scans_arr", "scans_aug_init", "scans_aug_relax", "augmentations", "path_hops",
+        "free_after_colred", "free_after_arr", "arr_rounds", "arr_retired", "arr_active_left")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+def jv_oracle_wide(cost, dtype=np.float32, max_rounds=-1, stop_phase=0):
+    """The wide-mode restatement (jv_oracle_impl.h, second half): Jacobi reduction transfer, Jacobi rounds of augmenting row
+    reduction, succ-clamped shortest-path augmentation -- what the HIP "wide" solver computes bit for bit.  Same optimum as
+    jv_oracle.  stop_phase 1 / 2: the state after reduction transfer / after the row-reduction rounds."""
+    c = np.ascontiguousarray(cost, dtype=dtype)
+    if c.ndim != 2 or c.shape[0] != c.shape[1]:
+        raise ValueError("cost must be a square 2-D array")
+    n = c.shape[0]
+    rowsol = np.empty(n, np.int32)
+    colsol = np.empty(n, np.int32)
+    u = np.empty(n, dtype)
+    v = np.empty(n, dtype)
+    tot = ctypes.c_double()
+    st = JVWideStats()
+    if dtype == np.float32:
+        fn, tt = _lib().jv_oracle_wide_f32, ctypes.c_float()
+    elif dtype == np.float64:
+        fn, tt = _lib().jv_oracle_wide_f64, ctypes.c_double()
+    else:
+        raise TypeError("dtype must be float32 or float64")
+    fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int]
+    rc = fn(n, c.ctypes.data, rowsol.ctypes.data, colsol.ctypes.data, u.ctypes.data, v.ctypes.data,
+            ctypes.addressof(tot), ctypes.addressof(tt), ctypes.addressof(st), int(max_rounds), int(stop_phase))
+    if rc == 2:
+        raise ValueError("cost matrix contains NaN/Inf")
+    if rc != 0:
+        raise RuntimeError(f"jv_oracle_wide failed with status {rc}")
+    return dict(rowsol=rowsol, colsol=colsol, u=u, v=v, total=tot.value, total_T=tt.value, stats=st)

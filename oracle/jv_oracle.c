@@ -10,9 +10,11 @@
 
 #define T float
 #define SUFFIX f32
+#define JV_T_IS_FLOAT 1
 #include "jv_oracle_impl.h"
 #undef T
 #undef SUFFIX
+#undef JV_T_IS_FLOAT
 
 #define T double
 #define SUFFIX f64

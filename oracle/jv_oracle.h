@@ -29,6 +29,24 @@ int jv_oracle_f32(int n, const float *cost, int32_t *rowsol, int32_t *colsol, fl
 int jv_oracle_f64(int n, const double *cost, int32_t *rowsol, int32_t *colsol, double *u, double *v,
                   double *total_f64, double *total_T, jv_stats *st);
 
+/* ---- wide mode (jv_oracle_impl.h, second half): Jacobi reduction transfer, Jacobi rounds of augmenting row reduction,
+ * succ-clamped shortest-path augmentation.  Same optimum as the classic mode; what the HIP "wide" solver computes bit for bit.
+ * max_rounds < 0: JV_WIDE_ROUNDS(n).  stop_phase: 0 = solve; 1 = return the state after reduction transfer, 2 = after the
+ * row-reduction rounds (rowsol[i] = -1 for free rows, colsol[j] = -1 for unassigned columns; u[free] = 0). */
+typedef struct {
+    int64_t scans_redtransfer, scans_arr, scans_aug_init, scans_aug_relax;
+    int64_t augmentations, path_hops;
+    int64_t free_after_colred, free_after_arr;
+    int64_t arr_rounds, arr_retired, arr_active_left;
+} jv_wide_stats;
+
+#define JV_WIDE_ROUNDS(n) (4096 + (int64_t)(n) / 4)
+
+int jv_oracle_wide_f32(int n, const float *cost, int32_t *rowsol, int32_t *colsol, float *u, float *v,
+                       double *total_f64, float *total_T, jv_wide_stats *st, int64_t max_rounds, int stop_phase);
+int jv_oracle_wide_f64(int n, const double *cost, int32_t *rowsol, int32_t *colsol, double *u, double *v,
+                       double *total_f64, double *total_T, jv_wide_stats *st, int64_t max_rounds, int stop_phase);
+
 #ifdef __cplusplus
 }
 #endif

@@ -221,6 +221,227 @@ int FN(jv_oracle_)(int n, const T *restrict cost, int32_t *restrict rowsol,
     return JV_OK;
 }
 
+
+/* =====================================================================================================
+ * WIDE MODE -- the same four JV phases in a form whose every phase has width (what the HIP "wide" solver
+ * computes; TEST INFRASTRUCTURE like the rest of this file).
+ *
+ * The classic order above is a Gauss-Seidel chain: reduction transfer and augmenting row reduction visit
+ * one row after the other and every step sees the prices the previous one left; the Dijkstra search settles
+ * one column per step.  Nothing in the METHOD needs that order -- any prices v with "every assigned row sits
+ * on a minimum of its reduced costs c[i][.] - v[.]" are a valid state for the augmentation phase, and the
+ * optimum reached is the same one (unique optimum => identical indices).  Wide mode fixes an order-free
+ * definition of each phase, so that a massively parallel schedule and this serial restatement produce the
+ * same bits:
+ *
+ *  COLUMN REDUCTION     as above.
+ *  REDUCTION TRANSFER   Jacobi: every row that owns exactly one column computes its margin against the
+ *                       post-column-reduction prices v0 (all rows read the same snapshot), then all margins
+ *                       are subtracted.  (Other prices can only have dropped too, so the margin is still a
+ *                       lower bound of the true second-best: the owned column stays a row minimum.)
+ *  AUGMENTING ROW REDUCTION  Jacobi rounds of an eps = 0 auction.  In a round EVERY active free row takes the
+ *                       lexicographic top-2 (value, column) of its reduced costs against the round's price
+ *                       snapshot and bids p = v[j1] - (u2 - u1) for its best column j1; if that does not
+ *                       lower the price (a tie) it may only claim an UNASSIGNED column at its current price
+ *                       (j1, else j2 when u2 == u1), otherwise it retires to the augmentation phase.  Per
+ *                       column the lowest (price, row) wins: price, owner and the displaced owner (active in
+ *                       the next round) change together; losers stay active.  Stops when no row is active
+ *                       or after JV_WIDE_ROUNDS(n) rounds.  A round is a pure function of the state: the
+ *                       order in which rows are visited cannot matter.
+ *  AUGMENTATION         free rows in ascending order, each by a shortest-path search whose labels are the
+ *                       UNIQUE fixed point of a monotone system, so that any label-correcting schedule
+ *                       (speculative, parallel) and Dijkstra's order below agree bit for bit:
+ *                         root f:               d[j] = fl(c[f][j] - v[j])
+ *                         column jp (label dp, owner i), h = fl(fl(c[i][jp] - v[jp]) - dp):
+ *                                               cand(j) = max( fl(fl(c[i][j] - v[j]) - h), succ(dp) )
+ *                       succ = next representable value: a label is strictly larger than its predecessor's,
+ *                       which (a) removes the rounding anomaly cand < dp, (b) makes equal-label columns
+ *                       independent of each other, (c) makes every predecessor chain acyclic on duplicated
+ *                       rows, where tight cycles are the rule.  pred[j] = the LOWEST row among those attaining
+ *                       d[j].  The search ends at the unassigned column with the smallest (label, column);
+ *                       columns with a label < that distance get the classic price update, clamped so that a
+ *                       price never rises: v[k] = min(v[k], fl(fl(v[k] + d[k]) - dist)).
+ * ===================================================================================================== */
+static inline T FN(succ_)(T x) {
+#if defined(JV_T_IS_FLOAT)
+    return nextafterf(x + 0.0f, INFINITY);
+#else
+    return nextafter(x + 0.0, INFINITY);
+#endif
+}
+
+int FN(jv_oracle_wide_)(int n, const T *restrict cost, int32_t *restrict rowsol, int32_t *restrict colsol,
+                        T *restrict u, T *restrict v, double *total_f64, T *total_T, jv_wide_stats *st,
+                        int64_t max_rounds, int stop_phase) {
+    jv_wide_stats s;
+    memset(&s, 0, sizeof s);
+    if (n <= 0) return JV_ERR_BAD_ARG;
+    const size_t N = (size_t)n;
+    for (size_t k = 0; k < N * N; k++)
+        if (!isfinite((double)cost[k])) return JV_ERR_NONFINITE;
+    if (max_rounds < 0) max_rounds = JV_WIDE_ROUNDS(n);
+
+    int32_t *freerows = (int32_t *)malloc(N * sizeof(int32_t));
+    int32_t *matches = (int32_t *)calloc(N, sizeof(int32_t));
+    int32_t *pred = (int32_t *)malloc(N * sizeof(int32_t));
+    int32_t *imin = (int32_t *)malloc(N * sizeof(int32_t));
+    int32_t *bidrow = (int32_t *)malloc(N * sizeof(int32_t));
+    int32_t *touched = (int32_t *)malloc(N * sizeof(int32_t));
+    uint8_t *scanned = (uint8_t *)malloc(N);
+    uint8_t *active = (uint8_t *)calloc(N, 1);
+    T *d = (T *)malloc(N * sizeof(T));
+    T *bidp = (T *)malloc(N * sizeof(T));
+    T *margin = (T *)malloc(N * sizeof(T));
+    int rc = JV_OK;
+    if (!freerows || !matches || !pred || !imin || !bidrow || !touched || !scanned || !active || !d || !bidp || !margin) { rc = JV_ERR_NOMEM; goto done; }
+
+    /* ---- COLUMN REDUCTION (identical to the classic mode) ---- */
+    for (int j = 0; j < n; j++) { v[j] = cost[j]; imin[j] = 0; }
+    for (int i = 1; i < n; i++) {
+        const T *restrict ci = cost + (size_t)i * N;
+        for (int j = 0; j < n; j++)
+            if (ci[j] < v[j]) { v[j] = ci[j]; imin[j] = i; }
+    }
+    for (int i = 0; i < n; i++) rowsol[i] = -1;
+    for (int j = n - 1; j >= 0; j--) {
+        int i = imin[j];
+        if (++matches[i] == 1) { rowsol[i] = j; colsol[j] = i; }
+        else colsol[j] = -1;
+    }
+
+    /* ---- REDUCTION TRANSFER, Jacobi ---- */
+    for (int i = 0; i < n; i++) {
+        if (matches[i] == 1 && n > 1) {
+            const int j1 = rowsol[i];
+            const T *restrict ci = cost + (size_t)i * N;
+            T mn = (T)INFINITY;
+            for (int j = 0; j < n; j++) {
+                T h = ci[j] - v[j];
+                if (j != j1 && h < mn) mn = h;
+            }
+            margin[i] = mn;
+            s.scans_redtransfer++;
+        }
+    }
+    for (int i = 0; i < n; i++)
+        if (matches[i] == 1 && n > 1) v[rowsol[i]] = v[rowsol[i]] - margin[i];
+    int nact = 0;
+    for (int i = 0; i < n; i++) if (rowsol[i] < 0) { active[i] = 1; nact++; }
+    s.free_after_colred = nact;
+    if (stop_phase == 1) goto finish;
+
+    /* ---- AUGMENTING ROW REDUCTION, Jacobi rounds ---- */
+    for (int j = 0; j < n; j++) bidrow[j] = -1;
+    while (nact > 0 && s.arr_rounds < max_rounds) {
+        int ntouched = 0;
+        for (int i = 0; i < n; i++) {
+            if (!active[i]) continue;
+            T umin, usub; int j1, j2;
+            FN(top2_)(n, cost + (size_t)i * N, v, &umin, &j1, &usub, &j2);
+            s.scans_arr++;
+            const T p = v[j1] - (usub - umin);
+            int jt = -1; T pt = 0;
+            if (p < v[j1]) { jt = j1; pt = p; }
+            else if (colsol[j1] < 0) { jt = j1; pt = v[j1]; }
+            else if (j2 >= 0 && usub == umin && colsol[j2] < 0) { jt = j2; pt = v[j2]; }
+            else { active[i] = 0; s.arr_retired++; }
+            if (jt >= 0) {
+                if (bidrow[jt] < 0) { touched[ntouched++] = jt; bidrow[jt] = i; bidp[jt] = pt; }
+                else if (pt < bidp[jt]) { bidrow[jt] = i; bidp[jt] = pt; }      /* rows ascend: an equal price keeps the lower row */
+            }
+        }
+        for (int t = 0; t < ntouched; t++) {
+            const int j = touched[t], w = bidrow[j], i0 = colsol[j];
+            v[j] = bidp[j]; colsol[j] = w; rowsol[w] = j; active[w] = 0;
+            if (i0 >= 0) { rowsol[i0] = -1; active[i0] = 1; }
+            bidrow[j] = -1;
+        }
+        nact = 0;
+        for (int i = 0; i < n; i++) nact += active[i];
+        s.arr_rounds++;
+    }
+    s.arr_active_left = nact;
+    {
+        int numfree = 0;
+        for (int i = 0; i < n; i++) if (rowsol[i] < 0) freerows[numfree++] = i;
+        s.free_after_arr = numfree;
+        if (stop_phase == 2) goto finish;
+
+        /* ---- AUGMENTATION: succ-clamped shortest paths (see the header of this mode) ---- */
+        for (int f = 0; f < numfree; f++) {
+            const int freerow = freerows[f];
+            const T *restrict cf = cost + (size_t)freerow * N;
+            for (int j = 0; j < n; j++) { d[j] = cf[j] - v[j]; pred[j] = freerow; scanned[j] = 0; }
+            s.scans_aug_init++;
+            int endofpath = -1;
+            T dist = 0;
+            for (;;) {
+                T dmin = (T)INFINITY;
+                for (int j = 0; j < n; j++) {
+                    T dj = scanned[j] ? (T)INFINITY : d[j];
+                    dmin = dj < dmin ? dj : dmin;
+                }
+                int jpick = -1, jfirst = -1;
+                for (int j = 0; j < n; j++) {
+                    if (!scanned[j] && d[j] == dmin) {
+                        if (jfirst < 0) jfirst = j;
+                        if (colsol[j] < 0) { jpick = j; break; }
+                    }
+                }
+                if (jpick < 0) jpick = jfirst;
+                if (jpick < 0) { rc = JV_ERR_INTERNAL; goto done; }
+                if (colsol[jpick] < 0) { endofpath = jpick; dist = dmin; break; }
+                scanned[jpick] = 1;
+                const int i = colsol[jpick];
+                const T *restrict ci = cost + (size_t)i * N;
+                const T h = (ci[jpick] - v[jpick]) - dmin;
+                const T lo = FN(succ_)(dmin);
+                for (int j = 0; j < n; j++) {
+                    T v2 = (ci[j] - v[j]) - h;
+                    v2 = v2 < lo ? lo : v2;
+                    const int upd = ((v2 < d[j]) | ((v2 == d[j]) & (i < pred[j]))) & !scanned[j];
+                    d[j] = upd ? v2 : d[j];
+                    pred[j] = upd ? i : pred[j];
+                }
+                s.scans_aug_relax++;
+            }
+            for (int j = 0; j < n; j++)
+                if (scanned[j] && d[j] < dist) { const T nv = (v[j] + d[j]) - dist; if (nv < v[j]) v[j] = nv; }
+            int i;
+            do {
+                i = pred[endofpath];
+                colsol[endofpath] = i;
+                const int j1 = endofpath;
+                endofpath = rowsol[i];
+                rowsol[i] = j1;
+                s.path_hops++;
+            } while (i != freerow);
+            s.augmentations++;
+        }
+    }
+
+finish:
+    {
+        double tot = 0.0;
+        T totT = 0;
+        for (int i = 0; i < n; i++) {
+            const int j = rowsol[i];
+            if (j < 0) { u[i] = 0; continue; }                 /* (only with stop_phase != 0) */
+            const T cij = cost[(size_t)i * N + j];
+            u[i] = cij - v[j];
+            totT = totT + cij;
+            tot += (double)cij;
+        }
+        if (total_f64) *total_f64 = tot;
+        if (total_T) *total_T = totT;
+    }
+    if (st) *st = s;
+done:
+    free(freerows); free(matches); free(pred); free(imin); free(bidrow); free(touched); free(scanned); free(active);
+    free(d); free(bidp); free(margin);
+    return rc;
+}
+
 #undef FN
 #undef CAT
 #undef CAT_
