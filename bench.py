@@ -59,15 +59,20 @@ def extra_n50000(dev):
     buf.free()
     i = r["info"]
     out = {"n": n, "ms_per_solve": round(wall * 1e3, 1), "assignments_per_s": round(n / wall, 1),
-           "kernel_ms": {"colred": round(i.ms_colred, 2), "row_caches": round(i.ms_cache, 2), "jv_chain2": round(i.ms_arr, 1),
-                         "jv_aug_lazy": round(i.ms_aug, 1)},
+           "kernel_ms": {"colred": round(i.ms_colred, 2), "row_caches": round(i.ms_cache, 2), "wide_rt+wide_arr" if i.wide else "jv_chain2": round(i.ms_arr, 1),
+                         "wide_aug" if i.wide else "jv_aug_lazy": round(i.ms_aug, 1)},
            "row_scans": int(i.row_scans), "algorithmic_GBs": round(4.0 * n * i.row_scans / wall / 1e9, 1),
            "hbm_frac_algorithmic": round(4.0 * n * i.row_scans / wall / 1e9 / HBM_PEAK_GBS, 5),
            "instance_seconds": round(t_gen, 1)}
     gpath = os.path.join(ROOT, "tests", "golden", "large_u50000.npz")
     if os.path.exists(gpath):
         d = np.load(gpath)
-        ok = bool(np.array_equal(r["colsol"], d["colsol"]) and _sha(r["u"]) == str(d["u_sha256"]) and _sha(r["v"]) == str(d["v_sha256"]))
+        ok = bool(np.array_equal(r["colsol"], d["colsol"]))           # the golden is uniqueness-certified: ANY exact solver's indices
+        wpath = os.path.join(ROOT, "tests", "golden", "large_u50000_wide.npz")
+        if ok and i.wide and os.path.exists(wpath):                  # ... and the wide restatement's duals, bit for bit
+            dw = np.load(wpath)
+            ok = bool(_sha(r["u"]) == str(dw["u_sha256"]) and _sha(r["v"]) == str(dw["v_sha256"]) and _sha(r["rowsol"]) == str(dw["rowsol_sha256"]))
+            out["duals_bit_exact_vs_wide_oracle_golden"] = ok
         out["bit_exact_vs_oracle_golden"] = ok
         if not ok:
             raise SystemExit("n50000: HIP result differs from tests/golden/large_u50000.npz")
@@ -253,7 +258,7 @@ def extra_c5_chunks(dev, K=50, G=500, chunk=10000, sets=8, cpu_n=10000, cpu_thre
     with ThreadPoolExecutor(T) as ex:
         ora = list(ex.map(lambda k: jv_oracle(costs[k % distinct], np.float32), range(T)))
     cpu_wall = time.perf_counter() - t
-    gp = [lap_solve(costs[k], np.float32, device_id=dev, return_info=True) for k in range(distinct)]
+    gp = [lap_solve(costs[k], np.float32, device_id=dev, return_info=True, opts=dict(mode=1)) for k in range(distinct)]   # the chain solver, as in the batch
     if not all(np.array_equal(gp[k]["colsol"], ora[k]["colsol"]) and np.array_equal(gp[k]["v"], ora[k]["v"]) for k in range(min(distinct, T))):
         raise SystemExit("c5_chunks: HIP result differs from the CPU oracle on the CPU sample")
     i0 = res[0][2]
@@ -326,7 +331,7 @@ def extra_c4_sharded(dev, rank, world, dist, chunks_per_rank, G=5000, S=50000, c
     comm.close()
     if dist is not None:
         import torch
-        tt = torch.tensor([el], dtype=torch.float64, device="cuda" if torch.cuda.is_available() else "cpu")
+        tt = torch.tensor([el], dtype=torch.float64, device=f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     i0 = res[0][2]
@@ -360,7 +365,7 @@ def main():
     ap.add_argument("--c4-chunks", type=int, default=256, help="concurrent chunk LAPs in the c4_chunks leg (256 = one chain per CU; 400 MB each)")
     ap.add_argument("--c4-rank-chunks", type=int, default=64, help="chunks per rank in the c4_sharded leg")
     ap.add_argument("--sharded-timeout", type=float, default=420.0, help="watchdog of the c4_sharded leg, seconds")
-    ap.add_argument("--pmc-tag", default="r02d", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
+    ap.add_argument("--pmc-tag", default="r03a", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
     args = ap.parse_args()
 
     # ONE JSON line on stdout: everything else this process (or a library under it: RCCL prints a version banner through C
@@ -381,7 +386,7 @@ def main():
 
     from cytospace_amd import _lib
     from cytospace_amd.lap import lap_solve
-    from oracle.jv import jv_oracle   # checker + cpu_baseline leg only
+    from oracle.jv import jv_oracle, jv_oracle_wide   # checker + cpu_baseline leg only
 
     ndev = _lib.device_count()
     if ndev < 1:
@@ -399,14 +404,19 @@ def main():
                 torch.cuda.synchronize()
         _lib.check(_lib.lib().cyto_device_synchronize(dev))
 
-    # ---- parity gate on a size the oracle finishes in a second (bit-exact, incl. duals) ----
+    # ---- parity gate on a size the oracles finish in a second (bit-exact, incl. duals): the wide solver (what a single
+    # solve runs) against its restatement, the chain solver (what the batched legs run) against the classic restatement ----
     pn = 3000
     pc = make_cost(pn, 1234 + rank)
     g = lap_solve(pc, np.float32, device_id=dev, return_info=True)
+    ow = jv_oracle_wide(pc, np.float32)
+    gc = lap_solve(pc, np.float32, device_id=dev, return_info=True, opts=dict(mode=1))
     o = jv_oracle(pc, np.float32)
-    parity_small = bool(np.array_equal(g["colsol"], o["colsol"]) and np.array_equal(g["rowsol"], o["rowsol"])
-                        and np.array_equal(g["u"], o["u"]) and np.array_equal(g["v"], o["v"])
-                        and g["info"].row_scans == o["stats"].row_scans)
+    parity_small = bool(g["info"].wide == 1 and all(np.array_equal(g[k], ow[k]) for k in ("rowsol", "colsol", "u", "v"))
+                        and g["info"].scans_arr == ow["stats"].scans_arr and g["info"].scans_aug_relax == ow["stats"].scans_aug_relax
+                        and all(np.array_equal(gc[k], o[k]) for k in ("rowsol", "colsol", "u", "v"))
+                        and gc["info"].row_scans == o["stats"].row_scans
+                        and np.array_equal(g["colsol"], o["colsol"]))
     if not parity_small:
         raise SystemExit("parity gate failed: HIP solver differs from the CPU oracle")
 
@@ -447,7 +457,7 @@ def main():
     c2_batch = None
     if world == 1 and not args.no_extras:
         c2_batch, r0 = extra_c2_batch(dev, buf, n)
-        if not (np.array_equal(r0["colsol"], colsol) and np.array_equal(r0["v"], res["v"])):
+        if not np.array_equal(r0["colsol"], colsol):      # (chain solver in the batch, wide solver alone: the same optimum)
             raise SystemExit("c2_batch: the batched solve differs from the single solve")
     buf.free()
 
@@ -461,6 +471,10 @@ def main():
 
         def _leg():
             try:
+                if dist is not None:            # the current HIP device is per THREAD: without this every rank's collectives
+                    import torch                # of this leg would run on cuda:0
+                    if torch.cuda.is_available():
+                        torch.cuda.set_device(local_rank)
                 box["r"] = extra_c4_sharded(dev, rank, world, dist, args.c4_rank_chunks)
             except BaseException as e:          # noqa: BLE001 (SystemExit from the leg's own gates included)
                 box["r"] = {"error": f"{type(e).__name__}: {e}"}
@@ -484,16 +498,16 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * n * args.steps / elapsed
 
-    # roofline of the dominant kernel, per launch, timed with HIP events on the launch stream
-    # (cyto_lap_info.ms_arr / ms_aug).  jv_chain2 = reduction transfer + augmenting row reduction (the
-    # longest kernel), jv_aug_lazy (n > 5120; jv_aug2 below) = augmentation.  Algorithmic bytes =
-    # 4 * n * row scans.
+    # roofline of the dominant kernel, per launch, timed with HIP events on the launch stream (cyto_lap_info.ms_arr / ms_aug).
+    # wide_arr = the Jacobi rounds of augmenting row reduction (wide_rt, the reduction transfer, is a sub-millisecond launch
+    # before it inside the same event bracket), wide_aug = the augmentation.  Algorithmic bytes = 4 * n * row scans:
+    # a bid is one row scan, a settled column of a search (the oracle's count, not the speculative re-settlements) is one.
     arr_scans = info.scans_redtransfer + info.scans_arr
     aug_scans = info.scans_aug_init + info.scans_aug_relax
     arr_ms = float(np.mean(arr_ms_l))
     aug_ms = float(np.mean(aug_ms_l))
-    aug_name = "jv_aug_lazy" if n > 5120 else "jv_aug2"
-    dom = ("jv_chain2", arr_scans, arr_ms) if arr_ms >= aug_ms else (aug_name, aug_scans, aug_ms)
+    arr_name, aug_name = ("wide_arr", "wide_aug") if info.wide else ("jv_chain2", "jv_aug_lazy" if n > 5120 else "jv_aug2")
+    dom = (arr_name, arr_scans, arr_ms) if arr_ms >= aug_ms else (aug_name, aug_scans, aug_ms)
     dom_bytes = 4.0 * n * dom[1]
     achieved = dom_bytes / (dom[2] * 1e-3) / 1e9
     traffic = None
@@ -501,10 +515,10 @@ def main():
     try:   # HBM bytes from the separate rocprofv3 --pmc pass committed under profiles/ (same n, same instance)
         traffic_source = f"profiles/{args.pmc_tag}_pmc_traffic_n{n}.json"
         if not os.path.exists(os.path.join(ROOT, traffic_source)):
-            traffic_source = f"profiles/r01e_pmc_traffic_n{n}.json"
+            traffic_source = f"profiles/r03_pmc_traffic_n{n}.json"
         pm = json.load(open(os.path.join(ROOT, traffic_source)))
         if pm.get("n") == n:
-            key = [k for k in pm["kernels"] if k.startswith(dom[0] + "<")]
+            key = [k for k in pm["kernels"] if k.startswith(dom[0] + "<") or k.startswith(dom[0] + "(") or k == dom[0]]
             if key:
                 traffic = pm["kernels"][key[0]]["hbm_read_bytes"] + pm["kernels"][key[0]]["hbm_write_bytes_uncalibrated"]
     except (OSError, ValueError, KeyError):
@@ -517,9 +531,12 @@ def main():
                                             "not re-measured in this run)") if traffic is not None else None,
         "algorithmic_bytes_per_launch": dom_bytes, "row_scans_per_launch": int(dom[1]), "kernel_ms_avg": round(dom[2], 3),
         "other_kernels": {
-            "jv_chain2": {"ms": round(arr_ms, 3), "row_scans": int(arr_scans), "algorithmic_GBs": round(4.0 * n * arr_scans / (arr_ms * 1e-3) / 1e9, 2)},
+            arr_name: {"ms": round(arr_ms, 3), "row_scans": int(arr_scans), "algorithmic_GBs": round(4.0 * n * arr_scans / (arr_ms * 1e-3) / 1e9, 2),
+                       "rounds": int(info.wide_rounds), "full_row_scans": int(info.wide_dense_arr)},
             aug_name: {"ms": round(aug_ms, 3), "row_scans": int(aug_scans), "algorithmic_GBs": round(4.0 * n * aug_scans / max(aug_ms, 1e-9) / 1e-3 / 1e9, 2),
-                       "full_row_scans": int(info.aug_dense_scans + info.augmentations - info.aug_sparse_inits)},
+                       "searches": int(info.augmentations), "columns_settled_speculatively": int(info.wide_aug_settled),
+                       "rounds_of_16_waves": int(info.wide_aug_rounds),
+                       "full_row_scans": int(info.wide_dense_aug if info.wide else info.aug_dense_scans + info.augmentations - info.aug_sparse_inits)},
             "colred(3 kernels)": {"ms": round(float(info.ms_colred), 3), "GBs": round(4.0 * n * n / (info.ms_colred * 1e-3) / 1e9, 1)},
             "build_row_caches": {"ms": round(float(info.ms_cache), 3), "GBs": round(4.0 * n * n / (info.ms_cache * 1e-3) / 1e9, 1)}},
         "whole_solve": {"row_scans": int(info.row_scans), "bytes": 4.0 * n * info.row_scans, "kernel_ms_avg": round(total_avg_ms, 3),
@@ -537,9 +554,14 @@ def main():
         t1 = time.perf_counter()
         oc = jv_oracle(cc, np.float32)
         dt = time.perf_counter() - t1
-        if same:   # the workload itself: the GPU result must be the oracle's, bit for bit
-            full_size_bit_exact = bool(all(np.array_equal(res[k], oc[k]) for k in ("rowsol", "colsol", "u", "v"))
-                                       and info.row_scans == oc["stats"].row_scans)
+        if same:   # the workload itself: the classic oracle's indices (the optimum is unique) and, bit for bit, the wide
+            # restatement's indices, duals and counters -- the solve above settled its columns speculatively, 16 at a time
+            t2 = time.perf_counter()
+            owf = jv_oracle_wide(cc, np.float32)
+            dt_wide = time.perf_counter() - t2
+            full_size_bit_exact = bool(np.array_equal(res["colsol"], oc["colsol"]) and np.array_equal(res["rowsol"], oc["rowsol"])
+                                       and all(np.array_equal(res[k], owf[k]) for k in ("rowsol", "colsol", "u", "v"))
+                                       and info.scans_arr == owf["stats"].scans_arr and info.scans_aug_relax == owf["stats"].scans_aug_relax)
             if not full_size_bit_exact:
                 raise SystemExit("full-size parity failed: HIP solver differs from the CPU oracle on the bench instance")
         cpu = {"value": round(cn / dt, 1), "unit": "assignments/s", "cores": 1, "kind": "port",

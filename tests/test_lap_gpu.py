@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from cytospace_amd.lap import lap_solve, lap_solve_rows, lapjv_hip
-from oracle.jv import jv_oracle
+from oracle.jv import jv_oracle, jv_oracle_wide
 
 pytestmark = pytest.mark.gpu
 
@@ -15,9 +15,34 @@ STAT_KEYS = ["scans_colred", "scans_redtransfer", "scans_arr", "scans_aug_init",
              "augmentations", "path_hops", "free_after_colred", "free_after_arr1", "free_after_arr2"]
 
 
+CHAIN = dict(mode=1)      # the chain solver: classic Gauss-Seidel order, oracle jv_oracle
+WIDE = dict(mode=2)       # the wide solver: order-free restatement, oracle jv_oracle_wide (the default for one float32 problem)
+WIDE_KEYS = [("scans_redtransfer", "scans_redtransfer"), ("scans_arr", "scans_arr"), ("scans_aug_init", "scans_aug_init"),
+             ("scans_aug_relax", "scans_aug_relax"), ("augmentations", "augmentations"), ("path_hops", "path_hops"),
+             ("free_after_colred", "free_after_colred"), ("free_after_arr2", "free_after_arr"), ("wide_rounds", "arr_rounds"),
+             ("wide_retired", "arr_retired")]
+
+
+def _check_wide(c, opts=None, rounds=0):
+    """The wide solver against ITS restatement (oracle/jv_oracle_impl.h, WIDE MODE): indices, duals and the semantic
+    counters bit for bit -- although the kernel settles columns speculatively, 16 at a time, in no fixed order."""
+    o = jv_oracle_wide(c, np.float32, max_rounds=-1 if rounds == 0 else max(rounds, 0))
+    g = lap_solve(c, np.float32, return_info=True, opts=dict(WIDE, wide_rounds=rounds, **(opts or {})))
+    for k in ("rowsol", "colsol", "v", "u"):
+        assert np.array_equal(g[k], o[k]), k
+    assert abs(g["total"] - o["total"]) <= 1e-5 * max(1.0, abs(o["total"]))
+    n = c.shape[0]
+    assert np.array_equal(np.sort(g["colsol"]), np.arange(n)) and np.array_equal(g["rowsol"][g["colsol"]], np.arange(n))
+    od, gd = o["stats"].as_dict(), g["info"].as_dict()
+    assert gd["wide"] == 1
+    for kg, ko in WIDE_KEYS:
+        assert gd[kg] == od[ko], (kg, gd[kg], od[ko])
+    return g, o
+
+
 def _check(c, dtype, opts=None):
     o = jv_oracle(c, dtype)
-    g = lap_solve(c, dtype, return_info=True, opts=opts)
+    g = lap_solve(c, dtype, return_info=True, opts=dict(CHAIN, **(opts or {})))
     assert np.array_equal(g["rowsol"], o["rowsol"])
     assert np.array_equal(g["colsol"], o["colsol"])
     assert np.array_equal(g["v"], o["v"]), "dual prices v differ"
@@ -30,6 +55,12 @@ def _check(c, dtype, opts=None):
     gd = g["info"].as_dict()
     for k in STAT_KEYS:
         assert gd[k] == od[k], (k, gd[k], od[k])
+    if dtype == np.float32 and not opts:
+        # the same instance through the wide solver; both solvers reach the same optimum
+        gw, ow = _check_wide(c)
+        assert abs(ow["total"] - o["total"]) <= 1e-5 * max(1.0, abs(o["total"]))
+        d = lap_solve(c, np.float32, return_info=True)              # what a caller gets by default: the wide solver
+        assert d["info"].wide == 1 and all(np.array_equal(d[k], gw[k]) for k in ("rowsol", "colsol", "u", "v"))
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 8, 63, 64, 65, 100, 256, 1000, 1023, 1024, 1025, 2500])
@@ -158,7 +189,7 @@ def test_duplicate_rows_skip_is_exact_and_deterministic(n, slots):
     c = np.repeat(base, slots, axis=0)
     o = jv_oracle(c, np.float32)
     for _ in range(3):
-        g = lap_solve(c, np.float32, return_info=True)
+        g = lap_solve(c, np.float32, return_info=True, opts=CHAIN)
         assert np.array_equal(g["rowsol"], o["rowsol"]) and np.array_equal(g["colsol"], o["colsol"])
         assert np.array_equal(g["u"], o["u"]) and np.array_equal(g["v"], o["v"])
         assert g["info"].scans_aug_relax == o["stats"].scans_aug_relax
@@ -229,7 +260,7 @@ def test_augmentation_handover_to_dense_kernel_on_deep_searches():
     rows = prof[rng.integers(0, types, n)] + 0.05 * rng.normal(size=(n, 64)).astype(np.float32)
     cols = prof[rng.integers(0, types, n)] + 0.05 * rng.normal(size=(n, 64)).astype(np.float32)
     c = -(rows @ cols.T).astype(np.float32)
-    g = lap_solve(c, np.float32, return_info=True)
+    g = lap_solve(c, np.float32, return_info=True, opts=CHAIN)
     o = jv_oracle(c, np.float32)
     for k in ("rowsol", "colsol", "u", "v"):
         assert np.array_equal(g[k], o[k]), k
@@ -266,7 +297,7 @@ def test_full_size_properties_bench_config():
     rows = np.random.default_rng(1).choice(n, 1024, replace=False)
     red = c[rows].astype(np.float64) - g["u"][rows].astype(np.float64)[:, None] - g["v"].astype(np.float64)[None, :]
     assert red.min() > -1e-5 and np.abs(red[np.arange(len(rows)), rowsol[rows]]).max() < 1e-5
-    assert g["info"].aug_dense_scans < 0.05 * g["info"].scans_aug_relax      # the augmentation ran from the row caches
+    assert g["info"].wide == 1 and g["info"].wide_dense_aug < 0.05 * g["info"].scans_aug_relax      # the augmentation ran from the row caches
 
 
 def test_float64_host_matrix_is_narrowed_on_the_device():
@@ -286,7 +317,7 @@ def test_float64_host_matrix_is_narrowed_on_the_device():
 
 # ---- SURVEY 8f rank 3 (first half): row indirection -- the cost holds every distinct spot row once ----
 
-@pytest.mark.parametrize("opts", [None, dict(chain_variant=1), dict(chain_variant=2), dict(chain_variant=3), dict(augmentation=1), dict(augmentation=2, no_handover=1)])
+@pytest.mark.parametrize("opts", [CHAIN, dict(chain_variant=1), dict(chain_variant=2), dict(chain_variant=3), dict(augmentation=1), dict(augmentation=2, no_handover=1)])
 def test_row_map_equals_the_materialised_matrix(opts):
     # cyto_lap_f32_rowmap(rows, np.repeat(arange(S), slots)) == cyto_lap_f32(rows[rowmap]) == the oracle, bit for bit,
     # with equal slots, ragged slots, stored rows nobody uses (slots == 0) and a single spot
@@ -359,3 +390,52 @@ def test_duplicate_row_group_state_in_global_memory(aug):
     # ... and the dense kernel's per-column auxiliaries in global memory as well (what it uses beyond ~13 000 columns)
     _check(c, np.float32, dict(augmentation=1, aux_state_global=1, group_state_global=aug - 1))
     _check(np.random.default_rng(4).random((700, 700)).astype(np.float32), np.float32, dict(augmentation=1, aux_state_global=1))
+
+
+# ---- the wide solver (cyto_lap_opts.mode = 2; the default for one float32 problem): lap_wide.hip vs oracle WIDE MODE ----
+
+@pytest.mark.parametrize("rounds", [-1, 1, 3, 40, 600])
+def test_wide_round_budget(rounds):
+    # the budget of Jacobi row-reduction rounds cuts the rounds short at the same point in the kernel and in the oracle; the rows
+    # still active go to the augmentation (wide_rounds = -1: no round at all -- every free row is augmented)
+    c = np.random.default_rng(900 + rounds).random((900, 900)).astype(np.float32)
+    g, o = _check_wide(c, rounds=rounds)
+    assert g["info"].wide_rounds <= max(rounds, 0)
+    assert np.array_equal(g["colsol"], jv_oracle(c, np.float32)["colsol"])          # a unique optimum: the chain's indices too
+
+
+def test_wide_row_map_and_duplicated_rows():
+    rng = np.random.default_rng(12)
+    for S, slots in ((12, np.full(12, 5)), (300, rng.integers(0, 6, 300)), (1, np.array([7])), (500, np.full(500, 4))):
+        n = int(slots.sum())
+        rows = -(rng.random((S, n)) ** 3).astype(np.float32)
+        rowmap = np.repeat(np.arange(S), slots).astype(np.int32)
+        full = rows[rowmap]
+        a = lap_solve_rows(rows, rowmap, return_info=True, opts=WIDE)
+        g, o = _check_wide(full)
+        for k in ("rowsol", "colsol", "u", "v"):
+            assert np.array_equal(a[k], g[k]), k
+        # the chain solver reaches the same optimum; which slot of a spot a cell takes is arbitrary, the spot is not
+        oc = jv_oracle(full, np.float32)
+        assert abs(oc["total"] - o["total"]) <= 1e-5 * max(1.0, abs(o["total"]))
+
+
+def test_wide_full_row_fallbacks_on_near_equal_columns():
+    # few cell types: hundreds of near-equal columns per row, the 63-column caches cannot certify -- bids and relaxations read
+    # the full cost row, the search re-converges after every certificate pass; still the oracle's answer bit for bit
+    rng = np.random.default_rng(5)
+    n, types = 1500, 6
+    prof = rng.normal(size=(types, 64)).astype(np.float32)
+    rows = prof[rng.integers(0, types, n)] + 0.05 * rng.normal(size=(n, 64)).astype(np.float32)
+    cols = prof[rng.integers(0, types, n)] + 0.05 * rng.normal(size=(n, 64)).astype(np.float32)
+    c = -(rows @ cols.T).astype(np.float32)
+    g, o = _check_wide(c)
+    assert g["info"].wide_dense_aug > 0 and g["info"].wide_dense_arr > 0
+    assert abs(jv_oracle(c, np.float32)["total"] - o["total"]) <= 1e-5 * max(1.0, abs(o["total"]))
+
+
+@pytest.mark.parametrize("n", [4100, 9000])
+def test_wide_uniform_larger(n):
+    c = np.random.default_rng(n).random((n, n)).astype(np.float32)
+    g, o = _check_wide(c)
+    assert g["info"].wide_aug_settled >= g["info"].scans_aug_relax        # speculative: a column may be settled more than once

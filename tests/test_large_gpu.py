@@ -26,6 +26,10 @@ STAT_KEYS = ["scans_colred", "scans_redtransfer", "scans_arr", "scans_aug_init",
              "augmentations", "path_hops", "free_after_colred", "free_after_arr1", "free_after_arr2"]
 
 
+CHAIN = dict(mode=1)     # the chain solver: what the goldens' duals and counters were made with (oracle classic mode)
+WIDE = dict(mode=2)      # the wide solver (the default for one problem): same optimum, its own duals
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -41,7 +45,7 @@ def _compare_with_golden(tag, buf, n, solve=None):
     rowsol / u / v by sha256 (bit-exact without shipping 3 more arrays), the work counters, the total."""
     d = _golden(tag)
     assert int(d["n"]) == n
-    g = solve() if solve else lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n)
+    g = solve() if solve else lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n, opts=CHAIN)
     assert np.array_equal(g["colsol"], d["colsol"]), f"{(g['colsol'] != d['colsol']).sum()} of {n} columns differ"
     assert sha(g["rowsol"]) == str(d["rowsol_sha256"])
     assert sha(g["v"]) == str(d["v_sha256"]), "dual prices v differ from the oracle's"
@@ -67,6 +71,53 @@ def test_uniform_true_size(n):
         buf.free()
 
 
+def _wide_vs_golden(tag, n, solve, loc=None):
+    """The wide solver at true size: the golden's indices (any exact solver must return them: the goldens are
+    uniqueness-certified; spot level where spot rows are duplicated), a permutation, and its OWN duals certify the optimum --
+    feasible on sampled rows, tight on the assignment, strong duality."""
+    d = _golden(tag)
+    g = solve()
+    assert g["info"].wide == 1
+    colsol, rowsol = g["colsol"], g["rowsol"]
+    assert np.array_equal(np.sort(colsol), np.arange(n)) and np.array_equal(rowsol[colsol], np.arange(n))
+    if loc is None:
+        assert np.array_equal(colsol, d["colsol"]), f"{(colsol != d['colsol']).sum()} of {n} columns differ"
+    else:
+        assert np.array_equal(loc[colsol], loc[d["colsol"]])
+    assert abs(g["total"] - float(d["total"])) <= 1e-5 * max(1.0, abs(float(d["total"])))
+    u, v = g["u"].astype(np.float64), g["v"].astype(np.float64)
+    assert abs(g["total"] - (u.sum() + v.sum())) <= 1e-5 * max(1.0, abs(g["total"]))
+    return g
+
+
+@pytest.mark.parametrize("n", [20000, 33000, 50000])
+def test_wide_uniform_true_size(n):
+    buf = instances.blocks_to_device(instances.uniform_cost_blocks(n), n)
+    try:
+        g = _wide_vs_golden(f"u{n}", n, lambda: lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n))
+        assert g["info"].wide_dense_aug < 0.05 * g["info"].scans_aug_relax
+    finally:
+        buf.free()
+
+
+def test_wide_c3_shaped_and_c4_chunk_true_size():
+    n = 50000
+    uniq, loc = instances.c3_shaped_unique(n)
+    buf = _lib.DeviceBuffer.from_numpy(uniq)
+    try:
+        g = _wide_vs_golden(f"c3s{n}", n, lambda: lap_solve_rows(None, loc, return_info=True, device_ptr=buf.ptr, nu=len(uniq), ld=n), loc)
+        assert np.array_equal(np.bincount(loc[g["colsol"]], minlength=n // 10), np.full(n // 10, 10))
+    finally:
+        buf.free()
+    n = 10000
+    cost, loc = instances.c4_chunk_cost(n)
+    buf = _lib.DeviceBuffer.from_numpy(cost)
+    try:
+        _wide_vs_golden(f"c4s{n}", n, lambda: lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n), loc)
+    finally:
+        buf.free()
+
+
 def test_c3_shaped_lap_50000():
     """c3's LAP shape: 5 000 spot rows x 10 slots against 50 000 cells (duplicate-row elision, sparse inits)."""
     n = 50000
@@ -87,7 +138,7 @@ def test_c3_shaped_lap_50000_through_the_row_map():
     buf = _lib.DeviceBuffer.from_numpy(uniq)
     try:
         _compare_with_golden(f"c3s{n}", None, n, solve=lambda: lap_solve_rows(None, loc, return_info=True, device_ptr=buf.ptr,
-                                                                              nu=len(uniq), ld=n))
+                                                                              nu=len(uniq), ld=n, opts=CHAIN))
     finally:
         buf.free()
 

@@ -182,3 +182,77 @@ def test_small_typed_instances_oracle_vs_scipy():
     sp = np.empty(600, np.int64)
     sp[ci] = ri
     assert np.array_equal(loc[r["colsol"]], loc[sp])
+
+
+# ---- the WIDE-mode restatement (oracle/jv_oracle_impl.h, second half): same optimum, pinned the same way ----
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 64, 256])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_wide_oracle_gv8_known_answers(n, dtype):
+    from oracle.jv import jv_oracle_wide
+    d = load("gv8_lap.npz")
+    r = jv_oracle_wide(d[f"n{n}_cost"], dtype)
+    assert np.array_equal(r["rowsol"], d[f"n{n}_rowsol"]) and np.array_equal(r["colsol"], d[f"n{n}_colsol"])
+    assert abs(r["total"] - float(d[f"n{n}_total"])) <= 1e-5 * max(1.0, abs(float(d[f"n{n}_total"])))
+
+
+@pytest.mark.parametrize("n", [5, 33, 128, 500, 1200, 3000])
+@pytest.mark.parametrize("rounds", [-1, 0, 3])
+def test_wide_oracle_vs_scipy_random(n, rounds):
+    # rounds: the budget of Jacobi row-reduction rounds (-1: the default; 0: none -- every free row is augmented; 3: cut short).
+    # Whatever the budget, the augmentation finishes the optimum.
+    from oracle.jv import jv_oracle_wide
+    c = np.random.default_rng(1000 + n).random((n, n)).astype(np.float32)
+    r = jv_oracle_wide(c, np.float32, max_rounds=rounds)
+    ri, ci = linear_sum_assignment(c.astype(np.float64))
+    assert np.array_equal(r["rowsol"], ci)
+    assert np.array_equal(r["colsol"], jv_oracle(c, np.float32)["colsol"])
+    u, v = r["u"].astype(np.float64), r["v"].astype(np.float64)
+    red = c.astype(np.float64) - u[:, None] - v[None, :]
+    assert red.min() > -1e-5 and np.abs(red[np.arange(n), r["rowsol"]]).max() < 1e-5
+    st = r["stats"]
+    assert st.arr_rounds <= (4096 + n // 4 if rounds < 0 else rounds)
+    assert st.scans_aug_init == st.augmentations == st.free_after_arr
+
+
+def test_wide_oracle_ties_duplicates_and_typed_instances():
+    from oracle.jv import jv_oracle_wide
+    from tools import instances
+    rng = np.random.default_rng(3)
+    cases = [rng.integers(0, 10, (200, 200)).astype(np.float32),                       # heavy exact ties
+             np.repeat(rng.random((60, 300)), 5, axis=0).astype(np.float32),           # every spot row five times
+             instances.c4_chunk_cost(600, seed=9)[0], instances.c3_shaped_cost(400, 10, 3)[0]]
+    for c in cases:
+        n = len(c)
+        r = jv_oracle_wide(c, np.float32)
+        ri, ci = linear_sum_assignment(c.astype(np.float64))
+        best = c.astype(np.float64)[ri, ci].sum()
+        assert np.array_equal(np.sort(r["colsol"]), np.arange(n)) and np.array_equal(r["rowsol"][r["colsol"]], np.arange(n))
+        assert abs(r["total"] - best) <= 1e-5 * max(1.0, abs(best))
+        u, v = r["u"].astype(np.float64), r["v"].astype(np.float64)
+        red = c.astype(np.float64) - u[:, None] - v[None, :]
+        assert red.min() > -1e-5 and np.abs(red[np.arange(n), r["rowsol"]]).max() < 1e-5
+    d = load("gv8_lap.npz")
+    r = jv_oracle_wide(d["dup_cost"], np.float32)
+    assert np.array_equal(r["colsol"] // 5, d["dup_spot_of_col"])
+
+
+@pytest.mark.parametrize("key", ["visium_s1", "single_s7"])
+def test_wide_oracle_on_the_reference_goldens_spot_level(key):
+    # the reference's own solve_linear_assignment_problem outputs (gv5): the wide restatement maps every cell to the same spot
+    from oracle.jv import jv_oracle_wide
+    d = load("gv5_solve_lap.npz")
+    dist, loc = ocost.calculate_cost(d[key + "_sc_norm"], d[key + "_st_norm"], d[key + "_slots"])
+    r = jv_oracle_wide(dist, np.float32)
+    assert np.array_equal(loc[r["colsol"]], d[key + "_mapped"])
+
+
+def test_wide_oracle_stop_phases_expose_the_intermediate_state():
+    from oracle.jv import jv_oracle_wide
+    c = np.random.default_rng(8).random((400, 400)).astype(np.float32)
+    a = jv_oracle_wide(c, np.float32, stop_phase=2)
+    free = np.flatnonzero(a["rowsol"] < 0)
+    assert len(free) == a["stats"].free_after_arr and (a["colsol"] < 0).sum() == len(free)
+    asg = np.flatnonzero(a["rowsol"] >= 0)
+    h = c[asg] - a["v"][None, :]                       # every assigned row sits on a minimum of its reduced costs
+    assert np.all(h[np.arange(len(asg)), a["rowsol"][asg]] <= h.min(1) + 1e-7)

@@ -1,0 +1,52 @@
+"""Wide solver at true sizes against the committed goldens (colsol; spot level where rows are duplicated) + timing.
+usage: wide_large.py [u20000 u50000 c3s50000 c4s10000 ...] [--chain] [--rounds R]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cytospace_amd.lap import lap_solve, lap_solve_rows  # noqa: E402
+from tools import instances as I  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def main():
+    tags = [a for a in sys.argv[1:] if not a.startswith("--")] or ["u20000"]
+    mode = 1 if "--chain" in sys.argv else 2
+    rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 0
+    reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 2
+    for tag in tags:
+        d = np.load(os.path.join(GOLD, f"large_{tag}.npz"))
+        n = int(d["n"])
+        loc = None
+        if tag.startswith("u"):
+            buf = I.blocks_to_device(I.uniform_cost_blocks(n), n)
+        elif tag.startswith("c3s"):
+            uniq, loc = I.c3_shaped_unique(n)
+            buf = I.blocks_to_device(I.repeated_row_blocks(uniq, loc), n)
+        elif tag.startswith("c4s"):
+            c, loc = I.c4_chunk_cost(n)
+            buf = I.blocks_to_device([(0, c)], n)
+        else:
+            raise SystemExit(f"unknown tag {tag}")
+        for rep in range(reps):
+            t = time.time()
+            g = lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n, opts=dict(mode=mode, wide_rounds=rounds))
+            wall = time.time() - t
+            inf = g["info"]
+            same = np.array_equal(g["colsol"], d["colsol"])
+            spot = same if loc is None else np.array_equal(loc[g["colsol"]], loc[d["colsol"]])
+            print(f"{tag} mode={mode} rep={rep}: colsol==golden {same} spot-level {spot} total diff {g['total'] - float(d['total']):.3e} "
+                  f"ms colred={inf.ms_colred:.2f} cache={inf.ms_cache:.2f} arr={inf.ms_arr:.2f} aug={inf.ms_aug:.2f} total={inf.ms_total:.2f} wall={wall * 1e3:.1f} | "
+                  f"free={inf.free_after_arr2} rounds={inf.wide_rounds} bids={inf.scans_arr} retired={inf.wide_retired} relax={inf.scans_aug_relax} "
+                  f"settled={inf.wide_aug_settled} aug_rounds={inf.wide_aug_rounds} dense=({inf.wide_dense_arr},{inf.wide_dense_aug}) "
+                  f"trivial={inf.wide_trivial} verify={inf.wide_verify_passes} hops={inf.path_hops}", flush=True)
+        buf.free()
+
+
+if __name__ == "__main__":
+    main()
