@@ -3139,14 +3139,14 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
         // workspace (blocks of the device cache: no hipMalloc / hipFree once a size has been seen)
         if ((rc = j.b_fws.alloc(6 * nT + 64, stream)) || (rc = j.b_iws.alloc(10 * nI + 64, stream)) || (rc = j.b_imin.alloc(nI, stream)) ||
             (rc = j.b_pmin.alloc((size_t)pl.rowblocks * nT, stream)) || (rc = j.b_parg.alloc((size_t)pl.rowblocks * nI, stream)) ||
-            (rc = j.b_misc.alloc(256, stream)) || (rc = j.b_same.alloc(nI, stream)) || (rc = j.b_gid.alloc(nI, stream)) ||
+            (rc = j.b_misc.alloc(512, stream)) || (rc = j.b_same.alloc(nI, stream)) || (rc = j.b_gid.alloc(nI, stream)) ||
             (rc = j.b_ccol.alloc((size_t)n * KC * sizeof(uint32_t), stream)) || (rc = j.b_cval.alloc((size_t)n * KC * sizeof(float), stream)))
             return rc;
         // float workspace: v | u | ... ; int workspace: rowsol | colsol | matches | freerows | rtrows | pred | ...
         float *d_v = j.b_fws.as<float>();
         int32_t *d_rowsol = j.b_iws.as<int32_t>(), *d_colsol = d_rowsol + n, *d_matches = d_rowsol + 2 * (size_t)n;
         // misc: [0] nonfinite flag (int), [1] chain status (int), [8..16) total (double), [16..) counters, [144] ngroups
-        CYTO_HIP(hipMemsetAsync(j.b_misc.p, 0, 256, stream));
+        CYTO_HIP(hipMemsetAsync(j.b_misc.p, 0, 512, stream));
         CYTO_HIP(hipMemsetAsync(d_rowsol, 0xFF, nI, stream));
         CYTO_HIP(hipMemsetAsync(d_matches, 0, nI, stream));
         {   // the column minima need every DISTINCT row once: with a row map only the stored rows in use are swept
@@ -3314,6 +3314,12 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
                 info->wide_dense_aug = wc[WC_DENSE_AUG]; info->wide_aug_rounds = wc[WC_AUG_ROUNDS]; info->wide_aug_settled = wc[WC_AUG_PROCESSED];
                 info->wide_trivial = wc[WC_TRIVIAL]; info->wide_verify_passes = wc[WC_VERIFY_PASSES];
                 info->aug_handover = -1;
+                if (getenv("CYTO_WIDE_DEBUG")) {
+                    long long dbg[16] = {0};
+                    CYTO_HIP(hipMemcpy(dbg, j.b_misc.as<char>() + 256, sizeof dbg, hipMemcpyDeviceToHost));
+                    fprintf(stderr, "[wide n=%d] arr: list rounds %lld (%.2f ms) chain rounds %lld (%.2f ms) deals %lld setup %.2f ms tail %.2f ms | aug: rounds %.2f ms verify %.2f ms finish %.2f ms trivial %.2f ms\n",
+                            n, dbg[0], dbg[1] * 1e-5, dbg[2], dbg[3] * 1e-5, dbg[4], dbg[5] * 1e-5, dbg[6] * 1e-5, dbg[8] * 1e-5, dbg[9] * 1e-5, dbg[10] * 1e-5, dbg[11] * 1e-5);
+                }
             }
         }
         if (h_status) j.status = CYTO_ERR_INTERNAL;

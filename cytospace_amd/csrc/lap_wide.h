@@ -13,15 +13,17 @@ namespace cyto {
 //   slot_j, slot_p, slot_c  [n] per active slot: the bid's column (-1 = retired), price, raw cost of that entry
 //   cache_col/val   [n][64] row caches (lap_jv.hip: build_row_caches)
 //   misc            256 bytes: +4 status, +8 double total, +16 long long counters[] (lap_jv.hip indices), +160.. wide counters
-struct WideArgs {
-    int n; int64_t ld; const float *cost; const int32_t *rowmap;
-    float *v, *u, *cassign; unsigned long long *label, *bid;
-    int32_t *rowsol, *colsol, *matches, *freerows, *act0, *act1, *touched, *slot_j;
-    float *slot_p, *slot_c;
-    uint32_t *cache_col; float *cache_val;
-    char *misc;
-    long long max_rounds;
-};
+// (fields through an X-macro: the kernels read the block through a mirror struct whose pointers are typed as GLOBAL, so that
+//  every access is a global_* instruction -- through pointers loaded from memory it would be a FLAT one, and flat accesses
+//  also count on lgkmcnt: every LDS wait would wait for the outstanding global loads too)
+#define WIDE_FIELDS(P, S)                                                                                                  \
+    S(int, n) S(int64_t, ld) P(const float, cost) P(const int32_t, rowmap) P(float, v) P(float, u) P(float, cassign)          \
+    P(unsigned long long, label) P(unsigned long long, bid) P(int32_t, rowsol) P(int32_t, colsol) P(int32_t, matches)          \
+    P(int32_t, freerows) P(int32_t, act0) P(int32_t, act1) P(int32_t, touched) P(int32_t, slot_j) P(float, slot_p)            \
+    P(float, slot_c) P(uint32_t, cache_col) P(float, cache_val) P(char, misc) S(long long, max_rounds)
+#define WIDE_F_PTR(T, name) T *name;
+#define WIDE_F_VAL(T, name) T name;
+struct WideArgs { WIDE_FIELDS(WIDE_F_PTR, WIDE_F_VAL) };
 
 // wide counters (long long each) at misc + 160
 enum { WC_ROUNDS = 0, WC_BIDS, WC_RETIRED, WC_ACTIVE_LEFT, WC_FREE_ARR, WC_DENSE_ARR, WC_DENSE_AUG, WC_AUG_ROUNDS, WC_AUG_PROCESSED,

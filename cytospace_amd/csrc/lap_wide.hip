@@ -41,7 +41,21 @@ template <typename T> __device__ __forceinline__ T ld_sc1(const T *p) { return _
 __device__ __forceinline__ int64_t wrow_off(const int32_t *__restrict__ rowmap, int i, int64_t ld) {
     return (int64_t)(rowmap ? rowmap[i] : i) * ld;
 }
+#define WIDE_F_GPTR(T, name) __attribute__((address_space(1))) T *name;
+#define WIDE_F_COPY_PTR(T, name) a.name = (T *)g.name;
+#define WIDE_F_COPY_VAL(T, name) a.name = g.name;
+struct WideArgsG { WIDE_FIELDS(WIDE_F_GPTR, WIDE_F_VAL) };
+static_assert(sizeof(WideArgs) == sizeof(WideArgsG), "mirror layout");
+__device__ __forceinline__ WideArgs load_wide_args(const WideArgs *__restrict__ batch, int b) {
+    const WideArgsG g = reinterpret_cast<const WideArgsG *>(batch)[b];
+    WideArgs a;
+    WIDE_FIELDS(WIDE_F_COPY_PTR, WIDE_F_COPY_VAL)
+    return a;
+}
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
+// value of lane l (wave-uniform l) without the LDS round trip of __shfl
+__device__ __forceinline__ uint32_t rdlane(uint32_t x, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, l); }
+__device__ __forceinline__ float rdlane(float x, int l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), l)); }
 
 }  // namespace
 
@@ -52,7 +66,7 @@ __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x
 // The cache was built against v0: it holds EVERY column with c - v0 < floor, so a cached minimum <= floor is the row's.
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RTB) void wide_rt(const WideArgs *__restrict__ batch) {
-    const WideArgs a = batch[blockIdx.y];
+    const WideArgs a = load_wide_args(batch, blockIdx.y);
     const int n = a.n;
     if (n < 2) return;
     const int lane = threadIdx.x & 63;
@@ -84,21 +98,114 @@ __global__ __launch_bounds__(RTB) void wide_rt(const WideArgs *__restrict__ batc
 
 // ------------------------------------------------------------------------------------------------------------------
 // AUGMENTING ROW REDUCTION, Jacobi rounds (oracle/jv_oracle_impl.h, wide mode).  One workgroup per problem.
+//
+// VLDS: the prices (f32) and the column owners (u16, 0xFFFF = unassigned) live in LDS beside their global copies (every
+// update goes to both), so a bid is: the row's cache (two coalesced 256-B loads), 63 LDS gathers, two DPP reductions, two
+// LDS look-ups.  Otherwise (n > ~26 000) both stay in L2 and are read with agent-scope loads.
+//
+// Two regimes.  LIST rounds (more than 64 active rows: the first few hundred rounds): the active rows are a list in
+// global memory, a wave takes four of them at a time (row ids, then the four caches, requested together); the bids of a
+// round meet in the per-column 64-bit atomic-min words `bid`.  CHAIN rounds (<= 64 active rows -- the long tail of the
+// price wars, thousands of rounds): every wave holds up to four rows IN REGISTERS; the row a slot works on in the next round
+// is the owner it displaces, known BEFORE the round's barrier, so that row's cache is requested at once and has arrived when
+// the next round starts; bids meet in LDS (a ballot finds a better bid on the same column), two barriers per round and no
+// global round trip on the path.  When half of the rows have dropped out the rest is dealt out again, one round-robin over
+// the waves.  Both regimes realise the same round (a pure function of the state).
 // ------------------------------------------------------------------------------------------------------------------
+constexpr int ACS = 4;                 // rows per wave in a chain round / requested together in a list round
+constexpr int ASL = WNW * ACS;         // slots of a chain round
+
 struct ArrShared {
     int cnt[2];
-    int retired, dense;
+    int retired, dense, ndeal;
     int wcnt[WNW];
-    int sm_j[64], sm_i[64];
-    float sm_p[64], sm_c[64];
+    int sm_j[ASL], sm_i[ASL];
+    float sm_p[ASL];
+    int deal[ASL];
 };
 
+size_t wide_arr_lds_bytes(int n, bool vlds) {
+    if (!vlds) return 16;
+    const size_t npad = ((size_t)n + 3) & ~(size_t)3;
+    return ((npad * 6 + 15) / 16) * 16;
+}
+bool wide_arr_vlds(int n) { return n <= 65534 && wide_arr_lds_bytes(n, true) + 4096 <= (size_t)LDS_DYNAMIC_MAX; }
+
+template <bool VLDS> struct ArrCtx {
+    WideArgs a;
+    float *s_v; uint16_t *s_cs; ArrShared *s;
+    int lane;
+    __device__ __forceinline__ float getv(int j) const { return VLDS ? s_v[j] : ld_sc1(a.v + j); }
+    __device__ __forceinline__ int getcs(int j) const {
+        if (VLDS) { const uint16_t x = s_cs[j]; return x == 0xFFFFu ? -1 : (int)x; }
+        return ld_sc1(a.colsol + j);
+    }
+    // a won bid: price, owner, displaced owner change together (LDS copies and global)
+    __device__ __forceinline__ void apply(int i, int jt, float pt, float ct, int i0) const {
+        if (VLDS) { s_v[jt] = pt; s_cs[jt] = (uint16_t)i; }
+        a.v[jt] = pt; a.colsol[jt] = i; a.rowsol[i] = jt; a.cassign[jt] = ct;
+        if (i0 >= 0) a.rowsol[i0] = -1;
+    }
+    // exact lexicographic top-2 of the whole row (the cache could not certify): rare, kept out of line
+    __device__ __noinline__ void top2_full(int i, float &u1, int &j1, float &c1, float &vj1, float &u2, int &j2, float &c2, float &vj2) const {
+        const int n = a.n;
+        const float *__restrict__ row = a.cost + wrow_off(a.rowmap, i, a.ld);
+        K2 d; d.m1 = KEYMAX; d.m2 = KEYMAX;
+        for (int c = lane; c < n; c += 64) k2_push(d, mkkey(row[c] - getv(c), (uint32_t)c));
+        d = k2_wave_allreduce(d);
+        u1 = key_val(d.m1); j1 = (int)(uint32_t)d.m1; c1 = row[j1]; vj1 = getv(j1);
+        u2 = INFINITY; j2 = -1; c2 = 0.0f; vj2 = 0.0f;
+        if (d.m2 != KEYMAX) { u2 = key_val(d.m2); j2 = (int)(uint32_t)d.m2; c2 = row[j2]; vj2 = getv(j2); }
+        if (lane == 0) atomicAdd(&s->dense, 1);
+    }
+    // the bid of row i (its cache row in col / val, lane = entry): target column jt (-1: the row retires), price, raw cost of
+    // the entry, and the owner it would displace
+    __device__ __forceinline__ void bid_of(int i, uint32_t col, float val, int &jt, float &pt, float &ct, int &i0) const {
+        // cache rows are sorted by column: among equal reduced costs the lowest lane is the lowest column, so the
+        // lexicographic (value, column) top-2 is two 32-bit min reductions and two ballots
+        const float tau = rdlane(val, KCU);
+        const bool valid = lane < KCU && col != COLSENT;
+        const float vj = valid ? getv((int)col) : 0.0f;
+        const uint32_t key = valid ? f2ord(val - vj) : 0xFFFFFFFFu;
+        const uint32_t k1 = wave_min_u32(key);
+        const int l1 = __ffsll((unsigned long long)__ballot(key == k1)) - 1;
+        const uint32_t key2 = lane == l1 ? 0xFFFFFFFFu : key;
+        const uint32_t k2 = wave_min_u32(key2);
+        float u1, u2, c1, c2, vj1, vj2;
+        int j1, j2;
+        if (k2 != 0xFFFFFFFFu && ord2f(k2) < tau) {           // the cached top-2 IS the row's lexicographic top-2
+            const int l2 = __ffsll((unsigned long long)__ballot(key2 == k2)) - 1;
+            u1 = ord2f(k1); j1 = (int)rdlane(col, l1); c1 = rdlane(val, l1); vj1 = rdlane(vj, l1);
+            u2 = ord2f(k2); j2 = (int)rdlane(col, l2); c2 = rdlane(val, l2); vj2 = rdlane(vj, l2);
+        } else {
+            top2_full(i, u1, j1, c1, vj1, u2, j2, c2, vj2);
+        }
+        const float p = vj1 - (u2 - u1);
+        jt = -1; pt = 0.0f; ct = 0.0f; i0 = -1;
+        const int o1 = getcs(j1);
+        if (p < vj1) { jt = j1; pt = p; ct = c1; i0 = o1; }
+        else if (o1 < 0) { jt = j1; pt = vj1; ct = c1; }
+        else if (j2 >= 0 && u2 == u1 && getcs(j2) < 0) { jt = j2; pt = vj2; ct = c2; }
+    }
+};
+
+template <bool VLDS>
 __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batch) {
+    extern __shared__ __align__(16) unsigned char w_smem[];
     __shared__ ArrShared s;
-    const WideArgs a = batch[blockIdx.x];
+    ArrCtx<VLDS> cx;
+    cx.a = load_wide_args(batch, blockIdx.x);
+    const WideArgs &a = cx.a;
     const int n = a.n, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) { s.cnt[0] = 0; s.cnt[1] = 0; s.retired = 0; s.dense = 0; }
+    cx.s_v = reinterpret_cast<float *>(w_smem);
+    cx.s_cs = reinterpret_cast<uint16_t *>(cx.s_v + ((n + 3) & ~3));
+    cx.s = &s; cx.lane = lane;
+    const long long t_kernel0 = wall_clock64();
+    if (tid == 0) { s.cnt[0] = 0; s.cnt[1] = 0; s.retired = 0; s.dense = 0; s.ndeal = 0; }
+    if (VLDS)
+        for (int j = tid; j < n; j += WT) { cx.s_v[j] = a.v[j]; const int o = a.colsol[j]; cx.s_cs[j] = o < 0 ? (uint16_t)0xFFFFu : (uint16_t)o; }
     __syncthreads();
+
     // the active list: every free row (in any order -- a round does not depend on it)
     for (int i0 = 0; i0 < n; i0 += WT) {
         const int i = i0 + tid;
@@ -113,89 +220,135 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
     const int free_cr = s.cnt[0];
     int cur = 0;
     long long round = 0, bids = 0;
+    const long long t_start = wall_clock64();
+    if (tid == 0) reinterpret_cast<long long *>(a.misc + 256)[5] = t_start - t_kernel0;
+    long long t_list = 0, t_chain = 0, n_list = 0, n_chain = 0, n_deal = 0;
     int32_t *A = a.act0, *B = a.act1;
+    int na = free_cr;
+    // ================= LIST rounds =================
     for (;;) {
-        const int na = s.cnt[cur];
-        if (na == 0 || round >= a.max_rounds) break;
-        const bool small = na <= 64;
-        // ---- bids: a wave per active row ----
-        for (int slot = w; slot < na; slot += WNW) {
-            const int i = ld_sc1(A + slot);
-            const uint32_t col = a.cache_col[(int64_t)i * KC + lane];
-            const float val = a.cache_val[(int64_t)i * KC + lane];
-            const float tau = __shfl(val, KCU);
-            const bool valid = lane < KCU && col != COLSENT;
-            const float vj = valid ? ld_sc1(a.v + col) : 0.0f;
-            K2 t; t.m1 = valid ? mkkey(val - vj, col) : KEYMAX; t.m2 = KEYMAX;
-            const uint64_t mykey = t.m1;
-            t = k2_wave_allreduce(t);
-            float u1, u2 = INFINITY, c1, c2 = 0.0f, vj1, vj2 = 0.0f;
-            int j1, j2 = -1;
-            if (t.m2 != KEYMAX && key_val(t.m2) < tau) {          // the cached top-2 IS the row's lexicographic top-2
-                const int l1 = __ffsll((unsigned long long)__ballot(mykey == t.m1)) - 1;
-                const int l2 = __ffsll((unsigned long long)__ballot(mykey == t.m2)) - 1;
-                u1 = key_val(t.m1); j1 = (int)(uint32_t)t.m1; c1 = __shfl(val, l1); vj1 = __shfl(vj, l1);
-                u2 = key_val(t.m2); j2 = (int)(uint32_t)t.m2; c2 = __shfl(val, l2); vj2 = __shfl(vj, l2);
-            } else {                                             // the whole row
-                const float *__restrict__ row = a.cost + wrow_off(a.rowmap, i, a.ld);
-                K2 d; d.m1 = KEYMAX; d.m2 = KEYMAX;
-                for (int c = lane; c < n; c += 64) k2_push(d, mkkey(row[c] - ld_sc1(a.v + c), (uint32_t)c));
-                d = k2_wave_allreduce(d);
-                u1 = key_val(d.m1); j1 = (int)(uint32_t)d.m1; c1 = row[j1]; vj1 = ld_sc1(a.v + j1);
-                if (d.m2 != KEYMAX) { u2 = key_val(d.m2); j2 = (int)(uint32_t)d.m2; c2 = row[j2]; vj2 = ld_sc1(a.v + j2); }
-                if (lane == 0) atomicAdd(&s.dense, 1);
-            }
-            const float p = vj1 - (u2 - u1);
-            int jt = -1;
-            float pt = 0.0f, ct = 0.0f;
-            if (p < vj1) { jt = j1; pt = p; ct = c1; }
-            else if (ld_sc1(a.colsol + j1) < 0) { jt = j1; pt = vj1; ct = c1; }
-            else if (j2 >= 0 && u2 == u1 && ld_sc1(a.colsol + j2) < 0) { jt = j2; pt = vj2; ct = c2; }
-            if (lane == 0) {
-                if (jt < 0) atomicAdd(&s.retired, 1);
-                if (small) { s.sm_j[slot] = jt; s.sm_i[slot] = i; s.sm_p[slot] = pt; s.sm_c[slot] = ct; }
-                else {
-                    if (jt >= 0) atomicMin(a.bid + jt, (unsigned long long)mkkey(pt, (uint32_t)i));
+        na = s.cnt[cur];
+        if (na <= ASL || round >= a.max_rounds) break;
+        for (int base = 0; base < na; base += ASL) {
+            int ri[ACS]; uint32_t col[ACS]; float val[ACS];
+#pragma unroll
+            for (int q = 0; q < ACS; q++) { const int slot = base + q * WNW + w; ri[q] = slot < na ? ld_sc1(A + slot) : -1; }
+#pragma unroll
+            for (int q = 0; q < ACS; q++)
+                if (ri[q] >= 0) { col[q] = a.cache_col[(int64_t)ri[q] * KC + lane]; val[q] = a.cache_val[(int64_t)ri[q] * KC + lane]; }
+#pragma unroll
+            for (int q = 0; q < ACS; q++) {
+                if (ri[q] < 0) continue;
+                const int slot = base + q * WNW + w;
+                int jt, i0; float pt, ct;
+                cx.bid_of(ri[q], col[q], val[q], jt, pt, ct, i0);
+                if (lane == 0) {
+                    if (jt < 0) atomicAdd(&s.retired, 1);
+                    else atomicMin(a.bid + jt, (unsigned long long)mkkey(pt, (uint32_t)ri[q]));
                     a.slot_j[slot] = jt; a.slot_p[slot] = pt; a.slot_c[slot] = ct;
                 }
             }
         }
         bids += na;
         __syncthreads();
-        // ---- per column the lowest (price, row) wins; price, owner and displaced owner change together ----
         for (int slot = tid; slot < na; slot += WT) {
-            int i, jt; float pt, ct;
-            bool win;
-            if (small) {
-                i = s.sm_i[slot]; jt = s.sm_j[slot]; pt = s.sm_p[slot]; ct = s.sm_c[slot];
-                win = jt >= 0;
-                for (int k = 0; k < na && win; k++)
-                    if (k != slot && s.sm_j[k] == jt && (s.sm_p[k] < pt || (s.sm_p[k] == pt && s.sm_i[k] < i))) win = false;
-            } else {
-                i = ld_sc1(A + slot); jt = ld_sc1(a.slot_j + slot); pt = ld_sc1(a.slot_p + slot); ct = ld_sc1(a.slot_c + slot);
-                win = jt >= 0 && (uint32_t)ld_sc1(a.bid + jt) == (uint32_t)i;
-            }
+            const int jt = ld_sc1(a.slot_j + slot);
             if (jt < 0) continue;                                // retired: stays free, bids no more
-            if (win) {
-                const int i0 = ld_sc1(a.colsol + jt);
-                a.v[jt] = pt; a.colsol[jt] = i; a.rowsol[i] = jt; a.cassign[jt] = ct;
-                if (i0 >= 0) { a.rowsol[i0] = -1; B[atomicAdd(&s.cnt[cur ^ 1], 1)] = i0; }
+            const int i = ld_sc1(A + slot);
+            if ((uint32_t)ld_sc1(a.bid + jt) == (uint32_t)i) {
+                const int i0 = cx.getcs(jt);
+                cx.apply(i, jt, ld_sc1(a.slot_p + slot), ld_sc1(a.slot_c + slot), i0);
+                if (i0 >= 0) B[atomicAdd(&s.cnt[cur ^ 1], 1)] = i0;
             } else {
                 B[atomicAdd(&s.cnt[cur ^ 1], 1)] = i;
             }
         }
         __syncthreads();
-        if (!small)
-            for (int slot = tid; slot < na; slot += WT) {
-                const int jt = ld_sc1(a.slot_j + slot);
-                if (jt >= 0) a.bid[jt] = ~0ull;
-            }
+        for (int slot = tid; slot < na; slot += WT) {
+            const int jt = ld_sc1(a.slot_j + slot);
+            if (jt >= 0) a.bid[jt] = ~0ull;
+        }
         if (tid == 0) s.cnt[cur] = 0;
         cur ^= 1;
         { int32_t *t_ = A; A = B; B = t_; }
         round++;
         __syncthreads();
     }
+    t_list = wall_clock64() - t_start; n_list = round;
+    const long long t_chain0 = wall_clock64();
+    // ================= CHAIN rounds: wave w holds the rows of slots q * 16 + w =================
+    int left = na;                                               // rows still active when the rounds end
+    if (na > 0 && na <= ASL && round < a.max_rounds) {
+        int my[ACS], jt[ACS], i0[ACS];
+        uint32_t col[ACS], ncol[ACS];
+        float val[ACS], nval[ACS], pt[ACS], ct[ACS];
+#pragma unroll
+        for (int q = 0; q < ACS; q++) {
+            const int e = q * WNW + w;
+            my[q] = e < na ? ld_sc1(A + e) : -1;
+            col[q] = COLSENT; val[q] = 0.0f; ncol[q] = COLSENT; nval[q] = 0.0f;
+            if (my[q] >= 0) { col[q] = a.cache_col[(int64_t)my[q] * KC + lane]; val[q] = a.cache_val[(int64_t)my[q] * KC + lane]; }
+        }
+        int dealt = na;
+        for (;;) {
+#pragma unroll
+            for (int q = 0; q < ACS; q++) {
+                jt[q] = -2; i0[q] = -1; pt[q] = 0.0f; ct[q] = 0.0f;
+                if (my[q] >= 0) {
+                    cx.bid_of(my[q], col[q], val[q], jt[q], pt[q], ct[q], i0[q]);
+                    if (i0[q] >= 0) { ncol[q] = a.cache_col[(int64_t)i0[q] * KC + lane]; nval[q] = a.cache_val[(int64_t)i0[q] * KC + lane]; }   // in flight across the barrier
+                    if (jt[q] < 0 && lane == 0) atomicAdd(&s.retired, 1);
+                }
+                if (lane == 0) { s.sm_j[q * WNW + w] = jt[q]; s.sm_i[q * WNW + w] = my[q]; s.sm_p[q * WNW + w] = pt[q]; }
+            }
+            bids += na;
+            lds_barrier();
+            int nact = 0;
+            {
+                const int oj = s.sm_j[lane], oi = s.sm_i[lane];
+                const float op = s.sm_p[lane];
+#pragma unroll
+                for (int q = 0; q < ACS; q++) {
+                    if (my[q] < 0) continue;
+                    if (jt[q] < 0) { my[q] = -1; continue; }      // retired
+                    const bool better = oj == jt[q] && lane != q * WNW + w && (op < pt[q] || (op == pt[q] && oi < my[q]));
+                    if (!__ballot(better)) {
+                        if (lane == 0) cx.apply(my[q], jt[q], pt[q], ct[q], i0[q]);
+                        my[q] = i0[q]; col[q] = ncol[q]; val[q] = nval[q];     // the displaced owner bids in the next round (or nobody)
+                    }
+                    nact += my[q] >= 0;
+                }
+            }
+            if (lane == 0) s.wcnt[w] = nact;
+            round++;
+            if (VLDS) lds_barrier();          // prices and owners are exchanged through LDS: the global stores may still be in flight
+            else __syncthreads();             // ... through L2: the round's stores are acknowledged before anyone bids again
+            na = 0;
+#pragma unroll
+            for (int k = 0; k < WNW; k++) na += s.wcnt[k];
+            left = na;
+            if (na == 0 || round >= a.max_rounds) break;
+            if (na * 2 <= dealt && dealt > WNW) {
+                // half of the rows have dropped out: deal the rest out again, round-robin over the waves
+#pragma unroll
+                for (int q = 0; q < ACS; q++)
+                    if (my[q] >= 0 && lane == 0) s.deal[atomicAdd(&s.ndeal, 1)] = my[q];
+                lds_barrier();
+#pragma unroll
+                for (int q = 0; q < ACS; q++) {
+                    const int e = q * WNW + w;
+                    my[q] = e < na ? s.deal[e] : -1;
+                    if (my[q] >= 0) { col[q] = a.cache_col[(int64_t)my[q] * KC + lane]; val[q] = a.cache_val[(int64_t)my[q] * KC + lane]; }
+                }
+                dealt = na; n_deal++;
+                lds_barrier();
+                if (tid == 0) s.ndeal = 0;
+            }
+        }
+    }
+    __syncthreads();
+    t_chain = wall_clock64() - t_chain0; n_chain = round - n_list;
+    const long long t_tail0 = wall_clock64();
     // ---- the rows still free, in ascending order, for the augmentation ----
     int numfree = 0;
     for (int i0 = 0; i0 < n; i0 += WT) {
@@ -215,9 +368,11 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
         long long *ctr = reinterpret_cast<long long *>(a.misc + 16);
         long long *wc = reinterpret_cast<long long *>(a.misc + 160);
         ctr[C_ARR] = bids; ctr[C_FREE_CR] = free_cr; ctr[C_FREE_A1] = numfree; ctr[C_FREE_A2] = numfree;
-        wc[WC_ROUNDS] = round; wc[WC_BIDS] = bids; wc[WC_RETIRED] = s.retired; wc[WC_ACTIVE_LEFT] = s.cnt[cur];
+        wc[WC_ROUNDS] = round; wc[WC_BIDS] = bids; wc[WC_RETIRED] = s.retired; wc[WC_ACTIVE_LEFT] = left;
         wc[WC_FREE_ARR] = numfree; wc[WC_DENSE_ARR] = s.dense;
         *reinterpret_cast<int *>(a.misc + 128) = numfree;
+        long long *dbg = reinterpret_cast<long long *>(a.misc + 256);      // (100 MHz ticks)
+        dbg[0] = n_list; dbg[1] = t_list; dbg[2] = n_chain; dbg[3] = t_chain; dbg[4] = n_deal; dbg[6] = wall_clock64() - t_tail0;
     }
 }
 
@@ -233,27 +388,35 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
 // is below s_T's; clears the dirty bit, reads the label, relaxes the owner row's cached columns.  Barrier.  The block
 // minimum of the block a wave took from is rebuilt.  Barrier.  No wave found work: converged.
 // ------------------------------------------------------------------------------------------------------------------
-size_t wide_aug_lds_bytes(int n) {
-    const size_t nblk = ((size_t)n + 63) / 64, nw32 = ((size_t)n + 31) / 32;
-    return ((nblk * 8 + 3 * nw32 * 4 + 15) / 16) * 16;
+constexpr int AP = 2;              // columns a wave settles per round (their loads are in flight together)
+
+size_t wide_aug_lds_bytes(int n, bool vlds) {
+    const size_t nblk = ((size_t)n + 63) / 64, nw32 = ((size_t)n + 31) / 32, npad = ((size_t)n + 3) & ~(size_t)3;
+    return ((nblk * 8 + 3 * nw32 * 4 + (vlds ? npad * 6 : 0) + 15) / 16) * 16;
 }
+bool wide_aug_vlds(int n) { return n <= 65534 && wide_aug_lds_bytes(n, true) + 4096 <= (size_t)LDS_DYNAMIC_MAX; }
+size_t wide_aug_lds_bytes(int n) { return wide_aug_lds_bytes(n, wide_aug_vlds(n)); }
 
 struct AugShared {
     unsigned long long T;          // best unassigned column: (ordered distance << 32 | column)
-    int ntouch, any, fail, anydense, rootdense, doroot, f, err;
+    int ntouch, any[2], fail, anydense, rootdense, doroot, f, err;
     int scans;
 };
 
+// VLDS: prices (f32) and column owners (u16) also in LDS (every update goes to both copies), as in wide_arr.
+template <bool VLDS>
 __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batch) {
     extern __shared__ __align__(16) unsigned char w_smem[];
     __shared__ AugShared s;
-    const WideArgs a = batch[blockIdx.x];
+    const WideArgs a = load_wide_args(batch, blockIdx.x);
     const int n = a.n, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nblk = (n + 63) / 64, nw32 = (n + 31) / 32;
     unsigned long long *bmin = reinterpret_cast<unsigned long long *>(w_smem);
     uint32_t *dirty = reinterpret_cast<uint32_t *>(bmin + nblk);
     uint32_t *asg = dirty + nw32;
     uint32_t *dense = asg + nw32;
+    float *s_v = reinterpret_cast<float *>(dense + nw32);
+    uint16_t *s_cs = reinterpret_cast<uint16_t *>(s_v + ((n + 3) & ~3));
     const int numfree = *reinterpret_cast<const int *>(a.misc + 128);
     for (int b = tid; b < nblk; b += WT) bmin[b] = ~0ull;
     for (int q = tid; q < nw32; q += WT) { dirty[q] = 0; dense[q] = 0; }
@@ -262,26 +425,41 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
         const uint64_t m = __ballot(c < n && a.colsol[c] >= 0);
         if (lane == 0 && (c >> 5) < nw32) { asg[c >> 5] = (uint32_t)m; if ((c >> 5) + 1 < nw32) asg[(c >> 5) + 1] = (uint32_t)(m >> 32); }
     }
-    if (tid == 0) { s.T = ~0ull; s.ntouch = 0; s.any = 0; s.fail = 0; s.anydense = 0; s.rootdense = 0; s.doroot = 0; s.f = 0; s.err = 0; s.scans = 0; }
+    if (VLDS)
+        for (int j = tid; j < n; j += WT) { s_v[j] = a.v[j]; const int o = a.colsol[j]; s_cs[j] = o < 0 ? (uint16_t)0xFFFFu : (uint16_t)o; }
+    if (tid == 0) { s.T = ~0ull; s.ntouch = 0; s.any[0] = 0; s.any[1] = 0; s.fail = 0; s.anydense = 0; s.rootdense = 0; s.doroot = 0; s.f = 0; s.err = 0; s.scans = 0; }
     __syncthreads();
+    auto getv = [&](int j) -> float { return VLDS ? s_v[j] : ld_sc1(a.v + j); };
+    auto getcs = [&](int j) -> int {
+        if (VLDS) { const uint16_t x = s_cs[j]; return x == 0xFFFFu ? -1 : (int)x; }
+        return ld_sc1(a.colsol + j);
+    };
+    auto is_asg = [&](int c) -> bool { return (asg[c >> 5] >> (c & 31)) & 1u; };
 
     long long c_relax = 0, c_hops = 0, c_rounds = 0, c_proc = 0, c_trivial = 0, c_dense = 0, c_verify = 0;   // (thread 0 / wave leaders)
+    long long t_rounds = 0, t_verify = 0, t_finish = 0, t_triv = 0, t_mark = wall_clock64();
+#define AUG_LAP(acc) { const long long now_ = wall_clock64(); acc += now_ - t_mark; t_mark = now_; }
 
-    // one relaxation: column `col` is offered the distance `co` (ordered) by row `row`
-    auto relax_to = [&](int col, uint32_t co, int row) {
+    // a relaxation in two halves: the offer (column `col` is offered the ordered distance `co` by row `row`; returns the label
+    // it replaced or lost against) and what follows from it -- first touch, dirty column, best unassigned column
+    auto offer = [&](int col, uint32_t co, int row) -> unsigned long long {
+        return atomicMin(a.label + col, ((unsigned long long)co << 32) | (uint32_t)row);
+    };
+    auto after_offer = [&](int col, uint32_t co, int row, unsigned long long old) {
         const unsigned long long key = ((unsigned long long)co << 32) | (uint32_t)row;
-        const unsigned long long old = atomicMin(a.label + col, key);
         if (key < old) {
             if (old == ~0ull) a.touched[atomicAdd(&s.ntouch, 1)] = col;
             if ((uint32_t)(old >> 32) > co) {                    // the distance itself dropped (not only the row of a tie)
                 const unsigned long long ck = ((unsigned long long)co << 32) | (uint32_t)col;
-                if ((asg[col >> 5] >> (col & 31)) & 1u) { atomicOr(&dirty[col >> 5], 1u << (col & 31)); atomicMin(&bmin[col >> 6], ck); }
+                if (is_asg(col)) { atomicOr(&dirty[col >> 5], 1u << (col & 31)); atomicMin(&bmin[col >> 6], ck); }
                 else atomicMin(&s.T, ck);
             }
         }
     };
+    auto relax_to = [&](int col, uint32_t co, int row) { after_offer(col, co, row, offer(col, co, row)); };
 
     int f = 0;
+    int par = 0;
     for (;;) {
         // ---- wave 0 disposes of the searches that end at once: the free row's best cached column is unassigned and its
         // cache certifies that (no column settled, no price changes: the path is one edge) ----
@@ -290,16 +468,17 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                 const int fr = a.freerows[f];
                 const uint32_t col = a.cache_col[(int64_t)fr * KC + lane];
                 const float val = a.cache_val[(int64_t)fr * KC + lane];
-                const float tau = __shfl(val, KCU);
+                const float tau = rdlane(val, KCU);
                 const bool valid = lane < KCU && col != COLSENT;
-                const uint32_t od = valid ? f2ord(val - ld_sc1(a.v + col)) : 0xFFFFFFFFu;
+                const uint32_t od = valid ? f2ord(val - getv((int)col)) : 0xFFFFFFFFu;
                 const uint32_t omin = wave_min_u32(od);
-                const bool un = valid && od == omin && !((asg[col >> 5] >> (col & 31)) & 1u);
+                const bool un = valid && od == omin && !is_asg((int)col);
                 const uint64_t mu = __ballot(un);
                 if (!(omin != 0xFFFFFFFFu && mu && tau > ord2f(omin))) break;
                 const int l = __ffsll((unsigned long long)mu) - 1;     // cache rows are sorted by column: the lowest such column
                 if (lane == l) {
                     a.rowsol[fr] = (int)col; a.colsol[col] = fr; a.cassign[col] = val;
+                    if (VLDS) s_cs[col] = (uint16_t)fr;
                     atomicOr(&asg[col >> 5], 1u << (col & 31));
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -309,6 +488,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             if (lane == 0) s.f = f;
         }
         __syncthreads();
+        AUG_LAP(t_triv)
         f = s.f;
         if (f >= numfree) break;
         const int fr = a.freerows[f];
@@ -319,7 +499,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
         if (w == 0) {
             const uint32_t col = a.cache_col[(int64_t)fr * KC + lane];
             const float val = a.cache_val[(int64_t)fr * KC + lane];
-            if (lane < KCU && col != COLSENT) relax_to((int)col, f2ord(val - ld_sc1(a.v + col)), fr);
+            if (lane < KCU && col != COLSENT) relax_to((int)col, f2ord(val - getv((int)col)), fr);
         }
         __syncthreads();
 
@@ -327,46 +507,74 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             // ================= rounds until no wave finds work =================
             for (;;) {
                 const uint32_t Tord = (uint32_t)(s.T >> 32);
-                unsigned long long m = ~0ull;
-                for (int b = w + WNW * lane; b < nblk; b += WNW * 64) m = umin64(m, bmin[b]);
-                m = min64_wave_allreduce(m);
-                const bool picked = m != ~0ull && (uint32_t)(m >> 32) < Tord;
-                int pj = -1;
-                if (picked) {
-                    pj = (int)(uint32_t)m;
-                    if (lane == 0) { atomicAnd(&dirty[pj >> 5], ~(1u << (pj & 31))); s.any = 1; }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the bit is cleared before the label is read
-                    const unsigned long long lab = ld_sc1(a.label + pj);
-                    const uint32_t dord = (uint32_t)(lab >> 32);
-                    if (dord < Tord) {
-                        const int i = ld_sc1(a.colsol + pj);
-                        const float d = ord2f(dord);
-                        const float h = (ld_sc1(a.cassign + pj) - ld_sc1(a.v + pj)) - d;
-                        const uint32_t lo = dord + 1u;
-                        if (!((dense[i >> 5] >> (i & 31)) & 1u)) {
-                            const uint32_t col = a.cache_col[(int64_t)i * KC + lane];
-                            const float val = a.cache_val[(int64_t)i * KC + lane];
-                            if (lane < KCU && col != COLSENT && (int)col != pj) {
-                                uint32_t co = f2ord((val - ld_sc1(a.v + col)) - h);
-                                co = co < lo ? lo : co;
-                                if (co <= Tord) relax_to((int)col, co, i);
-                            }
-                        } else {
-                            const float *__restrict__ row = a.cost + wrow_off(a.rowmap, i, a.ld);
-                            for (int c = lane; c < n; c += 64) {
-                                if (c == pj) continue;
-                                uint32_t co = f2ord((row[c] - ld_sc1(a.v + c)) - h);
-                                co = co < lo ? lo : co;
-                                if (co <= (uint32_t)(s.T >> 32)) relax_to(c, co, i);
-                            }
-                            c_dense++;
-                        }
+                // the two best dirty columns among the wave's blocks (one key per block: two different blocks)
+                K2 t; t.m1 = KEYMAX; t.m2 = KEYMAX;
+                for (int b = w + WNW * lane; b < nblk; b += WNW * 64) k2_push(t, bmin[b]);
+                t = k2_wave_allreduce(t);
+                const uint64_t pkey[AP] = {t.m1, t.m2};
+                bool pk[AP]; int pj[AP], oi[AP];
+                unsigned long long lab[AP];
+                float ca[AP], vp[AP], val[AP];
+                uint32_t col[AP];
+#pragma unroll
+                for (int q = 0; q < AP; q++) {
+                    pk[q] = pkey[q] != KEYMAX && (uint32_t)(pkey[q] >> 32) < Tord;
+                    pj[q] = (int)(uint32_t)pkey[q];
+                    if (pk[q] && lane == 0) { atomicAnd(&dirty[pj[q] >> 5], ~(1u << (pj[q] & 31))); s.any[par] = 1; }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the bits are cleared before the labels are read
+#pragma unroll
+                for (int q = 0; q < AP; q++) {
+                    lab[q] = ~0ull; ca[q] = 0.0f; vp[q] = 0.0f; oi[q] = 0;
+                    if (pk[q]) { lab[q] = ld_sc1(a.label + pj[q]); ca[q] = ld_sc1(a.cassign + pj[q]); vp[q] = getv(pj[q]); oi[q] = getcs(pj[q]); }
+                }
+#pragma unroll
+                for (int q = 0; q < AP; q++) {
+                    col[q] = COLSENT; val[q] = 0.0f;
+                    if (pk[q]) { col[q] = a.cache_col[(int64_t)oi[q] * KC + lane]; val[q] = a.cache_val[(int64_t)oi[q] * KC + lane]; }
+                }
+                unsigned long long old[AP];
+                uint32_t co[AP];
+                bool off[AP], dn[AP];
+#pragma unroll
+                for (int q = 0; q < AP; q++) {
+                    off[q] = false; dn[q] = false; old[q] = 0; co[q] = 0;
+                    const uint32_t dord = (uint32_t)(lab[q] >> 32);
+                    if (pk[q] && dord < Tord) {
                         c_proc++;
+                        if ((dense[oi[q] >> 5] >> (oi[q] & 31)) & 1u) { dn[q] = true; continue; }
+                        const float h = (ca[q] - vp[q]) - ord2f(dord);
+                        const uint32_t lo = dord + 1u;
+                        if (lane < KCU && col[q] != COLSENT && (int)col[q] != pj[q]) {
+                            uint32_t c = f2ord((val[q] - getv((int)col[q])) - h);
+                            c = c < lo ? lo : c;
+                            if (c <= Tord) { off[q] = true; co[q] = c; old[q] = offer((int)col[q], c, oi[q]); }
+                        }
                     }
                 }
+#pragma unroll
+                for (int q = 0; q < AP; q++)
+                    if (off[q]) after_offer((int)col[q], co[q], oi[q], old[q]);
+#pragma unroll
+                for (int q = 0; q < AP; q++) {
+                    if (!dn[q]) continue;                          // the owner's cache could not certify: its whole cost row
+                    const uint32_t dord = (uint32_t)(lab[q] >> 32);
+                    const float h = (ca[q] - vp[q]) - ord2f(dord);
+                    const uint32_t lo = dord + 1u;
+                    const float *__restrict__ row = a.cost + wrow_off(a.rowmap, oi[q], a.ld);
+                    for (int c = lane; c < n; c += 64) {
+                        if (c == pj[q]) continue;
+                        uint32_t cc = f2ord((row[c] - getv(c)) - h);
+                        cc = cc < lo ? lo : cc;
+                        if (cc <= (uint32_t)(s.T >> 32)) relax_to(c, cc, oi[q]);
+                    }
+                    c_dense++;
+                }
                 __syncthreads();
-                if (picked) {                                   // the block the wave took from: its smallest dirty column now
-                    const int b = pj >> 6, c = b * 64 + lane;
+#pragma unroll
+                for (int q = 0; q < AP; q++) {
+                    if (!pk[q]) continue;                          // the block the wave took from: its smallest dirty column now
+                    const int b = pj[q] >> 6, c = b * 64 + lane;
                     const bool db = c < n && ((dirty[c >> 5] >> (c & 31)) & 1u);
                     unsigned long long key = ~0ull;
                     if (__ballot(db)) {
@@ -375,17 +583,15 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     }
                     if (lane == 0) bmin[b] = key;
                 }
-                const int any = s.any;
+                const int any = s.any[par];
+                if (tid == 0) s.any[par ^ 1] = 0;
+                par ^= 1;
                 c_rounds++;
                 __syncthreads();
-                if (tid == 0) s.any = 0;
                 if (!any) break;
-                // (s.any is re-armed by the picks of the next round only after every wave has read it: the write above
-                //  and the next round's s.any = 1 are separated by the program order of wave 0 and the barrier below)
-                __syncthreads();
             }
             // ================= converged: do the caches certify what was skipped? =================
-            __syncthreads();
+            AUG_LAP(t_rounds)
             const unsigned long long Tk = s.T;
             const uint32_t Dord = (uint32_t)(Tk >> 32);
             const float D = Tk == ~0ull ? INFINITY : ord2f(Dord);
@@ -393,10 +599,10 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             for (int q = tid; q < nt; q += WT) {
                 const int k = ld_sc1(a.touched + q);
                 const uint32_t dord = (uint32_t)(ld_sc1(a.label + k) >> 32);
-                if (dord < Dord && ((asg[k >> 5] >> (k & 31)) & 1u)) {
-                    const int i = ld_sc1(a.colsol + k);
+                if (dord < Dord && is_asg(k)) {
+                    const int i = getcs(k);
                     if (!((dense[i >> 5] >> (i & 31)) & 1u)) {
-                        const float h = (ld_sc1(a.cassign + k) - ld_sc1(a.v + k)) - ord2f(dord);
+                        const float h = (ld_sc1(a.cassign + k) - getv(k)) - ord2f(dord);
                         const float bound = a.cache_val[(int64_t)i * KC + KCU] - h;
                         if (!(bound > D)) {
                             atomicOr(&dense[i >> 5], 1u << (i & 31));
@@ -413,12 +619,13 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             const int fail = s.fail;
             if (s.doroot)
                 for (int c = tid; c < n; c += WT) {
-                    const uint32_t co = f2ord(frow[c] - ld_sc1(a.v + c));
+                    const uint32_t co = f2ord(frow[c] - getv(c));
                     if (co <= (uint32_t)(s.T >> 32)) relax_to(c, co, fr);
                 }
             __syncthreads();
             if (tid == 0) { if (fail) s.anydense = 1; s.fail = 0; s.doroot = 0; }
             __syncthreads();
+            AUG_LAP(t_verify)
             if (!fail) break;
         }
 
@@ -433,10 +640,10 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
         for (int q = tid; q < nt; q += WT) {
             const int k = ld_sc1(a.touched + q);
             const uint32_t dord = (uint32_t)(ld_sc1(a.label + k) >> 32);
-            if (dord < Dord && ((asg[k >> 5] >> (k & 31)) & 1u)) {
-                const float vk = ld_sc1(a.v + k);
+            if (dord < Dord && is_asg(k)) {
+                const float vk = getv(k);
                 const float nv = (vk + ord2f(dord)) - D;
-                if (nv < vk) a.v[k] = nv;
+                if (nv < vk) { a.v[k] = nv; if (VLDS) s_v[k] = nv; }
                 myscans++;
             }
         }
@@ -447,6 +654,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                 const int i = (int)(uint32_t)ld_sc1(a.label + j);
                 const int jn = ld_sc1(a.rowsol + i);
                 a.colsol[j] = i; a.rowsol[i] = j; a.cassign[j] = a.cost[wrow_off(a.rowmap, i, a.ld) + j];
+                if (VLDS) s_cs[j] = (uint16_t)i;
                 c_hops++;
                 if (i == fr) break;
                 j = jn;
@@ -465,6 +673,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
         if (tid == 0) { c_relax += s.scans; s.scans = 0; s.T = ~0ull; s.ntouch = 0; s.anydense = 0; s.rootdense = 0; s.f = f + 1; }
         f++;
         __syncthreads();
+        AUG_LAP(t_finish)
     }
 
     // ---- duals, total, counters ----
@@ -496,6 +705,8 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
         ctr[C_AUG_INIT] = numfree; ctr[C_AUG_RELAX] = c_relax; ctr[C_AUGS] = numfree; ctr[C_HOPS] = hops0;
         wc[WC_DENSE_AUG] = dn; wc[WC_AUG_ROUNDS] = c_rounds; wc[WC_AUG_PROCESSED] = proc; wc[WC_TRIVIAL] = triv; wc[WC_VERIFY_PASSES] = c_verify;
         if (s.err) *reinterpret_cast<int *>(a.misc + 4) = 1;
+        long long *dbg = reinterpret_cast<long long *>(a.misc + 256);      // (100 MHz ticks)
+        dbg[8] = t_rounds; dbg[9] = t_verify; dbg[10] = t_finish; dbg[11] = t_triv;
     }
 }
 
@@ -508,18 +719,23 @@ int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream) {
 }
 
 int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream) {
-    (void)n;
-    hipLaunchKernelGGL(wide_arr, dim3(nb), dim3(WT), 0, stream, d_args);
+    const bool vlds = wide_arr_vlds(n);
+    void (*k)(const WideArgs *) = vlds ? wide_arr<true> : wide_arr<false>;
+    int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(k));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k, dim3(nb), dim3(WT), wide_arr_lds_bytes(n, vlds), stream, d_args);
     CYTO_HIP(hipGetLastError());
     return CYTO_OK;
 }
 
 int wide_launch_aug(const WideArgs *d_args, int nb, int n, hipStream_t stream) {
-    const size_t shm = wide_aug_lds_bytes(n);
+    const bool vlds = wide_aug_vlds(n);
+    const size_t shm = wide_aug_lds_bytes(n, vlds);
     if (shm > (size_t)LDS_DYNAMIC_MAX) return CYTO_ERR_UNSUPPORTED;
-    int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(wide_aug));
+    void (*k)(const WideArgs *) = vlds ? wide_aug<true> : wide_aug<false>;
+    int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(k));
     if (rc) return rc;
-    hipLaunchKernelGGL(wide_aug, dim3(nb), dim3(WT), shm, stream, d_args);
+    hipLaunchKernelGGL(k, dim3(nb), dim3(WT), shm, stream, d_args);
     CYTO_HIP(hipGetLastError());
     return CYTO_OK;
 }
