@@ -9,7 +9,7 @@ LIB = os.path.join(HERE, "libcytohip.so")
 SOURCES = ["core.hip", "lap_jv.hip", "lap_wide.hip", "cost.hip", "batch.hip"]
 # -ffp-contract=off: the JV kernels must evaluate exactly the subtract/compare sequence of the
 # oracle (no FMA contraction, no re-association).  MFMA use in the cost kernels is explicit.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+FLAGS = (["-DCYTO_WIDE_PROF"] if os.environ.get("CYTO_WIDE_PROF") else []) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wall", "-Wno-unused-result"]
 
 

@@ -3319,6 +3319,8 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
                     CYTO_HIP(hipMemcpy(dbg, j.b_misc.as<char>() + 256, sizeof dbg, hipMemcpyDeviceToHost));
                     fprintf(stderr, "[wide n=%d] arr: list rounds %lld (%.2f ms) chain rounds %lld (%.2f ms) deals %lld setup %.2f ms tail %.2f ms | aug: rounds %.2f ms verify %.2f ms finish %.2f ms trivial %.2f ms\n",
                             n, dbg[0], dbg[1] * 1e-5, dbg[2], dbg[3] * 1e-5, dbg[4], dbg[5] * 1e-5, dbg[6] * 1e-5, dbg[8] * 1e-5, dbg[9] * 1e-5, dbg[10] * 1e-5, dbg[11] * 1e-5);
+                    fprintf(stderr, "[wide n=%d] chain-round profile (wave 0, ms): wait-prefetch %.2f bids %.2f barrier1 %.2f resolve %.2f barrier2+count %.2f\n",
+                            n, dbg[12] * 1e-5, dbg[13] * 1e-5, dbg[14] * 1e-5, dbg[15] * 1e-5, dbg[7] * 1e-5);
                 }
             }
         }

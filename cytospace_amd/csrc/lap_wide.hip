@@ -53,6 +53,14 @@ __device__ __forceinline__ WideArgs load_wide_args(const WideArgs *__restrict__ 
     return a;
 }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
+// a value every lane holds alike, moved to an SGPR: what depends on it becomes scalar code (scalar branches instead of
+// exec-mask regions, scalar address arithmetic) -- the compiler cannot see that e.g. the wave index is uniform
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ float uni(float x) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x))); }
+__device__ __forceinline__ unsigned long long uni(unsigned long long x) {
+    return ((unsigned long long)uni((uint32_t)(x >> 32)) << 32) | uni((uint32_t)x);
+}
 // value of lane l (wave-uniform l) without the LDS round trip of __shfl
 __device__ __forceinline__ uint32_t rdlane(uint32_t x, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, l); }
 __device__ __forceinline__ float rdlane(float x, int l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), l)); }
@@ -146,16 +154,18 @@ template <bool VLDS> struct ArrCtx {
         a.v[jt] = pt; a.colsol[jt] = i; a.rowsol[i] = jt; a.cassign[jt] = ct;
         if (i0 >= 0) a.rowsol[i0] = -1;
     }
-    // exact lexicographic top-2 of the whole row (the cache could not certify): rare, kept out of line
-    __device__ __noinline__ void top2_full(int i, float &u1, int &j1, float &c1, float &vj1, float &u2, int &j2, float &c2, float &vj2) const {
+    // exact lexicographic top-2 of the whole row (the cache could not certify).  (Inlined on purpose: as an out-of-line call its
+    // eight results travel through scratch memory, and every bid -- also the certified ones -- then stores and reloads them
+    // through the vector memory path, waiting for the prefetched cache rows each time.)
+    __device__ __forceinline__ void top2_full(int i, float &u1, int &j1, float &c1, float &vj1, float &u2, int &j2, float &c2, float &vj2) const {
         const int n = a.n;
         const float *__restrict__ row = a.cost + wrow_off(a.rowmap, i, a.ld);
         K2 d; d.m1 = KEYMAX; d.m2 = KEYMAX;
         for (int c = lane; c < n; c += 64) k2_push(d, mkkey(row[c] - getv(c), (uint32_t)c));
         d = k2_wave_allreduce(d);
-        u1 = key_val(d.m1); j1 = (int)(uint32_t)d.m1; c1 = row[j1]; vj1 = getv(j1);
+        u1 = key_val(d.m1); j1 = (int)(uint32_t)d.m1; c1 = uni(row[j1]); vj1 = uni(getv(j1));
         u2 = INFINITY; j2 = -1; c2 = 0.0f; vj2 = 0.0f;
-        if (d.m2 != KEYMAX) { u2 = key_val(d.m2); j2 = (int)(uint32_t)d.m2; c2 = row[j2]; vj2 = getv(j2); }
+        if (d.m2 != KEYMAX) { u2 = key_val(d.m2); j2 = (int)(uint32_t)d.m2; c2 = uni(row[j2]); vj2 = uni(getv(j2)); }
         if (lane == 0) atomicAdd(&s->dense, 1);
     }
     // the bid of row i (its cache row in col / val, lane = entry): target column jt (-1: the row retires), price, raw cost of
@@ -182,10 +192,11 @@ template <bool VLDS> struct ArrCtx {
         }
         const float p = vj1 - (u2 - u1);
         jt = -1; pt = 0.0f; ct = 0.0f; i0 = -1;
-        const int o1 = getcs(j1);
+        const int o1 = uni(getcs(j1));
         if (p < vj1) { jt = j1; pt = p; ct = c1; i0 = o1; }
         else if (o1 < 0) { jt = j1; pt = vj1; ct = c1; }
-        else if (j2 >= 0 && u2 == u1 && getcs(j2) < 0) { jt = j2; pt = vj2; ct = c2; }
+        else if (j2 >= 0 && u2 == u1 && uni(getcs(j2)) < 0) { jt = j2; pt = vj2; ct = c2; }
+        jt = uni(jt); pt = uni(pt); ct = uni(ct); i0 = uni(i0);
     }
 };
 
@@ -196,7 +207,7 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
     ArrCtx<VLDS> cx;
     cx.a = load_wide_args(batch, blockIdx.x);
     const WideArgs &a = cx.a;
-    const int n = a.n, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n = a.n, tid = threadIdx.x, lane = tid & 63, w = uni((int)(threadIdx.x >> 6));
     cx.s_v = reinterpret_cast<float *>(w_smem);
     cx.s_cs = reinterpret_cast<uint16_t *>(cx.s_v + ((n + 3) & ~3));
     cx.s = &s; cx.lane = lane;
@@ -227,12 +238,12 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
     int na = free_cr;
     // ================= LIST rounds =================
     for (;;) {
-        na = s.cnt[cur];
+        na = uni(s.cnt[cur]);
         if (na <= ASL || round >= a.max_rounds) break;
         for (int base = 0; base < na; base += ASL) {
             int ri[ACS]; uint32_t col[ACS]; float val[ACS];
 #pragma unroll
-            for (int q = 0; q < ACS; q++) { const int slot = base + q * WNW + w; ri[q] = slot < na ? ld_sc1(A + slot) : -1; }
+            for (int q = 0; q < ACS; q++) { const int slot = base + q * WNW + w; ri[q] = slot < na ? uni(ld_sc1(A + slot)) : -1; }
 #pragma unroll
             for (int q = 0; q < ACS; q++)
                 if (ri[q] >= 0) { col[q] = a.cache_col[(int64_t)ri[q] * KC + lane]; val[q] = a.cache_val[(int64_t)ri[q] * KC + lane]; }
@@ -285,12 +296,18 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
 #pragma unroll
         for (int q = 0; q < ACS; q++) {
             const int e = q * WNW + w;
-            my[q] = e < na ? ld_sc1(A + e) : -1;
+            my[q] = e < na ? uni(ld_sc1(A + e)) : -1;
             col[q] = COLSENT; val[q] = 0.0f; ncol[q] = COLSENT; nval[q] = 0.0f;
             if (my[q] >= 0) { col[q] = a.cache_col[(int64_t)my[q] * KC + lane]; val[q] = a.cache_val[(int64_t)my[q] * KC + lane]; }
         }
         int dealt = na;
+        long long tp[5] = {0, 0, 0, 0, 0}, tm = wall_clock64();
+#define CH_LAP(k) { const long long now_ = wall_clock64(); tp[k] += now_ - tm; tm = now_; }
         for (;;) {
+#ifdef CYTO_WIDE_PROF
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            CH_LAP(0)
+#endif
 #pragma unroll
             for (int q = 0; q < ACS; q++) {
                 jt[q] = -2; i0[q] = -1; pt[q] = 0.0f; ct[q] = 0.0f;
@@ -302,7 +319,13 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
                 if (lane == 0) { s.sm_j[q * WNW + w] = jt[q]; s.sm_i[q * WNW + w] = my[q]; s.sm_p[q * WNW + w] = pt[q]; }
             }
             bids += na;
+#ifdef CYTO_WIDE_PROF
+            CH_LAP(1)
+#endif
             lds_barrier();
+#ifdef CYTO_WIDE_PROF
+            CH_LAP(2)
+#endif
             int nact = 0;
             {
                 const int oj = s.sm_j[lane], oi = s.sm_i[lane];
@@ -321,12 +344,19 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
             }
             if (lane == 0) s.wcnt[w] = nact;
             round++;
+#ifdef CYTO_WIDE_PROF
+            CH_LAP(3)
+#endif
             if (VLDS) lds_barrier();          // prices and owners are exchanged through LDS: the global stores may still be in flight
             else __syncthreads();             // ... through L2: the round's stores are acknowledged before anyone bids again
             na = 0;
 #pragma unroll
             for (int k = 0; k < WNW; k++) na += s.wcnt[k];
+            na = uni(na);
             left = na;
+#ifdef CYTO_WIDE_PROF
+            CH_LAP(4)
+#endif
             if (na == 0 || round >= a.max_rounds) break;
             if (na * 2 <= dealt && dealt > WNW) {
                 // half of the rows have dropped out: deal the rest out again, round-robin over the waves
@@ -337,7 +367,7 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
 #pragma unroll
                 for (int q = 0; q < ACS; q++) {
                     const int e = q * WNW + w;
-                    my[q] = e < na ? s.deal[e] : -1;
+                    my[q] = e < na ? uni(s.deal[e]) : -1;
                     if (my[q] >= 0) { col[q] = a.cache_col[(int64_t)my[q] * KC + lane]; val[q] = a.cache_val[(int64_t)my[q] * KC + lane]; }
                 }
                 dealt = na; n_deal++;
@@ -345,6 +375,9 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
                 if (tid == 0) s.ndeal = 0;
             }
         }
+#ifdef CYTO_WIDE_PROF
+        if (tid == 0) { long long *dbg = reinterpret_cast<long long *>(a.misc + 256); for (int k = 0; k < 5; k++) dbg[12 + k > 15 ? 15 : 12 + k] = tp[k]; dbg[7] = tp[4]; }
+#endif
     }
     __syncthreads();
     t_chain = wall_clock64() - t_chain0; n_chain = round - n_list;
@@ -409,7 +442,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
     extern __shared__ __align__(16) unsigned char w_smem[];
     __shared__ AugShared s;
     const WideArgs a = load_wide_args(batch, blockIdx.x);
-    const int n = a.n, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n = a.n, tid = threadIdx.x, lane = tid & 63, w = uni((int)(threadIdx.x >> 6));
     const int nblk = (n + 63) / 64, nw32 = (n + 31) / 32;
     unsigned long long *bmin = reinterpret_cast<unsigned long long *>(w_smem);
     uint32_t *dirty = reinterpret_cast<uint32_t *>(bmin + nblk);
@@ -489,7 +522,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
         }
         __syncthreads();
         AUG_LAP(t_triv)
-        f = s.f;
+        f = uni(s.f);
         if (f >= numfree) break;
         const int fr = a.freerows[f];
         const float *__restrict__ frow = a.cost + wrow_off(a.rowmap, fr, a.ld);
@@ -506,12 +539,23 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
         for (;;) {
             // ================= rounds until no wave finds work =================
             for (;;) {
-                const uint32_t Tord = (uint32_t)(s.T >> 32);
-                // the two best dirty columns among the wave's blocks (one key per block: two different blocks)
-                K2 t; t.m1 = KEYMAX; t.m2 = KEYMAX;
-                for (int b = w + WNW * lane; b < nblk; b += WNW * 64) k2_push(t, bmin[b]);
-                t = k2_wave_allreduce(t);
-                const uint64_t pkey[AP] = {t.m1, t.m2};
+                const uint32_t Tord = uni((uint32_t)(s.T >> 32));
+                // two good dirty columns among the wave's blocks: the smallest distance, then the smallest of the other lanes
+                // (32-bit reductions on the distance alone; which of several equal distances is taken does not matter --
+                // no schedule does)
+                unsigned long long mk = ~0ull;
+                for (int b = w + WNW * lane; b < nblk; b += WNW * 64) mk = umin64(mk, bmin[b]);
+                uint64_t pkey[AP];
+                {
+                    uint32_t dk = (uint32_t)(mk >> 32);
+#pragma unroll
+                    for (int q = 0; q < AP; q++) {
+                        const uint32_t m = wave_min_u32(dk);
+                        const int l = __ffsll((unsigned long long)__ballot(dk == m)) - 1;
+                        pkey[q] = m == 0xFFFFFFFFu ? KEYMAX : (((uint64_t)m << 32) | rdlane((uint32_t)mk, l));
+                        if (lane == l) dk = 0xFFFFFFFFu;
+                    }
+                }
                 bool pk[AP]; int pj[AP], oi[AP];
                 unsigned long long lab[AP];
                 float ca[AP], vp[AP], val[AP];
@@ -526,7 +570,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
 #pragma unroll
                 for (int q = 0; q < AP; q++) {
                     lab[q] = ~0ull; ca[q] = 0.0f; vp[q] = 0.0f; oi[q] = 0;
-                    if (pk[q]) { lab[q] = ld_sc1(a.label + pj[q]); ca[q] = ld_sc1(a.cassign + pj[q]); vp[q] = getv(pj[q]); oi[q] = getcs(pj[q]); }
+                    if (pk[q]) { lab[q] = uni(ld_sc1(a.label + pj[q])); ca[q] = uni(ld_sc1(a.cassign + pj[q])); vp[q] = uni(getv(pj[q])); oi[q] = uni(getcs(pj[q])); }
                 }
 #pragma unroll
                 for (int q = 0; q < AP; q++) {
@@ -553,8 +597,10 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < AP; q++)
-                    if (off[q]) after_offer((int)col[q], co[q], oi[q], old[q]);
+                for (int q = 0; q < AP; q++) {
+                    const bool better = off[q] && ((((unsigned long long)co[q] << 32) | (uint32_t)oi[q]) < old[q]);
+                    if (__ballot(better) && better) after_offer((int)col[q], co[q], oi[q], old[q]);
+                }
 #pragma unroll
                 for (int q = 0; q < AP; q++) {
                     if (!dn[q]) continue;                          // the owner's cache could not certify: its whole cost row
@@ -578,12 +624,14 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     const bool db = c < n && ((dirty[c >> 5] >> (c & 31)) & 1u);
                     unsigned long long key = ~0ull;
                     if (__ballot(db)) {
-                        if (db) key = ((ld_sc1(a.label + c) >> 32) << 32) | (uint32_t)c;
-                        key = min64_wave_allreduce(key);
+                        const uint32_t dk = db ? (uint32_t)(ld_sc1(a.label + c) >> 32) : 0xFFFFFFFFu;
+                        const uint32_t m = wave_min_u32(dk);
+                        const int l = __ffsll((unsigned long long)__ballot(dk == m)) - 1;
+                        key = ((unsigned long long)m << 32) | (uint32_t)(b * 64 + l);
                     }
                     if (lane == 0) bmin[b] = key;
                 }
-                const int any = s.any[par];
+                const int any = uni(s.any[par]);
                 if (tid == 0) s.any[par ^ 1] = 0;
                 par ^= 1;
                 c_rounds++;
