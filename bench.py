@@ -125,7 +125,7 @@ def extra_c2_batch(dev, cost_buf, n, B=32):
     i = res[0]["info"]
     return {"workload": f"{B} copies of the headline instance ({n} x {n}) solved together, each on its own copy of the matrix",
             "wall_s": round(wall, 3), "assignments_per_s": round(B * n / wall, 1), "batch_kernel_ms": round(i.ms_total, 1),
-            "jv_chain2_ms": round(i.ms_arr, 1), "jv_aug_lazy_ms": round(i.ms_aug, 1), "copies_identical": same}, res[0]
+            "row_reduction_ms": round(i.ms_arr, 1), "augmentation_ms": round(i.ms_aug, 1), "wide_solver": bool(i.wide), "copies_identical": same}, res[0]
 
 
 def _usable_cores():
@@ -147,7 +147,7 @@ def extra_c4_chunks(dev, K, distinct=4, cpu_n=5000, cpu_threads=64):
     from concurrent.futures import ThreadPoolExecutor
     from cytospace_amd import _lib
     from cytospace_amd.lap import lap_solve_batch_device
-    from oracle.jv import jv_oracle
+    from oracle.jv import jv_oracle, jv_oracle_wide
     from tools import instances
     n = 10000
     t = time.perf_counter()
@@ -168,11 +168,18 @@ def extra_c4_chunks(dev, K, distinct=4, cpu_n=5000, cpu_threads=64):
     exact = None
     gpath = os.path.join(ROOT, "tests", "golden", "large_c4s10000.npz")
     if os.path.exists(gpath):            # instance 0 (seed 4) is the golden instance: every copy of it must match the oracle's answer
+        # spot rows are duplicated: the spot of every cell is what any exact solver must return (the golden is certified for that);
+        # the wide restatement's own golden pins the slots and the duals bit for bit
         d = np.load(gpath)
-        exact = all(np.array_equal(res[k]["colsol"], d["colsol"]) and _sha(res[k]["v"]) == str(d["v_sha256"])
-                    for k in range(0, K, distinct))
+        loc0 = instances.c4_chunk_cost(n, seed=4)[1]
+        exact = all(np.array_equal(loc0[res[k]["colsol"]], loc0[d["colsol"]]) for k in range(0, K, distinct))
+        wpath = os.path.join(ROOT, "tests", "golden", "large_c4s10000_wide.npz")
+        if exact and res[0]["info"].wide and os.path.exists(wpath):
+            dw = np.load(wpath)
+            exact = all(np.array_equal(res[k]["colsol"], dw["colsol"]) and _sha(res[k]["v"]) == str(dw["v_sha256"])
+                        and _sha(res[k]["u"]) == str(dw["u_sha256"]) for k in range(0, K, distinct))
         if not exact:
-            raise SystemExit("c4_chunks: HIP result differs from tests/golden/large_c4s10000.npz")
+            raise SystemExit("c4_chunks: HIP result differs from tests/golden/large_c4s10000[_wide].npz")
     same = all(np.array_equal(res[k]["colsol"], res[k % distinct]["colsol"]) for k in range(K))
     if not same:
         raise SystemExit("c4_chunks: copies of one instance solved concurrently gave different answers")
@@ -190,21 +197,24 @@ def extra_c4_chunks(dev, K, distinct=4, cpu_n=5000, cpu_threads=64):
     rs = lap_solve_batch_device([b.ptr for b in bs], [cpu_n] * distinct, device_id=dev, max_concurrent=distinct, return_info=True)
     for b in bs:
         b.free()
-    small_exact = all(np.array_equal(rs[k]["colsol"], ora[k]["colsol"]) and np.array_equal(rs[k]["v"], ora[k]["v"])
+    with ThreadPoolExecutor(T) as ex:      # the batch runs the wide solver: its restatement on the same instances (not timed)
+        oraw = list(ex.map(lambda k: jv_oracle_wide(small[k], np.float32), range(min(distinct, T))))
+    small_exact = all(np.array_equal(rs[k]["colsol"], oraw[k]["colsol"]) and np.array_equal(rs[k]["v"], oraw[k]["v"])
+                      and abs(oraw[k]["total"] - ora[k]["total"]) <= 1e-5 * max(1.0, abs(ora[k]["total"]))
                       for k in range(min(distinct, T)))
     if not small_exact or not np.array_equal(o1["colsol"], ora[0]["colsol"]):
         raise SystemExit("c4_chunks: HIP result differs from the CPU oracle on the CPU sample")
     i0 = one["info"]
     return {"workload": f"{K} concurrent {n} x {n} sub-spot chunk LAPs ({distinct} distinct seeded instances, every chain on its own copy), "
-                        "cost resident in HBM, ONE launch per chain phase with a workgroup per chunk",
+                        "cost resident in HBM, ONE launch per solver phase with a workgroup per chunk",
             "chunks": K, "wall_s": round(wall, 2), "assignments_per_s": round(K * n / wall, 1),
             # what the 256 chains together draw from HBM: every full-row scan reads its 4 n bytes (the cached scans read none)
             "hbm_rows_read": int(sum(r["info"].hbm_row_reads for r in res)),
             "hbm_GBs_rows_read": round(sum(r["info"].hbm_row_reads for r in res) * 4.0 * n / wall / 1e9, 1),
             "one_chunk_alone": {"wall_s": round(wall1, 2), "assignments_per_s": round(n / wall1, 1), "kernel_ms": round(i0.ms_total, 1),
-                                "jv_chain2_ms": round(i0.ms_arr, 1), "augmentation_ms": round(i0.ms_aug, 1),
+                                "row_reduction_ms": round(i0.ms_arr, 1), "augmentation_ms": round(i0.ms_aug, 1), "wide_solver": bool(i0.wide),
                                 "row_scans": int(i0.row_scans), "aug_scans": int(i0.scans_aug_relax),
-                                "aug_full_row_scans": int(i0.aug_dense_scans), "handover_at_search": int(i0.aug_handover),
+                                "aug_full_row_scans": int(i0.wide_dense_aug if i0.wide else i0.aug_dense_scans),
                                 "us_per_aug_scan": round(i0.ms_aug * 1e3 / max(1, i0.scans_aug_relax), 3)},
             "bit_exact_vs_oracle_golden": exact, "copies_identical": same,
             "cpu_baseline": {"value": round(T * cpu_n / cpu_wall, 1), "unit": "assignments/s", "cores": T, "kind": "port",
@@ -228,7 +238,7 @@ def extra_c5_chunks(dev, K=50, G=500, chunk=10000, sets=8, cpu_n=10000, cpu_thre
     from cytospace_amd import common
     from cytospace_amd.cytospace import ExpressionContext
     from cytospace_amd.lap import lap_solve
-    from oracle.jv import jv_oracle
+    from oracle.jv import jv_oracle, jv_oracle_wide
     from tools import instances
     t = time.perf_counter()
     sc, st = instances.single_cell_expression(G, sets * chunk, sets * chunk, seed=5)
@@ -258,15 +268,19 @@ def extra_c5_chunks(dev, K=50, G=500, chunk=10000, sets=8, cpu_n=10000, cpu_thre
     with ThreadPoolExecutor(T) as ex:
         ora = list(ex.map(lambda k: jv_oracle(costs[k % distinct], np.float32), range(T)))
     cpu_wall = time.perf_counter() - t
-    gp = [lap_solve(costs[k], np.float32, device_id=dev, return_info=True, opts=dict(mode=1)) for k in range(distinct)]   # the chain solver, as in the batch
-    if not all(np.array_equal(gp[k]["colsol"], ora[k]["colsol"]) and np.array_equal(gp[k]["v"], ora[k]["v"]) for k in range(min(distinct, T))):
+    gp = [lap_solve(costs[k], np.float32, device_id=dev, return_info=True, opts=dict(mode=1)) for k in range(distinct)]   # the chain solver
+    gw = [lap_solve(costs[k], np.float32, device_id=dev, return_info=True) for k in range(distinct)]                      # the wide solver (the batch's)
+    oraw = [jv_oracle_wide(costs[k], np.float32) for k in range(distinct)]
+    if not all(np.array_equal(gp[k]["colsol"], ora[k]["colsol"]) and np.array_equal(gp[k]["v"], ora[k]["v"])
+               and np.array_equal(gw[k]["colsol"], oraw[k]["colsol"]) and np.array_equal(gw[k]["v"], oraw[k]["v"])
+               and abs(oraw[k]["total"] - ora[k]["total"]) <= 1e-5 * max(1.0, abs(ora[k]["total"])) for k in range(min(distinct, T))):
         raise SystemExit("c5_chunks: HIP result differs from the CPU oracle on the CPU sample")
     i0 = res[0][2]
     return {"workload": f"{K} single-cell-mode chunks ({chunk} cells x {chunk} single-cell spots, {G}-gene panel; configs[4] = 50 such chunks) "
                         "through one batched context call on one GPU: per-chunk gather + MFMA cost build, then every LAP together",
             "chunks": K, "wall_s": round(wall, 2), "assignments_per_s": round(K * chunk / wall, 1),
             "context_s": round(t1 - t0, 2), "cost_build_ms_total": round(sum(r[2].ms_standardize + r[2].ms_gemm for r in res), 1),
-            "chunk0": {"lap_batch_kernel_ms": round(i0.lap.ms_total, 1), "jv_chain2_ms": round(i0.lap.ms_arr, 1),
+            "chunk0": {"lap_batch_kernel_ms": round(i0.lap.ms_total, 1), "row_reduction_ms": round(i0.lap.ms_arr, 1), "wide_solver": bool(i0.lap.wide),
                        "augmentation_ms": round(i0.lap.ms_aug, 1), "row_scans": int(i0.lap.row_scans),
                        "aug_scans": int(i0.lap.scans_aug_relax), "searches": int(i0.lap.augmentations)},
             "cpu_baseline": {"value": round(T * cpu_n / cpu_wall, 1), "unit": "assignments/s", "cores": T, "kind": "port",
@@ -457,7 +471,7 @@ def main():
     c2_batch = None
     if world == 1 and not args.no_extras:
         c2_batch, r0 = extra_c2_batch(dev, buf, n)
-        if not np.array_equal(r0["colsol"], colsol):      # (chain solver in the batch, wide solver alone: the same optimum)
+        if not (np.array_equal(r0["colsol"], colsol) and np.array_equal(r0["v"], res["v"])):
             raise SystemExit("c2_batch: the batched solve differs from the single solve")
     buf.free()
 

@@ -130,12 +130,14 @@ def lib():
         L.cyto_memcpy_d2d.restype = ctypes.c_int
         L.cyto_assign_pearson.argtypes = [i32, i32, i32, vp, vp, vp, i32, vp, dp, ctypes.POINTER(AssignInfo), i32]
         L.cyto_lap_batch_f32.argtypes = [i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32]
+        L.cyto_lap_batch_f32_opts.argtypes = [i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, ctypes.POINTER(LapOpts)]
+        L.cyto_lap_batch_f32_opts.restype = ctypes.c_int
         L.cyto_comm_unique_id.argtypes = [ctypes.c_char_p]
         L.cyto_comm_init.argtypes = [ctypes.c_char_p, i32, i32, i32, ctypes.POINTER(vp)]
         L.cyto_comm_bcast_f32.argtypes = [vp, vp, ctypes.c_size_t, i32, i32, vp]
         L.cyto_comm_destroy.argtypes = [vp]
         for name in ("cyto_normalize_data", "cyto_standardize", "cyto_cost_pearson", "cyto_assign_pearson",
-                     "cyto_lap_batch_f32", "cyto_comm_unique_id", "cyto_comm_init", "cyto_comm_bcast_f32",
+                     "cyto_lap_batch_f32", "cyto_lap_batch_f32_opts", "cyto_comm_unique_id", "cyto_comm_init", "cyto_comm_bcast_f32",
                      "cyto_comm_destroy"):
             getattr(L, name).restype = ctypes.c_int
         for name in ("cyto_device_count", "cyto_device_name", "cyto_malloc", "cyto_free", "cyto_memcpy_h2d",

@@ -16,7 +16,8 @@ namespace cyto {
 // cyto_lap_batch_f32 with optional row maps (rowmap[b] != NULL: cost[b] holds nu[b] distinct rows, see cyto_lap_f32_rowmap)
 int lap_batch_any(int nb, const int *n, const float *const *cost, const int64_t *ld, int cost_on_device,
                   const int32_t *const *rowmap, const int *nu, int32_t *const *rowsol, int32_t *const *colsol, float *const *u,
-                  float *const *v, double *total, cyto_lap_info *info, int *status_out, int max_concurrent, int device_id) {
+                  float *const *v, double *total, cyto_lap_info *info, int *status_out, int max_concurrent, int device_id,
+                  const cyto_lap_opts *opts) {
     if (nb < 0 || (nb > 0 && (!n || !cost || !ld))) return CYTO_ERR_BAD_ARG;
     if (nb == 0) return CYTO_OK;
     int rc = select_device(device_id);
@@ -51,7 +52,7 @@ int lap_batch_any(int nb, const int *n, const float *const *cost, const int64_t 
                 if (rowmap && rowmap[b]) { rm[(size_t)k] = rowmap[b]; nus[(size_t)k] = nu ? nu[b] : 0; }
             }
             const int brc = lap_batch_same_n(kv.first, cnt, c.data(), l.data(), cost_on_device, rs.data(), cs.data(), uu.data(), vv.data(),
-                                             tot.data(), inf.data(), stat.data(), device_id, guard.s, rm.data(), nus.data());
+                                             tot.data(), inf.data(), stat.data(), device_id, guard.s, rm.data(), nus.data(), opts);
             for (int k = 0; k < cnt; k++) {
                 const int b = ids[lo + (size_t)k];
                 st[(size_t)b] = brc ? brc : stat[(size_t)k];
@@ -95,6 +96,14 @@ int cyto_lap_batch_f32(int nb, const int *n, const float *const *cost, const int
                        cyto_lap_info *info, int *status_out, int max_concurrent, int device_id) {
     return cyto::lap_batch_any(nb, n, cost, ld, cost_on_device, nullptr, nullptr, rowsol, colsol, u, v, total, info, status_out,
                                max_concurrent, device_id);
+}
+
+// The same with kernel-selection options (NULL = the defaults): cyto_lap_opts.mode picks the solver for the whole batch.
+int cyto_lap_batch_f32_opts(int nb, const int *n, const float *const *cost, const int64_t *ld, int cost_on_device,
+                            int32_t *const *rowsol, int32_t *const *colsol, float *const *u, float *const *v, double *total,
+                            cyto_lap_info *info, int *status_out, int max_concurrent, int device_id, const cyto_lap_opts *opts) {
+    return cyto::lap_batch_any(nb, n, cost, ld, cost_on_device, nullptr, nullptr, rowsol, colsol, u, v, total, info, status_out,
+                               max_concurrent, device_id, opts);
 }
 
 // ---- RCCL (xGMI): the only collective on the path is the broadcast of the shared standardised ST

@@ -76,11 +76,13 @@ int select_device(int device_id);
 // lap_jv.hip: float32 problems of ONE size solved as a batch (one launch per chain phase, a workgroup per problem)
 int lap_batch_same_n(int n, int nb, const float *const *cost, const int64_t *ld, int cost_on_device, int32_t *const *rowsol,
                      int32_t *const *colsol, float *const *u, float *const *v, double *total, cyto_lap_info *info, int *status,
-                     int device_id, hipStream_t stream, const int32_t *const *rowmap = nullptr, const int *nu = nullptr);
+                     int device_id, hipStream_t stream, const int32_t *const *rowmap = nullptr, const int *nu = nullptr,
+                     const cyto_lap_opts *opts = nullptr);
 // batch.hip: cyto_lap_batch_f32 with optional row maps
 int lap_batch_any(int nb, const int *n, const float *const *cost, const int64_t *ld, int cost_on_device,
                   const int32_t *const *rowmap, const int *nu, int32_t *const *rowsol, int32_t *const *colsol, float *const *u,
-                  float *const *v, double *total, cyto_lap_info *info, int *status_out, int max_concurrent, int device_id);
+                  float *const *v, double *total, cyto_lap_info *info, int *status_out, int max_concurrent, int device_id,
+                  const cyto_lap_opts *opts = nullptr);
 // batch.hip: one int32 from `root` to every rank of the communicator (status agreement before the operand broadcast)
 int comm_bcast_status(void *comm, int *status, int root, int device_id);
 }  // namespace cyto

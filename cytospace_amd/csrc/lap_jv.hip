@@ -3076,11 +3076,11 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
     const int per2 = 4 * BLOCK2;
     // which chain variant: by size, or the large-n variants forced at a small n (opts.chain_variant; the test-suite
     // runs them on instances the CPU oracle solves in a second)
-    // which solver: the wide one (lap_wide.hip) for a single problem unless the caller selected chain kernels explicitly; a batch
-    // runs its problems side by side, a workgroup each, through the chain kernels
+    // which solver: the wide one (lap_wide.hip) unless the caller selected the chain solver or one of its kernels explicitly.
+    // A batch runs its problems side by side, a workgroup each, through either
     const bool chain_opts = opts.chain_variant || opts.augmentation || opts.no_handover || opts.inject_exceptions ||
                             opts.group_state_global || opts.aux_state_global;
-    pl.wide = opts.mode == 2 || (opts.mode == 0 && nb == 1 && !chain_opts);
+    pl.wide = opts.mode == 2 || (opts.mode == 0 && !chain_opts);
     pl.wide_rounds = opts.wide_rounds < 0 ? 0 : (opts.wide_rounds > 0 ? opts.wide_rounds : 4096 + (long long)n / 4);
     pl.force_l2 = opts.chain_variant != 0;
     pl.no_cs_lds = opts.chain_variant == 3;            // (3: as 2, with colsol in global memory too -- what n > 65 535 uses)
@@ -3474,7 +3474,7 @@ static int lap_solve_f32(int n, const float *cost, int64_t ld, int cost_on_devic
 // C ABI helper of cyto_lap_batch_f32 (batch.hip): problems of equal size go through the chains together
 int lap_batch_same_n(int n, int nb, const float *const *cost, const int64_t *ld, int cost_on_device, int32_t *const *rowsol,
                      int32_t *const *colsol, float *const *u, float *const *v, double *total, cyto_lap_info *info, int *status,
-                     int device_id, hipStream_t stream, const int32_t *const *rowmap, const int *nu) {
+                     int device_id, hipStream_t stream, const int32_t *const *rowmap, const int *nu, const cyto_lap_opts *opts) {
     std::vector<F32Job> jobs((size_t)nb);
     for (int b = 0; b < nb; b++) {
         F32Job &j = jobs[(size_t)b];
@@ -3484,11 +3484,7 @@ int lap_batch_same_n(int n, int nb, const float *const *cost, const int64_t *ld,
         j.u = u ? u[b] : nullptr; j.v = v ? v[b] : nullptr;
         j.total = total ? &total[b] : nullptr; j.info = info ? &info[b] : nullptr;
     }
-    // the batch entry points (cyto_lap_batch_f32, cyto_ctx_assign_chunks: CytoSPACE's chunked modes) run the chain solver, one
-    // workgroup per problem, whatever the number of problems in this group
-    cyto_lap_opts chain = k_default_opts;
-    chain.mode = 1;
-    const int rc = lap_solve_f32_batch(n, jobs, device_id, stream, chain);
+    const int rc = lap_solve_f32_batch(n, jobs, device_id, stream, opts ? *opts : k_default_opts);
     for (int b = 0; b < nb; b++) status[b] = rc ? rc : jobs[(size_t)b].status;
     return rc;
 }

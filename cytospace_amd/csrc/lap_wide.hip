@@ -61,6 +61,21 @@ __device__ __forceinline__ float uni(float x) { return __uint_as_float((uint32_t
 __device__ __forceinline__ unsigned long long uni(unsigned long long x) {
     return ((unsigned long long)uni((uint32_t)(x >> 32)) << 32) | uni((uint32_t)x);
 }
+// One full cost row by one wave: 16 bytes per lane and step, four steps' loads in flight (rows are 16-byte aligned and their
+// pitch is a multiple of four elements: lap_jv.hip stages anything else).  f(column, cost) for every column < n.
+template <typename F> __device__ __forceinline__ void wave_row_sweep(const float *__restrict__ row, int n, int lane, F &&f) {
+    const int nq = (n + 3) >> 2;
+    const float4 *__restrict__ r4 = reinterpret_cast<const float4 *>(row);
+#pragma unroll 4
+    for (int q = lane; q < nq; q += 64) {
+        const float4 x = r4[q];
+        const int c = q * 4;
+        f(c, x.x);
+        if (c + 1 < n) f(c + 1, x.y);
+        if (c + 2 < n) f(c + 2, x.z);
+        if (c + 3 < n) f(c + 3, x.w);
+    }
+}
 // value of lane l (wave-uniform l) without the LDS round trip of __shfl
 __device__ __forceinline__ uint32_t rdlane(uint32_t x, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, l); }
 __device__ __forceinline__ float rdlane(float x, int l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), l)); }
@@ -94,8 +109,7 @@ __global__ __launch_bounds__(RTB) void wide_rt(const WideArgs *__restrict__ batc
         if (!(mk != 0xFFFFFFFFu && ord2f(mk) <= tau)) {       // the cache cannot certify the margin: the whole row
             const float *__restrict__ row = a.cost + wrow_off(a.rowmap, i, a.ld);
             uint32_t k2 = 0xFFFFFFFFu;
-            for (int c = lane; c < n; c += 64)
-                if (c != j1) k2 = umin32(k2, f2ord(row[c] - v0[c]));
+            wave_row_sweep(row, n, lane, [&](int c, float x) { if (c != j1) k2 = umin32(k2, f2ord(x - v0[c])); });
             mk = wave_min_u32(k2);
         }
         if (lane == 0) a.v[j1] = v0[j1] - ord2f(mk);
@@ -161,7 +175,7 @@ template <bool VLDS> struct ArrCtx {
         const int n = a.n;
         const float *__restrict__ row = a.cost + wrow_off(a.rowmap, i, a.ld);
         K2 d; d.m1 = KEYMAX; d.m2 = KEYMAX;
-        for (int c = lane; c < n; c += 64) k2_push(d, mkkey(row[c] - getv(c), (uint32_t)c));
+        wave_row_sweep(row, n, lane, [&](int c, float x) { k2_push(d, mkkey(x - getv(c), (uint32_t)c)); });
         d = k2_wave_allreduce(d);
         u1 = key_val(d.m1); j1 = (int)(uint32_t)d.m1; c1 = uni(row[j1]); vj1 = uni(getv(j1));
         u2 = INFINITY; j2 = -1; c2 = 0.0f; vj2 = 0.0f;
@@ -608,12 +622,12 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     const float h = (ca[q] - vp[q]) - ord2f(dord);
                     const uint32_t lo = dord + 1u;
                     const float *__restrict__ row = a.cost + wrow_off(a.rowmap, oi[q], a.ld);
-                    for (int c = lane; c < n; c += 64) {
-                        if (c == pj[q]) continue;
-                        uint32_t cc = f2ord((row[c] - getv(c)) - h);
+                    const int pjq = pj[q], oiq = oi[q];
+                    wave_row_sweep(row, n, lane, [&](int c, float x) {
+                        uint32_t cc = f2ord((x - getv(c)) - h);
                         cc = cc < lo ? lo : cc;
-                        if (cc <= (uint32_t)(s.T >> 32)) relax_to(c, cc, oi[q]);
-                    }
+                        if (c != pjq && cc <= (uint32_t)(s.T >> 32)) relax_to(c, cc, oiq);
+                    });
                     c_dense++;
                 }
                 __syncthreads();

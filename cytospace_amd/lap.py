@@ -116,10 +116,11 @@ def lapjv_hip(cost, verbose=0, force_doubles=False):
     return r["rowsol"], r["colsol"], (r["total"], r["u"], r["v"])
 
 
-def lap_solve_batch(costs, device_id=0, max_concurrent=0, return_info=False):
-    """Solve several independent square LAPs concurrently on one GPU (C ABI: cyto_lap_batch_f32).
+def lap_solve_batch(costs, device_id=0, max_concurrent=0, return_info=False, opts=None):
+    """Solve several independent square LAPs concurrently on one GPU (C ABI: cyto_lap_batch_f32[_opts]).
 
-    costs: list of 2-D float arrays (host).  Returns a list of dicts like lap_solve()."""
+    costs: list of 2-D float arrays (host).  opts: None or a dict of cyto_lap_opts fields for the whole batch.
+    Returns a list of dicts like lap_solve()."""
     L = _lib.lib()
     nb = len(costs)
     if nb == 0:
@@ -140,8 +141,9 @@ def lap_solve_batch(costs, device_id=0, max_concurrent=0, return_info=False):
     totals = (ctypes.c_double * nb)()
     infos = (_lib.LapInfo * nb)()
     status = (ctypes.c_int * nb)()
-    st = L.cyto_lap_batch_f32(nb, ns, cptr, lds, 0, ptrs("rowsol"), ptrs("colsol"), ptrs("u"), ptrs("v"), totals, infos,
-                              status, max_concurrent, device_id)
+    o = _lib.LapOpts(**opts) if opts else None
+    st = L.cyto_lap_batch_f32_opts(nb, ns, cptr, lds, 0, ptrs("rowsol"), ptrs("colsol"), ptrs("u"), ptrs("v"), totals, infos,
+                                   status, max_concurrent, device_id, ctypes.byref(o) if o is not None else None)
     _lib.check(st)
     for b, o in enumerate(outs):
         o["total"] = totals[b]
@@ -150,7 +152,7 @@ def lap_solve_batch(costs, device_id=0, max_concurrent=0, return_info=False):
     return outs
 
 
-def lap_solve_batch_device(device_ptrs, ns, lds=None, device_id=0, max_concurrent=0, return_info=False):
+def lap_solve_batch_device(device_ptrs, ns, lds=None, device_id=0, max_concurrent=0, return_info=False, opts=None):
     """lap_solve_batch for cost matrices that are already resident in HBM (row-major float32, ld elements per row)."""
     L = _lib.lib()
     nb = len(device_ptrs)
@@ -169,8 +171,9 @@ def lap_solve_batch_device(device_ptrs, ns, lds=None, device_id=0, max_concurren
     totals = (ctypes.c_double * nb)()
     infos = (_lib.LapInfo * nb)()
     status = (ctypes.c_int * nb)()
-    st = L.cyto_lap_batch_f32(nb, n_arr, cptr, ld_arr, 1, ptrs("rowsol"), ptrs("colsol"), ptrs("u"), ptrs("v"), totals, infos,
-                              status, max_concurrent, device_id)
+    o = _lib.LapOpts(**opts) if opts else None
+    st = L.cyto_lap_batch_f32_opts(nb, n_arr, cptr, ld_arr, 1, ptrs("rowsol"), ptrs("colsol"), ptrs("u"), ptrs("v"), totals, infos,
+                                   status, max_concurrent, device_id, ctypes.byref(o) if o is not None else None)
     _lib.check(st)
     for b, o in enumerate(outs):
         o["total"] = totals[b]

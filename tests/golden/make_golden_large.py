@@ -1,6 +1,8 @@
 """Goldens for the LARGE LAP instances (BASELINE configs c2/c3/c4 at true size), made in the build container.
 
-Run:  python tests/golden/make_golden_large.py [tag ...]      (tags: u20000 u24000 u30000 u33000 u50000 c3s50000 c4s10000)
+Run:  python tests/golden/make_golden_large.py [tag ...]      (tags: u20000 u24000 u30000 u33000 u50000 u70000 c3s50000 c4s10000)
+      python tests/golden/make_golden_large.py --wide [tag ...]   the same instances through the oracle's WIDE mode -> large_<tag>_wide.npz
+      python tests/golden/make_golden_large.py --f64 [tag ...]    float64 solves (uniform tags only) -> large_<tag>_f64.npz
 
 For every instance (generators: tools/instances.py, reproducible bit for bit on any machine) this stores what the
 CPU JV oracle (oracle/jv_oracle.c, float32) returns -- colsol (int32), the float64 re-summed total, sha256 of u and v,
@@ -28,7 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from scipy.optimize import linear_sum_assignment  # noqa: E402
 
-from oracle.jv import jv_oracle  # noqa: E402
+from oracle.jv import jv_oracle, jv_oracle_wide  # noqa: E402
 from tools import instances  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
@@ -116,7 +118,7 @@ def make(tag):
         raise SystemExit(f"[{tag}] the oracle's duals do not certify its assignment: not a golden")
     key = (lambda x: x) if loc is None else (lambda x: loc[x])
     t = time.time()
-    sp = scipy_colsol(cost, SCIPY_LIMIT_S)
+    sp = scipy_colsol(cost, SCIPY_LIMIT_S) if n <= 50000 else None       # (beyond that its float64 copy alone is 39 GB)
     t_sp = time.time() - t
     if sp is None:
         print(f"[{tag}] scipy did not finish within {SCIPY_LIMIT_S}s (not checked)", flush=True)
@@ -140,6 +142,86 @@ def make(tag):
     print(f"[{tag}] written ({os.path.getsize(os.path.join(OUT, f'large_{tag}.npz')) / 1e3:.0f} kB), {time.time() - t0:.0f}s", flush=True)
 
 
+def instance(tag):
+    if tag.startswith("u"):
+        n = int(tag[1:])
+        return n, instances.uniform_cost(n), None
+    if tag.startswith("c3s"):
+        n = int(tag[3:])
+        return (n,) + instances.c3_shaped_cost(n)
+    if tag.startswith("c4s"):
+        n = int(tag[3:])
+        return (n,) + instances.c4_chunk_cost(n)
+    raise SystemExit(f"unknown tag {tag}")
+
+
+def make_wide(tag):
+    """The wide-mode restatement (oracle/jv_oracle_impl.h, WIDE MODE) on the same instance: what the HIP wide solver must return
+    bit for bit (rowsol / u / v by sha256, its counters).  Certified by its own duals and, where large_<tag>.npz exists, by giving
+    the classic mode's indices (spot level where spot rows are duplicated)."""
+    t0 = time.time()
+    n, cost, loc = instance(tag)
+    t = time.time()
+    o = jv_oracle_wide(cost, np.float32)
+    t_or = time.time() - t
+    colsol = o["colsol"]
+    total = float(cost[colsol, np.arange(n)].astype(np.float64).sum())
+    print(f"[{tag} wide] oracle {t_or:.1f}s total={total:.9f} stats={o['stats'].as_dict()}", flush=True)
+    mn, tight, gap = dual_certificate(cost, o)
+    cert = bool(mn >= -1e-6 and tight <= 1e-6 and abs(gap) <= 1e-6 * n)
+    print(f"[{tag} wide] dual certificate: min reduced cost {mn:.3e}, max |reduced| on the assignment {tight:.3e}, gap {gap:.3e} -> {cert}", flush=True)
+    if not cert:
+        raise SystemExit(f"[{tag} wide] the duals do not certify the assignment: not a golden")
+    same = None
+    cpath = os.path.join(OUT, f"large_{tag}.npz")
+    if os.path.exists(cpath):
+        d = np.load(cpath)
+        key = (lambda x: x) if loc is None else (lambda x: loc[x])
+        same = bool(np.array_equal(key(colsol), key(d["colsol"])))
+        print(f"[{tag} wide] same {'slot' if loc is None else 'spot'}-level answer as the classic golden: {same}", flush=True)
+        if not same or abs(total - float(d["total"])) > 1e-5 * max(1.0, abs(total)):
+            raise SystemExit(f"[{tag} wide] wide and classic mode disagree: not a golden")
+    st = o["stats"].as_dict()
+    np.savez_compressed(
+        os.path.join(OUT, f"large_{tag}_wide.npz"), n=n, colsol=colsol.astype(np.int32), total=total, cost_sha256=sha(cost),
+        u_sha256=sha(o["u"]), v_sha256=sha(o["v"]), rowsol_sha256=sha(o["rowsol"]), spot_level=loc is not None,
+        oracle_seconds=t_or, same_as_classic=-1 if same is None else int(same), dual_certificate=np.array([mn, tight, gap]),
+        stats_keys=np.array(list(st.keys())), stats_vals=np.array(list(st.values()), np.int64))
+    print(f"[{tag} wide] written, {time.time() - t0:.0f}s", flush=True)
+
+
+def make_f64(tag):
+    """float64 solve (the force_doubles / lapjv_compat precision) of a uniform instance: the float32 matrix as float64."""
+    t0 = time.time()
+    n, cost, loc = instance(tag)
+    c64 = cost.astype(np.float64)
+    t = time.time()
+    o = jv_oracle(c64, np.float64)
+    t_or = time.time() - t
+    colsol = o["colsol"]
+    total = float(c64[colsol, np.arange(n)].sum())
+    print(f"[{tag} f64] oracle {t_or:.1f}s total={total:.12f} scans={o['stats'].as_dict()}", flush=True)
+    mn, tight, gap = dual_certificate(c64, o)
+    cert = bool(mn >= -1e-12 and tight <= 1e-12 and abs(gap) <= 1e-12 * n)
+    print(f"[{tag} f64] dual certificate: {mn:.3e} {tight:.3e} {gap:.3e} -> {cert}", flush=True)
+    if not cert:
+        raise SystemExit(f"[{tag} f64] not certified")
+    st = o["stats"].as_dict()
+    np.savez_compressed(
+        os.path.join(OUT, f"large_{tag}_f64.npz"), n=n, colsol=colsol.astype(np.int32), total=total, cost_sha256=sha(cost),
+        u_sha256=sha(o["u"]), v_sha256=sha(o["v"]), rowsol_sha256=sha(o["rowsol"]), oracle_seconds=t_or,
+        dual_certificate=np.array([mn, tight, gap]), stats_keys=np.array(list(st.keys())), stats_vals=np.array(list(st.values()), np.int64))
+    print(f"[{tag} f64] written, {time.time() - t0:.0f}s", flush=True)
+
+
 if __name__ == "__main__":
-    for tg in (sys.argv[1:] or ["c3s50000", "c4s10000", "u20000", "u33000", "u50000"]):
-        make(tg)
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if "--wide" in sys.argv:
+        for tg in (args or ["u20000", "u50000", "c3s50000", "c4s10000"]):
+            make_wide(tg)
+    elif "--f64" in sys.argv:
+        for tg in (args or ["u17000"]):
+            make_f64(tg)
+    else:
+        for tg in (args or ["c3s50000", "c4s10000", "u20000", "u33000", "u50000"]):
+            make(tg)

@@ -152,13 +152,19 @@ def test_batch_of_independent_laps():
     from cytospace_amd.lap import lap_solve_batch
     sizes = [5, 300, 1200, 64, 2100, 700, 33]
     costs = [np.random.default_rng(100 + n).random((n, n)).astype(np.float32) for n in sizes]
-    res = lap_solve_batch(costs, max_concurrent=4, return_info=True)
-    assert len(res) == len(sizes)
-    for c, r in zip(costs, res):
-        o = jv_oracle(c, np.float32)
-        assert np.array_equal(r["colsol"], o["colsol"]) and np.array_equal(r["rowsol"], o["rowsol"])
-        assert np.array_equal(r["u"], o["u"]) and np.array_equal(r["v"], o["v"])
-        assert r["info"].row_scans == o["stats"].row_scans
+    # a batch runs a workgroup per problem through one solver: the wide one by default, the chain solver on request
+    for opts, oracle in ((None, jv_oracle_wide), (CHAIN, jv_oracle)):
+        res = lap_solve_batch(costs, max_concurrent=4, return_info=True, opts=opts)
+        assert len(res) == len(sizes)
+        for c, r in zip(costs, res):
+            o = oracle(c, np.float32)
+            assert np.array_equal(r["colsol"], o["colsol"]) and np.array_equal(r["rowsol"], o["rowsol"])
+            assert np.array_equal(r["u"], o["u"]) and np.array_equal(r["v"], o["v"])
+            assert r["info"].wide == (0 if opts else 1)
+            if opts:
+                assert r["info"].row_scans == o["stats"].row_scans
+            else:
+                assert r["info"].scans_arr == o["stats"].scans_arr and r["info"].scans_aug_relax == o["stats"].scans_aug_relax
     bad = [costs[0], np.full((4, 4), np.nan, np.float32)]
     with pytest.raises(ValueError):
         lap_solve_batch(bad)
