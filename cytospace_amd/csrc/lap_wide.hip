@@ -64,16 +64,22 @@ __device__ __forceinline__ unsigned long long uni(unsigned long long x) {
 // One full cost row by one wave: 16 bytes per lane and step, four steps' loads in flight (rows are 16-byte aligned and their
 // pitch is a multiple of four elements: lap_jv.hip stages anything else).  f(column, cost) for every column < n.
 template <typename F> __device__ __forceinline__ void wave_row_sweep(const float *__restrict__ row, int n, int lane, F &&f) {
+    constexpr int U = 8;                                   // 8 KB of the row in flight per wave (12 measured slower: registers): a lone load per step is latency-bound
     const int nq = (n + 3) >> 2;
     const float4 *__restrict__ r4 = reinterpret_cast<const float4 *>(row);
-#pragma unroll 4
-    for (int q = lane; q < nq; q += 64) {
-        const float4 x = r4[q];
-        const int c = q * 4;
-        f(c, x.x);
-        if (c + 1 < n) f(c + 1, x.y);
-        if (c + 2 < n) f(c + 2, x.z);
-        if (c + 3 < n) f(c + 3, x.w);
+    for (int q0 = lane; q0 < nq; q0 += 64 * U) {
+        float4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int q = q0 + 64 * u; x[u] = q < nq ? r4[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int q = q0 + 64 * u, c = q * 4;
+            if (q >= nq) continue;
+            f(c, x[u].x);
+            if (c + 1 < n) f(c + 1, x[u].y);
+            if (c + 2 < n) f(c + 2, x[u].z);
+            if (c + 3 < n) f(c + 3, x[u].w);
+        }
     }
 }
 // value of lane l (wave-uniform l) without the LDS round trip of __shfl
@@ -144,14 +150,17 @@ struct ArrShared {
     int sm_j[ASL], sm_i[ASL];
     float sm_p[ASL];
     int deal[ASL];
+    int rf_cnt[WNW];                    // cache refresh (a wave rebuilds the cache of the row it just read in full): staging
+    uint32_t rf_col[WNW][KC];
+    float rf_val[WNW][KC];
 };
 
+constexpr size_t ARR_SHARED_BYTES = (sizeof(ArrShared) + 15) / 16 * 16;     // (in the dynamic region: a kernel's static LDS is limited to 2 KB here)
 size_t wide_arr_lds_bytes(int n, bool vlds) {
-    if (!vlds) return 16;
     const size_t npad = ((size_t)n + 3) & ~(size_t)3;
-    return ((npad * 6 + 15) / 16) * 16;
+    return ARR_SHARED_BYTES + (vlds ? ((npad * 6 + 15) / 16) * 16 : 0);
 }
-bool wide_arr_vlds(int n) { return n <= 65534 && wide_arr_lds_bytes(n, true) + 4096 <= (size_t)LDS_DYNAMIC_MAX; }
+bool wide_arr_vlds(int n) { return n <= 65534 && wide_arr_lds_bytes(n, true) + 1024 <= (size_t)LDS_DYNAMIC_MAX; }
 
 template <bool VLDS> struct ArrCtx {
     WideArgs a;
@@ -168,23 +177,73 @@ template <bool VLDS> struct ArrCtx {
         a.v[jt] = pt; a.colsol[jt] = i; a.rowsol[i] = jt; a.cassign[jt] = ct;
         if (i0 >= 0) a.rowsol[i0] = -1;
     }
-    // exact lexicographic top-2 of the whole row (the cache could not certify).  (Inlined on purpose: as an out-of-line call its
-    // eight results travel through scratch memory, and every bid -- also the certified ones -- then stores and reloads them
-    // through the vector memory path, waiting for the prefetched cache rows each time.)
-    __device__ __forceinline__ void top2_full(int i, float &u1, int &j1, float &c1, float &vj1, float &u2, int &j2, float &c2, float &vj2) const {
+    // exact lexicographic top-2 of the whole row (the cache could not certify) -- and a fresh cache for the row against the
+    // current prices, so that its next bids are certified again (in a price war the same few rows bid thousands of times).
+    // The new floor is one of the 64 per-lane minima of the sweep (sorted; the 48th, else the 32nd, 16th ... smallest): every
+    // column below it is collected in a second sweep of the now L2-resident row; more than 63 of them -> the next candidate.
+    // (Inlined on purpose: as an out-of-line call its results travel through scratch memory, and every bid -- also the
+    // certified ones -- then stores and reloads them through the vector memory path.)
+    __device__ __forceinline__ void top2_full(int i, int w, uint32_t &col, float &val, float &u1, int &j1, float &c1, float &vj1,
+                                              float &u2, int &j2, float &c2, float &vj2) const {
         const int n = a.n;
         const float *__restrict__ row = a.cost + wrow_off(a.rowmap, i, a.ld);
         K2 d; d.m1 = KEYMAX; d.m2 = KEYMAX;
         wave_row_sweep(row, n, lane, [&](int c, float x) { k2_push(d, mkkey(x - getv(c), (uint32_t)c)); });
+        uint32_t lm = (uint32_t)(d.m1 >> 32);                     // this lane's smallest reduced cost (ordered)
         d = k2_wave_allreduce(d);
         u1 = key_val(d.m1); j1 = (int)(uint32_t)d.m1; c1 = uni(row[j1]); vj1 = uni(getv(j1));
         u2 = INFINITY; j2 = -1; c2 = 0.0f; vj2 = 0.0f;
         if (d.m2 != KEYMAX) { u2 = key_val(d.m2); j2 = (int)(uint32_t)d.m2; c2 = uni(row[j2]); vj2 = uni(getv(j2)); }
         if (lane == 0) atomicAdd(&s->dense, 1);
+        // ---- the row's new cache ----
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {                       // bitonic sort of the 64 lane minima, ascending over the lanes
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)lm, j);
+                const bool take_min = ((lane & j) == 0) == ((lane & k) == 0);
+                lm = take_min ? umin32(lm, o) : (lm > o ? lm : o);
+            }
+        }
+        uint32_t tk = 0;                                           // ordered floor; 0 = none found
+        int cnt = 0;
+        for (int pos = 47; pos >= 2 && !tk; pos = (pos + 1) / 2 - 1) {
+            const uint32_t cand = rdlane(lm, pos);
+            if (cand == 0xFFFFFFFFu) continue;
+            if (lane == 0) s->rf_cnt[w] = 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wave_row_sweep(row, n, lane, [&](int c, float x) {
+                if (f2ord(x - getv(c)) < cand) {
+                    const int p = atomicAdd(&s->rf_cnt[w], 1);
+                    if (p < KCU) { s->rf_col[w][p] = (uint32_t)c; s->rf_val[w][p] = x; }
+                }
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            cnt = uni(s->rf_cnt[w]);
+            if (cnt <= KCU) tk = cand;
+        }
+        const float tau = tk ? ord2f(tk) : -INFINITY;
+        uint32_t kc = (tk && lane < cnt) ? s->rf_col[w][lane] : COLSENT;
+        float kv = (tk && lane < cnt) ? s->rf_val[w][lane] : 0.0f;
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {                       // cache rows are kept sorted by column (unused slots last)
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const uint32_t pk = (uint32_t)__shfl_xor((int)kc, j);
+                const float pv = __shfl_xor(kv, j);
+                const bool take_min = ((lane & j) == 0) == ((lane & k) == 0);
+                const bool sw = take_min ? (pk < kc) : (pk > kc);
+                kc = sw ? pk : kc; kv = sw ? pv : kv;
+            }
+        }
+        if (lane == KCU) { kc = COLSENT; kv = tau; }               // (at most 63 entries: lane 63 held a sentinel)
+        a.cache_col[(int64_t)i * KC + lane] = kc;
+        a.cache_val[(int64_t)i * KC + lane] = kv;
+        col = kc; val = kv;
     }
     // the bid of row i (its cache row in col / val, lane = entry): target column jt (-1: the row retires), price, raw cost of
     // the entry, and the owner it would displace
-    __device__ __forceinline__ void bid_of(int i, uint32_t col, float val, int &jt, float &pt, float &ct, int &i0) const {
+    __device__ __forceinline__ void bid_of(int i, int w, uint32_t &col, float &val, int &jt, float &pt, float &ct, int &i0) const {
         // cache rows are sorted by column: among equal reduced costs the lowest lane is the lowest column, so the
         // lexicographic (value, column) top-2 is two 32-bit min reductions and two ballots
         const float tau = rdlane(val, KCU);
@@ -202,7 +261,7 @@ template <bool VLDS> struct ArrCtx {
             u1 = ord2f(k1); j1 = (int)rdlane(col, l1); c1 = rdlane(val, l1); vj1 = rdlane(vj, l1);
             u2 = ord2f(k2); j2 = (int)rdlane(col, l2); c2 = rdlane(val, l2); vj2 = rdlane(vj, l2);
         } else {
-            top2_full(i, u1, j1, c1, vj1, u2, j2, c2, vj2);
+            top2_full(i, w, col, val, u1, j1, c1, vj1, u2, j2, c2, vj2);
         }
         const float p = vj1 - (u2 - u1);
         jt = -1; pt = 0.0f; ct = 0.0f; i0 = -1;
@@ -217,12 +276,12 @@ template <bool VLDS> struct ArrCtx {
 template <bool VLDS>
 __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batch) {
     extern __shared__ __align__(16) unsigned char w_smem[];
-    __shared__ ArrShared s;
+    ArrShared &s = *reinterpret_cast<ArrShared *>(w_smem);
     ArrCtx<VLDS> cx;
     cx.a = load_wide_args(batch, blockIdx.x);
     const WideArgs &a = cx.a;
     const int n = a.n, tid = threadIdx.x, lane = tid & 63, w = uni((int)(threadIdx.x >> 6));
-    cx.s_v = reinterpret_cast<float *>(w_smem);
+    cx.s_v = reinterpret_cast<float *>(w_smem + ARR_SHARED_BYTES);
     cx.s_cs = reinterpret_cast<uint16_t *>(cx.s_v + ((n + 3) & ~3));
     cx.s = &s; cx.lane = lane;
     const long long t_kernel0 = wall_clock64();
@@ -266,7 +325,7 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
                 if (ri[q] < 0) continue;
                 const int slot = base + q * WNW + w;
                 int jt, i0; float pt, ct;
-                cx.bid_of(ri[q], col[q], val[q], jt, pt, ct, i0);
+                cx.bid_of(ri[q], w, col[q], val[q], jt, pt, ct, i0);
                 if (lane == 0) {
                     if (jt < 0) atomicAdd(&s.retired, 1);
                     else atomicMin(a.bid + jt, (unsigned long long)mkkey(pt, (uint32_t)ri[q]));
@@ -326,7 +385,7 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
             for (int q = 0; q < ACS; q++) {
                 jt[q] = -2; i0[q] = -1; pt[q] = 0.0f; ct[q] = 0.0f;
                 if (my[q] >= 0) {
-                    cx.bid_of(my[q], col[q], val[q], jt[q], pt[q], ct[q], i0[q]);
+                    cx.bid_of(my[q], w, col[q], val[q], jt[q], pt[q], ct[q], i0[q]);
                     if (i0[q] >= 0) { ncol[q] = a.cache_col[(int64_t)i0[q] * KC + lane]; nval[q] = a.cache_val[(int64_t)i0[q] * KC + lane]; }   // in flight across the barrier
                     if (jt[q] < 0 && lane == 0) atomicAdd(&s.retired, 1);
                 }
@@ -623,10 +682,13 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     const uint32_t lo = dord + 1u;
                     const float *__restrict__ row = a.cost + wrow_off(a.rowmap, oi[q], a.ld);
                     const int pjq = pj[q], oiq = oi[q];
+                    // (a full row offers hundreds of candidates below the best unassigned distance when many columns are near-equal:
+                    //  the label is read first -- a plain L2 load -- and the atomic follows only where it would change something)
                     wave_row_sweep(row, n, lane, [&](int c, float x) {
                         uint32_t cc = f2ord((x - getv(c)) - h);
                         cc = cc < lo ? lo : cc;
-                        if (c != pjq && cc <= (uint32_t)(s.T >> 32)) relax_to(c, cc, oiq);
+                        if (c != pjq && cc <= (uint32_t)(s.T >> 32) &&
+                            ((((unsigned long long)cc << 32) | (uint32_t)oiq) < ld_sc1(a.label + c))) relax_to(c, cc, oiq);
                     });
                     c_dense++;
                 }
@@ -682,7 +744,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             if (s.doroot)
                 for (int c = tid; c < n; c += WT) {
                     const uint32_t co = f2ord(frow[c] - getv(c));
-                    if (co <= (uint32_t)(s.T >> 32)) relax_to(c, co, fr);
+                    if (co <= (uint32_t)(s.T >> 32) && ((((unsigned long long)co << 32) | (uint32_t)fr) < ld_sc1(a.label + c))) relax_to(c, co, fr);
                 }
             __syncthreads();
             if (tid == 0) { if (fail) s.anydense = 1; s.fail = 0; s.doroot = 0; }
@@ -730,6 +792,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             atomicAnd(&dirty[k >> 5], ~(1u << (k & 31)));
             bmin[k >> 6] = ~0ull;
         }
+        // (keeping the dense bits across searches was measured: fewer rounds, but more full-row relaxations -- slower)
         if (s.anydense) for (int q = tid; q < nw32; q += WT) dense[q] = 0;
         __syncthreads();
         if (tid == 0) { c_relax += s.scans; s.scans = 0; s.T = ~0ull; s.ntouch = 0; s.anydense = 0; s.rootdense = 0; s.f = f + 1; }
