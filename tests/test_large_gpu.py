@@ -87,11 +87,26 @@ def _wide_vs_golden(tag, n, solve, loc=None):
     assert abs(g["total"] - float(d["total"])) <= 1e-5 * max(1.0, abs(float(d["total"])))
     u, v = g["u"].astype(np.float64), g["v"].astype(np.float64)
     assert abs(g["total"] - (u.sum() + v.sum())) <= 1e-5 * max(1.0, abs(g["total"]))
+    wpath = os.path.join(GOLD, f"large_{tag}_wide.npz")
+    if os.path.exists(wpath):
+        # the wide restatement's own answer for this instance (make_golden_large.py --wide): the slots, the duals and the semantic
+        # counters bit for bit -- although the kernel settles columns speculatively, in no fixed order
+        dw = np.load(wpath)
+        assert np.array_equal(colsol, dw["colsol"])
+        assert sha(rowsol) == str(dw["rowsol_sha256"]) and sha(g["u"]) == str(dw["u_sha256"]) and sha(g["v"]) == str(dw["v_sha256"])
+        want = dict(zip([str(k) for k in dw["stats_keys"]], dw["stats_vals"].tolist()))
+        got = g["info"].as_dict()
+        for kg, ko in (("scans_redtransfer", "scans_redtransfer"), ("scans_arr", "scans_arr"), ("scans_aug_relax", "scans_aug_relax"),
+                       ("augmentations", "augmentations"), ("path_hops", "path_hops"), ("free_after_arr2", "free_after_arr"),
+                       ("wide_rounds", "arr_rounds"), ("wide_retired", "arr_retired")):
+            assert got[kg] == want[ko], (kg, got[kg], want[ko])
     return g
 
 
-@pytest.mark.parametrize("n", [20000, 33000, 50000])
+@pytest.mark.parametrize("n", [20000, 33000, 50000, 70000])
 def test_wide_uniform_true_size(n):
+    if not os.path.exists(os.path.join(GOLD, f"large_u{n}.npz")):
+        pytest.skip(f"large_u{n}.npz not generated")
     buf = instances.blocks_to_device(instances.uniform_cost_blocks(n), n)
     try:
         g = _wide_vs_golden(f"u{n}", n, lambda: lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n))
@@ -116,6 +131,33 @@ def test_wide_c3_shaped_and_c4_chunk_true_size():
         _wide_vs_golden(f"c4s{n}", n, lambda: lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n), loc)
     finally:
         buf.free()
+
+
+def test_chain_uniform_70000_colsol_in_global_memory():
+    """n > 65 535: the chain kernels with colsol in global memory too (chain_variant 3's range) at a true size, 19.6 GB of cost."""
+    n = 70000
+    if not os.path.exists(os.path.join(GOLD, f"large_u{n}.npz")):
+        pytest.skip(f"large_u{n}.npz not generated")
+    buf = instances.blocks_to_device(instances.uniform_cost_blocks(n), n)
+    try:
+        _compare_with_golden(f"u{n}", buf, n)
+    finally:
+        buf.free()
+
+
+def test_float64_uniform_17000_prices_in_l2():
+    """float64 beyond ~15 800 columns: the streaming chain with the prices in L2 (not LDS) during row reduction, at a true size."""
+    n = 17000
+    d = _golden(f"u{n}_f64")
+    c = instances.uniform_cost(n).astype(np.float64)
+    g = lap_solve(c, np.float64, return_info=True)
+    assert np.array_equal(g["colsol"], d["colsol"])
+    assert sha(g["rowsol"]) == str(d["rowsol_sha256"]) and sha(g["u"]) == str(d["u_sha256"]) and sha(g["v"]) == str(d["v_sha256"])
+    assert abs(g["total"] - float(d["total"])) <= 1e-9 * max(1.0, abs(float(d["total"])))
+    want = dict(zip([str(k) for k in d["stats_keys"]], d["stats_vals"].tolist()))
+    got = g["info"].as_dict()
+    for k in STAT_KEYS:
+        assert got[k] == want[k], (k, got[k], want[k])
 
 
 def test_c3_shaped_lap_50000():
@@ -295,3 +337,64 @@ def test_fused_block_pipeline_equals_the_split_path(metric):
     g = lap_solve_rows(rows, loc)                                        # the same unique rows, built in one piece
     assert np.array_equal(loc[g["colsol"]], mapped)
     assert abs(g["total"] - total) <= 1e-5 * max(1.0, abs(total))
+
+
+# ---- configs[3] as configured: 200 000 cells -> 20 sub-spot chunks of 10 000 cells against 50 000 spots, ONE batched call ----
+
+def test_c4_all_20_chunks_in_one_call():
+    G, C, S, chunk = 2000, 200000, 50000, 10000
+    sc, st, slots = instances.synth_expression(G, C, S, seed=2)
+    rng = np.random.default_rng(0)
+    slot_ids = rng.permutation(np.repeat(np.arange(S), slots))          # which spot every cell's slot belongs to
+    nchunks = C // chunk
+    idx = [np.arange(k * chunk, (k + 1) * chunk) for k in range(nchunks)]
+    sub = [np.bincount(slot_ids[ix], minlength=S) for ix in idx]       # per-chunk slot counts (cytospace.py:436-439)
+    assert sum(s_.sum() for s_ in sub) == C and np.array_equal(sum(sub), slots)
+    with ExpressionContext(sc, st, already_normalized=False) as ctx:
+        res = ctx.assign_chunks([(idx[k], sub[k]) for k in range(nchunks)], max_concurrent=nchunks, return_info=True)
+    assert len(res) == nchunks
+    for k, (mapped, total, info) in enumerate(res):
+        assert np.array_equal(np.bincount(mapped, minlength=S), sub[k]), k       # every chunk fills exactly its sub-spot slots
+        assert info.lap.wide == 1
+    # all chunks together: every spot receives exactly its cells (apply_linear_assignment concatenates: cytospace.py:453-467)
+    assert np.array_equal(np.bincount(np.concatenate([m for m, _, _ in res]), minlength=S), slots)
+    # the optimum, on the float64 reference cost, for two of the chunks
+    scn_all = None
+    stn = ocost.normalize_data(st.astype(np.float64))
+    for k in (3, 17):
+        mapped, total, info = res[k]
+        scn = ocost.normalize_data(sc[:, idx[k]].astype(np.float64))
+        spots = np.flatnonzero(sub[k])
+        ref = -ocost.matrix_correlation_pearson(scn, stn[:, spots])
+        pos = np.searchsorted(spots, mapped)
+        mine = ref[pos, np.arange(chunk)].sum()
+        o = jv_oracle(ref[np.repeat(np.arange(len(spots)), sub[k][spots])].astype(np.float32), np.float32)
+        best = float(o["total"])
+        assert abs(mine - best) <= 1e-5 * max(1.0, abs(best)), (k, mine, best)
+        assert abs(total - best) <= 1e-5 * max(1.0, abs(best))
+    del scn_all
+
+
+# ---- configs[4]'s LAP work at scale: 500 000 cells = 50 single-cell-mode chunks of 10 000 cells x 10 000 spots, ONE batched call ----
+
+def test_c5_50_chunks_of_10000_in_one_call():
+    G, chunk, sets, K = 500, 10000, 8, 50
+    sc, st = instances.single_cell_expression(G, sets * chunk, sets * chunk, seed=5)
+    ones = np.ones(chunk, np.int64)
+    work = [(np.arange((k % sets) * chunk, (k % sets + 1) * chunk), ones,
+             np.arange(((k // sets) % sets) * chunk, ((k // sets) % sets + 1) * chunk)) for k in range(K)]
+    with ExpressionContext(sc, st, already_normalized=False) as ctx:
+        res = ctx.assign_chunks(work, max_concurrent=K, return_info=True)
+    assert len(res) == K
+    for k, (mapped, total, info) in enumerate(res):
+        assert np.array_equal(np.sort(mapped), np.arange(chunk)), k       # positions in the chunk's spot list: a permutation
+        assert info.lap.wide == 1 and info.lap.row_groups == chunk
+    scn = ocost.normalize_data(sc.astype(np.float64))
+    stn = ocost.normalize_data(st.astype(np.float64))
+    for k in (7, 42):
+        mapped, total, info = res[k]
+        ref = -ocost.matrix_correlation_pearson(scn[:, work[k][0]], stn[:, work[k][2]])     # chunk spots x chunk cells, float64
+        o = jv_oracle(ref.astype(np.float32), np.float32)
+        best = float(ref[o["colsol"], np.arange(chunk)].sum())
+        mine = float(ref[mapped, np.arange(chunk)].sum())
+        assert abs(mine - best) <= 1e-5 * max(1.0, abs(best)), (k, mine, best)

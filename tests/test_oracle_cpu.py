@@ -256,3 +256,20 @@ def test_wide_oracle_stop_phases_expose_the_intermediate_state():
     asg = np.flatnonzero(a["rowsol"] >= 0)
     h = c[asg] - a["v"][None, :]                       # every assigned row sits on a minimum of its reduced costs
     assert np.all(h[np.arange(len(asg)), a["rowsol"][asg]] <= h.min(1) + 1e-7)
+
+
+@pytest.mark.parametrize("tag", ["u20000", "u50000", "c3s50000", "c4s10000"])
+def test_wide_large_goldens_are_certified(tag):
+    # the wide restatement's answers at true size: certified by their own duals on ALL n^2 entries and equal (slot level; spot
+    # level where spot rows are duplicated) to the classic goldens, which scipy and the perturbation re-solve certify
+    path = os.path.join(G, f"large_{tag}_wide.npz")
+    assert os.path.exists(path), "run tests/golden/make_golden_large.py --wide"
+    d, c = np.load(path), np.load(os.path.join(G, f"large_{tag}.npz"))
+    n = int(d["n"])
+    assert np.array_equal(np.sort(d["colsol"]), np.arange(n)) and int(d["same_as_classic"]) == 1
+    assert str(d["cost_sha256"]) == str(c["cost_sha256"])
+    mn, tight, gap = d["dual_certificate"]
+    assert mn >= -1e-6 and tight <= 1e-6 and abs(gap) <= 1e-6 * n
+    if not bool(d["spot_level"]):
+        assert np.array_equal(d["colsol"], c["colsol"])
+    assert abs(float(d["total"]) - float(c["total"])) <= 1e-5 * max(1.0, abs(float(c["total"])))
