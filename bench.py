@@ -291,7 +291,7 @@ def extra_c5_chunks(dev, K=50, G=500, chunk=10000, sets=8, cpu_n=10000, cpu_thre
             "instance_seconds": round(t_gen, 1)}
 
 
-def extra_c4_sharded(dev, rank, world, dist, chunks_per_rank, G=5000, S=50000, chunk=10000, cell_sets=8):
+def extra_c4_sharded(dev, rank, world, dist, chunks_per_rank, G=5000, S=50000, chunk=10000, cell_sets=8, total_chunks=0):
     """BASELINE configs[3]'s structure on N GPUs (weak scaling: chunks_per_rank chunks of 10 000 cells per GPU against
     50 000 spots): rank 0 transforms the ST matrix and broadcasts the float32 operand over xGMI (RCCL; the one collective of
     the path), every rank uploads only its own cells as raw counts and solves its chunks in one batched call.
@@ -299,6 +299,12 @@ def extra_c4_sharded(dev, rank, world, dist, chunks_per_rank, G=5000, S=50000, c
     so 64 chunks need the expression of 80 000 cells, not 640 000.)"""
     from cytospace_amd import _lib
     from cytospace_amd.cytospace import ExpressionContext
+    # total_chunks > 0: STRONG scaling -- the fixed problem of configs[3] (200 000 cells = 20 chunks of 10 000), chunk k on rank
+    # k % world (equal sizes: what the LPT schedule gives), every chunk with its own seeded cells whatever the world size
+    strong = total_chunks > 0
+    mine = list(range(rank, total_chunks, world)) if strong else list(range(chunks_per_rank))
+    if strong:
+        chunks_per_rank, cell_sets = len(mine), max(1, len(mine))
     K = 10
     g = np.random.default_rng(5)                                   # shared by all ranks: gene means, type multipliers
     m = g.lognormal(0.0, 1.5, G).astype(np.float32)
@@ -309,6 +315,8 @@ def extra_c4_sharded(dev, rank, world, dist, chunks_per_rank, G=5000, S=50000, c
     C = cell_sets * chunk
     sc = np.empty((G, C), np.float32)
     for lo in range(0, C, 5000):
+        if strong and mine:                                        # cell set q of this rank = the cells of global chunk mine[q]
+            r = np.random.default_rng(7000 + 2 * mine[lo // chunk] + (lo % chunk) // 5000)
         ty = r.integers(0, K, 5000)
         sc[:, lo:lo + 5000] = r.poisson(0.3 * m[:, None] * mult[ty].T)
     st = None
@@ -317,7 +325,10 @@ def extra_c4_sharded(dev, rank, world, dist, chunks_per_rank, G=5000, S=50000, c
         for lo in range(0, S, 5000):
             ty = g.integers(0, K, (4, 5000))
             st[:, lo:lo + 5000] = g.poisson(0.3 * m[:, None] * (mult[ty[0]] + mult[ty[1]] + mult[ty[2]] + mult[ty[3]]).T)
-    subs = [np.bincount(r.integers(0, S, chunk), minlength=S) for _ in range(chunks_per_rank)]    # sub-spot slot counts
+    if strong:
+        subs = [np.bincount(np.random.default_rng(9000 + k).integers(0, S, chunk), minlength=S) for k in mine]
+    else:
+        subs = [np.bincount(r.integers(0, S, chunk), minlength=S) for _ in range(chunks_per_rank)]    # sub-spot slot counts
     t_gen = time.perf_counter() - t
     # communicator: the 128-byte id travels through the launcher's own channel
     uid = [_lib.Communicator.unique_id() if rank == 0 else None]
@@ -348,7 +359,14 @@ def extra_c4_sharded(dev, rank, world, dist, chunks_per_rank, G=5000, S=50000, c
         tt = torch.tensor([el], dtype=torch.float64, device=f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
-    i0 = res[0][2]
+    i0 = res[0][2] if res else None
+    if strong:
+        return {"workload": f"configs[3] as configured: {total_chunks * chunk} cells = {total_chunks} sub-spot chunks of {chunk} cells against {S} spots, "
+                            f"{G} genes, on {world} GPU(s): chunk k on rank k % {world}; ST transformed on rank 0 + RCCL broadcast",
+                "assignments_per_s": round(total_chunks * chunk / el, 1), "seconds": round(el, 2), "scaling": "strong",
+                "chunks_on_rank0": len(mine), "bcast_ms_rank0": None if bcast_ms is None else round(bcast_ms, 3),
+                "rank0_longest_lap_kernel_ms": round(max(r_[2].lap.ms_total for r_ in res), 1) if res else None,
+                "bincount_equals_slots": ok, "instance_seconds_rank0": round(t_gen, 1)}
     return {"workload": f"{world} GPU(s) x {chunks_per_rank} sub-spot chunks of {chunk} cells against {S} spots, {G} genes: "
                         "ST transformed on rank 0 + RCCL broadcast, per-rank raw-count upload, batched chunk solves",
             "assignments_per_s": round(world * chunks_per_rank * chunk / el, 1), "seconds": round(el, 2), "scaling": "weak",
@@ -378,7 +396,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no n50000 / c3 / c4_chunks / c5_chunks)")
     ap.add_argument("--c4-chunks", type=int, default=256, help="concurrent chunk LAPs in the c4_chunks leg (256 = one chain per CU; 400 MB each)")
     ap.add_argument("--c4-rank-chunks", type=int, default=64, help="chunks per rank in the c4_sharded leg")
-    ap.add_argument("--sharded-timeout", type=float, default=420.0, help="watchdog of the c4_sharded leg, seconds")
+    ap.add_argument("--sharded-timeout", type=float, default=600.0, help="watchdog of the c4_sharded leg, seconds")
     ap.add_argument("--pmc-tag", default="r03a", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
     args = ap.parse_args()
 
@@ -475,13 +493,12 @@ def main():
             raise SystemExit("c2_batch: the batched solve differs from the single solve")
     buf.free()
 
-    sharded, sharded_stuck = None, False
+    sharded, sharded_stuck, box = None, False, {}
     if not args.no_extras:
         # every rank takes part.  The headline above is already measured: a failure or a hang of this additional multi-rank leg
         # (it cannot be exercised on the one-GPU development box beyond world size 1) must not cost the line, so it runs under a
         # watchdog and reports what happened instead.
         import threading
-        box = {}
 
         def _leg():
             try:
@@ -489,6 +506,7 @@ def main():
                     import torch                # of this leg would run on cuda:0
                     if torch.cuda.is_available():
                         torch.cuda.set_device(local_rank)
+                box["strong"] = extra_c4_sharded(dev, rank, world, dist, 0, G=2000, total_chunks=20)
                 box["r"] = extra_c4_sharded(dev, rank, world, dist, args.c4_rank_chunks)
             except BaseException as e:          # noqa: BLE001 (SystemExit from the leg's own gates included)
                 box["r"] = {"error": f"{type(e).__name__}: {e}"}
@@ -603,6 +621,8 @@ def main():
     }
     if c2_batch is not None:
         out["c2_batch"] = c2_batch
+    if box.get("strong") is not None:
+        out["c4_strong"] = box["strong"]
     if sharded is not None:
         out["c4_sharded"] = sharded
     if world == 1 and not args.no_extras:

@@ -2888,14 +2888,14 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(const LazyArgs *__restrict
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-static const cyto_lap_opts k_default_opts = {0, 0, 0, 0, 0, 0, 0, 0};
+static const cyto_lap_opts k_default_opts = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 static int check_opts(const cyto_lap_opts &o) {
     if (o.chain_variant < 0 || o.chain_variant > 3 || o.augmentation < 0 || o.augmentation > 2 || o.inject_exceptions < 0 ||
         o.no_handover < 0 || o.no_handover > 1)
         return CYTO_ERR_BAD_ARG;
     if (o.group_state_global < 0 || o.group_state_global > 1 || o.aux_state_global < 0 || o.aux_state_global > 1) return CYTO_ERR_BAD_ARG;
-    if (o.mode < 0 || o.mode > 2 || o.wide_rounds < -1) return CYTO_ERR_BAD_ARG;
+    if (o.mode < 0 || o.mode > 2 || o.wide_rounds < -1 || o.wide_groups < -1 || o.wide_groups > 32 || o.reserved) return CYTO_ERR_BAD_ARG;
     return CYTO_OK;
 }
 
@@ -2922,6 +2922,7 @@ struct F32Plan {            // what depends on n (and the options) only: identic
     int n, colblocks, rowblocks, rows_per_block, cache_grid;
     bool force_l2, lds_variant, lazy, lz_lds_state, lz_cs_lds, no_cs_lds, wide;
     long long wide_rounds;
+    int wide_groups;
     size_t shm_chain, lz_base_shm;
 };
 
@@ -2973,7 +2974,9 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
         std::vector<WideArgs> h_wa((size_t)nl);
         for (int k = 0; k < nl; k++) {
             F32Job &j = jobs[live[k]];
-            if ((rc = j.b_wide.alloc(4 * nT + 64, stream))) return rc;
+            const int mcg = nl != 1 ? 0 : (pl.wide_groups > 0 ? pl.wide_groups : (pl.wide_groups < 0 ? 0 : wide_mc_groups(nl, n)));
+            const size_t mcb = mcg > 0 ? wide_mc_state_bytes(n) : 0;
+            if ((rc = j.b_wide.alloc(2 * nT + 256 + mcb, stream))) return rc;
             const Chain2Args &c = j.c2;
             WideArgs &wa = h_wa[k];
             wa.n = n; wa.ld = c.ld; wa.cost = c.cost; wa.rowmap = c.rowmap;
@@ -2986,6 +2989,18 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             wa.slot_p = j.b_wide.as<float>(); wa.slot_c = wa.slot_p + n;
             wa.cache_col = c.cache_col; wa.cache_val = c.cache_val; wa.misc = c.misc;
             wa.max_rounds = pl.wide_rounds;
+            wa.mc_groups = mcg; wa.gbmin = nullptr; wa.gdirty = nullptr; wa.gasg = nullptr; wa.gdense = nullptr; wa.ctl = nullptr;
+            if (mcg > 0) {
+                const size_t nblk = ((size_t)n + 63) / 64, nw32 = ((size_t)n + 31) / 32;
+                char *base = j.b_wide.as<char>() + ((2 * nT + 255) / 256) * 256;
+                wa.gbmin = reinterpret_cast<unsigned long long *>(base);          // nblk records of 128 bytes: [0] block minimum, [1] dirty bits
+                wa.gasg = reinterpret_cast<uint32_t *>(base + nblk * 128);
+                wa.gdense = wa.gasg + nw32; wa.gdirty = nullptr;
+                wa.ctl = base + wide_mc_state_bytes(n) - 256;
+                CYTO_HIP(hipMemsetAsync(wa.gbmin, 0, nblk * 128 + 2 * nw32 * 4, stream));
+                CYTO_HIP(hipMemset2DAsync(wa.gbmin, 128, 0xFF, 8, nblk, stream));   // the block minima: all-ones
+                CYTO_HIP(hipMemsetAsync(wa.ctl, 0, 256, stream));
+            }
             // the post-column-reduction prices: snapshot for the reduction transfer AND the raw cost of every owner entry
             CYTO_HIP(hipMemcpyAsync(wa.cassign, wa.v, nT, hipMemcpyDeviceToDevice, stream));
             CYTO_HIP(hipMemsetAsync(wa.label, 0xFF, 2 * nT, stream));
@@ -2997,7 +3012,7 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
         if ((rc = wide_launch_rt(d_wa.as<WideArgs>(), nl, n, stream)) || (rc = wide_launch_arr(d_wa.as<WideArgs>(), nl, n, stream))) return rc;
         CYTO_HIP(hipEventRecord(ev_arr_done, stream));
         if ((rc = build_caches())) return rc;                      // fresh floors against the prices the augmentation starts from
-        if ((rc = wide_launch_aug(d_wa.as<WideArgs>(), nl, n, stream))) return rc;
+        if ((rc = wide_launch_aug(d_wa.as<WideArgs>(), nl, n, stream, h_wa[0].mc_groups))) return rc;
         CYTO_HIP(hipStreamSynchronize(stream));                    // (d_wa is read by the kernels until here)
         return CYTO_OK;
     }
@@ -3082,6 +3097,7 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
                             opts.group_state_global || opts.aux_state_global;
     pl.wide = opts.mode == 2 || (opts.mode == 0 && !chain_opts);
     pl.wide_rounds = opts.wide_rounds < 0 ? 0 : (opts.wide_rounds > 0 ? opts.wide_rounds : 4096 + (long long)n / 4);
+    pl.wide_groups = opts.wide_groups;
     pl.force_l2 = opts.chain_variant != 0;
     pl.no_cs_lds = opts.chain_variant == 3;            // (3: as 2, with colsol in global memory too -- what n > 65 535 uses)
     pl.lds_variant = !pl.force_l2 && n <= 13 * per2;

@@ -12,7 +12,10 @@ namespace cyto {
 //   act0, act1      [n] active-row lists of the row-reduction rounds;  freerows [n];  touched [n] columns labelled in a search
 //   slot_j, slot_p, slot_c  [n] per active slot: the bid's column (-1 = retired), price, raw cost of that entry
 //   cache_col/val   [n][64] row caches (lap_jv.hip: build_row_caches)
-//   misc            256 bytes: +4 status, +8 double total, +16 long long counters[] (lap_jv.hip indices), +160.. wide counters
+//   misc            512 bytes: +4 status, +8 double total, +16 long long counters[] (lap_jv.hip indices), +160.. wide counters
+//   gbmin, gdirty, gasg, gdense, ctl   the multi-workgroup augmentation's shared state (global memory; wide_aug_mc): per 64-column
+//                   block the smallest dirty label, dirty / assigned / dense bitmaps, a 256-byte control block (zeroed by the host)
+//   mc_groups       workgroups that search one problem together (0: the one-workgroup kernel)
 // (fields through an X-macro: the kernels read the block through a mirror struct whose pointers are typed as GLOBAL, so that
 //  every access is a global_* instruction -- through pointers loaded from memory it would be a FLAT one, and flat accesses
 //  also count on lgkmcnt: every LDS wait would wait for the outstanding global loads too)
@@ -20,7 +23,8 @@ namespace cyto {
     S(int, n) S(int64_t, ld) P(const float, cost) P(const int32_t, rowmap) P(float, v) P(float, u) P(float, cassign)          \
     P(unsigned long long, label) P(unsigned long long, bid) P(int32_t, rowsol) P(int32_t, colsol) P(int32_t, matches)          \
     P(int32_t, freerows) P(int32_t, act0) P(int32_t, act1) P(int32_t, touched) P(int32_t, slot_j) P(float, slot_p)            \
-    P(float, slot_c) P(uint32_t, cache_col) P(float, cache_val) P(char, misc) S(long long, max_rounds)
+    P(float, slot_c) P(uint32_t, cache_col) P(float, cache_val) P(char, misc) S(long long, max_rounds)                     \
+    P(unsigned long long, gbmin) P(uint32_t, gdirty) P(uint32_t, gasg) P(uint32_t, gdense) P(char, ctl) S(int, mc_groups)
 #define WIDE_F_PTR(T, name) T *name;
 #define WIDE_F_VAL(T, name) T name;
 struct WideArgs { WIDE_FIELDS(WIDE_F_PTR, WIDE_F_VAL) };
@@ -33,6 +37,8 @@ size_t wide_aug_lds_bytes(int n);
 // phases, each one launch for the whole batch (d_args: device array of nb WideArgs)
 int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream);        // Jacobi reduction transfer (v0 snapshot in cassign)
 int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream);       // Jacobi rounds of augmenting row reduction + free list
-int wide_launch_aug(const WideArgs *d_args, int nb, int n, hipStream_t stream);       // succ-clamped shortest-path augmentation, duals, total
+int wide_launch_aug(const WideArgs *d_args, int nb, int n, hipStream_t stream, int mc_groups);   // succ-clamped shortest-path augmentation, duals, total
+int wide_mc_groups(int nb, int n);                                                     // how many workgroups search one problem together (0: one)
+size_t wide_mc_state_bytes(int n);                                                     // gbmin + 3 bitmaps + control block
 
 }  // namespace cyto

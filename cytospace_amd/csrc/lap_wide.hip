@@ -836,6 +836,392 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// AUGMENTATION on SEVERAL workgroups (one problem): the same searches, the same labels -- the fixed point of §"AUGMENTATION"
+// above does not care who relaxes what when -- with the search state in global memory (L2) instead of LDS and NO barrier
+// inside a search's steady state: every wave of every workgroup loops on its own { take the best dirty columns of the blocks
+// it owns, settle them, rebuild those blocks' minima }.  Exchange is by agent-scope atomics only (labels, dirty bits, block
+// minima, best unassigned column); everything mutable is read with sc1 loads and written with sc1 stores / atomics.
+//   * block minimum rebuilt without losing a concurrent update: the owner stores all-ones, WAITS, reads the block's dirty bits
+//     and labels, then atomic-mins what it found; an updater completes its label atomic, then its dirty bit (waits), then
+//     atomic-mins the block minimum -- whichever way they interleave, the owner either sees the dirty column or the
+//     updater's atomic min lands after the owner's store;
+//   * settling: dirty bit cleared, WAIT, label read -- an update in between sets the bit again;
+//   * termination: a wave without work leaves the `active` count and polls; all waves idle -> grid barrier -> did anyone
+//     settle anything since the last barrier?  No: converged (nothing can appear while nobody runs).  Yes: once more.
+// Grid barriers (a monotonic arrival counter, bounded spins) separate only the phases of a search: root, rounds, certificate
+// pass, price update + path flip, reset.  Workgroups 0, 8, 16 ... of the launch take part (observed: block b runs on XCD b % 8,
+// so they share one L2 -- a speed matter only, nothing here depends on placement).
+// ------------------------------------------------------------------------------------------------------------------
+struct McCtl {
+    unsigned long long T;
+    int ntouch, active, progress[2], fail, doroot, rootdense, anydense, f, err, scans;
+    unsigned int bar_arrive, bar_gen;
+    int pad_;
+    long long c_relax, c_hops, c_macro, c_proc, c_dense, c_trivial, c_verify;
+};
+static_assert(sizeof(McCtl) <= 256, "control block");
+
+// per 64-column block ONE 128-byte record (its own cache line: the block minimum and the dirty bits take atomics from every
+// workgroup, and atomics to one line serialise): [0] smallest dirty label, [1] dirty bits
+constexpr int MC_REC = 16;             // 64-bit words per record
+size_t wide_mc_state_bytes(int n) {
+    const size_t nblk = ((size_t)n + 63) / 64, nw32 = ((size_t)n + 31) / 32;
+    return ((nblk * 128 + 2 * nw32 * 4 + 255) / 256) * 256 + 256;
+}
+int wide_mc_groups(int nb, int n) {
+    // Measured (round 3, tools/wide_large.py --groups G): on uniform instances the one-workgroup kernel is faster (n = 20 000: 39 ms
+    // against 46 ms with 4-8 groups, 55 ms with 16) -- 4-8x the waves settle 1.8-2.6x the columns (speculation further from the
+    // frontier) and every exchange is a global atomic instead of an LDS one; on few-cell-type chunks, where full-row relaxations
+    // dominate, 8 groups are 1.4x faster (10 000-cell chunk: 2.55 -> 1.79 s).  So: on request only (cyto_lap_opts.wide_groups).
+    (void)nb; (void)n;
+    return 0;
+}
+
+template <typename T> __device__ __forceinline__ void st_sc1(T *p, T x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#define MC_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+__device__ __forceinline__ void mc_barrier(McCtl *c, int G, unsigned &gen) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        MC_WAIT_VM();
+        const unsigned arrived = atomicAdd(&c->bar_arrive, 1u) + 1u;
+        if (arrived == (gen + 1u) * (unsigned)G) st_sc1(&c->bar_gen, gen + 1u);
+        else {
+            long long spins = 0;
+            while (ld_sc1(&c->bar_gen) <= gen) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1ll << 25)) { atomicExch(&c->err, 2); break; }      // (a lost workgroup must not hang the device)
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    gen++;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(WT) void wide_aug_mc(const WideArgs *__restrict__ batch) {
+    if (blockIdx.x & 7) return;
+    const int g = uni((int)(blockIdx.x >> 3));
+    const WideArgs a = load_wide_args(batch, 0);
+    const int G = a.mc_groups;
+    McCtl *c = reinterpret_cast<McCtl *>(a.ctl);
+    const int n = a.n, tid = threadIdx.x, lane = tid & 63, w = uni((int)(threadIdx.x >> 6));
+    const int gw = g * WNW + w, W = G * WNW, gtid = g * WT + tid, GT = G * WT;
+    const int nblk = (n + 63) / 64, nw32 = (n + 31) / 32;
+    const int numfree = *reinterpret_cast<const int *>(a.misc + 128);
+    unsigned gen = 0;
+    __shared__ double s_tot[WNW];
+    // assigned bits (block minima, dirty and dense bits, the control block: initialised by the host)
+    for (int c0 = gw * 64; c0 < nw32 * 32; c0 += W * 64) {
+        const int cc = c0 + lane;
+        const uint64_t m = __ballot(cc < n && a.colsol[cc] >= 0);
+        if (lane == 0) { st_sc1(a.gasg + (c0 >> 5), (uint32_t)m); if ((c0 >> 5) + 1 < nw32) st_sc1(a.gasg + (c0 >> 5) + 1, (uint32_t)(m >> 32)); }
+    }
+    if (gtid == 0) st_sc1(&c->T, ~0ull);
+    mc_barrier(c, G, gen);
+
+    auto is_asg = [&](int col) -> bool { return (ld_sc1(a.gasg + (col >> 5)) >> (col & 31)) & 1u; };
+    auto is_dense = [&](int i) -> bool { return (ld_sc1(a.gdense + (i >> 5)) >> (i & 31)) & 1u; };
+    auto offer = [&](int col, uint32_t co, int row) -> unsigned long long {
+        return atomicMin(a.label + col, ((unsigned long long)co << 32) | (uint32_t)row);
+    };
+    auto after_offer = [&](int col, uint32_t co, int row, unsigned long long old) {
+        const unsigned long long key = ((unsigned long long)co << 32) | (uint32_t)row;
+        if (key < old) {
+            if (old == ~0ull) st_sc1(a.touched + atomicAdd(&c->ntouch, 1), col);
+            if ((uint32_t)(old >> 32) > co) {
+                const unsigned long long ck = ((unsigned long long)co << 32) | (uint32_t)col;
+                if (is_asg(col)) {
+                    atomicOr(a.gbmin + (int64_t)(col >> 6) * MC_REC + 1, 1ull << (col & 63));
+                    MC_WAIT_VM();                                   // the dirty bit is in place before the block minimum says so
+                    atomicMin(a.gbmin + (int64_t)(col >> 6) * MC_REC, ck);
+                } else atomicMin(&c->T, ck);
+            }
+        }
+    };
+    auto relax_to = [&](int col, uint32_t co, int row) { after_offer(col, co, row, offer(col, co, row)); };
+
+    long long c_proc = 0, c_dense = 0, c_trivial = 0, c_hops = 0, c_macro = 0, c_verify = 0;
+    int f = 0, par = 0;
+    for (;;) {
+        // ---- searches that end at the free row's own best column: workgroup 0, wave 0 ----
+        if (g == 0 && w == 0) {
+            while (f < numfree) {
+                const int fr = a.freerows[f];
+                const uint32_t col = a.cache_col[(int64_t)fr * KC + lane];
+                const float val = a.cache_val[(int64_t)fr * KC + lane];
+                const float tau = rdlane(val, KCU);
+                const bool valid = lane < KCU && col != COLSENT;
+                const uint32_t od = valid ? f2ord(val - ld_sc1(a.v + (valid ? col : 0))) : 0xFFFFFFFFu;
+                const uint32_t omin = wave_min_u32(od);
+                const bool un = valid && od == omin && !is_asg((int)col);
+                const uint64_t mu = __ballot(un);
+                if (!(omin != 0xFFFFFFFFu && mu && tau > ord2f(omin))) break;
+                const int l = __ffsll((unsigned long long)mu) - 1;
+                if (lane == l) {
+                    st_sc1(a.rowsol + fr, (int32_t)col); st_sc1(a.colsol + col, (int32_t)fr); st_sc1(a.cassign + col, val);
+                    atomicOr(a.gasg + (col >> 5), 1u << (col & 31));
+                }
+                MC_WAIT_VM();
+                c_trivial++; c_hops++;
+                f++;
+            }
+            if (lane == 0) st_sc1(&c->f, f);
+        }
+        mc_barrier(c, G, gen);
+        f = uni(ld_sc1(&c->f));
+        if (f >= numfree || ld_sc1(&c->err)) break;
+        const int fr = a.freerows[f];
+        const float *__restrict__ frow = a.cost + wrow_off(a.rowmap, fr, a.ld);
+        const float ftau = a.cache_val[(int64_t)fr * KC + KCU];
+        if (g == 0 && w == 0) {                                    // root: d[j] = c[fr][j] - v[j] for the cached columns
+            const uint32_t col = a.cache_col[(int64_t)fr * KC + lane];
+            const float val = a.cache_val[(int64_t)fr * KC + lane];
+            if (lane < KCU && col != COLSENT) relax_to((int)col, f2ord(val - ld_sc1(a.v + col)), fr);
+        }
+        if (gtid == 0) { st_sc1(&c->active, W); st_sc1(&c->progress[par], 0); }
+        mc_barrier(c, G, gen);
+
+        for (;;) {
+            // ================= asynchronous rounds, until a whole macro round settles nothing =================
+            for (;;) {
+                bool counted = true, progressed = false;
+                long long idle = 0;
+                for (;;) {
+                    const uint32_t Tord = uni((uint32_t)(ld_sc1(&c->T) >> 32));
+                    unsigned long long mk = ~0ull;
+                    for (int b = gw + W * lane; b < nblk; b += W * 64) mk = umin64(mk, ld_sc1(a.gbmin + (int64_t)b * MC_REC));
+                    uint64_t pkey[AP];
+                    {
+                        uint32_t dk = (uint32_t)(mk >> 32);
+#pragma unroll
+                        for (int q = 0; q < AP; q++) {
+                            const uint32_t m = wave_min_u32(dk);
+                            const int l = __ffsll((unsigned long long)__ballot(dk == m)) - 1;
+                            pkey[q] = (m == 0xFFFFFFFFu || m >= Tord) ? KEYMAX : (((uint64_t)m << 32) | rdlane((uint32_t)mk, l));
+                            if (lane == l) dk = 0xFFFFFFFFu;
+                        }
+                    }
+                    if (pkey[0] == KEYMAX) {                       // nothing to settle in this wave's blocks right now
+                        if (counted) { MC_WAIT_VM(); if (lane == 0) atomicSub(&c->active, 1); counted = false; }
+                        if (uni(ld_sc1(&c->active)) <= 0) break;
+                        __builtin_amdgcn_s_sleep(127);              // (hundreds of idle waves polling three words must not saturate their L2 channel)
+                        if (++idle > (1ll << 21)) { if (lane == 0) atomicExch(&c->err, 3); break; }
+                        continue;
+                    }
+                    if (!counted) { if (lane == 0) atomicAdd(&c->active, 1); counted = true; }
+                    if (!progressed) { if (lane == 0) st_sc1(&c->progress[par], 1); progressed = true; }
+                    bool pk[AP]; int pj[AP], oi[AP];
+                    unsigned long long lab[AP];
+                    float ca[AP], vp[AP], val[AP];
+                    uint32_t col[AP];
+#pragma unroll
+                    for (int q = 0; q < AP; q++) {
+                        pk[q] = pkey[q] != KEYMAX;
+                        pj[q] = (int)(uint32_t)pkey[q];
+                        if (pk[q] && lane == 0) atomicAnd(a.gbmin + (int64_t)(pj[q] >> 6) * MC_REC + 1, ~(1ull << (pj[q] & 63)));
+                    }
+                    MC_WAIT_VM();                                   // the bits are cleared before the labels are read
+#pragma unroll
+                    for (int q = 0; q < AP; q++) {
+                        lab[q] = ~0ull; ca[q] = 0.0f; vp[q] = 0.0f; oi[q] = 0;
+                        if (pk[q]) { lab[q] = uni(ld_sc1(a.label + pj[q])); ca[q] = uni(ld_sc1(a.cassign + pj[q])); vp[q] = uni(ld_sc1(a.v + pj[q])); oi[q] = uni(ld_sc1(a.colsol + pj[q])); }
+                    }
+#pragma unroll
+                    for (int q = 0; q < AP; q++) {
+                        col[q] = COLSENT; val[q] = 0.0f;
+                        if (pk[q]) { col[q] = a.cache_col[(int64_t)oi[q] * KC + lane]; val[q] = a.cache_val[(int64_t)oi[q] * KC + lane]; }
+                    }
+                    unsigned long long old[AP];
+                    uint32_t co[AP];
+                    bool off[AP], dn[AP];
+                    const uint32_t Tnow = uni((uint32_t)(ld_sc1(&c->T) >> 32));
+#pragma unroll
+                    for (int q = 0; q < AP; q++) {
+                        off[q] = false; dn[q] = false; old[q] = 0; co[q] = 0;
+                        const uint32_t dord = (uint32_t)(lab[q] >> 32);
+                        if (pk[q] && dord < Tnow) {
+                            c_proc++;
+                            if (is_dense(oi[q])) { dn[q] = true; continue; }
+                            const float h = (ca[q] - vp[q]) - ord2f(dord);
+                            const uint32_t lo = dord + 1u;
+                            if (lane < KCU && col[q] != COLSENT && (int)col[q] != pj[q]) {
+                                uint32_t cc = f2ord((val[q] - ld_sc1(a.v + col[q])) - h);
+                                cc = cc < lo ? lo : cc;
+                                if (cc <= Tnow) { off[q] = true; co[q] = cc; old[q] = offer((int)col[q], cc, oi[q]); }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < AP; q++) {
+                        const bool better = off[q] && ((((unsigned long long)co[q] << 32) | (uint32_t)oi[q]) < old[q]);
+                        if (__ballot(better) && better) after_offer((int)col[q], co[q], oi[q], old[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < AP; q++) {
+                        if (!dn[q]) continue;                      // the owner's cache could not certify: its whole cost row
+                        const uint32_t dord = (uint32_t)(lab[q] >> 32);
+                        const float h = (ca[q] - vp[q]) - ord2f(dord);
+                        const uint32_t lo = dord + 1u;
+                        const float *__restrict__ row = a.cost + wrow_off(a.rowmap, oi[q], a.ld);
+                        const int pjq = pj[q], oiq = oi[q];
+                        const uint32_t Tsw = uni((uint32_t)(ld_sc1(&c->T) >> 32));     // (once per sweep: a stale bound only prunes less)
+                        wave_row_sweep(row, n, lane, [&](int cidx, float x) {
+                            uint32_t cc = f2ord((x - ld_sc1(a.v + cidx)) - h);
+                            cc = cc < lo ? lo : cc;
+                            if (cidx != pjq && cc <= Tsw &&
+                                ((((unsigned long long)cc << 32) | (uint32_t)oiq) < ld_sc1(a.label + cidx))) relax_to(cidx, cc, oiq);
+                        });
+                        c_dense++;
+                    }
+                    // the blocks this wave took from: their smallest dirty column now
+#pragma unroll
+                    for (int q = 0; q < AP; q++)
+                        if (pk[q] && lane == 0) st_sc1(a.gbmin + (int64_t)(pj[q] >> 6) * MC_REC, ~0ull);
+                    MC_WAIT_VM();                                   // (also: this wave's own dirty bits and block-minimum updates are in place)
+#pragma unroll
+                    for (int q = 0; q < AP; q++) {
+                        if (!pk[q]) continue;
+                        const int b = pj[q] >> 6, cc = b * 64 + lane;
+                        const bool db = cc < n && ((uni(ld_sc1(a.gbmin + (int64_t)b * MC_REC + 1)) >> lane) & 1ull);
+                        if (__ballot(db)) {
+                            const uint32_t dk = db ? (uint32_t)(ld_sc1(a.label + cc) >> 32) : 0xFFFFFFFFu;
+                            const uint32_t m = wave_min_u32(dk);
+                            const int l = __ffsll((unsigned long long)__ballot(dk == m)) - 1;
+                            if (lane == 0) atomicMin(a.gbmin + (int64_t)b * MC_REC, ((unsigned long long)m << 32) | (uint32_t)(b * 64 + l));
+                        }
+                    }
+                }
+                c_macro++;
+                mc_barrier(c, G, gen);
+                const int prog = uni(ld_sc1(&c->progress[par]));
+                if (gtid == 0) { st_sc1(&c->progress[par ^ 1], 0); st_sc1(&c->active, W); }
+                par ^= 1;
+                mc_barrier(c, G, gen);
+                if (!prog || ld_sc1(&c->err)) break;
+            }
+            // ================= converged: do the caches certify what was skipped? =================
+            const unsigned long long Tk = ld_sc1(&c->T);
+            const uint32_t Dord = (uint32_t)(Tk >> 32);
+            const float D = Tk == ~0ull ? INFINITY : ord2f(Dord);
+            const int nt = uni(ld_sc1(&c->ntouch));
+            for (int q = gtid; q < nt; q += GT) {
+                const int k = ld_sc1(a.touched + q);
+                const uint32_t dord = (uint32_t)(ld_sc1(a.label + k) >> 32);
+                if (dord < Dord && is_asg(k)) {
+                    const int i = ld_sc1(a.colsol + k);
+                    if (!is_dense(i)) {
+                        const float h = (ld_sc1(a.cassign + k) - ld_sc1(a.v + k)) - ord2f(dord);
+                        const float bound = a.cache_val[(int64_t)i * KC + KCU] - h;
+                        if (!(bound > D)) {
+                            atomicOr(a.gdense + (i >> 5), 1u << (i & 31));
+                            atomicOr(a.gbmin + (int64_t)(k >> 6) * MC_REC + 1, 1ull << (k & 63));
+                            MC_WAIT_VM();
+                            atomicMin(a.gbmin + (int64_t)(k >> 6) * MC_REC, ((unsigned long long)dord << 32) | (uint32_t)k);
+                            atomicAdd(&c->fail, 1);
+                        }
+                    }
+                }
+            }
+            if (gtid == 0 && !ld_sc1(&c->rootdense) && !(ftau > D)) { st_sc1(&c->rootdense, 1); st_sc1(&c->doroot, 1); atomicAdd(&c->fail, 1); }
+            c_verify++;
+            mc_barrier(c, G, gen);
+            const int fail = uni(ld_sc1(&c->fail)), doroot = uni(ld_sc1(&c->doroot));
+            if (doroot)
+                for (int cc = gtid; cc < n; cc += GT) {
+                    const uint32_t co = f2ord(frow[cc] - ld_sc1(a.v + cc));
+                    if (co <= (uint32_t)(ld_sc1(&c->T) >> 32) && ((((unsigned long long)co << 32) | (uint32_t)fr) < ld_sc1(a.label + cc))) relax_to(cc, co, fr);
+                }
+            mc_barrier(c, G, gen);
+            if (gtid == 0) { if (fail) st_sc1(&c->anydense, 1); st_sc1(&c->fail, 0); st_sc1(&c->doroot, 0); }
+            if (!fail || ld_sc1(&c->err)) break;
+            mc_barrier(c, G, gen);                                  // (the resets above are in place before anyone counts failures again)
+        }
+
+        // ---- the search has ended at T: price update, path flip, reset ----
+        const unsigned long long Tk = ld_sc1(&c->T);
+        if (Tk == ~0ull || ld_sc1(&c->err)) { if (gtid == 0 && Tk == ~0ull) atomicExch(&c->err, 1); break; }
+        const uint32_t Dord = (uint32_t)(Tk >> 32);
+        const float D = ord2f(Dord);
+        const int sink = (int)(uint32_t)Tk;
+        const int nt = uni(ld_sc1(&c->ntouch));
+        const int anydense = uni(ld_sc1(&c->anydense));
+        int myscans = 0;
+        for (int q = gtid; q < nt; q += GT) {
+            const int k = ld_sc1(a.touched + q);
+            const uint32_t dord = (uint32_t)(ld_sc1(a.label + k) >> 32);
+            if (dord < Dord && is_asg(k)) {
+                const float vk = ld_sc1(a.v + k);
+                const float nv = (vk + ord2f(dord)) - D;
+                if (nv < vk) st_sc1(a.v + k, nv);
+                myscans++;
+            }
+        }
+        if (myscans) atomicAdd(&c->scans, myscans);
+        if (gtid == 0) {
+            int j = sink;
+            for (;;) {
+                const int i = (int)(uint32_t)ld_sc1(a.label + j);
+                const int jn = ld_sc1(a.rowsol + i);
+                st_sc1(a.colsol + j, (int32_t)i); st_sc1(a.rowsol + i, (int32_t)j); st_sc1(a.cassign + j, a.cost[wrow_off(a.rowmap, i, a.ld) + j]);
+                c_hops++;
+                if (i == fr) break;
+                j = jn;
+            }
+            atomicOr(a.gasg + (sink >> 5), 1u << (sink & 31));
+        }
+        mc_barrier(c, G, gen);
+        for (int q = gtid; q < nt; q += GT) {
+            const int k = ld_sc1(a.touched + q);
+            st_sc1(a.label + k, ~0ull);
+            atomicAnd(a.gbmin + (int64_t)(k >> 6) * MC_REC + 1, ~(1ull << (k & 63)));
+            st_sc1(a.gbmin + (int64_t)(k >> 6) * MC_REC, ~0ull);
+        }
+        if (anydense) for (int q = gtid; q < nw32; q += GT) st_sc1(a.gdense + q, 0u);
+        if (gtid == 0) {
+            c->c_relax += ld_sc1(&c->scans);
+            st_sc1(&c->scans, 0); st_sc1(&c->T, ~0ull); st_sc1(&c->ntouch, 0); st_sc1(&c->anydense, 0); st_sc1(&c->rootdense, 0); st_sc1(&c->f, f + 1);
+        }
+        f++;
+        mc_barrier(c, G, gen);
+    }
+
+    // ---- counters of every wave; duals and total by workgroup 0 ----
+    if (lane == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(&c->c_proc), (unsigned long long)c_proc);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&c->c_dense), (unsigned long long)c_dense);
+        if (g == 0 && w == 0) { c->c_trivial = c_trivial; c->c_hops += c_hops; c->c_macro = c_macro; c->c_verify = c_verify; }
+    }
+    mc_barrier(c, G, gen);
+    if (g != 0) return;
+    double tot = 0.0;
+    for (int i = tid; i < n; i += WT) {
+        const int j = ld_sc1(a.rowsol + i);
+        if (j >= 0) {
+            const float cij = ld_sc1(a.cassign + j);
+            a.u[i] = cij - ld_sc1(a.v + j);
+            tot += (double)cij;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+    if (lane == 0) s_tot[w] = tot;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int k = 0; k < WNW; k++) t += s_tot[k];
+        *reinterpret_cast<double *>(a.misc + 8) = t;
+        long long *ctr = reinterpret_cast<long long *>(a.misc + 16);
+        long long *wc = reinterpret_cast<long long *>(a.misc + 160);
+        ctr[C_AUG_INIT] = numfree; ctr[C_AUG_RELAX] = c->c_relax; ctr[C_AUGS] = numfree; ctr[C_HOPS] = c->c_hops;
+        wc[WC_DENSE_AUG] = ld_sc1(&c->c_dense); wc[WC_AUG_ROUNDS] = c->c_macro; wc[WC_AUG_PROCESSED] = ld_sc1(&c->c_proc);
+        wc[WC_TRIVIAL] = c->c_trivial; wc[WC_VERIFY_PASSES] = c->c_verify;
+        if (ld_sc1(&c->err)) *reinterpret_cast<int *>(a.misc + 4) = 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream) {
     const int blocks = std::max(1, std::min((n + RTB / 64 - 1) / (RTB / 64), 2048 / std::max(1, std::min(nb, 8))));
     hipLaunchKernelGGL(wide_rt, dim3(blocks, nb), dim3(RTB), 0, stream, d_args);
@@ -853,7 +1239,12 @@ int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream) {
     return CYTO_OK;
 }
 
-int wide_launch_aug(const WideArgs *d_args, int nb, int n, hipStream_t stream) {
+int wide_launch_aug(const WideArgs *d_args, int nb, int n, hipStream_t stream, int mc_groups) {
+    if (mc_groups > 0) {                                           // one problem, several workgroups (blocks 0, 8, 16 ... take part)
+        hipLaunchKernelGGL(wide_aug_mc, dim3(8 * mc_groups), dim3(WT), 0, stream, d_args);
+        CYTO_HIP(hipGetLastError());
+        return CYTO_OK;
+    }
     const bool vlds = wide_aug_vlds(n);
     const size_t shm = wide_aug_lds_bytes(n, vlds);
     if (shm > (size_t)LDS_DYNAMIC_MAX) return CYTO_ERR_UNSUPPORTED;

@@ -123,6 +123,10 @@ typedef struct {
                                    succ-clamped shortest paths -- same file, "WIDE MODE"; float32).  Both reach the same optimum;
                                    the duals and, where the optimum is not unique, the particular optimal assignment differ */
     int32_t wide_rounds;        /* wide solver: budget of row-reduction rounds.  0: 4096 + n / 4.  -1: none */
+    int32_t wide_groups;        /* wide solver, one problem: workgroups that run a search together, asynchronously, with the search
+                                   state in L2 (wide_aug_mc).  0 / -1: one workgroup, state in LDS (faster on everything but
+                                   few-cell-type chunks).  k > 0: k (<= 32).  Results do not depend on it */
+    int32_t reserved;           /* must be 0 */
 } cyto_lap_opts;
 int cyto_lap_f32_opts(int n, const float *cost, int64_t ld, int cost_on_device,
                       int32_t *rowsol, int32_t *colsol, float *u, float *v, double *total,

@@ -445,3 +445,22 @@ def test_wide_uniform_larger(n):
     c = np.random.default_rng(n).random((n, n)).astype(np.float32)
     g, o = _check_wide(c)
     assert g["info"].wide_aug_settled >= g["info"].scans_aug_relax        # speculative: a column may be settled more than once
+
+
+@pytest.mark.parametrize("groups", [2, 5, 16])
+def test_wide_search_on_several_workgroups(groups):
+    # cyto_lap_opts.wide_groups: the augmentation's searches run on several workgroups at once, asynchronously (no barrier inside a
+    # search's steady state; labels, dirty bits and block minima exchanged through agent-scope atomics in L2).  The labels are the
+    # fixed point of a monotone system, so who settles what when cannot matter: the oracle's answer bit for bit, every time.
+    rng = np.random.default_rng(40 + groups)
+    cases = [rng.random((n, n)).astype(np.float32) for n in (3, 64, 700, 2300)]
+    cases.append(np.repeat(rng.random((150, 600)), 4, axis=0).astype(np.float32))                     # duplicated rows: tight cycles
+    cases.append(rng.integers(0, 10, (400, 400)).astype(np.float32))                                    # heavy ties
+    prof = rng.normal(size=(6, 64)).astype(np.float32)                                                  # few cell types: full-row relaxations
+    rows = prof[rng.integers(0, 6, 1200)] + 0.05 * rng.normal(size=(1200, 64)).astype(np.float32)
+    cols = prof[rng.integers(0, 6, 1200)] + 0.05 * rng.normal(size=(1200, 64)).astype(np.float32)
+    cases.append(-(rows @ cols.T).astype(np.float32))
+    for c in cases:
+        for rounds in (0, 2):                                    # (a short row reduction leaves many searches)
+            g, o = _check_wide(c, opts=dict(wide_groups=groups), rounds=rounds)
+            assert g["info"].wide == 1

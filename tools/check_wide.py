@@ -10,7 +10,7 @@ from cytospace_amd.lap import lap_solve, lap_solve_rows  # noqa: E402
 from oracle.jv import jv_oracle_wide, jv_oracle  # noqa: E402
 from tools import instances as I  # noqa: E402
 
-WIDE = dict(mode=2)
+WIDE = dict(mode=2, wide_groups=int(sys.argv[sys.argv.index("--groups") + 1]) if "--groups" in sys.argv else 0)
 
 
 def one(c, label, rounds=0, rowmap=None, uniq=None):

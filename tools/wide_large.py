@@ -15,10 +15,11 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 def main():
-    tags = [a for a in sys.argv[1:] if not a.startswith("--")] or ["u20000"]
+    tags = [a for a in sys.argv[1:] if not a.startswith("--") and not a.lstrip("-").isdigit()] or ["u20000"]
     mode = 1 if "--chain" in sys.argv else 2
     rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 0
     reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 2
+    groups = int(sys.argv[sys.argv.index("--groups") + 1]) if "--groups" in sys.argv else 0
     for tag in tags:
         d = np.load(os.path.join(GOLD, f"large_{tag}.npz"))
         n = int(d["n"])
@@ -35,7 +36,7 @@ def main():
             raise SystemExit(f"unknown tag {tag}")
         for rep in range(reps):
             t = time.time()
-            g = lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n, opts=dict(mode=mode, wide_rounds=rounds))
+            g = lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n, opts=dict(mode=mode, wide_rounds=rounds, wide_groups=groups))
             wall = time.time() - t
             inf = g["info"]
             same = np.array_equal(g["colsol"], d["colsol"])
