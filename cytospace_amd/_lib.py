@@ -31,7 +31,9 @@ class LapInfo(ctypes.Structure):
                                                         ("row_groups", ctypes.c_int64), ("aug_dense_scans", ctypes.c_int64),
                                                         ("aug_sparse_inits", ctypes.c_int64), ("aug_handover", ctypes.c_int64)] + \
         [(k, ctypes.c_int64) for k in ("wide", "wide_rounds", "wide_retired", "wide_dense_arr", "wide_dense_aug", "wide_aug_rounds",
-                                       "wide_aug_settled", "wide_trivial", "wide_verify_passes")]
+                                       "wide_aug_settled", "wide_trivial", "wide_verify_passes", "wide_list_rounds", "wide_chain_rounds")] + \
+        [(k, ctypes.c_double) for k in ("wide_ms_list", "wide_ms_chain", "wide_ms_aug_rounds", "wide_ms_aug_verify", "wide_ms_aug_finish",
+                                        "wide_ms_aug_trivial")]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -3330,13 +3330,13 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
                 info->wide_dense_aug = wc[WC_DENSE_AUG]; info->wide_aug_rounds = wc[WC_AUG_ROUNDS]; info->wide_aug_settled = wc[WC_AUG_PROCESSED];
                 info->wide_trivial = wc[WC_TRIVIAL]; info->wide_verify_passes = wc[WC_VERIFY_PASSES];
                 info->aug_handover = -1;
-                if (getenv("CYTO_WIDE_DEBUG")) {
+                {   // phase timers the wide kernels keep (100 MHz ticks at misc + 256): diagnostics for tools/wide_large.py
                     long long dbg[16] = {0};
                     CYTO_HIP(hipMemcpy(dbg, j.b_misc.as<char>() + 256, sizeof dbg, hipMemcpyDeviceToHost));
-                    fprintf(stderr, "[wide n=%d] arr: list rounds %lld (%.2f ms) chain rounds %lld (%.2f ms) deals %lld setup %.2f ms tail %.2f ms | aug: rounds %.2f ms verify %.2f ms finish %.2f ms trivial %.2f ms\n",
-                            n, dbg[0], dbg[1] * 1e-5, dbg[2], dbg[3] * 1e-5, dbg[4], dbg[5] * 1e-5, dbg[6] * 1e-5, dbg[8] * 1e-5, dbg[9] * 1e-5, dbg[10] * 1e-5, dbg[11] * 1e-5);
-                    fprintf(stderr, "[wide n=%d] chain-round profile (wave 0, ms): wait-prefetch %.2f bids %.2f barrier1 %.2f resolve %.2f barrier2+count %.2f\n",
-                            n, dbg[12] * 1e-5, dbg[13] * 1e-5, dbg[14] * 1e-5, dbg[15] * 1e-5, dbg[7] * 1e-5);
+                    info->wide_list_rounds = dbg[0]; info->wide_chain_rounds = dbg[2];
+                    info->wide_ms_list = dbg[1] * 1e-5; info->wide_ms_chain = dbg[3] * 1e-5;
+                    info->wide_ms_aug_rounds = dbg[8] * 1e-5; info->wide_ms_aug_verify = dbg[9] * 1e-5;
+                    info->wide_ms_aug_finish = dbg[10] * 1e-5; info->wide_ms_aug_trivial = dbg[11] * 1e-5;
                 }
             }
         }

@@ -91,6 +91,10 @@ typedef struct {
     int64_t wide_aug_settled;    /* augmentation: columns settled, re-settlements after a label improved included */
     int64_t wide_trivial;        /* augmentation: searches that ended at the free row's own best column */
     int64_t wide_verify_passes;  /* augmentation: certificate passes (>= one per non-trivial search) */
+    int64_t wide_list_rounds, wide_chain_rounds;   /* row-reduction rounds in the list / chain regime */
+    double wide_ms_list, wide_ms_chain;            /* time inside wide_arr spent in them (the kernels' own 100 MHz clock) */
+    double wide_ms_aug_rounds, wide_ms_aug_verify, wide_ms_aug_finish, wide_ms_aug_trivial;   /* wide_aug: search rounds, certificate
+                                                      passes, price update + flip + reset, one-edge searches (one-workgroup kernel) */
 } cyto_lap_info;
 
 int cyto_lap_f32(int n, const float *cost, int64_t ld, int cost_on_device,

@@ -464,3 +464,19 @@ def test_wide_search_on_several_workgroups(groups):
         for rounds in (0, 2):                                    # (a short row reduction leaves many searches)
             g, o = _check_wide(c, opts=dict(wide_groups=groups), rounds=rounds)
             assert g["info"].wide == 1
+
+
+def test_one_process_two_devices():
+    # kernels that need more than 64 KB of dynamic LDS (prices and owners in LDS) get their per-device attribute on EVERY device a
+    # process uses: device 0 first, then device 1 (needs two GPUs)
+    from cytospace_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip("needs two devices in one process")
+    n = 12000
+    c = np.random.default_rng(n).random((n, n)).astype(np.float32)
+    for opts in (None, CHAIN):
+        a = lap_solve(c, np.float32, device_id=0, opts=opts)
+        b = lap_solve(c, np.float32, device_id=1, opts=opts)
+        for k in ("rowsol", "colsol", "u", "v"):
+            assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(lap_solve(c, np.float32, device_id=1)["colsol"], jv_oracle(c, np.float32)["colsol"])

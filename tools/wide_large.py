@@ -46,6 +46,9 @@ def main():
                   f"free={inf.free_after_arr2} rounds={inf.wide_rounds} bids={inf.scans_arr} retired={inf.wide_retired} relax={inf.scans_aug_relax} "
                   f"settled={inf.wide_aug_settled} aug_rounds={inf.wide_aug_rounds} dense=({inf.wide_dense_arr},{inf.wide_dense_aug}) "
                   f"trivial={inf.wide_trivial} verify={inf.wide_verify_passes} hops={inf.path_hops}", flush=True)
+            print(f"    wide_arr: list rounds {inf.wide_list_rounds} ({inf.wide_ms_list:.2f} ms), chain rounds {inf.wide_chain_rounds} ({inf.wide_ms_chain:.2f} ms) | "
+                  f"wide_aug: rounds {inf.wide_ms_aug_rounds:.2f} ms, certificate passes {inf.wide_ms_aug_verify:.2f}, update+flip+reset {inf.wide_ms_aug_finish:.2f}, "
+                  f"one-edge searches {inf.wide_ms_aug_trivial:.2f}", flush=True)
         buf.free()
 
 
