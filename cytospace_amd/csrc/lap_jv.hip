@@ -1283,7 +1283,8 @@ __device__ __forceinline__ K2 refresh_row(int i, int n, int64_t ld, const float 
 template <int CH>
 __global__ __launch_bounds__(BLOCK2) void build_row_caches(int n, int64_t ld, const float *__restrict__ cost,
                                                           const float *__restrict__ v, uint32_t *__restrict__ cache_col,
-                                                          float *__restrict__ cache_val, const int32_t *__restrict__ rowmap) {
+                                                          float *__restrict__ cache_val, const int32_t *__restrict__ rowmap,
+                                                          const int32_t *__restrict__ same_prev) {
     constexpr int NC = CH * 4;
     __shared__ Scratch2 s;
     const int tid = threadIdx.x;
@@ -1297,8 +1298,26 @@ __global__ __launch_bounds__(BLOCK2) void build_row_caches(int n, int64_t ld, co
         if (c < n) { validm |= (1ull << sl); vreg[sl] = v[c]; }
     }
     float delta = 0.0f;
-    for (int i = blockIdx.x; i < n; i += gridDim.x)
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        if (same_prev && same_prev[i]) continue;                          // a copy of the previous row: replicate_group_caches
         (void)refresh_row<CH>(i, n, ld, RBASE(cost, rowmap, i, ld), vreg, validm, cache_col, cache_val, delta, s, par);
+    }
+}
+
+// Runs of bitwise identical consecutive rows (same_prev[i] = row i equals row i - 1: rows_same_as_prev / rows_same_from_map --
+// CytoSPACE repeats every spot row slots[s] times) have identical caches: the build kernels make the cache of the first row of
+// every run, this one copies it to the others (a wave per run; c3: ten rows per spot -- a tenth of the cache-build work).
+__global__ __launch_bounds__(256) void replicate_group_caches(int n, const int32_t *__restrict__ same_prev, uint32_t *__restrict__ cache_col,
+                                                               float *__restrict__ cache_val) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    for (int f = gw; f < n; f += nw) {
+        if (same_prev[f]) continue;                                        // not the first row of its run
+        if (f + 1 >= n || !same_prev[f + 1]) continue;                     // a run of one
+        const uint32_t c = cache_col[(int64_t)f * KC + lane];
+        const float x = cache_val[(int64_t)f * KC + lane];
+        for (int i = f + 1; i < n && same_prev[i]; i++) { cache_col[(int64_t)i * KC + lane] = c; cache_val[(int64_t)i * KC + lane] = x; }
+    }
 }
 
 // Streaming variant of refresh_row for large n: no per-lane arrays.  The row and the prices come through
@@ -1380,12 +1399,15 @@ __device__ __forceinline__ K2 refresh_row_stream(int i, int n, int64_t ld, const
 
 __global__ __launch_bounds__(BLOCK2) void build_row_caches_stream(int n, int64_t ld, const float *__restrict__ cost,
                                                                  const float *v, uint32_t *__restrict__ cache_col,
-                                                                 float *__restrict__ cache_val, const int32_t *__restrict__ rowmap) {
+                                                                 float *__restrict__ cache_val, const int32_t *__restrict__ rowmap,
+                                                                 const int32_t *__restrict__ same_prev) {
     __shared__ Scratch2 s;
     int par = 0;
     float delta = 0.0f;
-    for (int i = blockIdx.x; i < n; i += gridDim.x)
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        if (same_prev && same_prev[i]) continue;                          // a copy of the previous row: replicate_group_caches
         (void)refresh_row_stream<0>(i, n, ld, RBASE(cost, rowmap, i, ld), v, cache_col, cache_val, delta, s, par);
+    }
 }
 
 // Argument block of one problem (kernels get an array of them: one workgroup per problem).  Fields through an X-macro because
@@ -2941,12 +2963,17 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
     auto build_caches = [&]() -> int {
         for (int b : live) {
             const Chain2Args &a = jobs[b].c2;
+            // (runs of identical rows: one cache per run, copied to the rest)
+            const int32_t *same = (jobs[b].h_ngroups < n && n >= 2) ? jobs[b].b_same.as<int32_t>() : nullptr;
             if constexpr (CH == 0)
                 hipLaunchKernelGGL(build_row_caches_stream, dim3(pl.cache_grid), dim3(BLOCK2), 0, stream, n, a.ld, a.cost,
-                                   (const float *)a.fws, a.cache_col, a.cache_val, a.rowmap);
+                                   (const float *)a.fws, a.cache_col, a.cache_val, a.rowmap, same);
             else
                 hipLaunchKernelGGL((build_row_caches<CH>), dim3(pl.cache_grid), dim3(BLOCK2), 0, stream, n, a.ld, a.cost,
-                                   (const float *)a.fws, a.cache_col, a.cache_val, a.rowmap);
+                                   (const float *)a.fws, a.cache_col, a.cache_val, a.rowmap, same);
+            if (same)
+                hipLaunchKernelGGL(replicate_group_caches, dim3(std::max(1, std::min((n + 3) / 4, 2048))), dim3(256), 0, stream, n, same,
+                                   a.cache_col, a.cache_val);
         }
         CYTO_HIP(hipGetLastError());
         return CYTO_OK;
