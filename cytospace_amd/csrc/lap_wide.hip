@@ -82,6 +82,20 @@ template <typename F> __device__ __forceinline__ void wave_row_sweep(const float
         }
     }
 }
+// Search labels (oracle/jv_oracle_impl.h, WIDE MODE): a 44-bit label value LV = ordered distance (32) | tight-hop count k (12),
+// then 20 bits of identity (the predecessor row in `label`, the column itself in the block minima and in the best unassigned
+// column): one unsigned 64-bit compare orders (distance, k, identity) lexicographically; key >> 32 is the ordered distance.
+constexpr uint32_t LKMAX = 4095u;
+__device__ __forceinline__ unsigned long long lkey(unsigned long long lv, uint32_t id) { return (lv << 20) | id; }
+__device__ __forceinline__ unsigned long long lv_of(unsigned long long key) { return key >> 20; }
+__device__ __forceinline__ uint32_t lid_of(unsigned long long key) { return (uint32_t)key & 0xFFFFFu; }
+// the label value an edge gives: raw candidate (ordered) c_raw out of a column labelled (dord, k).  A candidate that does not
+// exceed the label it comes from (a tight edge; rounding can even put it below) keeps the distance and counts one more tight hop
+// -- nothing is added to the distance (LKMAX hops in a row: the next representable distance).
+__device__ __forceinline__ unsigned long long edge_lv(uint32_t c_raw, uint32_t dord, uint32_t k) {
+    return c_raw > dord ? ((unsigned long long)c_raw << 12)
+                        : (k < LKMAX ? (((unsigned long long)dord << 12) | (k + 1u)) : ((unsigned long long)(dord + 1u) << 12));
+}
 // value of lane l (wave-uniform l) without the LDS round trip of __shfl
 __device__ __forceinline__ uint32_t rdlane(uint32_t x, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, l); }
 __device__ __forceinline__ float rdlane(float x, int l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), l)); }
@@ -548,21 +562,21 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
 
     // a relaxation in two halves: the offer (column `col` is offered the ordered distance `co` by row `row`; returns the label
     // it replaced or lost against) and what follows from it -- first touch, dirty column, best unassigned column
-    auto offer = [&](int col, uint32_t co, int row) -> unsigned long long {
-        return atomicMin(a.label + col, ((unsigned long long)co << 32) | (uint32_t)row);
+    auto offer = [&](int col, unsigned long long lv, int row) -> unsigned long long {
+        return atomicMin(a.label + col, lkey(lv, (uint32_t)row));
     };
-    auto after_offer = [&](int col, uint32_t co, int row, unsigned long long old) {
-        const unsigned long long key = ((unsigned long long)co << 32) | (uint32_t)row;
+    auto after_offer = [&](int col, unsigned long long lv, int row, unsigned long long old) {
+        const unsigned long long key = lkey(lv, (uint32_t)row);
         if (key < old) {
             if (old == ~0ull) a.touched[atomicAdd(&s.ntouch, 1)] = col;
-            if ((uint32_t)(old >> 32) > co) {                    // the distance itself dropped (not only the row of a tie)
-                const unsigned long long ck = ((unsigned long long)co << 32) | (uint32_t)col;
+            if (lv_of(old) > lv) {                              // the label value itself dropped (not only the row of a tie)
+                const unsigned long long ck = lkey(lv, (uint32_t)col);
                 if (is_asg(col)) { atomicOr(&dirty[col >> 5], 1u << (col & 31)); atomicMin(&bmin[col >> 6], ck); }
                 else atomicMin(&s.T, ck);
             }
         }
     };
-    auto relax_to = [&](int col, uint32_t co, int row) { after_offer(col, co, row, offer(col, co, row)); };
+    auto relax_to = [&](int col, unsigned long long lv, int row) { after_offer(col, lv, row, offer(col, lv, row)); };
 
     int f = 0;
     int par = 0;
@@ -605,28 +619,27 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
         if (w == 0) {
             const uint32_t col = a.cache_col[(int64_t)fr * KC + lane];
             const float val = a.cache_val[(int64_t)fr * KC + lane];
-            if (lane < KCU && col != COLSENT) relax_to((int)col, f2ord(val - getv((int)col)), fr);
+            if (lane < KCU && col != COLSENT) relax_to((int)col, (unsigned long long)f2ord(val - getv((int)col)) << 12, fr);
         }
         __syncthreads();
 
         for (;;) {
             // ================= rounds until no wave finds work =================
             for (;;) {
-                const uint32_t Tord = uni((uint32_t)(s.T >> 32));
-                // two good dirty columns among the wave's blocks: the smallest distance, then the smallest of the other lanes
-                // (32-bit reductions on the distance alone; which of several equal distances is taken does not matter --
-                // no schedule does)
+                const unsigned long long Tlv = uni(lv_of(s.T));          // label value of the best unassigned column so far
+                // the two best dirty columns among the wave's blocks (one key per lane: the smallest of the blocks it looks at)
                 unsigned long long mk = ~0ull;
                 for (int b = w + WNW * lane; b < nblk; b += WNW * 64) mk = umin64(mk, bmin[b]);
                 uint64_t pkey[AP];
-                {
-                    uint32_t dk = (uint32_t)(mk >> 32);
+                {   // (the lexicographic minimum of the lanes' keys as two 32-bit reductions: distance, then k | column among its ties --
+                    //  the smallest (distance, k) must not be missed: it alone may still be below the best unassigned column's)
 #pragma unroll
                     for (int q = 0; q < AP; q++) {
+                        const uint32_t dk = (uint32_t)(mk >> 32);
                         const uint32_t m = wave_min_u32(dk);
-                        const int l = __ffsll((unsigned long long)__ballot(dk == m)) - 1;
-                        pkey[q] = m == 0xFFFFFFFFu ? KEYMAX : (((uint64_t)m << 32) | rdlane((uint32_t)mk, l));
-                        if (lane == l) dk = 0xFFFFFFFFu;
+                        const uint32_t m2 = wave_min_u32(dk == m ? (uint32_t)mk : 0xFFFFFFFFu);
+                        pkey[q] = m == 0xFFFFFFFFu ? KEYMAX : (((uint64_t)m << 32) | m2);
+                        if (mk == pkey[q]) mk = ~0ull;
                     }
                 }
                 bool pk[AP]; int pj[AP], oi[AP];
@@ -635,8 +648,8 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                 uint32_t col[AP];
 #pragma unroll
                 for (int q = 0; q < AP; q++) {
-                    pk[q] = pkey[q] != KEYMAX && (uint32_t)(pkey[q] >> 32) < Tord;
-                    pj[q] = (int)(uint32_t)pkey[q];
+                    pk[q] = pkey[q] != KEYMAX && lv_of(pkey[q]) < Tlv;
+                    pj[q] = (int)lid_of(pkey[q]);
                     if (pk[q] && lane == 0) { atomicAnd(&dirty[pj[q] >> 5], ~(1u << (pj[q] & 31))); s.any[par] = 1; }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the bits are cleared before the labels are read
@@ -650,45 +663,39 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     col[q] = COLSENT; val[q] = 0.0f;
                     if (pk[q]) { col[q] = a.cache_col[(int64_t)oi[q] * KC + lane]; val[q] = a.cache_val[(int64_t)oi[q] * KC + lane]; }
                 }
-                unsigned long long old[AP];
-                uint32_t co[AP];
+                unsigned long long old[AP], co[AP];
                 bool off[AP], dn[AP];
 #pragma unroll
                 for (int q = 0; q < AP; q++) {
                     off[q] = false; dn[q] = false; old[q] = 0; co[q] = 0;
-                    const uint32_t dord = (uint32_t)(lab[q] >> 32);
-                    if (pk[q] && dord < Tord) {
+                    const uint32_t dord = (uint32_t)(lab[q] >> 32), kq = (uint32_t)(lab[q] >> 20) & LKMAX;
+                    if (pk[q] && lv_of(lab[q]) < Tlv) {
                         c_proc++;
                         if ((dense[oi[q] >> 5] >> (oi[q] & 31)) & 1u) { dn[q] = true; continue; }
                         const float h = (ca[q] - vp[q]) - ord2f(dord);
-                        const uint32_t lo = dord + 1u;
                         if (lane < KCU && col[q] != COLSENT && (int)col[q] != pj[q]) {
-                            uint32_t c = f2ord((val[q] - getv((int)col[q])) - h);
-                            c = c < lo ? lo : c;
-                            if (c <= Tord) { off[q] = true; co[q] = c; old[q] = offer((int)col[q], c, oi[q]); }
+                            const unsigned long long lv = edge_lv(f2ord((val[q] - getv((int)col[q])) - h), dord, kq);
+                            if (lv <= Tlv) { off[q] = true; co[q] = lv; old[q] = offer((int)col[q], lv, oi[q]); }
                         }
                     }
                 }
 #pragma unroll
                 for (int q = 0; q < AP; q++) {
-                    const bool better = off[q] && ((((unsigned long long)co[q] << 32) | (uint32_t)oi[q]) < old[q]);
+                    const bool better = off[q] && (lkey(co[q], (uint32_t)oi[q]) < old[q]);
                     if (__ballot(better) && better) after_offer((int)col[q], co[q], oi[q], old[q]);
                 }
 #pragma unroll
                 for (int q = 0; q < AP; q++) {
                     if (!dn[q]) continue;                          // the owner's cache could not certify: its whole cost row
-                    const uint32_t dord = (uint32_t)(lab[q] >> 32);
+                    const uint32_t dord = (uint32_t)(lab[q] >> 32), kq = (uint32_t)(lab[q] >> 20) & LKMAX;
                     const float h = (ca[q] - vp[q]) - ord2f(dord);
-                    const uint32_t lo = dord + 1u;
                     const float *__restrict__ row = a.cost + wrow_off(a.rowmap, oi[q], a.ld);
                     const int pjq = pj[q], oiq = oi[q];
                     // (a full row offers hundreds of candidates below the best unassigned distance when many columns are near-equal:
                     //  the label is read first -- a plain L2 load -- and the atomic follows only where it would change something)
                     wave_row_sweep(row, n, lane, [&](int c, float x) {
-                        uint32_t cc = f2ord((x - getv(c)) - h);
-                        cc = cc < lo ? lo : cc;
-                        if (c != pjq && cc <= (uint32_t)(s.T >> 32) &&
-                            ((((unsigned long long)cc << 32) | (uint32_t)oiq) < ld_sc1(a.label + c))) relax_to(c, cc, oiq);
+                        const unsigned long long lv = edge_lv(f2ord((x - getv(c)) - h), dord, kq);
+                        if (c != pjq && lv <= lv_of(s.T) && (lkey(lv, (uint32_t)oiq) < ld_sc1(a.label + c))) relax_to(c, lv, oiq);
                     });
                     c_dense++;
                 }
@@ -699,11 +706,12 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     const int b = pj[q] >> 6, c = b * 64 + lane;
                     const bool db = c < n && ((dirty[c >> 5] >> (c & 31)) & 1u);
                     unsigned long long key = ~0ull;
-                    if (__ballot(db)) {
-                        const uint32_t dk = db ? (uint32_t)(ld_sc1(a.label + c) >> 32) : 0xFFFFFFFFu;
+                    if (__ballot(db)) {                              // smallest (distance, k) among the dirty columns: two 32-bit reductions
+                        const unsigned long long lb = db ? ld_sc1(a.label + c) : ~0ull;
+                        const uint32_t dk = (uint32_t)(lb >> 32);
                         const uint32_t m = wave_min_u32(dk);
-                        const int l = __ffsll((unsigned long long)__ballot(dk == m)) - 1;
-                        key = ((unsigned long long)m << 32) | (uint32_t)(b * 64 + l);
+                        const uint32_t lo2 = (db && dk == m) ? (((uint32_t)lb & 0xFFF00000u) | (uint32_t)c) : 0xFFFFFFFFu;
+                        key = ((unsigned long long)m << 32) | wave_min_u32(lo2);
                     }
                     if (lane == 0) bmin[b] = key;
                 }
@@ -722,7 +730,8 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             const int nt = s.ntouch;
             for (int q = tid; q < nt; q += WT) {
                 const int k = ld_sc1(a.touched + q);
-                const uint32_t dord = (uint32_t)(ld_sc1(a.label + k) >> 32);
+                const unsigned long long lbk = ld_sc1(a.label + k);
+                const uint32_t dord = (uint32_t)(lbk >> 32);
                 if (dord < Dord && is_asg(k)) {
                     const int i = getcs(k);
                     if (!((dense[i >> 5] >> (i & 31)) & 1u)) {
@@ -731,7 +740,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                         if (!(bound > D)) {
                             atomicOr(&dense[i >> 5], 1u << (i & 31));
                             atomicOr(&dirty[k >> 5], 1u << (k & 31));
-                            atomicMin(&bmin[k >> 6], ((unsigned long long)dord << 32) | (uint32_t)k);
+                            atomicMin(&bmin[k >> 6], lkey(lv_of(lbk), (uint32_t)k));
                             atomicAdd(&s.fail, 1);
                         }
                     }
@@ -743,8 +752,8 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             const int fail = s.fail;
             if (s.doroot)
                 for (int c = tid; c < n; c += WT) {
-                    const uint32_t co = f2ord(frow[c] - getv(c));
-                    if (co <= (uint32_t)(s.T >> 32) && ((((unsigned long long)co << 32) | (uint32_t)fr) < ld_sc1(a.label + c))) relax_to(c, co, fr);
+                    const unsigned long long lv = (unsigned long long)f2ord(frow[c] - getv(c)) << 12;
+                    if (lv <= lv_of(s.T) && (lkey(lv, (uint32_t)fr) < ld_sc1(a.label + c))) relax_to(c, lv, fr);
                 }
             __syncthreads();
             if (tid == 0) { if (fail) s.anydense = 1; s.fail = 0; s.doroot = 0; }
@@ -758,7 +767,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
         if (Tk == ~0ull) { if (tid == 0) s.err = 1; __syncthreads(); break; }
         const uint32_t Dord = (uint32_t)(Tk >> 32);
         const float D = ord2f(Dord);
-        const int sink = (int)(uint32_t)Tk;
+        const int sink = (int)lid_of(Tk);
         const int nt = s.ntouch;
         int myscans = 0;
         for (int q = tid; q < nt; q += WT) {
@@ -775,7 +784,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
         if (tid == 0) {
             int j = sink;
             for (;;) {
-                const int i = (int)(uint32_t)ld_sc1(a.label + j);
+                const int i = (int)lid_of(ld_sc1(a.label + j));
                 const int jn = ld_sc1(a.rowsol + i);
                 a.colsol[j] = i; a.rowsol[i] = j; a.cassign[j] = a.cost[wrow_off(a.rowmap, i, a.ld) + j];
                 if (VLDS) s_cs[j] = (uint16_t)i;
@@ -923,15 +932,15 @@ __global__ __launch_bounds__(WT) void wide_aug_mc(const WideArgs *__restrict__ b
 
     auto is_asg = [&](int col) -> bool { return (ld_sc1(a.gasg + (col >> 5)) >> (col & 31)) & 1u; };
     auto is_dense = [&](int i) -> bool { return (ld_sc1(a.gdense + (i >> 5)) >> (i & 31)) & 1u; };
-    auto offer = [&](int col, uint32_t co, int row) -> unsigned long long {
-        return atomicMin(a.label + col, ((unsigned long long)co << 32) | (uint32_t)row);
+    auto offer = [&](int col, unsigned long long lv, int row) -> unsigned long long {
+        return atomicMin(a.label + col, lkey(lv, (uint32_t)row));
     };
-    auto after_offer = [&](int col, uint32_t co, int row, unsigned long long old) {
-        const unsigned long long key = ((unsigned long long)co << 32) | (uint32_t)row;
+    auto after_offer = [&](int col, unsigned long long lv, int row, unsigned long long old) {
+        const unsigned long long key = lkey(lv, (uint32_t)row);
         if (key < old) {
             if (old == ~0ull) st_sc1(a.touched + atomicAdd(&c->ntouch, 1), col);
-            if ((uint32_t)(old >> 32) > co) {
-                const unsigned long long ck = ((unsigned long long)co << 32) | (uint32_t)col;
+            if (lv_of(old) > lv) {                              // the label value itself dropped (not only the row of a tie)
+                const unsigned long long ck = lkey(lv, (uint32_t)col);
                 if (is_asg(col)) {
                     atomicOr(a.gbmin + (int64_t)(col >> 6) * MC_REC + 1, 1ull << (col & 63));
                     MC_WAIT_VM();                                   // the dirty bit is in place before the block minimum says so
@@ -940,7 +949,7 @@ __global__ __launch_bounds__(WT) void wide_aug_mc(const WideArgs *__restrict__ b
             }
         }
     };
-    auto relax_to = [&](int col, uint32_t co, int row) { after_offer(col, co, row, offer(col, co, row)); };
+    auto relax_to = [&](int col, unsigned long long lv, int row) { after_offer(col, lv, row, offer(col, lv, row)); };
 
     long long c_proc = 0, c_dense = 0, c_trivial = 0, c_hops = 0, c_macro = 0, c_verify = 0;
     int f = 0, par = 0;
@@ -978,7 +987,7 @@ __global__ __launch_bounds__(WT) void wide_aug_mc(const WideArgs *__restrict__ b
         if (g == 0 && w == 0) {                                    // root: d[j] = c[fr][j] - v[j] for the cached columns
             const uint32_t col = a.cache_col[(int64_t)fr * KC + lane];
             const float val = a.cache_val[(int64_t)fr * KC + lane];
-            if (lane < KCU && col != COLSENT) relax_to((int)col, f2ord(val - ld_sc1(a.v + col)), fr);
+            if (lane < KCU && col != COLSENT) relax_to((int)col, (unsigned long long)f2ord(val - ld_sc1(a.v + col)) << 12, fr);
         }
         if (gtid == 0) { st_sc1(&c->active, W); st_sc1(&c->progress[par], 0); }
         mc_barrier(c, G, gen);
@@ -989,18 +998,19 @@ __global__ __launch_bounds__(WT) void wide_aug_mc(const WideArgs *__restrict__ b
                 bool counted = true, progressed = false;
                 long long idle = 0;
                 for (;;) {
-                    const uint32_t Tord = uni((uint32_t)(ld_sc1(&c->T) >> 32));
+                    const unsigned long long Tlv = uni(lv_of(ld_sc1(&c->T)));
                     unsigned long long mk = ~0ull;
                     for (int b = gw + W * lane; b < nblk; b += W * 64) mk = umin64(mk, ld_sc1(a.gbmin + (int64_t)b * MC_REC));
                     uint64_t pkey[AP];
                     {
-                        uint32_t dk = (uint32_t)(mk >> 32);
 #pragma unroll
                         for (int q = 0; q < AP; q++) {
+                            const uint32_t dk = (uint32_t)(mk >> 32);
                             const uint32_t m = wave_min_u32(dk);
-                            const int l = __ffsll((unsigned long long)__ballot(dk == m)) - 1;
-                            pkey[q] = (m == 0xFFFFFFFFu || m >= Tord) ? KEYMAX : (((uint64_t)m << 32) | rdlane((uint32_t)mk, l));
-                            if (lane == l) dk = 0xFFFFFFFFu;
+                            const uint32_t m2 = wave_min_u32(dk == m ? (uint32_t)mk : 0xFFFFFFFFu);
+                            pkey[q] = m == 0xFFFFFFFFu ? KEYMAX : (((uint64_t)m << 32) | m2);
+                            if (mk == pkey[q]) mk = ~0ull;
+                            if (lv_of(pkey[q]) >= Tlv) pkey[q] = KEYMAX;
                         }
                     }
                     if (pkey[0] == KEYMAX) {                       // nothing to settle in this wave's blocks right now
@@ -1019,7 +1029,7 @@ __global__ __launch_bounds__(WT) void wide_aug_mc(const WideArgs *__restrict__ b
 #pragma unroll
                     for (int q = 0; q < AP; q++) {
                         pk[q] = pkey[q] != KEYMAX;
-                        pj[q] = (int)(uint32_t)pkey[q];
+                        pj[q] = (int)lid_of(pkey[q]);
                         if (pk[q] && lane == 0) atomicAnd(a.gbmin + (int64_t)(pj[q] >> 6) * MC_REC + 1, ~(1ull << (pj[q] & 63)));
                     }
                     MC_WAIT_VM();                                   // the bits are cleared before the labels are read
@@ -1033,45 +1043,39 @@ __global__ __launch_bounds__(WT) void wide_aug_mc(const WideArgs *__restrict__ b
                         col[q] = COLSENT; val[q] = 0.0f;
                         if (pk[q]) { col[q] = a.cache_col[(int64_t)oi[q] * KC + lane]; val[q] = a.cache_val[(int64_t)oi[q] * KC + lane]; }
                     }
-                    unsigned long long old[AP];
-                    uint32_t co[AP];
+                    unsigned long long old[AP], co[AP];
                     bool off[AP], dn[AP];
-                    const uint32_t Tnow = uni((uint32_t)(ld_sc1(&c->T) >> 32));
+                    const unsigned long long Tnow = uni(lv_of(ld_sc1(&c->T)));
 #pragma unroll
                     for (int q = 0; q < AP; q++) {
                         off[q] = false; dn[q] = false; old[q] = 0; co[q] = 0;
-                        const uint32_t dord = (uint32_t)(lab[q] >> 32);
-                        if (pk[q] && dord < Tnow) {
+                        const uint32_t dord = (uint32_t)(lab[q] >> 32), kq = (uint32_t)(lab[q] >> 20) & LKMAX;
+                        if (pk[q] && lv_of(lab[q]) < Tnow) {
                             c_proc++;
                             if (is_dense(oi[q])) { dn[q] = true; continue; }
                             const float h = (ca[q] - vp[q]) - ord2f(dord);
-                            const uint32_t lo = dord + 1u;
                             if (lane < KCU && col[q] != COLSENT && (int)col[q] != pj[q]) {
-                                uint32_t cc = f2ord((val[q] - ld_sc1(a.v + col[q])) - h);
-                                cc = cc < lo ? lo : cc;
-                                if (cc <= Tnow) { off[q] = true; co[q] = cc; old[q] = offer((int)col[q], cc, oi[q]); }
+                                const unsigned long long lv = edge_lv(f2ord((val[q] - ld_sc1(a.v + col[q])) - h), dord, kq);
+                                if (lv <= Tnow) { off[q] = true; co[q] = lv; old[q] = offer((int)col[q], lv, oi[q]); }
                             }
                         }
                     }
 #pragma unroll
                     for (int q = 0; q < AP; q++) {
-                        const bool better = off[q] && ((((unsigned long long)co[q] << 32) | (uint32_t)oi[q]) < old[q]);
+                        const bool better = off[q] && (lkey(co[q], (uint32_t)oi[q]) < old[q]);
                         if (__ballot(better) && better) after_offer((int)col[q], co[q], oi[q], old[q]);
                     }
 #pragma unroll
                     for (int q = 0; q < AP; q++) {
                         if (!dn[q]) continue;                      // the owner's cache could not certify: its whole cost row
-                        const uint32_t dord = (uint32_t)(lab[q] >> 32);
+                        const uint32_t dord = (uint32_t)(lab[q] >> 32), kq = (uint32_t)(lab[q] >> 20) & LKMAX;
                         const float h = (ca[q] - vp[q]) - ord2f(dord);
-                        const uint32_t lo = dord + 1u;
                         const float *__restrict__ row = a.cost + wrow_off(a.rowmap, oi[q], a.ld);
                         const int pjq = pj[q], oiq = oi[q];
-                        const uint32_t Tsw = uni((uint32_t)(ld_sc1(&c->T) >> 32));     // (once per sweep: a stale bound only prunes less)
+                        const unsigned long long Tsw = uni(lv_of(ld_sc1(&c->T)));        // (once per sweep: a stale bound only prunes less)
                         wave_row_sweep(row, n, lane, [&](int cidx, float x) {
-                            uint32_t cc = f2ord((x - ld_sc1(a.v + cidx)) - h);
-                            cc = cc < lo ? lo : cc;
-                            if (cidx != pjq && cc <= Tsw &&
-                                ((((unsigned long long)cc << 32) | (uint32_t)oiq) < ld_sc1(a.label + cidx))) relax_to(cidx, cc, oiq);
+                            const unsigned long long lv = edge_lv(f2ord((x - ld_sc1(a.v + cidx)) - h), dord, kq);
+                            if (cidx != pjq && lv <= Tsw && (lkey(lv, (uint32_t)oiq) < ld_sc1(a.label + cidx))) relax_to(cidx, lv, oiq);
                         });
                         c_dense++;
                     }
@@ -1086,10 +1090,12 @@ __global__ __launch_bounds__(WT) void wide_aug_mc(const WideArgs *__restrict__ b
                         const int b = pj[q] >> 6, cc = b * 64 + lane;
                         const bool db = cc < n && ((uni(ld_sc1(a.gbmin + (int64_t)b * MC_REC + 1)) >> lane) & 1ull);
                         if (__ballot(db)) {
-                            const uint32_t dk = db ? (uint32_t)(ld_sc1(a.label + cc) >> 32) : 0xFFFFFFFFu;
+                            const unsigned long long lb = db ? ld_sc1(a.label + cc) : ~0ull;
+                            const uint32_t dk = (uint32_t)(lb >> 32);
                             const uint32_t m = wave_min_u32(dk);
-                            const int l = __ffsll((unsigned long long)__ballot(dk == m)) - 1;
-                            if (lane == 0) atomicMin(a.gbmin + (int64_t)b * MC_REC, ((unsigned long long)m << 32) | (uint32_t)(b * 64 + l));
+                            const uint32_t lo2 = (db && dk == m) ? (((uint32_t)lb & 0xFFF00000u) | (uint32_t)cc) : 0xFFFFFFFFu;
+                            const uint32_t m2 = wave_min_u32(lo2);
+                            if (lane == 0) atomicMin(a.gbmin + (int64_t)b * MC_REC, ((unsigned long long)m << 32) | m2);
                         }
                     }
                 }
@@ -1108,7 +1114,8 @@ __global__ __launch_bounds__(WT) void wide_aug_mc(const WideArgs *__restrict__ b
             const int nt = uni(ld_sc1(&c->ntouch));
             for (int q = gtid; q < nt; q += GT) {
                 const int k = ld_sc1(a.touched + q);
-                const uint32_t dord = (uint32_t)(ld_sc1(a.label + k) >> 32);
+                const unsigned long long lbk = ld_sc1(a.label + k);
+                const uint32_t dord = (uint32_t)(lbk >> 32);
                 if (dord < Dord && is_asg(k)) {
                     const int i = ld_sc1(a.colsol + k);
                     if (!is_dense(i)) {
@@ -1118,7 +1125,7 @@ __global__ __launch_bounds__(WT) void wide_aug_mc(const WideArgs *__restrict__ b
                             atomicOr(a.gdense + (i >> 5), 1u << (i & 31));
                             atomicOr(a.gbmin + (int64_t)(k >> 6) * MC_REC + 1, 1ull << (k & 63));
                             MC_WAIT_VM();
-                            atomicMin(a.gbmin + (int64_t)(k >> 6) * MC_REC, ((unsigned long long)dord << 32) | (uint32_t)k);
+                            atomicMin(a.gbmin + (int64_t)(k >> 6) * MC_REC, lkey(lv_of(lbk), (uint32_t)k));
                             atomicAdd(&c->fail, 1);
                         }
                     }
@@ -1130,8 +1137,8 @@ __global__ __launch_bounds__(WT) void wide_aug_mc(const WideArgs *__restrict__ b
             const int fail = uni(ld_sc1(&c->fail)), doroot = uni(ld_sc1(&c->doroot));
             if (doroot)
                 for (int cc = gtid; cc < n; cc += GT) {
-                    const uint32_t co = f2ord(frow[cc] - ld_sc1(a.v + cc));
-                    if (co <= (uint32_t)(ld_sc1(&c->T) >> 32) && ((((unsigned long long)co << 32) | (uint32_t)fr) < ld_sc1(a.label + cc))) relax_to(cc, co, fr);
+                    const unsigned long long lv = (unsigned long long)f2ord(frow[cc] - ld_sc1(a.v + cc)) << 12;
+                    if (lv <= lv_of(ld_sc1(&c->T)) && (lkey(lv, (uint32_t)fr) < ld_sc1(a.label + cc))) relax_to(cc, lv, fr);
                 }
             mc_barrier(c, G, gen);
             if (gtid == 0) { if (fail) st_sc1(&c->anydense, 1); st_sc1(&c->fail, 0); st_sc1(&c->doroot, 0); }
@@ -1144,7 +1151,7 @@ __global__ __launch_bounds__(WT) void wide_aug_mc(const WideArgs *__restrict__ b
         if (Tk == ~0ull || ld_sc1(&c->err)) { if (gtid == 0 && Tk == ~0ull) atomicExch(&c->err, 1); break; }
         const uint32_t Dord = (uint32_t)(Tk >> 32);
         const float D = ord2f(Dord);
-        const int sink = (int)(uint32_t)Tk;
+        const int sink = (int)lid_of(Tk);
         const int nt = uni(ld_sc1(&c->ntouch));
         const int anydense = uni(ld_sc1(&c->anydense));
         int myscans = 0;
@@ -1162,7 +1169,7 @@ __global__ __launch_bounds__(WT) void wide_aug_mc(const WideArgs *__restrict__ b
         if (gtid == 0) {
             int j = sink;
             for (;;) {
-                const int i = (int)(uint32_t)ld_sc1(a.label + j);
+                const int i = (int)lid_of(ld_sc1(a.label + j));
                 const int jn = ld_sc1(a.rowsol + i);
                 st_sc1(a.colsol + j, (int32_t)i); st_sc1(a.rowsol + i, (int32_t)j); st_sc1(a.cassign + j, a.cost[wrow_off(a.rowmap, i, a.ld) + j]);
                 c_hops++;

@@ -41,6 +41,7 @@ typedef struct {
 } jv_wide_stats;
 
 #define JV_WIDE_ROUNDS(n) (4096 + (int64_t)(n) / 4)
+#define JV_WIDE_KMAX 4095            /* tight hops a label counts before the distance itself is stepped */
 
 int jv_oracle_wide_f32(int n, const float *cost, int32_t *rowsol, int32_t *colsol, float *u, float *v,
                        double *total_f64, float *total_T, jv_wide_stats *st, int64_t max_rounds, int stop_phase);

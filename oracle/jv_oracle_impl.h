@@ -250,17 +250,23 @@ int FN(jv_oracle_)(int n, const T *restrict cost, int32_t *restrict rowsol,
  *                       order in which rows are visited cannot matter.
  *  AUGMENTATION         free rows in ascending order, each by a shortest-path search whose labels are the
  *                       UNIQUE fixed point of a monotone system, so that any label-correcting schedule
- *                       (speculative, parallel) and Dijkstra's order below agree bit for bit:
- *                         root f:               d[j] = fl(c[f][j] - v[j])
- *                         column jp (label dp, owner i), h = fl(fl(c[i][jp] - v[jp]) - dp):
- *                                               cand(j) = max( fl(fl(c[i][j] - v[j]) - h), succ(dp) )
- *                       succ = next representable value: a label is strictly larger than its predecessor's,
- *                       which (a) removes the rounding anomaly cand < dp, (b) makes equal-label columns
- *                       independent of each other, (c) makes every predecessor chain acyclic on duplicated
- *                       rows, where tight cycles are the rule.  pred[j] = the LOWEST row among those attaining
- *                       d[j].  The search ends at the unassigned column with the smallest (label, column);
- *                       columns with a label < that distance get the classic price update, clamped so that a
- *                       price never rises: v[k] = min(v[k], fl(fl(v[k] + d[k]) - dist)).
+ *                       (speculative, parallel) and Dijkstra's order below agree bit for bit.  A label is a pair
+ *                       (distance d, tight-hop count k), ordered lexicographically:
+ *                         root f:               (fl(c[f][j] - v[j]), 0)
+ *                         column jp with label (dp, kp), owner i, h = fl(fl(c[i][jp] - v[jp]) - dp),
+ *                         raw = fl(fl(c[i][j] - v[j]) - h):
+ *                                               raw > dp  ->  (raw, 0)
+ *                                               else      ->  (dp, kp + 1)      [a tight edge: the distance does not grow]
+ *                       (kp = JV_WIDE_KMAX: (succ(dp), 0) instead, succ = next representable value).  Every label is
+ *                       strictly larger than its predecessor's, the edge functions are monotone: ONE fixed point,
+ *                       equal labels cannot influence each other, predecessor chains are acyclic even on duplicated
+ *                       rows, where tight cycles are the rule -- and the DISTANCES carry no bias: the rounding anomaly
+ *                       raw < dp is clamped to dp, nothing is added (a first version clamped to succ(dp): one ulp per
+ *                       tight hop, and searches run along thousands of tight edges the earlier price updates left --
+ *                       at n = 70 000 the sum was enough to miss the optimum by 2e-8).  pred[j] = the LOWEST row among
+ *                       those attaining the label.  The search ends at the unassigned column with the smallest
+ *                       (label, column); columns with a distance < that distance get the classic price update,
+ *                       clamped so that a price never rises: v[k] = min(v[k], fl(fl(v[k] + d[k]) - dist)).
  * ===================================================================================================== */
 static inline T FN(succ_)(T x) {
 #if defined(JV_T_IS_FLOAT)
@@ -287,13 +293,14 @@ int FN(jv_oracle_wide_)(int n, const T *restrict cost, int32_t *restrict rowsol,
     int32_t *imin = (int32_t *)malloc(N * sizeof(int32_t));
     int32_t *bidrow = (int32_t *)malloc(N * sizeof(int32_t));
     int32_t *touched = (int32_t *)malloc(N * sizeof(int32_t));
+    int32_t *kk = (int32_t *)malloc(N * sizeof(int32_t));
     uint8_t *scanned = (uint8_t *)malloc(N);
     uint8_t *active = (uint8_t *)calloc(N, 1);
     T *d = (T *)malloc(N * sizeof(T));
     T *bidp = (T *)malloc(N * sizeof(T));
     T *margin = (T *)malloc(N * sizeof(T));
     int rc = JV_OK;
-    if (!freerows || !matches || !pred || !imin || !bidrow || !touched || !scanned || !active || !d || !bidp || !margin) { rc = JV_ERR_NOMEM; goto done; }
+    if (!freerows || !matches || !pred || !imin || !bidrow || !touched || !kk || !scanned || !active || !d || !bidp || !margin) { rc = JV_ERR_NOMEM; goto done; }
 
     /* ---- COLUMN REDUCTION (identical to the classic mode) ---- */
     for (int j = 0; j < n; j++) { v[j] = cost[j]; imin[j] = 0; }
@@ -367,23 +374,27 @@ int FN(jv_oracle_wide_)(int n, const T *restrict cost, int32_t *restrict rowsol,
         s.free_after_arr = numfree;
         if (stop_phase == 2) goto finish;
 
-        /* ---- AUGMENTATION: succ-clamped shortest paths (see the header of this mode) ---- */
+        /* ---- AUGMENTATION: shortest paths with (distance, tight-hop count) labels (see the header of this mode) ---- */
         for (int f = 0; f < numfree; f++) {
             const int freerow = freerows[f];
             const T *restrict cf = cost + (size_t)freerow * N;
-            for (int j = 0; j < n; j++) { d[j] = cf[j] - v[j]; pred[j] = freerow; scanned[j] = 0; }
+            for (int j = 0; j < n; j++) { d[j] = cf[j] - v[j]; kk[j] = 0; pred[j] = freerow; scanned[j] = 0; }
             s.scans_aug_init++;
             int endofpath = -1;
             T dist = 0;
             for (;;) {
+                /* pick: lexicographic min of (d, k) over the unscanned columns; among those an unassigned column first, else the lowest */
                 T dmin = (T)INFINITY;
                 for (int j = 0; j < n; j++) {
                     T dj = scanned[j] ? (T)INFINITY : d[j];
                     dmin = dj < dmin ? dj : dmin;
                 }
+                int kmin = INT32_MAX;
+                for (int j = 0; j < n; j++)
+                    if (!scanned[j] && d[j] == dmin && kk[j] < kmin) kmin = kk[j];
                 int jpick = -1, jfirst = -1;
                 for (int j = 0; j < n; j++) {
-                    if (!scanned[j] && d[j] == dmin) {
+                    if (!scanned[j] && d[j] == dmin && kk[j] == kmin) {
                         if (jfirst < 0) jfirst = j;
                         if (colsol[j] < 0) { jpick = j; break; }
                     }
@@ -395,16 +406,24 @@ int FN(jv_oracle_wide_)(int n, const T *restrict cost, int32_t *restrict rowsol,
                 const int i = colsol[jpick];
                 const T *restrict ci = cost + (size_t)i * N;
                 const T h = (ci[jpick] - v[jpick]) - dmin;
-                const T lo = FN(succ_)(dmin);
+                /* a candidate that does not exceed the label it comes from (a tight edge; rounding can even put it below) takes
+                 * that label and one more tight hop; JV_WIDE_KMAX tight hops in a row: the next representable distance instead */
+                const T dtight = kmin < JV_WIDE_KMAX ? dmin : FN(succ_)(dmin);
+                const int ktight = kmin < JV_WIDE_KMAX ? kmin + 1 : 0;
                 for (int j = 0; j < n; j++) {
-                    T v2 = (ci[j] - v[j]) - h;
-                    v2 = v2 < lo ? lo : v2;
-                    const int upd = ((v2 < d[j]) | ((v2 == d[j]) & (i < pred[j]))) & !scanned[j];
-                    d[j] = upd ? v2 : d[j];
+                    const T raw = (ci[j] - v[j]) - h;
+                    const int strict = raw > dmin;
+                    const T nd = strict ? raw : dtight;
+                    const int nk = strict ? 0 : ktight;
+                    const int less = (nd < d[j]) | ((nd == d[j]) & (nk < kk[j]));
+                    const int same = (nd == d[j]) & (nk == kk[j]);
+                    const int upd = (less | (same & (i < pred[j]))) & !scanned[j];
+                    d[j] = upd ? nd : d[j];
+                    kk[j] = upd ? nk : kk[j];
                     pred[j] = upd ? i : pred[j];
                 }
-                s.scans_aug_relax++;
             }
+            for (int j = 0; j < n; j++) s.scans_aug_relax += scanned[j] && d[j] < dist;     /* (columns settled below the final distance) */
             for (int j = 0; j < n; j++)
                 if (scanned[j] && d[j] < dist) { const T nv = (v[j] + d[j]) - dist; if (nv < v[j]) v[j] = nv; }
             int i;
@@ -437,7 +456,7 @@ finish:
     }
     if (st) *st = s;
 done:
-    free(freerows); free(matches); free(pred); free(imin); free(bidrow); free(touched); free(scanned); free(active);
+    free(freerows); free(matches); free(pred); free(imin); free(bidrow); free(touched); free(kk); free(scanned); free(active);
     free(d); free(bidp); free(margin);
     return rc;
 }
