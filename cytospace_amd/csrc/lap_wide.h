@@ -6,7 +6,7 @@ namespace cyto {
 
 // One problem of a batch.  Every pointer is device memory; the work arrays are the driver's (lap_jv.hip: F32Job).
 //   v, u, cassign   [n] prices, row duals (written at the end), c[colsol[j]][j] per column
-//   label           [n] 64-bit search labels (ordered distance << 32 | predecessor row); all-ones between searches
+//   label           [n] 64-bit search labels (ordered distance << 32 | tight-hop count << 20 | predecessor row); all-ones between searches
 //   bid             [n] 64-bit bids of a row-reduction round (ordered price << 32 | row); all-ones between rounds
 //   rowsol, colsol  [n] (-1 = free / unassigned), matches [n] columns claimed per row by the column reduction
 //   act0, act1      [n] active-row lists of the row-reduction rounds;  freerows [n];  touched [n] columns labelled in a search

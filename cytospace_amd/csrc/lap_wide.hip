@@ -13,7 +13,7 @@
 //              active in the next round.  One 16-wave workgroup per problem, a wave per bidding row, 16 bids in flight;
 //              a round is a pure function of the state, so no visiting order exists to be reproduced.
 //   wide_aug   AUGMENTATION: per free row a shortest-path search whose labels are the unique fixed point of a monotone
-//              system (succ-clamped candidates), so the search is run SPECULATIVELY: every round each of the 16 waves
+//              system ((distance, tight-hop count) labels), so the search is run SPECULATIVELY: every round each of the 16 waves
 //              settles the best unsettled column of the column blocks it owns and relaxes that column's owner row from
 //              its row cache; a label that later improves is simply settled again.  Any schedule reaches the oracle's
 //              Dijkstra labels.  Row caches certify the scans (floor > final distance, checked when the search has
@@ -497,9 +497,9 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// AUGMENTATION (oracle/jv_oracle_impl.h, wide mode): succ-clamped shortest paths, run speculatively.
+// AUGMENTATION (oracle/jv_oracle_impl.h, wide mode): shortest paths with (distance, tight-hop count) labels, run speculatively.
 //
-// Per column (global, L2): label = (ordered distance << 32 | predecessor row), all-ones = unlabelled; an atomic min on it
+// Per column (global, L2): label = (ordered distance << 32 | tight hops << 20 | predecessor row), all-ones = unlabelled; an atomic min on it
 // keeps the smallest distance and, among equal distances, the lowest row -- the oracle's pred.
 // In LDS: per 64-column block the smallest (distance, column) among its DIRTY columns (labelled, assigned, not settled at
 // their current label), a dirty bit and an assigned bit per column, a dense bit per row (its cache could not certify the
@@ -518,9 +518,11 @@ bool wide_aug_vlds(int n) { return n <= 65534 && wide_aug_lds_bytes(n, true) + 4
 size_t wide_aug_lds_bytes(int n) { return wide_aug_lds_bytes(n, wide_aug_vlds(n)); }
 
 struct AugShared {
-    unsigned long long T;          // best unassigned column: (ordered distance << 32 | column)
+    unsigned long long T;          // best unassigned column: (ordered distance << 32 | tight hops << 20 | column)
     int ntouch, any[2], fail, anydense, rootdense, doroot, f, err;
     int scans;
+    int st_row[64], st_col[64];    // one-edge searches: their results, stored to global memory 64 at a time
+    float st_val[64];
 };
 
 // VLDS: prices (f32) and column owners (u16) also in LDS (every update goes to both copies), as in wide_arr.
@@ -584,27 +586,51 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
         // ---- wave 0 disposes of the searches that end at once: the free row's best cached column is unassigned and its
         // cache certifies that (no column settled, no price changes: the path is one edge) ----
         if (w == 0) {
+            // a two-deep pipeline over the free list (35 000 such searches at c3): while search f is decided, the prices of search
+            // f + 1's cached columns and the cache row of search f + 2 are in flight -- prices do not change in this loop
+            auto row_of = [&](int ff) -> int { return ff < numfree ? uni(a.freerows[ff]) : -1; };
+            auto flush_one_edge = [&](int cnt) {
+                if (lane < cnt) {
+                    const int r = s.st_row[lane], cc = s.st_col[lane];
+                    a.rowsol[r] = cc; a.colsol[cc] = r; a.cassign[cc] = s.st_val[lane];
+                }
+            };
+            int nst = 0;
+            int fr1 = row_of(f), fr2 = row_of(f + 1);
+            uint32_t col1 = COLSENT, col2 = COLSENT;
+            float val1 = 0.0f, val2 = 0.0f, vv1 = 0.0f;
+            if (fr1 >= 0) { col1 = a.cache_col[(int64_t)fr1 * KC + lane]; val1 = a.cache_val[(int64_t)fr1 * KC + lane]; }
+            if (fr2 >= 0) { col2 = a.cache_col[(int64_t)fr2 * KC + lane]; val2 = a.cache_val[(int64_t)fr2 * KC + lane]; }
+            if (fr1 >= 0 && lane < KCU && col1 != COLSENT) vv1 = getv((int)col1);
             while (f < numfree) {
-                const int fr = a.freerows[f];
-                const uint32_t col = a.cache_col[(int64_t)fr * KC + lane];
-                const float val = a.cache_val[(int64_t)fr * KC + lane];
+                const int fr = fr1;
+                const uint32_t col = col1;
+                const float val = val1, vv = vv1;
+                // advance the pipeline: search f + 1's prices, search f + 2's cache row
+                fr1 = fr2; col1 = col2; val1 = val2;
+                vv1 = (fr1 >= 0 && lane < KCU && col1 != COLSENT) ? getv((int)col1) : 0.0f;
+                fr2 = row_of(f + 2);
+                if (fr2 >= 0) { col2 = a.cache_col[(int64_t)fr2 * KC + lane]; val2 = a.cache_val[(int64_t)fr2 * KC + lane]; }
                 const float tau = rdlane(val, KCU);
                 const bool valid = lane < KCU && col != COLSENT;
-                const uint32_t od = valid ? f2ord(val - getv((int)col)) : 0xFFFFFFFFu;
+                const uint32_t od = valid ? f2ord(val - vv) : 0xFFFFFFFFu;
                 const uint32_t omin = wave_min_u32(od);
                 const bool un = valid && od == omin && !is_asg((int)col);
                 const uint64_t mu = __ballot(un);
                 if (!(omin != 0xFFFFFFFFu && mu && tau > ord2f(omin))) break;
                 const int l = __ffsll((unsigned long long)mu) - 1;     // cache rows are sorted by column: the lowest such column
                 if (lane == l) {
-                    a.rowsol[fr] = (int)col; a.colsol[col] = fr; a.cassign[col] = val;
+                    // (no global store in the loop: a load is only returned after the stores issued before it are acknowledged, so
+                    //  three stores per search made every search wait for the previous one's)
+                    s.st_row[nst] = fr; s.st_col[nst] = (int)col; s.st_val[nst] = val;
                     if (VLDS) s_cs[col] = (uint16_t)fr;
                     atomicOr(&asg[col >> 5], 1u << (col & 31));
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 c_trivial++; c_hops++;
                 f++;
+                if (++nst == 64) { flush_one_edge(nst); nst = 0; }
             }
+            flush_one_edge(nst);
             if (lane == 0) s.f = f;
         }
         __syncthreads();

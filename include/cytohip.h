@@ -124,7 +124,7 @@ typedef struct {
     int32_t mode;               /* 0: default.  1: the chain solver (classic Gauss-Seidel order: reduction transfer and augmenting row
                                    reduction row after row, Dijkstra one column per step -- oracle/jv_oracle_impl.h, first half).
                                    2: the wide solver (Jacobi reduction transfer, Jacobi rounds of row reduction, speculative
-                                   succ-clamped shortest paths -- same file, "WIDE MODE"; float32).  Both reach the same optimum;
+                                   shortest paths with (distance, tight-hop) labels -- same file, "WIDE MODE"; float32).  Both reach the same optimum;
                                    the duals and, where the optimum is not unique, the particular optimal assignment differ */
     int32_t wide_rounds;        /* wide solver: budget of row-reduction rounds.  0: 4096 + n / 4.  -1: none */
     int32_t wide_groups;        /* wide solver, one problem: workgroups that run a search together, asynchronously, with the search
