@@ -3036,7 +3036,7 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
         DevBuf d_wa;
         if ((rc = d_wa.alloc(sizeof(WideArgs) * nl, stream))) return rc;
         CYTO_HIP(hipMemcpyAsync(d_wa.p, h_wa.data(), sizeof(WideArgs) * nl, hipMemcpyHostToDevice, stream));
-        if ((rc = wide_launch_rt(d_wa.as<WideArgs>(), nl, n, stream)) || (rc = wide_launch_arr(d_wa.as<WideArgs>(), nl, n, stream))) return rc;
+        if ((rc = wide_launch_rt(d_wa.as<WideArgs>(), nl, n, stream)) || (rc = wide_launch_arr(d_wa.as<WideArgs>(), nl, n, stream, pl.wide_rounds))) return rc;
         CYTO_HIP(hipEventRecord(ev_arr_done, stream));
         if ((rc = build_caches())) return rc;                      // fresh floors against the prices the augmentation starts from
         if ((rc = wide_launch_aug(d_wa.as<WideArgs>(), nl, n, stream, h_wa[0].mc_groups))) return rc;

@@ -12,7 +12,8 @@ namespace cyto {
 //   act0, act1      [n] active-row lists of the row-reduction rounds;  freerows [n];  touched [n] columns labelled in a search
 //   slot_j, slot_p, slot_c  [n] per active slot: the bid's column (-1 = retired), price, raw cost of that entry
 //   cache_col/val   [n][64] row caches (lap_jv.hip: build_row_caches)
-//   misc            512 bytes: +4 status, +8 double total, +16 long long counters[] (lap_jv.hip indices), +160.. wide counters
+//   misc            512 bytes: +4 status, +8 double total, +16 long long counters[] (lap_jv.hip indices), +160.. wide counters,
+//                   +256 phase timers, +384 the control block the first row-reduction rounds leave for wide_arr
 //   gbmin, gdirty, gasg, gdense, ctl   the multi-workgroup augmentation's shared state (global memory; wide_aug_mc): per 64-column
 //                   block the smallest dirty label, dirty / assigned / dense bitmaps, a 256-byte control block (zeroed by the host)
 //   mc_groups       workgroups that search one problem together (0: the one-workgroup kernel)
@@ -36,7 +37,7 @@ enum { WC_ROUNDS = 0, WC_BIDS, WC_RETIRED, WC_ACTIVE_LEFT, WC_FREE_ARR, WC_DENSE
 size_t wide_aug_lds_bytes(int n);
 // phases, each one launch for the whole batch (d_args: device array of nb WideArgs)
 int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream);        // Jacobi reduction transfer (v0 snapshot in cassign)
-int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream);       // Jacobi rounds of augmenting row reduction + free list
+int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, long long max_rounds);   // Jacobi rounds of augmenting row reduction + free list
 int wide_launch_aug(const WideArgs *d_args, int nb, int n, hipStream_t stream, int mc_groups);   // succ-clamped shortest-path augmentation, duals, total
 int wide_mc_groups(int nb, int n);                                                     // how many workgroups search one problem together (0: one)
 size_t wide_mc_state_bytes(int n);                                                     // gbmin + 3 bitmaps + control block

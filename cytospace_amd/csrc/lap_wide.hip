@@ -287,6 +287,99 @@ template <bool VLDS> struct ArrCtx {
     }
 };
 
+// The first rounds on the whole chip.  A problem starts with a third of its rows free (column reduction leaves n/e of them;
+// c3: 45 000 of 50 000): thousands of independent bids per round, which one workgroup would take one by one.  wide_arr_head_* run
+// round r as three launches over all CUs -- bids (a wave per active row, prices and owners read from L2), resolution (a thread per
+// bid), reset of the bid words -- and leave the active list, the round count and the counters in the control block at misc + 384,
+// where wide_arr picks them up.  The same round as in wide_arr (a pure function of the state).
+struct ArrHead { int cnt[2]; int started, free_cr; long long round, bids; int retired, dense; };
+constexpr int HEADB = 256;             // threads of the head kernels' workgroups
+
+__global__ __launch_bounds__(HEADB) void wide_arr_head_init(const WideArgs *__restrict__ batch) {
+    const WideArgs a = load_wide_args(batch, blockIdx.y);
+    ArrHead *h = reinterpret_cast<ArrHead *>(a.misc + 384);
+    const int n = a.n, lane = threadIdx.x & 63;
+    for (int i0 = blockIdx.x * HEADB; i0 < n; i0 += gridDim.x * HEADB) {
+        const int i = i0 + threadIdx.x;
+        const bool fr = i < n && a.rowsol[i] < 0;
+        const uint64_t m = __ballot(fr);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&h->cnt[0], __popcll(m));
+        base = __shfl(base, 0);
+        if (fr) a.act0[base + __popcll(m & lanemask_lt())] = i;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) h->started = 1;
+}
+
+__global__ __launch_bounds__(HEADB) void wide_arr_head_bid(const WideArgs *__restrict__ batch, int r) {
+    extern __shared__ __align__(16) unsigned char w_smem[];
+    ArrShared &s = *reinterpret_cast<ArrShared *>(w_smem);
+    ArrCtx<false> cx;
+    cx.a = load_wide_args(batch, blockIdx.y);
+    const WideArgs &a = cx.a;
+    ArrHead *h = reinterpret_cast<ArrHead *>(a.misc + 384);
+    const int cur = r & 1, na = h->cnt[cur];
+    // the list this round appends to starts empty -- also when there is nothing to do: the launches after an empty round must
+    // find an empty list too, not the one before last
+    if (blockIdx.x == 0 && threadIdx.x == 0) { h->cnt[cur ^ 1] = 0; if (r == 0) h->free_cr = na; }
+    if (na == 0) return;
+    const int lane = threadIdx.x & 63, w = uni((int)(threadIdx.x >> 6));
+    cx.s_v = nullptr; cx.s_cs = nullptr; cx.s = &s; cx.lane = lane;
+    if (threadIdx.x == 0) { s.retired = 0; s.dense = 0; }
+    __syncthreads();
+    const int32_t *A = cur ? a.act1 : a.act0;
+    const int gw = blockIdx.x * (HEADB / 64) + w, nw = gridDim.x * (HEADB / 64);
+    for (int slot = gw; slot < na; slot += nw) {
+        const int i = uni(A[slot]);
+        uint32_t col = a.cache_col[(int64_t)i * KC + lane];
+        float val = a.cache_val[(int64_t)i * KC + lane];
+        int jt, i0; float pt, ct;
+        cx.bid_of(i, w, col, val, jt, pt, ct, i0);
+        if (lane == 0) {
+            if (jt < 0) atomicAdd(&s.retired, 1);
+            else atomicMin(a.bid + jt, (unsigned long long)mkkey(pt, (uint32_t)i));
+            a.slot_j[slot] = jt; a.slot_p[slot] = pt; a.slot_c[slot] = ct;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { if (s.retired) atomicAdd(&h->retired, s.retired); if (s.dense) atomicAdd(&h->dense, s.dense); }
+}
+
+__global__ __launch_bounds__(HEADB) void wide_arr_head_resolve(const WideArgs *__restrict__ batch, int r) {
+    ArrCtx<false> cx;
+    cx.a = load_wide_args(batch, blockIdx.y);
+    const WideArgs &a = cx.a;
+    ArrHead *h = reinterpret_cast<ArrHead *>(a.misc + 384);
+    const int cur = r & 1, na = h->cnt[cur];
+    cx.s_v = nullptr; cx.s_cs = nullptr; cx.s = nullptr; cx.lane = threadIdx.x & 63;
+    const int32_t *A = cur ? a.act1 : a.act0;
+    int32_t *B = cur ? a.act0 : a.act1;
+    for (int slot = blockIdx.x * HEADB + threadIdx.x; slot < na; slot += gridDim.x * HEADB) {
+        const int jt = a.slot_j[slot];
+        if (jt < 0) continue;                                    // retired: stays free, bids no more
+        const int i = A[slot];
+        if ((uint32_t)a.bid[jt] == (uint32_t)i) {
+            const int i0 = a.colsol[jt];
+            cx.apply(i, jt, a.slot_p[slot], a.slot_c[slot], i0);
+            if (i0 >= 0) B[atomicAdd(&h->cnt[cur ^ 1], 1)] = i0;
+        } else {
+            B[atomicAdd(&h->cnt[cur ^ 1], 1)] = i;
+        }
+    }
+}
+
+__global__ __launch_bounds__(HEADB) void wide_arr_head_reset(const WideArgs *__restrict__ batch, int r) {
+    const WideArgs a = load_wide_args(batch, blockIdx.y);
+    ArrHead *h = reinterpret_cast<ArrHead *>(a.misc + 384);
+    const int cur = r & 1, na = h->cnt[cur];
+    if (na == 0) return;
+    for (int slot = blockIdx.x * HEADB + threadIdx.x; slot < na; slot += gridDim.x * HEADB) {
+        const int jt = a.slot_j[slot];
+        if (jt >= 0) a.bid[jt] = ~0ull;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { h->bids += na; h->round += 1; }     // (read by nobody before wide_arr)
+}
+
 template <bool VLDS>
 __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batch) {
     extern __shared__ __align__(16) unsigned char w_smem[];
@@ -304,24 +397,32 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
         for (int j = tid; j < n; j += WT) { cx.s_v[j] = a.v[j]; const int o = a.colsol[j]; cx.s_cs[j] = o < 0 ? (uint16_t)0xFFFFu : (uint16_t)o; }
     __syncthreads();
 
-    // the active list: every free row (in any order -- a round does not depend on it)
-    for (int i0 = 0; i0 < n; i0 += WT) {
-        const int i = i0 + tid;
-        const bool fr = i < n && a.rowsol[i] < 0;
-        const uint64_t m = __ballot(fr);
-        int base = 0;
-        if (lane == 0 && m) base = atomicAdd(&s.cnt[0], __popcll(m));
-        base = __shfl(base, 0);
-        if (fr) a.act0[base + __popcll(m & lanemask_lt())] = i;
-    }
-    __syncthreads();
-    const int free_cr = s.cnt[0];
+    // the active list: what the first rounds on the whole chip left (wide_arr_head_*), else every free row (in any order -- a
+    // round does not depend on it)
+    const ArrHead *h = reinterpret_cast<const ArrHead *>(a.misc + 384);
+    const bool headed = h->started != 0;
     int cur = 0;
     long long round = 0, bids = 0;
+    if (headed) {
+        round = h->round; bids = h->bids; cur = (int)(round & 1);
+        if (tid == 0) { s.cnt[cur] = h->cnt[cur]; s.retired = h->retired; s.dense = h->dense; }
+    } else {
+        for (int i0 = 0; i0 < n; i0 += WT) {
+            const int i = i0 + tid;
+            const bool fr = i < n && a.rowsol[i] < 0;
+            const uint64_t m = __ballot(fr);
+            int base = 0;
+            if (lane == 0 && m) base = atomicAdd(&s.cnt[0], __popcll(m));
+            base = __shfl(base, 0);
+            if (fr) a.act0[base + __popcll(m & lanemask_lt())] = i;
+        }
+    }
+    __syncthreads();
+    const int free_cr = headed ? h->free_cr : s.cnt[0];
     const long long t_start = wall_clock64();
     if (tid == 0) reinterpret_cast<long long *>(a.misc + 256)[5] = t_start - t_kernel0;
     long long t_list = 0, t_chain = 0, n_list = 0, n_chain = 0, n_deal = 0;
-    int32_t *A = a.act0, *B = a.act1;
+    int32_t *A = cur ? a.act1 : a.act0, *B = cur ? a.act0 : a.act1;
     int na = free_cr;
     // ================= LIST rounds =================
     for (;;) {
@@ -1262,7 +1363,21 @@ int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream) {
     return CYTO_OK;
 }
 
-int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream) {
+int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, long long max_rounds) {
+    // the first rounds, with thousands of bids each, on the whole chip; the long tail on one workgroup per problem
+    if (n >= 4096 && max_rounds > 0) {
+        const int rounds = (int)std::min<long long>(8, max_rounds);
+        const int bx = std::max(1, std::min((n + 255) / 256, 1024 / std::max(1, std::min(nb, 8))));
+        int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(wide_arr_head_bid));
+        if (rc) return rc;
+        hipLaunchKernelGGL(wide_arr_head_init, dim3(bx, nb), dim3(HEADB), 0, stream, d_args);
+        for (int r = 0; r < rounds; r++) {
+            hipLaunchKernelGGL(wide_arr_head_bid, dim3(bx, nb), dim3(HEADB), ARR_SHARED_BYTES, stream, d_args, r);
+            hipLaunchKernelGGL(wide_arr_head_resolve, dim3(bx, nb), dim3(HEADB), 0, stream, d_args, r);
+            hipLaunchKernelGGL(wide_arr_head_reset, dim3(bx, nb), dim3(HEADB), 0, stream, d_args, r);
+        }
+        CYTO_HIP(hipGetLastError());
+    }
     const bool vlds = wide_arr_vlds(n);
     void (*k)(const WideArgs *) = vlds ? wide_arr<true> : wide_arr<false>;
     int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(k));

@@ -480,3 +480,14 @@ def test_one_process_two_devices():
         for k in ("rowsol", "colsol", "u", "v"):
             assert np.array_equal(a[k], b[k]), k
     assert np.array_equal(lap_solve(c, np.float32, device_id=1)["colsol"], jv_oracle(c, np.float32)["colsol"])
+
+
+@pytest.mark.parametrize("rounds", [1, 3, 8, 9, 60])
+def test_wide_first_rounds_on_the_whole_chip(rounds):
+    # from n = 4096 on the first eight row-reduction rounds are three full-chip launches each (wide_arr_head_*), the rest runs in
+    # the one-workgroup kernel: the same rounds, so any budget -- inside the head, at its end, beyond -- gives the oracle's state
+    n = 4300
+    c = np.random.default_rng(n + rounds).random((n, n)).astype(np.float32)
+    _check_wide(c, rounds=rounds)
+    base = -(np.random.default_rng(rounds).random((n // 10, n)) ** 3).astype(np.float32)
+    _check_wide(np.repeat(base, 10, axis=0), rounds=rounds)           # duplicated rows: most bids lose their round

@@ -58,6 +58,10 @@ def main():
         ok &= one(np.repeat(rng.random(((n + 3) // 4, n)), 4, axis=0)[:n].astype(np.float32), "dups")
     for r in (-1, 1, 2, 7, 50):
         ok &= one(rng.random((700, 700)).astype(np.float32), "budget", rounds=r)
+    for r in (1, 3, 8, 9, 40):                       # the first eight rounds run on the whole chip from n = 4096 on
+        ok &= one(rng.random((4200, 4200)).astype(np.float32), "head", rounds=r)
+    c, loc = I.c3_shaped_cost(5000, 10, 3)
+    ok &= one(c, "c3-head")
     c, loc = I.c3_shaped_cost(3000, 10, 3)
     ok &= one(c, "c3-shaped")
     uniq, loc = I.c3_shaped_unique(3000, 10, 3)
