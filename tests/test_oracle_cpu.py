@@ -258,7 +258,7 @@ def test_wide_oracle_stop_phases_expose_the_intermediate_state():
     assert np.all(h[np.arange(len(asg)), a["rowsol"][asg]] <= h.min(1) + 1e-7)
 
 
-@pytest.mark.parametrize("tag", ["u20000", "u50000", "c3s50000", "c4s10000"])
+@pytest.mark.parametrize("tag", ["u20000", "u50000", "u70000", "c3s50000", "c4s10000"])
 def test_wide_large_goldens_are_certified(tag):
     # the wide restatement's answers at true size: certified by their own duals on ALL n^2 entries and equal (slot level; spot
     # level where spot rows are duplicated) to the classic goldens, which scipy and the perturbation re-solve certify
