@@ -397,7 +397,7 @@ def main():
     ap.add_argument("--c4-chunks", type=int, default=256, help="concurrent chunk LAPs in the c4_chunks leg (256 = one chain per CU; 400 MB each)")
     ap.add_argument("--c4-rank-chunks", type=int, default=64, help="chunks per rank in the c4_sharded leg")
     ap.add_argument("--sharded-timeout", type=float, default=600.0, help="watchdog of the c4_sharded leg, seconds")
-    ap.add_argument("--pmc-tag", default="r03a", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
+    ap.add_argument("--pmc-tag", default="r03b", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
     args = ap.parse_args()
 
     # ONE JSON line on stdout: everything else this process (or a library under it: RCCL prints a version banner through C
@@ -547,7 +547,7 @@ def main():
     try:   # HBM bytes from the separate rocprofv3 --pmc pass committed under profiles/ (same n, same instance)
         traffic_source = f"profiles/{args.pmc_tag}_pmc_traffic_n{n}.json"
         if not os.path.exists(os.path.join(ROOT, traffic_source)):
-            traffic_source = f"profiles/r03_pmc_traffic_n{n}.json"
+            traffic_source = f"profiles/r03a_pmc_traffic_n{n}.json"
         pm = json.load(open(os.path.join(ROOT, traffic_source)))
         if pm.get("n") == n:
             key = [k for k in pm["kernels"] if k.startswith(dom[0] + "<") or k.startswith(dom[0] + "(") or k == dom[0]]

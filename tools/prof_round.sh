@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-end measurement set: bench line, rocprofv3 kernel stats of the same command (headline only, and with the extra
 # legs), PMC traffic passes of the 20 000 LAP, PMC pass of the c3-sized cost GEMM.  Usage (gpurun): bash tools/prof_round.sh r02a
-TAG=${1:-r03a}
+TAG=${1:-r03b}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 python $R/bench.py --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
