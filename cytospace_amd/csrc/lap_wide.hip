@@ -489,8 +489,10 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
             if (my[q] >= 0) { col[q] = a.cache_col[(int64_t)my[q] * KC + lane]; val[q] = a.cache_val[(int64_t)my[q] * KC + lane]; }
         }
         int dealt = na;
+#ifdef CYTO_WIDE_PROF
         long long tp[5] = {0, 0, 0, 0, 0}, tm = wall_clock64();
 #define CH_LAP(k) { const long long now_ = wall_clock64(); tp[k] += now_ - tm; tm = now_; }
+#endif
         for (;;) {
 #ifdef CYTO_WIDE_PROF
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -859,7 +861,9 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                 const int k = ld_sc1(a.touched + q);
                 const unsigned long long lbk = ld_sc1(a.label + k);
                 const uint32_t dord = (uint32_t)(lbk >> 32);
-                if (dord < Dord && is_asg(k)) {
+                // every settled column: label below the end's -- also at the end's DISTANCE with fewer tight hops: an uncached
+                // tight edge out of such a column would give (distance, k + 1), possibly below the end's label
+                if (lv_of(lbk) < lv_of(Tk) && is_asg(k)) {
                     const int i = getcs(k);
                     if (!((dense[i >> 5] >> (i & 31)) & 1u)) {
                         const float h = (ld_sc1(a.cassign + k) - getv(k)) - ord2f(dord);
@@ -1243,7 +1247,7 @@ __global__ __launch_bounds__(WT) void wide_aug_mc(const WideArgs *__restrict__ b
                 const int k = ld_sc1(a.touched + q);
                 const unsigned long long lbk = ld_sc1(a.label + k);
                 const uint32_t dord = (uint32_t)(lbk >> 32);
-                if (dord < Dord && is_asg(k)) {
+                if (lv_of(lbk) < lv_of(Tk) && is_asg(k)) {             // (every settled column: see wide_aug)
                     const int i = ld_sc1(a.colsol + k);
                     if (!is_dense(i)) {
                         const float h = (ld_sc1(a.cassign + k) - ld_sc1(a.v + k)) - ord2f(dord);

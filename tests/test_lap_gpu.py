@@ -491,3 +491,21 @@ def test_wide_first_rounds_on_the_whole_chip(rounds):
     _check_wide(c, rounds=rounds)
     base = -(np.random.default_rng(rounds).random((n // 10, n)) ** 3).astype(np.float32)
     _check_wide(np.repeat(base, 10, axis=0), rounds=rounds)           # duplicated rows: most bids lose their round
+
+
+@pytest.mark.parametrize("groups", [0, 3])
+def test_wide_plateaus_every_distance_equal(groups):
+    # small integer costs: after the reductions every reduced cost in play is 0, so every label of a search has the SAME distance
+    # and only the tight-hop counts order them (a breadth-first search in the tight subgraph).  Found by tools/stress_lap.py: the
+    # certificate pass must cover every settled column -- also those at the end's distance with fewer hops --, an uncached tight
+    # edge out of one of them changes which unassigned column is reached first.
+    for seed, n in ((1110, 2270), (7, 900), (8, 1500)):
+        rng = np.random.default_rng(seed)
+        k = int(rng.integers(3, 50)) if seed == 1110 else 4
+        if seed == 1110:
+            n = int(np.random.default_rng(1110).integers(300, 3000))
+            rng = np.random.default_rng(1110); rng.integers(300, 3000)
+            c = rng.integers(0, int(rng.integers(3, 50)), (n, n)).astype(np.float32)
+        else:
+            c = rng.integers(0, k, (n, n)).astype(np.float32)
+        _check_wide(c, opts=dict(wide_groups=groups))

@@ -1,10 +1,12 @@
-"""Randomised parity stress of the default float32 dispatch against the CPU oracle (structures that reach the rare
-paths: duplicated rows, heavy integer ties, few cell types, constant columns, tiny and huge magnitudes)."""
+"""Randomised parity stress against the CPU oracle (structures that reach the rare paths: duplicated rows, heavy integer ties,
+few cell types, constant columns, tiny and huge magnitudes).  Default: the float32 dispatch = the wide solver against the oracle's
+WIDE mode (--groups G: its searches on G workgroups; --rounds R: round budget); --chain: the chain solver against the classic mode;
+--f64: float64 through the streaming chain.  usage: stress_lap.py [seed0 count lo hi] [--chain | --f64] [--groups G] [--rounds R]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from cytospace_amd.lap import lap_solve
-from oracle.jv import jv_oracle
+from oracle.jv import jv_oracle, jv_oracle_wide
 
 def make(kind, n, rng):
     if kind == "uniform":
@@ -26,10 +28,17 @@ def make(kind, n, rng):
     raise ValueError(kind)
 
 if __name__ == "__main__":
+    def flag(name, default):
+        if name in sys.argv:
+            k = sys.argv.index(name); v = int(sys.argv[k + 1]); del sys.argv[k:k + 2]; return v
+        return default
+    groups, rounds = flag("--groups", 0), flag("--rounds", 0)
     f64 = "--f64" in sys.argv                 # float64 through the streaming chain with row caches (chain_variant 1) at any size
-    sys.argv = [a for a in sys.argv if a != "--f64"]
+    chain = "--chain" in sys.argv
+    sys.argv = [a for a in sys.argv if a not in ("--f64", "--chain")]
     dt = np.float64 if f64 else np.float32
-    opts = dict(chain_variant=1) if f64 else None
+    opts = dict(chain_variant=1) if f64 else (dict(mode=1) if chain else dict(mode=2, wide_groups=groups, wide_rounds=rounds))
+    wide = not (f64 or chain)
     seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 36
     lo, hi = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (5200, 8200)
@@ -41,10 +50,19 @@ if __name__ == "__main__":
         kind = kinds[s % len(kinds)]; n = int(rng.integers(lo, hi))
         c = make(kind, n, rng)
         if f64: c = c.astype(np.float64) + (1e-16 * rng.random(c.shape) if s % 2 else 0.0)
-        g = lap_solve(c, dt, return_info=True, opts=opts); o = jv_oracle(c, dt)
-        ok = all(np.array_equal(g[k], o[k]) for k in ("rowsol", "colsol", "u", "v")) and g["info"].row_scans == o["stats"].row_scans
+        g = lap_solve(c, dt, return_info=True, opts=opts)
         i = g["info"]
-        print(f"{s:3d} {kind:9s} n={n}: {'ok ' if ok else 'MISMATCH'} rows read {i.hbm_row_reads} of {i.row_scans} scans, aug scans {i.scans_aug_relax} dense {i.aug_dense_scans} sparse {i.aug_sparse_inits}/{i.augmentations} "
-              f"handover {i.aug_handover} arr refresh {i.dense_refreshes} {i.ms_total:.0f} ms", flush=True)
+        if wide:
+            o = jv_oracle_wide(c, dt, max_rounds=(-1 if rounds == 0 else max(rounds, 0)))
+            st = o["stats"]
+            ok = all(np.array_equal(g[k], o[k]) for k in ("rowsol", "colsol", "u", "v")) and i.scans_arr == st.scans_arr and \
+                i.scans_aug_relax == st.scans_aug_relax and i.wide_rounds == st.arr_rounds and i.wide_retired == st.arr_retired and i.path_hops == st.path_hops
+            print(f"{s:3d} {kind:9s} n={n}: {'ok ' if ok else 'MISMATCH'} rounds {i.wide_rounds} bids {i.scans_arr} free {i.free_after_arr2} settled {i.wide_aug_settled} "
+                  f"for {i.scans_aug_relax} dense ({i.wide_dense_arr},{i.wide_dense_aug}) one-edge {i.wide_trivial} {i.ms_total:.0f} ms", flush=True)
+        else:
+            o = jv_oracle(c, dt)
+            ok = all(np.array_equal(g[k], o[k]) for k in ("rowsol", "colsol", "u", "v")) and g["info"].row_scans == o["stats"].row_scans
+            print(f"{s:3d} {kind:9s} n={n}: {'ok ' if ok else 'MISMATCH'} rows read {i.hbm_row_reads} of {i.row_scans} scans, aug scans {i.scans_aug_relax} dense {i.aug_dense_scans} sparse {i.aug_sparse_inits}/{i.augmentations} "
+                  f"handover {i.aug_handover} arr refresh {i.dense_refreshes} {i.ms_total:.0f} ms", flush=True)
         bad += (not ok)
     print(f"{count} instances, {bad} mismatches, {time.time()-t0:.0f}s")
