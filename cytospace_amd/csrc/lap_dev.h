@@ -57,6 +57,10 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
     x = row_min_u32(x);
     return umin32(umin32(readlane32(x, 0), readlane32(x, 16)), umin32(readlane32(x, 32), readlane32(x, 48)));
 }
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
+    x += dpp32<0xB1>(x); x += dpp32<0x4E>(x); x += dpp32<0x141>(x); x += dpp32<0x140>(x);
+    return readlane32(x, 0) + readlane32(x, 16) + readlane32(x, 32) + readlane32(x, 48);
+}
 template <int CTRL> __device__ __forceinline__ void k2_step(K2 &t) {
     K2 o; o.m1 = dpp64<CTRL>(t.m1); o.m2 = dpp64<CTRL>(t.m2);
     k2_merge(t, o);

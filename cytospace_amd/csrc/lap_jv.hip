@@ -1112,10 +1112,6 @@ __device__ __forceinline__ uint64_t wg_min64(uint64_t x, Scratch2 &s, int &par) 
     par ^= 1;
     return readlane64(r, 0);
 }
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
-    x += dpp32<0xB1>(x); x += dpp32<0x4E>(x); x += dpp32<0x141>(x); x += dpp32<0x140>(x);
-    return readlane32(x, 0) + readlane32(x, 16) + readlane32(x, 32) + readlane32(x, 48);
-}
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // sum over the waves of a wave-uniform int; *base = exclusive prefix for this wave
 __device__ __forceinline__ int wg_sum_waves(int wave_val, Scratch2 &s, int &par, int *base) {
@@ -2917,7 +2913,7 @@ static int check_opts(const cyto_lap_opts &o) {
         o.no_handover < 0 || o.no_handover > 1)
         return CYTO_ERR_BAD_ARG;
     if (o.group_state_global < 0 || o.group_state_global > 1 || o.aux_state_global < 0 || o.aux_state_global > 1) return CYTO_ERR_BAD_ARG;
-    if (o.mode < 0 || o.mode > 2 || o.wide_rounds < -1 || o.wide_groups < -1 || o.wide_groups > 32 || o.reserved) return CYTO_ERR_BAD_ARG;
+    if (o.mode < 0 || o.mode > 2 || o.wide_rounds < -1 || o.wide_groups < -1 || o.wide_groups > 32 || o.wide_band < -1 || o.wide_band > 4096 || (o.wide_band > 0 && o.wide_band % 64)) return CYTO_ERR_BAD_ARG;
     return CYTO_OK;
 }
 
@@ -2931,7 +2927,7 @@ struct F32Job {
     int status = CYTO_OK;
     // device state
     DevBuf staged, b_fws, b_iws, b_imin, b_pmin, b_parg, b_misc, b_same, b_gid, b_ccol, b_cval, b_ghb, b_ghs, b_lzhb, b_lzhs;
-    DevBuf b_rowmap, b_ulist, b_ufirst, b_wide;
+    DevBuf b_rowmap, b_ulist, b_ufirst, b_wide, b_band;
     int nused = 0;
     const float *dcost = nullptr; int64_t dld = 0;
     int h_nonfinite = 0, h_ngroups = 0, h_hand[3] = {0, 0, 0};
@@ -2944,7 +2940,7 @@ struct F32Plan {            // what depends on n (and the options) only: identic
     int n, colblocks, rowblocks, rows_per_block, cache_grid;
     bool force_l2, lds_variant, lazy, lz_lds_state, lz_cs_lds, no_cs_lds, wide;
     long long wide_rounds;
-    int wide_groups;
+    int wide_groups, wide_band;
     size_t shm_chain, lz_base_shm;
 };
 
@@ -3016,6 +3012,19 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             wa.slot_p = j.b_wide.as<float>(); wa.slot_c = wa.slot_p + n;
             wa.cache_col = c.cache_col; wa.cache_val = c.cache_val; wa.misc = c.misc;
             wa.max_rounds = pl.wide_rounds;
+            // second-level caches of the augmentation (wide_band_build): 8 bytes per entry; none if the memory is not there
+            wa.band_k = (mcg > 0 || n < 2 * pl.wide_band) ? 0 : pl.wide_band;
+            wa.band_col = nullptr; wa.band_val = nullptr; wa.band_tau = nullptr; wa.band_cnt = nullptr;
+            if (wa.band_k > 0) {
+                const size_t ent = (size_t)n * (size_t)wa.band_k;
+                const int rb = j.b_band.alloc(ent * 8 + (size_t)n * 8, stream);
+                if (rb == CYTO_ERR_NOMEM) wa.band_k = 0;
+                else if (rb) return rb;
+                else {
+                    wa.band_col = j.b_band.as<uint32_t>(); wa.band_val = reinterpret_cast<float *>(wa.band_col + ent);
+                    wa.band_tau = wa.band_val + ent; wa.band_cnt = reinterpret_cast<int32_t *>(wa.band_tau + n);
+                }
+            }
             wa.mc_groups = mcg; wa.gbmin = nullptr; wa.gdirty = nullptr; wa.gasg = nullptr; wa.gdense = nullptr; wa.ctl = nullptr;
             if (mcg > 0) {
                 const size_t nblk = ((size_t)n + 63) / 64, nw32 = ((size_t)n + 31) / 32;
@@ -3039,6 +3048,9 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
         if ((rc = wide_launch_rt(d_wa.as<WideArgs>(), nl, n, stream)) || (rc = wide_launch_arr(d_wa.as<WideArgs>(), nl, n, stream, pl.wide_rounds))) return rc;
         CYTO_HIP(hipEventRecord(ev_arr_done, stream));
         if ((rc = build_caches())) return rc;                      // fresh floors against the prices the augmentation starts from
+        bool any_band = false;
+        for (const WideArgs &wa : h_wa) any_band = any_band || wa.band_k > 0;
+        if (any_band && (rc = wide_launch_band(d_wa.as<WideArgs>(), nl, n, stream))) return rc;
         if ((rc = wide_launch_aug(d_wa.as<WideArgs>(), nl, n, stream, h_wa[0].mc_groups))) return rc;
         CYTO_HIP(hipStreamSynchronize(stream));                    // (d_wa is read by the kernels until here)
         return CYTO_OK;
@@ -3125,6 +3137,7 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
     pl.wide = opts.mode == 2 || (opts.mode == 0 && !chain_opts);
     pl.wide_rounds = opts.wide_rounds < 0 ? 0 : (opts.wide_rounds > 0 ? opts.wide_rounds : 4096 + (long long)n / 4);
     pl.wide_groups = opts.wide_groups;
+    pl.wide_band = opts.wide_band < 0 ? 0 : (opts.wide_band > 0 ? opts.wide_band : 1024);
     pl.force_l2 = opts.chain_variant != 0;
     pl.no_cs_lds = opts.chain_variant == 3;            // (3: as 2, with colsol in global memory too -- what n > 65 535 uses)
     pl.lds_variant = !pl.force_l2 && n <= 13 * per2;
@@ -3355,7 +3368,7 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
                 info->wide = 1;
                 info->wide_rounds = wc[WC_ROUNDS]; info->wide_retired = wc[WC_RETIRED]; info->wide_dense_arr = wc[WC_DENSE_ARR];
                 info->wide_dense_aug = wc[WC_DENSE_AUG]; info->wide_aug_rounds = wc[WC_AUG_ROUNDS]; info->wide_aug_settled = wc[WC_AUG_PROCESSED];
-                info->wide_trivial = wc[WC_TRIVIAL]; info->wide_verify_passes = wc[WC_VERIFY_PASSES];
+                info->wide_trivial = wc[WC_TRIVIAL]; info->wide_verify_passes = wc[WC_VERIFY_PASSES]; info->wide_band_aug = wc[WC_BAND_AUG];
                 info->aug_handover = -1;
                 {   // phase timers the wide kernels keep (100 MHz ticks at misc + 256): diagnostics for tools/wide_large.py
                     long long dbg[16] = {0};

@@ -170,24 +170,26 @@ struct ArrShared {
 };
 
 constexpr size_t ARR_SHARED_BYTES = (sizeof(ArrShared) + 15) / 16 * 16;     // (in the dynamic region: a kernel's static LDS is limited to 2 KB here)
-size_t wide_arr_lds_bytes(int n, bool vlds) {
+size_t wide_arr_lds_bytes(int n, bool vlds, bool clds) {
     const size_t npad = ((size_t)n + 3) & ~(size_t)3;
-    return ARR_SHARED_BYTES + (vlds ? ((npad * 6 + 15) / 16) * 16 : 0);
+    return ARR_SHARED_BYTES + ((npad * ((vlds ? 4 : 0) + (clds ? 2 : 0)) + 15) / 16) * 16;
 }
-bool wide_arr_vlds(int n) { return n <= 65534 && wide_arr_lds_bytes(n, true) + 1024 <= (size_t)LDS_DYNAMIC_MAX; }
+bool wide_arr_vlds(int n) { return n <= 65534 && wide_arr_lds_bytes(n, true, true) + 1024 <= (size_t)LDS_DYNAMIC_MAX; }
+bool wide_arr_clds(int n) { return n <= 65534 && wide_arr_lds_bytes(n, false, true) + 1024 <= (size_t)LDS_DYNAMIC_MAX; }
 
-template <bool VLDS> struct ArrCtx {
+template <bool VLDS, bool CLDS> struct ArrCtx {
     WideArgs a;
     float *s_v; uint16_t *s_cs; ArrShared *s;
     int lane;
     __device__ __forceinline__ float getv(int j) const { return VLDS ? s_v[j] : ld_sc1(a.v + j); }
     __device__ __forceinline__ int getcs(int j) const {
-        if (VLDS) { const uint16_t x = s_cs[j]; return x == 0xFFFFu ? -1 : (int)x; }
+        if (CLDS) { const uint16_t x = s_cs[j]; return x == 0xFFFFu ? -1 : (int)x; }
         return ld_sc1(a.colsol + j);
     }
     // a won bid: price, owner, displaced owner change together (LDS copies and global)
     __device__ __forceinline__ void apply(int i, int jt, float pt, float ct, int i0) const {
-        if (VLDS) { s_v[jt] = pt; s_cs[jt] = (uint16_t)i; }
+        if (VLDS) s_v[jt] = pt;
+        if (CLDS) s_cs[jt] = (uint16_t)i;
         a.v[jt] = pt; a.colsol[jt] = i; a.rowsol[i] = jt; a.cassign[jt] = ct;
         if (i0 >= 0) a.rowsol[i0] = -1;
     }
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(HEADB) void wide_arr_head_init(const WideArgs *__re
 __global__ __launch_bounds__(HEADB) void wide_arr_head_bid(const WideArgs *__restrict__ batch, int r) {
     extern __shared__ __align__(16) unsigned char w_smem[];
     ArrShared &s = *reinterpret_cast<ArrShared *>(w_smem);
-    ArrCtx<false> cx;
+    ArrCtx<false, false> cx;
     cx.a = load_wide_args(batch, blockIdx.y);
     const WideArgs &a = cx.a;
     ArrHead *h = reinterpret_cast<ArrHead *>(a.misc + 384);
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(HEADB) void wide_arr_head_bid(const WideArgs *__res
 }
 
 __global__ __launch_bounds__(HEADB) void wide_arr_head_resolve(const WideArgs *__restrict__ batch, int r) {
-    ArrCtx<false> cx;
+    ArrCtx<false, false> cx;
     cx.a = load_wide_args(batch, blockIdx.y);
     const WideArgs &a = cx.a;
     ArrHead *h = reinterpret_cast<ArrHead *>(a.misc + 384);
@@ -380,21 +382,24 @@ __global__ __launch_bounds__(HEADB) void wide_arr_head_reset(const WideArgs *__r
     if (blockIdx.x == 0 && threadIdx.x == 0) { h->bids += na; h->round += 1; }     // (read by nobody before wide_arr)
 }
 
-template <bool VLDS>
+template <bool VLDS, bool CLDS>
 __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batch) {
     extern __shared__ __align__(16) unsigned char w_smem[];
     ArrShared &s = *reinterpret_cast<ArrShared *>(w_smem);
-    ArrCtx<VLDS> cx;
+    ArrCtx<VLDS, CLDS> cx;
     cx.a = load_wide_args(batch, blockIdx.x);
     const WideArgs &a = cx.a;
     const int n = a.n, tid = threadIdx.x, lane = tid & 63, w = uni((int)(threadIdx.x >> 6));
     cx.s_v = reinterpret_cast<float *>(w_smem + ARR_SHARED_BYTES);
-    cx.s_cs = reinterpret_cast<uint16_t *>(cx.s_v + ((n + 3) & ~3));
+    cx.s_cs = reinterpret_cast<uint16_t *>(cx.s_v + (VLDS ? ((n + 3) & ~3) : 0));
     cx.s = &s; cx.lane = lane;
     const long long t_kernel0 = wall_clock64();
     if (tid == 0) { s.cnt[0] = 0; s.cnt[1] = 0; s.retired = 0; s.dense = 0; s.ndeal = 0; }
-    if (VLDS)
-        for (int j = tid; j < n; j += WT) { cx.s_v[j] = a.v[j]; const int o = a.colsol[j]; cx.s_cs[j] = o < 0 ? (uint16_t)0xFFFFu : (uint16_t)o; }
+    if (CLDS)
+        for (int j = tid; j < n; j += WT) {
+            if (VLDS) cx.s_v[j] = a.v[j];
+            const int o = a.colsol[j]; cx.s_cs[j] = o < 0 ? (uint16_t)0xFFFFu : (uint16_t)o;
+        }
     __syncthreads();
 
     // the active list: what the first rounds on the whole chip left (wide_arr_head_*), else every free row (in any order -- a
@@ -600,6 +605,76 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// SECOND-LEVEL ROW CACHES for the augmentation ("bands"): per row the up to band_k columns whose reduced cost c - v is below a
+// floor band_tau[i] (chosen per row so that band_k / 2 .. band_k columns qualify), against the prices the augmentation starts from.
+// Same contract as the 63-column caches (prices only decrease from here on: a column outside the band stays above the floor), at
+// 16 .. 64 times the width: on instances with hundreds of near-equal columns per row (few cell types: c4) the 63-column caches
+// certify next to nothing in a search and every settlement of such a row used to read its whole cost row.
+// A wave per row: the row minimum (the row comes from HBM once), count sweeps over the now L2-resident row until the floor
+// fits, one collecting sweep.  Entries in no particular order (the search offers them with atomic mins).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wide_band_build(const WideArgs *__restrict__ batch) {
+    const WideArgs a = load_wide_args(batch, blockIdx.y);
+    const int n = a.n, K2 = a.band_k;
+    if (K2 <= 0) return;
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    float delta = 0.0f;                                         // carried from row to row: neighbouring rows need similar floors
+    for (int i = gw; i < n; i += nw) {
+        const float *__restrict__ row = a.cost + wrow_off(a.rowmap, i, a.ld);
+        uint32_t lm = 0xFFFFFFFFu;
+        wave_row_sweep(row, n, lane, [&](int c, float x) { lm = umin32(lm, f2ord(x - a.v[c])); });
+        const float umin = ord2f(wave_min_u32(lm));
+        auto count_below = [&](float tau, uint32_t &mine) -> int {
+            uint32_t tc = 0;
+            wave_row_sweep(row, n, lane, [&](int c, float x) { tc += (x - a.v[c]) < tau ? 1u : 0u; });
+            mine = tc;
+            return (int)wave_sum_u32(tc);
+        };
+        // the first guess scales the 63-column cache's floor (it holds 32 .. 63 columns below tau1) to the band's width
+        const float tau1 = a.cache_val[(int64_t)i * KC + KCU];
+        if (!(delta > 0.0f) || !(delta < 1e30f)) {
+            delta = (tau1 - umin) * (float)(K2 / 64);
+            if (!(delta > 0.0f) || !(delta < 1e30f)) delta = 1e-3f;
+        }
+        float lo = 0.0f, hi = INFINITY, tau = -INFINITY;
+        int cnt = 0, cnt_lo = 0;
+        uint32_t mine = 0;
+        bool ok = false;
+        for (int it = 0; it < 24; it++) {
+            tau = umin + delta;
+            cnt = count_below(tau, mine);
+            if (cnt > K2) {
+                hi = delta;
+                float nd = lo > 0.0f ? 0.5f * (lo + hi) : delta * fmaxf(0.0625f, 0.75f * (float)K2 / (float)cnt);
+                if (!(nd < hi) || !(nd > lo)) break;                // cannot separate: too many ties
+                delta = nd;
+            } else if (cnt < K2 / 2 && cnt < n && delta < 1e30f) {
+                lo = delta; cnt_lo = cnt;
+                float nd = hi < INFINITY ? 0.5f * (lo + hi) : delta * fminf(16.0f, 0.75f * (float)K2 / (float)(cnt > 0 ? cnt : 1));
+                if (hi < INFINITY && (!(nd < hi) || !(nd > lo))) { ok = true; break; }
+                delta = nd;
+            } else { ok = true; break; }
+        }
+        if (!ok || cnt > K2) {                                     // the largest floor known to admit <= band_k columns (possibly none)
+            if (lo > 0.0f) { delta = lo; tau = umin + lo; cnt = count_below(tau, mine); (void)cnt_lo; }
+            else { tau = -INFINITY; cnt = 0; mine = 0; }
+            if (cnt > K2) { tau = -INFINITY; cnt = 0; mine = 0; }
+        }
+        // collect: lane-local runs, the lanes' counts prefix-summed
+        uint32_t inc = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)inc, off); if (lane >= off) inc += y; }
+        int pos = (int)(inc - mine);
+        uint32_t *__restrict__ bc = a.band_col + (int64_t)i * K2;
+        float *__restrict__ bv = a.band_val + (int64_t)i * K2;
+        if (cnt > 0)
+            wave_row_sweep(row, n, lane, [&](int c, float x) { if ((x - a.v[c]) < tau) { bc[pos] = (uint32_t)c; bv[pos] = x; pos++; } });
+        if (lane == 0) { a.band_cnt[i] = cnt; a.band_tau[i] = tau; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // AUGMENTATION (oracle/jv_oracle_impl.h, wide mode): shortest paths with (distance, tight-hop count) labels, run speculatively.
 //
 // Per column (global, L2): label = (ordered distance << 32 | tight hops << 20 | predecessor row), all-ones = unlabelled; an atomic min on it
@@ -613,12 +688,13 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int AP = 2;              // columns a wave settles per round (their loads are in flight together)
 
-size_t wide_aug_lds_bytes(int n, bool vlds) {
+size_t wide_aug_lds_bytes(int n, bool vlds, bool clds) {
     const size_t nblk = ((size_t)n + 63) / 64, nw32 = ((size_t)n + 31) / 32, npad = ((size_t)n + 3) & ~(size_t)3;
-    return ((nblk * 8 + 3 * nw32 * 4 + (vlds ? npad * 6 : 0) + 15) / 16) * 16;
+    return ((nblk * 8 + 4 * nw32 * 4 + npad * ((vlds ? 4 : 0) + (clds ? 2 : 0)) + 15) / 16) * 16;
 }
-bool wide_aug_vlds(int n) { return n <= 65534 && wide_aug_lds_bytes(n, true) + 4096 <= (size_t)LDS_DYNAMIC_MAX; }
-size_t wide_aug_lds_bytes(int n) { return wide_aug_lds_bytes(n, wide_aug_vlds(n)); }
+bool wide_aug_vlds(int n) { return n <= 65534 && wide_aug_lds_bytes(n, true, true) + 4096 <= (size_t)LDS_DYNAMIC_MAX; }
+bool wide_aug_clds(int n) { return n <= 65534 && wide_aug_lds_bytes(n, false, true) + 4096 <= (size_t)LDS_DYNAMIC_MAX; }
+size_t wide_aug_lds_bytes(int n) { return wide_aug_lds_bytes(n, wide_aug_vlds(n), wide_aug_clds(n)); }
 
 struct AugShared {
     unsigned long long T;          // best unassigned column: (ordered distance << 32 | tight hops << 20 | column)
@@ -629,7 +705,7 @@ struct AugShared {
 };
 
 // VLDS: prices (f32) and column owners (u16) also in LDS (every update goes to both copies), as in wide_arr.
-template <bool VLDS>
+template <bool VLDS, bool CLDS>
 __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batch) {
     extern __shared__ __align__(16) unsigned char w_smem[];
     __shared__ AugShared s;
@@ -639,29 +715,34 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
     unsigned long long *bmin = reinterpret_cast<unsigned long long *>(w_smem);
     uint32_t *dirty = reinterpret_cast<uint32_t *>(bmin + nblk);
     uint32_t *asg = dirty + nw32;
-    uint32_t *dense = asg + nw32;
-    float *s_v = reinterpret_cast<float *>(dense + nw32);
-    uint16_t *s_cs = reinterpret_cast<uint16_t *>(s_v + ((n + 3) & ~3));
+    uint32_t *dense = asg + nw32;              // rows whose 63-column cache could not certify the search ...
+    uint32_t *dense2 = dense + nw32;           // ... and whose band could not either: relaxed from the full cost row
+    float *s_v = reinterpret_cast<float *>(dense2 + nw32);
+    uint16_t *s_cs = reinterpret_cast<uint16_t *>(s_v + (VLDS ? ((n + 3) & ~3) : 0));
     const int numfree = *reinterpret_cast<const int *>(a.misc + 128);
+    const int K2 = a.band_k;
     for (int b = tid; b < nblk; b += WT) bmin[b] = ~0ull;
-    for (int q = tid; q < nw32; q += WT) { dirty[q] = 0; dense[q] = 0; }
+    for (int q = tid; q < nw32; q += WT) { dirty[q] = 0; dense[q] = 0; dense2[q] = 0; }
     for (int c0 = 0; c0 < nw32 * 32; c0 += WT) {                 // assigned bits, 64 columns per wave and step
         const int c = c0 + tid;
         const uint64_t m = __ballot(c < n && a.colsol[c] >= 0);
         if (lane == 0 && (c >> 5) < nw32) { asg[c >> 5] = (uint32_t)m; if ((c >> 5) + 1 < nw32) asg[(c >> 5) + 1] = (uint32_t)(m >> 32); }
     }
-    if (VLDS)
-        for (int j = tid; j < n; j += WT) { s_v[j] = a.v[j]; const int o = a.colsol[j]; s_cs[j] = o < 0 ? (uint16_t)0xFFFFu : (uint16_t)o; }
+    if (CLDS)
+        for (int j = tid; j < n; j += WT) {
+            if (VLDS) s_v[j] = a.v[j];
+            const int o = a.colsol[j]; s_cs[j] = o < 0 ? (uint16_t)0xFFFFu : (uint16_t)o;
+        }
     if (tid == 0) { s.T = ~0ull; s.ntouch = 0; s.any[0] = 0; s.any[1] = 0; s.fail = 0; s.anydense = 0; s.rootdense = 0; s.doroot = 0; s.f = 0; s.err = 0; s.scans = 0; }
     __syncthreads();
     auto getv = [&](int j) -> float { return VLDS ? s_v[j] : ld_sc1(a.v + j); };
     auto getcs = [&](int j) -> int {
-        if (VLDS) { const uint16_t x = s_cs[j]; return x == 0xFFFFu ? -1 : (int)x; }
+        if (CLDS) { const uint16_t x = s_cs[j]; return x == 0xFFFFu ? -1 : (int)x; }
         return ld_sc1(a.colsol + j);
     };
     auto is_asg = [&](int c) -> bool { return (asg[c >> 5] >> (c & 31)) & 1u; };
 
-    long long c_relax = 0, c_hops = 0, c_rounds = 0, c_proc = 0, c_trivial = 0, c_dense = 0, c_verify = 0;   // (thread 0 / wave leaders)
+    long long c_relax = 0, c_hops = 0, c_rounds = 0, c_proc = 0, c_trivial = 0, c_dense = 0, c_band = 0, c_verify = 0;   // (thread 0 / wave leaders)
     long long t_rounds = 0, t_verify = 0, t_finish = 0, t_triv = 0, t_mark = wall_clock64();
 #define AUG_LAP(acc) { const long long now_ = wall_clock64(); acc += now_ - t_mark; t_mark = now_; }
 
@@ -726,7 +807,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     // (no global store in the loop: a load is only returned after the stores issued before it are acknowledged, so
                     //  three stores per search made every search wait for the previous one's)
                     s.st_row[nst] = fr; s.st_col[nst] = (int)col; s.st_val[nst] = val;
-                    if (VLDS) s_cs[col] = (uint16_t)fr;
+                    if (CLDS) s_cs[col] = (uint16_t)fr;
                     atomicOr(&asg[col >> 5], 1u << (col & 31));
                 }
                 c_trivial++; c_hops++;
@@ -818,15 +899,30 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     if (!dn[q]) continue;                          // the owner's cache could not certify: its whole cost row
                     const uint32_t dord = (uint32_t)(lab[q] >> 32), kq = (uint32_t)(lab[q] >> 20) & LKMAX;
                     const float h = (ca[q] - vp[q]) - ord2f(dord);
-                    const float *__restrict__ row = a.cost + wrow_off(a.rowmap, oi[q], a.ld);
                     const int pjq = pj[q], oiq = oi[q];
-                    // (a full row offers hundreds of candidates below the best unassigned distance when many columns are near-equal:
+                    // (such a row offers hundreds of candidates below the best unassigned distance when many columns are near-equal:
                     //  the label is read first -- a plain L2 load -- and the atomic follows only where it would change something)
-                    wave_row_sweep(row, n, lane, [&](int c, float x) {
+                    auto relax_dense = [&](int c, float x) {
                         const unsigned long long lv = edge_lv(f2ord((x - getv(c)) - h), dord, kq);
                         if (c != pjq && lv <= lv_of(s.T) && (lkey(lv, (uint32_t)oiq) < ld_sc1(a.label + c))) relax_to(c, lv, oiq);
-                    });
-                    c_dense++;
+                    };
+                    if (K2 > 0 && !((dense2[oiq >> 5] >> (oiq & 31)) & 1u)) {
+                        // its band: up to band_k (column, cost) pairs, four 256-byte loads of each array in flight
+                        const int cnt = uni(a.band_cnt[oiq]);
+                        const uint32_t *__restrict__ bc = a.band_col + (int64_t)oiq * K2;
+                        const float *__restrict__ bv = a.band_val + (int64_t)oiq * K2;
+                        for (int e0 = 0; e0 < cnt; e0 += 256) {
+                            uint32_t cc[4]; float xx[4];
+#pragma unroll
+                            for (int r = 0; r < 4; r++) { const int e = e0 + r * 64 + lane; cc[r] = COLSENT; xx[r] = 0.0f; if (e < cnt) { cc[r] = bc[e]; xx[r] = bv[e]; } }
+#pragma unroll
+                            for (int r = 0; r < 4; r++) if (cc[r] != COLSENT) relax_dense((int)cc[r], xx[r]);
+                        }
+                        c_band++;
+                    } else {
+                        wave_row_sweep(a.cost + wrow_off(a.rowmap, oiq, a.ld), n, lane, relax_dense);
+                        c_dense++;
+                    }
                 }
                 __syncthreads();
 #pragma unroll
@@ -865,11 +961,14 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                 // tight edge out of such a column would give (distance, k + 1), possibly below the end's label
                 if (lv_of(lbk) < lv_of(Tk) && is_asg(k)) {
                     const int i = getcs(k);
-                    if (!((dense[i >> 5] >> (i & 31)) & 1u)) {
+                    const bool d1 = (dense[i >> 5] >> (i & 31)) & 1u, d2 = (dense2[i >> 5] >> (i & 31)) & 1u;
+                    if (!d1 || (K2 > 0 && !d2)) {
                         const float h = (ld_sc1(a.cassign + k) - getv(k)) - ord2f(dord);
-                        const float bound = a.cache_val[(int64_t)i * KC + KCU] - h;
-                        if (!(bound > D)) {
-                            atomicOr(&dense[i >> 5], 1u << (i & 31));
+                        bool failed = false;
+                        if (!d1 && !((a.cache_val[(int64_t)i * KC + KCU] - h) > D)) { atomicOr(&dense[i >> 5], 1u << (i & 31)); failed = true; }
+                        // (a row that fails its cache's floor is checked against its band's at once: no pass in between)
+                        if ((d1 || failed) && K2 > 0 && !((a.band_tau[i] - h) > D)) { atomicOr(&dense2[i >> 5], 1u << (i & 31)); failed = true; }
+                        if (failed) {
                             atomicOr(&dirty[k >> 5], 1u << (k & 31));
                             atomicMin(&bmin[k >> 6], lkey(lv_of(lbk), (uint32_t)k));
                             atomicAdd(&s.fail, 1);
@@ -918,7 +1017,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                 const int i = (int)lid_of(ld_sc1(a.label + j));
                 const int jn = ld_sc1(a.rowsol + i);
                 a.colsol[j] = i; a.rowsol[i] = j; a.cassign[j] = a.cost[wrow_off(a.rowmap, i, a.ld) + j];
-                if (VLDS) s_cs[j] = (uint16_t)i;
+                if (CLDS) s_cs[j] = (uint16_t)i;
                 c_hops++;
                 if (i == fr) break;
                 j = jn;
@@ -933,7 +1032,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             bmin[k >> 6] = ~0ull;
         }
         // (keeping the dense bits across searches was measured: fewer rounds, but more full-row relaxations -- slower)
-        if (s.anydense) for (int q = tid; q < nw32; q += WT) dense[q] = 0;
+        if (s.anydense) for (int q = tid; q < nw32; q += WT) { dense[q] = 0; dense2[q] = 0; }
         __syncthreads();
         if (tid == 0) { c_relax += s.scans; s.scans = 0; s.T = ~0ull; s.ntouch = 0; s.anydense = 0; s.rootdense = 0; s.f = f + 1; }
         f++;
@@ -957,18 +1056,18 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
     if (lane == 0) s_tot[w] = tot;
     // per-wave counters of the wave leaders
-    __shared__ long long s_wc[WNW][4];
-    if (lane == 0) { s_wc[w][0] = c_proc; s_wc[w][1] = c_dense; s_wc[w][2] = c_trivial; s_wc[w][3] = (w == 0) ? c_hops : 0; }
+    __shared__ long long s_wc[WNW][5];
+    if (lane == 0) { s_wc[w][0] = c_proc; s_wc[w][1] = c_dense; s_wc[w][2] = c_trivial; s_wc[w][3] = (w == 0) ? c_hops : 0; s_wc[w][4] = c_band; }
     __syncthreads();
     if (tid == 0) {
         double t = 0.0;
-        long long proc = 0, dn = 0, triv = 0, hops0 = 0;
-        for (int k = 0; k < WNW; k++) { t += s_tot[k]; proc += s_wc[k][0]; dn += s_wc[k][1]; triv += s_wc[k][2]; hops0 += s_wc[k][3]; }
+        long long proc = 0, dn = 0, triv = 0, hops0 = 0, bnd = 0;
+        for (int k = 0; k < WNW; k++) { t += s_tot[k]; proc += s_wc[k][0]; dn += s_wc[k][1]; triv += s_wc[k][2]; hops0 += s_wc[k][3]; bnd += s_wc[k][4]; }
         *reinterpret_cast<double *>(a.misc + 8) = t;
         long long *ctr = reinterpret_cast<long long *>(a.misc + 16);
         long long *wc = reinterpret_cast<long long *>(a.misc + 160);
         ctr[C_AUG_INIT] = numfree; ctr[C_AUG_RELAX] = c_relax; ctr[C_AUGS] = numfree; ctr[C_HOPS] = hops0;
-        wc[WC_DENSE_AUG] = dn; wc[WC_AUG_ROUNDS] = c_rounds; wc[WC_AUG_PROCESSED] = proc; wc[WC_TRIVIAL] = triv; wc[WC_VERIFY_PASSES] = c_verify;
+        wc[WC_DENSE_AUG] = dn; wc[WC_BAND_AUG] = bnd; wc[WC_AUG_ROUNDS] = c_rounds; wc[WC_AUG_PROCESSED] = proc; wc[WC_TRIVIAL] = triv; wc[WC_VERIFY_PASSES] = c_verify;
         if (s.err) *reinterpret_cast<int *>(a.misc + 4) = 1;
         long long *dbg = reinterpret_cast<long long *>(a.misc + 256);      // (100 MHz ticks)
         dbg[8] = t_rounds; dbg[9] = t_verify; dbg[10] = t_finish; dbg[11] = t_triv;
@@ -1008,6 +1107,13 @@ size_t wide_mc_state_bytes(int n) {
     const size_t nblk = ((size_t)n + 63) / 64, nw32 = ((size_t)n + 31) / 32;
     return ((nblk * 128 + 2 * nw32 * 4 + 255) / 256) * 256 + 256;
 }
+int wide_launch_band(const WideArgs *d_args, int nb, int n, hipStream_t stream) {
+    const int blocks = std::max(1, std::min((n + 3) / 4, std::max(64, 4096 / std::max(nb, 1))));
+    hipLaunchKernelGGL(wide_band_build, dim3(blocks, nb), dim3(256), 0, stream, d_args);
+    CYTO_HIP(hipGetLastError());
+    return CYTO_OK;
+}
+
 int wide_mc_groups(int nb, int n) {
     // Measured (round 3, tools/wide_large.py --groups G): on uniform instances the one-workgroup kernel is faster (n = 20 000: 39 ms
     // against 46 ms with 4-8 groups, 55 ms with 16) -- 4-8x the waves settle 1.8-2.6x the columns (speculation further from the
@@ -1382,11 +1488,11 @@ int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, l
         }
         CYTO_HIP(hipGetLastError());
     }
-    const bool vlds = wide_arr_vlds(n);
-    void (*k)(const WideArgs *) = vlds ? wide_arr<true> : wide_arr<false>;
+    const bool vlds = wide_arr_vlds(n), clds = wide_arr_clds(n);
+    void (*k)(const WideArgs *) = vlds ? wide_arr<true, true> : clds ? wide_arr<false, true> : wide_arr<false, false>;
     int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(k));
     if (rc) return rc;
-    hipLaunchKernelGGL(k, dim3(nb), dim3(WT), wide_arr_lds_bytes(n, vlds), stream, d_args);
+    hipLaunchKernelGGL(k, dim3(nb), dim3(WT), wide_arr_lds_bytes(n, vlds, clds), stream, d_args);
     CYTO_HIP(hipGetLastError());
     return CYTO_OK;
 }
@@ -1397,10 +1503,10 @@ int wide_launch_aug(const WideArgs *d_args, int nb, int n, hipStream_t stream, i
         CYTO_HIP(hipGetLastError());
         return CYTO_OK;
     }
-    const bool vlds = wide_aug_vlds(n);
-    const size_t shm = wide_aug_lds_bytes(n, vlds);
+    const bool vlds = wide_aug_vlds(n), clds = wide_aug_clds(n);
+    const size_t shm = wide_aug_lds_bytes(n, vlds, clds);
     if (shm > (size_t)LDS_DYNAMIC_MAX) return CYTO_ERR_UNSUPPORTED;
-    void (*k)(const WideArgs *) = vlds ? wide_aug<true> : wide_aug<false>;
+    void (*k)(const WideArgs *) = vlds ? wide_aug<true, true> : clds ? wide_aug<false, true> : wide_aug<false, false>;
     int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(k));
     if (rc) return rc;
     hipLaunchKernelGGL(k, dim3(nb), dim3(WT), shm, stream, d_args);
