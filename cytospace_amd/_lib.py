@@ -33,7 +33,7 @@ class LapInfo(ctypes.Structure):
         [(k, ctypes.c_int64) for k in ("wide", "wide_rounds", "wide_retired", "wide_dense_arr", "wide_dense_aug", "wide_aug_rounds",
                                        "wide_aug_settled", "wide_trivial", "wide_verify_passes", "wide_list_rounds", "wide_chain_rounds")] + \
         [(k, ctypes.c_double) for k in ("wide_ms_list", "wide_ms_chain", "wide_ms_aug_rounds", "wide_ms_aug_verify", "wide_ms_aug_finish",
-                                        "wide_ms_aug_trivial")] + [("wide_band_aug", ctypes.c_int64)]
+                                        "wide_ms_aug_trivial")] + [("wide_aug_launches", ctypes.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -47,7 +47,7 @@ class LapInfo(ctypes.Structure):
 class LapOpts(ctypes.Structure):
     """cyto_lap_opts (include/cytohip.h): kernel-selection options; results never depend on them."""
     _fields_ = [("chain_variant", ctypes.c_int32), ("augmentation", ctypes.c_int32), ("no_handover", ctypes.c_int32),
-                ("inject_exceptions", ctypes.c_int32), ("group_state_global", ctypes.c_int32), ("aux_state_global", ctypes.c_int32), ("mode", ctypes.c_int32), ("wide_rounds", ctypes.c_int32), ("wide_groups", ctypes.c_int32), ("wide_band", ctypes.c_int32)]
+                ("inject_exceptions", ctypes.c_int32), ("group_state_global", ctypes.c_int32), ("aux_state_global", ctypes.c_int32), ("mode", ctypes.c_int32), ("wide_rounds", ctypes.c_int32), ("wide_groups", ctypes.c_int32), ("wide_rebuild", ctypes.c_int32)]
 
 
 class AssignInfo(ctypes.Structure):

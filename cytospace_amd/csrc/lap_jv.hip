@@ -2913,7 +2913,7 @@ static int check_opts(const cyto_lap_opts &o) {
         o.no_handover < 0 || o.no_handover > 1)
         return CYTO_ERR_BAD_ARG;
     if (o.group_state_global < 0 || o.group_state_global > 1 || o.aux_state_global < 0 || o.aux_state_global > 1) return CYTO_ERR_BAD_ARG;
-    if (o.mode < 0 || o.mode > 2 || o.wide_rounds < -1 || o.wide_groups < -1 || o.wide_groups > 32 || o.wide_band < -1 || o.wide_band > 4096 || (o.wide_band > 0 && o.wide_band % 64)) return CYTO_ERR_BAD_ARG;
+    if (o.mode < 0 || o.mode > 2 || o.wide_rounds < -1 || o.wide_groups < -1 || o.wide_groups > 32 || o.wide_rebuild < -1) return CYTO_ERR_BAD_ARG;
     return CYTO_OK;
 }
 
@@ -2927,7 +2927,7 @@ struct F32Job {
     int status = CYTO_OK;
     // device state
     DevBuf staged, b_fws, b_iws, b_imin, b_pmin, b_parg, b_misc, b_same, b_gid, b_ccol, b_cval, b_ghb, b_ghs, b_lzhb, b_lzhs;
-    DevBuf b_rowmap, b_ulist, b_ufirst, b_wide, b_band;
+    DevBuf b_rowmap, b_ulist, b_ufirst, b_wide;
     int nused = 0;
     const float *dcost = nullptr; int64_t dld = 0;
     int h_nonfinite = 0, h_ngroups = 0, h_hand[3] = {0, 0, 0};
@@ -2940,7 +2940,7 @@ struct F32Plan {            // what depends on n (and the options) only: identic
     int n, colblocks, rowblocks, rows_per_block, cache_grid;
     bool force_l2, lds_variant, lazy, lz_lds_state, lz_cs_lds, no_cs_lds, wide;
     long long wide_rounds;
-    int wide_groups, wide_band;
+    int wide_groups, wide_rebuild;
     size_t shm_chain, lz_base_shm;
 };
 
@@ -2956,8 +2956,10 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
     const bool cs_lds = !LDS_STATE && n <= 65535 && !pl.no_cs_lds;
     void (*kern)(const Chain2Args *) = jv_chain2<CH, LDS_STATE, false>;
     if constexpr (!LDS_STATE) { if (cs_lds) kern = jv_chain2<CH, false, true>; }
-    auto build_caches = [&]() -> int {
-        for (int b : live) {
+    auto build_caches = [&](const int *remaining) -> int {      // remaining: per live problem, 0 = nothing left to do for it (or null)
+        for (int k = 0; k < nl; k++) {
+            if (remaining && remaining[k] == 0) continue;
+            const int b = live[k];
             const Chain2Args &a = jobs[b].c2;
             // (runs of identical rows: one cache per run, copied to the rest)
             const int32_t *same = (jobs[b].h_ngroups < n && n >= 2) ? jobs[b].b_same.as<int32_t>() : nullptr;
@@ -2988,7 +2990,7 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
     CYTO_HIP(hipMemcpyAsync(d_c2.p, h_c2.data(), sizeof(Chain2Args) * nl, hipMemcpyHostToDevice, stream));
     CYTO_HIP(hipMemcpyAsync(d_la.p, h_la.data(), sizeof(LazyArgs) * nl, hipMemcpyHostToDevice, stream));
 
-    if ((rc = build_caches())) return rc;
+    if ((rc = build_caches(nullptr))) return rc;
     CYTO_HIP(hipEventRecord(ev_cache_done, stream));
     if (pl.wide) {
         // the wide solver (lap_wide.hip): Jacobi reduction transfer, Jacobi rounds of row reduction, speculative shortest-path
@@ -3012,19 +3014,10 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             wa.slot_p = j.b_wide.as<float>(); wa.slot_c = wa.slot_p + n;
             wa.cache_col = c.cache_col; wa.cache_val = c.cache_val; wa.misc = c.misc;
             wa.max_rounds = pl.wide_rounds;
-            // second-level caches of the augmentation (wide_band_build): 8 bytes per entry; none if the memory is not there
-            wa.band_k = (mcg > 0 || n < 2 * pl.wide_band) ? 0 : pl.wide_band;
-            wa.band_col = nullptr; wa.band_val = nullptr; wa.band_tau = nullptr; wa.band_cnt = nullptr;
-            if (wa.band_k > 0) {
-                const size_t ent = (size_t)n * (size_t)wa.band_k;
-                const int rb = j.b_band.alloc(ent * 8 + (size_t)n * 8, stream);
-                if (rb == CYTO_ERR_NOMEM) wa.band_k = 0;
-                else if (rb) return rb;
-                else {
-                    wa.band_col = j.b_band.as<uint32_t>(); wa.band_val = reinterpret_cast<float *>(wa.band_col + ent);
-                    wa.band_tau = wa.band_val + ent; wa.band_cnt = reinterpret_cast<int32_t *>(wa.band_tau + n);
-                }
-            }
+            wa.aug_seg = mcg > 0 ? -1 : pl.wide_rebuild;
+            wa.aug_waste = (int)std::max<long long>(16, (2000000ll + (long long)n * n / 100) / n);   // what a rebuild costs, in full-row relaxations
+            wa.seg_quorum = nl > 1 ? std::max(1, nl / 4) : 0;
+            wa.seg_sync = nullptr;
             wa.mc_groups = mcg; wa.gbmin = nullptr; wa.gdirty = nullptr; wa.gasg = nullptr; wa.gdense = nullptr; wa.ctl = nullptr;
             if (mcg > 0) {
                 const size_t nblk = ((size_t)n + 63) / 64, nw32 = ((size_t)n + 31) / 32;
@@ -3042,17 +3035,26 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             CYTO_HIP(hipMemsetAsync(wa.label, 0xFF, 2 * nT, stream));
             CYTO_HIP(hipMemsetAsync(wa.bid, 0xFF, 2 * nT, stream));
         }
-        DevBuf d_wa;
-        if ((rc = d_wa.alloc(sizeof(WideArgs) * nl, stream))) return rc;
+        DevBuf d_wa, d_sync;
+        if ((rc = d_wa.alloc(sizeof(WideArgs) * nl, stream)) || (rc = d_sync.alloc(sizeof(int32_t) * ((size_t)nl + 1), stream))) return rc;
+        for (WideArgs &wa : h_wa) wa.seg_sync = d_sync.as<int32_t>();
         CYTO_HIP(hipMemcpyAsync(d_wa.p, h_wa.data(), sizeof(WideArgs) * nl, hipMemcpyHostToDevice, stream));
         if ((rc = wide_launch_rt(d_wa.as<WideArgs>(), nl, n, stream)) || (rc = wide_launch_arr(d_wa.as<WideArgs>(), nl, n, stream, pl.wide_rounds))) return rc;
         CYTO_HIP(hipEventRecord(ev_arr_done, stream));
-        if ((rc = build_caches())) return rc;                      // fresh floors against the prices the augmentation starts from
-        bool any_band = false;
-        for (const WideArgs &wa : h_wa) any_band = any_band || wa.band_k > 0;
-        if (any_band && (rc = wide_launch_band(d_wa.as<WideArgs>(), nl, n, stream))) return rc;
-        if ((rc = wide_launch_aug(d_wa.as<WideArgs>(), nl, n, stream, h_wa[0].mc_groups))) return rc;
-        CYTO_HIP(hipStreamSynchronize(stream));                    // (d_wa is read by the kernels until here)
+        // the searches, in as many launches as they ask for: wide_aug returns when its row caches have gone stale (lap_wide.hip) and
+        // the whole chip rebuilds them against the prices reached -- only for the problems that still have searches to run
+        std::vector<int32_t> h_sync((size_t)nl + 1, 1);
+        for (int pass = 0;; pass++) {
+            if ((rc = build_caches(pass ? h_sync.data() + 1 : nullptr))) return rc;
+            CYTO_HIP(hipMemsetAsync(d_sync.p, 0, sizeof(int32_t), stream));
+            if ((rc = wide_launch_aug(d_wa.as<WideArgs>(), nl, n, stream, h_wa[0].mc_groups))) return rc;
+            if (h_wa[0].mc_groups > 0) { CYTO_HIP(hipStreamSynchronize(stream)); break; }
+            CYTO_HIP(hipMemcpyAsync(h_sync.data(), d_sync.p, sizeof(int32_t) * ((size_t)nl + 1), hipMemcpyDeviceToHost, stream));
+            CYTO_HIP(hipStreamSynchronize(stream));                // (d_wa is read by the kernels until here)
+            bool done = true;
+            for (int k = 0; k < nl; k++) done = done && h_sync[(size_t)k + 1] == 0;
+            if (done) break;
+        }
         return CYTO_OK;
     }
     if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern)))) return rc;
@@ -3076,7 +3078,7 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
     if (!pl.lazy) return launch_dense(d_c2.as<Chain2Args>(), nl);
 
     // fresh caches (floors against the prices the augmentation starts from), then the cache-certified search
-    if ((rc = build_caches())) return rc;
+    if ((rc = build_caches(nullptr))) return rc;
     void (*lk)(const LazyArgs *) = pl.lz_lds_state ? jv_aug_lazy<true> : (pl.lz_cs_lds ? jv_aug_lazy<false, true> : jv_aug_lazy<false>);
     if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(lk)))) return rc;
     hipLaunchKernelGGL(lk, dim3(nl), dim3(BLOCK2), shm_lazy, stream, d_la.as<LazyArgs>());
@@ -3137,7 +3139,7 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
     pl.wide = opts.mode == 2 || (opts.mode == 0 && !chain_opts);
     pl.wide_rounds = opts.wide_rounds < 0 ? 0 : (opts.wide_rounds > 0 ? opts.wide_rounds : 4096 + (long long)n / 4);
     pl.wide_groups = opts.wide_groups;
-    pl.wide_band = opts.wide_band < 0 ? 0 : (opts.wide_band > 0 ? opts.wide_band : 1024);
+    pl.wide_rebuild = opts.wide_rebuild;
     pl.force_l2 = opts.chain_variant != 0;
     pl.no_cs_lds = opts.chain_variant == 3;            // (3: as 2, with colsol in global memory too -- what n > 65 535 uses)
     pl.lds_variant = !pl.force_l2 && n <= 13 * per2;
@@ -3368,7 +3370,7 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
                 info->wide = 1;
                 info->wide_rounds = wc[WC_ROUNDS]; info->wide_retired = wc[WC_RETIRED]; info->wide_dense_arr = wc[WC_DENSE_ARR];
                 info->wide_dense_aug = wc[WC_DENSE_AUG]; info->wide_aug_rounds = wc[WC_AUG_ROUNDS]; info->wide_aug_settled = wc[WC_AUG_PROCESSED];
-                info->wide_trivial = wc[WC_TRIVIAL]; info->wide_verify_passes = wc[WC_VERIFY_PASSES]; info->wide_band_aug = wc[WC_BAND_AUG];
+                info->wide_trivial = wc[WC_TRIVIAL]; info->wide_verify_passes = wc[WC_VERIFY_PASSES]; info->wide_aug_launches = wc[WC_AUG_LAUNCHES];
                 info->aug_handover = -1;
                 {   // phase timers the wide kernels keep (100 MHz ticks at misc + 256): diagnostics for tools/wide_large.py
                     long long dbg[16] = {0};

@@ -17,8 +17,11 @@ namespace cyto {
 //   gbmin, gdirty, gasg, gdense, ctl   the multi-workgroup augmentation's shared state (global memory; wide_aug_mc): per 64-column
 //                   block the smallest dirty label, dirty / assigned / dense bitmaps, a 256-byte control block (zeroed by the host)
 //   mc_groups       workgroups that search one problem together (0: the one-workgroup kernel)
-//   band_col/val    [n][band_k] second-level row caches of the augmentation (wide_band_build): the band_cnt[i] columns of row i
-//                   whose reduced cost was below band_tau[i] when they were built, in no order; band_k = 0: none
+//   seg_sync        shared by the launch, or null: [0] workgroups that asked for fresh caches (zeroed by the driver before every launch
+//                   of wide_aug), [1 + b] searches problem b still has to run when the launch ends
+//   aug_seg         when a launch of wide_aug returns to the driver for fresh row caches: -1 never, k > 0 after k searches, 0 when
+//                   its full-row relaxations reach aug_waste or seg_quorum workgroups of the launch have asked (misc + 132 holds the
+//                   number of searches done)
 // (fields through an X-macro: the kernels read the block through a mirror struct whose pointers are typed as GLOBAL, so that
 //  every access is a global_* instruction -- through pointers loaded from memory it would be a FLAT one, and flat accesses
 //  also count on lgkmcnt: every LDS wait would wait for the outstanding global loads too)
@@ -28,14 +31,14 @@ namespace cyto {
     P(int32_t, freerows) P(int32_t, act0) P(int32_t, act1) P(int32_t, touched) P(int32_t, slot_j) P(float, slot_p)            \
     P(float, slot_c) P(uint32_t, cache_col) P(float, cache_val) P(char, misc) S(long long, max_rounds)                     \
     P(unsigned long long, gbmin) P(uint32_t, gdirty) P(uint32_t, gasg) P(uint32_t, gdense) P(char, ctl) S(int, mc_groups)  \
-    P(uint32_t, band_col) P(float, band_val) P(float, band_tau) P(int32_t, band_cnt) S(int, band_k)
+    P(int32_t, seg_sync) S(int, aug_seg) S(int, aug_waste) S(int, seg_quorum)
 #define WIDE_F_PTR(T, name) T *name;
 #define WIDE_F_VAL(T, name) T name;
 struct WideArgs { WIDE_FIELDS(WIDE_F_PTR, WIDE_F_VAL) };
 
 // wide counters (long long each) at misc + 160
 enum { WC_ROUNDS = 0, WC_BIDS, WC_RETIRED, WC_ACTIVE_LEFT, WC_FREE_ARR, WC_DENSE_ARR, WC_DENSE_AUG, WC_AUG_ROUNDS, WC_AUG_PROCESSED,
-       WC_TRIVIAL, WC_VERIFY_PASSES, WC_BAND_AUG, WC_N };
+       WC_TRIVIAL, WC_VERIFY_PASSES, WC_AUG_LAUNCHES, WC_N };
 
 size_t wide_aug_lds_bytes(int n);
 // phases, each one launch for the whole batch (d_args: device array of nb WideArgs)
@@ -44,6 +47,5 @@ int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, l
 int wide_launch_aug(const WideArgs *d_args, int nb, int n, hipStream_t stream, int mc_groups);   // succ-clamped shortest-path augmentation, duals, total
 int wide_mc_groups(int nb, int n);                                                     // how many workgroups search one problem together (0: one)
 size_t wide_mc_state_bytes(int n);                                                     // gbmin + 3 bitmaps + control block
-int wide_launch_band(const WideArgs *d_args, int nb, int n, hipStream_t stream);   // second-level row caches against the current prices
 
 }  // namespace cyto

@@ -38,6 +38,7 @@ constexpr int RTB = 256;          // threads of the reduction-transfer workgroup
 enum { C_RT = 0, C_ARR, C_AUG_INIT, C_AUG_RELAX, C_AUGS, C_HOPS, C_FREE_CR, C_FREE_A1, C_FREE_A2, C_ROWS_READ };
 
 template <typename T> __device__ __forceinline__ T ld_sc1(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ void st_sc1(T *p, T x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int64_t wrow_off(const int32_t *__restrict__ rowmap, int i, int64_t ld) {
     return (int64_t)(rowmap ? rowmap[i] : i) * ld;
 }
@@ -605,76 +606,6 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// SECOND-LEVEL ROW CACHES for the augmentation ("bands"): per row the up to band_k columns whose reduced cost c - v is below a
-// floor band_tau[i] (chosen per row so that band_k / 2 .. band_k columns qualify), against the prices the augmentation starts from.
-// Same contract as the 63-column caches (prices only decrease from here on: a column outside the band stays above the floor), at
-// 16 .. 64 times the width: on instances with hundreds of near-equal columns per row (few cell types: c4) the 63-column caches
-// certify next to nothing in a search and every settlement of such a row used to read its whole cost row.
-// A wave per row: the row minimum (the row comes from HBM once), count sweeps over the now L2-resident row until the floor
-// fits, one collecting sweep.  Entries in no particular order (the search offers them with atomic mins).
-// ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wide_band_build(const WideArgs *__restrict__ batch) {
-    const WideArgs a = load_wide_args(batch, blockIdx.y);
-    const int n = a.n, K2 = a.band_k;
-    if (K2 <= 0) return;
-    const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
-    float delta = 0.0f;                                         // carried from row to row: neighbouring rows need similar floors
-    for (int i = gw; i < n; i += nw) {
-        const float *__restrict__ row = a.cost + wrow_off(a.rowmap, i, a.ld);
-        uint32_t lm = 0xFFFFFFFFu;
-        wave_row_sweep(row, n, lane, [&](int c, float x) { lm = umin32(lm, f2ord(x - a.v[c])); });
-        const float umin = ord2f(wave_min_u32(lm));
-        auto count_below = [&](float tau, uint32_t &mine) -> int {
-            uint32_t tc = 0;
-            wave_row_sweep(row, n, lane, [&](int c, float x) { tc += (x - a.v[c]) < tau ? 1u : 0u; });
-            mine = tc;
-            return (int)wave_sum_u32(tc);
-        };
-        // the first guess scales the 63-column cache's floor (it holds 32 .. 63 columns below tau1) to the band's width
-        const float tau1 = a.cache_val[(int64_t)i * KC + KCU];
-        if (!(delta > 0.0f) || !(delta < 1e30f)) {
-            delta = (tau1 - umin) * (float)(K2 / 64);
-            if (!(delta > 0.0f) || !(delta < 1e30f)) delta = 1e-3f;
-        }
-        float lo = 0.0f, hi = INFINITY, tau = -INFINITY;
-        int cnt = 0, cnt_lo = 0;
-        uint32_t mine = 0;
-        bool ok = false;
-        for (int it = 0; it < 24; it++) {
-            tau = umin + delta;
-            cnt = count_below(tau, mine);
-            if (cnt > K2) {
-                hi = delta;
-                float nd = lo > 0.0f ? 0.5f * (lo + hi) : delta * fmaxf(0.0625f, 0.75f * (float)K2 / (float)cnt);
-                if (!(nd < hi) || !(nd > lo)) break;                // cannot separate: too many ties
-                delta = nd;
-            } else if (cnt < K2 / 2 && cnt < n && delta < 1e30f) {
-                lo = delta; cnt_lo = cnt;
-                float nd = hi < INFINITY ? 0.5f * (lo + hi) : delta * fminf(16.0f, 0.75f * (float)K2 / (float)(cnt > 0 ? cnt : 1));
-                if (hi < INFINITY && (!(nd < hi) || !(nd > lo))) { ok = true; break; }
-                delta = nd;
-            } else { ok = true; break; }
-        }
-        if (!ok || cnt > K2) {                                     // the largest floor known to admit <= band_k columns (possibly none)
-            if (lo > 0.0f) { delta = lo; tau = umin + lo; cnt = count_below(tau, mine); (void)cnt_lo; }
-            else { tau = -INFINITY; cnt = 0; mine = 0; }
-            if (cnt > K2) { tau = -INFINITY; cnt = 0; mine = 0; }
-        }
-        // collect: lane-local runs, the lanes' counts prefix-summed
-        uint32_t inc = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)inc, off); if (lane >= off) inc += y; }
-        int pos = (int)(inc - mine);
-        uint32_t *__restrict__ bc = a.band_col + (int64_t)i * K2;
-        float *__restrict__ bv = a.band_val + (int64_t)i * K2;
-        if (cnt > 0)
-            wave_row_sweep(row, n, lane, [&](int c, float x) { if ((x - a.v[c]) < tau) { bc[pos] = (uint32_t)c; bv[pos] = x; pos++; } });
-        if (lane == 0) { a.band_cnt[i] = cnt; a.band_tau[i] = tau; }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // AUGMENTATION (oracle/jv_oracle_impl.h, wide mode): shortest paths with (distance, tight-hop count) labels, run speculatively.
 //
 // Per column (global, L2): label = (ordered distance << 32 | tight hops << 20 | predecessor row), all-ones = unlabelled; an atomic min on it
@@ -690,7 +621,7 @@ constexpr int AP = 2;              // columns a wave settles per round (their lo
 
 size_t wide_aug_lds_bytes(int n, bool vlds, bool clds) {
     const size_t nblk = ((size_t)n + 63) / 64, nw32 = ((size_t)n + 31) / 32, npad = ((size_t)n + 3) & ~(size_t)3;
-    return ((nblk * 8 + 4 * nw32 * 4 + npad * ((vlds ? 4 : 0) + (clds ? 2 : 0)) + 15) / 16) * 16;
+    return ((nblk * 8 + 3 * nw32 * 4 + npad * ((vlds ? 4 : 0) + (clds ? 2 : 0)) + 15) / 16) * 16;
 }
 bool wide_aug_vlds(int n) { return n <= 65534 && wide_aug_lds_bytes(n, true, true) + 4096 <= (size_t)LDS_DYNAMIC_MAX; }
 bool wide_aug_clds(int n) { return n <= 65534 && wide_aug_lds_bytes(n, false, true) + 4096 <= (size_t)LDS_DYNAMIC_MAX; }
@@ -699,6 +630,7 @@ size_t wide_aug_lds_bytes(int n) { return wide_aug_lds_bytes(n, wide_aug_vlds(n)
 struct AugShared {
     unsigned long long T;          // best unassigned column: (ordered distance << 32 | tight hops << 20 | column)
     int ntouch, any[2], fail, anydense, rootdense, doroot, f, err;
+    int waste, stop;               // full-row relaxations of this launch; "return to the driver for fresh caches"
     int scans;
     int st_row[64], st_col[64];    // one-edge searches: their results, stored to global memory 64 at a time
     float st_val[64];
@@ -715,14 +647,12 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
     unsigned long long *bmin = reinterpret_cast<unsigned long long *>(w_smem);
     uint32_t *dirty = reinterpret_cast<uint32_t *>(bmin + nblk);
     uint32_t *asg = dirty + nw32;
-    uint32_t *dense = asg + nw32;              // rows whose 63-column cache could not certify the search ...
-    uint32_t *dense2 = dense + nw32;           // ... and whose band could not either: relaxed from the full cost row
-    float *s_v = reinterpret_cast<float *>(dense2 + nw32);
+    uint32_t *dense = asg + nw32;
+    float *s_v = reinterpret_cast<float *>(dense + nw32);
     uint16_t *s_cs = reinterpret_cast<uint16_t *>(s_v + (VLDS ? ((n + 3) & ~3) : 0));
     const int numfree = *reinterpret_cast<const int *>(a.misc + 128);
-    const int K2 = a.band_k;
     for (int b = tid; b < nblk; b += WT) bmin[b] = ~0ull;
-    for (int q = tid; q < nw32; q += WT) { dirty[q] = 0; dense[q] = 0; dense2[q] = 0; }
+    for (int q = tid; q < nw32; q += WT) { dirty[q] = 0; dense[q] = 0; }
     for (int c0 = 0; c0 < nw32 * 32; c0 += WT) {                 // assigned bits, 64 columns per wave and step
         const int c = c0 + tid;
         const uint64_t m = __ballot(c < n && a.colsol[c] >= 0);
@@ -733,7 +663,23 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             if (VLDS) s_v[j] = a.v[j];
             const int o = a.colsol[j]; s_cs[j] = o < 0 ? (uint16_t)0xFFFFu : (uint16_t)o;
         }
-    if (tid == 0) { s.T = ~0ull; s.ntouch = 0; s.any[0] = 0; s.any[1] = 0; s.fail = 0; s.anydense = 0; s.rootdense = 0; s.doroot = 0; s.f = 0; s.err = 0; s.scans = 0; }
+    // The searches may take several launches, with the row caches rebuilt by the whole chip in between (misc + 132 = searches
+    // done so far).  A cache floor bounds c - v in absolute terms, as of the build; every search lowers the prices of the columns it
+    // settles and raises their rows' duals with them, so after a few DEEP searches (few-cell-type chunks: a search settles most
+    // columns) the floors lie below what the next search asks for and row after row falls back to its full cost row -- while
+    // fresh caches certify practically everything (10 000-cell c4 chunk: 1.14 M full-row relaxations without a rebuild, 18 000
+    // with one every 32 searches).  a.aug_seg: -1 never return early; k > 0 after k searches; 0: when the full-row relaxations of
+    // this launch reach a.aug_waste (what a rebuild costs), or when a.seg_quorum workgroups of the launch have asked for one.
+    const int f0 = *reinterpret_cast<const int *>(a.misc + 132);
+    {
+        long long *wc = reinterpret_cast<long long *>(a.misc + 160);
+        if (wc[WC_AUG_LAUNCHES] > 0 && f0 >= numfree) {          // finished in an earlier launch
+            if (tid == 0 && a.seg_sync) a.seg_sync[1 + blockIdx.x] = 0;
+            return;
+        }
+    }
+    if (tid == 0) { s.waste = 0; s.stop = 0; }
+    if (tid == 0) { s.T = ~0ull; s.ntouch = 0; s.any[0] = 0; s.any[1] = 0; s.fail = 0; s.anydense = 0; s.rootdense = 0; s.doroot = 0; s.f = f0; s.err = 0; s.scans = 0; }
     __syncthreads();
     auto getv = [&](int j) -> float { return VLDS ? s_v[j] : ld_sc1(a.v + j); };
     auto getcs = [&](int j) -> int {
@@ -742,8 +688,9 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
     };
     auto is_asg = [&](int c) -> bool { return (asg[c >> 5] >> (c & 31)) & 1u; };
 
-    long long c_relax = 0, c_hops = 0, c_rounds = 0, c_proc = 0, c_trivial = 0, c_dense = 0, c_band = 0, c_verify = 0;   // (thread 0 / wave leaders)
+    long long c_relax = 0, c_hops = 0, c_rounds = 0, c_proc = 0, c_trivial = 0, c_dense = 0, c_verify = 0;   // (thread 0 / wave leaders)
     long long t_rounds = 0, t_verify = 0, t_finish = 0, t_triv = 0, t_mark = wall_clock64();
+
 #define AUG_LAP(acc) { const long long now_ = wall_clock64(); acc += now_ - t_mark; t_mark = now_; }
 
     // a relaxation in two halves: the offer (column `col` is offered the ordered distance `co` by row `row`; returns the label
@@ -764,8 +711,10 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
     };
     auto relax_to = [&](int col, unsigned long long lv, int row) { after_offer(col, lv, row, offer(col, lv, row)); };
 
-    int f = 0;
+    int f = f0;
     int par = 0;
+    int seg_done = 0;                                            // searches (other than one-edge ones) of this launch
+    bool announced = false;
     for (;;) {
         // ---- wave 0 disposes of the searches that end at once: the free row's best cached column is unassigned and its
         // cache certifies that (no column settled, no price changes: the path is one edge) ----
@@ -815,12 +764,23 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                 if (++nst == 64) { flush_one_edge(nst); nst = 0; }
             }
             flush_one_edge(nst);
-            if (lane == 0) s.f = f;
+            if (lane == 0) {
+                s.f = f;
+                if (seg_done > 0 && f < numfree) {               // back to the driver?  (never before one search is done)
+                    bool stop = a.aug_seg > 0 && seg_done >= a.aug_seg;
+                    if (a.aug_seg == 0) {
+                        if (s.waste >= a.aug_waste) { stop = true; if (!announced && a.seg_sync) atomicAdd(a.seg_sync, 1); announced = true; }
+                        else if (a.seg_sync && a.seg_quorum > 0 && ld_sc1(a.seg_sync) >= a.seg_quorum) stop = true;
+                    }
+                    if (stop) s.stop = 1;
+                }
+            }
         }
         __syncthreads();
         AUG_LAP(t_triv)
         f = uni(s.f);
-        if (f >= numfree) break;
+        if (f >= numfree || uni(s.stop)) break;
+        seg_done++;
         const int fr = a.freerows[f];
         const float *__restrict__ frow = a.cost + wrow_off(a.rowmap, fr, a.ld);
         const float ftau = a.cache_val[(int64_t)fr * KC + KCU];
@@ -899,30 +859,16 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     if (!dn[q]) continue;                          // the owner's cache could not certify: its whole cost row
                     const uint32_t dord = (uint32_t)(lab[q] >> 32), kq = (uint32_t)(lab[q] >> 20) & LKMAX;
                     const float h = (ca[q] - vp[q]) - ord2f(dord);
+                    const float *__restrict__ row = a.cost + wrow_off(a.rowmap, oi[q], a.ld);
                     const int pjq = pj[q], oiq = oi[q];
-                    // (such a row offers hundreds of candidates below the best unassigned distance when many columns are near-equal:
+                    // (a full row offers hundreds of candidates below the best unassigned distance when many columns are near-equal:
                     //  the label is read first -- a plain L2 load -- and the atomic follows only where it would change something)
-                    auto relax_dense = [&](int c, float x) {
+                    wave_row_sweep(row, n, lane, [&](int c, float x) {
                         const unsigned long long lv = edge_lv(f2ord((x - getv(c)) - h), dord, kq);
                         if (c != pjq && lv <= lv_of(s.T) && (lkey(lv, (uint32_t)oiq) < ld_sc1(a.label + c))) relax_to(c, lv, oiq);
-                    };
-                    if (K2 > 0 && !((dense2[oiq >> 5] >> (oiq & 31)) & 1u)) {
-                        // its band: up to band_k (column, cost) pairs, four 256-byte loads of each array in flight
-                        const int cnt = uni(a.band_cnt[oiq]);
-                        const uint32_t *__restrict__ bc = a.band_col + (int64_t)oiq * K2;
-                        const float *__restrict__ bv = a.band_val + (int64_t)oiq * K2;
-                        for (int e0 = 0; e0 < cnt; e0 += 256) {
-                            uint32_t cc[4]; float xx[4];
-#pragma unroll
-                            for (int r = 0; r < 4; r++) { const int e = e0 + r * 64 + lane; cc[r] = COLSENT; xx[r] = 0.0f; if (e < cnt) { cc[r] = bc[e]; xx[r] = bv[e]; } }
-#pragma unroll
-                            for (int r = 0; r < 4; r++) if (cc[r] != COLSENT) relax_dense((int)cc[r], xx[r]);
-                        }
-                        c_band++;
-                    } else {
-                        wave_row_sweep(a.cost + wrow_off(a.rowmap, oiq, a.ld), n, lane, relax_dense);
-                        c_dense++;
-                    }
+                    });
+                    c_dense++;
+                    if (lane == 0) atomicAdd(&s.waste, 1);
                 }
                 __syncthreads();
 #pragma unroll
@@ -961,14 +907,11 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                 // tight edge out of such a column would give (distance, k + 1), possibly below the end's label
                 if (lv_of(lbk) < lv_of(Tk) && is_asg(k)) {
                     const int i = getcs(k);
-                    const bool d1 = (dense[i >> 5] >> (i & 31)) & 1u, d2 = (dense2[i >> 5] >> (i & 31)) & 1u;
-                    if (!d1 || (K2 > 0 && !d2)) {
+                    if (!((dense[i >> 5] >> (i & 31)) & 1u)) {
                         const float h = (ld_sc1(a.cassign + k) - getv(k)) - ord2f(dord);
-                        bool failed = false;
-                        if (!d1 && !((a.cache_val[(int64_t)i * KC + KCU] - h) > D)) { atomicOr(&dense[i >> 5], 1u << (i & 31)); failed = true; }
-                        // (a row that fails its cache's floor is checked against its band's at once: no pass in between)
-                        if ((d1 || failed) && K2 > 0 && !((a.band_tau[i] - h) > D)) { atomicOr(&dense2[i >> 5], 1u << (i & 31)); failed = true; }
-                        if (failed) {
+                        const float bound = a.cache_val[(int64_t)i * KC + KCU] - h;
+                        if (!(bound > D)) {
+                            atomicOr(&dense[i >> 5], 1u << (i & 31));
                             atomicOr(&dirty[k >> 5], 1u << (k & 31));
                             atomicMin(&bmin[k >> 6], lkey(lv_of(lbk), (uint32_t)k));
                             atomicAdd(&s.fail, 1);
@@ -1032,7 +975,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             bmin[k >> 6] = ~0ull;
         }
         // (keeping the dense bits across searches was measured: fewer rounds, but more full-row relaxations -- slower)
-        if (s.anydense) for (int q = tid; q < nw32; q += WT) { dense[q] = 0; dense2[q] = 0; }
+        if (s.anydense) for (int q = tid; q < nw32; q += WT) dense[q] = 0;
         __syncthreads();
         if (tid == 0) { c_relax += s.scans; s.scans = 0; s.T = ~0ull; s.ntouch = 0; s.anydense = 0; s.rootdense = 0; s.f = f + 1; }
         f++;
@@ -1056,21 +999,23 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
     if (lane == 0) s_tot[w] = tot;
     // per-wave counters of the wave leaders
-    __shared__ long long s_wc[WNW][5];
-    if (lane == 0) { s_wc[w][0] = c_proc; s_wc[w][1] = c_dense; s_wc[w][2] = c_trivial; s_wc[w][3] = (w == 0) ? c_hops : 0; s_wc[w][4] = c_band; }
+    __shared__ long long s_wc[WNW][4];
+    if (lane == 0) { s_wc[w][0] = c_proc; s_wc[w][1] = c_dense; s_wc[w][2] = c_trivial; s_wc[w][3] = (w == 0) ? c_hops : 0; }
     __syncthreads();
     if (tid == 0) {
         double t = 0.0;
-        long long proc = 0, dn = 0, triv = 0, hops0 = 0, bnd = 0;
-        for (int k = 0; k < WNW; k++) { t += s_tot[k]; proc += s_wc[k][0]; dn += s_wc[k][1]; triv += s_wc[k][2]; hops0 += s_wc[k][3]; bnd += s_wc[k][4]; }
+        long long proc = 0, dn = 0, triv = 0, hops0 = 0;
+        for (int k = 0; k < WNW; k++) { t += s_tot[k]; proc += s_wc[k][0]; dn += s_wc[k][1]; triv += s_wc[k][2]; hops0 += s_wc[k][3]; }
         *reinterpret_cast<double *>(a.misc + 8) = t;
         long long *ctr = reinterpret_cast<long long *>(a.misc + 16);
         long long *wc = reinterpret_cast<long long *>(a.misc + 160);
-        ctr[C_AUG_INIT] = numfree; ctr[C_AUG_RELAX] = c_relax; ctr[C_AUGS] = numfree; ctr[C_HOPS] = hops0;
-        wc[WC_DENSE_AUG] = dn; wc[WC_BAND_AUG] = bnd; wc[WC_AUG_ROUNDS] = c_rounds; wc[WC_AUG_PROCESSED] = proc; wc[WC_TRIVIAL] = triv; wc[WC_VERIFY_PASSES] = c_verify;
+        ctr[C_AUG_INIT] = numfree; ctr[C_AUG_RELAX] += c_relax; ctr[C_AUGS] = numfree; ctr[C_HOPS] += hops0;
+        wc[WC_DENSE_AUG] += dn; wc[WC_AUG_LAUNCHES] += 1; wc[WC_AUG_ROUNDS] += c_rounds; wc[WC_AUG_PROCESSED] += proc; wc[WC_TRIVIAL] += triv; wc[WC_VERIFY_PASSES] += c_verify;
         if (s.err) *reinterpret_cast<int *>(a.misc + 4) = 1;
+        *reinterpret_cast<int *>(a.misc + 132) = s.err ? numfree : f;      // searches done (an error ends them)
+        if (a.seg_sync) a.seg_sync[1 + blockIdx.x] = s.err ? 0 : numfree - f;
         long long *dbg = reinterpret_cast<long long *>(a.misc + 256);      // (100 MHz ticks)
-        dbg[8] = t_rounds; dbg[9] = t_verify; dbg[10] = t_finish; dbg[11] = t_triv;
+        dbg[8] += t_rounds; dbg[9] += t_verify; dbg[10] += t_finish; dbg[11] += t_triv;
     }
 }
 
@@ -1107,13 +1052,6 @@ size_t wide_mc_state_bytes(int n) {
     const size_t nblk = ((size_t)n + 63) / 64, nw32 = ((size_t)n + 31) / 32;
     return ((nblk * 128 + 2 * nw32 * 4 + 255) / 256) * 256 + 256;
 }
-int wide_launch_band(const WideArgs *d_args, int nb, int n, hipStream_t stream) {
-    const int blocks = std::max(1, std::min((n + 3) / 4, std::max(64, 4096 / std::max(nb, 1))));
-    hipLaunchKernelGGL(wide_band_build, dim3(blocks, nb), dim3(256), 0, stream, d_args);
-    CYTO_HIP(hipGetLastError());
-    return CYTO_OK;
-}
-
 int wide_mc_groups(int nb, int n) {
     // Measured (round 3, tools/wide_large.py --groups G): on uniform instances the one-workgroup kernel is faster (n = 20 000: 39 ms
     // against 46 ms with 4-8 groups, 55 ms with 16) -- 4-8x the waves settle 1.8-2.6x the columns (speculation further from the
@@ -1123,7 +1061,6 @@ int wide_mc_groups(int nb, int n) {
     return 0;
 }
 
-template <typename T> __device__ __forceinline__ void st_sc1(T *p, T x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #define MC_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 __device__ __forceinline__ void mc_barrier(McCtl *c, int G, unsigned &gen) {

@@ -95,7 +95,7 @@ typedef struct {
     double wide_ms_list, wide_ms_chain;            /* time inside wide_arr spent in them (the kernels' own 100 MHz clock) */
     double wide_ms_aug_rounds, wide_ms_aug_verify, wide_ms_aug_finish, wide_ms_aug_trivial;   /* wide_aug: search rounds, certificate
                                                       passes, price update + flip + reset, one-edge searches (one-workgroup kernel) */
-    int64_t wide_band_aug;       /* augmentation: relaxations from a row's second-level cache (cyto_lap_opts.wide_band) */
+    int64_t wide_aug_launches;   /* augmentation: launches of the search kernel (row-cache rebuilds in between: cyto_lap_opts.wide_rebuild) */
 } cyto_lap_info;
 
 int cyto_lap_f32(int n, const float *cost, int64_t ld, int cost_on_device,
@@ -131,9 +131,10 @@ typedef struct {
     int32_t wide_groups;        /* wide solver, one problem: workgroups that run a search together, asynchronously, with the search
                                    state in L2 (wide_aug_mc).  0 / -1: one workgroup, state in LDS (faster on everything but
                                    few-cell-type chunks).  k > 0: k (<= 32).  Results do not depend on it */
-    int32_t wide_band;          /* wide solver, augmentation: entries of the second-level row caches (a row whose 63-column cache
-                                   cannot certify a search is relaxed from its band before its full cost row is read; 8 bytes per
-                                   entry and row).  0: 1024.  -1: none.  k > 0: k (a multiple of 64, <= 4096).  Results do not depend on it */
+    int32_t wide_rebuild;       /* wide solver, augmentation: when the searches pause for the row caches to be rebuilt by the whole chip against
+                                   the prices reached (a floor goes stale as searches lower the prices; deep-search instances otherwise
+                                   fall back to full cost rows).  0: when the full-row relaxations since the last rebuild have cost what
+                                   a rebuild costs.  -1: never.  k > 0: every k searches.  Results do not depend on it */
 } cyto_lap_opts;
 int cyto_lap_f32_opts(int n, const float *cost, int64_t ld, int cost_on_device,
                       int32_t *rowsol, int32_t *colsol, float *u, float *v, double *total,

@@ -466,6 +466,56 @@ def test_wide_search_on_several_workgroups(groups):
             assert g["info"].wide == 1
 
 
+@pytest.mark.parametrize("rebuild", [0, 1, 3, -1])
+def test_wide_row_caches_rebuilt_between_searches(rebuild):
+    # cyto_lap_opts.wide_rebuild: the search kernel returns to the driver when its row caches have gone stale (every search lowers
+    # prices; a floor is a bound as of the build), the whole chip rebuilds them against the prices reached and the searches go on
+    # where they stopped (few cell types: without it most settlements fall back to full cost rows).  The labels of a search do not
+    # depend on which rows were read in full: the oracle's answer bit for bit, whatever the schedule.
+    rng = np.random.default_rng(77)
+    prof = rng.normal(size=(6, 64)).astype(np.float32)
+    cases = []
+    for n in (1200, 4200):
+        rows = prof[rng.integers(0, 6, n)] + 0.05 * rng.normal(size=(n, 64)).astype(np.float32)
+        cols = prof[rng.integers(0, 6, n)] + 0.05 * rng.normal(size=(n, 64)).astype(np.float32)
+        cases.append(-(rows @ cols.T).astype(np.float32))
+    cases.append(rng.random((2500, 2500)).astype(np.float32))
+    cases.append(np.repeat(rng.random((300, 1200)), 4, axis=0).astype(np.float32))
+    launches = []
+    for c in cases:
+        for rounds in (0, 2):
+            g, o = _check_wide(c, opts=dict(wide_rebuild=rebuild), rounds=rounds)
+            launches.append(g["info"].wide_aug_launches)
+    assert all(k >= 1 for k in launches)
+    if rebuild == -1:
+        assert all(k == 1 for k in launches)
+    if rebuild == 1:
+        assert max(launches) > 10                              # one launch per search (one-edge searches aside)
+
+
+def test_wide_batch_rebuilds_only_what_is_unfinished():
+    # a batch in one launch per phase: problems that need fresh caches and problems that are done long before share the launches
+    from cytospace_amd.lap import lap_solve_batch
+    rng = np.random.default_rng(78)
+    prof = rng.normal(size=(5, 48)).astype(np.float32)
+    n = 3000
+    cs = []
+    for k in range(6):
+        if k % 2:
+            cs.append(rng.random((n, n)).astype(np.float32))
+        else:
+            rows = prof[rng.integers(0, 5, n)] + 0.05 * rng.normal(size=(n, 48)).astype(np.float32)
+            cols = prof[rng.integers(0, 5, n)] + 0.05 * rng.normal(size=(n, 48)).astype(np.float32)
+            cs.append(-(rows @ cols.T).astype(np.float32))
+    for rebuild in (0, 2):
+        res = lap_solve_batch(cs, return_info=True, opts=dict(mode=2, wide_rebuild=rebuild))
+        for c, g in zip(cs, res):
+            o = jv_oracle_wide(c, np.float32)
+            for key in ("rowsol", "colsol", "u", "v"):
+                assert np.array_equal(g[key], o[key]), key
+            assert g["info"].scans_aug_relax == o["stats"].scans_aug_relax and g["info"].path_hops == o["stats"].path_hops
+
+
 def test_one_process_two_devices():
     # kernels that need more than 64 KB of dynamic LDS (prices and owners in LDS) get their per-device attribute on EVERY device a
     # process uses: device 0 first, then device 1 (needs two GPUs)

@@ -1,10 +1,14 @@
-"""Throughput of K concurrent sub-spot chunk LAPs (10 000 cells each, c4/c5's unit of work) on ONE GPU, K = 1 ... 128."""
+"""Throughput of K concurrent sub-spot chunk LAPs (10 000 cells each, c4/c5's unit of work) on ONE GPU, K = 1 ... 128.
+usage: c4_concurrency.py [n K1 K2 ...] [--rebuild B]   (B: cyto_lap_opts.wide_rebuild; -1 = the row caches are never rebuilt during the searches)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from cytospace_amd import _lib
 from cytospace_amd.lap import lap_solve_batch_device
 from tools import instances
+rebuild = 0
+if "--rebuild" in sys.argv:
+    k = sys.argv.index("--rebuild"); rebuild = int(sys.argv[k + 1]); del sys.argv[k:k + 2]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 Ks = [int(x) for x in sys.argv[2:]] or [1, 8, 32, 64, 128]
 distinct = 4
@@ -14,7 +18,7 @@ lap_solve_batch_device([bufs[0].ptr], [n], max_concurrent=1)
 ref = None
 for K in Ks:
     t = time.perf_counter()
-    res = lap_solve_batch_device([b.ptr for b in bufs[:K]], [n] * K, max_concurrent=K, return_info=True)
+    res = lap_solve_batch_device([b.ptr for b in bufs[:K]], [n] * K, max_concurrent=K, return_info=True, opts=dict(wide_rebuild=rebuild))
     wall = time.perf_counter() - t
     ref = res[0]["colsol"] if ref is None else ref
     ok = all(np.array_equal(res[k]["colsol"], res[k % distinct]["colsol"]) for k in range(K)) and np.array_equal(res[0]["colsol"], ref)
