@@ -3015,7 +3015,11 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             wa.cache_col = c.cache_col; wa.cache_val = c.cache_val; wa.misc = c.misc;
             wa.max_rounds = pl.wide_rounds;
             wa.aug_seg = mcg > 0 ? -1 : pl.wide_rebuild;
-            wa.aug_waste = (int)std::max<long long>(16, (2000000ll + (long long)n * n / 100) / n);   // what a rebuild costs, in full-row relaxations
+            // what a rebuild costs, in full-row relaxations of ONE workgroup (a relaxation sweeps n elements at ~5 G/s; a pass costs
+            // ~0.4 ms of launches and synchronisation plus one read of every unfinished problem's matrix by the whole chip, ~100x
+            // faster per element -- and the problems of a batch are rebuilt one after the other while their workgroups all wait)
+            wa.aug_waste = (int)std::min<long long>(1 << 30, std::max<long long>(16, (2000000ll + (long long)nl * n * n / 100) / n));
+            wa.arr_waste = std::max(8, wa.aug_waste / 3);          // (a full-row bid with its cache refresh: three sweeps)
             wa.seg_quorum = nl > 1 ? std::max(1, nl / 4) : 0;
             wa.seg_sync = nullptr;
             wa.mc_groups = mcg; wa.gbmin = nullptr; wa.gdirty = nullptr; wa.gasg = nullptr; wa.gdense = nullptr; wa.ctl = nullptr;
@@ -3039,11 +3043,22 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
         if ((rc = d_wa.alloc(sizeof(WideArgs) * nl, stream)) || (rc = d_sync.alloc(sizeof(int32_t) * ((size_t)nl + 1), stream))) return rc;
         for (WideArgs &wa : h_wa) wa.seg_sync = d_sync.as<int32_t>();
         CYTO_HIP(hipMemcpyAsync(d_wa.p, h_wa.data(), sizeof(WideArgs) * nl, hipMemcpyHostToDevice, stream));
-        if ((rc = wide_launch_rt(d_wa.as<WideArgs>(), nl, n, stream)) || (rc = wide_launch_arr(d_wa.as<WideArgs>(), nl, n, stream, pl.wide_rounds))) return rc;
+        if ((rc = wide_launch_rt(d_wa.as<WideArgs>(), nl, n, stream))) return rc;
+        std::vector<int32_t> h_sync((size_t)nl + 1, 1);
+        for (int pass = 0;; pass++) {                              // the row-reduction rounds (they pause when the caches have gone stale)
+            if (pass && (rc = build_caches(h_sync.data() + 1))) return rc;
+            CYTO_HIP(hipMemsetAsync(d_sync.p, 0, sizeof(int32_t), stream));
+            if ((rc = wide_launch_arr(d_wa.as<WideArgs>(), nl, n, stream, pl.wide_rounds, pass > 0))) return rc;
+            if (h_wa[0].aug_seg != 0) break;                       // (no pauses asked for: nothing to wait for)
+            CYTO_HIP(hipMemcpyAsync(h_sync.data(), d_sync.p, sizeof(int32_t) * ((size_t)nl + 1), hipMemcpyDeviceToHost, stream));
+            CYTO_HIP(hipStreamSynchronize(stream));
+            bool done = true;
+            for (int k = 0; k < nl; k++) done = done && h_sync[(size_t)k + 1] == 0;
+            if (done) break;
+        }
         CYTO_HIP(hipEventRecord(ev_arr_done, stream));
         // the searches, in as many launches as they ask for: wide_aug returns when its row caches have gone stale (lap_wide.hip) and
         // the whole chip rebuilds them against the prices reached -- only for the problems that still have searches to run
-        std::vector<int32_t> h_sync((size_t)nl + 1, 1);
         for (int pass = 0;; pass++) {
             if ((rc = build_caches(pass ? h_sync.data() + 1 : nullptr))) return rc;
             CYTO_HIP(hipMemsetAsync(d_sync.p, 0, sizeof(int32_t), stream));
@@ -3379,6 +3394,7 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
                     info->wide_ms_list = dbg[1] * 1e-5; info->wide_ms_chain = dbg[3] * 1e-5;
                     info->wide_ms_aug_rounds = dbg[8] * 1e-5; info->wide_ms_aug_verify = dbg[9] * 1e-5;
                     info->wide_ms_aug_finish = dbg[10] * 1e-5; info->wide_ms_aug_trivial = dbg[11] * 1e-5;
+                    info->wide_arr_launches = dbg[12];
                 }
             }
         }

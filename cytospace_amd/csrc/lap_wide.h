@@ -13,12 +13,13 @@ namespace cyto {
 //   slot_j, slot_p, slot_c  [n] per active slot: the bid's column (-1 = retired), price, raw cost of that entry
 //   cache_col/val   [n][64] row caches (lap_jv.hip: build_row_caches)
 //   misc            512 bytes: +4 status, +8 double total, +16 long long counters[] (lap_jv.hip indices), +160.. wide counters,
-//                   +256 phase timers, +384 the control block the first row-reduction rounds leave for wide_arr
+//                   +256 phase timers ([12]: launches of wide_arr), +384 the control block the first row-reduction rounds leave for wide_arr
 //   gbmin, gdirty, gasg, gdense, ctl   the multi-workgroup augmentation's shared state (global memory; wide_aug_mc): per 64-column
 //                   block the smallest dirty label, dirty / assigned / dense bitmaps, a 256-byte control block (zeroed by the host)
 //   mc_groups       workgroups that search one problem together (0: the one-workgroup kernel)
 //   seg_sync        shared by the launch, or null: [0] workgroups that asked for fresh caches (zeroed by the driver before every launch
-//                   of wide_aug), [1 + b] searches problem b still has to run when the launch ends
+//                   of wide_arr / wide_aug), [1 + b] wide_arr: 1 = problem b's rounds paused; wide_aug: searches problem b still has to run
+//   arr_waste       wide_arr: full-row bids (with their cache refresh) of one launch after which the list rounds pause (aug_seg == 0)
 //   aug_seg         when a launch of wide_aug returns to the driver for fresh row caches: -1 never, k > 0 after k searches, 0 when
 //                   its full-row relaxations reach aug_waste or seg_quorum workgroups of the launch have asked (misc + 132 holds the
 //                   number of searches done)
@@ -31,7 +32,7 @@ namespace cyto {
     P(int32_t, freerows) P(int32_t, act0) P(int32_t, act1) P(int32_t, touched) P(int32_t, slot_j) P(float, slot_p)            \
     P(float, slot_c) P(uint32_t, cache_col) P(float, cache_val) P(char, misc) S(long long, max_rounds)                     \
     P(unsigned long long, gbmin) P(uint32_t, gdirty) P(uint32_t, gasg) P(uint32_t, gdense) P(char, ctl) S(int, mc_groups)  \
-    P(int32_t, seg_sync) S(int, aug_seg) S(int, aug_waste) S(int, seg_quorum)
+    P(int32_t, seg_sync) S(int, aug_seg) S(int, aug_waste) S(int, arr_waste) S(int, seg_quorum)
 #define WIDE_F_PTR(T, name) T *name;
 #define WIDE_F_VAL(T, name) T name;
 struct WideArgs { WIDE_FIELDS(WIDE_F_PTR, WIDE_F_VAL) };
@@ -43,7 +44,7 @@ enum { WC_ROUNDS = 0, WC_BIDS, WC_RETIRED, WC_ACTIVE_LEFT, WC_FREE_ARR, WC_DENSE
 size_t wide_aug_lds_bytes(int n);
 // phases, each one launch for the whole batch (d_args: device array of nb WideArgs)
 int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream);        // Jacobi reduction transfer (v0 snapshot in cassign)
-int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, long long max_rounds);   // Jacobi rounds of augmenting row reduction + free list
+int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, long long max_rounds, bool resume);   // Jacobi rounds of augmenting row reduction + free list
 int wide_launch_aug(const WideArgs *d_args, int nb, int n, hipStream_t stream, int mc_groups);   // succ-clamped shortest-path augmentation, duals, total
 int wide_mc_groups(int nb, int n);                                                     // how many workgroups search one problem together (0: one)
 size_t wide_mc_state_bytes(int n);                                                     // gbmin + 3 bitmaps + control block

@@ -161,6 +161,7 @@ constexpr int ASL = WNW * ACS;         // slots of a chain round
 struct ArrShared {
     int cnt[2];
     int retired, dense, ndeal;
+    int pause;                          // the list rounds return to the driver for fresh row caches
     int wcnt[WNW];
     int sm_j[ASL], sm_i[ASL];
     float sm_p[ASL];
@@ -295,7 +296,7 @@ template <bool VLDS, bool CLDS> struct ArrCtx {
 // round r as three launches over all CUs -- bids (a wave per active row, prices and owners read from L2), resolution (a thread per
 // bid), reset of the bid words -- and leave the active list, the round count and the counters in the control block at misc + 384,
 // where wide_arr picks them up.  The same round as in wide_arr (a pure function of the state).
-struct ArrHead { int cnt[2]; int started, free_cr; long long round, bids; int retired, dense; };
+struct ArrHead { int cnt[2]; int started, free_cr; long long round, bids; int retired, dense; int done, launches; };
 constexpr int HEADB = 256;             // threads of the head kernels' workgroups
 
 __global__ __launch_bounds__(HEADB) void wide_arr_head_init(const WideArgs *__restrict__ batch) {
@@ -395,7 +396,16 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
     cx.s_cs = reinterpret_cast<uint16_t *>(cx.s_v + (VLDS ? ((n + 3) & ~3) : 0));
     cx.s = &s; cx.lane = lane;
     const long long t_kernel0 = wall_clock64();
-    if (tid == 0) { s.cnt[0] = 0; s.cnt[1] = 0; s.retired = 0; s.dense = 0; s.ndeal = 0; }
+    // The rounds may take several launches (the control block at misc + 384 carries the state): like the searches of wide_aug, the
+    // list rounds return to the driver when the row caches have gone stale -- a row whose cache cannot certify its bid reads its
+    // full row and rebuilds its own cache, three sweeps on one wave; once those have cost what a rebuild of ALL caches by the
+    // whole chip costs (a.arr_waste of them in this launch; or a.seg_quorum workgroups of the launch have asked), that is cheaper.
+    ArrHead *h = reinterpret_cast<ArrHead *>(a.misc + 384);
+    if (h->done) {                                               // finished in an earlier launch
+        if (tid == 0 && a.seg_sync) a.seg_sync[1 + blockIdx.x] = 0;
+        return;
+    }
+    if (tid == 0) { s.cnt[0] = 0; s.cnt[1] = 0; s.retired = 0; s.dense = 0; s.ndeal = 0; s.pause = 0; }
     if (CLDS)
         for (int j = tid; j < n; j += WT) {
             if (VLDS) cx.s_v[j] = a.v[j];
@@ -405,7 +415,6 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
 
     // the active list: what the first rounds on the whole chip left (wide_arr_head_*), else every free row (in any order -- a
     // round does not depend on it)
-    const ArrHead *h = reinterpret_cast<const ArrHead *>(a.misc + 384);
     const bool headed = h->started != 0;
     int cur = 0;
     long long round = 0, bids = 0;
@@ -430,10 +439,14 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
     long long t_list = 0, t_chain = 0, n_list = 0, n_chain = 0, n_deal = 0;
     int32_t *A = cur ? a.act1 : a.act0, *B = cur ? a.act0 : a.act1;
     int na = free_cr;
+    const int dense0 = s.dense;
+    const long long round0 = round;
+    bool paused = false, announced = false;
     // ================= LIST rounds =================
     for (;;) {
         na = uni(s.cnt[cur]);
         if (na <= ASL || round >= a.max_rounds) break;
+        if (uni(s.pause)) { paused = true; break; }
         for (int base = 0; base < na; base += ASL) {
             int ri[ACS]; uint32_t col[ACS]; float val[ACS];
 #pragma unroll
@@ -473,7 +486,13 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
             const int jt = ld_sc1(a.slot_j + slot);
             if (jt >= 0) a.bid[jt] = ~0ull;
         }
-        if (tid == 0) s.cnt[cur] = 0;
+        if (tid == 0) {
+            s.cnt[cur] = 0;
+            if (a.aug_seg == 0 && a.seg_sync && round > round0) {     // (s.dense: complete since the barrier behind the bids)
+                if (s.dense - dense0 >= a.arr_waste) { s.pause = 1; if (!announced) atomicAdd(a.seg_sync, 1); announced = true; }
+                else if (a.seg_quorum > 0 && ld_sc1(a.seg_sync) >= a.seg_quorum) s.pause = 1;
+            }
+        }
         cur ^= 1;
         { int32_t *t_ = A; A = B; B = t_; }
         round++;
@@ -483,7 +502,7 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
     const long long t_chain0 = wall_clock64();
     // ================= CHAIN rounds: wave w holds the rows of slots q * 16 + w =================
     int left = na;                                               // rows still active when the rounds end
-    if (na > 0 && na <= ASL && round < a.max_rounds) {
+    if (!paused && na > 0 && na <= ASL && round < a.max_rounds) {
         int my[ACS], jt[ACS], i0[ACS];
         uint32_t col[ACS], ncol[ACS];
         float val[ACS], nval[ACS], pt[ACS], ct[ACS];
@@ -601,7 +620,14 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
         wc[WC_FREE_ARR] = numfree; wc[WC_DENSE_ARR] = s.dense;
         *reinterpret_cast<int *>(a.misc + 128) = numfree;
         long long *dbg = reinterpret_cast<long long *>(a.misc + 256);      // (100 MHz ticks)
-        dbg[0] = n_list; dbg[1] = t_list; dbg[2] = n_chain; dbg[3] = t_chain; dbg[4] = n_deal; dbg[6] = wall_clock64() - t_tail0;
+        dbg[0] = n_list; dbg[1] += t_list; dbg[2] = n_chain; dbg[3] += t_chain; dbg[4] = n_deal; dbg[6] = wall_clock64() - t_tail0;
+        // the state for the next launch, if the rounds paused (cur == round & 1: both flip together)
+        h->started = 1; h->round = round; h->bids = bids; h->retired = s.retired; h->dense = s.dense; h->cnt[cur] = paused ? na : 0;
+        h->cnt[cur ^ 1] = 0; h->free_cr = free_cr; h->done = paused ? 0 : 1; h->launches += 1;
+#ifndef CYTO_WIDE_PROF
+        dbg[12] = h->launches;
+#endif
+        if (a.seg_sync) a.seg_sync[1 + blockIdx.x] = paused ? 1 : 0;
     }
 }
 
@@ -1410,9 +1436,10 @@ int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream) {
     return CYTO_OK;
 }
 
-int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, long long max_rounds) {
+int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, long long max_rounds, bool resume) {
     // the first rounds, with thousands of bids each, on the whole chip; the long tail on one workgroup per problem
-    if (n >= 4096 && max_rounds > 0) {
+    // (resume: the rounds paused for fresh row caches -- wide_arr alone picks them up)
+    if (n >= 4096 && max_rounds > 0 && !resume) {
         const int rounds = (int)std::min<long long>(8, max_rounds);
         const int bx = std::max(1, std::min((n + 255) / 256, 1024 / std::max(1, std::min(nb, 8))));
         int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(wide_arr_head_bid));

@@ -95,6 +95,7 @@ typedef struct {
     double wide_ms_list, wide_ms_chain;            /* time inside wide_arr spent in them (the kernels' own 100 MHz clock) */
     double wide_ms_aug_rounds, wide_ms_aug_verify, wide_ms_aug_finish, wide_ms_aug_trivial;   /* wide_aug: search rounds, certificate
                                                       passes, price update + flip + reset, one-edge searches (one-workgroup kernel) */
+    int64_t wide_arr_launches;   /* row reduction: launches of the round kernel (row-cache rebuilds in between) */
     int64_t wide_aug_launches;   /* augmentation: launches of the search kernel (row-cache rebuilds in between: cyto_lap_opts.wide_rebuild) */
 } cyto_lap_info;
 

@@ -15,6 +15,12 @@ distinct = 4
 costs = [instances.c4_chunk_cost(n, seed=4 + k)[0] for k in range(distinct)]
 bufs = [_lib.DeviceBuffer.from_numpy(costs[k % distinct]) for k in range(max(Ks))]
 lap_solve_batch_device([bufs[0].ptr], [n], max_concurrent=1)
+for k in range(min(distinct, len(bufs))):                     # every distinct instance alone: the slowest one bounds a batch from below
+    t = time.perf_counter()
+    r = lap_solve_batch_device([bufs[k].ptr], [n], max_concurrent=1, return_info=True, opts=dict(wide_rebuild=rebuild))[0]
+    i = r["info"]
+    print(f"instance {k} alone: {time.perf_counter() - t:.2f} s (arr {i.ms_arr:.0f} ms, aug {i.ms_aug:.0f} ms, launches {i.wide_arr_launches} + {i.wide_aug_launches}, "
+          f"full-row bids {i.wide_dense_arr}, full-row relaxations {i.wide_dense_aug})", flush=True)
 ref = None
 for K in Ks:
     t = time.perf_counter()
@@ -23,4 +29,6 @@ for K in Ks:
     ref = res[0]["colsol"] if ref is None else ref
     ok = all(np.array_equal(res[k]["colsol"], res[k % distinct]["colsol"]) for k in range(K)) and np.array_equal(res[0]["colsol"], ref)
     kms = [r["info"].ms_total for r in res]
+    i0 = res[0]["info"]
+    print(f"      problem 0: arr {i0.ms_arr:.0f} ms in {i0.wide_arr_launches} launches, aug {i0.ms_aug:.0f} ms in {i0.wide_aug_launches}; full-row bids {i0.wide_dense_arr}, relaxations {i0.wide_dense_aug}")
     print(f"K={K:4d}: wall {wall:7.2f} s  {K * n / wall:9.0f} assignments/s  per-chunk kernel ms min/mean/max {min(kms):.0f}/{np.mean(kms):.0f}/{max(kms):.0f}  identical={ok}", flush=True)

@@ -26,4 +26,4 @@ with ExpressionContext(sc, st, already_normalized=False) as ctx:
         print(f"K={K:3d}: wall {wall:6.2f} s  {K * chunk / wall:9.0f} assignments/s  chunk0: gather {i0.ms_standardize:.1f} gemm {i0.ms_gemm:.1f} "
               f"lap {i0.lap.ms_total:.0f} ms (arr {i0.lap.ms_arr:.0f}, aug {i0.lap.ms_aug:.0f}), scans rt+arr {i0.lap.scans_redtransfer + i0.lap.scans_arr} "
               f"aug {i0.lap.scans_aug_relax} (dense {i0.lap.aug_dense_scans}, skipped {i0.lap.aug_scans_skipped}), searches {i0.lap.augmentations}, "
-              f"handover {i0.lap.aug_handover}  perm={ok}", flush=True)
+              f"launches {i0.lap.wide_arr_launches}+{i0.lap.wide_aug_launches} full-row bids {i0.lap.wide_dense_arr} relaxations {i0.lap.wide_dense_aug}  perm={ok}", flush=True)
