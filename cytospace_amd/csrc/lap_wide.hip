@@ -296,7 +296,7 @@ template <bool VLDS, bool CLDS> struct ArrCtx {
 // round r as three launches over all CUs -- bids (a wave per active row, prices and owners read from L2), resolution (a thread per
 // bid), reset of the bid words -- and leave the active list, the round count and the counters in the control block at misc + 384,
 // where wide_arr picks them up.  The same round as in wide_arr (a pure function of the state).
-struct ArrHead { int cnt[2]; int started, free_cr; long long round, bids; int retired, dense; int done, launches; };
+struct ArrHead { int cnt[2]; int started, free_cr; long long round, bids; int retired, dense; int done, launches; long long list_rounds; };
 constexpr int HEADB = 256;             // threads of the head kernels' workgroups
 
 __global__ __launch_bounds__(HEADB) void wide_arr_head_init(const WideArgs *__restrict__ batch) {
@@ -498,7 +498,8 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
         round++;
         __syncthreads();
     }
-    t_list = wall_clock64() - t_start; n_list = round;
+    t_list = wall_clock64() - t_start;
+    n_list = (headed && h->launches > 0) ? h->list_rounds + (round - round0) : round;      // (the head rounds count as list rounds)
     const long long t_chain0 = wall_clock64();
     // ================= CHAIN rounds: wave w holds the rows of slots q * 16 + w =================
     int left = na;                                               // rows still active when the rounds end
@@ -559,6 +560,12 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
             }
             if (lane == 0) s.wcnt[w] = nact;
             round++;
+            // (a full-row bid with its cache refresh holds up the whole round here: 16 waves wait for the one that sweeps -- a
+            //  quarter of the list regime's allowance, then the rows go back to the list and the rounds pause for fresh caches)
+            if (tid == 0 && a.aug_seg == 0 && a.seg_sync) {
+                if (s.dense - dense0 >= (a.arr_waste + 3) / 4) { s.pause = 1; if (!announced) atomicAdd(a.seg_sync, 1); announced = true; }
+                else if (a.seg_quorum > 0 && ld_sc1(a.seg_sync) >= a.seg_quorum) s.pause = 1;
+            }
 #ifdef CYTO_WIDE_PROF
             CH_LAP(3)
 #endif
@@ -573,6 +580,17 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
             CH_LAP(4)
 #endif
             if (na == 0 || round >= a.max_rounds) break;
+            if (uni(s.pause)) {
+                cur = (int)(round & 1);                                // the list the next launch reads: by the round's parity
+                A = cur ? a.act1 : a.act0;
+                if (tid == 0) s.cnt[cur] = 0;
+                lds_barrier();
+#pragma unroll
+                for (int q = 0; q < ACS; q++)
+                    if (my[q] >= 0 && lane == 0) st_sc1(A + atomicAdd(&s.cnt[cur], 1), (int32_t)my[q]);
+                paused = true;
+                break;
+            }
             if (na * 2 <= dealt && dealt > WNW) {
                 // half of the rows have dropped out: deal the rest out again, round-robin over the waves
 #pragma unroll
@@ -623,7 +641,7 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
         dbg[0] = n_list; dbg[1] += t_list; dbg[2] = n_chain; dbg[3] += t_chain; dbg[4] = n_deal; dbg[6] = wall_clock64() - t_tail0;
         // the state for the next launch, if the rounds paused (cur == round & 1: both flip together)
         h->started = 1; h->round = round; h->bids = bids; h->retired = s.retired; h->dense = s.dense; h->cnt[cur] = paused ? na : 0;
-        h->cnt[cur ^ 1] = 0; h->free_cr = free_cr; h->done = paused ? 0 : 1; h->launches += 1;
+        h->cnt[cur ^ 1] = 0; h->free_cr = free_cr; h->done = paused ? 0 : 1; h->launches += 1; h->list_rounds = n_list;
 #ifndef CYTO_WIDE_PROF
         dbg[12] = h->launches;
 #endif

@@ -27,3 +27,6 @@ with ExpressionContext(sc, st, already_normalized=False) as ctx:
               f"lap {i0.lap.ms_total:.0f} ms (arr {i0.lap.ms_arr:.0f}, aug {i0.lap.ms_aug:.0f}), scans rt+arr {i0.lap.scans_redtransfer + i0.lap.scans_arr} "
               f"aug {i0.lap.scans_aug_relax} (dense {i0.lap.aug_dense_scans}, skipped {i0.lap.aug_scans_skipped}), searches {i0.lap.augmentations}, "
               f"launches {i0.lap.wide_arr_launches}+{i0.lap.wide_aug_launches} full-row bids {i0.lap.wide_dense_arr} relaxations {i0.lap.wide_dense_aug}  perm={ok}", flush=True)
+        L = i0.lap
+        print(f"        wide_arr: {L.wide_list_rounds} list rounds {L.wide_ms_list:.1f} ms, {L.wide_chain_rounds} chain rounds {L.wide_ms_chain:.1f} ms, retired {L.wide_retired}, free after {L.free_after_arr2} | "
+              f"wide_aug: {L.wide_aug_rounds} rounds {L.wide_ms_aug_rounds:.1f} ms, settled {L.wide_aug_settled}, verify {L.wide_ms_aug_verify:.1f}, finish {L.wide_ms_aug_finish:.1f}, one-edge {L.wide_trivial} in {L.wide_ms_aug_trivial:.1f} ms", flush=True)
