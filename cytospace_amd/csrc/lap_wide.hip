@@ -867,18 +867,40 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     if (pk[q] && lane == 0) { atomicAnd(&dirty[pj[q] >> 5], ~(1u << (pj[q] & 31))); s.any[par] = 1; }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the bits are cleared before the labels are read
+                // Everything the two settlements read is requested in ONE go, without a branch in between: label and owner entry of
+                // both columns, then (the owners come from LDS) both cache rows -- a wave without a pick reads column 0's, harmlessly.
+                // (With the loads inside `if (picked)` blocks the compiler drains the memory counter at every join: label 0, label 1,
+                //  cache rows, offer 0, offer 1 were five L2 round trips in a row, most of a round's 4.1 us.)
+                int pjx[AP];
+                unsigned long long lab_r[AP];
+                float ca_r[AP], vp_r[AP];
+                int oi_r[AP];
 #pragma unroll
                 for (int q = 0; q < AP; q++) {
-                    lab[q] = ~0ull; ca[q] = 0.0f; vp[q] = 0.0f; oi[q] = 0;
-                    if (pk[q]) { lab[q] = uni(ld_sc1(a.label + pj[q])); ca[q] = uni(ld_sc1(a.cassign + pj[q])); vp[q] = uni(getv(pj[q])); oi[q] = uni(getcs(pj[q])); }
+                    pjx[q] = pk[q] ? pj[q] : 0;
+                    lab_r[q] = ld_sc1(a.label + pjx[q]); ca_r[q] = ld_sc1(a.cassign + pjx[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < AP; q++) { vp_r[q] = getv(pjx[q]); oi_r[q] = getcs(pjx[q]); }
+#pragma unroll
+                for (int q = 0; q < AP; q++) {
+                    oi[q] = uni(oi_r[q]);
+                    const int oix = oi[q] < 0 ? 0 : oi[q];
+                    col[q] = a.cache_col[(int64_t)oix * KC + lane]; val[q] = a.cache_val[(int64_t)oix * KC + lane];
                 }
 #pragma unroll
                 for (int q = 0; q < AP; q++) {
-                    col[q] = COLSENT; val[q] = 0.0f;
-                    if (pk[q]) { col[q] = a.cache_col[(int64_t)oi[q] * KC + lane]; val[q] = a.cache_val[(int64_t)oi[q] * KC + lane]; }
+                    lab[q] = pk[q] ? uni(lab_r[q]) : ~0ull; ca[q] = uni(ca_r[q]); vp[q] = uni(vp_r[q]);
+                    if (!pk[q]) { col[q] = COLSENT; oi[q] = 0; }
                 }
                 unsigned long long old[AP], co[AP];
                 bool off[AP], dn[AP];
+                float vc[AP];
+#pragma unroll
+                for (int q = 0; q < AP; q++) {                       // (the cached columns' prices: LDS, or one more request for both)
+                    const bool valid = lane < KCU && col[q] != COLSENT;
+                    vc[q] = getv(valid ? (int)col[q] : pjx[q]);
+                }
 #pragma unroll
                 for (int q = 0; q < AP; q++) {
                     off[q] = false; dn[q] = false; old[q] = 0; co[q] = 0;
@@ -887,10 +909,31 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                         c_proc++;
                         if ((dense[oi[q] >> 5] >> (oi[q] & 31)) & 1u) { dn[q] = true; continue; }
                         const float h = (ca[q] - vp[q]) - ord2f(dord);
-                        if (lane < KCU && col[q] != COLSENT && (int)col[q] != pj[q]) {
-                            const unsigned long long lv = edge_lv(f2ord((val[q] - getv((int)col[q])) - h), dord, kq);
-                            if (lv <= Tlv) { off[q] = true; co[q] = lv; old[q] = offer((int)col[q], lv, oi[q]); }
-                        }
+                        const unsigned long long lv = edge_lv(f2ord((val[q] - vc[q]) - h), dord, kq);
+                        off[q] = lane < KCU && col[q] != COLSENT && (int)col[q] != pj[q] && lv <= Tlv;
+                        co[q] = lv;
+                    }
+                }
+                {   // both columns' offers (a returning atomic min per lane that has one) in flight together: the lanes are masked by
+                    // hand -- as two `if` blocks each atomic was followed by a full wait at the block's end
+                    static_assert(AP == 2, "two offers per wave and round");
+                    const uint64_t m0 = __ballot(off[0]), m1 = __ballot(off[1]);
+                    if (m0 | m1) {
+                        unsigned long long *p0 = a.label + (off[0] ? (int)col[0] : 0), *p1 = a.label + (off[1] ? (int)col[1] : 0);
+                        const unsigned long long k0 = lkey(co[0], (uint32_t)oi[0]), k1 = lkey(co[1], (uint32_t)oi[1]);
+                        unsigned long long r0, r1;
+                        uint64_t sv;
+                        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                                     "s_and_b64 exec, %[sv], %[m0]\n\t"
+                                     "global_atomic_umin_x2 %[r0], %[a0], %[d0], off sc0\n\t"
+                                     "s_and_b64 exec, %[sv], %[m1]\n\t"
+                                     "global_atomic_umin_x2 %[r1], %[a1], %[d1], off sc0\n\t"
+                                     "s_mov_b64 exec, %[sv]\n\t"
+                                     "s_waitcnt vmcnt(0)"
+                                     : [r0] "=&v"(r0), [r1] "=&v"(r1), [sv] "=&s"(sv)
+                                     : [a0] "v"(p0), [d0] "v"(k0), [a1] "v"(p1), [d1] "v"(k1), [m0] "s"(m0), [m1] "s"(m1)
+                                     : "memory");
+                        old[0] = off[0] ? r0 : 0; old[1] = off[1] ? r1 : 0;
                     }
                 }
 #pragma unroll
@@ -915,20 +958,26 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     if (lane == 0) atomicAdd(&s.waste, 1);
                 }
                 __syncthreads();
+                {   // the blocks the wave took from: their smallest dirty columns now (both blocks' labels requested together; a lane
+                    // whose column is not dirty reads the picked column's label instead of branching around the load)
+                    bool db[AP]; unsigned long long lbr[AP];
 #pragma unroll
-                for (int q = 0; q < AP; q++) {
-                    if (!pk[q]) continue;                          // the block the wave took from: its smallest dirty column now
-                    const int b = pj[q] >> 6, c = b * 64 + lane;
-                    const bool db = c < n && ((dirty[c >> 5] >> (c & 31)) & 1u);
-                    unsigned long long key = ~0ull;
-                    if (__ballot(db)) {                              // smallest (distance, k) among the dirty columns: two 32-bit reductions
-                        const unsigned long long lb = db ? ld_sc1(a.label + c) : ~0ull;
+                    for (int q = 0; q < AP; q++) {
+                        const int c = (pjx[q] >> 6) * 64 + lane;
+                        db[q] = pk[q] && c < n && ((dirty[c >> 5] >> (c & 31)) & 1u);
+                        lbr[q] = ld_sc1(a.label + (db[q] ? c : pjx[q]));
+                    }
+#pragma unroll
+                    for (int q = 0; q < AP; q++) {
+                        if (!pk[q]) continue;
+                        const int b = pj[q] >> 6, c = b * 64 + lane;
+                        const unsigned long long lb = db[q] ? lbr[q] : ~0ull;       // smallest (distance, k): two 32-bit reductions
                         const uint32_t dk = (uint32_t)(lb >> 32);
                         const uint32_t m = wave_min_u32(dk);
-                        const uint32_t lo2 = (db && dk == m) ? (((uint32_t)lb & 0xFFF00000u) | (uint32_t)c) : 0xFFFFFFFFu;
-                        key = ((unsigned long long)m << 32) | wave_min_u32(lo2);
+                        const uint32_t lo2 = (db[q] && dk == m) ? (((uint32_t)lb & 0xFFF00000u) | (uint32_t)c) : 0xFFFFFFFFu;
+                        const unsigned long long key = m == 0xFFFFFFFFu ? ~0ull : (((unsigned long long)m << 32) | wave_min_u32(lo2));
+                        if (lane == 0) bmin[b] = key;
                     }
-                    if (lane == 0) bmin[b] = key;
                 }
                 const int any = uni(s.any[par]);
                 if (tid == 0) s.any[par ^ 1] = 0;
