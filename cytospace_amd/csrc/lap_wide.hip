@@ -673,7 +673,7 @@ size_t wide_aug_lds_bytes(int n) { return wide_aug_lds_bytes(n, wide_aug_vlds(n)
 
 struct AugShared {
     unsigned long long T;          // best unassigned column: (ordered distance << 32 | tight hops << 20 | column)
-    int ntouch, any[2], fail, anydense, rootdense, doroot, f, err;
+    int ntouch, any[3], fail, anydense, rootdense, doroot, f, err;
     int waste, stop;               // full-row relaxations of this launch; "return to the driver for fresh caches"
     int scans;
     int st_row[64], st_col[64];    // one-edge searches: their results, stored to global memory 64 at a time
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
         }
     }
     if (tid == 0) { s.waste = 0; s.stop = 0; }
-    if (tid == 0) { s.T = ~0ull; s.ntouch = 0; s.any[0] = 0; s.any[1] = 0; s.fail = 0; s.anydense = 0; s.rootdense = 0; s.doroot = 0; s.f = f0; s.err = 0; s.scans = 0; }
+    if (tid == 0) { s.T = ~0ull; s.ntouch = 0; s.any[0] = 0; s.any[1] = 0; s.any[2] = 0; s.fail = 0; s.anydense = 0; s.rootdense = 0; s.doroot = 0; s.f = f0; s.err = 0; s.scans = 0; }
     __syncthreads();
     auto getv = [&](int j) -> float { return VLDS ? s_v[j] : ld_sc1(a.v + j); };
     auto getcs = [&](int j) -> int {
@@ -756,7 +756,10 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
     auto relax_to = [&](int col, unsigned long long lv, int row) { after_offer(col, lv, row, offer(col, lv, row)); };
 
     int f = f0;
-    int par = 0;
+    int ph = 0;                                                  // round flag in use (three take turns: one barrier per round)
+    int rb[AP];                                                  // blocks this wave took from in the last round: their minima are due
+#pragma unroll
+    for (int q = 0; q < AP; q++) rb[q] = -1;
     int seg_done = 0;                                            // searches (other than one-edge ones) of this launch
     bool announced = false;
     for (;;) {
@@ -864,8 +867,10 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                 for (int q = 0; q < AP; q++) {
                     pk[q] = pkey[q] != KEYMAX && lv_of(pkey[q]) < Tlv;
                     pj[q] = (int)lid_of(pkey[q]);
-                    if (pk[q] && lane == 0) { atomicAnd(&dirty[pj[q] >> 5], ~(1u << (pj[q] & 31))); s.any[par] = 1; }
+                    // (the block's minimum is void from here on; it is rebuilt in the NEXT round, see below)
+                    if (pk[q] && lane == 0) { atomicAnd(&dirty[pj[q] >> 5], ~(1u << (pj[q] & 31))); bmin[pj[q] >> 6] = ~0ull; }
                 }
+                if (lane == 0 && (pk[0] || pk[1] || rb[0] >= 0 || rb[1] >= 0)) s.any[ph] = 1;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the bits are cleared before the labels are read
                 // Everything the two settlements read is requested in ONE go, without a branch in between: label and owner entry of
                 // both columns, then (the owners come from LDS) both cache rows -- a wave without a pick reads column 0's, harmlessly.
@@ -879,6 +884,19 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                 for (int q = 0; q < AP; q++) {
                     pjx[q] = pk[q] ? pj[q] : 0;
                     lab_r[q] = ld_sc1(a.label + pjx[q]); ca_r[q] = ld_sc1(a.cassign + pjx[q]);
+                }
+                // ... and with them the labels of the dirty columns of the blocks the wave took from in the LAST round: the new
+                // minimum of such a block is not on any round's critical path this way (it used to be a third round trip, behind a
+                // second barrier).  Safe against the offers that go on meanwhile: the minimum was voided at the pick (store), the
+                // dirty bits are read here, the labels after them, the result is merged with an atomic min -- an offer either set
+                // its dirty bit before this read (then its label, completed before the bit, is seen) or lowers the minimum itself
+                // after the void store.  The block yields no pick for one round; no round ends the search while a rebuild is due.
+                bool db[AP]; unsigned long long lbr[AP];
+#pragma unroll
+                for (int q = 0; q < AP; q++) {
+                    const int c = (rb[q] < 0 ? 0 : rb[q]) * 64 + lane;
+                    db[q] = rb[q] >= 0 && c < n && ((dirty[c >> 5] >> (c & 31)) & 1u);
+                    lbr[q] = ld_sc1(a.label + (db[q] ? c : pjx[q]));
                 }
 #pragma unroll
                 for (int q = 0; q < AP; q++) { vp_r[q] = getv(pjx[q]); oi_r[q] = getcs(pjx[q]); }
@@ -957,33 +975,24 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     c_dense++;
                     if (lane == 0) atomicAdd(&s.waste, 1);
                 }
-                __syncthreads();
-                {   // the blocks the wave took from: their smallest dirty columns now (both blocks' labels requested together; a lane
-                    // whose column is not dirty reads the picked column's label instead of branching around the load)
-                    bool db[AP]; unsigned long long lbr[AP];
 #pragma unroll
-                    for (int q = 0; q < AP; q++) {
-                        const int c = (pjx[q] >> 6) * 64 + lane;
-                        db[q] = pk[q] && c < n && ((dirty[c >> 5] >> (c & 31)) & 1u);
-                        lbr[q] = ld_sc1(a.label + (db[q] ? c : pjx[q]));
-                    }
-#pragma unroll
-                    for (int q = 0; q < AP; q++) {
-                        if (!pk[q]) continue;
-                        const int b = pj[q] >> 6, c = b * 64 + lane;
-                        const unsigned long long lb = db[q] ? lbr[q] : ~0ull;       // smallest (distance, k): two 32-bit reductions
+                for (int q = 0; q < AP; q++) {                       // last round's blocks: smallest (distance, k) among their dirty columns
+                    if (rb[q] >= 0) {
+                        const int c = rb[q] * 64 + lane;
+                        const unsigned long long lb = db[q] ? lbr[q] : ~0ull;       // (two 32-bit reductions)
                         const uint32_t dk = (uint32_t)(lb >> 32);
                         const uint32_t m = wave_min_u32(dk);
                         const uint32_t lo2 = (db[q] && dk == m) ? (((uint32_t)lb & 0xFFF00000u) | (uint32_t)c) : 0xFFFFFFFFu;
-                        const unsigned long long key = m == 0xFFFFFFFFu ? ~0ull : (((unsigned long long)m << 32) | wave_min_u32(lo2));
-                        if (lane == 0) bmin[b] = key;
+                        const uint32_t m2 = wave_min_u32(lo2);
+                        if (lane == 0 && m != 0xFFFFFFFFu) atomicMin(&bmin[rb[q]], ((unsigned long long)m << 32) | m2);
                     }
+                    rb[q] = pk[q] ? (pj[q] >> 6) : -1;
                 }
-                const int any = uni(s.any[par]);
-                if (tid == 0) s.any[par ^ 1] = 0;
-                par ^= 1;
-                c_rounds++;
                 __syncthreads();
+                const int any = uni(s.any[ph]);
+                if (tid == 0) s.any[(ph + 2) % 3] = 0;             // (last read before this barrier, next set after the next one)
+                ph = (ph + 1) % 3;
+                c_rounds++;
                 if (!any) break;
             }
             // ================= converged: do the caches certify what was skipped? =================
