@@ -3045,10 +3045,12 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
         CYTO_HIP(hipMemcpyAsync(d_wa.p, h_wa.data(), sizeof(WideArgs) * nl, hipMemcpyHostToDevice, stream));
         if ((rc = wide_launch_rt(d_wa.as<WideArgs>(), nl, n, stream))) return rc;
         std::vector<int32_t> h_sync((size_t)nl + 1, 1);
+        using BuildFn = decltype(build_caches);
+        auto rebuild_tramp = +[](void *ctx, const int32_t *flags) -> int { return (*static_cast<BuildFn *>(ctx))(reinterpret_cast<const int *>(flags)); };
         for (int pass = 0;; pass++) {                              // the row-reduction rounds (they pause when the caches have gone stale)
             if (pass && (rc = build_caches(h_sync.data() + 1))) return rc;
             CYTO_HIP(hipMemsetAsync(d_sync.p, 0, sizeof(int32_t), stream));
-            if ((rc = wide_launch_arr(d_wa.as<WideArgs>(), nl, n, stream, pl.wide_rounds, pass > 0))) return rc;
+            if ((rc = wide_launch_arr(d_wa.as<WideArgs>(), nl, n, stream, pl.wide_rounds, pass > 0, d_sync.as<int32_t>(), rebuild_tramp, &build_caches))) return rc;
             if (h_wa[0].aug_seg != 0) break;                       // (no pauses asked for: nothing to wait for)
             CYTO_HIP(hipMemcpyAsync(h_sync.data(), d_sync.p, sizeof(int32_t) * ((size_t)nl + 1), hipMemcpyDeviceToHost, stream));
             CYTO_HIP(hipStreamSynchronize(stream));

@@ -296,7 +296,15 @@ template <bool VLDS, bool CLDS> struct ArrCtx {
 // round r as three launches over all CUs -- bids (a wave per active row, prices and owners read from L2), resolution (a thread per
 // bid), reset of the bid words -- and leave the active list, the round count and the counters in the control block at misc + 384,
 // where wide_arr picks them up.  The same round as in wide_arr (a pure function of the state).
-struct ArrHead { int cnt[2]; int started, free_cr; long long round, bids; int retired, dense; int done, launches; long long list_rounds; };
+// The bid word of a column: | 12 bits ~round | 32 bits ordered price | 20 bits row |, merged with an atomic min: within a round the
+// lowest (price, row) wins, and ANY bid of a later round beats what earlier rounds left behind -- the words are never reset (that
+// was a third pass and a third barrier / launch per round).  The round tag wraps every 4096 rounds: then the words are wiped.
+__device__ __forceinline__ unsigned long long bidkey(long long round, float price, int row) {
+    return ((unsigned long long)(~(uint32_t)round & 0xFFFu) << 52) | ((unsigned long long)f2ord(price) << 20) | (uint32_t)row;
+}
+__device__ __forceinline__ bool bid_won(unsigned long long word, int row) { return (int)((uint32_t)word & 0xFFFFFu) == row; }
+
+struct ArrHead { int cnt[2]; int started, free_cr; long long round, bids; int retired, dense; int done, launches; long long list_rounds; int head_over, bid_epoch, dense_mark; };
 constexpr int HEADB = 256;             // threads of the head kernels' workgroups
 
 __global__ __launch_bounds__(HEADB) void wide_arr_head_init(const WideArgs *__restrict__ batch) {
@@ -322,9 +330,11 @@ __global__ __launch_bounds__(HEADB) void wide_arr_head_bid(const WideArgs *__res
     cx.a = load_wide_args(batch, blockIdx.y);
     const WideArgs &a = cx.a;
     ArrHead *h = reinterpret_cast<ArrHead *>(a.misc + 384);
+    if (h->head_over) return;                                    // (sticky: the rounds after it must not touch the lists)
     const int cur = r & 1, na = h->cnt[cur];
-    // the list this round appends to starts empty -- also when there is nothing to do: the launches after an empty round must
-    // find an empty list too, not the one before last
+    // the whole chip takes the rounds while the active list is long; at <= 64 rows (one chain round of wide_arr) it is over
+    if (r > 0 && na <= ASL) { if (blockIdx.x == 0 && threadIdx.x == 0) h->head_over = 1; return; }
+    // the list this round appends to starts empty
     if (blockIdx.x == 0 && threadIdx.x == 0) { h->cnt[cur ^ 1] = 0; if (r == 0) h->free_cr = na; }
     if (na == 0) return;
     const int lane = threadIdx.x & 63, w = uni((int)(threadIdx.x >> 6));
@@ -341,7 +351,7 @@ __global__ __launch_bounds__(HEADB) void wide_arr_head_bid(const WideArgs *__res
         cx.bid_of(i, w, col, val, jt, pt, ct, i0);
         if (lane == 0) {
             if (jt < 0) atomicAdd(&s.retired, 1);
-            else atomicMin(a.bid + jt, (unsigned long long)mkkey(pt, (uint32_t)i));
+            else atomicMin(a.bid + jt, bidkey(r, pt, i));
             a.slot_j[slot] = jt; a.slot_p[slot] = pt; a.slot_c[slot] = ct;
         }
     }
@@ -354,6 +364,7 @@ __global__ __launch_bounds__(HEADB) void wide_arr_head_resolve(const WideArgs *_
     cx.a = load_wide_args(batch, blockIdx.y);
     const WideArgs &a = cx.a;
     ArrHead *h = reinterpret_cast<ArrHead *>(a.misc + 384);
+    if (h->head_over) return;
     const int cur = r & 1, na = h->cnt[cur];
     cx.s_v = nullptr; cx.s_cs = nullptr; cx.s = nullptr; cx.lane = threadIdx.x & 63;
     const int32_t *A = cur ? a.act1 : a.act0;
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(HEADB) void wide_arr_head_resolve(const WideArgs *_
         const int jt = a.slot_j[slot];
         if (jt < 0) continue;                                    // retired: stays free, bids no more
         const int i = A[slot];
-        if ((uint32_t)a.bid[jt] == (uint32_t)i) {
+        if (bid_won(a.bid[jt], i)) {
             const int i0 = a.colsol[jt];
             cx.apply(i, jt, a.slot_p[slot], a.slot_c[slot], i0);
             if (i0 >= 0) B[atomicAdd(&h->cnt[cur ^ 1], 1)] = i0;
@@ -370,18 +381,28 @@ __global__ __launch_bounds__(HEADB) void wide_arr_head_resolve(const WideArgs *_
             B[atomicAdd(&h->cnt[cur ^ 1], 1)] = i;
         }
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && na > 0) { h->bids += na; h->round += 1; }     // (read by nobody before wide_arr)
 }
 
-__global__ __launch_bounds__(HEADB) void wide_arr_head_reset(const WideArgs *__restrict__ batch, int r) {
+// after a group of rounds: which problems are still in their long-list rounds (seg_sync[0] counts them; the driver enqueues the
+// next group or stops), and which of them want their row caches rebuilt before it -- seg_sync[1 + b] = 1: the full-row bids since the
+// last rebuild have reached a.arr_waste (see wide_arr), 2: there were some, 0: none.  wipe: the bid words' round tag is about to wrap
+__global__ __launch_bounds__(HEADB) void wide_arr_head_check(const WideArgs *__restrict__ batch, int r_next, int wipe) {
     const WideArgs a = load_wide_args(batch, blockIdx.y);
     ArrHead *h = reinterpret_cast<ArrHead *>(a.misc + 384);
-    const int cur = r & 1, na = h->cnt[cur];
-    if (na == 0) return;
-    for (int slot = blockIdx.x * HEADB + threadIdx.x; slot < na; slot += gridDim.x * HEADB) {
-        const int jt = a.slot_j[slot];
-        if (jt >= 0) a.bid[jt] = ~0ull;
+    const bool over = h->head_over || h->cnt[r_next & 1] <= ASL;
+    if (over) { if (blockIdx.x == 0 && threadIdx.x == 0 && a.seg_sync) a.seg_sync[1 + blockIdx.y] = 0; return; }
+    if (wipe) for (int j = blockIdx.x * HEADB + threadIdx.x; j < a.n; j += gridDim.x * HEADB) a.bid[j] = ~0ull;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (wipe) h->bid_epoch = r_next >> 12;
+        if (a.seg_sync) {
+            atomicAdd(a.seg_sync, 1);
+            const int since = h->dense - h->dense_mark;
+            const bool want = a.aug_seg == 0 && since >= a.arr_waste;
+            if (want) h->dense_mark = h->dense;
+            a.seg_sync[1 + blockIdx.y] = want ? 1 : (since > 0 ? 2 : 0);
+        }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { h->bids += na; h->round += 1; }     // (read by nobody before wide_arr)
 }
 
 template <bool VLDS, bool CLDS>
@@ -441,12 +462,18 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
     int na = free_cr;
     const int dense0 = s.dense;
     const long long round0 = round;
+    int bid_epoch = h->bid_epoch;
     bool paused = false, announced = false;
     // ================= LIST rounds =================
     for (;;) {
         na = uni(s.cnt[cur]);
         if (na <= ASL || round >= a.max_rounds) break;
         if (uni(s.pause)) { paused = true; break; }
+        if ((int)(round >> 12) != bid_epoch) {                       // the bid words' round tag has wrapped since they were last wiped
+            for (int j = tid; j < n; j += WT) a.bid[j] = ~0ull;
+            bid_epoch = (int)(round >> 12);
+            __syncthreads();
+        }
         for (int base = 0; base < na; base += ASL) {
             int ri[ACS]; uint32_t col[ACS]; float val[ACS];
 #pragma unroll
@@ -462,7 +489,7 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
                 cx.bid_of(ri[q], w, col[q], val[q], jt, pt, ct, i0);
                 if (lane == 0) {
                     if (jt < 0) atomicAdd(&s.retired, 1);
-                    else atomicMin(a.bid + jt, (unsigned long long)mkkey(pt, (uint32_t)ri[q]));
+                    else atomicMin(a.bid + jt, bidkey(round, pt, ri[q]));
                     a.slot_j[slot] = jt; a.slot_p[slot] = pt; a.slot_c[slot] = ct;
                 }
             }
@@ -473,18 +500,13 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
             const int jt = ld_sc1(a.slot_j + slot);
             if (jt < 0) continue;                                // retired: stays free, bids no more
             const int i = ld_sc1(A + slot);
-            if ((uint32_t)ld_sc1(a.bid + jt) == (uint32_t)i) {
+            if (bid_won(ld_sc1(a.bid + jt), i)) {
                 const int i0 = cx.getcs(jt);
                 cx.apply(i, jt, ld_sc1(a.slot_p + slot), ld_sc1(a.slot_c + slot), i0);
                 if (i0 >= 0) B[atomicAdd(&s.cnt[cur ^ 1], 1)] = i0;
             } else {
                 B[atomicAdd(&s.cnt[cur ^ 1], 1)] = i;
             }
-        }
-        __syncthreads();
-        for (int slot = tid; slot < na; slot += WT) {
-            const int jt = ld_sc1(a.slot_j + slot);
-            if (jt >= 0) a.bid[jt] = ~0ull;
         }
         if (tid == 0) {
             s.cnt[cur] = 0;
@@ -641,7 +663,7 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
         dbg[0] = n_list; dbg[1] += t_list; dbg[2] = n_chain; dbg[3] += t_chain; dbg[4] = n_deal; dbg[6] = wall_clock64() - t_tail0;
         // the state for the next launch, if the rounds paused (cur == round & 1: both flip together)
         h->started = 1; h->round = round; h->bids = bids; h->retired = s.retired; h->dense = s.dense; h->cnt[cur] = paused ? na : 0;
-        h->cnt[cur ^ 1] = 0; h->free_cr = free_cr; h->done = paused ? 0 : 1; h->launches += 1; h->list_rounds = n_list;
+        h->cnt[cur ^ 1] = 0; h->free_cr = free_cr; h->done = paused ? 0 : 1; h->launches += 1; h->list_rounds = n_list; h->bid_epoch = bid_epoch;
 #ifndef CYTO_WIDE_PROF
         dbg[12] = h->launches;
 #endif
@@ -1512,19 +1534,42 @@ int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream) {
     return CYTO_OK;
 }
 
-int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, long long max_rounds, bool resume) {
-    // the first rounds, with thousands of bids each, on the whole chip; the long tail on one workgroup per problem
-    // (resume: the rounds paused for fresh row caches -- wide_arr alone picks them up)
+int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, long long max_rounds, bool resume, int32_t *d_sync,
+                    int (*rebuild)(void *ctx, const int32_t *flags), void *ctx) {
+    // the rounds with a long active list on the whole chip (two launches per round: bids, resolution), in groups of 16, 32, 64, 128 ...
+    // rounds -- after a group the driver asks whether any problem's list is still long (one 4-byte read); the long tail (<= 64 active
+    // rows) and whatever the budget leaves on one workgroup per problem.  resume: the rounds paused for fresh row caches -- wide_arr
+    // alone picks them up
     if (n >= 4096 && max_rounds > 0 && !resume) {
-        const int rounds = (int)std::min<long long>(8, max_rounds);
         const int bx = std::max(1, std::min((n + 255) / 256, 1024 / std::max(1, std::min(nb, 8))));
         int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(wide_arr_head_bid));
         if (rc) return rc;
         hipLaunchKernelGGL(wide_arr_head_init, dim3(bx, nb), dim3(HEADB), 0, stream, d_args);
-        for (int r = 0; r < rounds; r++) {
-            hipLaunchKernelGGL(wide_arr_head_bid, dim3(bx, nb), dim3(HEADB), ARR_SHARED_BYTES, stream, d_args, r);
-            hipLaunchKernelGGL(wide_arr_head_resolve, dim3(bx, nb), dim3(HEADB), 0, stream, d_args, r);
-            hipLaunchKernelGGL(wide_arr_head_reset, dim3(bx, nb), dim3(HEADB), 0, stream, d_args, r);
+        // (a batch keeps only its first eight rounds here: its problems run side by side on a workgroup each anyway, at their own pace,
+        //  while a round here costs two launches for all of them -- measured: 50 c5 chunks 1.15 s that way, 1.57 s with every long-list
+        //  round on the whole chip; 256 c4 chunks 2.0 against 2.2 s)
+        const long long head_rounds = nb <= 4 ? max_rounds : std::min<long long>(8, max_rounds);
+        int r = 0, group = 16;
+        while (r < head_rounds) {
+            const int r1 = (int)std::min<long long>(head_rounds, std::min<long long>(r + group, ((long long)(r >> 12) + 1) << 12));
+            for (; r < r1; r++) {
+                hipLaunchKernelGGL(wide_arr_head_bid, dim3(bx, nb), dim3(HEADB), ARR_SHARED_BYTES, stream, d_args, r);
+                hipLaunchKernelGGL(wide_arr_head_resolve, dim3(bx, nb), dim3(HEADB), 0, stream, d_args, r);
+            }
+            if (!d_sync || r >= head_rounds) break;
+            std::vector<int32_t> h_sync((size_t)nb + 1, 0);
+            CYTO_HIP(hipMemsetAsync(d_sync, 0, sizeof(int32_t), stream));
+            hipLaunchKernelGGL(wide_arr_head_check, dim3(bx, nb), dim3(HEADB), 0, stream, d_args, r, (r & 0xFFF) == 0 ? 1 : 0);
+            CYTO_HIP(hipMemcpyAsync(h_sync.data(), d_sync, sizeof(int32_t) * ((size_t)nb + 1), hipMemcpyDeviceToHost, stream));
+            CYTO_HIP(hipStreamSynchronize(stream));
+            if (!h_sync[0]) break;
+            bool want = false, some = false;
+            for (int b = 0; b < nb; b++) { want = want || h_sync[(size_t)b + 1] == 1; some = some || h_sync[(size_t)b + 1] != 0; }
+            if (want && rebuild) {                                 // fresh row caches for the problems that asked (their floors have gone stale)
+                for (int b = 0; b < nb; b++) h_sync[(size_t)b + 1] = h_sync[(size_t)b + 1] == 1 ? 1 : 0;
+                if ((rc = rebuild(ctx, h_sync.data() + 1))) return rc;
+            }
+            group = some ? 16 : std::min(group * 2, 256);           // (full-row bids about: stay close to the next rebuild)
         }
         CYTO_HIP(hipGetLastError());
     }
