@@ -869,26 +869,27 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                 // the two best dirty columns among the wave's blocks (one key per lane: the smallest of the blocks it looks at)
                 unsigned long long mk = ~0ull;
                 for (int b = w + WNW * lane; b < nblk; b += WNW * 64) mk = umin64(mk, bmin[b]);
-                uint64_t pkey[AP];
-                {   // (the lexicographic minimum of the lanes' keys as two 32-bit reductions: distance, then k | column among its ties --
-                    //  the smallest (distance, k) must not be missed: it alone may still be below the best unassigned column's)
-#pragma unroll
-                    for (int q = 0; q < AP; q++) {
-                        const uint32_t dk = (uint32_t)(mk >> 32);
-                        const uint32_t m = wave_min_u32(dk);
-                        const uint32_t m2 = wave_min_u32(dk == m ? (uint32_t)mk : 0xFFFFFFFFu);
-                        pkey[q] = m == 0xFFFFFFFFu ? KEYMAX : (((uint64_t)m << 32) | m2);
-                        if (mk == pkey[q]) mk = ~0ull;
-                    }
-                }
+                // Which dirty column a wave settles next is a matter of efficiency only (any schedule reaches the same labels), what
+                // must be exact is WHETHER a block holds work: a lane is eligible if its best key is below the best unassigned
+                // column's label; among the eligible lanes the smallest distance goes first (one 32-bit reduction and a ballot per
+                // pick -- the tight-hop counts do not order the picks).
                 bool pk[AP]; int pj[AP], oi[AP];
                 unsigned long long lab[AP];
                 float ca[AP], vp[AP], val[AP];
                 uint32_t col[AP];
+                {
+                    uint32_t dk = lv_of(mk) < Tlv ? (uint32_t)(mk >> 32) : 0xFFFFFFFFu;
+#pragma unroll
+                    for (int q = 0; q < AP; q++) {
+                        const uint32_t m = wave_min_u32(dk);
+                        pk[q] = m != 0xFFFFFFFFu;
+                        const int l = pk[q] ? __ffsll((unsigned long long)__ballot(dk == m)) - 1 : 0;
+                        pj[q] = (int)(rdlane((uint32_t)mk, l) & 0xFFFFFu);
+                        if (lane == l) dk = 0xFFFFFFFFu;
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < AP; q++) {
-                    pk[q] = pkey[q] != KEYMAX && lv_of(pkey[q]) < Tlv;
-                    pj[q] = (int)lid_of(pkey[q]);
                     // (the block's minimum is void from here on; it is rebuilt in the NEXT round, see below)
                     if (pk[q] && lane == 0) { atomicAnd(&dirty[pj[q] >> 5], ~(1u << (pj[q] & 31))); bmin[pj[q] >> 6] = ~0ull; }
                 }
@@ -1001,12 +1002,14 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                 for (int q = 0; q < AP; q++) {                       // last round's blocks: smallest (distance, k) among their dirty columns
                     if (rb[q] >= 0) {
                         const int c = rb[q] * 64 + lane;
-                        const unsigned long long lb = db[q] ? lbr[q] : ~0ull;       // (two 32-bit reductions)
-                        const uint32_t dk = (uint32_t)(lb >> 32);
+                        // (the smallest distance with hop count 0 and one of its columns: a lower bound of the block's smallest label
+                        //  is all a minimum has to be -- a pick re-reads the label)
+                        const uint32_t dk = db[q] ? (uint32_t)(lbr[q] >> 32) : 0xFFFFFFFFu;
                         const uint32_t m = wave_min_u32(dk);
-                        const uint32_t lo2 = (db[q] && dk == m) ? (((uint32_t)lb & 0xFFF00000u) | (uint32_t)c) : 0xFFFFFFFFu;
-                        const uint32_t m2 = wave_min_u32(lo2);
-                        if (lane == 0 && m != 0xFFFFFFFFu) atomicMin(&bmin[rb[q]], ((unsigned long long)m << 32) | m2);
+                        if (m != 0xFFFFFFFFu) {
+                            const int l = __ffsll((unsigned long long)__ballot(dk == m)) - 1;
+                            if (lane == 0) atomicMin(&bmin[rb[q]], ((unsigned long long)m << 32) | (uint32_t)(c - lane + l));
+                        }
                     }
                     rb[q] = pk[q] ? (pj[q] >> 6) : -1;
                 }
