@@ -397,7 +397,7 @@ def main():
     ap.add_argument("--c4-chunks", type=int, default=256, help="concurrent chunk LAPs in the c4_chunks leg (256 = one chain per CU; 400 MB each)")
     ap.add_argument("--c4-rank-chunks", type=int, default=64, help="chunks per rank in the c4_sharded leg")
     ap.add_argument("--sharded-timeout", type=float, default=600.0, help="watchdog of the c4_sharded leg, seconds")
-    ap.add_argument("--pmc-tag", default="r03b", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
+    ap.add_argument("--pmc-tag", default="r03h", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
     args = ap.parse_args()
 
     # ONE JSON line on stdout: everything else this process (or a library under it: RCCL prints a version banner through C
@@ -539,7 +539,11 @@ def main():
     arr_ms = float(np.mean(arr_ms_l))
     aug_ms = float(np.mean(aug_ms_l))
     arr_name, aug_name = ("wide_arr", "wide_aug") if info.wide else ("jv_chain2", "jv_aug_lazy" if n > 5120 else "jv_aug2")
-    dom = (arr_name, arr_scans, arr_ms) if arr_ms >= aug_ms else (aug_name, aug_scans, aug_ms)
+    # (the wide solver's row reduction is a PHASE of thousands of launches -- the long-list rounds on the whole chip, two small
+    #  launches each, then the wide_arr kernel for the tail: arr_ms brackets the phase, the wide_arr kernel alone is its own clock's
+    #  list + chain time; the dominant KERNEL is the longest single launch)
+    arr_kernel_ms = float(info.wide_ms_list + info.wide_ms_chain) if info.wide else arr_ms
+    dom = (arr_name, arr_scans, arr_ms) if arr_kernel_ms >= aug_ms else (aug_name, aug_scans, aug_ms)
     dom_bytes = 4.0 * n * dom[1]
     achieved = dom_bytes / (dom[2] * 1e-3) / 1e9
     traffic = None
@@ -564,7 +568,9 @@ def main():
         "algorithmic_bytes_per_launch": dom_bytes, "row_scans_per_launch": int(dom[1]), "kernel_ms_avg": round(dom[2], 3),
         "other_kernels": {
             arr_name: {"ms": round(arr_ms, 3), "row_scans": int(arr_scans), "algorithmic_GBs": round(4.0 * n * arr_scans / (arr_ms * 1e-3) / 1e9, 2),
-                       "rounds": int(info.wide_rounds), "full_row_scans": int(info.wide_dense_arr)},
+                       "rounds": int(info.wide_rounds), "full_row_scans": int(info.wide_dense_arr),
+                       "note": "the row-reduction PHASE (HIP events around wide_rt, the long-list rounds as two whole-chip launches each, wide_arr)",
+                       "wide_arr_kernel_ms": round(arr_kernel_ms, 3), "long_list_rounds_on_the_whole_chip": int(info.wide_list_rounds)},
             aug_name: {"ms": round(aug_ms, 3), "row_scans": int(aug_scans), "algorithmic_GBs": round(4.0 * n * aug_scans / max(aug_ms, 1e-9) / 1e-3 / 1e9, 2),
                        "searches": int(info.augmentations), "columns_settled_speculatively": int(info.wide_aug_settled),
                        "rounds_of_16_waves": int(info.wide_aug_rounds),

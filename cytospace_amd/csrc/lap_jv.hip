@@ -3058,11 +3058,11 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             for (int k = 0; k < nl; k++) done = done && h_sync[(size_t)k + 1] == 0;
             if (done) break;
         }
-        CYTO_HIP(hipEventRecord(ev_arr_done, stream));
         // the searches, in as many launches as they ask for: wide_aug returns when its row caches have gone stale (lap_wide.hip) and
         // the whole chip rebuilds them against the prices reached -- only for the problems that still have searches to run
         for (int pass = 0;; pass++) {
             if ((rc = build_caches(pass ? h_sync.data() + 1 : nullptr))) return rc;
+            if (pass == 0) CYTO_HIP(hipEventRecord(ev_arr_done, stream));   // (ms_aug: the search kernel -- and what later passes add)
             CYTO_HIP(hipMemsetAsync(d_sync.p, 0, sizeof(int32_t), stream));
             if ((rc = wide_launch_aug(d_wa.as<WideArgs>(), nl, n, stream, h_wa[0].mc_groups))) return rc;
             if (h_wa[0].mc_groups > 0) { CYTO_HIP(hipStreamSynchronize(stream)); break; }

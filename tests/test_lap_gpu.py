@@ -496,9 +496,10 @@ def test_wide_row_caches_rebuilt_between_searches(rebuild):
 def test_wide_batch_rebuilds_only_what_is_unfinished():
     # a batch in one launch per phase: problems that need fresh caches and problems that are done long before share the launches
     from cytospace_amd.lap import lap_solve_batch
+    # (n >= 4096 and more than four problems: the first eight rounds on the whole chip, the other long-list rounds in wide_arr)
     rng = np.random.default_rng(78)
     prof = rng.normal(size=(5, 48)).astype(np.float32)
-    n = 3000
+    n = 4200
     cs = []
     for k in range(6):
         if k % 2:
@@ -507,10 +508,10 @@ def test_wide_batch_rebuilds_only_what_is_unfinished():
             rows = prof[rng.integers(0, 5, n)] + 0.05 * rng.normal(size=(n, 48)).astype(np.float32)
             cols = prof[rng.integers(0, 5, n)] + 0.05 * rng.normal(size=(n, 48)).astype(np.float32)
             cs.append(-(rows @ cols.T).astype(np.float32))
+    oracle = [jv_oracle_wide(c, np.float32) for c in cs]
     for rebuild in (0, 2):
         res = lap_solve_batch(cs, return_info=True, opts=dict(mode=2, wide_rebuild=rebuild))
-        for c, g in zip(cs, res):
-            o = jv_oracle_wide(c, np.float32)
+        for c, g, o in zip(cs, res, oracle):
             for key in ("rowsol", "colsol", "u", "v"):
                 assert np.array_equal(g[key], o[key]), key
             assert g["info"].scans_aug_relax == o["stats"].scans_aug_relax and g["info"].path_hops == o["stats"].path_hops
