@@ -1335,56 +1335,80 @@ __global__ __launch_bounds__(256) void replicate_group_caches(int n, const int32
 template <int VAUX>
 __device__ __forceinline__ K2 refresh_row_stream(int i, int n, int64_t ld, const float *__restrict__ cost, const float *gv,
                                                  uint32_t *__restrict__ cache_col, float *__restrict__ cache_val, float &delta,
-                                                 Scratch2 &s, int &par) {
+                                                 float &tau_guess, Scratch2 &s, int &par) {
+    // Sweeps of the row: the first from HBM (top-2 keys AND the count below the previous row's floor -- neighbouring rows need
+    // similar floors, and ANY floor that admits <= 63 columns makes a valid cache), then one per step of the threshold search from
+    // L2.  Every counting sweep also keeps the thread's first two columns below the threshold, so the cache is written without
+    // another sweep (a thread with more than two re-sweeps its own quads).  Typically one or two sweeps per row (six before:
+    // the build was bound by L2, 10 TB/s of it for 1.5 TB/s of HBM at n = 50 000).
     const int tid = threadIdx.x, lane = tid & 63;
     const int nquad = (n + 3) >> 2;
     const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(cost + (int64_t)i * ld), 0, (int)(ld * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gv), 0, nquad * 16, 0x00020000);
+    uint32_t tc = 0, hc0 = 0, hc1 = 0;                          // this thread's columns below the threshold: count, the first two
+    float hr0 = 0.0f, hr1 = 0.0f;
+#define STREAM_HIT(T) if (h < (T)) { if (tc == 0) { hc0 = c; hr0 = raw; } else if (tc == 1) { hc1 = c; hr1 = raw; } tc++; }
     K2 loc; loc.m1 = KEYMAX; loc.m2 = KEYMAX;
-    STREAM_SWEEP((void)raw; k2_push(loc, mkkey(h, c));)
+    const float tau0 = tau_guess;
+    STREAM_SWEEP(k2_push(loc, mkkey(h, c)); STREAM_HIT(tau0))
     const K2 g = wg_k2(loc, s, par);
     const float umin = key_val(g.m1);
-
-    float lo = 0.0f, hi = INFINITY, tau = INFINITY;
-    int cnt = 0;
-    bool okc = false;
-    if (!(delta > 0.0f) || !(delta < 1e30f)) delta = 1e-3f;
-    for (int it = 0; it < 24 && !okc; it++) {
-        tau = umin + delta;
-        uint32_t tc = 0;
-        STREAM_SWEEP((void)raw; tc += (h < tau) ? 1u : 0u;)
-        cnt = wg_sum_waves((int)wave_sum_u32(tc), s, par, nullptr);
-        if (cnt > KCU) {
-            hi = delta;
-            const float mid = (lo > 0.0f) ? 0.5f * (lo + hi) : 0.5f * delta;
-            if (!(mid < hi) || !(mid > lo)) break;
-            delta = mid;
-        } else if (cnt < KCU / 2 && cnt < n && delta < 1e30f) {
-            lo = delta;
-            const float mid = (hi < INFINITY) ? 0.5f * (lo + hi) : 2.0f * delta;
-            if (hi < INFINITY && (!(mid < hi) || !(mid > lo))) { okc = true; break; }
-            delta = mid;
-        } else {
-            okc = true;
+    int base = 0;
+    int cnt = wg_sum_waves((int)wave_sum_u32(tc), s, par, &base);
+    float tau = tau0;
+    bool have = tau0 < INFINITY && cnt <= KCU && (cnt >= KCU / 2 || cnt >= n);      // the guess fits: done after one sweep
+    if (have) delta = tau - umin;
+    if (!have) {
+        float lo = 0.0f, hi = INFINITY;
+        bool okc = false;
+        if (tau0 < INFINITY && tau0 > umin && cnt > 0) {          // scale the guess by how far its count was off
+            const float d0 = tau0 - umin;
+            if (cnt > KCU) { hi = d0; delta = d0 * fmaxf(0.0625f, 0.75f * (float)KCU / (float)cnt); }
+            else { lo = d0; delta = d0 * fminf(16.0f, 0.75f * (float)KCU / (float)cnt); }
+        }
+        if (!(delta > 0.0f) || !(delta < 1e30f)) delta = 1e-3f;
+        for (int it = 0; it < 24 && !okc; it++) {
+            tau = umin + delta;
+            tc = 0;
+            STREAM_SWEEP(STREAM_HIT(tau))
+            cnt = wg_sum_waves((int)wave_sum_u32(tc), s, par, &base);
+            if (cnt > KCU) {
+                hi = delta;
+                const float mid = (lo > 0.0f) ? 0.5f * (lo + hi) : 0.5f * delta;
+                if (!(mid < hi) || !(mid > lo)) break;
+                delta = mid;
+            } else if (cnt < KCU / 2 && cnt < n && delta < 1e30f) {
+                lo = delta;
+                const float mid = (hi < INFINITY) ? 0.5f * (lo + hi) : 2.0f * delta;
+                if (hi < INFINITY && (!(mid < hi) || !(mid > lo))) { okc = true; break; }
+                delta = mid;
+            } else {
+                okc = true;
+            }
+        }
+        if (!okc || cnt > KCU) {
+            // the largest threshold known to admit <= KCU columns (possibly none): counted once more, with its columns
+            if (lo > 0.0f) { delta = lo; tau = umin + lo; } else { tau = -INFINITY; }
+            tc = 0;
+            STREAM_SWEEP(STREAM_HIT(tau))
+            cnt = wg_sum_waves((int)wave_sum_u32(tc), s, par, &base);
+            if (cnt > KCU) { tau = -INFINITY; cnt = 0; tc = 0; }
         }
     }
-    if (!okc || cnt > KCU) {
-        if (lo > 0.0f) { delta = lo; tau = umin + lo; } else { tau = -INFINITY; }
-    }
-    uint32_t tc = 0;
-    STREAM_SWEEP((void)raw; tc += (h < tau) ? 1u : 0u;)
-    int base = 0;
-    cnt = wg_sum_waves((int)wave_sum_u32(tc), s, par, &base);
-    if (cnt > KCU) { tau = -INFINITY; cnt = 0; tc = 0; }
+    tau_guess = tau > -INFINITY ? tau : INFINITY;
+#undef STREAM_HIT
     uint32_t *ccol = cache_col + (int64_t)i * KC;
     float *cval = cache_val + (int64_t)i * KC;
     uint32_t inc = tc;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(inc, off); if (lane >= off) inc += y; }
     int pos = base + (int)(inc - tc);
-    if (tc != 0) {
+    if (tc > 2) {
         STREAM_SWEEP(if (h < tau) { ccol[pos] = c; cval[pos] = raw; pos++; })
+    } else {
+        if (tc >= 1) { ccol[pos] = hc0; cval[pos] = hr0; }
+        if (tc == 2) { ccol[pos + 1] = hc1; cval[pos + 1] = hr1; }
     }
     if (tid >= cnt && tid < KCU) { ccol[tid] = COLSENT; cval[tid] = 0.0f; }
     if (tid == KCU) { ccol[KCU] = COLSENT; cval[KCU] = tau; }
@@ -1399,10 +1423,10 @@ __global__ __launch_bounds__(BLOCK2) void build_row_caches_stream(int n, int64_t
                                                                  const int32_t *__restrict__ same_prev) {
     __shared__ Scratch2 s;
     int par = 0;
-    float delta = 0.0f;
+    float delta = 0.0f, tau_guess = INFINITY;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         if (same_prev && same_prev[i]) continue;                          // a copy of the previous row: replicate_group_caches
-        (void)refresh_row_stream<0>(i, n, ld, RBASE(cost, rowmap, i, ld), v, cache_col, cache_val, delta, s, par);
+        (void)refresh_row_stream<0>(i, n, ld, RBASE(cost, rowmap, i, ld), v, cache_col, cache_val, delta, tau_guess, s, par);
     }
 }
 
@@ -1902,7 +1926,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(const Chain2Args *__restrict
     }
     __syncthreads();
 
-    float delta = 0.0f;
+    float delta = 0.0f, tau_guess = INFINITY;
     int c_rt = 0, c_arr = 0, c_dense = 0;
     int c_free_cr = numfree, c_free_a1 = 0, c_free_a2 = 0;
 
@@ -2090,7 +2114,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_chain2(const Chain2Args *__restrict
         const int op = s.cmd_op, row = s.cmd_row;
         if (op == OP_EXIT) break;
         if constexpr (CH == 0) {
-            gd = refresh_row_stream<0x10>(row, n, ld, RBASE(cost, a.rowmap, row, ld), gv, a.cache_col, a.cache_val, delta, s, par);
+            gd = refresh_row_stream<0x10>(row, n, ld, RBASE(cost, a.rowmap, row, ld), gv, a.cache_col, a.cache_val, delta, tau_guess, s, par);
             have_dense = true;
         } else {
             float vreg[NC > 0 ? NC : 1];
