@@ -1294,7 +1294,10 @@ __global__ __launch_bounds__(BLOCK2) void build_row_caches(int n, int64_t ld, co
         if (c < n) { validm |= (1ull << sl); vreg[sl] = v[c]; }
     }
     float delta = 0.0f;
-    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    // (a contiguous range of rows per workgroup, not a stride: with runs of identical rows -- ten per spot at c3 -- a stride that
+    //  shares a factor with the run length leaves the first rows of the runs, the only ones that are built, to a few workgroups)
+    const int per = (n + (int)gridDim.x - 1) / (int)gridDim.x, i_end = min(n, ((int)blockIdx.x + 1) * per);
+    for (int i = (int)blockIdx.x * per; i < i_end; i++) {
         if (same_prev && same_prev[i]) continue;                          // a copy of the previous row: replicate_group_caches
         (void)refresh_row<CH>(i, n, ld, RBASE(cost, rowmap, i, ld), vreg, validm, cache_col, cache_val, delta, s, par);
     }
@@ -1424,7 +1427,8 @@ __global__ __launch_bounds__(BLOCK2) void build_row_caches_stream(int n, int64_t
     __shared__ Scratch2 s;
     int par = 0;
     float delta = 0.0f, tau_guess = INFINITY;
-    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int per = (n + (int)gridDim.x - 1) / (int)gridDim.x, i_end = min(n, ((int)blockIdx.x + 1) * per);      // (see build_row_caches)
+    for (int i = (int)blockIdx.x * per; i < i_end; i++) {
         if (same_prev && same_prev[i]) continue;                          // a copy of the previous row: replicate_group_caches
         (void)refresh_row_stream<0>(i, n, ld, RBASE(cost, rowmap, i, ld), v, cache_col, cache_val, delta, tau_guess, s, par);
     }
