@@ -3050,6 +3050,7 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             wa.arr_waste = std::max(8, wa.aug_waste / 3);          // (a full-row bid with its cache refresh: three sweeps)
             wa.seg_quorum = nl > 1 ? std::max(1, nl / 4) : 0;
             wa.seg_sync = nullptr;
+            wa.same_prev = (j.h_ngroups < n && n >= 2) ? j.b_same.as<int32_t>() : nullptr;
             wa.mc_groups = mcg; wa.gbmin = nullptr; wa.gdirty = nullptr; wa.gasg = nullptr; wa.gdense = nullptr; wa.ctl = nullptr;
             if (mcg > 0) {
                 const size_t nblk = ((size_t)n + 63) / 64, nw32 = ((size_t)n + 31) / 32;

@@ -17,6 +17,7 @@ namespace cyto {
 //   gbmin, gdirty, gasg, gdense, ctl   the multi-workgroup augmentation's shared state (global memory; wide_aug_mc): per 64-column
 //                   block the smallest dirty label, dirty / assigned / dense bitmaps, a 256-byte control block (zeroed by the host)
 //   mc_groups       workgroups that search one problem together (0: the one-workgroup kernel)
+//   same_prev       [n] 1 = the row equals the row before it (runs of identical rows: CytoSPACE repeats a spot's row per slot), or null
 //   seg_sync        shared by the launch, or null: [0] workgroups that asked for fresh caches (zeroed by the driver before every launch
 //                   of wide_arr / wide_aug), [1 + b] wide_arr: 1 = problem b's rounds paused; wide_aug: searches problem b still has to run
 //   arr_waste       wide_arr: full-row bids (with their cache refresh) of one launch after which the list rounds pause (aug_seg == 0)
@@ -32,7 +33,7 @@ namespace cyto {
     P(int32_t, freerows) P(int32_t, act0) P(int32_t, act1) P(int32_t, touched) P(int32_t, slot_j) P(float, slot_p)            \
     P(float, slot_c) P(uint32_t, cache_col) P(float, cache_val) P(char, misc) S(long long, max_rounds)                     \
     P(unsigned long long, gbmin) P(uint32_t, gdirty) P(uint32_t, gasg) P(uint32_t, gdense) P(char, ctl) S(int, mc_groups)  \
-    P(int32_t, seg_sync) S(int, aug_seg) S(int, aug_waste) S(int, arr_waste) S(int, seg_quorum)
+    P(const int32_t, same_prev) P(int32_t, seg_sync) S(int, aug_seg) S(int, aug_waste) S(int, arr_waste) S(int, seg_quorum)
 #define WIDE_F_PTR(T, name) T *name;
 #define WIDE_F_VAL(T, name) T name;
 struct WideArgs { WIDE_FIELDS(WIDE_F_PTR, WIDE_F_VAL) };

@@ -808,6 +808,14 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                 const int fr = fr1;
                 const uint32_t col = col1;
                 const float val = val1, vv = vv1;
+                // runs of identical rows (ten slots per spot at c3) are free together and have identical caches (built once per run):
+                // with the prices fixed in this loop, the t-th of them takes the t-th lowest of the unassigned columns that tie at
+                // the minimum -- the whole run is one step.  Lane t looks at the t-th free row after this one.
+                bool follower = false;
+                if (a.same_prev) {
+                    const int ft = f + lane;
+                    follower = lane > 0 && ft < numfree && a.freerows[ft] == fr + lane && a.same_prev[fr + lane] != 0;
+                }
                 // advance the pipeline: search f + 1's prices, search f + 2's cache row
                 fr1 = fr2; col1 = col2; val1 = val2;
                 vv1 = (fr1 >= 0 && lane < KCU && col1 != COLSENT) ? getv((int)col1) : 0.0f;
@@ -820,17 +828,33 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                 const bool un = valid && od == omin && !is_asg((int)col);
                 const uint64_t mu = __ballot(un);
                 if (!(omin != 0xFFFFFFFFu && mu && tau > ord2f(omin))) break;
-                const int l = __ffsll((unsigned long long)mu) - 1;     // cache rows are sorted by column: the lowest such column
-                if (lane == l) {
+                // this row and the identical free rows right behind it, as many as there are tied unassigned columns
+                int m = 1;
+                if (a.same_prev) {
+                    const int cntmu = __popcll(mu);
+                    const uint64_t okm = __ballot(follower && lane < cntmu) | 1ull;
+                    m = __ffsll((unsigned long long)~okm) - 1;          // leading ones (bit 63 is never set: lane 63 < cntmu <= 63 fails)
+                }
+                if (nst + m > 64) { flush_one_edge(nst); nst = 0; }
+                const int rank = __popcll(mu & lanemask_lt());           // cache rows are sorted by column: ranks go by column
+                if (un && rank < m) {
                     // (no global store in the loop: a load is only returned after the stores issued before it are acknowledged, so
                     //  three stores per search made every search wait for the previous one's)
-                    s.st_row[nst] = fr; s.st_col[nst] = (int)col; s.st_val[nst] = val;
-                    if (CLDS) s_cs[col] = (uint16_t)fr;
+                    s.st_row[nst + rank] = fr + rank; s.st_col[nst + rank] = (int)col; s.st_val[nst + rank] = val;
+                    if (CLDS) s_cs[col] = (uint16_t)(fr + rank);
                     atomicOr(&asg[col >> 5], 1u << (col & 31));
                 }
-                c_trivial++; c_hops++;
-                f++;
-                if (++nst == 64) { flush_one_edge(nst); nst = 0; }
+                c_trivial += m; c_hops += m;
+                f += m;
+                nst += m;
+                if (nst == 64) { flush_one_edge(nst); nst = 0; }
+                if (m > 1) {                                             // the rows in flight were part of the run: start the pipeline again
+                    fr1 = row_of(f); fr2 = row_of(f + 1);
+                    col1 = COLSENT; col2 = COLSENT; val1 = 0.0f; val2 = 0.0f; vv1 = 0.0f;
+                    if (fr1 >= 0) { col1 = a.cache_col[(int64_t)fr1 * KC + lane]; val1 = a.cache_val[(int64_t)fr1 * KC + lane]; }
+                    if (fr2 >= 0) { col2 = a.cache_col[(int64_t)fr2 * KC + lane]; val2 = a.cache_val[(int64_t)fr2 * KC + lane]; }
+                    if (fr1 >= 0 && lane < KCU && col1 != COLSENT) vv1 = getv((int)col1);
+                }
             }
             flush_one_edge(nst);
             if (lane == 0) {
