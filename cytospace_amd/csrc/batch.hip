@@ -9,6 +9,7 @@
 #include <rccl/rccl.h>
 #include <algorithm>
 #include <map>
+#include <thread>
 #include <vector>
 
 namespace cyto {
@@ -51,10 +52,49 @@ int lap_batch_any(int nb, const int *n, const float *const *cost, const int64_t 
                 uu[(size_t)k] = u ? u[b] : nullptr; vv[(size_t)k] = v ? v[b] : nullptr;
                 if (rowmap && rowmap[b]) { rm[(size_t)k] = rowmap[b]; nus[(size_t)k] = nu ? nu[b] : 0; }
             }
-            const int brc = lap_batch_same_n(kv.first, cnt, c.data(), l.data(), cost_on_device, rs.data(), cs.data(), uu.data(), vv.data(),
-                                             tot.data(), inf.data(), stat.data(), device_id, guard.s, rm.data(), nus.data(), opts);
+            // A large batch goes as G interleaved sub-batches, each on its own stream and host thread: the phases of a sub-batch are
+            // launches for all its problems, and some of them (the cache rebuilds between searches, the waits for its slowest
+            // problem) leave most of the chip idle -- another sub-batch's workgroups fill it.
+            const int G = cnt >= 128 ? 8 : (cnt >= 32 ? 4 : (cnt >= 16 ? 2 : 1));
+            std::vector<int> brcs((size_t)G, CYTO_OK);
+            if (G == 1) {
+                brcs[0] = lap_batch_same_n(kv.first, cnt, c.data(), l.data(), cost_on_device, rs.data(), cs.data(), uu.data(), vv.data(),
+                                           tot.data(), inf.data(), stat.data(), device_id, guard.s, rm.data(), nus.data(), opts);
+            } else {
+                std::vector<std::vector<int>> part((size_t)G);
+                for (int k = 0; k < cnt; k++) part[(size_t)(k % G)].push_back(k);
+                std::vector<std::thread> th;
+                for (int g = 0; g < G; g++) {
+                    th.emplace_back([&, g]() {
+                        const std::vector<int> &ks = part[(size_t)g];
+                        const int m = (int)ks.size();
+                        if (select_device(device_id)) { brcs[(size_t)g] = CYTO_ERR_HIP; return; }
+                        StreamGuard sg;
+                        if (hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking) != hipSuccess) { brcs[(size_t)g] = CYTO_ERR_HIP; return; }
+                        sg.own = true;
+                        std::vector<const float *> c2((size_t)m); std::vector<int64_t> l2((size_t)m);
+                        std::vector<int32_t *> rs2((size_t)m), cs2((size_t)m); std::vector<float *> u2((size_t)m), v2((size_t)m);
+                        std::vector<double> tot2((size_t)m); std::vector<cyto_lap_info> inf2((size_t)m);
+                        std::vector<int> stat2((size_t)m, CYTO_OK), nus2((size_t)m, 0); std::vector<const int32_t *> rm2((size_t)m, nullptr);
+                        for (int q = 0; q < m; q++) {
+                            const size_t k = (size_t)ks[(size_t)q];
+                            c2[(size_t)q] = c[k]; l2[(size_t)q] = l[k]; rs2[(size_t)q] = rs[k]; cs2[(size_t)q] = cs[k];
+                            u2[(size_t)q] = uu[k]; v2[(size_t)q] = vv[k]; rm2[(size_t)q] = rm[k]; nus2[(size_t)q] = nus[k];
+                        }
+                        brcs[(size_t)g] = lap_batch_same_n(kv.first, m, c2.data(), l2.data(), cost_on_device, rs2.data(), cs2.data(), u2.data(),
+                                                          v2.data(), tot2.data(), inf2.data(), stat2.data(), device_id, sg.s, rm2.data(),
+                                                          nus2.data(), opts);
+                        for (int q = 0; q < m; q++) {
+                            const size_t k = (size_t)ks[(size_t)q];
+                            tot[k] = tot2[(size_t)q]; inf[k] = inf2[(size_t)q]; stat[k] = stat2[(size_t)q];
+                        }
+                    });
+                }
+                for (auto &t : th) t.join();
+            }
             for (int k = 0; k < cnt; k++) {
                 const int b = ids[lo + (size_t)k];
+                const int brc = brcs[(size_t)(G == 1 ? 0 : k % G)];
                 st[(size_t)b] = brc ? brc : stat[(size_t)k];
                 if (total) total[b] = tot[(size_t)k];
                 if (info) info[b] = inf[(size_t)k];
