@@ -3029,7 +3029,8 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             F32Job &j = jobs[live[k]];
             const int mcg = nl != 1 ? 0 : (pl.wide_groups > 0 ? pl.wide_groups : (pl.wide_groups < 0 ? 0 : wide_mc_groups(nl, n)));
             const size_t mcb = mcg > 0 ? wide_mc_state_bytes(n) : 0;
-            if ((rc = j.b_wide.alloc(2 * nT + 256 + mcb, stream))) return rc;
+            const size_t sc_off = ((2 * nT + 255) / 256) * 256 + mcb;       // the phase machine's control block behind everything else
+            if ((rc = j.b_wide.alloc(sc_off + WIDE_SC_BYTES, stream))) return rc;
             const Chain2Args &c = j.c2;
             WideArgs &wa = h_wa[k];
             wa.n = n; wa.ld = c.ld; wa.cost = c.cost; wa.rowmap = c.rowmap;
@@ -3051,6 +3052,8 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             wa.seg_quorum = nl > 1 ? std::max(1, nl / 4) : 0;
             wa.seg_sync = nullptr;
             wa.same_prev = (j.h_ngroups < n && n >= 2) ? j.b_same.as<int32_t>() : nullptr;
+            wa.sc = j.b_wide.as<char>() + sc_off;
+            CYTO_HIP(hipMemsetAsync(wa.sc, 0, WIDE_SC_BYTES, stream));
             wa.mc_groups = mcg; wa.gbmin = nullptr; wa.gdirty = nullptr; wa.gasg = nullptr; wa.gdense = nullptr; wa.ctl = nullptr;
             if (mcg > 0) {
                 const size_t nblk = ((size_t)n + 63) / 64, nw32 = ((size_t)n + 31) / 32;
@@ -3425,7 +3428,7 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
                     info->wide_ms_list = dbg[1] * 1e-5; info->wide_ms_chain = dbg[3] * 1e-5;
                     info->wide_ms_aug_rounds = dbg[8] * 1e-5; info->wide_ms_aug_verify = dbg[9] * 1e-5;
                     info->wide_ms_aug_finish = dbg[10] * 1e-5; info->wide_ms_aug_trivial = dbg[11] * 1e-5;
-                    info->wide_arr_launches = dbg[12];
+                    info->wide_arr_launches = dbg[12]; info->wide_scaled = dbg[13]; info->wide_phases = dbg[14];
                 }
             }
         }

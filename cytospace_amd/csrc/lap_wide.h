@@ -13,13 +13,14 @@ namespace cyto {
 //   slot_j, slot_p, slot_c  [n] per active slot: the bid's column (-1 = retired), price, raw cost of that entry
 //   cache_col/val   [n][64] row caches (lap_jv.hip: build_row_caches)
 //   misc            512 bytes: +4 status, +8 double total, +16 long long counters[] (lap_jv.hip indices), +160.. wide counters,
-//                   +256 phase timers ([12]: launches of wide_arr), +384 the control block the first row-reduction rounds leave for wide_arr
+//                   +256 phase timers ([12]: launches of wide_arr, [13] scaled?, [14] phases begun), +384 what the phase machine of the row reduction leaves for wide_arr
 //   gbmin, gdirty, gasg, gdense, ctl   the multi-workgroup augmentation's shared state (global memory; wide_aug_mc): per 64-column
 //                   block the smallest dirty label, dirty / assigned / dense bitmaps, a 256-byte control block (zeroed by the host)
 //   mc_groups       workgroups that search one problem together (0: the one-workgroup kernel)
 //   same_prev       [n] 1 = the row equals the row before it (runs of identical rows: CytoSPACE repeats a spot's row per slot), or null
 //   seg_sync        shared by the launch, or null: [0] workgroups that asked for fresh caches (zeroed by the driver before every launch
 //                   of wide_arr / wide_aug), [1 + b] wide_arr: 1 = problem b's rounds paused; wide_aug: searches problem b still has to run
+//   sc              2 KB, zeroed by the driver: the control block of the row-reduction phase machine (lap_wide.hip: ScCtl)
 //   arr_waste       wide_arr: full-row bids (with their cache refresh) of one launch after which the list rounds pause (aug_seg == 0)
 //   aug_seg         when a launch of wide_aug returns to the driver for fresh row caches: -1 never, k > 0 after k searches, 0 when
 //                   its full-row relaxations reach aug_waste or seg_quorum workgroups of the launch have asked (misc + 132 holds the
@@ -33,7 +34,8 @@ namespace cyto {
     P(int32_t, freerows) P(int32_t, act0) P(int32_t, act1) P(int32_t, touched) P(int32_t, slot_j) P(float, slot_p)            \
     P(float, slot_c) P(uint32_t, cache_col) P(float, cache_val) P(char, misc) S(long long, max_rounds)                     \
     P(unsigned long long, gbmin) P(uint32_t, gdirty) P(uint32_t, gasg) P(uint32_t, gdense) P(char, ctl) S(int, mc_groups)  \
-    P(const int32_t, same_prev) P(int32_t, seg_sync) S(int, aug_seg) S(int, aug_waste) S(int, arr_waste) S(int, seg_quorum)
+    P(const int32_t, same_prev) P(int32_t, seg_sync) S(int, aug_seg) S(int, aug_waste) S(int, arr_waste) S(int, seg_quorum)   \
+    P(char, sc)
 #define WIDE_F_PTR(T, name) T *name;
 #define WIDE_F_VAL(T, name) T name;
 struct WideArgs { WIDE_FIELDS(WIDE_F_PTR, WIDE_F_VAL) };
@@ -42,6 +44,7 @@ struct WideArgs { WIDE_FIELDS(WIDE_F_PTR, WIDE_F_VAL) };
 enum { WC_ROUNDS = 0, WC_BIDS, WC_RETIRED, WC_ACTIVE_LEFT, WC_FREE_ARR, WC_DENSE_ARR, WC_DENSE_AUG, WC_AUG_ROUNDS, WC_AUG_PROCESSED,
        WC_TRIVIAL, WC_VERIFY_PASSES, WC_AUG_LAUNCHES, WC_N };
 
+constexpr size_t WIDE_SC_BYTES = 2048;
 size_t wide_aug_lds_bytes(int n);
 // phases, each one launch for the whole batch (d_args: device array of nb WideArgs)
 int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream);        // Jacobi reduction transfer (v0 snapshot in cassign)

@@ -104,38 +104,90 @@ __device__ __forceinline__ float rdlane(float x, int l) { return __uint_as_float
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
-// REDUCTION TRANSFER (Jacobi).  v0 = the post-column-reduction prices (a copy lives in a.cassign, which also is the
-// raw cost of every column's owner entry at that point: the column minimum).  Row i with exactly one column j1:
-//   v[j1] = v0[j1] - min_{j != j1} (c[i][j] - v0[j])
-// The cache was built against v0: it holds EVERY column with c - v0 < floor, so a cached minimum <= floor is the row's.
+// The control block of the row-reduction phase (WideArgs.sc, 2 KB, zeroed by the driver): the scale of the instance that
+// wide_rt measures, and the state of the phase machine below (wide_sc_*).
+// ------------------------------------------------------------------------------------------------------------------
+enum { SC_LEGACY = 0, SC_EPS = 1, SC_FINAL = 2, SC_HANDOVER = 3, SC_DONE = 4 };   // modes (>= SC_HANDOVER: the machine is through)
+enum { SC_ACT_NONE = 0, SC_ACT_ROUND = 1, SC_ACT_RESET = 2 };                      // what a launch pair does
+struct ScSlot { int mode, k, rip, cur, act; float eps; long long total, bids; };
+struct ScCtl {
+    int hist[256];                 // rows per binary exponent (the exponent FIELD) of their gap u2 - u1 at the post-column-reduction prices
+    uint32_t vmaxbits;             // bits of max_j |v0[j]|
+    int e0;                        // exponent field of eps_0 (0: the instance never scales)
+    float epsmin;                  // phases end below this eps (the resolution of the prices)
+    int stop;                      // WIDE_STOP(n)
+    int cnt[2];                    // lengths of the two active lists
+    int retired, dense, dense_mark, phases, free_cr, pad_;
+    unsigned long long base;       // `total` when the bid words were last wiped (their 12-bit round tag is relative to it)
+    ScSlot slot[2];                // launch pair L reads slot[L & 1] and leaves slot[(L + 1) & 1]
+};
+static_assert(sizeof(ScCtl) <= 2048, "control block of the row-reduction phase");
+// the constants of the restatement (oracle/jv_oracle.h: JV_WIDE_*)
+constexpr int SC_K0 = 8, SC_NPH = 10, SC_PHCAP = 1024, SC_EMULT = 5, SC_ESTEP = 2;
+__host__ __device__ inline int wide_stop(int n) { return n / 128 < 8 ? 8 : (n / 128 > 64 ? 64 : n / 128); }
+// the next representable value below x (+0 and -0 are one value): oracle pred_
+__device__ __forceinline__ float pred_f32(float x) {
+    const uint32_t o = f2ord(x);
+    float r = ord2f(o - 1u);
+    if (!(r < x)) r = ord2f(o - 2u);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// REDUCTION TRANSFER (Jacobi) -- and the scale of the instance.  v0 = the post-column-reduction prices (a copy lives in
+// a.cassign, which also is the raw cost of every column's owner entry at that point: the column minimum).
+// Every row takes the lexicographic top-2 (u1, j1), (u2, j2) of c[i][.] - v0[.]: its gap u2 - u1 goes into the histogram of
+// binary exponents (integer counts: no order); a row that owns exactly one column jo subtracts its margin
+//   v[jo] = v0[jo] - min_{j != jo} (c[i][j] - v0[j])        (= u2 if j1 == jo, else u1)
+// The cache was built against v0: it holds EVERY column with c - v0 < floor, so a cached second minimum < floor is the row's.
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RTB) void wide_rt(const WideArgs *__restrict__ batch) {
     const WideArgs a = load_wide_args(batch, blockIdx.y);
     const int n = a.n;
     if (n < 2) return;
+    __shared__ int s_hist[256];
+    __shared__ uint32_t s_vmax;
+    for (int e = threadIdx.x; e < 256; e += RTB) s_hist[e] = 0;
+    if (threadIdx.x == 0) s_vmax = 0;
+    __syncthreads();
+    ScCtl *sc = reinterpret_cast<ScCtl *>(a.sc);
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * (RTB / 64) + (threadIdx.x >> 6), nw = gridDim.x * (RTB / 64);
     const float *__restrict__ v0 = a.cassign;
+    {
+        uint32_t m = 0;
+        for (int j = blockIdx.x * RTB + threadIdx.x; j < n; j += gridDim.x * RTB) { const uint32_t x = __float_as_uint(fabsf(v0[j])); m = m > x ? m : x; }
+        if (m) atomicMax(&s_vmax, m);
+    }
     long long done = 0;
     for (int i = gw; i < n; i += nw) {
-        if (a.matches[i] != 1) continue;
-        const int j1 = a.rowsol[i];
         const uint32_t col = a.cache_col[(int64_t)i * KC + lane];
         const float val = a.cache_val[(int64_t)i * KC + lane];
         const float tau = __shfl(val, KCU);
-        const bool valid = lane < KCU && col != COLSENT && (int)col != j1;
-        uint32_t key = 0xFFFFFFFFu;
-        if (valid) key = f2ord(val - v0[col]);
-        uint32_t mk = wave_min_u32(key);
-        if (!(mk != 0xFFFFFFFFu && ord2f(mk) <= tau)) {       // the cache cannot certify the margin: the whole row
+        const bool valid = lane < KCU && col != COLSENT;
+        const uint32_t key = valid ? f2ord(val - v0[col]) : 0xFFFFFFFFu;
+        const uint32_t k1 = wave_min_u32(key);
+        const int l1 = __ffsll((unsigned long long)__ballot(key == k1)) - 1;
+        const uint32_t k2 = wave_min_u32(lane == l1 ? 0xFFFFFFFFu : key);
+        float u1, u2; int j1;
+        if (k2 != 0xFFFFFFFFu && ord2f(k2) < tau) { u1 = ord2f(k1); u2 = ord2f(k2); j1 = (int)rdlane(col, l1); }
+        else {                                                  // the cache cannot certify the top-2: the whole row
             const float *__restrict__ row = a.cost + wrow_off(a.rowmap, i, a.ld);
-            uint32_t k2 = 0xFFFFFFFFu;
-            wave_row_sweep(row, n, lane, [&](int c, float x) { if (c != j1) k2 = umin32(k2, f2ord(x - v0[c])); });
-            mk = wave_min_u32(k2);
+            K2 d; d.m1 = KEYMAX; d.m2 = KEYMAX;
+            wave_row_sweep(row, n, lane, [&](int c, float x) { k2_push(d, mkkey(x - v0[c], (uint32_t)c)); });
+            d = k2_wave_allreduce(d);
+            u1 = key_val(d.m1); u2 = key_val(d.m2); j1 = (int)(uint32_t)d.m1;
         }
-        if (lane == 0) a.v[j1] = v0[j1] - ord2f(mk);
-        done++;
+        if (lane == 0) atomicAdd(&s_hist[(__float_as_uint(u2 - u1) >> 23) & 0xFFu], 1);
+        if (a.matches[i] == 1) {
+            const int jo = a.rowsol[i];
+            if (lane == 0) a.v[jo] = v0[jo] - (j1 == jo ? u2 : u1);
+            done++;
+        }
     }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 256; e += RTB) if (s_hist[e]) atomicAdd(&sc->hist[e], s_hist[e]);
+    if (threadIdx.x == 0 && s_vmax) atomicMax(&sc->vmaxbits, s_vmax);
     if (lane == 0 && done) atomicAdd(reinterpret_cast<unsigned long long *>(a.misc + 16) + C_RT, (unsigned long long)done);
 }
 
@@ -261,7 +313,8 @@ template <bool VLDS, bool CLDS> struct ArrCtx {
     }
     // the bid of row i (its cache row in col / val, lane = entry): target column jt (-1: the row retires), price, raw cost of
     // the entry, and the owner it would displace
-    __device__ __forceinline__ void bid_of(int i, int w, uint32_t &col, float &val, int &jt, float &pt, float &ct, int &i0) const {
+    // eps > 0 (a scaled phase): every bid lowers its column's price by the gap + eps, by one ulp at least -- no claims, nobody retires
+    __device__ __forceinline__ void bid_of(int i, int w, uint32_t &col, float &val, int &jt, float &pt, float &ct, int &i0, float eps = 0.0f) const {
         // cache rows are sorted by column: among equal reduced costs the lowest lane is the lowest column, so the
         // lexicographic (value, column) top-2 is two 32-bit min reductions and two ballots
         const float tau = rdlane(val, KCU);
@@ -281,9 +334,16 @@ template <bool VLDS, bool CLDS> struct ArrCtx {
         } else {
             top2_full(i, w, col, val, u1, j1, c1, vj1, u2, j2, c2, vj2);
         }
-        const float p = vj1 - (u2 - u1);
         jt = -1; pt = 0.0f; ct = 0.0f; i0 = -1;
         const int o1 = uni(getcs(j1));
+        if (eps > 0.0f) {
+            float p = vj1 - ((u2 - u1) + eps);
+            if (!(p < vj1)) p = pred_f32(vj1);
+            jt = j1; pt = p; ct = c1; i0 = o1;
+            jt = uni(jt); pt = uni(pt); ct = uni(ct); i0 = uni(i0);
+            return;
+        }
+        const float p = vj1 - (u2 - u1);
         if (p < vj1) { jt = j1; pt = p; ct = c1; i0 = o1; }
         else if (o1 < 0) { jt = j1; pt = vj1; ct = c1; }
         else if (j2 >= 0 && u2 == u1 && uni(getcs(j2)) < 0) { jt = j2; pt = vj2; ct = c2; }
@@ -291,81 +351,146 @@ template <bool VLDS, bool CLDS> struct ArrCtx {
     }
 };
 
-// The first rounds on the whole chip.  A problem starts with a third of its rows free (column reduction leaves n/e of them;
-// c3: 45 000 of 50 000): thousands of independent bids per round, which one workgroup would take one by one.  wide_arr_head_* run
-// round r as three launches over all CUs -- bids (a wave per active row, prices and owners read from L2), resolution (a thread per
-// bid), reset of the bid words -- and leave the active list, the round count and the counters in the control block at misc + 384,
-// where wide_arr picks them up.  The same round as in wide_arr (a pure function of the state).
-// The bid word of a column: | 12 bits ~round | 32 bits ordered price | 20 bits row |, merged with an atomic min: within a round the
-// lowest (price, row) wins, and ANY bid of a later round beats what earlier rounds left behind -- the words are never reset (that
-// was a third pass and a third barrier / launch per round).  The round tag wraps every 4096 rounds: then the words are wiped.
+// The rounds on the whole chip: the phase machine of the row reduction (oracle/jv_oracle_impl.h, WIDE MODE).
+//   LEGACY   eps = 0 rounds from the column reduction's state (claims, retirements).  After SC_K0 of them an instance whose active
+//            list is still longer than wide_stop(n) -- generic costs: no ties to retire on, price wars without end -- SCALES; any
+//            other one goes on until its list is short (<= 64 rows: the chain rounds of wide_arr take over) or empty.
+//   EPS      phase k: every row unassigned, prices kept; rounds with eps_k = eps_0 / 4^k (every bid lowers its column's price by the
+//            gap + eps_k) until the list is down to wide_stop(n) rows -- the sequential tail of a phase is cut, the next phase
+//            takes every row up again.  eps_0 = 2^SC_EMULT x the median binade of the rows' gaps at the post-column-reduction prices.
+//   FINAL    the same with eps = 0 and the claim / retire rules: what it leaves free goes to the searches.
+// A round is two launches over all CUs -- bids (a wave per active row, prices and owners read from L2), resolution (a thread per
+// bid); a phase boundary is one such pair too (everything unassigned, the list = every row).  The driver enqueues pairs in groups and
+// asks after each group who is through.  Launch pair L reads the state in slot[L & 1]; every workgroup of its first kernel derives
+// the same step from it (a pure function of the slot and the list length), workgroup 0 leaves the next state in slot[(L + 1) & 1].
+// The bid word of a column: | 12 bits ~(round - base) | 32 bits ordered price | 20 bits row |, merged with an atomic min: within a
+// round the lowest (price, row) wins, and ANY bid of a later round beats what earlier rounds left behind -- the words are never reset
+// between rounds; wide_sc_wipe (every 2048 pairs) resets them and moves `base`.
 __device__ __forceinline__ unsigned long long bidkey(long long round, float price, int row) {
     return ((unsigned long long)(~(uint32_t)round & 0xFFFu) << 52) | ((unsigned long long)f2ord(price) << 20) | (uint32_t)row;
 }
 __device__ __forceinline__ bool bid_won(unsigned long long word, int row) { return (int)((uint32_t)word & 0xFFFFFu) == row; }
 
-struct ArrHead { int cnt[2]; int started, free_cr; long long round, bids; int retired, dense; int done, launches; long long list_rounds; int head_over, bid_epoch, dense_mark; };
-constexpr int HEADB = 256;             // threads of the head kernels' workgroups
+struct ArrHead { int cnt[2]; int started, free_cr; long long round, bids; int retired, dense; int done, launches; long long list_rounds; int no_more, pad_; };
+constexpr int HEADB = 256;             // threads of the machine's workgroups
 
-__global__ __launch_bounds__(HEADB) void wide_arr_head_init(const WideArgs *__restrict__ batch) {
+__device__ __forceinline__ float sc_eps_of(const ScCtl *sc, int k) {       // eps of phase k, 0 = there is no such phase
+    if (k >= SC_NPH) return 0.0f;
+    const int ek = sc->e0 - SC_ESTEP * k;
+    if (ek < 1) return 0.0f;
+    const float eps = __uint_as_float((uint32_t)ek << 23);
+    return eps < sc->epsmin ? 0.0f : eps;
+}
+// the step of launch pair L (every thread of the pair's first kernel computes the same)
+__device__ __forceinline__ ScSlot sc_step(const ScCtl *sc, const ScSlot &S, int na, int n, long long max_rounds) {
+    ScSlot N = S;
+    N.act = SC_ACT_NONE;
+    if (S.mode >= SC_HANDOVER) return N;
+    // (the budget of rounds ends the LEGACY rounds and the scaled phases, never the FINAL phase: the assignments a scaled phase leaves
+    //  satisfy eps-complementary slackness only, the searches need the eps = 0 phase's)
+    const bool over = S.total >= max_rounds;
+    bool next_phase = false, last = false;
+    if (S.mode == SC_LEGACY) {
+        if (over || na == 0) { N.mode = SC_DONE; return N; }
+        if (S.rip == SC_K0 && na > sc->stop && sc->e0 > 0) { next_phase = true; N.k = -1; }
+        else if (S.rip >= SC_K0 && na <= ASL) { N.mode = SC_HANDOVER; return N; }
+    } else if (S.mode == SC_EPS) {
+        if (over) { next_phase = true; last = true; }
+        else if (S.rip >= 1 && (na <= sc->stop || S.rip >= SC_PHCAP)) next_phase = true;
+    } else if (S.rip >= 1 && (na <= sc->stop || S.rip >= SC_PHCAP)) { N.mode = SC_DONE; return N; }
+    if (next_phase) {
+        N.k = N.k + 1;
+        const float eps = last ? 0.0f : sc_eps_of(sc, N.k);
+        N.mode = eps > 0.0f ? SC_EPS : SC_FINAL; N.eps = eps; N.rip = 0; N.cur = S.cur ^ 1; N.act = SC_ACT_RESET;
+        return N;
+    }
+    N.act = SC_ACT_ROUND; N.rip = S.rip + 1; N.total = S.total + 1; N.bids = S.bids + na; N.cur = S.cur ^ 1;
+    return N;
+}
+
+__global__ __launch_bounds__(HEADB) void wide_sc_init(const WideArgs *__restrict__ batch) {
     const WideArgs a = load_wide_args(batch, blockIdx.y);
-    ArrHead *h = reinterpret_cast<ArrHead *>(a.misc + 384);
+    ScCtl *sc = reinterpret_cast<ScCtl *>(a.sc);
     const int n = a.n, lane = threadIdx.x & 63;
     for (int i0 = blockIdx.x * HEADB; i0 < n; i0 += gridDim.x * HEADB) {
         const int i = i0 + threadIdx.x;
         const bool fr = i < n && a.rowsol[i] < 0;
         const uint64_t m = __ballot(fr);
         int base = 0;
-        if (lane == 0 && m) base = atomicAdd(&h->cnt[0], __popcll(m));
+        if (lane == 0 && m) base = atomicAdd(&sc->cnt[0], __popcll(m));
         base = __shfl(base, 0);
         if (fr) a.act0[base + __popcll(m & lanemask_lt())] = i;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) h->started = 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // the median binade of the gaps (wide_rt's histogram), eps_0 = 2^SC_EMULT times it; no scaling when half the gaps are zero
+        long long cum = 0; int me = 0;
+        for (int e = 0; e < 256; e++) { cum += sc->hist[e]; if (cum * 2 >= n) { me = e; break; } }
+        sc->e0 = me > 0 ? (me + SC_EMULT > 254 ? 254 : me + SC_EMULT) : 0;
+        sc->epsmin = __uint_as_float(sc->vmaxbits) * 1.1920928955078125e-07f;
+        sc->stop = wide_stop(n);
+        ScSlot S; S.mode = SC_LEGACY; S.k = 0; S.rip = 0; S.cur = 0; S.act = SC_ACT_NONE; S.eps = 0.0f; S.total = 0; S.bids = 0;
+        sc->slot[0] = S;
+    }
 }
 
-__global__ __launch_bounds__(HEADB) void wide_arr_head_bid(const WideArgs *__restrict__ batch, int r) {
+__global__ __launch_bounds__(HEADB) void wide_sc_bid(const WideArgs *__restrict__ batch, int L) {
     extern __shared__ __align__(16) unsigned char w_smem[];
     ArrShared &s = *reinterpret_cast<ArrShared *>(w_smem);
     ArrCtx<false, false> cx;
     cx.a = load_wide_args(batch, blockIdx.y);
     const WideArgs &a = cx.a;
-    ArrHead *h = reinterpret_cast<ArrHead *>(a.misc + 384);
-    if (h->head_over) return;                                    // (sticky: the rounds after it must not touch the lists)
-    const int cur = r & 1, na = h->cnt[cur];
-    // the whole chip takes the rounds while the active list is long; at <= 64 rows (one chain round of wide_arr) it is over
-    if (r > 0 && na <= ASL) { if (blockIdx.x == 0 && threadIdx.x == 0) h->head_over = 1; return; }
-    // the list this round appends to starts empty
-    if (blockIdx.x == 0 && threadIdx.x == 0) { h->cnt[cur ^ 1] = 0; if (r == 0) h->free_cr = na; }
-    if (na == 0) return;
+    ScCtl *sc = reinterpret_cast<ScCtl *>(a.sc);
+    const ScSlot S = sc->slot[L & 1];
+    if (S.mode >= SC_HANDOVER) {                                 // through: the state stays (both slots)
+        if (blockIdx.x == 0 && threadIdx.x == 0 && sc->slot[(L + 1) & 1].mode != S.mode) { ScSlot N = S; N.act = SC_ACT_NONE; sc->slot[(L + 1) & 1] = N; }
+        return;
+    }
+    const int n = a.n, cur = S.cur, na = sc->cnt[cur];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && S.total == 0 && S.rip == 0 && S.mode == SC_LEGACY) sc->free_cr = na;
+    const ScSlot N = sc_step(sc, S, na, n, a.max_rounds);
+    const int32_t *A = cur ? a.act1 : a.act0;
+    int32_t *B = cur ? a.act0 : a.act1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc->slot[(L + 1) & 1] = N;
+        if (N.act == SC_ACT_ROUND) sc->cnt[cur ^ 1] = 0;         // the list this round's resolution appends to starts empty
+        if (N.act == SC_ACT_RESET) { sc->cnt[cur ^ 1] = n; sc->phases += 1; }
+    }
+    if (N.act == SC_ACT_RESET) {                                 // a phase begins: everything unassigned, every row on the list
+        for (int i = blockIdx.x * HEADB + threadIdx.x; i < n; i += gridDim.x * HEADB) { a.rowsol[i] = -1; a.colsol[i] = -1; B[i] = i; }
+        return;
+    }
+    if (N.act != SC_ACT_ROUND) return;
     const int lane = threadIdx.x & 63, w = uni((int)(threadIdx.x >> 6));
     cx.s_v = nullptr; cx.s_cs = nullptr; cx.s = &s; cx.lane = lane;
     if (threadIdx.x == 0) { s.retired = 0; s.dense = 0; }
     __syncthreads();
-    const int32_t *A = cur ? a.act1 : a.act0;
+    const long long tag = S.total - (long long)sc->base;
+    const float eps = S.eps;
     const int gw = blockIdx.x * (HEADB / 64) + w, nw = gridDim.x * (HEADB / 64);
     for (int slot = gw; slot < na; slot += nw) {
         const int i = uni(A[slot]);
         uint32_t col = a.cache_col[(int64_t)i * KC + lane];
         float val = a.cache_val[(int64_t)i * KC + lane];
         int jt, i0; float pt, ct;
-        cx.bid_of(i, w, col, val, jt, pt, ct, i0);
+        cx.bid_of(i, w, col, val, jt, pt, ct, i0, eps);
         if (lane == 0) {
             if (jt < 0) atomicAdd(&s.retired, 1);
-            else atomicMin(a.bid + jt, bidkey(r, pt, i));
+            else atomicMin(a.bid + jt, bidkey(tag, pt, i));
             a.slot_j[slot] = jt; a.slot_p[slot] = pt; a.slot_c[slot] = ct;
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) { if (s.retired) atomicAdd(&h->retired, s.retired); if (s.dense) atomicAdd(&h->dense, s.dense); }
+    if (threadIdx.x == 0) { if (s.retired) atomicAdd(&sc->retired, s.retired); if (s.dense) atomicAdd(&sc->dense, s.dense); }
 }
 
-__global__ __launch_bounds__(HEADB) void wide_arr_head_resolve(const WideArgs *__restrict__ batch, int r) {
+__global__ __launch_bounds__(HEADB) void wide_sc_resolve(const WideArgs *__restrict__ batch, int L) {
     ArrCtx<false, false> cx;
     cx.a = load_wide_args(batch, blockIdx.y);
     const WideArgs &a = cx.a;
-    ArrHead *h = reinterpret_cast<ArrHead *>(a.misc + 384);
-    if (h->head_over) return;
-    const int cur = r & 1, na = h->cnt[cur];
+    ScCtl *sc = reinterpret_cast<ScCtl *>(a.sc);
+    const ScSlot N = sc->slot[(L + 1) & 1];                      // (written by this pair's first kernel)
+    if (N.act != SC_ACT_ROUND) return;
+    const int cur = N.cur ^ 1, na = sc->cnt[cur];                // the list the bids were made from
     cx.s_v = nullptr; cx.s_cs = nullptr; cx.s = nullptr; cx.lane = threadIdx.x & 63;
     const int32_t *A = cur ? a.act1 : a.act0;
     int32_t *B = cur ? a.act0 : a.act1;
@@ -376,32 +501,56 @@ __global__ __launch_bounds__(HEADB) void wide_arr_head_resolve(const WideArgs *_
         if (bid_won(a.bid[jt], i)) {
             const int i0 = a.colsol[jt];
             cx.apply(i, jt, a.slot_p[slot], a.slot_c[slot], i0);
-            if (i0 >= 0) B[atomicAdd(&h->cnt[cur ^ 1], 1)] = i0;
+            if (i0 >= 0) B[atomicAdd(&sc->cnt[cur ^ 1], 1)] = i0;
         } else {
-            B[atomicAdd(&h->cnt[cur ^ 1], 1)] = i;
+            B[atomicAdd(&sc->cnt[cur ^ 1], 1)] = i;
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && na > 0) { h->bids += na; h->round += 1; }     // (read by nobody before wide_arr)
 }
 
-// after a group of rounds: which problems are still in their long-list rounds (seg_sync[0] counts them; the driver enqueues the
-// next group or stops), and which of them want their row caches rebuilt before it -- seg_sync[1 + b] = 1: the full-row bids since the
-// last rebuild have reached a.arr_waste (see wide_arr), 2: there were some, 0: none.  wipe: the bid words' round tag is about to wrap
-__global__ __launch_bounds__(HEADB) void wide_arr_head_check(const WideArgs *__restrict__ batch, int r_next, int wipe) {
+// after a group of pairs (the next pair is L): seg_sync[0] counts the problems whose machine is not through, seg_sync[1 + b] = 1: the
+// full-row bids since the last rebuild have reached a.arr_waste -- problem b wants its row caches rebuilt before the next group
+__global__ void wide_sc_check(const WideArgs *__restrict__ batch, int L) {
+    const WideArgs a = load_wide_args(batch, blockIdx.x);
+    ScCtl *sc = reinterpret_cast<ScCtl *>(a.sc);
+    if (threadIdx.x != 0 || !a.seg_sync) return;
+    const bool through = sc->slot[L & 1].mode >= SC_HANDOVER;
+    int want = 0;
+    if (!through) {
+        atomicAdd(a.seg_sync, 1);
+        const int since = sc->dense - sc->dense_mark;
+        if (a.aug_seg == 0 && since >= a.arr_waste) { want = 1; sc->dense_mark = sc->dense; }
+    }
+    a.seg_sync[1 + blockIdx.x] = want;
+}
+
+// between two pairs (the next one is L): the bid words start over
+__global__ __launch_bounds__(HEADB) void wide_sc_wipe(const WideArgs *__restrict__ batch, int L) {
     const WideArgs a = load_wide_args(batch, blockIdx.y);
+    ScCtl *sc = reinterpret_cast<ScCtl *>(a.sc);
+    for (int j = blockIdx.x * HEADB + threadIdx.x; j < a.n; j += gridDim.x * HEADB) a.bid[j] = ~0ull;
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc->base = (unsigned long long)sc->slot[L & 1].total;
+}
+
+// the machine is through (the next pair would be L): what wide_arr picks up -- the short list of a LEGACY problem for its chain rounds
+// (on the list its round's parity names), the counters; no_more: the rounds are over (budget, or a scaled problem's last phase)
+__global__ void wide_sc_finish(const WideArgs *__restrict__ batch, int L) {
+    const WideArgs a = load_wide_args(batch, blockIdx.x);
+    ScCtl *sc = reinterpret_cast<ScCtl *>(a.sc);
     ArrHead *h = reinterpret_cast<ArrHead *>(a.misc + 384);
-    const bool over = h->head_over || h->cnt[r_next & 1] <= ASL;
-    if (over) { if (blockIdx.x == 0 && threadIdx.x == 0 && a.seg_sync) a.seg_sync[1 + blockIdx.y] = 0; return; }
-    if (wipe) for (int j = blockIdx.x * HEADB + threadIdx.x; j < a.n; j += gridDim.x * HEADB) a.bid[j] = ~0ull;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (wipe) h->bid_epoch = r_next >> 12;
-        if (a.seg_sync) {
-            atomicAdd(a.seg_sync, 1);
-            const int since = h->dense - h->dense_mark;
-            const bool want = a.aug_seg == 0 && since >= a.arr_waste;
-            if (want) h->dense_mark = h->dense;
-            a.seg_sync[1 + blockIdx.y] = want ? 1 : (since > 0 ? 2 : 0);
-        }
+    const ScSlot S = sc->slot[L & 1];
+    const int na = sc->cnt[S.cur], want = (int)(S.total & 1);
+    const bool chain = S.mode == SC_HANDOVER;
+    if (chain && want != S.cur) {
+        const int32_t *A = S.cur ? a.act1 : a.act0;
+        int32_t *B = S.cur ? a.act0 : a.act1;
+        for (int q = threadIdx.x; q < na; q += blockDim.x) B[q] = A[q];
+    }
+    if (threadIdx.x == 0) {
+        h->cnt[want] = na; h->cnt[want ^ 1] = 0; h->started = 1; h->free_cr = sc->free_cr; h->round = S.total; h->bids = S.bids;
+        h->retired = sc->retired; h->dense = sc->dense; h->done = 0; h->launches = 0; h->list_rounds = S.total; h->no_more = chain ? 0 : 1;
+        long long *dbg = reinterpret_cast<long long *>(a.misc + 256);
+        dbg[13] = sc->phases > 0 ? 1 : 0; dbg[14] = sc->phases;
     }
 }
 
@@ -462,16 +611,15 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
     int na = free_cr;
     const int dense0 = s.dense;
     const long long round0 = round;
-    int bid_epoch = h->bid_epoch;
+    const bool no_more = h->no_more != 0;
     bool paused = false, announced = false;
     // ================= LIST rounds =================
     for (;;) {
         na = uni(s.cnt[cur]);
-        if (na <= ASL || round >= a.max_rounds) break;
+        if (na <= ASL || round >= a.max_rounds || no_more) break;
         if (uni(s.pause)) { paused = true; break; }
-        if ((int)(round >> 12) != bid_epoch) {                       // the bid words' round tag has wrapped since they were last wiped
+        if (round == round0 || (round & 0xFFF) == 0) {               // the bid words: wiped at the start and whenever their round tag wraps
             for (int j = tid; j < n; j += WT) a.bid[j] = ~0ull;
-            bid_epoch = (int)(round >> 12);
             __syncthreads();
         }
         for (int base = 0; base < na; base += ASL) {
@@ -525,7 +673,7 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
     const long long t_chain0 = wall_clock64();
     // ================= CHAIN rounds: wave w holds the rows of slots q * 16 + w =================
     int left = na;                                               // rows still active when the rounds end
-    if (!paused && na > 0 && na <= ASL && round < a.max_rounds) {
+    if (!paused && !no_more && na > 0 && na <= ASL && round < a.max_rounds) {
         int my[ACS], jt[ACS], i0[ACS];
         uint32_t col[ACS], ncol[ACS];
         float val[ACS], nval[ACS], pt[ACS], ct[ACS];
@@ -663,7 +811,7 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
         dbg[0] = n_list; dbg[1] += t_list; dbg[2] = n_chain; dbg[3] += t_chain; dbg[4] = n_deal; dbg[6] = wall_clock64() - t_tail0;
         // the state for the next launch, if the rounds paused (cur == round & 1: both flip together)
         h->started = 1; h->round = round; h->bids = bids; h->retired = s.retired; h->dense = s.dense; h->cnt[cur] = paused ? na : 0;
-        h->cnt[cur ^ 1] = 0; h->free_cr = free_cr; h->done = paused ? 0 : 1; h->launches += 1; h->list_rounds = n_list; h->bid_epoch = bid_epoch;
+        h->cnt[cur ^ 1] = 0; h->free_cr = free_cr; h->done = paused ? 0 : 1; h->launches += 1; h->list_rounds = n_list;
 #ifndef CYTO_WIDE_PROF
         dbg[12] = h->launches;
 #endif
@@ -1572,47 +1720,45 @@ int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream) {
 
 int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, long long max_rounds, bool resume, int32_t *d_sync,
                     int (*rebuild)(void *ctx, const int32_t *flags), void *ctx) {
-    // the rounds with a long active list on the whole chip (two launches per round: bids, resolution), in groups of 16, 32, 64, 128 ...
-    // rounds -- after a group the driver asks whether any problem's list is still long (one 4-byte read); the long tail (<= 64 active
-    // rows) and whatever the budget leaves on one workgroup per problem.  resume: the rounds paused for fresh row caches -- wide_arr
-    // alone picks them up
-    if (n >= 4096 && max_rounds > 0 && !resume) {
-        const int bx = std::max(1, std::min((n + 255) / 256, 1024 / std::max(1, std::min(nb, 8))));
-        int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(wide_arr_head_bid));
-        if (rc) return rc;
-        hipLaunchKernelGGL(wide_arr_head_init, dim3(bx, nb), dim3(HEADB), 0, stream, d_args);
-        // (a batch keeps only its first eight rounds here: its problems run side by side on a workgroup each anyway, at their own pace,
-        //  while a round here costs two launches for all of them -- measured: 50 c5 chunks 1.15 s that way, 1.57 s with every long-list
-        //  round on the whole chip; 256 c4 chunks 2.0 against 2.2 s)
-        const long long head_rounds = nb <= 4 ? max_rounds : std::min<long long>(8, max_rounds);
-        int r = 0, group = 16;
-        while (r < head_rounds) {
-            const int r1 = (int)std::min<long long>(head_rounds, std::min<long long>(r + group, ((long long)(r >> 12) + 1) << 12));
-            for (; r < r1; r++) {
-                hipLaunchKernelGGL(wide_arr_head_bid, dim3(bx, nb), dim3(HEADB), ARR_SHARED_BYTES, stream, d_args, r);
-                hipLaunchKernelGGL(wide_arr_head_resolve, dim3(bx, nb), dim3(HEADB), 0, stream, d_args, r);
+    // The phase machine on the whole chip (two launches per round), in groups of pairs: after a group the driver asks which problems
+    // are not through (one small read) and rebuilds the row caches of those whose floors have gone stale; then wide_arr -- one
+    // workgroup per problem -- for the chain rounds of the problems that did not scale (<= 64 active rows) and the free lists.
+    // resume: wide_arr's chain rounds paused for fresh row caches -- it alone picks them up
+    (void)max_rounds;
+    int rc;
+    if (n >= 2 && !resume) {
+        // a wave per bid while the chip has room for them (a bid is a chain of L2 round trips: what counts is how many are in flight);
+        // the other kernels of the machine are a thread per row / slot
+        const int bx = std::max(1, std::min((n + HEADB / 64 - 1) / (HEADB / 64), std::max(64, 4096 / std::max(1, nb))));
+        const int bxr = std::max(1, std::min((n + HEADB - 1) / HEADB, 2048 / std::max(1, std::min(nb, 16))));
+        if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(wide_sc_bid)))) return rc;
+        hipLaunchKernelGGL(wide_sc_init, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args);
+        std::vector<int32_t> h_sync((size_t)nb + 1, 0);
+        int L = 0, group = 32;
+        for (;;) {
+            for (int g = 0; g < group; g++, L++) {
+                if (L > 0 && (L & 2047) == 0) hipLaunchKernelGGL(wide_sc_wipe, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args, L);
+                hipLaunchKernelGGL(wide_sc_bid, dim3(bx, nb), dim3(HEADB), ARR_SHARED_BYTES, stream, d_args, L);
+                hipLaunchKernelGGL(wide_sc_resolve, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args, L);
             }
-            if (!d_sync || r >= head_rounds) break;
-            std::vector<int32_t> h_sync((size_t)nb + 1, 0);
+            if (!d_sync) return CYTO_ERR_INTERNAL;
             CYTO_HIP(hipMemsetAsync(d_sync, 0, sizeof(int32_t), stream));
-            hipLaunchKernelGGL(wide_arr_head_check, dim3(bx, nb), dim3(HEADB), 0, stream, d_args, r, (r & 0xFFF) == 0 ? 1 : 0);
+            hipLaunchKernelGGL(wide_sc_check, dim3(nb), dim3(64), 0, stream, d_args, L);
             CYTO_HIP(hipMemcpyAsync(h_sync.data(), d_sync, sizeof(int32_t) * ((size_t)nb + 1), hipMemcpyDeviceToHost, stream));
             CYTO_HIP(hipStreamSynchronize(stream));
             if (!h_sync[0]) break;
-            bool want = false, some = false;
-            for (int b = 0; b < nb; b++) { want = want || h_sync[(size_t)b + 1] == 1; some = some || h_sync[(size_t)b + 1] != 0; }
-            if (want && rebuild) {                                 // fresh row caches for the problems that asked (their floors have gone stale)
-                for (int b = 0; b < nb; b++) h_sync[(size_t)b + 1] = h_sync[(size_t)b + 1] == 1 ? 1 : 0;
-                if ((rc = rebuild(ctx, h_sync.data() + 1))) return rc;
-            }
-            group = some ? 16 : std::min(group * 2, 256);           // (full-row bids about: stay close to the next rebuild)
+            bool want = false;
+            for (int b = 0; b < nb; b++) want = want || h_sync[(size_t)b + 1] == 1;
+            if (want && rebuild && (rc = rebuild(ctx, h_sync.data() + 1))) return rc;
+            group = 64;
+            if (L > (1 << 22)) return CYTO_ERR_INTERNAL;               // (every phase is bounded: cannot happen)
         }
+        hipLaunchKernelGGL(wide_sc_finish, dim3(nb), dim3(64), 0, stream, d_args, L);
         CYTO_HIP(hipGetLastError());
     }
     const bool vlds = wide_arr_vlds(n), clds = wide_arr_clds(n);
     void (*k)(const WideArgs *) = vlds ? wide_arr<true, true> : clds ? wide_arr<false, true> : wide_arr<false, false>;
-    int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(k));
-    if (rc) return rc;
+    if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(k)))) return rc;
     hipLaunchKernelGGL(k, dim3(nb), dim3(WT), wide_arr_lds_bytes(n, vlds, clds), stream, d_args);
     CYTO_HIP(hipGetLastError());
     return CYTO_OK;

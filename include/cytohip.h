@@ -99,6 +99,8 @@ typedef struct {
                                                       passes, price update + flip + reset, one-edge searches (one-workgroup kernel) */
     int64_t wide_arr_launches;   /* row reduction: launches of the round kernel (row-cache rebuilds in between) */
     int64_t wide_aug_launches;   /* augmentation: launches of the search kernel (row-cache rebuilds in between: cyto_lap_opts.wide_rebuild) */
+    int64_t wide_scaled;         /* row reduction: 1 = the instance went through the eps-scaled phases */
+    int64_t wide_phases;         /* row reduction: phases begun (scaled phases + the final eps = 0 phase) */
 } cyto_lap_info;
 
 int cyto_lap_f32(int n, const float *cost, int64_t ld, int cost_on_device,

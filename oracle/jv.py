@@ -78,7 +78,8 @@ def jv_oracle(cost, dtype=np.float32):
 class JVWideStats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int64) for k in (
         "scans_redtransfer", "scans_arr", "scans_aug_init", "scans_aug_relax", "augmentations", "path_hops",
-        "free_after_colred", "free_after_arr", "arr_rounds", "arr_retired", "arr_active_left")]
+        "free_after_colred", "free_after_arr", "arr_rounds", "arr_retired", "arr_active_left",
+        "arr_scaled", "arr_phases", "gap_exp")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

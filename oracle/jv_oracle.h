@@ -38,9 +38,19 @@ typedef struct {
     int64_t augmentations, path_hops;
     int64_t free_after_colred, free_after_arr;
     int64_t arr_rounds, arr_retired, arr_active_left;
+    int64_t arr_scaled, arr_phases, gap_exp;
 } jv_wide_stats;
 
 #define JV_WIDE_ROUNDS(n) (4096 + (int64_t)(n) / 4)
+/* the eps-scaled row reduction (jv_oracle_impl.h, WIDE MODE): eps = 0 rounds before the decision, the active-list length at which a
+ * phase ends (and below which an instance never scales), phases at most, rounds per phase at most, eps_0 = 2^EMULT x the median gap's
+ * binade, eps_k = eps_0 / 2^(ESTEP k) */
+#define JV_WIDE_K0 8
+#define JV_WIDE_STOP(n) ((n) / 128 < 8 ? 8 : ((n) / 128 > 64 ? 64 : (n) / 128))
+#define JV_WIDE_NPH 10
+#define JV_WIDE_PHCAP 1024
+#define JV_WIDE_EMULT 5
+#define JV_WIDE_ESTEP 2
 #define JV_WIDE_KMAX 4095            /* tight hops a label counts before the distance itself is stepped */
 
 int jv_oracle_wide_f32(int n, const float *cost, int32_t *rowsol, int32_t *colsol, float *u, float *v,

@@ -276,6 +276,38 @@ static inline T FN(succ_)(T x) {
 #endif
 }
 
+/* the next representable value BELOW x (x finite; +0 and -0 are one value) */
+static inline T FN(pred_)(T x) {
+#if defined(JV_T_IS_FLOAT)
+    return nextafterf(x + 0.0f, -INFINITY);
+#else
+    return nextafter(x + 0.0, -INFINITY);
+#endif
+}
+static inline int FN(expfield_)(T g) {
+#if defined(JV_T_IS_FLOAT)
+    uint32_t b; memcpy(&b, &g, 4); return (int)((b >> 23) & 0xFFu);
+#else
+    uint64_t b; memcpy(&b, &g, 8); return (int)((b >> 52) & 0x7FFu);
+#endif
+}
+static inline T FN(pow2_)(int expfield) {       /* the power of two whose exponent field is expfield (1 <= expfield < all-ones) */
+#if defined(JV_T_IS_FLOAT)
+    const uint32_t b = (uint32_t)expfield << 23; T x; memcpy(&x, &b, 4); return x;
+#else
+    const uint64_t b = (uint64_t)expfield << 52; T x; memcpy(&x, &b, 8); return x;
+#endif
+}
+#if defined(JV_T_IS_FLOAT)
+#define JV_T_EXPMAX 255
+#define JV_T_ULP1 ((T)1.1920928955078125e-07)        /* 2^-23 */
+#else
+#undef JV_T_EXPMAX
+#undef JV_T_ULP1
+#define JV_T_EXPMAX 2047
+#define JV_T_ULP1 ((T)2.220446049250313e-16)         /* 2^-52 */
+#endif
+
 int FN(jv_oracle_wide_)(int n, const T *restrict cost, int32_t *restrict rowsol, int32_t *restrict colsol,
                         T *restrict u, T *restrict v, double *total_f64, T *total_T, jv_wide_stats *st,
                         int64_t max_rounds, int stop_phase) {
@@ -299,8 +331,10 @@ int FN(jv_oracle_wide_)(int n, const T *restrict cost, int32_t *restrict rowsol,
     T *d = (T *)malloc(N * sizeof(T));
     T *bidp = (T *)malloc(N * sizeof(T));
     T *margin = (T *)malloc(N * sizeof(T));
+    int32_t *alist = (int32_t *)malloc(N * sizeof(int32_t)), *abj = (int32_t *)malloc(N * sizeof(int32_t));
+    T *abp = (T *)malloc(N * sizeof(T));
     int rc = JV_OK;
-    if (!freerows || !matches || !pred || !imin || !bidrow || !touched || !kk || !scanned || !active || !d || !bidp || !margin) { rc = JV_ERR_NOMEM; goto done; }
+    if (!freerows || !matches || !pred || !imin || !bidrow || !touched || !kk || !scanned || !active || !d || !bidp || !margin || !alist || !abj || !abp) { rc = JV_ERR_NOMEM; goto done; }
 
     /* ---- COLUMN REDUCTION (identical to the classic mode) ---- */
     for (int j = 0; j < n; j++) { v[j] = cost[j]; imin[j] = 0; }
@@ -315,6 +349,28 @@ int FN(jv_oracle_wide_)(int n, const T *restrict cost, int32_t *restrict rowsol,
         if (++matches[i] == 1) { rowsol[i] = j; colsol[j] = i; }
         else colsol[j] = -1;
     }
+
+    /* ---- the scale of the instance, taken at the post-column-reduction prices: the median binary exponent of the rows' gaps
+     * u2 - u1 (lexicographic top-2 of c[i][.] - v0[.]; bin = the exponent FIELD of the gap, 0 for a zero or subnormal gap: integer
+     * counts, no visiting order), and the largest |v0[j]| ---- */
+    int gap_exp = 0;
+    T vmax = 0;
+    if (n > 1) {
+        int64_t *hist = (int64_t *)calloc(JV_T_EXPMAX + 1, sizeof(int64_t));
+        if (!hist) { rc = JV_ERR_NOMEM; goto done; }
+        _Pragma("omp parallel for schedule(dynamic, 16)")
+        for (int i = 0; i < n; i++) {
+            T umin, usub; int j1, j2;
+            FN(top2_)(n, cost + (size_t)i * N, v, &umin, &j1, &usub, &j2);
+            abj[i] = FN(expfield_)(usub - umin);
+        }
+        for (int i = 0; i < n; i++) hist[abj[i]]++;
+        int64_t cum = 0;
+        for (int e = 0; e <= JV_T_EXPMAX; e++) { cum += hist[e]; if (cum * 2 >= n) { gap_exp = e; break; } }
+        free(hist);
+        for (int j = 0; j < n; j++) { const T a = v[j] < 0 ? -v[j] : v[j]; if (a > vmax) vmax = a; }
+    }
+    s.gap_exp = gap_exp;
 
     /* ---- REDUCTION TRANSFER, Jacobi ---- */
     for (int i = 0; i < n; i++) {
@@ -337,35 +393,98 @@ int FN(jv_oracle_wide_)(int n, const T *restrict cost, int32_t *restrict rowsol,
     s.free_after_colred = nact;
     if (stop_phase == 1) goto finish;
 
-    /* ---- AUGMENTING ROW REDUCTION, Jacobi rounds ---- */
+    /* ---- AUGMENTING ROW REDUCTION: Jacobi rounds, eps-scaled when the instance asks for it (see the header of this mode) ---- */
     for (int j = 0; j < n; j++) bidrow[j] = -1;
-    while (nact > 0 && s.arr_rounds < max_rounds) {
-        int ntouched = 0;
-        for (int i = 0; i < n; i++) {
-            if (!active[i]) continue;
-            T umin, usub; int j1, j2;
-            FN(top2_)(n, cost + (size_t)i * N, v, &umin, &j1, &usub, &j2);
-            s.scans_arr++;
-            const T p = v[j1] - (usub - umin);
-            int jt = -1; T pt = 0;
-            if (p < v[j1]) { jt = j1; pt = p; }
-            else if (colsol[j1] < 0) { jt = j1; pt = v[j1]; }
-            else if (j2 >= 0 && usub == umin && colsol[j2] < 0) { jt = j2; pt = v[j2]; }
-            else { active[i] = 0; s.arr_retired++; }
-            if (jt >= 0) {
-                if (bidrow[jt] < 0) { touched[ntouched++] = jt; bidrow[jt] = i; bidp[jt] = pt; }
-                else if (pt < bidp[jt]) { bidrow[jt] = i; bidp[jt] = pt; }      /* rows ascend: an equal price keeps the lower row */
+    {
+        int64_t total = 0, rip = 0;
+        int scaled = 0;
+        /* a round (eps == 0: the claim / retire rules; eps > 0: every bid lowers its column's price by gap + eps, at least one ulp) */
+#define JV_WIDE_ROUND(EPS)                                                                                                 \
+        do {                                                                                                               \
+            const T eps_ = (EPS);                                                                                          \
+            int na_ = 0;                                                                                                   \
+            for (int i = 0; i < n; i++) if (active[i]) alist[na_++] = i;                                                   \
+            _Pragma("omp parallel for schedule(dynamic, 16)")                                                              \
+            for (int t = 0; t < na_; t++) {                                                                                \
+                const int i = alist[t];                                                                                    \
+                T umin, usub; int j1, j2;                                                                                  \
+                FN(top2_)(n, cost + (size_t)i * N, v, &umin, &j1, &usub, &j2);                                             \
+                int jt = -1; T pt = 0;                                                                                     \
+                if (eps_ > 0) {                                                                                            \
+                    T p = v[j1] - ((usub - umin) + eps_);                                                                  \
+                    if (!(p < v[j1])) p = FN(pred_)(v[j1]);                                                                \
+                    jt = j1; pt = p;                                                                                       \
+                } else {                                                                                                   \
+                    const T p = v[j1] - (usub - umin);                                                                     \
+                    if (p < v[j1]) { jt = j1; pt = p; }                                                                    \
+                    else if (colsol[j1] < 0) { jt = j1; pt = v[j1]; }                                                      \
+                    else if (j2 >= 0 && usub == umin && colsol[j2] < 0) { jt = j2; pt = v[j2]; }                           \
+                }                                                                                                          \
+                abj[t] = jt; abp[t] = pt;                                                                                  \
+            }                                                                                                              \
+            int ntouched = 0;                                                                                              \
+            for (int t = 0; t < na_; t++) {                                                                                \
+                const int i = alist[t], jt = abj[t]; const T pt = abp[t];                                                  \
+                if (jt < 0) { active[i] = 0; s.arr_retired++; continue; }                                                  \
+                if (bidrow[jt] < 0) { touched[ntouched++] = jt; bidrow[jt] = i; bidp[jt] = pt; }                           \
+                else if (pt < bidp[jt]) { bidrow[jt] = i; bidp[jt] = pt; }   /* rows ascend: an equal price keeps the lower row */ \
+            }                                                                                                              \
+            for (int t = 0; t < ntouched; t++) {                                                                           \
+                const int j = touched[t], w = bidrow[j], i0 = colsol[j];                                                   \
+                v[j] = bidp[j]; colsol[j] = w; rowsol[w] = j; active[w] = 0;                                               \
+                if (i0 >= 0) { rowsol[i0] = -1; active[i0] = 1; }                                                          \
+                bidrow[j] = -1;                                                                                            \
+            }                                                                                                              \
+            s.scans_arr += na_;                                                                                            \
+            nact = 0;                                                                                                      \
+            for (int i = 0; i < n; i++) nact += active[i];                                                                 \
+            total++; rip++;                                                                                                \
+        } while (0)
+#define JV_WIDE_RESET()                                                                                                    \
+        do {                                                                                                               \
+            for (int i = 0; i < n; i++) { rowsol[i] = -1; active[i] = 1; }                                                 \
+            for (int j = 0; j < n; j++) colsol[j] = -1;                                                                    \
+            nact = n; rip = 0;                                                                                             \
+        } while (0)
+
+        /* the phase machine.  LEGACY: the eps = 0 rounds from the column reduction's state; after JV_WIDE_K0 of them an instance whose
+         * list of active rows is still long (no ties to retire on, no end in sight: the price wars of generic costs) switches to the
+         * scaled phases, any other one goes on until nobody is active.  EPS (phase k): every row unassigned, prices kept, rounds with
+         * eps_k until the list is short.  FINAL: the same with eps = 0 and the claim / retire rules. */
+        enum { M_LEGACY, M_EPS, M_FINAL } mode = M_LEGACY;
+        int k = 0;
+        T eps = 0;
+        const int e0 = gap_exp > 0 ? (gap_exp + JV_WIDE_EMULT > JV_T_EXPMAX - 1 ? JV_T_EXPMAX - 1 : gap_exp + JV_WIDE_EMULT) : 0;
+        const T epsmin = vmax * JV_T_ULP1;                               /* below the resolution of the prices: no such phase */
+        for (;;) {
+            /* the budget of rounds ends the LEGACY rounds and the scaled phases -- never the FINAL phase: the assignments a
+             * scaled phase leaves satisfy eps-complementary slackness only, the augmentation needs the eps = 0 phase's */
+            const int over = total >= max_rounds;
+            int next_phase = 0, last = 0;
+            if (mode == M_LEGACY) {
+                if (over || nact == 0) break;
+                if (rip == JV_WIDE_K0 && nact > JV_WIDE_STOP(n) && e0 > 0) { next_phase = 1; k = -1; }
+            } else if (mode == M_EPS) {
+                if (over) { next_phase = 1; last = 1; }
+                else if (rip >= 1 && (nact <= JV_WIDE_STOP(n) || rip >= JV_WIDE_PHCAP)) next_phase = 1;
+            } else if (rip >= 1 && (nact <= JV_WIDE_STOP(n) || rip >= JV_WIDE_PHCAP)) break;
+            if (next_phase) {
+                k++;
+                const int ek = e0 - JV_WIDE_ESTEP * k;
+                eps = (!last && k < JV_WIDE_NPH && ek >= 1) ? FN(pow2_)(ek) : (T)0;
+                if (eps < epsmin) eps = 0;
+                mode = eps > 0 ? M_EPS : M_FINAL;
+                JV_WIDE_RESET();
+                s.arr_phases++;
+                scaled = 1;
+                continue;
             }
+            JV_WIDE_ROUND(mode == M_EPS ? eps : (T)0);
         }
-        for (int t = 0; t < ntouched; t++) {
-            const int j = touched[t], w = bidrow[j], i0 = colsol[j];
-            v[j] = bidp[j]; colsol[j] = w; rowsol[w] = j; active[w] = 0;
-            if (i0 >= 0) { rowsol[i0] = -1; active[i0] = 1; }
-            bidrow[j] = -1;
-        }
-        nact = 0;
-        for (int i = 0; i < n; i++) nact += active[i];
-        s.arr_rounds++;
+        s.arr_rounds = total;
+        s.arr_scaled = scaled;
+#undef JV_WIDE_ROUND
+#undef JV_WIDE_RESET
     }
     s.arr_active_left = nact;
     {
@@ -457,7 +576,7 @@ finish:
     if (st) *st = s;
 done:
     free(freerows); free(matches); free(pred); free(imin); free(bidrow); free(touched); free(kk); free(scanned); free(active);
-    free(d); free(bidp); free(margin);
+    free(d); free(bidp); free(margin); free(alist); free(abj); free(abp);
     return rc;
 }
 

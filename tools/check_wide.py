@@ -31,10 +31,10 @@ def one(c, label, rounds=0, rowmap=None, uniq=None):
     st = o["stats"]
     cnt = (inf.scans_arr == st.scans_arr, inf.free_after_arr2 == st.free_after_arr, inf.scans_aug_relax == st.scans_aug_relax,
            inf.path_hops == st.path_hops, inf.wide_rounds == st.arr_rounds, inf.wide_retired == st.arr_retired,
-           inf.scans_redtransfer == st.scans_redtransfer)
+           inf.scans_redtransfer == st.scans_redtransfer, inf.wide_scaled == st.arr_scaled, inf.wide_phases == st.arr_phases)
     ok = all(same) and all(cnt) and abs(g["total"] - o["total"]) <= 1e-6 * max(1.0, abs(o["total"]))
     print(f"{label:12s} n={len(c):6d} rounds={rounds:5d} {'OK ' if ok else 'BAD'} same(r,c,u,v)={same} counters={cnt} "
-          f"free={inf.free_after_arr2} arr_rounds={inf.wide_rounds} relax={inf.scans_aug_relax} settled={inf.wide_aug_settled} "
+          f"free={inf.free_after_arr2} scaled={inf.wide_scaled}/{inf.wide_phases} arr_rounds={inf.wide_rounds} relax={inf.scans_aug_relax} settled={inf.wide_aug_settled} "
           f"aug_rounds={inf.wide_aug_rounds} dense(arr,aug)=({inf.wide_dense_arr},{inf.wide_dense_aug}) trivial={inf.wide_trivial} "
           f"ms: arr={inf.ms_arr:.2f} aug={inf.ms_aug:.2f} cache={inf.ms_cache:.2f} colred={inf.ms_colred:.2f} | oracle {to:.2f}s gpu-call {tg:.2f}s",
           flush=True)
