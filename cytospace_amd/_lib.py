@@ -48,7 +48,8 @@ class LapInfo(ctypes.Structure):
 class LapOpts(ctypes.Structure):
     """cyto_lap_opts (include/cytohip.h): kernel-selection options; results never depend on them."""
     _fields_ = [("chain_variant", ctypes.c_int32), ("augmentation", ctypes.c_int32), ("no_handover", ctypes.c_int32),
-                ("inject_exceptions", ctypes.c_int32), ("group_state_global", ctypes.c_int32), ("aux_state_global", ctypes.c_int32), ("mode", ctypes.c_int32), ("wide_rounds", ctypes.c_int32), ("wide_groups", ctypes.c_int32), ("wide_rebuild", ctypes.c_int32)]
+                ("inject_exceptions", ctypes.c_int32), ("group_state_global", ctypes.c_int32), ("aux_state_global", ctypes.c_int32), ("mode", ctypes.c_int32), ("wide_rounds", ctypes.c_int32), ("wide_groups", ctypes.c_int32), ("wide_rebuild", ctypes.c_int32),
+                ("wide_wipe", ctypes.c_int32)]
 
 
 class AssignInfo(ctypes.Structure):

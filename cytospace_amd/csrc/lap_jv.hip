@@ -2934,14 +2934,15 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(const LazyArgs *__restrict
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-static const cyto_lap_opts k_default_opts = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static const cyto_lap_opts k_default_opts = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 static int check_opts(const cyto_lap_opts &o) {
     if (o.chain_variant < 0 || o.chain_variant > 3 || o.augmentation < 0 || o.augmentation > 2 || o.inject_exceptions < 0 ||
         o.no_handover < 0 || o.no_handover > 1)
         return CYTO_ERR_BAD_ARG;
     if (o.group_state_global < 0 || o.group_state_global > 1 || o.aux_state_global < 0 || o.aux_state_global > 1) return CYTO_ERR_BAD_ARG;
-    if (o.mode < 0 || o.mode > 2 || o.wide_rounds < -1 || o.wide_groups < -1 || o.wide_groups > 32 || o.wide_rebuild < -1) return CYTO_ERR_BAD_ARG;
+    if (o.mode < 0 || o.mode > 2 || o.wide_rounds < -1 || o.wide_groups < -1 || o.wide_groups > 32 || o.wide_rebuild < -1 ||
+        o.wide_wipe < 0 || o.wide_wipe > 2048) return CYTO_ERR_BAD_ARG;
     return CYTO_OK;
 }
 
@@ -2968,7 +2969,7 @@ struct F32Plan {            // what depends on n (and the options) only: identic
     int n, colblocks, rowblocks, rows_per_block, cache_grid;
     bool force_l2, lds_variant, lazy, lz_lds_state, lz_cs_lds, no_cs_lds, wide;
     long long wide_rounds;
-    int wide_groups, wide_rebuild;
+    int wide_groups, wide_rebuild, wide_wipe;
     size_t shm_chain, lz_base_shm;
 };
 
@@ -3082,7 +3083,7 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
         for (int pass = 0;; pass++) {                              // the row-reduction rounds (they pause when the caches have gone stale)
             if (pass && (rc = build_caches(h_sync.data() + 1))) return rc;
             CYTO_HIP(hipMemsetAsync(d_sync.p, 0, sizeof(int32_t), stream));
-            if ((rc = wide_launch_arr(d_wa.as<WideArgs>(), nl, n, stream, pl.wide_rounds, pass > 0, d_sync.as<int32_t>(), rebuild_tramp, &build_caches))) return rc;
+            if ((rc = wide_launch_arr(d_wa.as<WideArgs>(), nl, n, stream, pl.wide_wipe, pass > 0, d_sync.as<int32_t>(), rebuild_tramp, &build_caches))) return rc;
             if (h_wa[0].aug_seg != 0) break;                       // (no pauses asked for: nothing to wait for)
             CYTO_HIP(hipMemcpyAsync(h_sync.data(), d_sync.p, sizeof(int32_t) * ((size_t)nl + 1), hipMemcpyDeviceToHost, stream));
             CYTO_HIP(hipStreamSynchronize(stream));
@@ -3189,6 +3190,7 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
     pl.wide_rounds = opts.wide_rounds < 0 ? 0 : (opts.wide_rounds > 0 ? opts.wide_rounds : 4096 + (long long)n / 4);
     pl.wide_groups = opts.wide_groups;
     pl.wide_rebuild = opts.wide_rebuild;
+    pl.wide_wipe = opts.wide_wipe;
     pl.force_l2 = opts.chain_variant != 0;
     pl.no_cs_lds = opts.chain_variant == 3;            // (3: as 2, with colsol in global memory too -- what n > 65 535 uses)
     pl.lds_variant = !pl.force_l2 && n <= 13 * per2;

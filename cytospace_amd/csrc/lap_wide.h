@@ -48,7 +48,7 @@ constexpr size_t WIDE_SC_BYTES = 2048;
 size_t wide_aug_lds_bytes(int n);
 // phases, each one launch for the whole batch (d_args: device array of nb WideArgs)
 int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream);        // Jacobi reduction transfer (v0 snapshot in cassign)
-int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, long long max_rounds, bool resume, int32_t *d_sync,
+int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, int wipe_every, bool resume, int32_t *d_sync,
                     int (*rebuild)(void *ctx, const int32_t *flags), void *ctx);   // rebuild: fresh row caches for the flagged problems   // Jacobi rounds of augmenting row reduction + free list
 int wide_launch_aug(const WideArgs *d_args, int nb, int n, hipStream_t stream, int mc_groups);   // succ-clamped shortest-path augmentation, duals, total
 int wide_mc_groups(int nb, int n);                                                     // how many workgroups search one problem together (0: one)

@@ -123,7 +123,7 @@ struct ScCtl {
 };
 static_assert(sizeof(ScCtl) <= 2048, "control block of the row-reduction phase");
 // the constants of the restatement (oracle/jv_oracle.h: JV_WIDE_*)
-constexpr int SC_K0 = 8, SC_NPH = 10, SC_PHCAP = 1024, SC_EMULT = 5, SC_ESTEP = 2;
+constexpr int SC_K0 = 8, SC_NPH = 16, SC_PHCAP = 1024, SC_EMULT = 3, SC_ESTEP = 1;
 __host__ __device__ inline int wide_stop(int n) { return n / 128 < 8 ? 8 : (n / 128 > 64 ? 64 : n / 128); }
 // the next representable value below x (+0 and -0 are one value): oracle pred_
 __device__ __forceinline__ float pred_f32(float x) {
@@ -355,7 +355,7 @@ template <bool VLDS, bool CLDS> struct ArrCtx {
 //   LEGACY   eps = 0 rounds from the column reduction's state (claims, retirements).  After SC_K0 of them an instance whose active
 //            list is still longer than wide_stop(n) -- generic costs: no ties to retire on, price wars without end -- SCALES; any
 //            other one goes on until its list is short (<= 64 rows: the chain rounds of wide_arr take over) or empty.
-//   EPS      phase k: every row unassigned, prices kept; rounds with eps_k = eps_0 / 4^k (every bid lowers its column's price by the
+//   EPS      phase k: every row unassigned, prices kept; rounds with eps_k = eps_0 / 2^k (every bid lowers its column's price by the
 //            gap + eps_k) until the list is down to wide_stop(n) rows -- the sequential tail of a phase is cut, the next phase
 //            takes every row up again.  eps_0 = 2^SC_EMULT x the median binade of the rows' gaps at the post-column-reduction prices.
 //   FINAL    the same with eps = 0 and the claim / retire rules: what it leaves free goes to the searches.
@@ -366,13 +366,163 @@ template <bool VLDS, bool CLDS> struct ArrCtx {
 // The bid word of a column: | 12 bits ~(round - base) | 32 bits ordered price | 20 bits row |, merged with an atomic min: within a
 // round the lowest (price, row) wins, and ANY bid of a later round beats what earlier rounds left behind -- the words are never reset
 // between rounds; wide_sc_wipe (every 2048 pairs) resets them and moves `base`.
+constexpr int HEADB = 256;             // threads of the machine's workgroups
+// ---- the machine's bids.  A row whose cache certifies its top-2 is one wave's work (the chain of a bid is L2 round trips: what
+// counts is how many bids are in flight, so a wave per bid while the chip has room).  A row whose cache cannot certify is read in
+// full -- by the WHOLE workgroup, after the wave's certified bids of the iteration: one wave sweeping an 80 KB row three times
+// (wide_arr's top2_full) is 170 us, and the round waits for its slowest bid.  Prices and owners do not change while the bids of
+// a round are made (the resolution is the next launch): plain loads, 16 bytes of the row and of the prices per lane and step.
+struct Top2 { float u1, c1, vj1, u2, c2, vj2; int j1, j2; };
+struct ScShared {
+    int nq, cnt, fill_;
+    uint32_t cand;
+    int qrow[HEADB / 64], qslot[HEADB / 64];
+    unsigned long long km1[HEADB / 64], km2[HEADB / 64];
+    uint32_t lmin[HEADB];
+    uint32_t ccol[KC];
+    float cval[KC];
+};
+constexpr size_t SC_SHARED_BYTES = (sizeof(ScShared) + 15) / 16 * 16;
+
+// the decision of a bid from its row's lexicographic top-2 (oracle: JV_WIDE_ROUND): target column (-1: the row retires), price, raw cost
+// of the entry, the owner it would displace.  eps > 0 (a scaled phase): every bid lowers its column's price by the gap + eps, by one
+// ulp at least -- no claims, nobody retires
+__device__ __forceinline__ void sc_decide(const WideArgs &a, const Top2 &t, float eps, int &jt, float &pt, float &ct, int &i0) {
+    jt = -1; pt = 0.0f; ct = 0.0f; i0 = -1;
+    const int o1 = uni(a.colsol[t.j1]);
+    if (eps > 0.0f) {
+        float p = t.vj1 - ((t.u2 - t.u1) + eps);
+        if (!(p < t.vj1)) p = pred_f32(t.vj1);
+        jt = t.j1; pt = p; ct = t.c1; i0 = o1;
+    } else {
+        const float p = t.vj1 - (t.u2 - t.u1);
+        if (p < t.vj1) { jt = t.j1; pt = p; ct = t.c1; i0 = o1; }
+        else if (o1 < 0) { jt = t.j1; pt = t.vj1; ct = t.c1; }
+        else if (t.j2 >= 0 && t.u2 == t.u1 && uni(a.colsol[t.j2]) < 0) { jt = t.j2; pt = t.vj2; ct = t.c2; }
+    }
+    jt = uni(jt); pt = uni(pt); ct = uni(ct); i0 = uni(i0);
+}
+// one wave: the top-2 from the row's cache (lane = entry); false: the cache cannot certify it
+__device__ __forceinline__ bool sc_top2_cached(const WideArgs &a, int lane, uint32_t col, float val, Top2 &t) {
+    const float tau = rdlane(val, KCU);
+    const bool valid = lane < KCU && col != COLSENT;
+    const float vj = valid ? a.v[col] : 0.0f;
+    const uint32_t key = valid ? f2ord(val - vj) : 0xFFFFFFFFu;
+    const uint32_t k1 = wave_min_u32(key);
+    const int l1 = __ffsll((unsigned long long)__ballot(key == k1)) - 1;
+    const uint32_t key2 = lane == l1 ? 0xFFFFFFFFu : key;
+    const uint32_t k2 = wave_min_u32(key2);
+    if (!(k2 != 0xFFFFFFFFu && ord2f(k2) < tau)) return false;
+    const int l2 = __ffsll((unsigned long long)__ballot(key2 == k2)) - 1;
+    t.u1 = ord2f(k1); t.j1 = (int)rdlane(col, l1); t.c1 = rdlane(val, l1); t.vj1 = rdlane(vj, l1);
+    t.u2 = ord2f(k2); t.j2 = (int)rdlane(col, l2); t.c2 = rdlane(val, l2); t.vj2 = rdlane(vj, l2);
+    return true;
+}
+// the whole workgroup (HEADB threads): f(column, cost, price) for every column of the row, 16 bytes of row and prices per lane and step
+template <typename F> __device__ __forceinline__ void block_row_sweep(const float *__restrict__ row, const float *__restrict__ v, int n, F &&f) {
+    constexpr int U = 4;
+    const int nq = (n + 3) >> 2;
+    const float4 *__restrict__ r4 = reinterpret_cast<const float4 *>(row);
+    const float4 *__restrict__ v4 = reinterpret_cast<const float4 *>(v);      // (16-byte aligned, followed by u in the workspace: whole quads stay in range)
+    for (int q0 = threadIdx.x; q0 < nq; q0 += HEADB * U) {
+        float4 x[U], p[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int q = q0 + HEADB * u;
+            x[u] = q < nq ? r4[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            p[u] = q < nq ? v4[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int q = q0 + HEADB * u, c = q * 4;
+            if (q >= nq) continue;
+            f(c, x[u].x, p[u].x);
+            if (c + 1 < n) f(c + 1, x[u].y, p[u].y);
+            if (c + 2 < n) f(c + 2, x[u].z, p[u].z);
+            if (c + 3 < n) f(c + 3, x[u].w, p[u].w);
+        }
+    }
+}
+// the whole workgroup: exact lexicographic top-2 of row i -- and a fresh cache for it against the current prices (floor = one of the 64
+// minima of the columns c with (c / 4) % 64 == l, sorted: the 48th, else the 24th, 12th ... smallest; the columns below it are collected in
+// a second sweep of the now L2-resident row; more than 63 of them -> the next candidate).  Every thread returns the same Top2.
+__device__ __forceinline__ Top2 sc_top2_block(const WideArgs &a, ScShared &ss, int i) {
+    const int n = a.n, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float *__restrict__ row = a.cost + wrow_off(a.rowmap, i, a.ld);
+    K2 d; d.m1 = KEYMAX; d.m2 = KEYMAX;
+    block_row_sweep(row, a.v, n, [&](int c, float x, float vc) { k2_push(d, mkkey(x - vc, (uint32_t)c)); });
+    ss.lmin[tid] = (uint32_t)(d.m1 >> 32);
+    d = k2_wave_allreduce(d);
+    if (lane == 0) { ss.km1[w] = d.m1; ss.km2[w] = d.m2; }
+    __syncthreads();
+    K2 g; g.m1 = ss.km1[0]; g.m2 = ss.km2[0];
+#pragma unroll
+    for (int k = 1; k < HEADB / 64; k++) { K2 o; o.m1 = ss.km1[k]; o.m2 = ss.km2[k]; k2_merge(g, o); }
+    Top2 t;
+    t.u1 = key_val(g.m1); t.j1 = (int)(uint32_t)g.m1; t.c1 = row[t.j1]; t.vj1 = a.v[t.j1];
+    t.u2 = INFINITY; t.j2 = -1; t.c2 = 0.0f; t.vj2 = 0.0f;
+    if (g.m2 != KEYMAX) { t.u2 = key_val(g.m2); t.j2 = (int)(uint32_t)g.m2; t.c2 = row[t.j2]; t.vj2 = a.v[t.j2]; }
+    // ---- the row's new cache ----
+    uint32_t lm = 0xFFFFFFFFu;
+    if (w == 0) {
+#pragma unroll
+        for (int k = 0; k < HEADB / 64; k++) lm = umin32(lm, ss.lmin[k * 64 + lane]);
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {                       // bitonic sort of the 64 minima, ascending over the lanes
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)lm, j);
+                const bool take_min = ((lane & j) == 0) == ((lane & k) == 0);
+                lm = take_min ? umin32(lm, o) : (lm > o ? lm : o);
+            }
+        }
+    }
+    uint32_t tk = 0;                                               // ordered floor; 0 = none found
+    int cnt = 0;
+    for (int pos = 47; pos >= 2 && !tk; pos = (pos + 1) / 2 - 1) {
+        if (w == 0 && lane == 0) { ss.cand = rdlane(lm, pos); ss.cnt = 0; }
+        __syncthreads();
+        const uint32_t cand = ss.cand;
+        if (cand != 0xFFFFFFFFu)
+            block_row_sweep(row, a.v, n, [&](int c, float x, float vc) {
+                if (f2ord(x - vc) < cand) {
+                    const int p = atomicAdd(&ss.cnt, 1);
+                    if (p < KCU) { ss.ccol[p] = (uint32_t)c; ss.cval[p] = x; }
+                }
+            });
+        __syncthreads();
+        cnt = ss.cnt;
+        if (cand != 0xFFFFFFFFu && cnt <= KCU) tk = cand;
+        __syncthreads();                                           // (everybody has read the count before the next candidate resets it)
+    }
+    if (w == 0) {
+        const float tau = tk ? ord2f(tk) : -INFINITY;
+        uint32_t kc = (tk && lane < cnt) ? ss.ccol[lane] : COLSENT;
+        float kv = (tk && lane < cnt) ? ss.cval[lane] : 0.0f;
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {                       // cache rows are kept sorted by column (unused slots last)
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const uint32_t pk = (uint32_t)__shfl_xor((int)kc, j);
+                const float pv = __shfl_xor(kv, j);
+                const bool take_min = ((lane & j) == 0) == ((lane & k) == 0);
+                const bool sw = take_min ? (pk < kc) : (pk > kc);
+                kc = sw ? pk : kc; kv = sw ? pv : kv;
+            }
+        }
+        if (lane == KCU) { kc = COLSENT; kv = tau; }               // (at most 63 entries: lane 63 held a sentinel)
+        a.cache_col[(int64_t)i * KC + lane] = kc;
+        a.cache_val[(int64_t)i * KC + lane] = kv;
+    }
+    return t;
+}
+
 __device__ __forceinline__ unsigned long long bidkey(long long round, float price, int row) {
     return ((unsigned long long)(~(uint32_t)round & 0xFFFu) << 52) | ((unsigned long long)f2ord(price) << 20) | (uint32_t)row;
 }
 __device__ __forceinline__ bool bid_won(unsigned long long word, int row) { return (int)((uint32_t)word & 0xFFFFFu) == row; }
 
 struct ArrHead { int cnt[2]; int started, free_cr; long long round, bids; int retired, dense; int done, launches; long long list_rounds; int no_more, pad_; };
-constexpr int HEADB = 256;             // threads of the machine's workgroups
 
 __device__ __forceinline__ float sc_eps_of(const ScCtl *sc, int k) {       // eps of phase k, 0 = there is no such phase
     if (k >= SC_NPH) return 0.0f;
@@ -435,10 +585,7 @@ __global__ __launch_bounds__(HEADB) void wide_sc_init(const WideArgs *__restrict
 
 __global__ __launch_bounds__(HEADB) void wide_sc_bid(const WideArgs *__restrict__ batch, int L) {
     extern __shared__ __align__(16) unsigned char w_smem[];
-    ArrShared &s = *reinterpret_cast<ArrShared *>(w_smem);
-    ArrCtx<false, false> cx;
-    cx.a = load_wide_args(batch, blockIdx.y);
-    const WideArgs &a = cx.a;
+    const WideArgs a = load_wide_args(batch, blockIdx.y);
     ScCtl *sc = reinterpret_cast<ScCtl *>(a.sc);
     const ScSlot S = sc->slot[L & 1];
     if (S.mode >= SC_HANDOVER) {                                 // through: the state stays (both slots)
@@ -461,26 +608,46 @@ __global__ __launch_bounds__(HEADB) void wide_sc_bid(const WideArgs *__restrict_
     }
     if (N.act != SC_ACT_ROUND) return;
     const int lane = threadIdx.x & 63, w = uni((int)(threadIdx.x >> 6));
-    cx.s_v = nullptr; cx.s_cs = nullptr; cx.s = &s; cx.lane = lane;
-    if (threadIdx.x == 0) { s.retired = 0; s.dense = 0; }
+    ScShared &ss = *reinterpret_cast<ScShared *>(w_smem);
+    if (threadIdx.x == 0) { ss.nq = 0; ss.fill_ = 0; }
     __syncthreads();
     const long long tag = S.total - (long long)sc->base;
     const float eps = S.eps;
-    const int gw = blockIdx.x * (HEADB / 64) + w, nw = gridDim.x * (HEADB / 64);
-    for (int slot = gw; slot < na; slot += nw) {
-        const int i = uni(A[slot]);
-        uint32_t col = a.cache_col[(int64_t)i * KC + lane];
-        float val = a.cache_val[(int64_t)i * KC + lane];
+    int retired = 0, dense = 0;                                   // (lane 0 of every wave)
+    auto record = [&](int slot, int i, const Top2 &t) {
         int jt, i0; float pt, ct;
-        cx.bid_of(i, w, col, val, jt, pt, ct, i0, eps);
+        sc_decide(a, t, eps, jt, pt, ct, i0);
         if (lane == 0) {
-            if (jt < 0) atomicAdd(&s.retired, 1);
+            if (jt < 0) retired++;
             else atomicMin(a.bid + jt, bidkey(tag, pt, i));
             a.slot_j[slot] = jt; a.slot_p[slot] = pt; a.slot_c[slot] = ct;
         }
+    };
+    const int per = (int)gridDim.x * (HEADB / 64);
+    for (int base = (int)blockIdx.x * (HEADB / 64); base < na; base += per) {      // (the same trips for every wave of the workgroup)
+        const int slot = base + w;
+        if (slot < na) {
+            const int i = uni(A[slot]);
+            const uint32_t col = a.cache_col[(int64_t)i * KC + lane];
+            const float val = a.cache_val[(int64_t)i * KC + lane];
+            Top2 t;
+            if (sc_top2_cached(a, lane, col, val, t)) record(slot, i, t);
+            else if (lane == 0) { const int q = atomicAdd(&ss.nq, 1); ss.qrow[q] = i; ss.qslot[q] = slot; }
+        }
+        __syncthreads();
+        const int nq = ss.nq;
+        __syncthreads();
+        if (nq) {                                                  // rows whose caches could not certify: the whole workgroup, one after the other
+            if (threadIdx.x == 0) ss.nq = 0;
+            for (int q = 0; q < nq; q++) {
+                const int i = ss.qrow[q], slot = ss.qslot[q];
+                const Top2 t = sc_top2_block(a, ss, i);
+                if (w == 0) { record(slot, i, t); dense++; }
+            }
+            __syncthreads();
+        }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) { if (s.retired) atomicAdd(&sc->retired, s.retired); if (s.dense) atomicAdd(&sc->dense, s.dense); }
+    if (lane == 0) { if (retired) atomicAdd(&sc->retired, retired); if (dense) atomicAdd(&sc->dense, dense); }
 }
 
 __global__ __launch_bounds__(HEADB) void wide_sc_resolve(const WideArgs *__restrict__ batch, int L) {
@@ -843,7 +1010,7 @@ size_t wide_aug_lds_bytes(int n) { return wide_aug_lds_bytes(n, wide_aug_vlds(n)
 
 struct AugShared {
     unsigned long long T;          // best unassigned column: (ordered distance << 32 | tight hops << 20 | column)
-    int ntouch, any[3], fail, anydense, rootdense, doroot, f, err;
+    int ntouch, any[3], npk[3], fail, anydense, rootdense, doroot, f, err;
     int waste, stop;               // full-row relaxations of this launch; "return to the driver for fresh caches"
     int nhop;                      // edges of the path being flipped
     int scans;
@@ -894,7 +1061,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
         }
     }
     if (tid == 0) { s.waste = 0; s.stop = 0; }
-    if (tid == 0) { s.T = ~0ull; s.ntouch = 0; s.any[0] = 0; s.any[1] = 0; s.any[2] = 0; s.fail = 0; s.anydense = 0; s.rootdense = 0; s.doroot = 0; s.f = f0; s.err = 0; s.scans = 0; }
+    if (tid == 0) { s.T = ~0ull; s.ntouch = 0; s.any[0] = 0; s.any[1] = 0; s.any[2] = 0; s.npk[0] = 0; s.npk[1] = 0; s.npk[2] = 0; s.fail = 0; s.anydense = 0; s.rootdense = 0; s.doroot = 0; s.f = f0; s.err = 0; s.scans = 0; }
     __syncthreads();
     auto getv = [&](int j) -> float { return VLDS ? s_v[j] : ld_sc1(a.v + j); };
     auto getcs = [&](int j) -> int {
@@ -932,6 +1099,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
 #pragma unroll
     for (int q = 0; q < AP; q++) rb[q] = -1;
     int seg_done = 0;                                            // searches (other than one-edge ones) of this launch
+    int wact = 4;                                                // waves that take part in the next round of a search (4 or all 16)
     bool announced = false;
     for (;;) {
         // ---- wave 0 disposes of the searches that end at once: the free row's best cached column is unassigned and its
@@ -1040,8 +1208,22 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             for (;;) {
                 const unsigned long long Tlv = uni(lv_of(s.T));          // label value of the best unassigned column so far
                 // the two best dirty columns among the wave's blocks (one key per lane: the smallest of the blocks it looks at)
+                // How many waves take part in a round: a round is bound by the CU's instruction issue (16 waves on 4 SIMDs: ~500
+                // instructions each), so while the frontier is narrow -- shallow searches, the first and last rounds of deep ones --
+                // four waves (one per SIMD, eight settlements at most) make a round several times shorter.  Block b belongs to wave
+                // b mod W in this round; which wave settles what is a matter of efficiency only.
+                const int W = wact;
+                if (w >= W && rb[0] < 0 && rb[1] < 0) {              // nothing to pick from, no minimum to rebuild: straight to the barrier
+                    __syncthreads();
+                    const int any0 = uni(s.any[ph]), np0 = uni(s.npk[ph]);
+                    ph = (ph + 1) % 3;
+                    c_rounds++;
+                    wact = np0 > 6 ? WNW : 4;
+                    if (!any0) break;
+                    continue;
+                }
                 unsigned long long mk = ~0ull;
-                for (int b = w + WNW * lane; b < nblk; b += WNW * 64) mk = umin64(mk, bmin[b]);
+                if (w < W) for (int b = w + W * lane; b < nblk; b += W * 64) mk = umin64(mk, bmin[b]);
                 // Which dirty column a wave settles next is a matter of efficiency only (any schedule reaches the same labels), what
                 // must be exact is WHETHER a block holds work: a lane is eligible if its best key is below the best unassigned
                 // column's label; among the eligible lanes the smallest distance goes first (one 32-bit reduction and a ballot per
@@ -1066,7 +1248,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     // (the block's minimum is void from here on; it is rebuilt in the NEXT round, see below)
                     if (pk[q] && lane == 0) { atomicAnd(&dirty[pj[q] >> 5], ~(1u << (pj[q] & 31))); bmin[pj[q] >> 6] = ~0ull; }
                 }
-                if (lane == 0 && (pk[0] || pk[1] || rb[0] >= 0 || rb[1] >= 0)) s.any[ph] = 1;
+                if (lane == 0 && (pk[0] || pk[1] || rb[0] >= 0 || rb[1] >= 0)) { s.any[ph] = 1; if (pk[0]) atomicAdd(&s.npk[ph], (int)pk[0] + (int)pk[1]); }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the bits are cleared before the labels are read
                 // Everything the two settlements read is requested in ONE go, without a branch in between: label and owner entry of
                 // both columns, then (the owners come from LDS) both cache rows -- a wave without a pick reads column 0's, harmlessly.
@@ -1187,10 +1369,11 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     rb[q] = pk[q] ? (pj[q] >> 6) : -1;
                 }
                 __syncthreads();
-                const int any = uni(s.any[ph]);
-                if (tid == 0) s.any[(ph + 2) % 3] = 0;             // (last read before this barrier, next set after the next one)
+                const int any = uni(s.any[ph]), np = uni(s.npk[ph]);
+                if (tid == 0) { s.any[(ph + 2) % 3] = 0; s.npk[(ph + 2) % 3] = 0; }   // (last read before this barrier, next set after the next one)
                 ph = (ph + 1) % 3;
                 c_rounds++;
+                wact = np > 6 ? WNW : 4;
                 if (!any) break;
             }
             // ================= converged: do the caches certify what was skipped? =================
@@ -1718,13 +1901,13 @@ int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream) {
     return CYTO_OK;
 }
 
-int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, long long max_rounds, bool resume, int32_t *d_sync,
+int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, int wipe_every, bool resume, int32_t *d_sync,
                     int (*rebuild)(void *ctx, const int32_t *flags), void *ctx) {
     // The phase machine on the whole chip (two launches per round), in groups of pairs: after a group the driver asks which problems
     // are not through (one small read) and rebuilds the row caches of those whose floors have gone stale; then wide_arr -- one
     // workgroup per problem -- for the chain rounds of the problems that did not scale (<= 64 active rows) and the free lists.
     // resume: wide_arr's chain rounds paused for fresh row caches -- it alone picks them up
-    (void)max_rounds;
+    const int wipe = wipe_every > 0 ? wipe_every : 2048;
     int rc;
     if (n >= 2 && !resume) {
         // a wave per bid while the chip has room for them (a bid is a chain of L2 round trips: what counts is how many are in flight);
@@ -1737,8 +1920,8 @@ int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, l
         int L = 0, group = 32;
         for (;;) {
             for (int g = 0; g < group; g++, L++) {
-                if (L > 0 && (L & 2047) == 0) hipLaunchKernelGGL(wide_sc_wipe, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args, L);
-                hipLaunchKernelGGL(wide_sc_bid, dim3(bx, nb), dim3(HEADB), ARR_SHARED_BYTES, stream, d_args, L);
+                if (L > 0 && L % wipe == 0) hipLaunchKernelGGL(wide_sc_wipe, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args, L);
+                hipLaunchKernelGGL(wide_sc_bid, dim3(bx, nb), dim3(HEADB), SC_SHARED_BYTES, stream, d_args, L);
                 hipLaunchKernelGGL(wide_sc_resolve, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args, L);
             }
             if (!d_sync) return CYTO_ERR_INTERNAL;

@@ -140,6 +140,9 @@ typedef struct {
                                    the prices reached (a floor goes stale as searches lower the prices; deep-search instances otherwise
                                    fall back to full cost rows).  0: when the full-row relaxations since the last rebuild have cost what
                                    a rebuild costs.  -1: never.  k > 0: every k searches.  Results do not depend on it */
+    int32_t wide_wipe;          /* wide solver, row reduction: the per-column bid words carry a 12-bit round tag relative to their last wipe;
+                                   0: wiped every 2048 launch pairs.  k > 0: every k pairs (a self-test of the protocol at sizes the CPU
+                                   oracle checks).  Results do not depend on it */
 } cyto_lap_opts;
 int cyto_lap_f32_opts(int n, const float *cost, int64_t ld, int cost_on_device,
                       int32_t *rowsol, int32_t *colsol, float *u, float *v, double *total,

@@ -47,10 +47,10 @@ typedef struct {
  * binade, eps_k = eps_0 / 2^(ESTEP k) */
 #define JV_WIDE_K0 8
 #define JV_WIDE_STOP(n) ((n) / 128 < 8 ? 8 : ((n) / 128 > 64 ? 64 : (n) / 128))
-#define JV_WIDE_NPH 10
+#define JV_WIDE_NPH 16
 #define JV_WIDE_PHCAP 1024
-#define JV_WIDE_EMULT 5
-#define JV_WIDE_ESTEP 2
+#define JV_WIDE_EMULT 3
+#define JV_WIDE_ESTEP 1
 #define JV_WIDE_KMAX 4095            /* tight hops a label counts before the distance itself is stepped */
 
 int jv_oracle_wide_f32(int n, const float *cost, int32_t *rowsol, int32_t *colsol, float *u, float *v,

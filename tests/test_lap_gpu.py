@@ -20,7 +20,7 @@ WIDE = dict(mode=2)       # the wide solver: order-free restatement, oracle jv_o
 WIDE_KEYS = [("scans_redtransfer", "scans_redtransfer"), ("scans_arr", "scans_arr"), ("scans_aug_init", "scans_aug_init"),
              ("scans_aug_relax", "scans_aug_relax"), ("augmentations", "augmentations"), ("path_hops", "path_hops"),
              ("free_after_colred", "free_after_colred"), ("free_after_arr2", "free_after_arr"), ("wide_rounds", "arr_rounds"),
-             ("wide_retired", "arr_retired")]
+             ("wide_retired", "arr_retired"), ("wide_scaled", "arr_scaled"), ("wide_phases", "arr_phases")]
 
 
 def _check_wide(c, opts=None, rounds=0):
@@ -40,7 +40,9 @@ def _check_wide(c, opts=None, rounds=0):
     return g, o
 
 
-def _check(c, dtype, opts=None):
+def _check(c, dtype, opts=None, unique=False):
+    """unique: the instance has ONE optimal assignment (generic costs), so the two solvers -- different restatements, different
+    duals -- must return the same indices element for element."""
     o = jv_oracle(c, dtype)
     g = lap_solve(c, dtype, return_info=True, opts=dict(CHAIN, **(opts or {})))
     assert np.array_equal(g["rowsol"], o["rowsol"])
@@ -59,6 +61,8 @@ def _check(c, dtype, opts=None):
         # the same instance through the wide solver; both solvers reach the same optimum
         gw, ow = _check_wide(c)
         assert abs(ow["total"] - o["total"]) <= 1e-5 * max(1.0, abs(o["total"]))
+        if unique:
+            assert np.array_equal(gw["colsol"], o["colsol"]) and np.array_equal(gw["rowsol"], o["rowsol"])
         d = lap_solve(c, np.float32, return_info=True)              # what a caller gets by default: the wide solver
         assert d["info"].wide == 1 and all(np.array_equal(d[k], gw[k]) for k in ("rowsol", "colsol", "u", "v"))
 
@@ -67,14 +71,14 @@ def _check(c, dtype, opts=None):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_uniform(n, dtype):
     c = np.random.default_rng(n).random((n, n)).astype(np.float32)
-    _check(c, dtype)
+    _check(c, dtype, unique=True)
 
 
 @pytest.mark.parametrize("n", [4100, 8200, 9000])
 def test_uniform_larger_variants(n):
     # crosses the per-thread column-chunk variants (CH = 2 / 5 for float32)
     c = np.random.default_rng(n).random((n, n)).astype(np.float32)
-    _check(c, np.float32)
+    _check(c, np.float32, unique=True)
 
 
 @pytest.mark.parametrize("n,slots", [(60, 5), (500, 5), (1000, 10), (2000, 4)])
@@ -97,7 +101,7 @@ def test_integer_ties(n):
 def test_negative_and_large_values():
     rng = np.random.default_rng(5)
     c = (rng.standard_normal((300, 300)) * 1e3).astype(np.float32)
-    _check(c, np.float32)
+    _check(c, np.float32, unique=True)
 
 
 def test_nan_rejected():
@@ -403,10 +407,12 @@ def test_duplicate_row_group_state_in_global_memory(aug):
 @pytest.mark.parametrize("rounds", [-1, 1, 3, 40, 600])
 def test_wide_round_budget(rounds):
     # the budget of Jacobi row-reduction rounds cuts the rounds short at the same point in the kernel and in the oracle; the rows
-    # still active go to the augmentation (wide_rounds = -1: no round at all -- every free row is augmented)
+    # still active go to the augmentation (wide_rounds = -1: no round at all -- every free row is augmented).  A budget that ends
+    # inside a SCALED phase still runs the final eps = 0 phase: only its assignments satisfy what the searches need
     c = np.random.default_rng(900 + rounds).random((900, 900)).astype(np.float32)
     g, o = _check_wide(c, rounds=rounds)
-    assert g["info"].wide_rounds <= max(rounds, 0)
+    assert g["info"].wide_rounds <= max(rounds, 0) or g["info"].wide_scaled == 1
+    assert (g["info"].wide_scaled == 1) == (rounds > 8)
     assert np.array_equal(g["colsol"], jv_oracle(c, np.float32)["colsol"])          # a unique optimum: the chain's indices too
 
 
@@ -517,6 +523,56 @@ def test_wide_batch_rebuilds_only_what_is_unfinished():
             assert g["info"].scans_aug_relax == o["stats"].scans_aug_relax and g["info"].path_hops == o["stats"].path_hops
 
 
+@pytest.mark.parametrize("n", [300, 1000, 2500, 4300])
+def test_wide_scaled_row_reduction(n):
+    # generic costs: after eight eps = 0 rounds the active list is still long, the instance goes through the eps-scaled phases
+    # (every row unassigned at each phase's start, prices kept, a phase's sequential tail cut) and a final eps = 0 phase; a
+    # duplicated-row instance never scales (its rows retire on ties at once).  The phase machine runs on the whole chip, two
+    # launches per round: the oracle's state bit for bit
+    rng = np.random.default_rng(n)
+    g, o = _check_wide(rng.random((n, n)).astype(np.float32))
+    assert g["info"].wide_scaled == 1 and g["info"].wide_phases >= 2
+    prof = rng.normal(size=(6, 64)).astype(np.float32)                          # few cell types: many full-row bids in the coarse phases
+    rows = prof[rng.integers(0, 6, n)] + 0.05 * rng.normal(size=(n, 64)).astype(np.float32)
+    cols = prof[rng.integers(0, 6, n)] + 0.05 * rng.normal(size=(n, 64)).astype(np.float32)
+    g, o = _check_wide(-(rows @ cols.T).astype(np.float32))
+    assert g["info"].wide_scaled == 1
+    g, o = _check_wide(np.repeat(rng.random((n // 5, n)), 5, axis=0).astype(np.float32))
+    assert g["info"].wide_scaled == 0
+
+
+@pytest.mark.parametrize("wipe", [1, 3, 50])
+def test_wide_bid_words_wiped_every_few_rounds(wipe):
+    # the per-column bid words carry a 12-bit round tag RELATIVE to their last wipe (a later round's bid beats whatever earlier
+    # rounds left, so the words are never reset between rounds); cyto_lap_opts.wide_wipe moves the wipes from every 2048 launch
+    # pairs to every few: the tags start over again and again in the middle of phases -- same rounds, same answer
+    rng = np.random.default_rng(60 + wipe)
+    for n in (700, 2600):
+        _check_wide(rng.random((n, n)).astype(np.float32), opts=dict(wide_wipe=wipe))
+    _check_wide(np.repeat(rng.random((200, 1000)), 5, axis=0).astype(np.float32), opts=dict(wide_wipe=wipe))
+
+
+@pytest.mark.parametrize("groups", [0, 4])
+def test_wide_more_tight_hops_than_a_label_counts(groups):
+    # a band matrix: row i is cheap on columns i and i + 1 only.  The column reduction gives column j to row j - 1 and leaves row
+    # n - 1 free and column 0 unassigned; with no row-reduction rounds the one search runs n - 1 TIGHT edges in a row (every
+    # reduced cost on the path is exactly 0 past the root's) -- more than the 4095 a label's hop field counts: there the distance is
+    # stepped to the next representable value (edge_lv in lap_wide.hip, JV_WIDE_KMAX in the oracle) and the count starts over
+    n = 6000
+    rng = np.random.default_rng(6)
+    c = (1.0 + rng.random((n, n))).astype(np.float32)
+    i = np.arange(n)
+    c[i, i] = 0.5
+    c[i[:-1], i[:-1] + 1] = 0.5
+    c[n - 1, n - 1] = 0.5 + 2.0 ** -10                     # the root's edge: a distance > 0 that the tight edges keep
+    g, o = _check_wide(c, opts=dict(wide_groups=groups), rounds=-1)
+    assert o["stats"].path_hops == n and g["info"].path_hops == n           # one path through every row
+    assert o["stats"].scans_aug_relax >= 4096
+    u, v = g["u"].astype(np.float64), g["v"].astype(np.float64)
+    red = c.astype(np.float64) - u[:, None] - v[None, :]
+    assert red.min() >= -1e-6 and np.abs(red[i, g["rowsol"]]).max() <= 1e-6      # the stepped distances still give feasible duals
+
+
 def test_one_process_two_devices():
     # kernels that need more than 64 KB of dynamic LDS (prices and owners in LDS) get their per-device attribute on EVERY device a
     # process uses: device 0 first, then device 1 (needs two GPUs)
@@ -535,8 +591,8 @@ def test_one_process_two_devices():
 
 @pytest.mark.parametrize("rounds", [1, 3, 8, 9, 60])
 def test_wide_first_rounds_on_the_whole_chip(rounds):
-    # from n = 4096 on the first eight row-reduction rounds are three full-chip launches each (wide_arr_head_*), the rest runs in
-    # the one-workgroup kernel: the same rounds, so any budget -- inside the head, at its end, beyond -- gives the oracle's state
+    # the rounds with a long active list are two full-chip launches each (the phase machine, wide_sc_*), a short list's rounds run in
+    # the one-workgroup kernel: the same rounds, so any budget -- inside the first eight, at their end, beyond -- gives the oracle's state
     n = 4300
     c = np.random.default_rng(n + rounds).random((n, n)).astype(np.float32)
     _check_wide(c, rounds=rounds)
