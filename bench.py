@@ -5,14 +5,16 @@
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one full solve of BASELINE.json's configs[1]: a 20000 x 20000 dense synthetic float32 cost
-matrix already resident in HBM -> assignment (column reduction, row-cache build, the RT/ARR chain kernel,
-the augmentation kernel).  With N GPUs every rank solves its own, differently seeded, instance of the same size (the
+matrix already resident in HBM -> assignment (column reduction, row-cache build, the row-reduction phase -- reduction
+transfer, then the eps-scaled Jacobi rounds as two whole-chip launches each --, the augmentation kernel).  With N GPUs every rank solves its own, differently seeded, instance of the same size (the
 reference shards independent sub-LAPs across workers: cytospace.py:430-451; no data-path collective),
 so scaling is "weak" and value = N * n / max-over-ranks time.
 
 Besides the headline (`value`, on configs[1]) the same JSON line carries, at N = 1, the other single-GPU
 workloads the north star names (skip them with --no-extras):
-  "c2_batch"  32 copies of the headline instance solved together (one launch per chain phase, a workgroup per problem)
+  "c2_batch"  32 copies of the headline instance solved together (one launch per solver phase for all of them)
+  "c2_cytolike" a 20 000 x 20 000 cost of the few-cell-type ("cytospace-like") generator, slots == 1, against its
+              committed certified golden -- the instance class CytoSPACE's chunks belong to, beside the uniform headline
   "n50000"    the 50 000 x 50 000 uniform LAP (ms, assignments/s, colsol compared with the committed oracle golden)
   "c3"        configs[2] end to end: 20 000 genes x 50 000 cells x 5 000 spots, normalise + standardise, fp32-MFMA cost
               GEMM (its own "roofline" against the 157.3 TFLOP/s f32 matrix peak), LAP; wall time includes the H2D copies
@@ -81,6 +83,54 @@ def extra_n50000(dev):
     return out
 
 
+def extra_c2_cytolike(dev):
+    """SURVEY 8(d)'s "cytospace-like" solver-only instance at configs[1]'s size: 20 000 spots x 20 000 cells of ten cell types
+    (tools/instances.typed_unique_cost, every slot count 1), resident in HBM.  Indices against the committed golden (classic
+    oracle, certified: duals on all n^2 entries, scipy, one-ulp perturbation), duals against the wide restatement's golden."""
+    from cytospace_amd.lap import lap_solve
+    from tools import instances
+    n = 20000
+    t = time.perf_counter()
+    cost, _ = instances.typed_unique_cost(n, n, 20)
+    t_gen = time.perf_counter() - t
+    from cytospace_amd import _lib
+    buf = _lib.DeviceBuffer.from_numpy(cost, dev)
+    lap_solve(None, np.float32, device_id=dev, device_ptr=buf.ptr, n=n, ld=n)          # warm-up
+    walls, r = [], None
+    for _ in range(3):
+        t = time.perf_counter()
+        r = lap_solve(None, np.float32, device_id=dev, return_info=True, device_ptr=buf.ptr, n=n, ld=n)
+        walls.append(time.perf_counter() - t)
+    buf.free()
+    wall = float(np.median(walls))
+    i = r["info"]
+    out = {"workload": f"{n} x {n} few-cell-type cost (typed_unique_cost seed 20, slots == 1) resident in HBM",
+           "ms_per_solve": round(wall * 1e3, 2), "assignments_per_s": round(n / wall, 1),
+           "kernel_ms": {"colred": round(i.ms_colred, 2), "row_caches": round(i.ms_cache, 2), "row_reduction": round(i.ms_arr, 2),
+                         "wide_aug": round(i.ms_aug, 2)},
+           "rounds": int(i.wide_rounds), "phases": int(i.wide_phases), "bids": int(i.scans_arr), "full_row_bids": int(i.wide_dense_arr),
+           "searches": int(i.augmentations), "columns_settled": int(i.scans_aug_relax),
+           "row_scans": int(i.row_scans), "algorithmic_GBs": round(4.0 * n * i.row_scans / wall / 1e9, 1),
+           "hbm_frac_algorithmic": round(4.0 * n * i.row_scans / wall / 1e9 / HBM_PEAK_GBS, 5),
+           "floor_4n2_frac": round(4.0 * n * n / wall / 1e9 / HBM_PEAK_GBS, 6), "instance_seconds": round(t_gen, 1)}
+    gpath = os.path.join(ROOT, "tests", "golden", "large_t20000.npz")
+    if os.path.exists(gpath):
+        d = np.load(gpath)
+        ok = bool(np.array_equal(r["colsol"], d["colsol"]))
+        out["cpu_oracle_seconds_in_the_build_container"] = round(float(d["oracle_seconds"]), 1)
+        wpath = os.path.join(ROOT, "tests", "golden", "large_t20000_wide.npz")
+        if ok and os.path.exists(wpath):
+            dw = np.load(wpath)
+            ok = bool(_sha(r["u"]) == str(dw["u_sha256"]) and _sha(r["v"]) == str(dw["v_sha256"]) and _sha(r["rowsol"]) == str(dw["rowsol_sha256"]))
+            out["duals_bit_exact_vs_wide_oracle_golden"] = ok
+        out["bit_exact_vs_oracle_golden"] = ok
+        if not ok:
+            raise SystemExit("c2_cytolike: HIP result differs from tests/golden/large_t20000[_wide].npz")
+    else:
+        out["bit_exact_vs_oracle_golden"] = None
+    return out
+
+
 def extra_c3(dev):
     """BASELINE configs[2]: 50k cells x 5k spots x 20k genes, fused on one GPU (raw float32 counts in, spots out)."""
     from cytospace_amd.cytospace import assign_pearson
@@ -97,6 +147,54 @@ def extra_c3(dev):
     if not ok:
         raise SystemExit("c3: bincount(mapped) != slots")
     tf = info.gemm_flops / (info.ms_gemm * 1e-3) / 1e12
+    # K1 alone (normalise + standardise: colsum, moments, write) on counts already RESIDENT in HBM -- in the fused call above it
+    # hides behind the PCIe upload.  SURVEY 8(d): bytes = (3 reads + 1 write) x 4 x G x columns
+    from cytospace_amd import _lib
+    k1 = None
+    try:
+        Cb = 16384
+        xb = _lib.DeviceBuffer.from_numpy(np.ascontiguousarray(sc[:, :Cb]), dev)
+        Gpad, ldz = -(-G // 32) * 32, -(-Cb // 128) * 128
+        zb = _lib.DeviceBuffer(Gpad * ldz * 4, dev)
+        L = _lib.lib()
+        for rep in range(3):
+            _lib.check(L.cyto_device_synchronize(dev))
+            t = time.perf_counter()
+            _lib.check(L.cyto_transform(0, G, Cb, xb.ptr, Cb, 0, 1, 0, zb.ptr, ldz, Gpad, dev, None))
+            _lib.check(L.cyto_device_synchronize(dev))
+            dt = time.perf_counter() - t
+        xb.free(); zb.free()
+        k1_bytes = 4.0 * 4 * G * Cb
+        k1 = {"bound": "hbm", "kernel": "K1: colsum_partial + colmoments_partial + standardize_write (+ finishers)", "columns": Cb,
+              "ms": round(dt * 1e3, 3), "algorithmic_bytes": k1_bytes, "achieved": round(k1_bytes / dt / 1e9, 1), "peak": HBM_PEAK_GBS,
+              "unit": "GB/s", "frac": round(k1_bytes / dt / 1e9 / HBM_PEAK_GBS, 4),
+              "note": "wall time of cyto_transform on device-resident float32 counts between two device synchronisations"}
+    except Exception as e:   # noqa: BLE001 (a diagnostic leg must not cost the line)
+        k1 = {"error": f"{type(e).__name__}: {e}"}
+    # CPU beside it: the numpy float64 restatement of normalize_data + matrix_correlation_pearson
+    # + the row gather (oracle/cost.py) on a bounded sample -- every spot against the first 2 000 cells
+    cpu_cost = None
+    try:
+        from oracle import cost as ocost
+        Cs = 2000
+        try:
+            from threadpoolctl import threadpool_info
+            blas = [f"{p.get('internal_api')}:{p.get('num_threads')}" for p in threadpool_info()]
+        except Exception:   # noqa: BLE001
+            blas = ["unknown"]
+        t = time.perf_counter()
+        a = ocost.normalize_data(sc[:, :Cs].astype(np.float64))
+        b = ocost.normalize_data(st.astype(np.float64))
+        dr, _ = ocost.calculate_cost(a, b, slots, "lapjv", "Pearson_correlation")
+        dt_cpu = time.perf_counter() - t
+        flops = 2.0 * G * S * Cs
+        cpu_cost = {"kind": "port", "sample": f"oracle/cost.py (numpy float64 restatement of common.py:142-147, 190-199 and the slot gather of "
+                                              f"linear_assignment_solvers.py:63-66) on all {S} spots x the first {Cs} of the {C} cells",
+                    "seconds": round(dt_cpu, 2), "cells_per_s": round(Cs / dt_cpu, 1), "GFLOPs_of_the_contraction_over_the_whole_time": round(flops / dt_cpu / 1e9, 1),
+                    "blas_threads": blas, "usable_cores": _usable_cores(), "cost_rows_x_cols": list(dr.shape)}
+        del a, b, dr
+    except Exception as e:   # noqa: BLE001
+        cpu_cost = {"error": f"{type(e).__name__}: {e}"}
     # the cells go up in blocks of 8192 and block b's contraction runs while block b + 1 is copied and transformed, so the
     # upload + transform time already contains all contractions but the last block's: the parts do not add up to the wall time
     return {"workload": f"{G} genes x {C} cells x {S} spots (10 slots each), float32 counts -> spots",
@@ -105,6 +203,10 @@ def extra_c3(dev):
                           "pearson_gemm_blocks_sum": round(info.ms_gemm, 2), "lap": round(info.lap.ms_total, 1)},
             "roofline": {"bound": "mfma", "kernel": "pearson_gemm", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF,
                          "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "flops_per_launch": info.gemm_flops},
+            "k1_roofline": k1, "cpu_baseline_cost_build": cpu_cost,
+            "counts_density": round(float(np.count_nonzero(sc[:, :2000])) / (G * 2000), 3),
+            "lap": {"ms": round(info.lap.ms_total, 2), "rounds": int(info.lap.wide_rounds), "scaled": bool(info.lap.wide_scaled),
+                    "one_edge_searches": int(info.lap.wide_trivial)},
             "lap_row_scans": int(info.lap.row_scans), "bincount_equals_slots": ok, "instance_seconds": round(t_gen, 1)}
 
 
@@ -142,8 +244,9 @@ def _usable_cores():
 
 def extra_c4_chunks(dev, K, distinct=4, cpu_n=5000, cpu_threads=64):
     """K concurrent sub-spot chunk LAPs (10 000 cells each) on one GPU; beside it the CPU oracle on the host's cores
-    (BASELINE.md section 3 item 2), on a BOUNDED sample: chunks of cpu_n cells (a 10 000-cell chunk takes the oracle
-    minutes when every core runs one; assignments/s falls with n, so the smaller sample flatters the CPU)."""
+    (BASELINE.md section 3 item 2), on a BOUNDED sample: chunks of cpu_n cells (a 10 000-cell chunk takes the classic oracle
+    155 s on one core -- tests/golden/large_c4s10000.npz records it --, so the default run times 5 000-cell chunks and puts the GPU's
+    rate ON THE SAME 5 000-cell chunks beside it: `gpu_on_the_same_sample`; assignments/s falls with n on both sides)."""
     from concurrent.futures import ThreadPoolExecutor
     from cytospace_amd import _lib
     from cytospace_amd.lap import lap_solve_batch_device
@@ -195,6 +298,14 @@ def extra_c4_chunks(dev, K, distinct=4, cpu_n=5000, cpu_threads=64):
     cpu_wall = time.perf_counter() - t
     bs = [_lib.DeviceBuffer.from_numpy(small[k], dev) for k in range(distinct)]
     rs = lap_solve_batch_device([b.ptr for b in bs], [cpu_n] * distinct, device_id=dev, max_concurrent=distinct, return_info=True)
+    # the GPU on the CPU's own sample (like for like): T chunks of cpu_n cells in one batched call, and one alone
+    bs += [bs[k % distinct].clone() for k in range(distinct, T)]
+    t = time.perf_counter()
+    lap_solve_batch_device([b.ptr for b in bs[:T]], [cpu_n] * T, device_id=dev, max_concurrent=T)
+    gpu_same_wall = time.perf_counter() - t
+    t = time.perf_counter()
+    lap_solve_batch_device([bs[0].ptr], [cpu_n], device_id=dev, max_concurrent=1)
+    gpu_same_one = time.perf_counter() - t
     for b in bs:
         b.free()
     with ThreadPoolExecutor(T) as ex:      # the batch runs the wide solver: its restatement on the same instances (not timed)
@@ -220,6 +331,9 @@ def extra_c4_chunks(dev, K, distinct=4, cpu_n=5000, cpu_threads=64):
             "cpu_baseline": {"value": round(T * cpu_n / cpu_wall, 1), "unit": "assignments/s", "cores": T, "kind": "port",
                              "usable_cores": cores, "host_cores": os.cpu_count(),
                              "one_thread_alone": round(cpu_n / cpu1, 1),
+                             "gpu_on_the_same_sample": {"assignments_per_s": round(T * cpu_n / gpu_same_wall, 1), "chunks": T, "wall_s": round(gpu_same_wall, 3),
+                                                        "one_chunk_alone_assignments_per_s": round(cpu_n / gpu_same_one, 1)},
+                             "ten_thousand_cell_chunk_one_thread_seconds_in_the_build_container": 154.6,
                              "sample": f"oracle/jv_oracle.c on sub-spot chunks of {cpu_n} cells (same generator): one thread alone {cpu1:.1f} s; "
                                        f"{T} threads at once, one chunk each, {cpu_wall:.1f} s; the HIP path solves the same {distinct} "
                                        f"instances bit-identically ({rs[0]['info'].ms_total:.0f} ms of kernels each)",
@@ -397,7 +511,7 @@ def main():
     ap.add_argument("--c4-chunks", type=int, default=256, help="concurrent chunk LAPs in the c4_chunks leg (256 = one chain per CU; 400 MB each)")
     ap.add_argument("--c4-rank-chunks", type=int, default=64, help="chunks per rank in the c4_sharded leg")
     ap.add_argument("--sharded-timeout", type=float, default=600.0, help="watchdog of the c4_sharded leg, seconds")
-    ap.add_argument("--pmc-tag", default="r03h", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
+    ap.add_argument("--pmc-tag", default="r04f", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
     args = ap.parse_args()
 
     # ONE JSON line on stdout: everything else this process (or a library under it: RCCL prints a version banner through C
@@ -538,7 +652,7 @@ def main():
     aug_scans = info.scans_aug_init + info.scans_aug_relax
     arr_ms = float(np.mean(arr_ms_l))
     aug_ms = float(np.mean(aug_ms_l))
-    arr_name, aug_name = ("wide_arr", "wide_aug") if info.wide else ("jv_chain2", "jv_aug_lazy" if n > 5120 else "jv_aug2")
+    arr_name, aug_name = ("row_reduction(wide_rt + wide_sc_* + wide_arr)", "wide_aug") if info.wide else ("jv_chain2", "jv_aug_lazy" if n > 5120 else "jv_aug2")
     # (the wide solver's row reduction is a PHASE of thousands of launches -- the long-list rounds on the whole chip, two small
     #  launches each, then the wide_arr kernel for the tail: arr_ms brackets the phase, the wide_arr kernel alone is its own clock's
     #  list + chain time; the dominant KERNEL is the longest single launch)
@@ -551,7 +665,7 @@ def main():
     try:   # HBM bytes from the separate rocprofv3 --pmc pass committed under profiles/ (same n, same instance)
         traffic_source = f"profiles/{args.pmc_tag}_pmc_traffic_n{n}.json"
         if not os.path.exists(os.path.join(ROOT, traffic_source)):
-            traffic_source = f"profiles/r03a_pmc_traffic_n{n}.json"
+            traffic_source = f"profiles/r03h_pmc_traffic_n{n}.json"
         pm = json.load(open(os.path.join(ROOT, traffic_source)))
         if pm.get("n") == n:
             key = [k for k in pm["kernels"] if k.startswith(dom[0] + "<") or k.startswith(dom[0] + "(") or k == dom[0]]
@@ -569,8 +683,9 @@ def main():
         "other_kernels": {
             arr_name: {"ms": round(arr_ms, 3), "row_scans": int(arr_scans), "algorithmic_GBs": round(4.0 * n * arr_scans / (arr_ms * 1e-3) / 1e9, 2),
                        "rounds": int(info.wide_rounds), "full_row_scans": int(info.wide_dense_arr),
-                       "note": "the row-reduction PHASE (HIP events around wide_rt, the long-list rounds as two whole-chip launches each, wide_arr)",
-                       "wide_arr_kernel_ms": round(arr_kernel_ms, 3), "long_list_rounds_on_the_whole_chip": int(info.wide_list_rounds)},
+                       "note": "the row-reduction PHASE (HIP events around wide_rt, the phase machine -- every round two whole-chip launches, "
+                               "wide_sc_bid + wide_sc_resolve -- and wide_arr)", "scaled": bool(info.wide_scaled), "phases": int(info.wide_phases),
+                       "wide_arr_kernel_ms": round(arr_kernel_ms, 3), "us_per_round": round(arr_ms * 1e3 / max(1, int(info.wide_rounds)), 2)},
             aug_name: {"ms": round(aug_ms, 3), "row_scans": int(aug_scans), "algorithmic_GBs": round(4.0 * n * aug_scans / max(aug_ms, 1e-9) / 1e-3 / 1e9, 2),
                        "searches": int(info.augmentations), "columns_settled_speculatively": int(info.wide_aug_settled),
                        "rounds_of_16_waves": int(info.wide_aug_rounds),
@@ -602,7 +717,21 @@ def main():
                                        and info.scans_arr == owf["stats"].scans_arr and info.scans_aug_relax == owf["stats"].scans_aug_relax)
             if not full_size_bit_exact:
                 raise SystemExit("full-size parity failed: HIP solver differs from the CPU oracle on the bench instance")
-        cpu = {"value": round(cn / dt, 1), "unit": "assignments/s", "cores": 1, "kind": "port",
+        scipy_leg = None
+        try:   # an independent second CPU number, on a bounded sample of the same generator
+            from scipy.optimize import linear_sum_assignment
+            sn = min(n, 6000)
+            scost = make_cost(sn, sn)
+            t3 = time.perf_counter()
+            sr, scol = linear_sum_assignment(scost.astype(np.float64))
+            dts = time.perf_counter() - t3
+            sg = lap_solve(scost, np.float32, device_id=dev)
+            scipy_leg = {"value": round(sn / dts, 1), "unit": "assignments/s", "cores": 1, "n": sn, "seconds": round(dts, 2),
+                         "same_assignment_as_the_hip_solver": bool(np.array_equal(sg["rowsol"], scol)),
+                         "note": "scipy.optimize.linear_sum_assignment (float64) on a smaller instance of the same generator; assignments/s falls with n"}
+        except Exception as e:   # noqa: BLE001
+            scipy_leg = {"error": f"{type(e).__name__}: {e}"}
+        cpu = {"value": round(cn / dt, 1), "unit": "assignments/s", "cores": 1, "kind": "port", "scipy": scipy_leg,
                "sample": f"oracle/jv_oracle.c (C port of JV, -O3 -mavx2, 1 thread; lapjv wheel unavailable) on "
                          + ("the bench instance itself" if same else "a smaller instance of the same generator")
                          + f" ({cn}x{cn} uniform): {dt:.1f} s, {oc['stats'].row_scans} row scans "
@@ -632,6 +761,7 @@ def main():
     if sharded is not None:
         out["c4_sharded"] = sharded
     if world == 1 and not args.no_extras:
+        out["c2_cytolike"] = extra_c2_cytolike(dev)
         out["n50000"] = extra_n50000(dev)
         out["c3"] = extra_c3(dev)
         out["c4_chunks"] = extra_c4_chunks(dev, args.c4_chunks)

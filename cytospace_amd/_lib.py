@@ -34,7 +34,7 @@ class LapInfo(ctypes.Structure):
                                        "wide_aug_settled", "wide_trivial", "wide_verify_passes", "wide_list_rounds", "wide_chain_rounds")] + \
         [(k, ctypes.c_double) for k in ("wide_ms_list", "wide_ms_chain", "wide_ms_aug_rounds", "wide_ms_aug_verify", "wide_ms_aug_finish",
                                         "wide_ms_aug_trivial")] + [("wide_arr_launches", ctypes.c_int64), ("wide_aug_launches", ctypes.c_int64),
-         ("wide_scaled", ctypes.c_int64), ("wide_phases", ctypes.c_int64)]
+         ("wide_scaled", ctypes.c_int64), ("wide_phases", ctypes.c_int64), ("f64_warm", ctypes.c_int64), ("f64_warm_ms", ctypes.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

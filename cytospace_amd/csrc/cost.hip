@@ -695,6 +695,9 @@ int cyto_assign_metric_typed(int metric, int G, int C, int S, const void *sc, co
         std::vector<hipEvent_t> evs((size_t)2 * nblocks, nullptr);     // per block: contraction begin / end
         struct EvGuard { std::vector<hipEvent_t> &v; ~EvGuard() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); } } evguard{evs};
         for (size_t k = 0; k < evs.size(); k++) CYTO_HIP(hipEventCreate(&evs[k]));
+        // every early return below leaves contractions queued on gcomp.s that write `cost` and read zst / zsc: both streams drain
+        // before any of the buffers is released (the block cache may hand a released block to another thread's solve at once)
+        StreamDrain drain_comp{gcomp.s}, drain_main{stream};
         for (int b = 0; b < nblocks; b++) {
             const int c0 = b * WBLK, w = std::min(WBLK, C - c0);
             const char *src = reinterpret_cast<const char *>(sc) + (size_t)c0 * esz;

@@ -58,11 +58,18 @@ template <int N> struct Events {
     hipEvent_t operator[](int i) const { return e[i]; }
 };
 
-// A private non-blocking stream for one call when the caller gave none.
+// A private non-blocking stream for one call when the caller gave none.  The stream is drained before it is destroyed: work that
+// an early return left queued must not outlive the call.
 struct StreamGuard {
     hipStream_t s = nullptr;
     bool own = false;
-    ~StreamGuard() { if (own && s) (void)hipStreamDestroy(s); }
+    ~StreamGuard() { if (own && s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } }
+};
+// Declared AFTER the device buffers a second stream works on (so destroyed BEFORE them): whatever path leaves the scope, the
+// stream has drained before a buffer goes back to the block cache, where another thread's call may be handed it.
+struct StreamDrain {
+    hipStream_t s = nullptr;
+    ~StreamDrain() { if (s) (void)hipStreamSynchronize(s); }
 };
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-symbol, process-wide setting: set it ONCE per kernel to the most

@@ -124,6 +124,7 @@ struct ScCtl {
 static_assert(sizeof(ScCtl) <= 2048, "control block of the row-reduction phase");
 // the constants of the restatement (oracle/jv_oracle.h: JV_WIDE_*)
 constexpr int SC_K0 = 8, SC_NPH = 16, SC_PHCAP = 1024, SC_EMULT = 3, SC_ESTEP = 1;
+constexpr int SC_COARSE = 4;           // phases whose full-row bids leave the row caches alone (a matter of speed only)
 __host__ __device__ inline int wide_stop(int n) { return n / 128 < 8 ? 8 : (n / 128 > 64 ? 64 : n / 128); }
 // the next representable value below x (+0 and -0 are one value): oracle pred_
 __device__ __forceinline__ float pred_f32(float x) {
@@ -446,7 +447,7 @@ template <typename F> __device__ __forceinline__ void block_row_sweep(const floa
 // the whole workgroup: exact lexicographic top-2 of row i -- and a fresh cache for it against the current prices (floor = one of the 64
 // minima of the columns c with (c / 4) % 64 == l, sorted: the 48th, else the 24th, 12th ... smallest; the columns below it are collected in
 // a second sweep of the now L2-resident row; more than 63 of them -> the next candidate).  Every thread returns the same Top2.
-__device__ __forceinline__ Top2 sc_top2_block(const WideArgs &a, ScShared &ss, int i) {
+__device__ __forceinline__ Top2 sc_top2_block(const WideArgs &a, ScShared &ss, int i, bool rebuild) {
     const int n = a.n, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float *__restrict__ row = a.cost + wrow_off(a.rowmap, i, a.ld);
     K2 d; d.m1 = KEYMAX; d.m2 = KEYMAX;
@@ -462,6 +463,7 @@ __device__ __forceinline__ Top2 sc_top2_block(const WideArgs &a, ScShared &ss, i
     t.u1 = key_val(g.m1); t.j1 = (int)(uint32_t)g.m1; t.c1 = row[t.j1]; t.vj1 = a.v[t.j1];
     t.u2 = INFINITY; t.j2 = -1; t.c2 = 0.0f; t.vj2 = 0.0f;
     if (g.m2 != KEYMAX) { t.u2 = key_val(g.m2); t.j2 = (int)(uint32_t)g.m2; t.c2 = row[t.j2]; t.vj2 = a.v[t.j2]; }
+    if (!rebuild) { __syncthreads(); return t; }                   // (the staging words are free again for the next row)
     // ---- the row's new cache ----
     uint32_t lm = 0xFFFFFFFFu;
     if (w == 0) {
@@ -613,6 +615,9 @@ __global__ __launch_bounds__(HEADB) void wide_sc_bid(const WideArgs *__restrict_
     __syncthreads();
     const long long tag = S.total - (long long)sc->base;
     const float eps = S.eps;
+    // a coarse phase (eps_k many times the span of a row's 63 cached columns) moves the prices past every cache within a bid or two:
+    // there a full-row bid does not rebuild its row's cache (half its cost) -- the later phases do, and keep their caches
+    const bool refresh = !(S.mode == SC_EPS && S.k < SC_COARSE);
     int retired = 0, dense = 0;                                   // (lane 0 of every wave)
     auto record = [&](int slot, int i, const Top2 &t) {
         int jt, i0; float pt, ct;
@@ -641,7 +646,7 @@ __global__ __launch_bounds__(HEADB) void wide_sc_bid(const WideArgs *__restrict_
             if (threadIdx.x == 0) ss.nq = 0;
             for (int q = 0; q < nq; q++) {
                 const int i = ss.qrow[q], slot = ss.qslot[q];
-                const Top2 t = sc_top2_block(a, ss, i);
+                const Top2 t = sc_top2_block(a, ss, i, refresh);
                 if (w == 0) { record(slot, i, t); dense++; }
             }
             __syncthreads();

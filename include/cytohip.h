@@ -101,6 +101,8 @@ typedef struct {
     int64_t wide_aug_launches;   /* augmentation: launches of the search kernel (row-cache rebuilds in between: cyto_lap_opts.wide_rebuild) */
     int64_t wide_scaled;         /* row reduction: 1 = the instance went through the eps-scaled phases */
     int64_t wide_phases;         /* row reduction: phases begun (scaled phases + the final eps = 0 phase) */
+    int64_t f64_warm;            /* float64: 1 = warm-started from the prices of the float32 wide solve of the narrowed matrix */
+    double f64_warm_ms;          /* float64: kernel time of that float32 solve */
 } cyto_lap_info;
 
 int cyto_lap_f32(int n, const float *cost, int64_t ld, int cost_on_device,

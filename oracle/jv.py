@@ -43,8 +43,10 @@ def _lib():
     return _LIB
 
 
-def jv_oracle(cost, dtype=np.float32):
+def jv_oracle(cost, dtype=np.float32, warm=False):
     """Solve the square LAP on the CPU.  Returns dict(rowsol, colsol, u, v, total, total_T, stats).
+    warm (float64 only): start from the prices of the float32 wide solve of the narrowed matrix, every row free
+    (jv_oracle_warm_f64: what the HIP float64 path computes by default).
 
     `cost` is cast to `dtype` first (lapjv 1.3.14 is recalled to down-cast to float32
     unless force_doubles is set -- SURVEY.md section 8c, UNVERIFIED)."""
@@ -61,9 +63,11 @@ def jv_oracle(cost, dtype=np.float32):
     if dtype == np.float32:
         fn, tt = _lib().jv_oracle_f32, ctypes.c_float()
     elif dtype == np.float64:
-        fn, tt = _lib().jv_oracle_f64, ctypes.c_double()
+        fn, tt = (_lib().jv_oracle_warm_f64 if warm else _lib().jv_oracle_f64), ctypes.c_double()
     else:
         raise TypeError("dtype must be float32 or float64")
+    if warm and dtype != np.float64:
+        raise TypeError("the warm start is a float64 mode")
     rc = fn(ctypes.c_int(n), c.ctypes.data_as(ctypes.c_void_p),
             rowsol.ctypes.data_as(ctypes.c_void_p), colsol.ctypes.data_as(ctypes.c_void_p),
             u.ctypes.data_as(ctypes.c_void_p), v.ctypes.data_as(ctypes.c_void_p),

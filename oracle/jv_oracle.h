@@ -29,6 +29,11 @@ int jv_oracle_f32(int n, const float *cost, int32_t *rowsol, int32_t *colsol, fl
 int jv_oracle_f64(int n, const double *cost, int32_t *rowsol, int32_t *colsol, double *u, double *v,
                   double *total_f64, double *total_T, jv_stats *st);
 
+/* float64 with a warm start: the prices of the float32 wide solve of the narrowed matrix, every row free, then the classic
+ * augmenting row reduction and augmentation in float64 (jv_oracle.c) */
+int jv_oracle_warm_f64(int n, const double *cost, int32_t *rowsol, int32_t *colsol, double *u, double *v,
+                       double *total_f64, double *total_T, jv_stats *st);
+
 /* ---- wide mode (jv_oracle_impl.h, second half): Jacobi reduction transfer, Jacobi rounds of augmenting row reduction,
  * succ-clamped shortest-path augmentation.  Same optimum as the classic mode; what the HIP "wide" solver computes bit for bit.
  * max_rounds < 0: JV_WIDE_ROUNDS(n).  stop_phase: 0 = solve; 1 = return the state after reduction transfer, 2 = after the

@@ -58,7 +58,10 @@ static void FN(top2_)(int n, const T *restrict c, const T *restrict v,
     *umin_o = umin; *j1_o = j1; *usub_o = usub; *j2_o = j2;
 }
 
-int FN(jv_oracle_)(int n, const T *restrict cost, int32_t *restrict rowsol,
+/* v_init != NULL: the WARM start -- prices given (any prices are a valid JV state as long as nothing is assigned), every row free:
+ * no column reduction, no reduction transfer; augmenting row reduction and augmentation as ever.  (jv_oracle_warm_f64: the prices
+ * of the float32 wide solve of the narrowed matrix.) */
+static int FN(jv_oracle_from_)(int n, const T *restrict cost, const T *restrict v_init, int32_t *restrict rowsol,
                    int32_t *restrict colsol, T *restrict u, T *restrict v,
                    double *total_f64, T *total_T, jv_stats *st) {
     jv_stats s;
@@ -79,19 +82,24 @@ int FN(jv_oracle_)(int n, const T *restrict cost, int32_t *restrict rowsol,
 
     /* ---- COLUMN REDUCTION: v[j] = min_i c[i][j] (lowest i on ties); columns are
      * claimed from the last to the first, the first claim of a row wins. ---- */
+    if (v_init) {
+        for (int j = 0; j < n; j++) { v[j] = v_init[j]; colsol[j] = -1; }
+        for (int i = 0; i < n; i++) rowsol[i] = -1;
+    } else {
     for (int j = 0; j < n; j++) { v[j] = cost[j]; imin[j] = 0; }
     for (int i = 1; i < n; i++) {
         const T *restrict ci = cost + (size_t)i * N;
         for (int j = 0; j < n; j++)
             if (ci[j] < v[j]) { v[j] = ci[j]; imin[j] = i; }
     }
-    s.scans_colred = n;
     for (int i = 0; i < n; i++) rowsol[i] = -1;
     for (int j = n - 1; j >= 0; j--) {
         int i = imin[j];
         if (++matches[i] == 1) { rowsol[i] = j; colsol[j] = i; }
         else colsol[j] = -1;
     }
+    }
+    s.scans_colred = n;
 
     /* ---- REDUCTION TRANSFER (rows in ascending order; later rows see the prices
      * lowered by earlier ones). n == 1 has no other column to transfer from. ---- */
@@ -219,6 +227,12 @@ int FN(jv_oracle_)(int n, const T *restrict cost, int32_t *restrict rowsol,
     if (st) *st = s;
     free(freerows); free(matches); free(pred); free(imin); free(lvl); free(scanned); free(d);
     return JV_OK;
+}
+
+
+int FN(jv_oracle_)(int n, const T *restrict cost, int32_t *restrict rowsol, int32_t *restrict colsol, T *restrict u, T *restrict v,
+                   double *total_f64, T *total_T, jv_stats *st) {
+    return FN(jv_oracle_from_)(n, cost, NULL, rowsol, colsol, u, v, total_f64, total_T, st);
 }
 
 

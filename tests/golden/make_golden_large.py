@@ -1,6 +1,6 @@
 """Goldens for the LARGE LAP instances (BASELINE configs c2/c3/c4 at true size), made in the build container.
 
-Run:  python tests/golden/make_golden_large.py [tag ...]      (tags: u20000 u24000 u30000 u33000 u50000 u70000 c3s50000 c4s10000)
+Run:  python tests/golden/make_golden_large.py [tag ...]      (tags: u20000 u24000 u30000 u33000 u50000 u70000 c3s50000 c4s10000 t20000)
       python tests/golden/make_golden_large.py --wide [tag ...]   the same instances through the oracle's WIDE mode -> large_<tag>_wide.npz
       python tests/golden/make_golden_large.py --f64 [tag ...]    float64 solves (uniform tags only) -> large_<tag>_f64.npz
 
@@ -101,6 +101,9 @@ def make(tag):
     elif tag.startswith("c4s"):
         n = int(tag[3:])
         cost, loc = instances.c4_chunk_cost(n)
+    elif tag.startswith("t"):                 # SURVEY 8(d) "cytospace-like" solver-only instance: few cell types, slots == 1
+        n = int(tag[1:])
+        cost, loc = instances.typed_unique_cost(n, n, 20)[0], None
     else:
         raise SystemExit(f"unknown tag {tag}")
     print(f"[{tag}] instance in {time.time() - t0:.1f}s, sha256(cost)={sha(cost)[:16]}", flush=True)
@@ -129,7 +132,8 @@ def make(tag):
         if not same or abs(sp_total - total) > 1e-5 * max(1.0, abs(total)):
             raise SystemExit(f"[{tag}] oracle and scipy disagree: not a golden")
     t = time.time()
-    p = jv_oracle(perturbed(cost, 99), np.float32)
+    # (any exact solver will do for the re-solve: the wide restatement is the faster one on few-cell-type instances)
+    p = (jv_oracle_wide if tag.startswith("t") else jv_oracle)(perturbed(cost, 99), np.float32)
     unique = bool(np.array_equal(key(p["colsol"]), key(colsol)))
     print(f"[{tag}] one-ulp perturbation re-solve {time.time() - t:.1f}s: answer unchanged = {unique}", flush=True)
     st = o["stats"].as_dict()
@@ -152,6 +156,9 @@ def instance(tag):
     if tag.startswith("c4s"):
         n = int(tag[3:])
         return (n,) + instances.c4_chunk_cost(n)
+    if tag.startswith("t"):
+        n = int(tag[1:])
+        return n, instances.typed_unique_cost(n, n, 20)[0], None
     raise SystemExit(f"unknown tag {tag}")
 
 
@@ -190,13 +197,17 @@ def make_wide(tag):
     print(f"[{tag} wide] written, {time.time() - t0:.0f}s", flush=True)
 
 
-def make_f64(tag):
-    """float64 solve (the force_doubles / lapjv_compat precision) of a uniform instance: the float32 matrix as float64."""
+def make_f64(tag, warm=False):
+    """float64 solve (the force_doubles / lapjv_compat precision) of a uniform instance: the float32 matrix as float64, plus a
+    float64 term below float32's resolution when warm (else the narrowed matrix IS the matrix).  warm: the warm-started restatement
+    (oracle/jv_oracle.c: jv_oracle_warm_f64) -> large_<tag>_f64_warm.npz; must give the cold golden's indices where that exists."""
     t0 = time.time()
     n, cost, loc = instance(tag)
     c64 = cost.astype(np.float64)
+    if warm:
+        c64 += np.random.default_rng(n).random((n, n)) * 2.0 ** -30
     t = time.time()
-    o = jv_oracle(c64, np.float64)
+    o = jv_oracle(c64, np.float64, warm=warm)
     t_or = time.time() - t
     colsol = o["colsol"]
     total = float(c64[colsol, np.arange(n)].sum())
@@ -207,8 +218,13 @@ def make_f64(tag):
     if not cert:
         raise SystemExit(f"[{tag} f64] not certified")
     st = o["stats"].as_dict()
+    if warm:
+        sp = scipy_colsol(c64.astype(np.float64), SCIPY_LIMIT_S)
+        if sp is None or not np.array_equal(sp, colsol):
+            raise SystemExit(f"[{tag} f64 warm] scipy disagrees or did not finish: not a golden")
+        print(f"[{tag} f64 warm] scipy gives the same permutation", flush=True)
     np.savez_compressed(
-        os.path.join(OUT, f"large_{tag}_f64.npz"), n=n, colsol=colsol.astype(np.int32), total=total, cost_sha256=sha(cost),
+        os.path.join(OUT, f"large_{tag}_f64{'_warm' if warm else ''}.npz"), n=n, colsol=colsol.astype(np.int32), total=total, cost_sha256=sha(cost),
         u_sha256=sha(o["u"]), v_sha256=sha(o["v"]), rowsol_sha256=sha(o["rowsol"]), oracle_seconds=t_or,
         dual_certificate=np.array([mn, tight, gap]), stats_keys=np.array(list(st.keys())), stats_vals=np.array(list(st.values()), np.int64))
     print(f"[{tag} f64] written, {time.time() - t0:.0f}s", flush=True)
@@ -219,6 +235,9 @@ if __name__ == "__main__":
     if "--wide" in sys.argv:
         for tg in (args or ["u20000", "u50000", "c3s50000", "c4s10000"]):
             make_wide(tg)
+    elif "--f64warm" in sys.argv:
+        for tg in (args or ["u17000"]):
+            make_f64(tg, warm=True)
     elif "--f64" in sys.argv:
         for tg in (args or ["u17000"]):
             make_f64(tg)

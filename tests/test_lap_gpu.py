@@ -380,7 +380,7 @@ def test_float64_streaming_chain_with_and_without_row_caches(variant):
 def test_float64_default_path_above_4096():
     n = 4500
     c = np.random.default_rng(n).random((n, n))
-    g = lap_solve(c, np.float64, return_info=True)
+    g = lap_solve(c, np.float64, return_info=True, opts=CHAIN)          # (the cold classic chain; the default is warm-started)
     _check(c, np.float64)
     assert g["info"].hbm_row_reads < g["info"].scans_redtransfer + g["info"].scans_arr      # most scans were served by the caches
 
@@ -400,6 +400,53 @@ def test_duplicate_row_group_state_in_global_memory(aug):
     # ... and the dense kernel's per-column auxiliaries in global memory as well (what it uses beyond ~13 000 columns)
     _check(c, np.float32, dict(augmentation=1, aux_state_global=1, group_state_global=aug - 1))
     _check(np.random.default_rng(4).random((700, 700)).astype(np.float32), np.float32, dict(augmentation=1, aux_state_global=1))
+
+
+# ---- float64 by default: warm-started from the float32 wide solve of the narrowed matrix (oracle: jv_oracle_warm_f64) ----
+
+def _check_warm(c64):
+    o = jv_oracle(c64, np.float64, warm=True)
+    g = lap_solve(c64, np.float64, return_info=True)
+    assert g["info"].f64_warm == 1
+    for k in ("rowsol", "colsol", "v", "u"):
+        assert np.array_equal(g[k], o[k]), k
+    assert abs(g["total"] - o["total"]) <= 1e-9 * max(1.0, abs(o["total"]))
+    od, gd = o["stats"].as_dict(), g["info"].as_dict()
+    for k in STAT_KEYS:
+        assert gd[k] == od[k], (k, gd[k], od[k])
+    return g, o
+
+
+@pytest.mark.parametrize("n", [2, 3, 64, 300, 1000, 2500, 4500, 6000])
+def test_float64_warm_start_uniform(n):
+    # the precision of lapjv(cost, force_doubles=True) / lap.lapjv (linear_assignment_solvers.py:13-15, 36): the float64 chain starts
+    # from the prices of the float32 wide solve of the narrowed matrix, every row free -- ~1.2 n row-reduction steps instead of ~100 n;
+    # the same optimum as the cold classic solve (unique: the same indices), its own duals
+    c = np.random.default_rng(7000 + n).random((n, n))
+    g, o = _check_warm(c)
+    cold = jv_oracle(c, np.float64)
+    assert np.array_equal(g["colsol"], cold["colsol"])
+    if n >= 300:
+        assert g["info"].scans_arr < 4 * n < cold["stats"].scans_arr
+
+
+def test_float64_warm_start_ties_duplicates_and_the_perturbation():
+    rng = np.random.default_rng(71)
+    _check_warm(rng.integers(0, 10, (400, 400)).astype(np.float64))                                   # heavy ties
+    base = -(rng.random((160, 800)) ** 3)
+    dup = np.repeat(base, 5, axis=0)
+    g, o = _check_warm(dup)                                                                            # duplicated spot rows
+    np.random.seed(1)
+    pert = dup + 1e-16 * np.random.rand(*dup.shape)                                                    # cytospace.py:325-327
+    g2, o2 = _check_warm(pert)
+    loc = np.repeat(np.arange(160), 5)
+    assert np.array_equal(loc[g["colsol"]], loc[jv_oracle(dup, np.float64)["colsol"]])                # spot level: any exact solver's
+    c = (rng.standard_normal((300, 300)) * 1e3)
+    _check_warm(c)
+    big = rng.random((50, 50)) * 1e300                                                                 # beyond float32's range: cold start
+    gb = lap_solve(big, np.float64, return_info=True)
+    ob = jv_oracle(big, np.float64, warm=True)
+    assert gb["info"].f64_warm == 0 and all(np.array_equal(gb[k], ob[k]) for k in ("rowsol", "colsol", "u", "v"))
 
 
 # ---- the wide solver (cyto_lap_opts.mode = 2; the default for one float32 problem): lap_wide.hip vs oracle WIDE MODE ----

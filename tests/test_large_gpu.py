@@ -98,7 +98,7 @@ def _wide_vs_golden(tag, n, solve, loc=None):
         got = g["info"].as_dict()
         for kg, ko in (("scans_redtransfer", "scans_redtransfer"), ("scans_arr", "scans_arr"), ("scans_aug_relax", "scans_aug_relax"),
                        ("augmentations", "augmentations"), ("path_hops", "path_hops"), ("free_after_arr2", "free_after_arr"),
-                       ("wide_rounds", "arr_rounds"), ("wide_retired", "arr_retired")):
+                       ("wide_rounds", "arr_rounds"), ("wide_retired", "arr_retired"), ("wide_scaled", "arr_scaled"), ("wide_phases", "arr_phases")):
             assert got[kg] == want[ko], (kg, got[kg], want[ko])
     return g
 
@@ -111,6 +111,22 @@ def test_wide_uniform_true_size(n):
     try:
         g = _wide_vs_golden(f"u{n}", n, lambda: lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n))
         assert g["info"].wide_dense_aug < 0.05 * g["info"].scans_aug_relax
+    finally:
+        buf.free()
+
+
+def test_wide_cytolike_20000():
+    """SURVEY 8(d)'s "cytospace-like" solver-only instance at c2's size: 20 000 spots x 20 000 cells of ten cell types, every slot
+    count 1 -- the deep-search class CytoSPACE's chunks belong to (the classic oracle needs 40x the row scans of the uniform c2)."""
+    n = 20000
+    if not os.path.exists(os.path.join(GOLD, f"large_t{n}.npz")):
+        pytest.skip(f"large_t{n}.npz not generated")
+    cost = instances.typed_unique_cost(n, n, 20)[0]
+    buf = _lib.DeviceBuffer.from_numpy(cost)
+    del cost
+    try:
+        g = _wide_vs_golden(f"t{n}", n, lambda: lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n))
+        assert g["info"].wide_scaled == 1
     finally:
         buf.free()
 
@@ -150,7 +166,7 @@ def test_float64_uniform_17000_prices_in_l2():
     n = 17000
     d = _golden(f"u{n}_f64")
     c = instances.uniform_cost(n).astype(np.float64)
-    g = lap_solve(c, np.float64, return_info=True)
+    g = lap_solve(c, np.float64, return_info=True, opts=CHAIN)          # the cold classic chain (the default is warm-started)
     assert np.array_equal(g["colsol"], d["colsol"])
     assert sha(g["rowsol"]) == str(d["rowsol_sha256"]) and sha(g["u"]) == str(d["u_sha256"]) and sha(g["v"]) == str(d["v_sha256"])
     assert abs(g["total"] - float(d["total"])) <= 1e-9 * max(1.0, abs(float(d["total"])))
@@ -158,6 +174,28 @@ def test_float64_uniform_17000_prices_in_l2():
     got = g["info"].as_dict()
     for k in STAT_KEYS:
         assert got[k] == want[k], (k, got[k], want[k])
+
+
+def test_float64_uniform_17000_warm_start():
+    """The float64 default at a true size: warm-started from the float32 wide solve of the narrowed matrix (the matrix carries a
+    term below float32's resolution, so the float64 problem is not the float32 one)."""
+    n = 17000
+    path = os.path.join(GOLD, f"large_u{n}_f64_warm.npz")
+    if not os.path.exists(path):
+        pytest.skip("large_u17000_f64_warm.npz not generated")
+    d = np.load(path)
+    c = instances.uniform_cost(n).astype(np.float64)
+    c += np.random.default_rng(n).random((n, n)) * 2.0 ** -30
+    g = lap_solve(c, np.float64, return_info=True)
+    assert g["info"].f64_warm == 1
+    assert np.array_equal(g["colsol"], d["colsol"])
+    assert sha(g["rowsol"]) == str(d["rowsol_sha256"]) and sha(g["u"]) == str(d["u_sha256"]) and sha(g["v"]) == str(d["v_sha256"])
+    assert abs(g["total"] - float(d["total"])) <= 1e-9 * max(1.0, abs(float(d["total"])))
+    want = dict(zip([str(k) for k in d["stats_keys"]], d["stats_vals"].tolist()))
+    got = g["info"].as_dict()
+    for k in STAT_KEYS:
+        assert got[k] == want[k], (k, got[k], want[k])
+    assert g["info"].ms_total < 1000.0
 
 
 def test_c3_shaped_lap_50000():
@@ -337,6 +375,46 @@ def test_fused_block_pipeline_equals_the_split_path(metric):
     g = lap_solve_rows(rows, loc)                                        # the same unique rows, built in one piece
     assert np.array_equal(loc[g["colsol"]], mapped)
     assert abs(g["total"] - total) <= 1e-5 * max(1.0, abs(total))
+
+
+def test_fused_block_pipeline_failure_then_another_thread_solves():
+    """Fault injection into the block pipeline of the fused path: a cell without counts in the SECOND of three blocks (zero
+    variance: its standardised column is NaN, cytospace/common/common.py:190-199 divides by the zero std just the same) makes
+    the call fail while contractions of other blocks were queued on the pipeline's second stream.  Every stream of the call has
+    drained before its buffers go back to the block cache, so solves on other threads -- which are handed those blocks at
+    once -- stay correct, during the failures and after them."""
+    import threading
+    G, C, S = 240, 17200, 1720
+    sc, st, slots = instances.synth_expression(G, C, S, seed=12)
+    want, want_total, _ = assign_pearson(sc, st, slots, already_normalized=False, return_info=True)
+    bad = sc.copy()
+    bad[:, 8192 + 77] = 0                                # (block 1 of 0..2)
+    errors, results = [], []
+
+    def failing():
+        for _ in range(4):
+            try:
+                assign_pearson(bad, st, slots, already_normalized=False)
+                errors.append("no exception")
+            except ValueError:
+                pass
+            except Exception as e:   # noqa: BLE001
+                errors.append(repr(e))
+
+    def solving():
+        for _ in range(4):
+            m, t, _ = assign_pearson(sc, st, slots, already_normalized=False, return_info=True)
+            results.append(bool(np.array_equal(m, want) and abs(t - want_total) <= 1e-9 * max(1.0, abs(want_total))))
+
+    th = [threading.Thread(target=failing), threading.Thread(target=solving), threading.Thread(target=solving)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 8 and all(results)
+    m, t, _ = assign_pearson(sc, st, slots, already_normalized=False, return_info=True)        # ... and afterwards
+    assert np.array_equal(m, want)
 
 
 # ---- configs[3] as configured: 200 000 cells -> 20 sub-spot chunks of 10 000 cells against 50 000 spots, ONE batched call ----
