@@ -550,8 +550,9 @@ def main():
                 torch.cuda.synchronize()
         _lib.check(_lib.lib().cyto_device_synchronize(dev))
 
-    # ---- parity gate on a size the oracles finish in a second (bit-exact, incl. duals): the wide solver (what a single
-    # solve runs) against its restatement, the chain solver (what the batched legs run) against the classic restatement ----
+    # ---- parity gate on a size the oracles finish in a second (bit-exact, incl. duals): the wide solver (what every float32 leg
+    # of this file runs: single solves, batches, chunks) against its restatement, the chain solver (cyto_lap_opts.mode = 1) against
+    # the classic restatement, and -- the instance has a unique optimum -- the same indices from both ----
     pn = 3000
     pc = make_cost(pn, 1234 + rank)
     g = lap_solve(pc, np.float32, device_id=dev, return_info=True)
@@ -740,7 +741,11 @@ def main():
 
     out = {
         "metric": "cell-to-spot assignments/sec on NxN synthetic cost; bit-exact vs lapjv",
-        "metric_note": "bit-exact vs the in-tree CPU JV oracle (== scipy on uniqueness-certified instances); the lapjv wheel is not in this image",
+        "metric_note": "bit-exact vs the in-tree CPU JV oracle: indices, duals and work counters of the wide solver vs the oracle's wide "
+                       "restatement, and the indices of the classic-order oracle (== scipy) on this uniqueness-certified instance; the lapjv "
+                       "wheel is not in this image.  Result contract of the default solver: an optimal assignment -- where the optimum is not "
+                       "unique (duplicated spot rows, integer costs) its choice among the optimal assignments differs from the classic "
+                       "Jonker-Volgenant tie-break (same spots, same total); cyto_lap_opts.mode = 1 gives the classic order",
         "value": round(value, 1), "unit": "assignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",

@@ -64,14 +64,14 @@ int lap_batch_any(int nb, const int *n, const float *const *cost, const int64_t 
             } else {
                 std::vector<std::vector<int>> part((size_t)G);
                 for (int k = 0; k < cnt; k++) part[(size_t)(k % G)].push_back(k);
-                std::vector<std::thread> th;
-                for (int g = 0; g < G; g++) {
-                    th.emplace_back([&, g]() {
+                // one sub-batch: a stream of its own, its problems' pointers, the solve, its results (an int status, never an exception)
+                auto run_part = [&](int g) -> int {
+                    try {
                         const std::vector<int> &ks = part[(size_t)g];
                         const int m = (int)ks.size();
-                        if (select_device(device_id)) { brcs[(size_t)g] = CYTO_ERR_HIP; return; }
+                        if (select_device(device_id)) return CYTO_ERR_HIP;
                         StreamGuard sg;
-                        if (hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking) != hipSuccess) { brcs[(size_t)g] = CYTO_ERR_HIP; return; }
+                        if (hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking) != hipSuccess) return CYTO_ERR_HIP;
                         sg.own = true;
                         std::vector<const float *> c2((size_t)m); std::vector<int64_t> l2((size_t)m);
                         std::vector<int32_t *> rs2((size_t)m), cs2((size_t)m); std::vector<float *> u2((size_t)m), v2((size_t)m);
@@ -82,16 +82,33 @@ int lap_batch_any(int nb, const int *n, const float *const *cost, const int64_t 
                             c2[(size_t)q] = c[k]; l2[(size_t)q] = l[k]; rs2[(size_t)q] = rs[k]; cs2[(size_t)q] = cs[k];
                             u2[(size_t)q] = uu[k]; v2[(size_t)q] = vv[k]; rm2[(size_t)q] = rm[k]; nus2[(size_t)q] = nus[k];
                         }
-                        brcs[(size_t)g] = lap_batch_same_n(kv.first, m, c2.data(), l2.data(), cost_on_device, rs2.data(), cs2.data(), u2.data(),
-                                                          v2.data(), tot2.data(), inf2.data(), stat2.data(), device_id, sg.s, rm2.data(),
-                                                          nus2.data(), opts);
+                        const int r = lap_batch_same_n(kv.first, m, c2.data(), l2.data(), cost_on_device, rs2.data(), cs2.data(), u2.data(),
+                                                       v2.data(), tot2.data(), inf2.data(), stat2.data(), device_id, sg.s, rm2.data(),
+                                                       nus2.data(), opts);
                         for (int q = 0; q < m; q++) {
                             const size_t k = (size_t)ks[(size_t)q];
                             tot[k] = tot2[(size_t)q]; inf[k] = inf2[(size_t)q]; stat[k] = stat2[(size_t)q];
                         }
-                    });
+                        return r;
+                    } catch (const std::bad_alloc &) {
+                        return CYTO_ERR_NOMEM;
+                    } catch (...) {
+                        return CYTO_ERR_INTERNAL;
+                    }
+                };
+                // (no exception may cross the C ABI: a thread that cannot be created -- std::system_error -- leaves its sub-batch to
+                //  this thread, after the others)
+                std::vector<std::thread> th;
+                std::vector<int> inline_parts;
+                for (int g = 0; g < G; g++) {
+                    try {
+                        th.emplace_back([&, g]() { brcs[(size_t)g] = run_part(g); });
+                    } catch (...) {
+                        inline_parts.push_back(g);
+                    }
                 }
                 for (auto &t : th) t.join();
+                for (int g : inline_parts) brcs[(size_t)g] = run_part(g);
             }
             for (int k = 0; k < cnt; k++) {
                 const int b = ids[lo + (size_t)k];
@@ -110,17 +127,18 @@ int lap_batch_any(int nb, const int *n, const float *const *cost, const int64_t 
     return first;
 }
 
-// One int32 from `root` to every rank (the status word that precedes the operand broadcast: cost.hip, ctx_create_impl).
-int comm_bcast_status(void *comm, int *status, int root, int device_id) {
-    if (!comm || !status) return CYTO_ERR_BAD_ARG;
+// nwords (<= 4) int32 from `root` to every rank (the status word and the operand's extents that precede the operand broadcast:
+// cost.hip, ctx_create_impl).
+int comm_bcast_status(void *comm, int *status, int root, int device_id, int nwords) {
+    if (!comm || !status || nwords < 1 || nwords > 4) return CYTO_ERR_BAD_ARG;
     int rc = select_device(device_id);
     if (rc) return rc;
     DevBuf word;
     if ((rc = word.alloc(16))) return rc;
-    CYTO_HIP(hipMemcpy(word.p, status, sizeof(int), hipMemcpyHostToDevice));
-    if (ncclBroadcast(word.p, word.p, 1, ncclInt32, root, reinterpret_cast<ncclComm_t>(comm), nullptr) != ncclSuccess) return CYTO_ERR_HIP;
+    CYTO_HIP(hipMemcpy(word.p, status, sizeof(int) * (size_t)nwords, hipMemcpyHostToDevice));
+    if (ncclBroadcast(word.p, word.p, (size_t)nwords, ncclInt32, root, reinterpret_cast<ncclComm_t>(comm), nullptr) != ncclSuccess) return CYTO_ERR_HIP;
     CYTO_HIP(hipStreamSynchronize(nullptr));
-    CYTO_HIP(hipMemcpy(status, word.p, sizeof(int), hipMemcpyDeviceToHost));
+    CYTO_HIP(hipMemcpy(status, word.p, sizeof(int) * (size_t)nwords, hipMemcpyDeviceToHost));
     return CYTO_OK;
 }
 

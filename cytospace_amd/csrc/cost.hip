@@ -796,19 +796,20 @@ static int ctx_create_impl(int metric, int G, int C, int S, const void *sc, int6
         rc = cyto_transform(transform, G, S, st, ldst_in, st_is_f64, st_on_device, already_normalized, ctx->zst.as<float>(), ctx->ldst,
                             ctx->Gpad, device_id, nullptr);
     if (comm) {
-        int root_rc = rc;                                                    // (only the root's value is sent)
-        const int brc = comm_bcast_status(comm, &root_rc, root, device_id);
+        // the root's status AND the extents of its operand: a rank that failed locally (bad G / S of its own) still receives exactly
+        // what the root sends -- into a scratch block --, so that nobody is left waiting and no two ranks disagree on the count
+        int words[3] = {rc, (int)round_up(G > 0 ? G : 1, BK), (int)round_up(S > 0 ? S : 1, BM)};   // (only the root's values are sent)
+        const int my_gpad = words[1], my_ldst = words[2];
+        const int brc = comm_bcast_status(comm, words, root, device_id, 3);
+        const int root_rc = words[0];
         if (brc) rc = rc ? rc : brc;
         else if (root_rc) rc = rc ? rc : root_rc;                            // the root failed: nobody enters the data broadcast
         else {
-            // every rank enters (one that failed locally receives into a scratch block so that the others are not left waiting)
+            if (!rc && (words[1] != my_gpad || words[2] != my_ldst)) rc = CYTO_ERR_BAD_ARG;       // this rank's G / S are not the root's
             DevBuf scratch;
             float *dst = (!rc && ctx) ? ctx->zst.as<float>() : nullptr;
-            size_t count = nst;
-            if (!dst) {
-                count = (size_t)round_up(G > 0 ? G : 1, BK) * (size_t)round_up(S > 0 ? S : 1, BM);
-                if (!scratch.alloc(count * 4)) dst = scratch.as<float>();
-            }
+            const size_t count = (size_t)words[1] * (size_t)words[2];
+            if (!dst && !scratch.alloc(count * 4)) dst = scratch.as<float>();
             Events<2> ev;
             if (dst && !ev.create()) {
                 (void)hipEventRecord(ev[0], nullptr);

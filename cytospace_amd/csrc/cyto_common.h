@@ -90,6 +90,6 @@ int lap_batch_any(int nb, const int *n, const float *const *cost, const int64_t 
                   const int32_t *const *rowmap, const int *nu, int32_t *const *rowsol, int32_t *const *colsol, float *const *u,
                   float *const *v, double *total, cyto_lap_info *info, int *status_out, int max_concurrent, int device_id,
                   const cyto_lap_opts *opts = nullptr);
-// batch.hip: one int32 from `root` to every rank of the communicator (status agreement before the operand broadcast)
-int comm_bcast_status(void *comm, int *status, int root, int device_id);
+// batch.hip: nwords (<= 4) int32 from `root` to every rank of the communicator (status agreement before the operand broadcast)
+int comm_bcast_status(void *comm, int *status, int root, int device_id, int nwords = 1);
 }  // namespace cyto

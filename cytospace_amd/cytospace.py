@@ -105,11 +105,10 @@ class ExpressionContext:
             sc, st, is64 = _pair(sc, st)
             n_spots = st.shape[1]
         else:
-            # (a root without the ST matrix is NOT rejected here: the other ranks are already on their way into the
-            #  collective, so the call goes through and the library's status word fails every rank together)
-            if n_spots is None and comm.rank != root:
-                raise ValueError("n_spots is required on ranks that do not hold the ST matrix")
-            n_spots = 1 if n_spots is None else n_spots
+            # (neither a root without the ST matrix nor a rank without n_spots is rejected HERE: the other ranks are already on
+            #  their way into the collective, so the call goes through -- with an invalid extent the library turns into its status --
+            #  and the status word / the root's extents fail every rank together instead of leaving the others blocked)
+            n_spots = (1 if comm.rank == root else 0) if n_spots is None else n_spots
             is64 = int(sc.dtype != np.float32)
             sc = np.ascontiguousarray(sc, dtype=np.float64 if is64 else np.float32)
         self.G, self.C = sc.shape

@@ -170,7 +170,7 @@ int cyto_lap_f32_from_f64(int n, const double *cost_host, int64_t ld, int32_t *r
  * apply_linear_assignment (cytospace/cytospace.py:430-451) for the solver-only seam: the sequential
  * chain of one solve occupies one workgroup, so chunks run side by side (one launch per phase, a workgroup per problem).
  * n[b], cost[b], ld[b]: per problem; outputs are arrays of per-problem host pointers (each may be NULL);
- * total/info/status_out: arrays of length nb (may be NULL).  max_concurrent <= 0 -> min(nb, 32). */
+ * total/info/status_out: arrays of length nb (may be NULL).  max_concurrent <= 0 -> min(nb, 256). */
 int cyto_lap_batch_f32(int nb, const int *n, const float *const *cost, const int64_t *ld, int cost_on_device,
                        int32_t *const *rowsol, int32_t *const *colsol, float *const *u, float *const *v,
                        double *total, cyto_lap_info *info, int *status_out, int max_concurrent, int device_id);

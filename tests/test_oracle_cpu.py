@@ -215,6 +215,68 @@ def test_wide_oracle_vs_scipy_random(n, rounds):
     assert st.scans_aug_init == st.augmentations == st.free_after_arr
 
 
+@pytest.mark.parametrize("n", [300, 1000, 2500])
+@pytest.mark.parametrize("rounds", [-1, 8, 9, 20, 100])
+def test_wide_oracle_scaled_phases_any_budget(n, rounds):
+    # generic costs: after eight eps = 0 rounds the active list is still long and the row reduction goes through the eps-scaled phases.
+    # A budget of rounds may end the scaled phases at any point -- never the final eps = 0 phase: the assignments a scaled phase leaves
+    # satisfy eps-complementary slackness only, and the augmentation would finish something that is NOT the optimum (this test failed
+    # for rounds = 20 and 100 before the rule)
+    from oracle.jv import jv_oracle_wide
+    c = np.random.default_rng(4000 + n).random((n, n)).astype(np.float32)
+    r = jv_oracle_wide(c, np.float32, max_rounds=rounds)
+    ri, ci = linear_sum_assignment(c.astype(np.float64))
+    assert np.array_equal(r["rowsol"], ci)
+    st = r["stats"]
+    assert st.arr_scaled == (0 if rounds == 8 else 1) and (st.arr_phases >= 2) == bool(st.arr_scaled)
+    assert st.gap_exp > 0
+    u, v = r["u"].astype(np.float64), r["v"].astype(np.float64)
+    red = c.astype(np.float64) - u[:, None] - v[None, :]
+    assert red.min() > -1e-5 and np.abs(red[np.arange(n), r["rowsol"]]).max() < 1e-5
+    if rounds < 0:                                     # the point of the phases: few rounds, shallow searches
+        cold = jv_oracle(c, np.float32)["stats"]
+        assert st.arr_rounds < 600 and st.scans_aug_relax < cold.scans_arr // 10
+
+
+def test_wide_oracle_duplicated_rows_and_ties_never_scale():
+    from oracle.jv import jv_oracle_wide
+    from tools import instances
+    rng = np.random.default_rng(31)
+    for c in (np.repeat(rng.random((200, 1000)), 5, axis=0).astype(np.float32), rng.integers(0, 10, (600, 600)).astype(np.float32),
+              instances.c3_shaped_cost(1000, 10, 3)[0]):
+        st = jv_oracle_wide(c, np.float32)["stats"]
+        assert st.arr_scaled == 0 and st.arr_phases == 0
+
+
+@pytest.mark.parametrize("n", [2, 3, 50, 400, 1500])
+def test_warm_float64_oracle(n):
+    # float64 warm-started from the float32 wide solve of the narrowed matrix (what the HIP float64 path computes by default): the
+    # float64 problem's optimum -- scipy on the float64 costs --, far fewer row-reduction steps than the cold classic solve
+    rng = np.random.default_rng(5000 + n)
+    c = rng.random((n, n)) + rng.random((n, n)) * 2.0 ** -30          # (a term below float32's resolution)
+    w = jv_oracle(c, np.float64, warm=True)
+    ri, ci = linear_sum_assignment(c)
+    assert np.array_equal(w["rowsol"], ci)
+    cold = jv_oracle(c, np.float64)
+    assert np.array_equal(w["colsol"], cold["colsol"]) and abs(w["total"] - cold["total"]) <= 1e-12 * max(1.0, abs(cold["total"]))
+    red = c - w["u"][:, None] - w["v"][None, :]
+    assert red.min() > -1e-12 and np.abs(red[np.arange(n), w["rowsol"]]).max() < 1e-12
+    if n >= 400:
+        assert w["stats"].scans_arr < 3 * n < cold["stats"].scans_arr
+    assert w["stats"].scans_redtransfer == 0 and w["stats"].free_after_colred == n
+
+
+def test_warm_float64_oracle_on_the_perturbed_reference_golden_and_beyond_float32_range():
+    d = load("gv5_solve_lap.npz")
+    dist, loc = ocost.calculate_cost(d["visium_s1_sc_norm"], d["visium_s1_st_norm"], d["visium_s1_slots"])
+    c = ocost.perturb(dist, 1)                                          # cytospace.py:325-327 on duplicated spot rows
+    w = jv_oracle(c, np.float64, warm=True)
+    assert np.array_equal(loc[w["colsol"]], d["visium_s1_mapped"])
+    big = np.random.default_rng(1).random((40, 40)) * 1e300            # narrows to inf: the cold start
+    a, b = jv_oracle(big, np.float64, warm=True), jv_oracle(big, np.float64)
+    assert all(np.array_equal(a[k], b[k]) for k in ("rowsol", "colsol", "u", "v"))
+
+
 def test_wide_oracle_ties_duplicates_and_typed_instances():
     from oracle.jv import jv_oracle_wide
     from tools import instances
@@ -258,7 +320,7 @@ def test_wide_oracle_stop_phases_expose_the_intermediate_state():
     assert np.all(h[np.arange(len(asg)), a["rowsol"][asg]] <= h.min(1) + 1e-7)
 
 
-@pytest.mark.parametrize("tag", ["u20000", "u50000", "u70000", "c3s50000", "c4s10000"])
+@pytest.mark.parametrize("tag", ["u20000", "u50000", "u70000", "c3s50000", "c4s10000", "t20000"])
 def test_wide_large_goldens_are_certified(tag):
     # the wide restatement's answers at true size: certified by their own duals on ALL n^2 entries and equal (slot level; spot
     # level where spot rows are duplicated) to the classic goldens, which scipy and the perturbation re-solve certify
@@ -273,3 +335,5 @@ def test_wide_large_goldens_are_certified(tag):
     if not bool(d["spot_level"]):
         assert np.array_equal(d["colsol"], c["colsol"])
     assert abs(float(d["total"]) - float(c["total"])) <= 1e-5 * max(1.0, abs(float(c["total"])))
+    st = dict(zip([str(k) for k in d["stats_keys"]], d["stats_vals"].tolist()))
+    assert st["arr_scaled"] == (0 if tag.startswith("c3s") else 1)     # made with the eps-scaled restatement (round 4)
