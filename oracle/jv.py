@@ -33,6 +33,18 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
 
 
+def _usable_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def _lib():
     global _LIB
     if _LIB is None:
@@ -40,6 +52,9 @@ def _lib():
         if not os.path.exists(path):
             build()
         _LIB = ctypes.CDLL(path)
+        # (libgomp's default is one thread per core of the HOST: in a container with 16 of 256 cores the rounds of the wide mode
+        #  would run on 256 spinning threads)
+        _LIB.jv_oracle_set_threads(int(os.environ.get("JV_ORACLE_THREADS", max(1, min(_usable_cores(), 32)))))
     return _LIB
 
 

@@ -7,6 +7,20 @@
 #include <stdlib.h>
 #include <string.h>
 #include "jv_oracle.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* the wide mode's bids of a round (independent of each other) run on this many threads: the binding sets it to the cores the
+ * process may really use -- libgomp's default is every core of the HOST, and a container with 16 of 256 cores then spends its
+ * time in 256 spinning threads */
+void jv_oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n >= 1) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 #define T float
 #define SUFFIX f32

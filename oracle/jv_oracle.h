@@ -29,6 +29,9 @@ int jv_oracle_f32(int n, const float *cost, int32_t *rowsol, int32_t *colsol, fl
 int jv_oracle_f64(int n, const double *cost, int32_t *rowsol, int32_t *colsol, double *u, double *v,
                   double *total_f64, double *total_T, jv_stats *st);
 
+/* threads for the wide mode's rounds (the bids of a round are independent): jv_oracle.c */
+void jv_oracle_set_threads(int n);
+
 /* float64 with a warm start: the prices of the float32 wide solve of the narrowed matrix, every row free, then the classic
  * augmenting row reduction and augmentation in float64 (jv_oracle.c) */
 int jv_oracle_warm_f64(int n, const double *cost, int32_t *rowsol, int32_t *colsol, double *u, double *v,
