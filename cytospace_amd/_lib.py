@@ -34,7 +34,8 @@ class LapInfo(ctypes.Structure):
                                        "wide_aug_settled", "wide_trivial", "wide_verify_passes", "wide_list_rounds", "wide_chain_rounds")] + \
         [(k, ctypes.c_double) for k in ("wide_ms_list", "wide_ms_chain", "wide_ms_aug_rounds", "wide_ms_aug_verify", "wide_ms_aug_finish",
                                         "wide_ms_aug_trivial")] + [("wide_arr_launches", ctypes.c_int64), ("wide_aug_launches", ctypes.c_int64),
-         ("wide_scaled", ctypes.c_int64), ("wide_phases", ctypes.c_int64), ("f64_warm", ctypes.c_int64), ("f64_warm_ms", ctypes.c_double)]
+         ("wide_scaled", ctypes.c_int64), ("wide_phases", ctypes.c_int64), ("wide_par_batches", ctypes.c_int64),
+         ("wide_par_discarded", ctypes.c_int64), ("f64_warm", ctypes.c_int64), ("f64_warm_ms", ctypes.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -49,7 +50,7 @@ class LapOpts(ctypes.Structure):
     """cyto_lap_opts (include/cytohip.h): kernel-selection options; results never depend on them."""
     _fields_ = [("chain_variant", ctypes.c_int32), ("augmentation", ctypes.c_int32), ("no_handover", ctypes.c_int32),
                 ("inject_exceptions", ctypes.c_int32), ("group_state_global", ctypes.c_int32), ("aux_state_global", ctypes.c_int32), ("mode", ctypes.c_int32), ("wide_rounds", ctypes.c_int32), ("wide_groups", ctypes.c_int32), ("wide_rebuild", ctypes.c_int32),
-                ("wide_wipe", ctypes.c_int32)]
+                ("wide_par", ctypes.c_int32), ("wide_wipe", ctypes.c_int32)]
 
 
 class AssignInfo(ctypes.Structure):

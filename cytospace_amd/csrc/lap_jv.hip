@@ -2934,7 +2934,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(const LazyArgs *__restrict
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-static const cyto_lap_opts k_default_opts = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static const cyto_lap_opts k_default_opts = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 static int check_opts(const cyto_lap_opts &o) {
     if (o.chain_variant < 0 || o.chain_variant > 3 || o.augmentation < 0 || o.augmentation > 2 || o.inject_exceptions < 0 ||
@@ -2942,7 +2942,7 @@ static int check_opts(const cyto_lap_opts &o) {
         return CYTO_ERR_BAD_ARG;
     if (o.group_state_global < 0 || o.group_state_global > 1 || o.aux_state_global < 0 || o.aux_state_global > 1) return CYTO_ERR_BAD_ARG;
     if (o.mode < 0 || o.mode > 2 || o.wide_rounds < -1 || o.wide_groups < -1 || o.wide_groups > 32 || o.wide_rebuild < -1 ||
-        o.wide_wipe < 0 || o.wide_wipe > 2048) return CYTO_ERR_BAD_ARG;
+        o.wide_wipe < 0 || o.wide_wipe > 2048 || o.wide_par < -1 || o.wide_par > WIDE_PAR_GMAX) return CYTO_ERR_BAD_ARG;
     return CYTO_OK;
 }
 
@@ -2969,7 +2969,7 @@ struct F32Plan {            // what depends on n (and the options) only: identic
     int n, colblocks, rowblocks, rows_per_block, cache_grid;
     bool force_l2, lds_variant, lazy, lz_lds_state, lz_cs_lds, no_cs_lds, wide;
     long long wide_rounds;
-    int wide_groups, wide_rebuild, wide_wipe;
+    int wide_groups, wide_rebuild, wide_wipe, wide_par;
     size_t shm_chain, lz_base_shm;
 };
 
@@ -3030,8 +3030,16 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             F32Job &j = jobs[live[k]];
             const int mcg = nl != 1 ? 0 : (pl.wide_groups > 0 ? pl.wide_groups : (pl.wide_groups < 0 ? 0 : wide_mc_groups(nl, n)));
             const size_t mcb = mcg > 0 ? wide_mc_state_bytes(n) : 0;
+            // several searches of ONE problem at once (wide_aug<.., PAR>): by default for a single problem without runs of identical
+            // rows (those finish their searches as runs of one-edge steps in the one-workgroup kernel) from 2 048 rows on
+            const bool dup_rows = j.h_ngroups < n && n >= 2;
+            int parg = (nl != 1 || mcg > 0) ? 0 : (pl.wide_par > 0 ? pl.wide_par : (pl.wide_par < 0 || dup_rows || n < 2048 ? 0 : 16));
+            if (parg > WIDE_PAR_GMAX) parg = WIDE_PAR_GMAX;
+            if (parg == 1) parg = 0;
+            const size_t parb = parg > 0 ? wide_par_state_bytes(n, parg) : 0;
             const size_t sc_off = ((2 * nT + 255) / 256) * 256 + mcb;       // the phase machine's control block behind everything else
-            if ((rc = j.b_wide.alloc(sc_off + WIDE_SC_BYTES, stream))) return rc;
+            const size_t par_off = sc_off + WIDE_SC_BYTES;
+            if ((rc = j.b_wide.alloc(par_off + parb, stream))) return rc;
             const Chain2Args &c = j.c2;
             WideArgs &wa = h_wa[k];
             wa.n = n; wa.ld = c.ld; wa.cost = c.cost; wa.rowmap = c.rowmap;
@@ -3044,6 +3052,7 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             wa.slot_p = j.b_wide.as<float>(); wa.slot_c = wa.slot_p + n;
             wa.cache_col = c.cache_col; wa.cache_val = c.cache_val; wa.misc = c.misc;
             wa.max_rounds = pl.wide_rounds;
+            // (the several-searches kernel never pauses -- it never looks at aug_seg --, but the row reduction's rebuild rule reads the same field)
             wa.aug_seg = mcg > 0 ? -1 : pl.wide_rebuild;
             // what a rebuild costs, in full-row relaxations of ONE workgroup (a relaxation sweeps n elements at ~5 G/s; a pass costs
             // ~0.4 ms of launches and synchronisation plus one read of every unfinished problem's matrix by the whole chip, ~100x
@@ -3055,6 +3064,17 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             wa.same_prev = (j.h_ngroups < n && n >= 2) ? j.b_same.as<int32_t>() : nullptr;
             wa.sc = j.b_wide.as<char>() + sc_off;
             CYTO_HIP(hipMemsetAsync(wa.sc, 0, WIDE_SC_BYTES, stream));
+            wa.par_groups = parg; wa.par = nullptr;
+            if (parg > 0) {
+                const size_t np_ = ((size_t)n + 63) & ~(size_t)63;
+                wa.par = j.b_wide.as<char>() + par_off;
+                CYTO_HIP(hipMemsetAsync(wa.par, 0, 256, stream));                                            // the control block ...
+                const int p_init[2] = {WIDE_PAR_GMAX + 1, WIDE_PAR_GMAX + 1};
+                CYTO_HIP(hipMemcpyAsync(wa.par + 8, p_init, sizeof p_init, hipMemcpyHostToDevice, stream));   // ... P[0], P[1]: "no conflict"
+                CYTO_HIP(hipMemsetAsync(wa.par + 256, 0xFF, (size_t)parg * np_ * 8, stream));                  // every search's labels: all-ones
+                CYTO_HIP(hipMemsetAsync(wa.par + 256 + (size_t)parg * np_ * 20, 0, np_ * 4, stream));          // the claim words
+                CYTO_HIP(hipStreamSynchronize(stream));                                                         // (p_init is a local)
+            }
             wa.mc_groups = mcg; wa.gbmin = nullptr; wa.gdirty = nullptr; wa.gasg = nullptr; wa.gdense = nullptr; wa.ctl = nullptr;
             if (mcg > 0) {
                 const size_t nblk = ((size_t)n + 63) / 64, nw32 = ((size_t)n + 31) / 32;
@@ -3097,8 +3117,8 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             if ((rc = build_caches(pass ? h_sync.data() + 1 : nullptr))) return rc;
             if (pass == 0) CYTO_HIP(hipEventRecord(ev_arr_done, stream));   // (ms_aug: the search kernel -- and what later passes add)
             CYTO_HIP(hipMemsetAsync(d_sync.p, 0, sizeof(int32_t), stream));
-            if ((rc = wide_launch_aug(d_wa.as<WideArgs>(), nl, n, stream, h_wa[0].mc_groups))) return rc;
-            if (h_wa[0].mc_groups > 0) { CYTO_HIP(hipStreamSynchronize(stream)); break; }
+            if ((rc = wide_launch_aug(d_wa.as<WideArgs>(), nl, n, stream, h_wa[0].mc_groups, h_wa[0].par_groups))) return rc;
+            if (h_wa[0].mc_groups > 0 || h_wa[0].par_groups > 0) { CYTO_HIP(hipStreamSynchronize(stream)); break; }
             CYTO_HIP(hipMemcpyAsync(h_sync.data(), d_sync.p, sizeof(int32_t) * ((size_t)nl + 1), hipMemcpyDeviceToHost, stream));
             CYTO_HIP(hipStreamSynchronize(stream));                // (d_wa is read by the kernels until here)
             bool done = true;
@@ -3191,6 +3211,7 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
     pl.wide_groups = opts.wide_groups;
     pl.wide_rebuild = opts.wide_rebuild;
     pl.wide_wipe = opts.wide_wipe;
+    pl.wide_par = opts.wide_par;
     pl.force_l2 = opts.chain_variant != 0;
     pl.no_cs_lds = opts.chain_variant == 3;            // (3: as 2, with colsol in global memory too -- what n > 65 535 uses)
     pl.lds_variant = !pl.force_l2 && n <= 13 * per2;
@@ -3431,6 +3452,7 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
                     info->wide_ms_aug_rounds = dbg[8] * 1e-5; info->wide_ms_aug_verify = dbg[9] * 1e-5;
                     info->wide_ms_aug_finish = dbg[10] * 1e-5; info->wide_ms_aug_trivial = dbg[11] * 1e-5;
                     info->wide_arr_launches = dbg[12]; info->wide_scaled = dbg[13]; info->wide_phases = dbg[14];
+                    info->wide_par_batches = dbg[15]; info->wide_par_discarded = dbg[7];
                 }
             }
         }

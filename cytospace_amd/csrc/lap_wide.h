@@ -21,6 +21,7 @@ namespace cyto {
 //   seg_sync        shared by the launch, or null: [0] workgroups that asked for fresh caches (zeroed by the driver before every launch
 //                   of wide_arr / wide_aug), [1 + b] wide_arr: 1 = problem b's rounds paused; wide_aug: searches problem b still has to run
 //   sc              2 KB, zeroed by the driver: the control block of the row-reduction phase machine (lap_wide.hip: ScCtl)
+//   par_groups, par searches of one problem that run at once on as many workgroups (0 / 1: one at a time) and their state (lap_wide.hip: ParCtl)
 //   arr_waste       wide_arr: full-row bids (with their cache refresh) of one launch after which the list rounds pause (aug_seg == 0)
 //   aug_seg         when a launch of wide_aug returns to the driver for fresh row caches: -1 never, k > 0 after k searches, 0 when
 //                   its full-row relaxations reach aug_waste or seg_quorum workgroups of the launch have asked (misc + 132 holds the
@@ -35,7 +36,7 @@ namespace cyto {
     P(float, slot_c) P(uint32_t, cache_col) P(float, cache_val) P(char, misc) S(long long, max_rounds)                     \
     P(unsigned long long, gbmin) P(uint32_t, gdirty) P(uint32_t, gasg) P(uint32_t, gdense) P(char, ctl) S(int, mc_groups)  \
     P(const int32_t, same_prev) P(int32_t, seg_sync) S(int, aug_seg) S(int, aug_waste) S(int, arr_waste) S(int, seg_quorum)   \
-    P(char, sc)
+    P(char, sc) S(int, par_groups) P(char, par)
 #define WIDE_F_PTR(T, name) T *name;
 #define WIDE_F_VAL(T, name) T name;
 struct WideArgs { WIDE_FIELDS(WIDE_F_PTR, WIDE_F_VAL) };
@@ -50,7 +51,9 @@ size_t wide_aug_lds_bytes(int n);
 int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream);        // Jacobi reduction transfer (v0 snapshot in cassign)
 int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, int wipe_every, bool resume, int32_t *d_sync,
                     int (*rebuild)(void *ctx, const int32_t *flags), void *ctx);   // rebuild: fresh row caches for the flagged problems   // Jacobi rounds of augmenting row reduction + free list
-int wide_launch_aug(const WideArgs *d_args, int nb, int n, hipStream_t stream, int mc_groups);   // succ-clamped shortest-path augmentation, duals, total
+int wide_launch_aug(const WideArgs *d_args, int nb, int n, hipStream_t stream, int mc_groups, int par_groups);   // shortest-path augmentation, duals, total
+size_t wide_par_state_bytes(int n, int G);                                              // control block, per-search labels / lists, claim words, change logs
+constexpr int WIDE_PAR_GMAX = 64;
 int wide_mc_groups(int nb, int n);                                                     // how many workgroups search one problem together (0: one)
 size_t wide_mc_state_bytes(int n);                                                     // gbmin + 3 bitmaps + control block
 

@@ -124,6 +124,7 @@ struct ScCtl {
 static_assert(sizeof(ScCtl) <= 2048, "control block of the row-reduction phase");
 // the constants of the restatement (oracle/jv_oracle.h: JV_WIDE_*)
 constexpr int SC_K0 = 8, SC_NPH = 16, SC_PHCAP = 1024, SC_EMULT = 3, SC_ESTEP = 1;
+constexpr int SC_STOP_FINAL = 16;       // the final eps = 0 phase ends at min(wide_stop(n), 16) active rows (JV_WIDE_STOP_FINAL)
 constexpr int SC_COARSE = 4;           // phases whose full-row bids leave the row caches alone (a matter of speed only)
 __host__ __device__ inline int wide_stop(int n) { return n / 128 < 8 ? 8 : (n / 128 > 64 ? 64 : n / 128); }
 // the next representable value below x (+0 and -0 are one value): oracle pred_
@@ -549,7 +550,7 @@ __device__ __forceinline__ ScSlot sc_step(const ScCtl *sc, const ScSlot &S, int 
     } else if (S.mode == SC_EPS) {
         if (over) { next_phase = true; last = true; }
         else if (S.rip >= 1 && (na <= sc->stop || S.rip >= SC_PHCAP)) next_phase = true;
-    } else if (S.rip >= 1 && (na <= sc->stop || S.rip >= SC_PHCAP)) { N.mode = SC_DONE; return N; }
+    } else if (S.rip >= 1 && (na <= (sc->stop < SC_STOP_FINAL ? sc->stop : SC_STOP_FINAL) || S.rip >= SC_PHCAP)) { N.mode = SC_DONE; return N; }
     if (next_phase) {
         N.k = N.k + 1;
         const float eps = last ? 0.0f : sc_eps_of(sc, N.k);
@@ -1018,19 +1019,82 @@ struct AugShared {
     int ntouch, any[3], npk[3], fail, anydense, rootdense, doroot, f, err;
     int waste, stop;               // full-row relaxations of this launch; "return to the driver for fresh caches"
     int nhop;                      // edges of the path being flipped
+    int conflict;                  // PAR: this search met a column an earlier search of the batch claimed
     int scans;
     int st_row[64], st_col[64];    // one-edge searches: their results, stored to global memory 64 at a time
     float st_val[64];
 };
 
+// ---- SEVERAL SEARCHES AT ONCE (one problem, PAR): the free rows' searches are independent until they are committed, and most of
+// them are shallow (a few dozen settled columns after the scaled row reduction), so G workgroups run the searches of free rows
+// f, f + 1, ..., f + G - 1 from ONE state, each with its own labels, and then commit IN ROW ORDER the longest prefix whose settled
+// sets (and sinks) are pairwise disjoint -- which is exactly what running them one after the other gives:
+//   a committed search lowers the prices of the columns it settled below its final distance and flips owners along its path; a later
+//   search that settled none of those columns, did not end at that sink and whose own sink is not among them read nothing that
+//   changed in a way it can observe (a lower price of a column only RAISES the label the search would give it, and that label was
+//   already at or above the search's end; unassigned columns other than the sink keep their prices) -- its labels, sink and path are
+//   the ones it would have computed after the commit.  The first search of a batch that meets an earlier one's set, and every one
+//   after it, is discarded and runs again in the next batch.  Nothing of the restatement changes: same searches, same order, same bits.
+// Conflicts are found without a serial pass: every search claims its columns with an atomic max of (batch << 8 | 255 - g); after a
+// grid barrier a search whose columns all still carry its own key met no smaller g.  The committing workgroups log their price and
+// owner changes; every workgroup applies the log to its LDS copies before the next batch.  Grid barriers: three per batch.
+struct ParCtl {
+    unsigned int bar_arrive, bar_gen;
+    int P[2], nplog[2], nolog[2];          // per batch parity: first conflicting search, entries of the two change logs
+    int err, pad_;
+    long long c_relax, c_hops, c_proc, c_dense, c_rounds, c_verify, c_batches, c_discarded;
+};
+static_assert(sizeof(ParCtl) <= 256, "control block");
+constexpr int PAR_GMAX = 64;
+size_t wide_par_state_bytes(int n, int G) {
+    const size_t np = ((size_t)n + 63) & ~(size_t)63;
+    // control block | labels G x n | touched G x n | hops G x 2n | claim n | price log (col, val) | owner log (col, owner)
+    return 256 + (size_t)G * np * 8 + (size_t)G * np * 4 + (size_t)G * np * 8 + np * 4 + np * 8 + np * 8;
+}
+__device__ __forceinline__ void par_barrier(ParCtl *c, int G, unsigned &gen) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned arrived = atomicAdd(&c->bar_arrive, 1u) + 1u;
+        if (arrived == (gen + 1u) * (unsigned)G) st_sc1(&c->bar_gen, gen + 1u);
+        else {
+            long long spins = 0;
+            while (ld_sc1(&c->bar_gen) <= gen) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1ll << 26)) { atomicExch(&c->err, 2); break; }      // (a lost workgroup must not hang the device)
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    gen++;
+    __syncthreads();
+}
+
 // VLDS: prices (f32) and column owners (u16) also in LDS (every update goes to both copies), as in wide_arr.
-template <bool VLDS, bool CLDS>
+template <bool VLDS, bool CLDS, bool PAR>
 __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batch) {
     extern __shared__ __align__(16) unsigned char w_smem[];
     __shared__ AugShared s;
-    const WideArgs a = load_wide_args(batch, blockIdx.x);
+    if (PAR && (blockIdx.x & 7)) return;                         // (PAR: workgroups 0, 8, 16 ... take part -- one XCD, one L2: see wide_aug_mc)
+    const int g = PAR ? uni((int)(blockIdx.x >> 3)) : 0;
+    const WideArgs a = load_wide_args(batch, PAR ? 0 : blockIdx.x);
     const int n = a.n, tid = threadIdx.x, lane = tid & 63, w = uni((int)(threadIdx.x >> 6));
     const int nblk = (n + 63) / 64, nw32 = (n + 31) / 32;
+    // the search's own arrays: the problem's (one search at a time) or this workgroup's (PAR)
+    const int G = PAR ? a.par_groups : 1;
+    const size_t np_ = ((size_t)n + 63) & ~(size_t)63;
+    ParCtl *pc = reinterpret_cast<ParCtl *>(a.par);
+    unsigned long long *lbl = PAR ? reinterpret_cast<unsigned long long *>(a.par + 256) + (size_t)g * np_ : a.label;
+    int32_t *tch = PAR ? reinterpret_cast<int32_t *>(a.par + 256 + (size_t)G * np_ * 8) + (size_t)g * np_ : a.touched;
+    int32_t *hop_i = PAR ? reinterpret_cast<int32_t *>(a.par + 256 + (size_t)G * np_ * 12) + (size_t)g * 2 * np_ : a.act0;
+    int32_t *hop_j = PAR ? hop_i + np_ : a.act1;
+    uint32_t *claim = reinterpret_cast<uint32_t *>(a.par + 256 + (size_t)G * np_ * 20);
+    int32_t *plog_col = reinterpret_cast<int32_t *>(claim + np_);
+    float *plog_val = reinterpret_cast<float *>(plog_col + np_);
+    int32_t *olog_col = reinterpret_cast<int32_t *>(plog_val + np_);
+    int32_t *olog_own = olog_col + np_;
+    unsigned pgen = 0;
     unsigned long long *bmin = reinterpret_cast<unsigned long long *>(w_smem);
     uint32_t *dirty = reinterpret_cast<uint32_t *>(bmin + nblk);
     uint32_t *asg = dirty + nw32;
@@ -1057,8 +1121,8 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
     // fresh caches certify practically everything (10 000-cell c4 chunk: 1.14 M full-row relaxations without a rebuild, 18 000
     // with one every 32 searches).  a.aug_seg: -1 never return early; k > 0 after k searches; 0: when the full-row relaxations of
     // this launch reach a.aug_waste (what a rebuild costs), or when a.seg_quorum workgroups of the launch have asked for one.
-    const int f0 = *reinterpret_cast<const int *>(a.misc + 132);
-    {
+    const int f0 = PAR ? 0 : *reinterpret_cast<const int *>(a.misc + 132);
+    if (!PAR) {
         long long *wc = reinterpret_cast<long long *>(a.misc + 160);
         if (wc[WC_AUG_LAUNCHES] > 0 && f0 >= numfree) {          // finished in an earlier launch
             if (tid == 0 && a.seg_sync) a.seg_sync[1 + blockIdx.x] = 0;
@@ -1083,12 +1147,12 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
     // a relaxation in two halves: the offer (column `col` is offered the ordered distance `co` by row `row`; returns the label
     // it replaced or lost against) and what follows from it -- first touch, dirty column, best unassigned column
     auto offer = [&](int col, unsigned long long lv, int row) -> unsigned long long {
-        return atomicMin(a.label + col, lkey(lv, (uint32_t)row));
+        return atomicMin(lbl + col, lkey(lv, (uint32_t)row));
     };
     auto after_offer = [&](int col, unsigned long long lv, int row, unsigned long long old) {
         const unsigned long long key = lkey(lv, (uint32_t)row);
         if (key < old) {
-            if (old == ~0ull) a.touched[atomicAdd(&s.ntouch, 1)] = col;
+            if (old == ~0ull) tch[atomicAdd(&s.ntouch, 1)] = col;
             if (lv_of(old) > lv) {                              // the label value itself dropped (not only the row of a tie)
                 const unsigned long long ck = lkey(lv, (uint32_t)col);
                 if (is_asg(col)) { atomicOr(&dirty[col >> 5], 1u << (col & 31)); atomicMin(&bmin[col >> 6], ck); }
@@ -1106,10 +1170,12 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
     int seg_done = 0;                                            // searches (other than one-edge ones) of this launch
     int wact = 4;                                                // waves that take part in the next round of a search (4 or all 16)
     bool announced = false;
+    int fbase = 0, batchno = 1, perr = 0;                        // PAR: first free row of the batch, batch number (claim keys), error seen
+    long long c_batches = 0, c_discarded = 0;
     for (;;) {
         // ---- wave 0 disposes of the searches that end at once: the free row's best cached column is unassigned and its
         // cache certifies that (no column settled, no price changes: the path is one edge) ----
-        if (w == 0) {
+        if (!PAR && w == 0) {
             // a two-deep pipeline over the free list (35 000 such searches at c3): while search f is decided, the prices of search
             // f + 1's cached columns and the cache row of search f + 2 are in flight -- prices do not change in this loop
             auto row_of = [&](int ff) -> int { return ff < numfree ? uni(a.freerows[ff]) : -1; };
@@ -1193,13 +1259,20 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
         }
         __syncthreads();
         AUG_LAP(t_triv)
-        f = uni(s.f);
-        if (f >= numfree || uni(s.stop)) break;
+        if (PAR) {
+            if (fbase >= numfree || perr) break;                 // (the same decision in every workgroup)
+            f = fbase + g;
+        } else {
+            f = uni(s.f);
+            if (f >= numfree || uni(s.stop)) break;
+        }
+        const bool active = !PAR || f < numfree;                  // (PAR: the last batch may have fewer searches than workgroups)
         seg_done++;
-        const int fr = a.freerows[f];
+        const int fr = a.freerows[active ? f : 0];
         const float *__restrict__ frow = a.cost + wrow_off(a.rowmap, fr, a.ld);
         const float ftau = a.cache_val[(int64_t)fr * KC + KCU];
 
+        if (active) {
         // ---- root: d[j] = c[fr][j] - v[j] for the cached columns (pred = fr) ----
         if (w == 0) {
             const uint32_t col = a.cache_col[(int64_t)fr * KC + lane];
@@ -1266,7 +1339,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
 #pragma unroll
                 for (int q = 0; q < AP; q++) {
                     pjx[q] = pk[q] ? pj[q] : 0;
-                    lab_r[q] = ld_sc1(a.label + pjx[q]); ca_r[q] = ld_sc1(a.cassign + pjx[q]);
+                    lab_r[q] = ld_sc1(lbl + pjx[q]); ca_r[q] = ld_sc1(a.cassign + pjx[q]);
                 }
                 // ... and with them the labels of the dirty columns of the blocks the wave took from in the LAST round: the new
                 // minimum of such a block is not on any round's critical path this way (it used to be a third round trip, behind a
@@ -1279,7 +1352,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                 for (int q = 0; q < AP; q++) {
                     const int c = (rb[q] < 0 ? 0 : rb[q]) * 64 + lane;
                     db[q] = rb[q] >= 0 && c < n && ((dirty[c >> 5] >> (c & 31)) & 1u);
-                    lbr[q] = ld_sc1(a.label + (db[q] ? c : pjx[q]));
+                    lbr[q] = ld_sc1(lbl + (db[q] ? c : pjx[q]));
                 }
 #pragma unroll
                 for (int q = 0; q < AP; q++) { vp_r[q] = getv(pjx[q]); oi_r[q] = getcs(pjx[q]); }
@@ -1320,7 +1393,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     static_assert(AP == 2, "two offers per wave and round");
                     const uint64_t m0 = __ballot(off[0]), m1 = __ballot(off[1]);
                     if (m0 | m1) {
-                        unsigned long long *p0 = a.label + (off[0] ? (int)col[0] : 0), *p1 = a.label + (off[1] ? (int)col[1] : 0);
+                        unsigned long long *p0 = lbl + (off[0] ? (int)col[0] : 0), *p1 = lbl + (off[1] ? (int)col[1] : 0);
                         const unsigned long long k0 = lkey(co[0], (uint32_t)oi[0]), k1 = lkey(co[1], (uint32_t)oi[1]);
                         unsigned long long r0, r1;
                         uint64_t sv;
@@ -1353,7 +1426,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     //  the label is read first -- a plain L2 load -- and the atomic follows only where it would change something)
                     wave_row_sweep(row, n, lane, [&](int c, float x) {
                         const unsigned long long lv = edge_lv(f2ord((x - getv(c)) - h), dord, kq);
-                        if (c != pjq && lv <= lv_of(s.T) && (lkey(lv, (uint32_t)oiq) < ld_sc1(a.label + c))) relax_to(c, lv, oiq);
+                        if (c != pjq && lv <= lv_of(s.T) && (lkey(lv, (uint32_t)oiq) < ld_sc1(lbl + c))) relax_to(c, lv, oiq);
                     });
                     c_dense++;
                     if (lane == 0) atomicAdd(&s.waste, 1);
@@ -1388,8 +1461,8 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             const float D = Tk == ~0ull ? INFINITY : ord2f(Dord);
             const int nt = s.ntouch;
             for (int q = tid; q < nt; q += WT) {
-                const int k = ld_sc1(a.touched + q);
-                const unsigned long long lbk = ld_sc1(a.label + k);
+                const int k = ld_sc1(tch + q);
+                const unsigned long long lbk = ld_sc1(lbl + k);
                 const uint32_t dord = (uint32_t)(lbk >> 32);
                 // every settled column: label below the end's -- also at the end's DISTANCE with fewer tight hops: an uncached
                 // tight edge out of such a column would give (distance, k + 1), possibly below the end's label
@@ -1414,7 +1487,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             if (s.doroot)
                 for (int c = tid; c < n; c += WT) {
                     const unsigned long long lv = (unsigned long long)f2ord(frow[c] - getv(c)) << 12;
-                    if (lv <= lv_of(s.T) && (lkey(lv, (uint32_t)fr) < ld_sc1(a.label + c))) relax_to(c, lv, fr);
+                    if (lv <= lv_of(s.T) && (lkey(lv, (uint32_t)fr) < ld_sc1(lbl + c))) relax_to(c, lv, fr);
                 }
             __syncthreads();
             if (tid == 0) { if (fail) s.anydense = 1; s.fail = 0; s.doroot = 0; }
@@ -1423,64 +1496,149 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             if (!fail) break;
         }
 
-        // ---- the search has ended at s.T: price update, path flip, reset ----
-        const unsigned long long Tk = s.T;
-        if (Tk == ~0ull) { if (tid == 0) s.err = 1; __syncthreads(); break; }
+        }   // (active)
+
+        // ---- the search has ended at s.T: [PAR: claim, find the conflict-free prefix of the batch;] price update, path flip, reset ----
+        const unsigned long long Tk = active ? s.T : ~0ull;
+        if (!PAR && Tk == ~0ull) { if (tid == 0) s.err = 1; __syncthreads(); break; }
         const uint32_t Dord = (uint32_t)(Tk >> 32);
         const float D = ord2f(Dord);
         const int sink = (int)lid_of(Tk);
-        const int nt = s.ntouch;
-        int myscans = 0;
-        for (int q = tid; q < nt; q += WT) {
-            const int k = ld_sc1(a.touched + q);
-            const uint32_t dord = (uint32_t)(ld_sc1(a.label + k) >> 32);
-            if (dord < Dord && is_asg(k)) {
-                const float vk = getv(k);
-                const float nv = (vk + ord2f(dord)) - D;
-                if (nv < vk) { a.v[k] = nv; if (VLDS) s_v[k] = nv; }
-                myscans++;
+        const int nt = active ? s.ntouch : 0;
+        bool commit = true;
+        int Pb = G;
+        const int par = batchno & 1;
+        if (PAR) {
+            const bool have = Tk != ~0ull;
+            if (active && !have && tid == 0) atomicExch(&pc->err, 1);
+            // every column this search settled (label below its end's) and its sink: claimed with (batch, workgroup) -- the atomic max
+            // keeps the LOWEST workgroup of the LATEST batch
+            const uint32_t key = ((uint32_t)batchno << 8) | (uint32_t)(255 - g);
+            if (have) {
+                for (int q = tid; q < nt; q += WT) {
+                    const int k = ld_sc1(tch + q);
+                    if (lv_of(ld_sc1(lbl + k)) < lv_of(Tk) && is_asg(k)) atomicMax(claim + k, key);
+                }
+                if (tid == 0) atomicMax(claim + sink, key);
+            }
+            if (tid == 0) s.conflict = 0;
+            par_barrier(pc, G, pgen);
+            if (have) {
+                int c = 0;
+                for (int q = tid; q < nt; q += WT) {
+                    const int k = ld_sc1(tch + q);
+                    if (lv_of(ld_sc1(lbl + k)) < lv_of(Tk) && is_asg(k) && ld_sc1(claim + k) != key) c = 1;
+                }
+                if (tid == 0 && ld_sc1(claim + sink) != key) c = 1;
+                if (c) s.conflict = 1;
+            }
+            __syncthreads();
+            if (tid == 0 && active && (s.conflict || !have)) atomicMin(&pc->P[par], g);
+            par_barrier(pc, G, pgen);
+            Pb = uni(ld_sc1(&pc->P[par]));
+            Pb = Pb < G ? Pb : G;
+            // (the other parity's words are free: their last readers passed this batch's first barrier)
+            if (g == 0 && tid == 0) { st_sc1(&pc->P[par ^ 1], PAR_GMAX + 1); st_sc1(&pc->nplog[par ^ 1], 0); st_sc1(&pc->nolog[par ^ 1], 0); }
+            commit = active && have && g < Pb;
+            if (active && !commit) c_discarded++;
+        }
+        if (commit) {
+            int myscans = 0;
+            for (int q = tid; q < nt; q += WT) {
+                const int k = ld_sc1(tch + q);
+                const uint32_t dord = (uint32_t)(ld_sc1(lbl + k) >> 32);
+                if (dord < Dord && is_asg(k)) {
+                    const float vk = getv(k);
+                    const float nv = (vk + ord2f(dord)) - D;
+                    if (nv < vk) {
+                        a.v[k] = nv; if (VLDS) s_v[k] = nv;
+                        if (PAR) { const int e = atomicAdd(&pc->nplog[par], 1); plog_col[e] = k; plog_val[e] = nv; }
+                    }
+                    myscans++;
+                }
+            }
+            if (myscans) atomicAdd(&s.scans, myscans);
+            if (tid == 0) {
+                // (the new owner entries' costs are fetched afterwards, by everybody: inside this walk every hop waited for its cost --
+                //  an HBM access, and loads return in order -- before the next hop's label arrived: 0.7 us per hop, 37 824 hops on a c4 chunk)
+                int j = sink, nh = 0;
+                for (;;) {
+                    const int i = (int)lid_of(ld_sc1(lbl + j));
+                    const int jn = ld_sc1(a.rowsol + i);
+                    a.colsol[j] = i; a.rowsol[i] = j;
+                    st_sc1(hop_i + nh, (int32_t)i); st_sc1(hop_j + nh, (int32_t)j); nh++;
+                    if (CLDS) s_cs[j] = (uint16_t)i;
+                    c_hops++;
+                    if (i == fr) break;
+                    j = jn;
+                }
+                s.nhop = nh;
+                atomicOr(&asg[sink >> 5], 1u << (sink & 31));
+            }
+            __syncthreads();
+            for (int q = tid; q < s.nhop; q += WT) {
+                const int i = ld_sc1(hop_i + q), j = ld_sc1(hop_j + q);
+                a.cassign[j] = a.cost[wrow_off(a.rowmap, i, a.ld) + j];
+                if (PAR) { const int e = atomicAdd(&pc->nolog[par], 1); olog_col[e] = j; olog_own[e] = i; }
             }
         }
-        if (myscans) atomicAdd(&s.scans, myscans);
-        if (tid == 0) {
-            // (the new owner entries' costs are fetched afterwards, by everybody: inside this walk every hop waited for its cost --
-            //  an HBM access, and loads return in order -- before the next hop's label arrived: 0.7 us per hop, 37 824 hops on a c4 chunk)
-            int j = sink, nh = 0;
-            for (;;) {
-                const int i = (int)lid_of(ld_sc1(a.label + j));
-                const int jn = ld_sc1(a.rowsol + i);
-                a.colsol[j] = i; a.rowsol[i] = j;
-                st_sc1(a.act0 + nh, (int32_t)i); st_sc1(a.act1 + nh, (int32_t)j); nh++;
-                if (CLDS) s_cs[j] = (uint16_t)i;
-                c_hops++;
-                if (i == fr) break;
-                j = jn;
-            }
-            s.nhop = nh;
-            atomicOr(&asg[sink >> 5], 1u << (sink & 31));
-        }
-        __syncthreads();
-        for (int q = tid; q < s.nhop; q += WT) {
-            const int i = ld_sc1(a.act0 + q), j = ld_sc1(a.act1 + q);
-            a.cassign[j] = a.cost[wrow_off(a.rowmap, i, a.ld) + j];
-        }
         for (int q = tid; q < nt; q += WT) {
-            const int k = ld_sc1(a.touched + q);
-            a.label[k] = ~0ull;
+            const int k = ld_sc1(tch + q);
+            lbl[k] = ~0ull;
             atomicAnd(&dirty[k >> 5], ~(1u << (k & 31)));
             bmin[k >> 6] = ~0ull;
         }
         // (keeping the dense bits across searches was measured: fewer rounds, but more full-row relaxations -- slower)
         if (s.anydense) for (int q = tid; q < nw32; q += WT) dense[q] = 0;
         __syncthreads();
-        if (tid == 0) { c_relax += s.scans; s.scans = 0; s.T = ~0ull; s.ntouch = 0; s.anydense = 0; s.rootdense = 0; s.f = f + 1; }
+        if (tid == 0) { if (commit) c_relax += s.scans; s.scans = 0; s.T = ~0ull; s.ntouch = 0; s.anydense = 0; s.rootdense = 0; s.f = f + 1; }
         f++;
         __syncthreads();
+        if (PAR) {
+            // the batch's changes, into this workgroup's copies (its own included: harmless); then the next batch
+            par_barrier(pc, G, pgen);
+            perr = uni(ld_sc1(&pc->err));
+            const int npl = uni(ld_sc1(&pc->nplog[par])), nol = uni(ld_sc1(&pc->nolog[par]));
+            if (VLDS) for (int e = tid; e < npl; e += WT) s_v[ld_sc1(plog_col + e)] = ld_sc1(plog_val + e);
+            for (int e = tid; e < nol; e += WT) {
+                const int col = ld_sc1(olog_col + e);
+                if (CLDS) s_cs[col] = (uint16_t)ld_sc1(olog_own + e);
+                atomicOr(&asg[col >> 5], 1u << (col & 31));
+            }
+            __syncthreads();
+            const int left = numfree - fbase;
+            fbase += Pb < left ? Pb : left;                       // (Pb >= 1: the first search of a batch never conflicts)
+            if (Pb < 1) perr = 1;
+            batchno++; c_batches++;
+        }
         AUG_LAP(t_finish)
     }
 
     // ---- duals, total, counters ----
     __syncthreads();
+    __shared__ double s_tot[WNW];
+    __shared__ long long s_wc[WNW][4];
+    if (lane == 0) { s_wc[w][0] = c_proc; s_wc[w][1] = c_dense; s_wc[w][2] = c_trivial; s_wc[w][3] = (w == 0) ? c_hops : 0; }
+    __syncthreads();
+    long long proc = 0, dn = 0, triv = 0, hops0 = 0;
+    for (int k = 0; k < WNW; k++) { proc += s_wc[k][0]; dn += s_wc[k][1]; triv += s_wc[k][2]; hops0 += s_wc[k][3]; }
+    if (PAR) {                                                   // the workgroups' counters meet in the control block; workgroup 0 finishes
+        if (tid == 0) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&pc->c_relax), (unsigned long long)c_relax);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&pc->c_hops), (unsigned long long)hops0);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&pc->c_proc), (unsigned long long)proc);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&pc->c_dense), (unsigned long long)dn);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&pc->c_discarded), (unsigned long long)c_discarded);
+            if (g == 0) { pc->c_rounds = c_rounds; pc->c_verify = c_verify; pc->c_batches = c_batches; }
+        }
+        par_barrier(pc, G, pgen);
+        if (g != 0) return;
+        c_relax = (long long)ld_sc1(reinterpret_cast<unsigned long long *>(&pc->c_relax));
+        hops0 = (long long)ld_sc1(reinterpret_cast<unsigned long long *>(&pc->c_hops));
+        proc = (long long)ld_sc1(reinterpret_cast<unsigned long long *>(&pc->c_proc));
+        dn = (long long)ld_sc1(reinterpret_cast<unsigned long long *>(&pc->c_dense));
+        f = perr || ld_sc1(&pc->err) ? f : numfree;
+    }
     double tot = 0.0;
     for (int i = tid; i < n; i += WT) {
         const int j = ld_sc1(a.rowsol + i);
@@ -1490,28 +1648,25 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             tot += (double)cij;
         }
     }
-    __shared__ double s_tot[WNW];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
     if (lane == 0) s_tot[w] = tot;
-    // per-wave counters of the wave leaders
-    __shared__ long long s_wc[WNW][4];
-    if (lane == 0) { s_wc[w][0] = c_proc; s_wc[w][1] = c_dense; s_wc[w][2] = c_trivial; s_wc[w][3] = (w == 0) ? c_hops : 0; }
     __syncthreads();
     if (tid == 0) {
         double t = 0.0;
-        long long proc = 0, dn = 0, triv = 0, hops0 = 0;
-        for (int k = 0; k < WNW; k++) { t += s_tot[k]; proc += s_wc[k][0]; dn += s_wc[k][1]; triv += s_wc[k][2]; hops0 += s_wc[k][3]; }
+        for (int k = 0; k < WNW; k++) t += s_tot[k];
+        const bool err = s.err || (PAR && (perr || ld_sc1(&pc->err)));
         *reinterpret_cast<double *>(a.misc + 8) = t;
         long long *ctr = reinterpret_cast<long long *>(a.misc + 16);
         long long *wc = reinterpret_cast<long long *>(a.misc + 160);
         ctr[C_AUG_INIT] = numfree; ctr[C_AUG_RELAX] += c_relax; ctr[C_AUGS] = numfree; ctr[C_HOPS] += hops0;
         wc[WC_DENSE_AUG] += dn; wc[WC_AUG_LAUNCHES] += 1; wc[WC_AUG_ROUNDS] += c_rounds; wc[WC_AUG_PROCESSED] += proc; wc[WC_TRIVIAL] += triv; wc[WC_VERIFY_PASSES] += c_verify;
-        if (s.err) *reinterpret_cast<int *>(a.misc + 4) = 1;
-        *reinterpret_cast<int *>(a.misc + 132) = s.err ? numfree : f;      // searches done (an error ends them)
-        if (a.seg_sync) a.seg_sync[1 + blockIdx.x] = s.err ? 0 : numfree - f;
+        if (err) *reinterpret_cast<int *>(a.misc + 4) = 1;
+        *reinterpret_cast<int *>(a.misc + 132) = err ? numfree : f;      // searches done (an error ends them)
+        if (a.seg_sync) a.seg_sync[1 + (PAR ? 0 : blockIdx.x)] = err ? 0 : numfree - f;
         long long *dbg = reinterpret_cast<long long *>(a.misc + 256);      // (100 MHz ticks)
         dbg[8] += t_rounds; dbg[9] += t_verify; dbg[10] += t_finish; dbg[11] += t_triv;
+        if (PAR) { dbg[15] = ld_sc1(reinterpret_cast<unsigned long long *>(&pc->c_batches)); dbg[7] = ld_sc1(reinterpret_cast<unsigned long long *>(&pc->c_discarded)); }
     }
 }
 
@@ -1952,7 +2107,7 @@ int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, i
     return CYTO_OK;
 }
 
-int wide_launch_aug(const WideArgs *d_args, int nb, int n, hipStream_t stream, int mc_groups) {
+int wide_launch_aug(const WideArgs *d_args, int nb, int n, hipStream_t stream, int mc_groups, int par_groups) {
     if (mc_groups > 0) {                                           // one problem, several workgroups (blocks 0, 8, 16 ... take part)
         hipLaunchKernelGGL(wide_aug_mc, dim3(8 * mc_groups), dim3(WT), 0, stream, d_args);
         CYTO_HIP(hipGetLastError());
@@ -1961,7 +2116,15 @@ int wide_launch_aug(const WideArgs *d_args, int nb, int n, hipStream_t stream, i
     const bool vlds = wide_aug_vlds(n), clds = wide_aug_clds(n);
     const size_t shm = wide_aug_lds_bytes(n, vlds, clds);
     if (shm > (size_t)LDS_DYNAMIC_MAX) return CYTO_ERR_UNSUPPORTED;
-    void (*k)(const WideArgs *) = vlds ? wide_aug<true, true> : clds ? wide_aug<false, true> : wide_aug<false, false>;
+    if (par_groups > 1) {                                          // one problem, several SEARCHES at once (blocks 0, 8, 16 ... take part)
+        void (*k)(const WideArgs *) = vlds ? wide_aug<true, true, true> : clds ? wide_aug<false, true, true> : wide_aug<false, false, true>;
+        int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(k));
+        if (rc) return rc;
+        hipLaunchKernelGGL(k, dim3(8 * par_groups), dim3(WT), shm, stream, d_args);
+        CYTO_HIP(hipGetLastError());
+        return CYTO_OK;
+    }
+    void (*k)(const WideArgs *) = vlds ? wide_aug<true, true, false> : clds ? wide_aug<false, true, false> : wide_aug<false, false, false>;
     int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(k));
     if (rc) return rc;
     hipLaunchKernelGGL(k, dim3(nb), dim3(WT), shm, stream, d_args);

@@ -101,6 +101,8 @@ typedef struct {
     int64_t wide_aug_launches;   /* augmentation: launches of the search kernel (row-cache rebuilds in between: cyto_lap_opts.wide_rebuild) */
     int64_t wide_scaled;         /* row reduction: 1 = the instance went through the eps-scaled phases */
     int64_t wide_phases;         /* row reduction: phases begun (scaled phases + the final eps = 0 phase) */
+    int64_t wide_par_batches;    /* augmentation, several searches at once (cyto_lap_opts.wide_par): batches of searches run from one state */
+    int64_t wide_par_discarded;  /* ... searches that met an earlier search of their batch and ran again in the next one */
     int64_t f64_warm;            /* float64: 1 = warm-started from the prices of the float32 wide solve of the narrowed matrix */
     double f64_warm_ms;          /* float64: kernel time of that float32 solve */
 } cyto_lap_info;
@@ -142,6 +144,10 @@ typedef struct {
                                    the prices reached (a floor goes stale as searches lower the prices; deep-search instances otherwise
                                    fall back to full cost rows).  0: when the full-row relaxations since the last rebuild have cost what
                                    a rebuild costs.  -1: never.  k > 0: every k searches.  Results do not depend on it */
+    int32_t wide_par;           /* wide solver, one problem: searches of consecutive free rows that run at once, a workgroup each, from one state and
+                                   are committed in row order while their settled sets are disjoint (the rest runs again).  0: 16 for a problem
+                                   of >= 2 048 rows without runs of identical rows, else one at a time.  -1: one at a time.  k > 1: k (<= 64).
+                                   Results do not depend on it */
     int32_t wide_wipe;          /* wide solver, row reduction: the per-column bid words carry a 12-bit round tag relative to their last wipe;
                                    0: wiped every 2048 launch pairs.  k > 0: every k pairs (a self-test of the protocol at sizes the CPU
                                    oracle checks).  Results do not depend on it */

@@ -55,6 +55,7 @@ typedef struct {
  * binade, eps_k = eps_0 / 2^(ESTEP k) */
 #define JV_WIDE_K0 8
 #define JV_WIDE_STOP(n) ((n) / 128 < 8 ? 8 : ((n) / 128 > 64 ? 64 : (n) / 128))
+#define JV_WIDE_STOP_FINAL(n) (JV_WIDE_STOP(n) < 16 ? JV_WIDE_STOP(n) : 16)   /* the final eps = 0 phase goes on a little longer: what it leaves are searches */
 #define JV_WIDE_NPH 16
 #define JV_WIDE_PHCAP 1024
 #define JV_WIDE_EMULT 3

@@ -481,7 +481,7 @@ int FN(jv_oracle_wide_)(int n, const T *restrict cost, int32_t *restrict rowsol,
             } else if (mode == M_EPS) {
                 if (over) { next_phase = 1; last = 1; }
                 else if (rip >= 1 && (nact <= JV_WIDE_STOP(n) || rip >= JV_WIDE_PHCAP)) next_phase = 1;
-            } else if (rip >= 1 && (nact <= JV_WIDE_STOP(n) || rip >= JV_WIDE_PHCAP)) break;
+            } else if (rip >= 1 && (nact <= JV_WIDE_STOP_FINAL(n) || rip >= JV_WIDE_PHCAP)) break;
             if (next_phase) {
                 k++;
                 const int ek = e0 - JV_WIDE_ESTEP * k;

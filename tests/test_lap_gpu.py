@@ -402,6 +402,51 @@ def test_duplicate_row_group_state_in_global_memory(aug):
     _check(np.random.default_rng(4).random((700, 700)).astype(np.float32), np.float32, dict(augmentation=1, aux_state_global=1))
 
 
+def test_chain_solver_seed_2407_results_exact_one_scan_apart():
+    # Pinned, not yet explained: on this duplicated-row instance of the randomised stress (tools/stress_lap.py
+    # seed 2407: n = 4 750, rows in runs of identical copies) the CHAIN solver (mode 1, dense augmentation kernel with duplicate-row
+    # elision) counts 126 544 augmentation scans where the classic oracle counts 126 543 -- indices, duals and every other counter
+    # are identical bit for bit.  (An extra scan of a column AT the final distance of a search is unobservable in the results: only
+    # columns scanned below it get a price update.)  The default solvers do not run this kernel.
+    from tools.stress_lap import make
+    rng = np.random.default_rng(1000 + 2407)
+    n = int(rng.integers(3000, 6000))
+    c = make("dup", n, rng)
+    o = jv_oracle(c, np.float32)
+    g = lap_solve(c, np.float32, return_info=True, opts=CHAIN)
+    for k in ("rowsol", "colsol", "u", "v"):
+        assert np.array_equal(g[k], o[k]), k
+    od, gd = o["stats"].as_dict(), g["info"].as_dict()
+    for k in STAT_KEYS:
+        if k != "scans_aug_relax":
+            assert gd[k] == od[k], (k, gd[k], od[k])
+    assert 0 <= gd["scans_aug_relax"] - od["scans_aug_relax"] <= 1
+    gw, ow = _check_wide(c)                                  # the wide solver: exact, counters included
+    assert abs(ow["total"] - o["total"]) <= 1e-5 * max(1.0, abs(o["total"]))
+
+
+@pytest.mark.parametrize("par", [2, 5, 16])
+def test_wide_several_searches_at_once(par):
+    # cyto_lap_opts.wide_par: the searches of `par` consecutive free rows run at once, a workgroup each, from ONE state; the longest
+    # prefix (in row order) whose settled sets and sinks are pairwise disjoint is committed, the rest runs again in the next batch --
+    # exactly what one search after the other computes: the oracle's answer and its semantic counters bit for bit, whatever `par`
+    rng = np.random.default_rng(90 + par)
+    cases = [rng.random((n, n)).astype(np.float32) for n in (3, 64, 700, 2300, 4300)]
+    cases.append(np.repeat(rng.random((150, 600)), 4, axis=0).astype(np.float32))                     # duplicated rows
+    cases.append(rng.integers(0, 10, (400, 400)).astype(np.float32))                                    # heavy ties: most searches collide
+    prof = rng.normal(size=(6, 64)).astype(np.float32)                                                  # few cell types: full-row relaxations
+    rows = prof[rng.integers(0, 6, 1200)] + 0.05 * rng.normal(size=(1200, 64)).astype(np.float32)
+    cols = prof[rng.integers(0, 6, 1200)] + 0.05 * rng.normal(size=(1200, 64)).astype(np.float32)
+    cases.append(-(rows @ cols.T).astype(np.float32))
+    seen = 0
+    for c in cases:
+        for rounds in (0, 2, -1):                                # (a short or no row reduction leaves many searches)
+            g, o = _check_wide(c, opts=dict(wide_par=par), rounds=rounds)
+            seen += g["info"].wide_par_batches
+            assert g["info"].wide_par_batches <= max(1, g["info"].augmentations)
+    assert seen > 0
+
+
 # ---- float64 by default: warm-started from the float32 wide solve of the narrowed matrix (oracle: jv_oracle_warm_f64) ----
 
 def _check_warm(c64):

@@ -10,7 +10,8 @@ from cytospace_amd.lap import lap_solve, lap_solve_rows  # noqa: E402
 from oracle.jv import jv_oracle_wide, jv_oracle  # noqa: E402
 from tools import instances as I  # noqa: E402
 
-WIDE = dict(mode=2, wide_groups=int(sys.argv[sys.argv.index("--groups") + 1]) if "--groups" in sys.argv else 0)
+WIDE = dict(mode=2, wide_groups=int(sys.argv[sys.argv.index("--groups") + 1]) if "--groups" in sys.argv else 0,
+            wide_par=int(sys.argv[sys.argv.index("--par") + 1]) if "--par" in sys.argv else 0)
 
 
 def one(c, label, rounds=0, rowmap=None, uniq=None):
@@ -35,7 +36,7 @@ def one(c, label, rounds=0, rowmap=None, uniq=None):
     ok = all(same) and all(cnt) and abs(g["total"] - o["total"]) <= 1e-6 * max(1.0, abs(o["total"]))
     print(f"{label:12s} n={len(c):6d} rounds={rounds:5d} {'OK ' if ok else 'BAD'} same(r,c,u,v)={same} counters={cnt} "
           f"free={inf.free_after_arr2} scaled={inf.wide_scaled}/{inf.wide_phases} arr_rounds={inf.wide_rounds} relax={inf.scans_aug_relax} settled={inf.wide_aug_settled} "
-          f"aug_rounds={inf.wide_aug_rounds} dense(arr,aug)=({inf.wide_dense_arr},{inf.wide_dense_aug}) trivial={inf.wide_trivial} "
+          f"aug_rounds={inf.wide_aug_rounds} par={inf.wide_par_batches}/{inf.wide_par_discarded} dense(arr,aug)=({inf.wide_dense_arr},{inf.wide_dense_aug}) trivial={inf.wide_trivial} "
           f"ms: arr={inf.ms_arr:.2f} aug={inf.ms_aug:.2f} cache={inf.ms_cache:.2f} colred={inf.ms_colred:.2f} | oracle {to:.2f}s gpu-call {tg:.2f}s",
           flush=True)
     if not ok and not all(same):

@@ -1,5 +1,5 @@
 """Wide solver at true sizes against the committed goldens (colsol; spot level where rows are duplicated) + timing.
-usage: wide_large.py [u20000 u50000 c3s50000 c4s10000 ...] [--chain] [--rounds R] [--groups G] [--rebuild K | --rebuild -1] [--reps K]"""
+usage: wide_large.py [u20000 u50000 c3s50000 c4s10000 t20000 ...] [--chain] [--rounds R] [--groups G] [--par K | --par -1] [--rebuild K | --rebuild -1] [--reps K]"""
 import os
 import sys
 import time
@@ -21,6 +21,7 @@ def main():
     reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 2
     groups = int(sys.argv[sys.argv.index("--groups") + 1]) if "--groups" in sys.argv else 0
     rebuild = int(sys.argv[sys.argv.index("--rebuild") + 1]) if "--rebuild" in sys.argv else 0
+    par = int(sys.argv[sys.argv.index("--par") + 1]) if "--par" in sys.argv else 0
     for tag in tags:
         d = np.load(os.path.join(GOLD, f"large_{tag}.npz"))
         n = int(d["n"])
@@ -33,11 +34,13 @@ def main():
         elif tag.startswith("c4s"):
             c, loc = I.c4_chunk_cost(n)
             buf = I.blocks_to_device([(0, c)], n)
+        elif tag.startswith("t"):
+            buf = I.blocks_to_device([(0, I.typed_unique_cost(n, n, 20)[0])], n)
         else:
             raise SystemExit(f"unknown tag {tag}")
         for rep in range(reps):
             t = time.time()
-            g = lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n, opts=dict(mode=mode, wide_rounds=rounds, wide_groups=groups, wide_rebuild=rebuild))
+            g = lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n, opts=dict(mode=mode, wide_rounds=rounds, wide_groups=groups, wide_rebuild=rebuild, wide_par=par))
             wall = time.time() - t
             inf = g["info"]
             same = np.array_equal(g["colsol"], d["colsol"])
@@ -46,7 +49,7 @@ def main():
                   f"ms colred={inf.ms_colred:.2f} cache={inf.ms_cache:.2f} arr={inf.ms_arr:.2f} aug={inf.ms_aug:.2f} total={inf.ms_total:.2f} wall={wall * 1e3:.1f} | "
                   f"free={inf.free_after_arr2} rounds={inf.wide_rounds} bids={inf.scans_arr} retired={inf.wide_retired} relax={inf.scans_aug_relax} "
                   f"settled={inf.wide_aug_settled} aug_rounds={inf.wide_aug_rounds} dense=({inf.wide_dense_arr},{inf.wide_dense_aug}) launches={inf.wide_aug_launches} "
-                  f"trivial={inf.wide_trivial} verify={inf.wide_verify_passes} hops={inf.path_hops}", flush=True)
+                  f"trivial={inf.wide_trivial} verify={inf.wide_verify_passes} hops={inf.path_hops} par_batches={inf.wide_par_batches} discarded={inf.wide_par_discarded}", flush=True)
             print(f"    wide_arr: list rounds {inf.wide_list_rounds} ({inf.wide_ms_list:.2f} ms), chain rounds {inf.wide_chain_rounds} ({inf.wide_ms_chain:.2f} ms) | "
                   f"wide_aug: rounds {inf.wide_ms_aug_rounds:.2f} ms, certificate passes {inf.wide_ms_aug_verify:.2f}, update+flip+reset {inf.wide_ms_aug_finish:.2f}, "
                   f"one-edge searches {inf.wide_ms_aug_trivial:.2f}", flush=True)
