@@ -691,15 +691,11 @@ __global__ void wide_sc_check(const WideArgs *__restrict__ batch, int L) {
     int want = 0;
     if (!through) {
         atomicAdd(a.seg_sync, 1);
-        // what a rebuild must beat here: a full-row bid costs its workgroup ~10 us and its round waits for it, a rebuild of all caches
-        // ~1 ms and a pipeline drain -- for a single problem that pays from ~n / 2 full-row bids per group on; never in a coarse
-        // phase (eps_k moves the prices past a fresh cache within a bid or two: those bids do not refresh their caches either)
-        const ScSlot S = sc->slot[L & 1];
+        // (measured on the few-cell-type 20 000^2 instance: a rebuild whenever a group of rounds saw a.arr_waste full-row bids -- ~14
+        //  rebuilds of 1 ms -- gives a 25 ms row reduction; rebuilding only from n / 2 full-row bids per group on and never in the
+        //  coarse phases 34 ms: a round waits for the workgroup with the most full-row bids, so few of them already cost every round)
         const int since = sc->dense - sc->dense_mark;
-        const int thr = gridDim.x == 1 ? (a.arr_waste > a.n / 2 ? a.arr_waste : a.n / 2) : a.arr_waste;
-        const bool coarse = S.mode == SC_EPS && S.k < SC_COARSE;
-        if (a.aug_seg == 0 && !coarse && since >= thr) { want = 1; sc->dense_mark = sc->dense; }
-        if (coarse) sc->dense_mark = sc->dense;
+        if (a.aug_seg == 0 && since >= a.arr_waste) { want = 1; sc->dense_mark = sc->dense; }
     }
     a.seg_sync[1 + blockIdx.x] = want;
 }
