@@ -1308,14 +1308,20 @@ __global__ __launch_bounds__(BLOCK2) void build_row_caches(int n, int64_t ld, co
 // every run, this one copies it to the others (a wave per run; c3: ten rows per spot -- a tenth of the cache-build work).
 __global__ __launch_bounds__(256) void replicate_group_caches(int n, const int32_t *__restrict__ same_prev, uint32_t *__restrict__ cache_col,
                                                                float *__restrict__ cache_val) {
+    // a wave per DESTINATION row (a copy of the row before it): its run's first row is found 64 rows at a time (lane l looks at row
+    // i - l), so a long run -- one spot with thousands of slots, a constant matrix -- is copied by as many waves as it has rows
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
-    for (int f = gw; f < n; f += nw) {
-        if (same_prev[f]) continue;                                        // not the first row of its run
-        if (f + 1 >= n || !same_prev[f + 1]) continue;                     // a run of one
-        const uint32_t c = cache_col[(int64_t)f * KC + lane];
-        const float x = cache_val[(int64_t)f * KC + lane];
-        for (int i = f + 1; i < n && same_prev[i]; i++) { cache_col[(int64_t)i * KC + lane] = c; cache_val[(int64_t)i * KC + lane] = x; }
+    for (int i = gw; i < n; i += nw) {
+        if (!same_prev[i]) continue;                                       // the first row of its run: built, not copied
+        int f = -1;
+        for (int base = i; f < 0; base -= 64) {
+            const int r = base - lane;
+            const uint64_t starts = __ballot(r >= 0 && !same_prev[r]);    // (row 0 always starts a run)
+            if (starts) f = base - (__ffsll((unsigned long long)starts) - 1);
+        }
+        cache_col[(int64_t)i * KC + lane] = cache_col[(int64_t)f * KC + lane];
+        cache_val[(int64_t)i * KC + lane] = cache_val[(int64_t)f * KC + lane];
     }
 }
 
@@ -3032,7 +3038,9 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             const size_t mcb = mcg > 0 ? wide_mc_state_bytes(n) : 0;
             // several searches of ONE problem at once (wide_aug<.., PAR>): by default for a single problem without runs of identical
             // rows (those finish their searches as runs of one-edge steps in the one-workgroup kernel) from 2 048 rows on
-            const bool dup_rows = j.h_ngroups < n && n >= 2;
+            // (runs of identical rows -- a Visium problem's slots: a tenth as many groups as rows -- finish most of their searches as
+            //  runs of one-edge steps in the one-workgroup kernel; a sub-spot chunk's few doubled spots do not matter)
+            const bool dup_rows = n >= 2 && (long long)j.h_ngroups * 5 < (long long)n * 4;
             int parg = (nl != 1 || mcg > 0) ? 0 : (pl.wide_par > 0 ? pl.wide_par : (pl.wide_par < 0 || dup_rows || n < 2048 ? 0 : 16));
             if (parg > WIDE_PAR_GMAX) parg = WIDE_PAR_GMAX;
             if (parg == 1) parg = 0;
@@ -3059,6 +3067,7 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             // faster per element -- and the problems of a batch are rebuilt one after the other while their workgroups all wait)
             wa.aug_waste = (int)std::min<long long>(1 << 30, std::max<long long>(16, (2000000ll + (long long)nl * n * n / 100) / n));
             wa.arr_waste = std::max(8, wa.aug_waste / 3);          // (a full-row bid with its cache refresh: three sweeps)
+            if (const char *e = getenv("CYTO_ARR_WASTE")) wa.arr_waste = std::max(1, atoi(e));     // (developer knob: tools/batch_chunks_bench.py)
             wa.seg_quorum = nl > 1 ? std::max(1, nl / 4) : 0;
             wa.seg_sync = nullptr;
             wa.same_prev = (j.h_ngroups < n && n >= 2) ? j.b_same.as<int32_t>() : nullptr;
@@ -3098,6 +3107,7 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
         CYTO_HIP(hipMemcpyAsync(d_wa.p, h_wa.data(), sizeof(WideArgs) * nl, hipMemcpyHostToDevice, stream));
         if ((rc = wide_launch_rt(d_wa.as<WideArgs>(), nl, n, stream))) return rc;
         std::vector<int32_t> h_sync((size_t)nl + 1, 1);
+        std::vector<char> caches_fresh((size_t)nl, 0);            // (wide_arr's word: hardly a full-row bid -- no rebuild before the searches)
         using BuildFn = decltype(build_caches);
         auto rebuild_tramp = +[](void *ctx, const int32_t *flags) -> int { return (*static_cast<BuildFn *>(ctx))(reinterpret_cast<const int *>(flags)); };
         for (int pass = 0;; pass++) {                              // the row-reduction rounds (they pause when the caches have gone stale)
@@ -3108,13 +3118,17 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             CYTO_HIP(hipMemcpyAsync(h_sync.data(), d_sync.p, sizeof(int32_t) * ((size_t)nl + 1), hipMemcpyDeviceToHost, stream));
             CYTO_HIP(hipStreamSynchronize(stream));
             bool done = true;
-            for (int k = 0; k < nl; k++) done = done && h_sync[(size_t)k + 1] == 0;
+            for (int k = 0; k < nl; k++) { done = done && (h_sync[(size_t)k + 1] & 1) == 0; caches_fresh[(size_t)k] = (h_sync[(size_t)k + 1] & 2) != 0; h_sync[(size_t)k + 1] &= 1; }
             if (done) break;
         }
         // the searches, in as many launches as they ask for: wide_aug returns when its row caches have gone stale (lap_wide.hip) and
         // the whole chip rebuilds them against the prices reached -- only for the problems that still have searches to run
         for (int pass = 0;; pass++) {
-            if ((rc = build_caches(pass ? h_sync.data() + 1 : nullptr))) return rc;
+            if (pass == 0) {
+                std::vector<int> need((size_t)nl);
+                for (int k = 0; k < nl; k++) need[(size_t)k] = caches_fresh[(size_t)k] ? 0 : 1;
+                if ((rc = build_caches(need.data()))) return rc;
+            } else if ((rc = build_caches(reinterpret_cast<const int *>(h_sync.data() + 1)))) return rc;
             if (pass == 0) CYTO_HIP(hipEventRecord(ev_arr_done, stream));   // (ms_aug: the search kernel -- and what later passes add)
             CYTO_HIP(hipMemsetAsync(d_sync.p, 0, sizeof(int32_t), stream));
             if ((rc = wide_launch_aug(d_wa.as<WideArgs>(), nl, n, stream, h_wa[0].mc_groups, h_wa[0].par_groups))) return rc;

@@ -627,6 +627,8 @@ __global__ __launch_bounds__(HEADB) void wide_sc_bid(const WideArgs *__restrict_
             if (jt < 0) retired++;
             else atomicMin(a.bid + jt, bidkey(tag, pt, i));
             a.slot_j[slot] = jt; a.slot_p[slot] = pt; a.slot_c[slot] = ct;
+            a.touched[slot] = i0;                                 // (the owner the bid would displace: owners do not change before the resolution;
+                                                                  //  `touched` is the searches' list, idle during the row reduction)
         }
     };
     const int per = (int)gridDim.x * (HEADB / 64);
@@ -672,7 +674,7 @@ __global__ __launch_bounds__(HEADB) void wide_sc_resolve(const WideArgs *__restr
         if (jt < 0) continue;                                    // retired: stays free, bids no more
         const int i = A[slot];
         if (bid_won(a.bid[jt], i)) {
-            const int i0 = a.colsol[jt];
+            const int i0 = a.touched[slot];                      // (recorded with the bid: one dependent load less than colsol[jt])
             cx.apply(i, jt, a.slot_p[slot], a.slot_c[slot], i0);
             if (i0 >= 0) B[atomicAdd(&sc->cnt[cur ^ 1], 1)] = i0;
         } else {
@@ -748,7 +750,7 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
     // whole chip costs (a.arr_waste of them in this launch; or a.seg_quorum workgroups of the launch have asked), that is cheaper.
     ArrHead *h = reinterpret_cast<ArrHead *>(a.misc + 384);
     if (h->done) {                                               // finished in an earlier launch
-        if (tid == 0 && a.seg_sync) a.seg_sync[1 + blockIdx.x] = 0;
+        if (tid == 0 && a.seg_sync) a.seg_sync[1 + blockIdx.x] = a.seg_sync[1 + blockIdx.x] & 2;
         return;
     }
     if (tid == 0) { s.cnt[0] = 0; s.cnt[1] = 0; s.retired = 0; s.dense = 0; s.ndeal = 0; s.pause = 0; }
@@ -991,7 +993,10 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
 #ifndef CYTO_WIDE_PROF
         dbg[12] = h->launches;
 #endif
-        if (a.seg_sync) a.seg_sync[1 + blockIdx.x] = paused ? 1 : 0;
+        // bit 0: the rounds paused for fresh row caches; bit 1: the row reduction hardly ever had to read a full row (<= n / 64 bids):
+        // the caches are evidently in good shape, the driver skips the rebuild before the searches (floors stay valid bounds while
+        // prices only fall; n = 50 000: 3.3 of 50 ms)
+        if (a.seg_sync) a.seg_sync[1 + blockIdx.x] = (paused ? 1 : 0) | ((!paused && s.dense <= n / 64) ? 2 : 0);
     }
 }
 
