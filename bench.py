@@ -654,7 +654,7 @@ def main():
     arr_ms = float(np.mean(arr_ms_l))
     aug_ms = float(np.mean(aug_ms_l))
     arr_name, aug_name = ("row_reduction(wide_rt + wide_sc_* + wide_arr)", "wide_aug") if info.wide else ("jv_chain2", "jv_aug_lazy" if n > 5120 else "jv_aug2")
-    # (the wide solver's row reduction is a PHASE of thousands of launches -- the long-list rounds on the whole chip, two small
+    # (the wide solver's row reduction is a PHASE of ~1 500 launches -- the phase machine's rounds on the whole chip, two small
     #  launches each, then the wide_arr kernel for the tail: arr_ms brackets the phase, the wide_arr kernel alone is its own clock's
     #  list + chain time; the dominant KERNEL is the longest single launch)
     arr_kernel_ms = float(info.wide_ms_list + info.wide_ms_chain) if info.wide else arr_ms

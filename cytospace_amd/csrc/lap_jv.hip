@@ -33,6 +33,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 
 namespace cyto {
 
@@ -2940,6 +2941,8 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(const LazyArgs *__restrict
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+static std::atomic<int> g_par_busy[64];     // per device: a several-searches-at-once kernel (wide_aug<..,PAR>) is in flight
+
 static const cyto_lap_opts k_default_opts = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 static int check_opts(const cyto_lap_opts &o) {
@@ -3027,6 +3030,11 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
 
     if ((rc = build_caches(nullptr))) return rc;
     CYTO_HIP(hipEventRecord(ev_cache_done, stream));
+    struct ParSlot { std::atomic<int> *p = nullptr; ~ParSlot() { if (p) p->store(0); } } par_slot;       // (released on every return path)
+    bool par_slot_held = false;
+    int dev_now = 0;
+    (void)hipGetDevice(&dev_now);
+    const int device_slot = dev_now >= 0 && dev_now < 64 ? dev_now : 0;
     if (pl.wide) {
         // the wide solver (lap_wide.hip): Jacobi reduction transfer, Jacobi rounds of row reduction, speculative shortest-path
         // augmentation -- one launch per phase for the whole batch
@@ -3042,8 +3050,16 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             //  runs of one-edge steps in the one-workgroup kernel; a sub-spot chunk's few doubled spots do not matter)
             const bool dup_rows = n >= 2 && (long long)j.h_ngroups * 5 < (long long)n * 4;
             int parg = (nl != 1 || mcg > 0) ? 0 : (pl.wide_par > 0 ? pl.wide_par : (pl.wide_par < 0 || dup_rows || n < 2048 ? 0 : 16));
+            // ONE such kernel per device at a time: its workgroups wait for each other at grid barriers and all sit on one XCD (32 CUs) --
+            // three of them launched from three host threads could each get a part of their workgroups scheduled and spin for the
+            // rest.  A solve that finds the slot taken runs its searches one at a time (same results).
+            if (parg > 1) {
+                if (g_par_busy[device_slot].exchange(1) != 0) parg = 0;
+                else par_slot_held = true;
+            }
             if (parg > WIDE_PAR_GMAX) parg = WIDE_PAR_GMAX;
             if (parg == 1) parg = 0;
+            if (par_slot_held) par_slot.p = &g_par_busy[device_slot];
             const size_t parb = parg > 0 ? wide_par_state_bytes(n, parg) : 0;
             const size_t sc_off = ((2 * nT + 255) / 256) * 256 + mcb;       // the phase machine's control block behind everything else
             const size_t par_off = sc_off + WIDE_SC_BYTES;

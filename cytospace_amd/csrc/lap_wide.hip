@@ -7,17 +7,22 @@
 // width, bit for bit:
 //
 //   wide_rt    REDUCTION TRANSFER, Jacobi: every row that owns exactly one column takes its margin against the
-//              post-column-reduction prices (snapshot), all margins are subtracted at once.  A wave per row, full chip.
-//   wide_arr   AUGMENTING ROW REDUCTION as Jacobi rounds of an eps = 0 auction: every active free row bids for its best
-//              column against the round's price snapshot; per column the lowest (price, row) wins, the displaced owner is
-//              active in the next round.  One 16-wave workgroup per problem, a wave per bidding row, 16 bids in flight;
-//              a round is a pure function of the state, so no visiting order exists to be reproduced.
+//              post-column-reduction prices (snapshot), all margins are subtracted at once; and the scale of the instance -- the
+//              histogram of the rows' gaps u2 - u1 -- for the eps schedule.  A wave per row, full chip.
+//   wide_sc_*  AUGMENTING ROW REDUCTION as Jacobi rounds of an auction, eps-SCALED where the instance has generic costs: eight
+//              eps = 0 rounds, then up to 16 phases eps_0 / 2^k (every row unassigned at a phase's start, prices kept, the phase's
+//              sequential tail cut), then a final eps = 0 phase.  The phase machine: every round two launches over the whole chip
+//              (bids: a wave per active row; resolution: a thread per bid), the state in a control block per problem, so a batch's
+//              problems run through their phases independently in the same launches.  A round is a pure function of the state.
+//   wide_arr   the chain rounds (<= 64 active rows) of instances that did not scale -- one 16-wave workgroup per problem, the
+//              rows in registers, bids meeting in LDS -- and every problem's list of free rows for the searches.
 //   wide_aug   AUGMENTATION: per free row a shortest-path search whose labels are the unique fixed point of a monotone
 //              system ((distance, tight-hop count) labels), so the search is run SPECULATIVELY: every round each of the 16 waves
-//              settles the best unsettled column of the column blocks it owns and relaxes that column's owner row from
-//              its row cache; a label that later improves is simply settled again.  Any schedule reaches the oracle's
+//              settles the best unsettled columns of the column blocks it owns and relaxes their owner rows from the
+//              row caches; a label that later improves is simply settled again.  Any schedule reaches the oracle's
 //              Dijkstra labels.  Row caches certify the scans (floor > final distance, checked when the search has
-//              converged; rows that fail are relaxed from their full cost row and the search continues).
+//              converged; rows that fail are relaxed from their full cost row and the search continues).  PAR: the searches of
+//              16 consecutive free rows of ONE problem at once, a workgroup each, the conflict-free prefix committed in row order.
 //
 // Row caches: lap_jv.hip (build_row_caches) -- <= 63 columns per row with their raw costs, sorted by column, and a floor
 // that bounds the reduced cost of every other column for as long as prices only decrease (they do: the price update of
@@ -761,7 +766,7 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
         }
     __syncthreads();
 
-    // the active list: what the first rounds on the whole chip left (wide_arr_head_*), else every free row (in any order -- a
+    // the active list: what the phase machine on the whole chip left (wide_sc_finish), else every free row (in any order -- a
     // round does not depend on it)
     const bool headed = h->started != 0;
     int cur = 0;
@@ -847,7 +852,7 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
         __syncthreads();
     }
     t_list = wall_clock64() - t_start;
-    n_list = (headed && h->launches > 0) ? h->list_rounds + (round - round0) : round;      // (the head rounds count as list rounds)
+    n_list = (headed && h->launches > 0) ? h->list_rounds + (round - round0) : round;      // (the machine's rounds count as list rounds)
     const long long t_chain0 = wall_clock64();
     // ================= CHAIN rounds: wave w holds the rows of slots q * 16 + w =================
     int left = na;                                               // rows still active when the rounds end

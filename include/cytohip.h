@@ -74,7 +74,7 @@ typedef struct {
     int64_t hbm_row_reads;   /* full cost rows the kernels actually fetched from HBM */
     int64_t dense_refreshes; /* RT/ARR steps whose row cache was exhausted (full re-scan) */
     double ms_arr;           /* float32 path: the RT+ARR kernel (jv_chain2) alone; wide solver: the row-reduction phase (wide_rt, the
-                                long-list rounds on the whole chip, wide_arr) and the cache build for the searches behind it */
+                                phase machine's rounds on the whole chip, wide_arr) and the cache build for the searches behind it */
     double ms_aug;           /* float32 path: the augmentation kernel alone (wide solver: wide_aug -- plus, where the searches
                                 paused for fresh caches, the rebuilds and the launches after the first) */
     int64_t aug_scans_skipped; /* augmentation scans elided as provable no-ops (duplicate rows) */

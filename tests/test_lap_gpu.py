@@ -447,6 +447,31 @@ def test_wide_several_searches_at_once(par):
     assert seen > 0
 
 
+def test_wide_single_solves_from_several_threads():
+    # a single problem's searches run 16 at a time on 16 workgroups that wait for each other at grid barriers: only ONE such kernel may
+    # be in flight per device (three of them could each get a part of their workgroups scheduled); a solve that finds the slot taken
+    # runs its searches one at a time -- the same answer either way
+    import threading
+    n = 2600
+    cs = [np.random.default_rng(300 + k).random((n, n)).astype(np.float32) for k in range(3)]
+    want = [jv_oracle_wide(c, np.float32) for c in cs]
+    bad, batches = [], []
+
+    def work(k):
+        for _ in range(4):
+            g = lap_solve(cs[k], np.float32, return_info=True)
+            batches.append(g["info"].wide_par_batches)
+            if not all(np.array_equal(g[key], want[k][key]) for key in ("rowsol", "colsol", "u", "v")):
+                bad.append(k)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not bad and len(batches) == 12 and max(batches) > 0
+
+
 # ---- float64 by default: warm-started from the float32 wide solve of the narrowed matrix (oracle: jv_oracle_warm_f64) ----
 
 def _check_warm(c64):
