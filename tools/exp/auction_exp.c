@@ -160,6 +160,61 @@ static void searches_spec(void) {
     for (int q = 0; q < K; q++) { setl[q] = malloc(sizeof(int) * n); setd[q] = malloc(sizeof(float) * n); pth[q] = malloc(sizeof(int) * 2 * n); }
     int *nset = malloc(sizeof(int) * K), *npth = malloc(sizeof(int) * K), *sink = malloc(sizeof(int) * K); float *dist = malloc(sizeof(float) * K);
     long batches = 0, wasted = 0, crit = 0, total_set = 0; int f = 0, batch_id = 0;
+    const int keep = getenv("SPEC_KEEP") != NULL;
+    /* per free row: a retained result (valid while disjoint from everything committed since it was computed) */
+    int *have = calloc(numfree, sizeof(int)); int **kset = calloc(numfree, sizeof(int *)); float **ksd = calloc(numfree, sizeof(float *)); int **kpth = calloc(numfree, sizeof(int *));
+    int *knset = calloc(numfree, sizeof(int)), *knpth = calloc(numfree, sizeof(int)), *ksink = calloc(numfree, sizeof(int)); float *kdist = calloc(numfree, sizeof(float));
+    while (keep && f < numfree) {
+        batch_id++; batches++;
+        int kk = numfree - f < K ? numfree - f : K;
+        long maxset = 0;
+        for (int q = 0; q < kk; q++) {
+            int fi = f + q;
+            if (have[fi]) continue;
+            int freerow = fr[fi]; const float *cf = cost + (size_t)freerow * n;
+            for (int j = 0; j < n; j++) { d[j] = cf[j] - v[j]; pred[j] = freerow; sc[j] = 0; }
+            int end = -1; float ds = 0; int ns = 0; int *sl = malloc(sizeof(int) * n);
+            for (;;) {
+                float dmin = INFINITY; int jp = -1;
+                for (int j = 0; j < n; j++) if (!sc[j] && (d[j] < dmin || (d[j] == dmin && jp >= 0 && colsol[jp] >= 0 && colsol[j] < 0))) { dmin = d[j]; jp = j; }
+                if (colsol[jp] < 0) { end = jp; ds = dmin; break; }
+                sc[jp] = 1; sl[ns++] = jp;
+                int i = colsol[jp]; const float *ci = cost + (size_t)i * n; float h = (ci[jp] - v[jp]) - dmin;
+                for (int j = 0; j < n; j++) { float v2 = (ci[j] - v[j]) - h; if (v2 < dmin) v2 = dmin; if (!sc[j] && v2 < d[j]) { d[j] = v2; pred[j] = i; } }
+            }
+            kset[fi] = realloc(sl, sizeof(int) * (ns + 1)); ksd[fi] = malloc(sizeof(float) * (ns + 1));
+            for (int t = 0; t < ns; t++) ksd[fi][t] = d[kset[fi][t]];
+            knset[fi] = ns; ksink[fi] = end; kdist[fi] = ds;
+            int *pp = malloc(sizeof(int) * 2 * (ns + 2)); int np = 0, e = end, i; do { i = pred[e]; pp[np++] = e; pp[np++] = i; e = rowsol[i]; } while (i != freerow);
+            kpth[fi] = pp; knpth[fi] = np; have[fi] = 1;
+            if (ns > maxset) maxset = ns;
+        }
+        crit += maxset;
+        int committed = 0;
+        for (int q = 0; q < kk; q++) {
+            int fi = f + q;
+            int conflict = stamp[ksink[fi]] == batch_id;
+            for (int t = 0; t < knset[fi] && !conflict; t++) conflict = stamp[kset[fi][t]] == batch_id;
+            if (conflict) break;
+            for (int t = 0; t < knset[fi]; t++) { int j = kset[fi][t]; stamp[j] = batch_id; if (ksd[fi][t] < kdist[fi]) { float nv = (v[j] + ksd[fi][t]) - kdist[fi]; if (nv < v[j]) v[j] = nv; } }
+            stamp[ksink[fi]] = batch_id;
+            for (int t = 0; t < knpth[fi]; t += 2) { int e = kpth[fi][t], i = kpth[fi][t + 1]; colsol[e] = i; rowsol[i] = e; }
+            committed++; total_set += knset[fi];
+        }
+        /* results computed but not committed: kept if disjoint from this batch's commits (checked for ALL retained results) */
+        for (int fi = f + committed; fi < numfree; fi++) if (have[fi]) {
+            int conflict = stamp[ksink[fi]] == batch_id;
+            for (int t = 0; t < knset[fi] && !conflict; t++) conflict = stamp[kset[fi][t]] == batch_id;
+            if (conflict) { wasted += knset[fi]; have[fi] = 0; free(kset[fi]); free(ksd[fi]); free(kpth[fi]); }
+        }
+        f += committed;
+    }
+    if (keep) {
+        printf("   speculative KEEP K=%d: free=%d batches=%ld critical-path settled=%ld (sequential %ld) wasted=%ld\n", K, numfree, batches, crit, total_set, wasted);
+        double tot = 0; for (int i = 0; i < n; i++) tot += cost[(size_t)i * n + rowsol[i]];
+        printf("   total = %.9f\n", tot);
+        return;
+    }
     while (f < numfree) {
         batch_id++; batches++;
         int kk = numfree - f < K ? numfree - f : K;
