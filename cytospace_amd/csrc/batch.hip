@@ -8,6 +8,7 @@
 #include "cyto_common.h"
 #include <rccl/rccl.h>
 #include <algorithm>
+#include <stdlib.h>
 #include <map>
 #include <thread>
 #include <vector>
@@ -56,7 +57,8 @@ int lap_batch_any(int nb, const int *n, const float *const *cost, const int64_t 
             // launches for all its problems, and some of them (the cache rebuilds between searches, the waits for its slowest
             // problem) leave most of the chip idle -- another sub-batch's workgroups fill it.
             // (chunk-sized problems only: 32 problems of 20 000 rows, which never pause, took 0.19 s in four sub-batches, 0.15 s in one)
-            const int G = kv.first > 16384 ? 1 : (cnt >= 128 ? 8 : (cnt >= 32 ? 4 : (cnt >= 16 ? 2 : 1)));
+            int G = kv.first > 16384 ? 1 : (cnt >= 128 ? 8 : (cnt >= 32 ? 4 : (cnt >= 16 ? 2 : 1)));
+            if (const char *e = getenv("CYTO_SUBBATCHES")) G = std::max(1, std::min(cnt, atoi(e)));       // (developer knob: tools/batch_chunks_bench.py)
             std::vector<int> brcs((size_t)G, CYTO_OK);
             if (G == 1) {
                 brcs[0] = lap_batch_same_n(kv.first, cnt, c.data(), l.data(), cost_on_device, rs.data(), cs.data(), uu.data(), vv.data(),
