@@ -171,6 +171,38 @@ def extra_c3(dev):
               "note": "wall time of cyto_transform on device-resident float32 counts between two device synchronisations"}
     except Exception as e:   # noqa: BLE001 (a diagnostic leg must not cost the line)
         k1 = {"error": f"{type(e).__name__}: {e}"}
+    # the whole of c3 with the counts already RESIDENT in HBM (device matrices into the context, one chunk = the whole problem):
+    # what the device does when the 4.4 GB upload at 57 GB/s does not hide it -- transforms, gathers, contraction, LAP
+    resident = None
+    try:
+        import ctypes
+        from cytospace_amd.cytospace import ExpressionContext
+        dsc = _lib.DeviceBuffer.from_numpy(np.ascontiguousarray(sc), dev)
+        dst = _lib.DeviceBuffer.from_numpy(np.ascontiguousarray(st), dev)
+        L = _lib.lib()
+        walls = []
+        for rep in range(2):
+            msc, mst = _lib.Matrix(), _lib.Matrix()
+            msc.data, msc.ld, msc.is_f64, msc.on_device = dsc.ptr, C, 0, 1
+            mst.data, mst.ld, mst.is_f64, mst.on_device = dst.ptr, S, 0, 1
+            _lib.check(L.cyto_device_synchronize(dev))
+            t = time.perf_counter()
+            ctx = ExpressionContext.__new__(ExpressionContext)
+            ctx.bcast_ms, ctx._h, ctx.G, ctx.C, ctx.S = None, ctypes.c_void_p(), G, C, S
+            ms = ctypes.c_double()
+            _lib.check(L.cyto_ctx_create_ex(0, G, ctypes.byref(msc), C, ctypes.byref(mst), S, 0, None, 0, 0, dev, ctypes.byref(ctx._h), ctypes.byref(ms)))
+            t_ctx = time.perf_counter() - t
+            m2, tot2, inf2 = ctx.assign_chunk(np.arange(C), slots, return_info=True)
+            walls.append((time.perf_counter() - t, t_ctx, inf2))
+            ctx.close()
+        dsc.free(); dst.free()
+        w, t_ctx, inf2 = min(walls, key=lambda x: x[0])
+        resident = {"wall_ms": round(w * 1e3, 1), "assignments_per_s": round(C / w, 1), "transforms_ms": round(t_ctx * 1e3, 1),
+                    "gather_ms": round(inf2.ms_standardize, 2), "gemm_ms": round(inf2.ms_gemm, 2), "lap_ms": round(inf2.lap.ms_total, 2),
+                    "same_mapping_as_the_fused_call": bool(np.array_equal(m2, mapped)),
+                    "note": "float32 counts uploaded beforehand (untimed); cyto_ctx_create_ex on device matrices + one chunk = the whole problem"}
+    except Exception as e:   # noqa: BLE001
+        resident = {"error": f"{type(e).__name__}: {e}"}
     # CPU beside it: the numpy float64 restatement of normalize_data + matrix_correlation_pearson
     # + the row gather (oracle/cost.py) on a bounded sample -- every spot against the first 2 000 cells
     cpu_cost = None
@@ -203,7 +235,7 @@ def extra_c3(dev):
                           "pearson_gemm_blocks_sum": round(info.ms_gemm, 2), "lap": round(info.lap.ms_total, 1)},
             "roofline": {"bound": "mfma", "kernel": "pearson_gemm", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF,
                          "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "flops_per_launch": info.gemm_flops},
-            "k1_roofline": k1, "cpu_baseline_cost_build": cpu_cost,
+            "k1_roofline": k1, "counts_resident_in_hbm": resident, "cpu_baseline_cost_build": cpu_cost,
             "counts_density": round(float(np.count_nonzero(sc[:, :2000])) / (G * 2000), 3),
             "lap": {"ms": round(info.lap.ms_total, 2), "rounds": int(info.lap.wide_rounds), "scaled": bool(info.lap.wide_scaled),
                     "one_edge_searches": int(info.lap.wide_trivial)},

@@ -1,7 +1,7 @@
 """Randomised parity stress against the CPU oracle (structures that reach the rare paths: duplicated rows, heavy integer ties,
 few cell types, constant columns, tiny and huge magnitudes).  Default: the float32 dispatch = the wide solver against the oracle's
 WIDE mode (--groups G: its searches on G workgroups; --rounds R: round budget; --rebuild K: row caches rebuilt every K searches, -1 never); --chain: the chain solver against the classic mode;
---f64: float64 through the streaming chain.  usage: stress_lap.py [seed0 count lo hi] [--chain | --f64] [--groups G] [--rounds R] [--rebuild K]"""
+--f64: float64 through the streaming chain.  usage: stress_lap.py [seed0 count lo hi] [--chain | --f64] [--groups G] [--par K] [--wipe K] [--rounds R] [--rebuild K]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -32,12 +32,12 @@ if __name__ == "__main__":
         if name in sys.argv:
             k = sys.argv.index(name); v = int(sys.argv[k + 1]); del sys.argv[k:k + 2]; return v
         return default
-    groups, rounds, rebuild = flag("--groups", 0), flag("--rounds", 0), flag("--rebuild", 0)
+    groups, rounds, rebuild, par, wipe = flag("--groups", 0), flag("--rounds", 0), flag("--rebuild", 0), flag("--par", 0), flag("--wipe", 0)
     f64 = "--f64" in sys.argv                 # float64 through the streaming chain with row caches (chain_variant 1) at any size
     chain = "--chain" in sys.argv
     sys.argv = [a for a in sys.argv if a not in ("--f64", "--chain")]
     dt = np.float64 if f64 else np.float32
-    opts = dict(chain_variant=1) if f64 else (dict(mode=1) if chain else dict(mode=2, wide_groups=groups, wide_rounds=rounds, wide_rebuild=rebuild))
+    opts = dict(chain_variant=1) if f64 else (dict(mode=1) if chain else dict(mode=2, wide_groups=groups, wide_rounds=rounds, wide_rebuild=rebuild, wide_par=par, wide_wipe=wipe))
     wide = not (f64 or chain)
     seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 36
@@ -56,8 +56,8 @@ if __name__ == "__main__":
             o = jv_oracle_wide(c, dt, max_rounds=(-1 if rounds == 0 else max(rounds, 0)))
             st = o["stats"]
             ok = all(np.array_equal(g[k], o[k]) for k in ("rowsol", "colsol", "u", "v")) and i.scans_arr == st.scans_arr and \
-                i.scans_aug_relax == st.scans_aug_relax and i.wide_rounds == st.arr_rounds and i.wide_retired == st.arr_retired and i.path_hops == st.path_hops
-            print(f"{s:3d} {kind:9s} n={n}: {'ok ' if ok else 'MISMATCH'} rounds {i.wide_rounds} bids {i.scans_arr} free {i.free_after_arr2} settled {i.wide_aug_settled} "
+                i.scans_aug_relax == st.scans_aug_relax and i.wide_rounds == st.arr_rounds and i.wide_retired == st.arr_retired and i.path_hops == st.path_hops and i.wide_scaled == st.arr_scaled and i.wide_phases == st.arr_phases
+            print(f"{s:3d} {kind:9s} n={n}: {'ok ' if ok else 'MISMATCH'} scaled {i.wide_scaled}/{i.wide_phases} par {i.wide_par_batches}/{i.wide_par_discarded} rounds {i.wide_rounds} bids {i.scans_arr} free {i.free_after_arr2} settled {i.wide_aug_settled} "
                   f"for {i.scans_aug_relax} dense ({i.wide_dense_arr},{i.wide_dense_aug}) launches {i.wide_aug_launches} one-edge {i.wide_trivial} {i.ms_total:.0f} ms", flush=True)
         else:
             o = jv_oracle(c, dt)
