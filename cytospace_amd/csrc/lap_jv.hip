@@ -1526,6 +1526,9 @@ __device__ __forceinline__ uint32_t wg_min_u32(uint32_t x, Scratch2 &s, int &par
     return readlane32(r, 0);
 }
 
+#ifdef CYTO_AUG_TRACE
+__device__ long long g_aug_trace[2 << 16];   // -DCYTO_AUG_TRACE (tools/trace_aug_scans.py): per search, cumulative scans and elided scans
+#endif
 // -DCYTO_AUG_PROF (tools/prof_aug_step.sh): s_memtime stamps of wave 0 inside a dense augmentation step
 #ifdef CYTO_AUG_PROF
 __device__ long long g_aug_prof[16];
@@ -1646,12 +1649,18 @@ __device__ __forceinline__ int chain_augment(int n, int64_t ld, const float *__r
         AP_STAMP(8)
         uint32_t lk = 0xFFFFFFFFu;
         const uint64_t holders = __ballot(lm == dminw && dminw < INFINITY);
+        bool one_group = false;
+        int mg = CH - 1;
         if (VEC && __builtin_popcountll(holders) == 1) {
-            // the usual case: ONE lane of the wave holds the minimum.  Its group of four (found with CH compares) is
-            // broadcast, the four slots are fetched with indirect addressing, the holder picks among them.
-            int mg = CH - 1;
+            // the usual case: ONE lane of the wave holds the minimum, in ONE of its groups of four.  (Two groups of the lane at the
+            // same value go the general way below: an unassigned column of the later group beats an assigned one of the first.)
+            int ng = cm[CH - 1] == dminw ? 1 : 0;
 #pragma unroll
-            for (int m = CH - 2; m >= 0; m--) mg = cm[m] == dminw ? m : mg;     // first group that holds the value
+            for (int m = CH - 2; m >= 0; m--) { const bool eq = cm[m] == dminw; mg = eq ? m : mg; ng += eq ? 1 : 0; }   // first group that holds the value
+            one_group = __builtin_amdgcn_readlane(ng, (int)__builtin_ctzll(holders)) == 1;
+        }
+        if (one_group) {
+            // The group (found with CH compares) is broadcast, the four slots are fetched with indirect addressing, the holder picks among them.
             const int hl = (int)__builtin_ctzll(holders);
             const int mgu = __builtin_amdgcn_readlane(mg, hl);                   // wave-uniform
             if (lm == dminw) {
@@ -2242,6 +2251,9 @@ __global__ __launch_bounds__(BS) void jv_aug2(const Chain2Args *__restrict__ bat
             err = chain_augment<CH, LDS_STATE, BS, false>(n, ld, cost, gv, sd, cassign, rowsol, gcolsol, slog_row, slog_h, s_v, s_cs, freerow, validm,
                                                           s, par, c_relax, c_hops, c_skipped, gmode, a.rowgid, a.iws + 6 * (int64_t)n, hb, hs, f + 1,
                                                           s_ca, s_cg, s_rec, a.rowmap);
+#ifdef CYTO_AUG_TRACE
+        if (threadIdx.x == 0 && f < (1 << 16)) { g_aug_trace[2 * f] = c_relax; g_aug_trace[2 * f + 1] = c_skipped; }
+#endif
         c_augs++;
     }
     // ---- write back prices and colsol, then duals u and the total ----
@@ -3748,6 +3760,14 @@ int cyto_arr_prof_read(long long *out16) {
 // profiling build only (tools/prof_lazy_step.py): the step-cycle accumulators of the last jv_aug_lazy launch
 int cyto_lz_prof_read(long long *out24) {
     CYTO_HIP(hipMemcpyFromSymbol(out24, HIP_SYMBOL(cyto::g_lz_prof), sizeof(long long) * 24));
+    return CYTO_OK;
+}
+#endif
+
+#ifdef CYTO_AUG_TRACE
+// debugging build only (tools/trace_aug_scans.py): cumulative scans / elided scans after every search of the last jv_aug2 launch
+int cyto_aug_trace_read(long long *out, int count) {
+    CYTO_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(cyto::g_aug_trace), sizeof(long long) * 2 * (size_t)count));
     return CYTO_OK;
 }
 #endif

@@ -94,6 +94,19 @@ def jv_oracle(cost, dtype=np.float32, warm=False):
     return dict(rowsol=rowsol, colsol=colsol, u=u, v=v, total=tot.value, total_T=tt.value, stats=st)
 
 
+def jv_oracle_trace(cost, rows=1 << 16):
+    """Debugging aid: the float32 classic solve plus, per search of the augmentation, (scans, free row, levels, sink column,
+    columns scanned at the final distance, unassigned columns at the final distance, final distance)."""
+    buf = np.zeros((rows, 7), np.float64)
+    L = _lib()
+    L.jv_oracle_set_trace(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(rows))
+    try:
+        o = jv_oracle(cost, np.float32)
+    finally:
+        L.jv_oracle_set_trace(None, ctypes.c_int(0))
+    return o, buf[:int(o["stats"].augmentations)]
+
+
 class JVWideStats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int64) for k in (
         "scans_redtransfer", "scans_arr", "scans_aug_init", "scans_aug_relax", "augmentations", "path_hops",

@@ -14,6 +14,12 @@
 /* the wide mode's bids of a round (independent of each other) run on this many threads: the binding sets it to the cores the
  * process may really use -- libgomp's default is every core of the HOST, and a container with 16 of 256 cores then spends its
  * time in 256 spinning threads */
+/* debugging aid (tools/trace_aug_scans.py): when set, the classic augmentation writes 7 doubles per search
+ * (scans, free row, levels, sink column, columns scanned AT the final distance, unassigned columns at the final distance, final distance) */
+double *jv_oracle_trace_buf = NULL;
+int jv_oracle_trace_rows = 0;
+void jv_oracle_set_trace(double *buf, int rows) { jv_oracle_trace_buf = buf; jv_oracle_trace_rows = rows; }
+
 void jv_oracle_set_threads(int n) {
 #ifdef _OPENMP
     if (n >= 1) omp_set_num_threads(n);

@@ -196,6 +196,12 @@ static int FN(jv_oracle_from_)(int n, const T *restrict cost, const T *restrict 
             }
             s.scans_aug_relax++;
         }
+        if (jv_oracle_trace_buf && f < jv_oracle_trace_rows) {
+            double *t = jv_oracle_trace_buf + 7 * (size_t)f;
+            int at = 0, un = 0, sc = 0;
+            for (int j = 0; j < n; j++) { sc += scanned[j]; at += scanned[j] && d[j] == curmin; un += !scanned[j] && colsol[j] < 0 && d[j] == curmin; }
+            t[0] = sc; t[1] = freerow; t[2] = level; t[3] = endofpath; t[4] = at; t[5] = un; t[6] = (double)curmin;
+        }
         /* price update: columns scanned at an earlier level than the final one */
         for (int j = 0; j < n; j++)
             if (scanned[j] && lvl[j] < level) v[j] = (v[j] + d[j]) - curmin;

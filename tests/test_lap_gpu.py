@@ -402,27 +402,19 @@ def test_duplicate_row_group_state_in_global_memory(aug):
     _check(np.random.default_rng(4).random((700, 700)).astype(np.float32), np.float32, dict(augmentation=1, aux_state_global=1))
 
 
-def test_chain_solver_seed_2407_results_exact_one_scan_apart():
-    # Pinned, not yet explained: on this duplicated-row instance of the randomised stress (tools/stress_lap.py
-    # seed 2407: n = 4 750, rows in runs of identical copies) the CHAIN solver (mode 1, dense augmentation kernel with duplicate-row
-    # elision) counts 126 544 augmentation scans where the classic oracle counts 126 543 -- indices, duals and every other counter
-    # are identical bit for bit.  (An extra scan of a column AT the final distance of a search is unobservable in the results: only
-    # columns scanned below it get a price update.)  The default solvers do not run this kernel.
+def test_chain_solver_tie_between_two_groups_of_one_lane():
+    # Regression (tools/stress_lap.py seed 2407: n = 4 750, rows in runs of identical copies; found by tools/trace_aug_scans.py).  In
+    # search 92 an assigned and an UNASSIGNED column sit at the same (final) distance in two different groups of four of the SAME lane
+    # of the dense augmentation kernel: the pick's one-holder shortcut looked at the first such group only and scanned the assigned
+    # column before ending at the unassigned one -- 126 544 scans against the oracle's 126 543, everything else identical (a scan AT
+    # the final distance changes no price).  The shortcut now needs ONE group at the value; counters equal the oracle's.
     from tools.stress_lap import make
     rng = np.random.default_rng(1000 + 2407)
     n = int(rng.integers(3000, 6000))
     c = make("dup", n, rng)
-    o = jv_oracle(c, np.float32)
+    _check(c, np.float32)                                    # every counter equal; the wide solver too
     g = lap_solve(c, np.float32, return_info=True, opts=CHAIN)
-    for k in ("rowsol", "colsol", "u", "v"):
-        assert np.array_equal(g[k], o[k]), k
-    od, gd = o["stats"].as_dict(), g["info"].as_dict()
-    for k in STAT_KEYS:
-        if k != "scans_aug_relax":
-            assert gd[k] == od[k], (k, gd[k], od[k])
-    assert 0 <= gd["scans_aug_relax"] - od["scans_aug_relax"] <= 1
-    gw, ow = _check_wide(c)                                  # the wide solver: exact, counters included
-    assert abs(ow["total"] - o["total"]) <= 1e-5 * max(1.0, abs(o["total"]))
+    assert g["info"].scans_aug_relax == 126543
 
 
 @pytest.mark.parametrize("par", [2, 5, 16])
