@@ -1441,6 +1441,169 @@ __global__ __launch_bounds__(BLOCK2) void build_row_caches_stream(int n, int64_t
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The full-chip cache build as ONE WAVE PER ROW (round 4; what the build before and between the solver's phases runs).  The
+// workgroup forms above hold a row in 187 VGPRs (CH = 10: one workgroup per CU, its loads never overlap its threshold search --
+// 2.1 TB/s at n = 20 000) or sweep it several times between workgroup barriers (the streaming form: 3.0 TB/s at n = 50 000).
+// Here a wave streams its row ONCE with U quads per lane in flight and no barrier anywhere: the floor is guessed (the floor of
+// the wave's previous row: rows of one matrix want similar floors, and ANY floor that admits <= 63 columns makes a valid
+// cache), the columns under it are compacted into a 512-byte staging line of the wave by ballot as they pass (some 50 of
+// n), the lane minima are kept for the case that the guess fails -- then the floor is searched as before, by further sweeps
+// of the (L2 / MALL resident) row.  A wave's first row has no guess: its floor is the 35th smallest of the 64 lane minima
+// (expected: ~48 columns below it).  Same cache contract as refresh_row.
+constexpr int CBW = 4;             // waves per workgroup (they share nothing but the launch)
+struct CbStage { uint32_t col[KC]; float val[KC]; };
+
+// one sweep of the row: counts the columns with h < tau and stages the first 64 of them; TRACK: also the lane minima
+template <int U, bool TRACK>
+__device__ __forceinline__ int cb_sweep(const __amdgpu_buffer_rsrc_t rrow, const __amdgpu_buffer_rsrc_t rv, const float *__restrict__ row,
+                                        const float *__restrict__ v, int n, int lane, float tau, float &lmin, CbStage &st) {
+    const int nfull = n >> 2, ntail = n & 3;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    int cnt = 0;
+    auto one = [&](uint32_t c, float raw, bool p) {                // (convergent: every lane of the wave calls it)
+        const uint64_t m = __ballot(p);
+        if (m) {
+            const int pos = cnt + __popcll(m & lt);
+            if (p && pos < KC) { st.col[pos] = c; st.val[pos] = raw; }
+            cnt += __popcll(m);
+        }
+    };
+    auto quad = [&](int q, const u32x4_t &xr, const u32x4_t &vr, bool inrange) {
+        const float r0 = __uint_as_float(xr.x), r1 = __uint_as_float(xr.y), r2 = __uint_as_float(xr.z), r3 = __uint_as_float(xr.w);
+        const float h0 = r0 - __uint_as_float(vr.x), h1 = r1 - __uint_as_float(vr.y), h2 = r2 - __uint_as_float(vr.z),
+                    h3 = r3 - __uint_as_float(vr.w);
+        float m4 = fminf(fminf(h0, h1), fminf(h2, h3));
+        if (!inrange) m4 = INFINITY;
+        if (TRACK) lmin = fminf(lmin, m4);
+        if (__ballot(m4 < tau)) {
+            const uint32_t c0 = (uint32_t)q * 4u;
+            one(c0, r0, inrange && h0 < tau); one(c0 + 1, r1, inrange && h1 < tau);
+            one(c0 + 2, r2, inrange && h2 < tau); one(c0 + 3, r3, inrange && h3 < tau);
+        }
+    };
+    int base = 0;
+    for (; base + 64 * U <= nfull; base += 64 * U) {                // (wave-uniform trips; all U quads of every lane in range)
+        u32x4_t xr[U], vr[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            xr[u] = __builtin_amdgcn_raw_buffer_load_b128(rrow, (base + 64 * u + lane) * 16, 0, 0);
+            vr[u] = __builtin_amdgcn_raw_buffer_load_b128(rv, (base + 64 * u + lane) * 16, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) quad(base + 64 * u + lane, xr[u], vr[u], true);
+    }
+    for (; base < nfull; base += 64) {                               // (reads past the descriptors' extents give zeros)
+        const int q = base + lane;
+        const u32x4_t xr = __builtin_amdgcn_raw_buffer_load_b128(rrow, q * 16, 0, 0);
+        const u32x4_t vr = __builtin_amdgcn_raw_buffer_load_b128(rv, q * 16, 0, 0);
+        quad(q, xr, vr, q < nfull);
+    }
+    if (ntail) {                                                     // the ragged last quad: a column per lane
+        const int c = nfull * 4 + lane;
+        const bool valid = lane < ntail;
+        const float raw = valid ? row[c] : 0.0f;
+        const float h = valid ? raw - v[c] : INFINITY;
+        if (TRACK) lmin = fminf(lmin, h);
+        one((uint32_t)c, raw, valid && h < tau);
+    }
+    return cnt;
+}
+
+template <int U>
+__global__ __launch_bounds__(64 * CBW) void build_row_caches_wave(int n, int64_t ld, const float *__restrict__ cost,
+                                                                 const float *__restrict__ v, uint32_t *__restrict__ cache_col,
+                                                                 float *__restrict__ cache_val, const int32_t *__restrict__ rowmap,
+                                                                 const int32_t *__restrict__ same_prev) {
+    __shared__ CbStage stage[CBW];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (scalar: row bases and descriptors stay in SGPRs)
+    CbStage &st = stage[w];
+    const int gw = (int)blockIdx.x * CBW + w, nw = (int)gridDim.x * CBW;
+    const int per = (n + nw - 1) / nw, i_end = min(n, (gw + 1) * per);      // (a contiguous range of rows per wave)
+    const int nquad = (n + 3) >> 2;
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(v), 0, nquad * 16, 0x00020000);
+    float tau_guess = INFINITY, delta = 0.0f;
+    for (int i = gw * per; i < i_end; i++) {
+        if (same_prev && same_prev[i]) continue;                          // a copy of the previous row: replicate_group_caches
+        const float *__restrict__ row = cost + row_off(rowmap, i, ld);
+        const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(row), 0, (int)(ld * 4), 0x00020000);
+        const float tau0 = tau_guess;
+        float lmin = INFINITY, dummy = 0.0f;
+        int cnt = cb_sweep<U, true>(rrow, rv, row, v, n, lane, tau0 < INFINITY ? tau0 : -INFINITY, lmin, st);
+        float tau = tau0;
+        const bool have = tau0 < INFINITY && cnt <= KCU && (cnt >= KCU / 2 || cnt >= n);      // the guess fits: one sweep
+        if (!have) {
+            const float umin = ord2f(wave_min_u32(f2ord(lmin)));
+            float lo = 0.0f, hi = INFINITY;
+            bool okc = false;
+            if (tau0 < INFINITY && tau0 > umin && cnt > 0) {              // scale the guess by how far its count was off
+                const float d0 = tau0 - umin;
+                if (cnt > KCU) { hi = d0; delta = d0 * fmaxf(0.0625f, 0.75f * (float)KCU / (float)cnt); }
+                else { lo = d0; delta = d0 * fminf(16.0f, 0.75f * (float)KCU / (float)cnt); }
+            } else if (!(tau0 < INFINITY)) {                             // no guess: from the order statistics of the lane minima
+                float lm = lmin;
+#pragma unroll
+                for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        const float o = __shfl_xor(lm, j);
+                        const bool take_min = ((lane & j) == 0) == ((lane & k) == 0);
+                        lm = take_min ? fminf(lm, o) : fmaxf(lm, o);
+                    }
+                }
+                const float m34 = __shfl(lm, 34);
+                if (m34 < INFINITY && m34 > umin) delta = m34 - umin;
+            }
+            if (!(delta > 0.0f) || !(delta < 1e30f)) delta = 1e-3f;
+            for (int it = 0; it < 24 && !okc; it++) {
+                tau = umin + delta;
+                cnt = cb_sweep<U, false>(rrow, rv, row, v, n, lane, tau, dummy, st);
+                if (cnt > KCU) {
+                    hi = delta;
+                    const float mid = (lo > 0.0f) ? 0.5f * (lo + hi) : 0.5f * delta;
+                    if (!(mid < hi) || !(mid > lo)) break;               // cannot separate: too many ties just above umin
+                    delta = mid;
+                } else if (cnt < KCU / 2 && cnt < n && delta < 1e30f) {
+                    lo = delta;
+                    const float mid = (hi < INFINITY) ? 0.5f * (lo + hi) : 2.0f * delta;
+                    if (hi < INFINITY && (!(mid < hi) || !(mid > lo))) { okc = true; break; }      // best separable threshold
+                    delta = mid;
+                } else {
+                    okc = true;
+                }
+            }
+            if (!okc || cnt > KCU) {
+                // the largest threshold known to admit <= KCU columns (possibly none), staged once more
+                if (lo > 0.0f) { delta = lo; tau = umin + lo; } else { tau = -INFINITY; }
+                cnt = cb_sweep<U, false>(rrow, rv, row, v, n, lane, tau, dummy, st);
+                if (cnt > KCU) { tau = -INFINITY; cnt = 0; }
+            }
+        }
+        tau_guess = tau > -INFINITY ? tau : INFINITY;
+        // the staged columns, sorted by column (unused slots last), the floor in slot 63
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t kc = lane < cnt ? st.col[lane] : COLSENT;
+        float kv = lane < cnt ? st.val[lane] : 0.0f;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const uint32_t pk = (uint32_t)__shfl_xor((int)kc, j);
+                const float pv = __shfl_xor(kv, j);
+                const bool take_min = ((lane & j) == 0) == ((lane & k) == 0);
+                const bool sw = take_min ? (pk < kc) : (pk > kc);
+                kc = sw ? pk : kc; kv = sw ? pv : kv;
+            }
+        }
+        if (lane == KCU) { kc = COLSENT; kv = tau; }               // (at most 63 entries: lane 63 held a sentinel)
+        cache_col[(int64_t)i * KC + lane] = kc;
+        cache_val[(int64_t)i * KC + lane] = kv;
+    }
+}
+
 // Argument block of one problem (kernels get an array of them: one workgroup per problem).  Fields through an X-macro because
 // the kernels read the block through a mirror struct whose pointers are typed as GLOBAL (LOAD_ARGS): pointers that are loaded from
 // memory are generic to the compiler, and every access through them would be a FLAT instruction instead of a global one.
@@ -2988,6 +3151,7 @@ struct F32Job {
 
 struct F32Plan {            // what depends on n (and the options) only: identical for every problem of the batch
     int n, colblocks, rowblocks, rows_per_block, cache_grid;
+    int cache_waves = 8, cache_unroll = 4, cus = 256;      // build_row_caches_wave: waves per CU, quads in flight per lane; CUs of the device
     bool force_l2, lds_variant, lazy, lz_lds_state, lz_cs_lds, no_cs_lds, wide;
     long long wide_rounds;
     int wide_groups, wide_rebuild, wide_wipe, wide_par;
@@ -3013,7 +3177,16 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             const Chain2Args &a = jobs[b].c2;
             // (runs of identical rows: one cache per run, copied to the rest)
             const int32_t *same = (jobs[b].h_ngroups < n && n >= 2) ? jobs[b].b_same.as<int32_t>() : nullptr;
-            if constexpr (CH == 0)
+            if (pl.cache_waves > 0) {
+                // (a wave per row; the grid: pl.cache_waves waves on every CU, four to a workgroup)
+                const int g = std::max(1, std::min((n + CBW - 1) / CBW, pl.cache_waves * pl.cus / CBW));
+                if (pl.cache_unroll == 8)
+                    hipLaunchKernelGGL(build_row_caches_wave<8>, dim3(g), dim3(64 * CBW), 0, stream, n, a.ld, a.cost, (const float *)a.fws,
+                                       a.cache_col, a.cache_val, a.rowmap, same);
+                else
+                    hipLaunchKernelGGL(build_row_caches_wave<4>, dim3(g), dim3(64 * CBW), 0, stream, n, a.ld, a.cost, (const float *)a.fws,
+                                       a.cache_col, a.cache_val, a.rowmap, same);
+            } else if constexpr (CH == 0)
                 hipLaunchKernelGGL(build_row_caches_stream, dim3(pl.cache_grid), dim3(BLOCK2), 0, stream, n, a.ld, a.cost,
                                    (const float *)a.fws, a.cache_col, a.cache_val, a.rowmap, same);
             else
@@ -3241,6 +3414,9 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
     pl.rows_per_block = (n + pl.rowblocks - 1) / pl.rowblocks;
     pl.rowblocks = (n + pl.rows_per_block - 1) / pl.rows_per_block;
     pl.cache_grid = max(1, min(n, 1024));
+    // (developer knobs, tools/cache_build_bench.py: CYTO_CACHE_WAVES = 0 selects the workgroup-per-row builders)
+    if (const char *e = getenv("CYTO_CACHE_WAVES")) pl.cache_waves = std::max(0, std::min(32, atoi(e)));
+    if (const char *e = getenv("CYTO_CACHE_UNROLL")) pl.cache_unroll = atoi(e) == 8 ? 8 : 4;
     const int per2 = 4 * BLOCK2;
     // which chain variant: by size, or the large-n variants forced at a small n (opts.chain_variant; the test-suite
     // runs them on instances the CPU oracle solves in a second)
