@@ -82,6 +82,135 @@ __global__ __launch_bounds__(256) void colmoments_partial(int G, int C, const TI
     p2[(int64_t)blockIdx.y * C + c] = s2;
 }
 
+// ---- the transform's streaming kernels (round 4) -------------------------------------------------------------------------------
+// A block = four waves on the same 64 * VEC columns; wave rs takes the genes g0 + rs, g0 + rs + 4, ... of a block of TGB genes, a lane
+// VEC consecutive columns (one 16-byte load per row for float32 counts, eight rows in flight), the four waves' partial sums are
+// combined in wave order through LDS: a column's sum is the same whatever VEC is (VEC = 1: any pitch / alignment).  The forms above
+// (a thread per column, scalar loads, 313 partials per column at G = 20 000) ran the three passes + a full memset of z at 1.8 TB/s.
+constexpr int TGB = 256;   // genes per block
+constexpr int TRS = 4;     // waves per block = row subgroups
+
+template <typename TIn, int VEC> __device__ __forceinline__ void load_cols(const TIn *__restrict__ p, TIn (&r)[VEC]) {
+    if constexpr (VEC == 1) {
+        r[0] = p[0];
+    } else if constexpr (sizeof(TIn) == 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+    } else {
+        const double2 a = reinterpret_cast<const double2 *>(p)[0], b = reinterpret_cast<const double2 *>(p)[1];
+        r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
+    }
+}
+
+// combine the four waves' partials (wave order) and store them as block blockIdx.y's partial
+template <int VEC>
+__device__ __forceinline__ void block_combine_store(double (&s)[VEC], double (*sh)[64 * VEC], int lane, int rs, bool act,
+                                                    double *__restrict__ part, int C, int c0) {
+    if (rs > 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) sh[rs - 1][e * 64 + lane] = s[e];
+    }
+    __syncthreads();
+    if (rs == 0 && act) {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            double t = s[e];
+#pragma unroll
+            for (int k = 0; k < TRS - 1; k++) t += sh[k][e * 64 + lane];
+            part[(int64_t)blockIdx.y * C + c0 + e] = t;
+        }
+    }
+}
+
+template <typename TIn, int VEC>
+__global__ __launch_bounds__(64 * TRS) void colsum_partial_v(int G, int C, const TIn *__restrict__ x, int64_t ldx,
+                                                             double *__restrict__ part) {
+    __shared__ double sh[TRS - 1][64 * VEC];
+    const int lane = threadIdx.x & 63, rs = threadIdx.x >> 6;
+    const int c0 = ((int)blockIdx.x * 64 + lane) * VEC;
+    const bool act = c0 < C;
+    const int g0 = blockIdx.y * TGB, g1 = min(G, g0 + TGB);
+    double s[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) s[e] = 0.0;
+    if (act) {
+        const TIn *__restrict__ p = x + (int64_t)(g0 + rs) * ldx + c0;
+#pragma unroll 8
+        for (int g = g0 + rs; g < g1; g += TRS, p += TRS * ldx) {
+            TIn r[VEC];
+            load_cols<TIn, VEC>(p, r);
+#pragma unroll
+            for (int e = 0; e < VEC; e++) s[e] += clean<TIn>(r[e]);
+        }
+    }
+    block_combine_store<VEC>(s, sh, lane, rs, act, part, C, c0);
+}
+
+template <typename TIn, int VEC>
+__global__ __launch_bounds__(64 * TRS) void colmoments_partial_v(int G, int C, const TIn *__restrict__ x, int64_t ldx,
+                                                                 const double *__restrict__ colsum, int already,
+                                                                 double *__restrict__ p1, double *__restrict__ p2) {
+    __shared__ double sh[TRS - 1][64 * VEC];
+    const int lane = threadIdx.x & 63, rs = threadIdx.x >> 6;
+    const int c0 = ((int)blockIdx.x * 64 + lane) * VEC;
+    const bool act = c0 < C;
+    const int g0 = blockIdx.y * TGB, g1 = min(G, g0 + TGB);
+    double s1[VEC], s2[VEC], scale[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) { s1[e] = 0.0; s2[e] = 0.0; scale[e] = (already || !act) ? 1.0 : 1e6 / colsum[c0 + e]; }
+    if (act) {
+        const TIn *__restrict__ p = x + (int64_t)(g0 + rs) * ldx + c0;
+#pragma unroll 4
+        for (int g = g0 + rs; g < g1; g += TRS, p += TRS * ldx) {
+            TIn r[VEC];
+            load_cols<TIn, VEC>(p, r);
+#pragma unroll
+            for (int e = 0; e < VEC; e++) {
+                const double y = normalized<TIn>(r[e], scale[e], already);
+                s1[e] += y;
+                s2[e] += y * y;
+            }
+        }
+    }
+    block_combine_store<VEC>(s1, sh, lane, rs, act, p1, C, c0);
+    __syncthreads();                                              // (the staging lines are read before the second moments overwrite them)
+    block_combine_store<VEC>(s2, sh, lane, rs, act, p2, C, c0);
+}
+
+// z = (y - mean) * inv (MODE 0) or z = y (MODE 1: the Euclidean metric's operand) as float32
+template <typename TIn, int VEC, int MODE>
+__global__ __launch_bounds__(64 * TRS) void transform_write_v(int G, int C, const TIn *__restrict__ x, int64_t ldx,
+                                                              const double *__restrict__ colsum, const double *__restrict__ mean,
+                                                              const double *__restrict__ inv, int already,
+                                                              float *__restrict__ z, int64_t ldz) {
+    const int lane = threadIdx.x & 63, rs = threadIdx.x >> 6;
+    const int c0 = ((int)blockIdx.x * 64 + lane) * VEC;
+    if (c0 >= C) return;
+    const int g0 = blockIdx.y * TGB, g1 = min(G, g0 + TGB);
+    double scale[VEC], m[VEC], iv[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) {
+        scale[e] = already ? 1.0 : 1e6 / colsum[c0 + e];
+        m[e] = MODE == 0 ? mean[c0 + e] : 0.0;
+        iv[e] = MODE == 0 ? inv[c0 + e] : 1.0;
+    }
+    const TIn *__restrict__ p = x + (int64_t)(g0 + rs) * ldx + c0;
+    float *__restrict__ q = z + (int64_t)(g0 + rs) * ldz + c0;
+#pragma unroll 4
+    for (int g = g0 + rs; g < g1; g += TRS, p += TRS * ldx, q += TRS * ldz) {
+        TIn r[VEC];
+        load_cols<TIn, VEC>(p, r);
+        float o[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            const double y = normalized<TIn>(r[e], scale[e], already);
+            o[e] = MODE == 0 ? (float)((y - m[e]) * iv[e]) : (float)y;
+        }
+        if constexpr (VEC == 4) *reinterpret_cast<float4 *>(q) = make_float4(o[0], o[1], o[2], o[3]);
+        else q[0] = o[0];
+    }
+}
+
 // combine the partials in ascending block order
 __global__ void col_finish_sum(int C, int nblk, const double *__restrict__ part, double *__restrict__ out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -472,31 +601,44 @@ static int standardize_dev(int G, int C, const TIn *dx, int64_t ldx, int already
         CYTO_HIP(hipGetLastError());
         return standardize_dev<float>(G, C, rp, C, 1, z, ldz, nullptr, 0, stream, 0);
     }
-    const int nblk = (G + GB - 1) / GB;
+    const bool want_moments = z && transform != 2;
+    const int nblk = (G + TGB - 1) / TGB, nblk_y = (G + GB - 1) / GB;
     DevBuf part1, part2, colsum, mean, inv;
     int rc;
-    if ((rc = part1.alloc((size_t)nblk * C * sizeof(double), stream)) || (rc = part2.alloc((size_t)nblk * C * sizeof(double), stream)) ||
+    if ((rc = part1.alloc((size_t)nblk * C * sizeof(double), stream)) ||
+        (want_moments && (rc = part2.alloc((size_t)nblk * C * sizeof(double), stream))) ||
         (rc = colsum.alloc((size_t)C * sizeof(double), stream)) || (rc = mean.alloc((size_t)C * sizeof(double), stream)) ||
         (rc = inv.alloc((size_t)C * sizeof(double), stream)))
         return rc;
-    const dim3 grid((C + 255) / 256, nblk), blk(256);
-    const dim3 g1((C + 255) / 256);
+    // four columns per lane when every row of x (and of z) can be read (written) as 16-byte quads; else a column per lane -- a column's
+    // numbers do not depend on which
+    const bool vec = C % 4 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(dx) % 16) == 0 &&
+                     (!z || (ldz % 4 == 0 && (reinterpret_cast<uintptr_t>(z) % 16) == 0));
+    const int cols_per_block = vec ? 256 : 64;
+    const dim3 grid((C + cols_per_block - 1) / cols_per_block, nblk), blk(64 * TRS);
+    const dim3 g1((C + 255) / 256), blk1(256);
     if (!already) {
-        hipLaunchKernelGGL(colsum_partial<TIn>, grid, blk, 0, stream, G, C, dx, ldx, part1.as<double>());
-        hipLaunchKernelGGL(col_finish_sum, g1, blk, 0, stream, C, nblk, part1.as<double>(), colsum.as<double>());
+        if (vec) hipLaunchKernelGGL((colsum_partial_v<TIn, 4>), grid, blk, 0, stream, G, C, dx, ldx, part1.as<double>());
+        else hipLaunchKernelGGL((colsum_partial_v<TIn, 1>), grid, blk, 0, stream, G, C, dx, ldx, part1.as<double>());
+        hipLaunchKernelGGL(col_finish_sum, g1, blk1, 0, stream, C, nblk, part1.as<double>(), colsum.as<double>());
     }
     if (ynorm) {
-        hipLaunchKernelGGL(normalize_write<TIn>, grid, blk, 0, stream, G, C, dx, ldx, colsum.as<double>(), ynorm, ldy);
+        hipLaunchKernelGGL(normalize_write<TIn>, dim3((C + 255) / 256, nblk_y), blk1, 0, stream, G, C, dx, ldx, colsum.as<double>(), ynorm, ldy);
     }
     if (z && transform == 2) {
-        hipLaunchKernelGGL(convert_write<TIn>, grid, blk, 0, stream, G, C, dx, ldx, colsum.as<double>(), already, z, ldz);
+        if (vec) hipLaunchKernelGGL((transform_write_v<TIn, 4, 1>), grid, blk, 0, stream, G, C, dx, ldx, colsum.as<double>(), nullptr, nullptr, already, z, ldz);
+        else hipLaunchKernelGGL((transform_write_v<TIn, 1, 1>), grid, blk, 0, stream, G, C, dx, ldx, colsum.as<double>(), nullptr, nullptr, already, z, ldz);
     } else if (z) {
-        hipLaunchKernelGGL(colmoments_partial<TIn>, grid, blk, 0, stream, G, C, dx, ldx, colsum.as<double>(), already,
-                           part1.as<double>(), part2.as<double>());
-        hipLaunchKernelGGL(col_finish_moments, g1, blk, 0, stream, G, C, nblk, part1.as<double>(), part2.as<double>(),
+        if (vec) hipLaunchKernelGGL((colmoments_partial_v<TIn, 4>), grid, blk, 0, stream, G, C, dx, ldx, colsum.as<double>(), already,
+                                    part1.as<double>(), part2.as<double>());
+        else hipLaunchKernelGGL((colmoments_partial_v<TIn, 1>), grid, blk, 0, stream, G, C, dx, ldx, colsum.as<double>(), already,
+                                part1.as<double>(), part2.as<double>());
+        hipLaunchKernelGGL(col_finish_moments, g1, blk1, 0, stream, G, C, nblk, part1.as<double>(), part2.as<double>(),
                            mean.as<double>(), inv.as<double>());
-        hipLaunchKernelGGL(standardize_write<TIn>, grid, blk, 0, stream, G, C, dx, ldx, colsum.as<double>(), mean.as<double>(),
-                           inv.as<double>(), already, z, ldz);
+        if (vec) hipLaunchKernelGGL((transform_write_v<TIn, 4, 0>), grid, blk, 0, stream, G, C, dx, ldx, colsum.as<double>(), mean.as<double>(),
+                                    inv.as<double>(), already, z, ldz);
+        else hipLaunchKernelGGL((transform_write_v<TIn, 1, 0>), grid, blk, 0, stream, G, C, dx, ldx, colsum.as<double>(), mean.as<double>(),
+                                inv.as<double>(), already, z, ldz);
     }
     CYTO_HIP(hipGetLastError());
     CYTO_HIP(hipStreamSynchronize(stream));   // the temporaries above die with this scope
@@ -544,7 +686,10 @@ int cyto_transform(int transform, int G, int C, const void *x, int64_t ldx, int 
         src = dx.p;
         sld = C;
     }
-    CYTO_HIP(hipMemsetAsync(z_dev, 0, (size_t)Gpad * ldz * sizeof(float), stream));
+    // the zero padding of z: the columns beyond C and the rows beyond G (the transform writes every element of the G x C block itself;
+    // a memset of the whole buffer was a fifth pass over a matrix the transform reads three times and writes once)
+    if (ldz > C) CYTO_HIP(hipMemset2DAsync(z_dev + C, (size_t)ldz * sizeof(float), 0, (size_t)(ldz - C) * sizeof(float), (size_t)G, stream));
+    if (Gpad > G) CYTO_HIP(hipMemsetAsync(z_dev + (size_t)G * ldz, 0, (size_t)(Gpad - G) * ldz * sizeof(float), stream));
     if (x_is_f64) return standardize_dev<double>(G, C, (const double *)src, sld, already_normalized, z_dev, ldz, nullptr, 0, stream, transform);
     return standardize_dev<float>(G, C, (const float *)src, sld, already_normalized, z_dev, ldz, nullptr, 0, stream, transform);
 }

@@ -1449,8 +1449,9 @@ __global__ __launch_bounds__(BLOCK2) void build_row_caches_stream(int n, int64_t
 // the wave's previous row: rows of one matrix want similar floors, and ANY floor that admits <= 63 columns makes a valid
 // cache), the columns under it are compacted into a 512-byte staging line of the wave by ballot as they pass (some 50 of
 // n), the lane minima are kept for the case that the guess fails -- then the floor is searched as before, by further sweeps
-// of the (L2 / MALL resident) row.  A wave's first row has no guess: its floor is the 35th smallest of the 64 lane minima
-// (expected: ~48 columns below it).  Same cache contract as refresh_row.
+// of the (L2 / MALL resident) row, starting from the 35th smallest of the 64 lane minima (49 +- 5 columns lie below it whatever
+// the distribution: two sweeps for a wave's first row and for every row whose neighbour's floor does not fit -- the rows of a
+// few-cell-type matrix).  Same cache contract as refresh_row.
 constexpr int CBW = 4;             // waves per workgroup (they share nothing but the launch)
 struct CbStage { uint32_t col[KC]; float val[KC]; };
 
@@ -1536,11 +1537,8 @@ __global__ __launch_bounds__(64 * CBW) void build_row_caches_wave(int n, int64_t
             const float umin = ord2f(wave_min_u32(f2ord(lmin)));
             float lo = 0.0f, hi = INFINITY;
             bool okc = false;
-            if (tau0 < INFINITY && tau0 > umin && cnt > 0) {              // scale the guess by how far its count was off
-                const float d0 = tau0 - umin;
-                if (cnt > KCU) { hi = d0; delta = d0 * fmaxf(0.0625f, 0.75f * (float)KCU / (float)cnt); }
-                else { lo = d0; delta = d0 * fminf(16.0f, 0.75f * (float)KCU / (float)cnt); }
-            } else if (!(tau0 < INFINITY)) {                             // no guess: from the order statistics of the lane minima
+            {   // the 35th smallest of the 64 lane minima: 49 +- 5 columns lie below it whatever the distribution (distinct values;
+                //  lap_wide.hip, SC_FLOOR_POS) -- the bisection that follows is for rows with ties
                 float lm = lmin;
 #pragma unroll
                 for (int k = 2; k <= 64; k <<= 1) {
@@ -1553,6 +1551,11 @@ __global__ __launch_bounds__(64 * CBW) void build_row_caches_wave(int n, int64_t
                 }
                 const float m34 = __shfl(lm, 34);
                 if (m34 < INFINITY && m34 > umin) delta = m34 - umin;
+                else if (tau0 < INFINITY && tau0 > umin && cnt > 0) {     // (fewer than 35 lanes have columns) scale the guess by its count
+                    const float d0 = tau0 - umin;
+                    if (cnt > KCU) { hi = d0; delta = d0 * fmaxf(0.0625f, 0.75f * (float)KCU / (float)cnt); }
+                    else { lo = d0; delta = d0 * fminf(16.0f, 0.75f * (float)KCU / (float)cnt); }
+                }
             }
             if (!(delta > 0.0f) || !(delta < 1e30f)) delta = 1e-3f;
             for (int it = 0; it < 24 && !okc; it++) {
@@ -3414,6 +3417,10 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
     pl.rows_per_block = (n + pl.rowblocks - 1) / pl.rowblocks;
     pl.rowblocks = (n + pl.rows_per_block - 1) / pl.rows_per_block;
     pl.cache_grid = max(1, min(n, 1024));
+    // (measured, tools/cache_build_bench.py, gpurun_out/r04v: n = 20 000: 8 waves per CU x 8 quads in flight 0.404 ms = 3.96 TB/s, 50 000:
+    //  2.13 ms = 4.69 TB/s -- the workgroup-per-row builders 0.750 / 3.27 ms; n = 10 000: 32 x 4 0.126 ms, 8 x 8 0.137, old 0.183:
+    //  with few rows per wave the second sweep of a wave's first row, from L2, costs less than the waves it would take away)
+    if (n < 16000) { pl.cache_waves = 32; pl.cache_unroll = 4; } else { pl.cache_waves = 8; pl.cache_unroll = 8; }
     // (developer knobs, tools/cache_build_bench.py: CYTO_CACHE_WAVES = 0 selects the workgroup-per-row builders)
     if (const char *e = getenv("CYTO_CACHE_WAVES")) pl.cache_waves = std::max(0, std::min(32, atoi(e)));
     if (const char *e = getenv("CYTO_CACHE_UNROLL")) pl.cache_unroll = atoi(e) == 8 ? 8 : 4;

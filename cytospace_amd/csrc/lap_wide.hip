@@ -92,6 +92,11 @@ template <typename F> __device__ __forceinline__ void wave_row_sweep(const float
 // then 20 bits of identity (the predecessor row in `label`, the column itself in the block minima and in the best unassigned
 // column): one unsigned 64-bit compare orders (distance, k, identity) lexicographically; key >> 32 is the ordered distance.
 constexpr uint32_t LKMAX = 4095u;
+// Which of the 64 sorted lane minima of a row is tried first as the floor of its fresh cache.  The number of columns below the
+// (k + 1)-th smallest lane minimum is the number of draws it takes to hit k + 1 of 64 lanes, less one (distribution-free when the
+// values are distinct): k = 34 -> 49 +- 5 columns, more than 63 in 0.4 % of the rows; k = 47 (rounds 3-4) -> 86 +- 10: the first
+// collecting sweep failed in 99.8 % of the rows and the second candidate (k = 23) left caches of 29 columns.
+constexpr int SC_FLOOR_POS = 34;
 __device__ __forceinline__ unsigned long long lkey(unsigned long long lv, uint32_t id) { return (lv << 20) | id; }
 __device__ __forceinline__ unsigned long long lv_of(unsigned long long key) { return key >> 20; }
 __device__ __forceinline__ uint32_t lid_of(unsigned long long key) { return (uint32_t)key & 0xFFFFFu; }
@@ -256,7 +261,7 @@ template <bool VLDS, bool CLDS> struct ArrCtx {
     }
     // exact lexicographic top-2 of the whole row (the cache could not certify) -- and a fresh cache for the row against the
     // current prices, so that its next bids are certified again (in a price war the same few rows bid thousands of times).
-    // The new floor is one of the 64 per-lane minima of the sweep (sorted; the 48th, else the 32nd, 16th ... smallest): every
+    // The new floor is one of the 64 per-lane minima of the sweep (sorted; the 35th, else the 17th, 8th ... smallest: SC_FLOOR_POS): every
     // column below it is collected in a second sweep of the now L2-resident row; more than 63 of them -> the next candidate.
     // (Inlined on purpose: as an out-of-line call its results travel through scratch memory, and every bid -- also the
     // certified ones -- then stores and reloads them through the vector memory path.)
@@ -284,7 +289,7 @@ template <bool VLDS, bool CLDS> struct ArrCtx {
         }
         uint32_t tk = 0;                                           // ordered floor; 0 = none found
         int cnt = 0;
-        for (int pos = 47; pos >= 2 && !tk; pos = (pos + 1) / 2 - 1) {
+        for (int pos = SC_FLOOR_POS; pos >= 2 && !tk; pos = (pos + 1) / 2 - 1) {
             const uint32_t cand = rdlane(lm, pos);
             if (cand == 0xFFFFFFFFu) continue;
             if (lane == 0) s->rf_cnt[w] = 0;
@@ -451,7 +456,7 @@ template <typename F> __device__ __forceinline__ void block_row_sweep(const floa
     }
 }
 // the whole workgroup: exact lexicographic top-2 of row i -- and a fresh cache for it against the current prices (floor = one of the 64
-// minima of the columns c with (c / 4) % 64 == l, sorted: the 48th, else the 24th, 12th ... smallest; the columns below it are collected in
+// minima of the columns c with (c / 4) % 64 == l, sorted: the 35th, else the 17th, 8th ... smallest; the columns below it are collected in
 // a second sweep of the now L2-resident row; more than 63 of them -> the next candidate).  Every thread returns the same Top2.
 __device__ __forceinline__ Top2 sc_top2_block(const WideArgs &a, ScShared &ss, int i, bool rebuild) {
     const int n = a.n, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -487,7 +492,7 @@ __device__ __forceinline__ Top2 sc_top2_block(const WideArgs &a, ScShared &ss, i
     }
     uint32_t tk = 0;                                               // ordered floor; 0 = none found
     int cnt = 0;
-    for (int pos = 47; pos >= 2 && !tk; pos = (pos + 1) / 2 - 1) {
+    for (int pos = SC_FLOOR_POS; pos >= 2 && !tk; pos = (pos + 1) / 2 - 1) {
         if (w == 0 && lane == 0) { ss.cand = rdlane(lm, pos); ss.cnt = 0; }
         __syncthreads();
         const uint32_t cand = ss.cand;

@@ -20,7 +20,7 @@ def main():
     for n in sizes:
         if typed:
             from tools.instances import typed_unique_cost
-            c = typed_unique_cost(n, n, 20)
+            c, _ = typed_unique_cost(n, n, 20)
         else:
             c = np.random.default_rng(n).random((n, n)).astype(np.float32)
         buf = _lib.DeviceBuffer.from_numpy(c)
