@@ -16,9 +16,9 @@
 // the LAP entry point then reports CYTO_ERR_NONFINITE.
 //
 // Kernels
-//   colsum_partial / colmoments_partial / col_finish : per-column statistics (HBM-bound streaming;
+//   colsum_partial_v / colmoments_partial_v / col_finish : per-column statistics (HBM-bound streaming;
 //       lanes run along the contiguous cell/spot axis, partial sums over blocks of genes).
-//   standardize_write : z in float32 into a zero-padded [Gpad][pitch] buffer (pitch % 128 == 0)
+//   transform_write_v : z in float32 into a zero-padded [Gpad][pitch] buffer (pitch % 128 == 0)
 //   normalize_write   : y in float64 (only for callers that want normalize_data itself)
 //   pearson_gemm      : 128x128x32 LDS-tiled TN GEMM on 32x32x2 fp32 MFMA, epilogue negates and
 //                       writes each spot row to its slots[s] consecutive LAP rows.
@@ -42,18 +42,6 @@ template <typename TIn> __device__ __forceinline__ double clean(TIn x) {
     return d;
 }
 
-// partial column sums of the cleaned input over a block of GB genes
-template <typename TIn>
-__global__ __launch_bounds__(256) void colsum_partial(int G, int C, const TIn *__restrict__ x, int64_t ldx,
-                                                      double *__restrict__ part) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const int g0 = blockIdx.y * GB, g1 = min(G, g0 + GB);
-    double s = 0.0;
-    for (int g = g0; g < g1; g++) s += clean<TIn>(x[(int64_t)g * ldx + c]);
-    part[(int64_t)blockIdx.y * C + c] = s;
-}
-
 // y = log2(x * 1e6 / colsum + 1) with NaN -> 0 (an all-zero column is 0/0)
 template <typename TIn> __device__ __forceinline__ double normalized(TIn x, double scale, bool already) {
     if (already) return clean<TIn>(x);
@@ -63,23 +51,98 @@ template <typename TIn> __device__ __forceinline__ double normalized(TIn x, doub
     return y;
 }
 
-// partial first and second moments of y over a block of genes
-template <typename TIn>
-__global__ __launch_bounds__(256) void colmoments_partial(int G, int C, const TIn *__restrict__ x, int64_t ldx,
-                                                          const double *__restrict__ colsum, int already,
-                                                          double *__restrict__ p1, double *__restrict__ p2) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const int g0 = blockIdx.y * GB, g1 = min(G, g0 + GB);
-    const double scale = already ? 1.0 : 1e6 / colsum[c];
-    double s1 = 0.0, s2 = 0.0;
-    for (int g = g0; g < g1; g++) {
-        const double y = normalized<TIn>(x[(int64_t)g * ldx + c], scale, already);
-        s1 += y;
-        s2 += y * y;
+// log2 of a double in [1, 2^1023) in ~25 instructions (ocml's log2: ~120, and the transform evaluates it twice per element -- at 65 f64
+// operations each the two passes were bound by the vector ALUs, not by HBM): t = 2^e m, m in [1, 2); the top six mantissa bits select
+// c_i = (129 + 2 i) / 128 (c_0 = 1: values next to 1 -- a count of zero is t = 1 exactly -- keep full RELATIVE accuracy, log2(1) = 0),
+// r = (m - c_i) / c_i with |r| <= 1 / 64 and m - c_i exact, log2 t = (e + log2 c_i) + log2(1 + r), the last as its Taylor polynomial of
+// degree 9 (the first dropped term: 1e-19).  Against long-double log2 on [1, 1e7] and next to 1: relative error <= 2.2e-16 (one ulp).
+// tbl[i] = { 1 / c_i, log2 c_i } (a copy of LOG2_TBL in LDS).
+__device__ const double LOG2_TBL[64][2] = {
+    {1.0, 0.0}, {0.9770992366412213, 0.03342300153745028},
+    {0.9624060150375939, 0.0552824355011896}, {0.9481481481481482, 0.0768155970508309},
+    {0.9343065693430657, 0.09803208296052672}, {0.920863309352518, 0.11894107272350743},
+    {0.9078014184397163, 0.13955135239879354}, {0.8951048951048951, 0.1598713367783894},
+    {0.8827586206896552, 0.17990909001493446}, {0.8707482993197279, 0.1996723448363644},
+    {0.8590604026845637, 0.21916852046216156}, {0.847682119205298, 0.2384047393250789},
+    {0.8366013071895425, 0.25738784269265175}, {0.8258064516129032, 0.27612440527423754},
+    {0.8152866242038217, 0.294620748891627}, {0.8050314465408805, 0.31288295528435534},
+    {0.7950310559006211, 0.33091687811461695}, {0.7852760736196319, 0.34872815423107756},
+    {0.7757575757575758, 0.3663222142458158}, {0.7664670658682635, 0.38370429247405224},
+    {0.757396449704142, 0.4008794362821843}, {0.7485380116959064, 0.41785251488589786},
+    {0.7398843930635838, 0.43462822763672465}, {0.7314285714285714, 0.4512111118323288},
+    {0.7231638418079096, 0.4676055500829974}, {0.7150837988826816, 0.4838157772642564},
+    {0.7071823204419889, 0.4998458870832054}, {0.6994535519125683, 0.5156998382840424},
+    {0.6918918918918919, 0.5313814605163121}, {0.6844919786096256, 0.5468944598876366},
+    {0.6772486772486772, 0.5622424242210726}, {0.6701570680628273, 0.5774288280357487},
+    {0.6632124352331606, 0.5924570372680804}, {0.6564102564102564, 0.6073303137496107},
+    {0.649746192893401, 0.6220518194563762}, {0.6432160804020101, 0.6366246205436489},
+    {0.6368159203980099, 0.6510516911789286}, {0.6305418719211823, 0.6653359171851763},
+    {0.624390243902439, 0.6794800995054461}, {0.6183574879227053, 0.6934869574993252},
+    {0.6124401913875598, 0.7073591320808827}, {0.6066350710900474, 0.7210991887071851},
+    {0.6009389671361502, 0.7347096202258382}, {0.5953488372093023, 0.7481928495894603},
+    {0.5898617511520737, 0.7615512324444793}, {0.5844748858447488, 0.7747870596011734},
+    {0.579185520361991, 0.7879025593914316}, {0.5739910313901345, 0.8008998999203047},
+    {0.5688888888888889, 0.8137811912170371}, {0.5638766519823789, 0.826548487290915},
+    {0.5589519650655022, 0.839203788096944}, {0.5541125541125541, 0.8517490414160576},
+    {0.5493562231759657, 0.8641861446542802}, {0.5446808510638298, 0.8765169465649997},
+    {0.540084388185654, 0.8887432488982591}, {0.5355648535564853, 0.9008668079807486},
+    {0.5311203319502075, 0.9128893362299616}, {0.5267489711934157, 0.9248125036057809},
+    {0.5224489795918368, 0.9366379390025705}, {0.5182186234817814, 0.9483672315846776},
+    {0.5140562248995983, 0.9600019320680809}, {0.5099601593625498, 0.971543553950772},
+    {0.5059288537549407, 0.9829935746943101}, {0.5019607843137255, 0.9943534368588579}};
+__device__ __forceinline__ double log2_ge1(double t, const double2 *__restrict__ tbl) {
+    const int hi = __double2hiint(t), lo = __double2loint(t);
+    const int e = ((hi >> 20) & 0x7FF) - 1023;
+    const double m = __hiloint2double((hi & 0x000FFFFF) | 0x3FF00000, lo);
+    const int i = (hi >> 14) & 63;
+    const double2 ck = tbl[i];
+    const double c = i ? (double)(129 + 2 * i) * 0.0078125 : 1.0;
+    const double r = (m - c) * ck.x;
+    double p = 0.1602994489876626;
+    p = fma(p, r, -0.18033688011112042);
+    p = fma(p, r, 0.2060992915555662);
+    p = fma(p, r, -0.2404491734814939);
+    p = fma(p, r, 0.28853900817779266);
+    p = fma(p, r, -0.36067376022224085);
+    p = fma(p, r, 0.4808983469629878);
+    p = fma(p, r, -0.7213475204444817);
+    p = fma(p, r, 1.4426950408889634);
+    return fma(r, p, (double)e + ck.y);
+}
+// (out of line: the rare path's ~120 instructions stay out of the streaming loops)
+__device__ __attribute__((noinline)) double log2_cleaned(double t) {
+    double y = log2(t);
+    if (y != y) y = 0.0;
+    if (y > 1.7976931348623157e308) y = 1.7976931348623157e308;
+    return y;
+}
+// `normalized` with the fast logarithm wherever its argument is an ordinary number >= 1 (every non-negative count of a column with a
+// positive sum); anything else -- negative or non-finite input, an all-zero column's 0 * inf -- takes the library's log2 as before
+template <typename TIn, int VEC>
+__device__ __forceinline__ void normalized_f(const TIn (&x)[VEC], const double (&scale)[VEC], bool already, const double2 *__restrict__ tbl,
+                                             double (&y)[VEC]) {
+    if (already) {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) y[e] = clean<TIn>(x[e]);
+        return;
     }
-    p1[(int64_t)blockIdx.y * C + c] = s1;
-    p2[(int64_t)blockIdx.y * C + c] = s2;
+    double t[VEC];
+    bool all_ok = true;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) {
+        t[e] = clean<TIn>(x[e]) * scale[e] + 1.0;
+        const bool ok = t[e] >= 1.0 && t[e] < 8.0e307;
+        all_ok = all_ok && ok;
+        y[e] = log2_ge1(ok ? t[e] : 1.0, tbl);                   // (straight-line for every lane; the odd ones are redone below)
+    }
+    if (!all_ok) {
+#pragma unroll
+        for (int e = 0; e < VEC; e++)
+            if (!(t[e] >= 1.0 && t[e] < 8.0e307)) y[e] = log2_cleaned(t[e]);
+    }
+}
+__device__ __forceinline__ void load_log2_table(double2 *tbl) {      // (64 entries; the caller synchronises)
+    if (threadIdx.x < 64) tbl[threadIdx.x] = make_double2(LOG2_TBL[threadIdx.x][0], LOG2_TBL[threadIdx.x][1]);
 }
 
 // ---- the transform's streaming kernels (round 4) -------------------------------------------------------------------------------
@@ -151,6 +214,9 @@ __global__ __launch_bounds__(64 * TRS) void colmoments_partial_v(int G, int C, c
                                                                  const double *__restrict__ colsum, int already,
                                                                  double *__restrict__ p1, double *__restrict__ p2) {
     __shared__ double sh[TRS - 1][64 * VEC];
+    __shared__ double2 tbl[64];
+    load_log2_table(tbl);
+    __syncthreads();
     const int lane = threadIdx.x & 63, rs = threadIdx.x >> 6;
     const int c0 = ((int)blockIdx.x * 64 + lane) * VEC;
     const bool act = c0 < C;
@@ -164,11 +230,12 @@ __global__ __launch_bounds__(64 * TRS) void colmoments_partial_v(int G, int C, c
         for (int g = g0 + rs; g < g1; g += TRS, p += TRS * ldx) {
             TIn r[VEC];
             load_cols<TIn, VEC>(p, r);
+            double y[VEC];
+            normalized_f<TIn, VEC>(r, scale, already, tbl, y);
 #pragma unroll
             for (int e = 0; e < VEC; e++) {
-                const double y = normalized<TIn>(r[e], scale[e], already);
-                s1[e] += y;
-                s2[e] += y * y;
+                s1[e] += y[e];
+                s2[e] += y[e] * y[e];
             }
         }
     }
@@ -183,6 +250,9 @@ __global__ __launch_bounds__(64 * TRS) void transform_write_v(int G, int C, cons
                                                               const double *__restrict__ colsum, const double *__restrict__ mean,
                                                               const double *__restrict__ inv, int already,
                                                               float *__restrict__ z, int64_t ldz) {
+    __shared__ double2 tbl[64];
+    load_log2_table(tbl);
+    __syncthreads();
     const int lane = threadIdx.x & 63, rs = threadIdx.x >> 6;
     const int c0 = ((int)blockIdx.x * 64 + lane) * VEC;
     if (c0 >= C) return;
@@ -201,11 +271,10 @@ __global__ __launch_bounds__(64 * TRS) void transform_write_v(int G, int C, cons
         TIn r[VEC];
         load_cols<TIn, VEC>(p, r);
         float o[VEC];
+        double y[VEC];
+        normalized_f<TIn, VEC>(r, scale, already, tbl, y);
 #pragma unroll
-        for (int e = 0; e < VEC; e++) {
-            const double y = normalized<TIn>(r[e], scale[e], already);
-            o[e] = MODE == 0 ? (float)((y - m[e]) * iv[e]) : (float)y;
-        }
+        for (int e = 0; e < VEC; e++) o[e] = MODE == 0 ? (float)((y[e] - m[e]) * iv[e]) : (float)y[e];
         if constexpr (VEC == 4) *reinterpret_cast<float4 *>(q) = make_float4(o[0], o[1], o[2], o[3]);
         else q[0] = o[0];
     }
@@ -235,22 +304,6 @@ __global__ void col_finish_moments(int G, int C, int nblk, const double *__restr
 }
 
 template <typename TIn>
-__global__ __launch_bounds__(256) void standardize_write(int G, int C, const TIn *__restrict__ x, int64_t ldx,
-                                                         const double *__restrict__ colsum, const double *__restrict__ mean,
-                                                         const double *__restrict__ inv, int already,
-                                                         float *__restrict__ z, int64_t ldz) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const int g0 = blockIdx.y * GB, g1 = min(G, g0 + GB);
-    const double scale = already ? 1.0 : 1e6 / colsum[c];
-    const double m = mean[c], iv = inv[c];
-    for (int g = g0; g < g1; g++) {
-        const double y = normalized<TIn>(x[(int64_t)g * ldx + c], scale, already);
-        z[(int64_t)g * ldz + c] = (float)((y - m) * iv);
-    }
-}
-
-template <typename TIn>
 __global__ __launch_bounds__(256) void normalize_write(int G, int C, const TIn *__restrict__ x, int64_t ldx,
                                                        const double *__restrict__ colsum, double *__restrict__ y, int64_t ldy) {
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -258,18 +311,6 @@ __global__ __launch_bounds__(256) void normalize_write(int G, int C, const TIn *
     const int g0 = blockIdx.y * GB, g1 = min(G, g0 + GB);
     const double scale = 1e6 / colsum[c];
     for (int g = g0; g < g1; g++) y[(int64_t)g * ldy + c] = normalized<TIn>(x[(int64_t)g * ldx + c], scale, false);
-}
-
-// z = y as float32 (no centring, no scaling): operand of the Euclidean metric
-template <typename TIn>
-__global__ __launch_bounds__(256) void convert_write(int G, int C, const TIn *__restrict__ x, int64_t ldx,
-                                                     const double *__restrict__ colsum, int already,
-                                                     float *__restrict__ z, int64_t ldz) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const int g0 = blockIdx.y * GB, g1 = min(G, g0 + GB);
-    const double scale = already ? 1.0 : 1e6 / colsum[c];
-    for (int g = g0; g < g1; g++) z[(int64_t)g * ldz + c] = (float)normalized<TIn>(x[(int64_t)g * ldx + c], scale, already);
 }
 
 // partial column sums of squares of a float32 matrix (the rounded values the matrix cores will see)

@@ -3420,7 +3420,11 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
     // (measured, tools/cache_build_bench.py, gpurun_out/r04v: n = 20 000: 8 waves per CU x 8 quads in flight 0.404 ms = 3.96 TB/s, 50 000:
     //  2.13 ms = 4.69 TB/s -- the workgroup-per-row builders 0.750 / 3.27 ms; n = 10 000: 32 x 4 0.126 ms, 8 x 8 0.137, old 0.183:
     //  with few rows per wave the second sweep of a wave's first row, from L2, costs less than the waves it would take away)
-    if (n < 16000) { pl.cache_waves = 32; pl.cache_unroll = 4; } else { pl.cache_waves = 8; pl.cache_unroll = 8; }
+    //  A few-cell-type matrix (tools/cache_build_bench.py 20000 --typed, gpurun_out/r04x) is another matter: its rows sit at different
+    //  levels, a neighbour's floor fits 6 % of them, nearly every row is swept twice (the second time from L2 by its one wave) and what
+    //  counts is how many waves there are: 8 x 8 1.36 ms, 20 x 8 1.01 ms, 32 x 4 1.02 ms, old 0.97 ms.  20 waves x 8 quads is within
+    //  5 % of the best setting of every instance measured (uniform 20 000: 0.412 ms, 50 000: 2.25 ms, 10 000: 0.123 ms).
+    pl.cache_waves = 20; pl.cache_unroll = 8;
     // (developer knobs, tools/cache_build_bench.py: CYTO_CACHE_WAVES = 0 selects the workgroup-per-row builders)
     if (const char *e = getenv("CYTO_CACHE_WAVES")) pl.cache_waves = std::max(0, std::min(32, atoi(e)));
     if (const char *e = getenv("CYTO_CACHE_UNROLL")) pl.cache_unroll = atoi(e) == 8 ? 8 : 4;
