@@ -3424,7 +3424,10 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
     //  levels, a neighbour's floor fits 6 % of them, nearly every row is swept twice (the second time from L2 by its one wave) and what
     //  counts is how many waves there are: 8 x 8 1.36 ms, 20 x 8 1.01 ms, 32 x 4 1.02 ms, old 0.97 ms.  20 waves x 8 quads is within
     //  5 % of the best setting of every instance measured (uniform 20 000: 0.412 ms, 50 000: 2.25 ms, 10 000: 0.123 ms).
-    pl.cache_waves = 20; pl.cache_unroll = 8;
+    //  n = 50 000 prefers 8 waves per CU by more than the build's own time (same box, gpurun_out/r04z: row reduction 21.5-23.0 ms after a
+    //  build with 8 waves, 24.0-24.8 ms after one with 20 -- 183 instead of 146 full-row bids, each holding up a round for one 200-KB sweep).
+    pl.cache_unroll = 8;
+    pl.cache_waves = n > 32768 ? 8 : 20;
     // (developer knobs, tools/cache_build_bench.py: CYTO_CACHE_WAVES = 0 selects the workgroup-per-row builders)
     if (const char *e = getenv("CYTO_CACHE_WAVES")) pl.cache_waves = std::max(0, std::min(32, atoi(e)));
     if (const char *e = getenv("CYTO_CACHE_UNROLL")) pl.cache_unroll = atoi(e) == 8 ? 8 : 4;

@@ -431,8 +431,7 @@ __device__ __forceinline__ bool sc_top2_cached(const WideArgs &a, int lane, uint
     return true;
 }
 // the whole workgroup (HEADB threads): f(column, cost, price) for every column of the row, 16 bytes of row and prices per lane and step
-template <typename F> __device__ __forceinline__ void block_row_sweep(const float *__restrict__ row, const float *__restrict__ v, int n, F &&f) {
-    constexpr int U = 4;
+template <int U, typename F> __device__ __forceinline__ void block_row_sweep(const float *__restrict__ row, const float *__restrict__ v, int n, F &&f) {
     const int nq = (n + 3) >> 2;
     const float4 *__restrict__ r4 = reinterpret_cast<const float4 *>(row);
     const float4 *__restrict__ v4 = reinterpret_cast<const float4 *>(v);      // (16-byte aligned, followed by u in the workspace: whole quads stay in range)
@@ -458,12 +457,14 @@ template <typename F> __device__ __forceinline__ void block_row_sweep(const floa
 // the whole workgroup: exact lexicographic top-2 of row i -- and a fresh cache for it against the current prices (floor = one of the 64
 // minima of the columns c with (c / 4) % 64 == l, sorted: the 35th, else the 17th, 8th ... smallest; the columns below it are collected in
 // a second sweep of the now L2-resident row; more than 63 of them -> the next candidate).  Every thread returns the same Top2.
+template <int U>
 __device__ __forceinline__ Top2 sc_top2_block(const WideArgs &a, ScShared &ss, int i, bool rebuild) {
     const int n = a.n, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float *__restrict__ row = a.cost + wrow_off(a.rowmap, i, a.ld);
     K2 d; d.m1 = KEYMAX; d.m2 = KEYMAX;
-    block_row_sweep(row, a.v, n, [&](int c, float x, float vc) { k2_push(d, mkkey(x - vc, (uint32_t)c)); });
-    ss.lmin[tid] = (uint32_t)(d.m1 >> 32);
+    block_row_sweep<U>(row, a.v, n, [&](int c, float x, float vc) { k2_push(d, mkkey(x - vc, (uint32_t)c)); });
+    const uint32_t my_min = (uint32_t)(d.m1 >> 32);              // the smallest reduced cost among THIS thread's columns (ordered)
+    ss.lmin[tid] = my_min;
     d = k2_wave_allreduce(d);
     if (lane == 0) { ss.km1[w] = d.m1; ss.km2[w] = d.m2; }
     __syncthreads();
@@ -496,8 +497,8 @@ __device__ __forceinline__ Top2 sc_top2_block(const WideArgs &a, ScShared &ss, i
         if (w == 0 && lane == 0) { ss.cand = rdlane(lm, pos); ss.cnt = 0; }
         __syncthreads();
         const uint32_t cand = ss.cand;
-        if (cand != 0xFFFFFFFFu)
-            block_row_sweep(row, a.v, n, [&](int c, float x, float vc) {
+        if (cand != 0xFFFFFFFFu && my_min < cand)                    // (a thread none of whose columns lies below the candidate reads nothing: ~4 of 5)
+            block_row_sweep<U>(row, a.v, n, [&](int c, float x, float vc) {
                 if (f2ord(x - vc) < cand) {
                     const int p = atomicAdd(&ss.cnt, 1);
                     if (p < KCU) { ss.ccol[p] = (uint32_t)c; ss.cval[p] = x; }
@@ -596,6 +597,7 @@ __global__ __launch_bounds__(HEADB) void wide_sc_init(const WideArgs *__restrict
     }
 }
 
+template <int U>
 __global__ __launch_bounds__(HEADB) void wide_sc_bid(const WideArgs *__restrict__ batch, int L) {
     extern __shared__ __align__(16) unsigned char w_smem[];
     const WideArgs a = load_wide_args(batch, blockIdx.y);
@@ -659,7 +661,7 @@ __global__ __launch_bounds__(HEADB) void wide_sc_bid(const WideArgs *__restrict_
             if (threadIdx.x == 0) ss.nq = 0;
             for (int q = 0; q < nq; q++) {
                 const int i = ss.qrow[q], slot = ss.qslot[q];
-                const Top2 t = sc_top2_block(a, ss, i, refresh);
+                const Top2 t = sc_top2_block<U>(a, ss, i, refresh);
                 if (w == 0) { record(slot, i, t); dense++; }
             }
             __syncthreads();
@@ -2092,14 +2094,17 @@ int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, i
         // the other kernels of the machine are a thread per row / slot
         const int bx = std::max(1, std::min((n + HEADB / 64 - 1) / (HEADB / 64), std::max(64, 4096 / std::max(1, nb))));
         const int bxr = std::max(1, std::min((n + HEADB - 1) / HEADB, 2048 / std::max(1, std::min(nb, 16))));
-        if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(wide_sc_bid)))) return rc;
+        // (quads of a full-row bid's sweep in flight per lane: developer knob CYTO_BID_UNROLL, tools/exp)
+        static const bool deep = [] { const char *e = getenv("CYTO_BID_UNROLL"); return e && atoi(e) == 8; }();
+        void (*bidk)(const WideArgs *, int) = deep ? wide_sc_bid<8> : wide_sc_bid<4>;
+        if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(bidk)))) return rc;
         hipLaunchKernelGGL(wide_sc_init, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args);
         std::vector<int32_t> h_sync((size_t)nb + 1, 0);
         int L = 0, group = 32;
         for (;;) {
             for (int g = 0; g < group; g++, L++) {
                 if (L > 0 && L % wipe == 0) hipLaunchKernelGGL(wide_sc_wipe, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args, L);
-                hipLaunchKernelGGL(wide_sc_bid, dim3(bx, nb), dim3(HEADB), SC_SHARED_BYTES, stream, d_args, L);
+                hipLaunchKernelGGL(bidk, dim3(bx, nb), dim3(HEADB), SC_SHARED_BYTES, stream, d_args, L);
                 hipLaunchKernelGGL(wide_sc_resolve, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args, L);
             }
             if (!d_sync) return CYTO_ERR_INTERNAL;
