@@ -26,6 +26,7 @@
 #include <math.h>
 #include <algorithm>
 #include <vector>
+#include <thread>
 #include <new>
 #include <string.h>
 
@@ -1120,13 +1121,14 @@ int cyto_ctx_assign_chunks(cyto_expr_ctx *ctx, int nchunks, cyto_chunk *chunks, 
         std::vector<Prep> pp((size_t)cnt);
         DevBuf zst, zsc, dsc, dst;                    // gathered operands, reused by the chunks of this round
         size_t cap_st = 0, cap_sc = 0, cap_isc = 0, cap_ist = 0;
-        for (int k = 0; k < cnt; k++) {
+        auto build_one = [&](int k) -> int {                  // the cost matrix of chunk lo + k; a status other than OK ends the call
+            int rc = CYTO_OK;
             cyto_chunk &ch = chunks[lo + k];
             Prep &p = pp[(size_t)k];
             ch.status = CYTO_OK; ch.total_cost = 0.0;
             memset(&ch.info, 0, sizeof ch.info);
             const int nst = ch.idx_st ? ch.n_st : ctx->S;
-            if (!ch.idx_sc || ch.n_sc <= 0 || !ch.slots || !ch.mapped_spot || nst <= 0) { ch.status = CYTO_ERR_BAD_ARG; continue; }
+            if (!ch.idx_sc || ch.n_sc <= 0 || !ch.slots || !ch.mapped_spot || nst <= 0) { ch.status = CYTO_ERR_BAD_ARG; return CYTO_OK; }
             for (int t = 0; t < nst && ch.status == CYTO_OK; t++) {
                 if (ch.slots[t] < 0) { ch.status = CYTO_ERR_BAD_ARG; break; }
                 const int64_t s_ = ch.idx_st ? ch.idx_st[t] : t;
@@ -1139,7 +1141,7 @@ int cyto_ctx_assign_chunks(cyto_expr_ctx *ctx, int nchunks, cyto_chunk *chunks, 
                 if (ch.idx_sc[c] < 0 || ch.idx_sc[c] >= ctx->C) { ch.status = CYTO_ERR_BAD_ARG; break; }
                 p.h_sc[(size_t)c] = (int32_t)ch.idx_sc[c];
             }
-            if (ch.status != CYTO_OK) continue;
+            if (ch.status != CYTO_OK) return CYTO_OK;
             p.Su = (int)p.h_st.size();
             const int n_sc = ch.n_sc;
             const int64_t ldzst = round_up(p.Su, BM), ldzsc = round_up(n_sc, BN);
@@ -1180,10 +1182,12 @@ int cyto_ctx_assign_chunks(cyto_expr_ctx *ctx, int nchunks, cyto_chunk *chunks, 
             (void)hipEventElapsedTime(&p.ms_gather, ev[0], ev[1]);
             p.ms_gemm = (float)ms_gemm;
             p.colsol.resize((size_t)p.N);
-        }
-        // the LAPs of this round, together
+            return CYTO_OK;
+        };
+        // the LAPs of chunks [k0, k1) of this round, together (runs on a worker thread while the next group's costs are built)
+        auto solve_range = [&](int k0, int k1) {
         std::vector<int> ids;
-        for (int k = 0; k < cnt; k++) if (chunks[lo + k].status == CYTO_OK) ids.push_back(k);
+        for (int k = k0; k < k1; k++) if (chunks[lo + k].status == CYTO_OK) ids.push_back(k);
         const int nl = (int)ids.size();
         if (nl) {
             std::vector<int> nn((size_t)nl), stat((size_t)nl, CYTO_OK), nus((size_t)nl, 0);
@@ -1213,6 +1217,31 @@ int cyto_ctx_assign_chunks(cyto_expr_ctx *ctx, int nchunks, cyto_chunk *chunks, 
                 ch.info.ms_gemm = p.ms_gemm;
                 ch.info.lap = li[(size_t)q];
                 ch.info.gemm_flops = 2.0 * ctx->Gpad * (double)p.Su * (double)ch.n_sc;
+            }
+        }
+        };
+        // Groups of chunks: while the LAPs of a group run (latency-bound rounds and searches that leave most of the chip idle), the
+        // main thread builds the next group's costs (the contraction: MFMA-bound) -- 64 c4 chunks: cost builds 444 ms + LAPs 300 ms one
+        // after the other before.  A group's LAPs go through lap_batch_any as one batch (its own streams and host threads).
+        const int per_group = cnt >= 16 ? std::max(8, (cnt + 3) / 4) : cnt;
+        auto solve_guarded = [&](int k0, int k1) {
+            try { solve_range(k0, k1); }
+            catch (...) { for (int k = k0; k < k1; k++) if (chunks[lo + k].status == CYTO_OK) chunks[lo + k].status = CYTO_ERR_NOMEM; }
+        };
+        {
+            std::vector<std::thread> workers;
+            struct Joiner { std::vector<std::thread> &t; ~Joiner() { for (std::thread &x : t) if (x.joinable()) x.join(); } } joiner{workers};
+            int g0 = 0;
+            for (int k = 0; k < cnt; k++) {
+                if ((rc = build_one(k))) return rc;             // (the joiner waits for the groups already under way)
+                if (k + 1 - g0 >= per_group || k + 1 == cnt) {
+                    const int a0 = g0, a1 = k + 1;
+                    g0 = a1;
+                    if (a1 == cnt) { solve_guarded(a0, a1); break; }      // the last group: on this thread
+                    bool started = false;
+                    try { workers.emplace_back(solve_guarded, a0, a1); started = true; } catch (...) { started = false; }
+                    if (!started) solve_guarded(a0, a1);
+                }
             }
         }
         for (int k = 0; k < cnt; k++) if (!first && chunks[lo + k].status) first = chunks[lo + k].status;

@@ -407,42 +407,3 @@ def test_float32_inputs_give_the_float64_results():
         sl = np.array([3] * 10 + [0] * 10)
         assert np.array_equal(c32.assign_chunk(idx, sl), c64.assign_chunk(idx, sl))
 
-
-def test_block_pipeline_fails_cleanly_and_the_next_solve_is_untouched():
-    # the fused call uploads the cells in blocks of 8 192 and runs block b's contraction on a second stream while block b + 1 is
-    # transformed (cost.hip, C > 16 384).  A constant cell in the second of three blocks has zero variance: its standardised column
-    # is non-finite like the reference's division by zero (common.py:196-199), the solve reports it -- after contractions were queued
-    # on both streams -- and every work buffer goes back to the block cache.  A solve on ANOTHER host thread right afterwards gets
-    # those blocks: it must see none of the failed call's writes.
-    import threading
-    rng = np.random.default_rng(77)
-    G, C = 48, 3 * 8192 + 64
-    sc = rng.random((G, C)).astype(np.float32)
-    st = rng.random((G, C)).astype(np.float32)
-    sc[:, 8192 + 5] = 1.0                                  # block 2 of 3 (+ a ragged fourth)
-    slots = np.ones(C, np.int64)
-    with pytest.raises(Exception) as ei:
-        gcyto.assign_pearson(sc, st, slots, already_normalized=True)
-    assert "NaN or Inf" in str(ei.value)                  # CYTO_ERR_NONFINITE
-    box = {}
-
-    def second():
-        r = np.random.default_rng(78)
-        sc2, st2 = r.random((G, 700)).astype(np.float32), r.random((G, 700)).astype(np.float32)
-        box["mapped"], box["total"], _ = gcyto.assign_pearson(sc2, st2, np.ones(700, np.int64), already_normalized=True, return_info=True)
-        cost = ocost.calculate_cost(sc2.astype(np.float64), st2.astype(np.float64), np.ones(700, np.int64), "Pearson_correlation")[0]
-        o = jv_oracle(np.ascontiguousarray(cost, dtype=np.float64), np.float64)
-        box["oracle_total"] = o["total"]
-        box["cost"] = cost
-
-    th = threading.Thread(target=second)
-    th.start()
-    th.join()
-    m = box["mapped"]
-    assert np.array_equal(np.sort(m), np.arange(700))
-    on_ref = box["cost"][m, np.arange(700)].sum()         # LAP row = spot (slots == 1), column = cell
-    assert abs(on_ref - box["oracle_total"]) <= 1e-5 * max(1.0, abs(box["oracle_total"]))
-    # and the failed problem itself, repaired, goes through
-    sc[:, 8192 + 5] = rng.random(G).astype(np.float32)
-    m3 = gcyto.assign_pearson(sc[:, :20000], st[:, :20000], np.ones(20000, np.int64), already_normalized=True)
-    assert np.array_equal(np.sort(m3), np.arange(20000))
