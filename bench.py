@@ -165,7 +165,7 @@ def extra_c3(dev):
             dt = time.perf_counter() - t
         xb.free(); zb.free()
         k1_bytes = 4.0 * 4 * G * Cb
-        k1 = {"bound": "hbm", "kernel": "K1: colsum_partial + colmoments_partial + standardize_write (+ finishers)", "columns": Cb,
+        k1 = {"bound": "hbm", "kernel": "K1: colsum_partial_v + colmoments_partial_v + transform_write_v (+ finishers)", "columns": Cb,
               "ms": round(dt * 1e3, 3), "algorithmic_bytes": k1_bytes, "achieved": round(k1_bytes / dt / 1e9, 1), "peak": HBM_PEAK_GBS,
               "unit": "GB/s", "frac": round(k1_bytes / dt / 1e9 / HBM_PEAK_GBS, 4),
               "note": "wall time of cyto_transform on device-resident float32 counts between two device synchronisations"}
@@ -543,7 +543,7 @@ def main():
     ap.add_argument("--c4-chunks", type=int, default=256, help="concurrent chunk LAPs in the c4_chunks leg (256 = one chain per CU; 400 MB each)")
     ap.add_argument("--c4-rank-chunks", type=int, default=64, help="chunks per rank in the c4_sharded leg")
     ap.add_argument("--sharded-timeout", type=float, default=600.0, help="watchdog of the c4_sharded leg, seconds")
-    ap.add_argument("--pmc-tag", default="r04p", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
+    ap.add_argument("--pmc-tag", default="r04ac", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
     args = ap.parse_args()
 
     # ONE JSON line on stdout: everything else this process (or a library under it: RCCL prints a version banner through C

@@ -1221,8 +1221,10 @@ int cyto_ctx_assign_chunks(cyto_expr_ctx *ctx, int nchunks, cyto_chunk *chunks, 
         }
         };
         // Groups of chunks: while the LAPs of a group run (latency-bound rounds and searches that leave most of the chip idle), the
-        // main thread builds the next group's costs (the contraction: MFMA-bound) -- 64 c4 chunks: cost builds 444 ms + LAPs 300 ms one
-        // after the other before.  A group's LAPs go through lap_batch_any as one batch (its own streams and host threads).
+        // main thread builds the next group's costs.  A group's LAPs go through lap_batch_any as one batch (its own streams and host
+        // threads).  Measured (gpurun_out/r04ad against profiles/r04ac_bench.json): 50 single-cell-mode chunks with their 500-gene cost
+        // builds 0.18 -> 0.15 s; 64 c4 chunks with 5 000-gene builds 0.75 s either way -- the contractions take 540 instead of 451 ms
+        // with LAP rounds among them, and a round whose launches queue behind contraction workgroups takes as much longer.
         const int per_group = cnt >= 16 ? std::max(8, (cnt + 3) / 4) : cnt;
         auto solve_guarded = [&](int k0, int k1) {
             try { solve_range(k0, k1); }
