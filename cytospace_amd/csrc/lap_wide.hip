@@ -2095,7 +2095,9 @@ int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, i
         // (at most 2 048 workgroups: late in a phase a few hundred rows bid and a launch is mostly the dispatch of workgroups that find
         //  nothing to do -- same box, gpurun_out/r04af, row-reduction phase with 4 096 / 2 048 / 1 024 / 256 workgroups: 20 000^2 7.9 / 7.5 /
         //  7.4 / 7.9 ms, 50 000^2 22.5-23.0 / 21.5 / 21.4-21.9 / 23.9 ms, few-cell-type 20 000^2 23.1-23.4 / 22.9 / 23.0-23.5 / 26.1 ms)
-        int bx = std::max(1, std::min((n + HEADB / 64 - 1) / (HEADB / 64), std::min(2048, std::max(64, 4096 / std::max(1, nb)))));
+        int bid_total = 4096;
+        if (const char *e = getenv("CYTO_BID_TOTAL")) bid_total = std::max(64, atoi(e));        // (developer knob: tools/exp/bid_grid_batch_ab.sh)
+        int bx = std::max(1, std::min((n + HEADB / 64 - 1) / (HEADB / 64), std::min(2048, std::max(64, bid_total / std::max(1, nb)))));
         if (const char *e = getenv("CYTO_BID_GRID")) bx = std::max(1, std::min(bx, atoi(e)));        // (developer knob: tools/exp/bid_grid_ab.sh)
         const int bxr = std::max(1, std::min((n + HEADB - 1) / HEADB, 2048 / std::max(1, std::min(nb, 16))));
         // (quads of a full-row bid's sweep in flight per lane: developer knob CYTO_BID_UNROLL, tools/exp)
