@@ -57,10 +57,12 @@ int lap_batch_any(int nb, const int *n, const float *const *cost, const int64_t 
             // launches for all its problems, and some of them (the cache rebuilds between searches, the waits for its slowest
             // problem) leave most of the chip idle -- another sub-batch's workgroups fill it.
             // (chunk-sized problems only: 32 problems of 20 000 rows, which never pause, took 0.19 s in four sub-batches, 0.15 s in one)
-            // (tools/exp/subbatch_ab.sh, gpurun_out/r04ai, 10 000-cell chunks: 8 problems 63 / 59 / 59 / 97 ms in 1 / 2 / 4 / 8 sub-batches, 20
-            //  problems 91 / 80 / 144 / 210 ms in 2 / 4 / 10 / 20, 64 problems 171 / 210 / 255 ms in 4 / 8 / 16, 256 problems 540 / 597 /
-            //  1 024 ms in 8 / 16 / 32: beyond a handful the host threads' launches get in each other's way)
-            int G = kv.first > 16384 ? 1 : (cnt >= 128 ? 8 : (cnt >= 16 ? 4 : (cnt >= 8 ? 2 : 1)));
+            // (more sub-batches for 8-31 problems -- 2 / 4 instead of 1 / 2 -- help a lone batch call (tools/exp/subbatch_ab.sh, gpurun_out/r04ai:
+            //  8 problems 63 / 59 / 59 / 97 ms in 1 / 2 / 4 / 8 sub-batches, 20 problems 91 / 80 / 144 / 210 ms in 2 / 4 / 10 / 20, 64 problems
+            //  171 / 210 / 255 ms in 4 / 8 / 16) and cost the context path, whose groups of chunks already run side by side (gpurun_out/r04aj:
+            //  50 c5 chunks 0.15 -> 0.21 s, configs[3]'s 20 chunks 0.31 -> 0.38 s): beyond a handful the host threads' launches get in each
+            //  other's way)
+            int G = kv.first > 16384 ? 1 : (cnt >= 128 ? 8 : (cnt >= 32 ? 4 : (cnt >= 16 ? 2 : 1)));
             if (const char *e = getenv("CYTO_SUBBATCHES")) G = std::max(1, std::min(cnt, atoi(e)));       // (developer knob: tools/batch_chunks_bench.py)
             std::vector<int> brcs((size_t)G, CYTO_OK);
             if (G == 1) {
