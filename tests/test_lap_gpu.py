@@ -581,6 +581,28 @@ def test_wide_search_on_several_workgroups(groups):
             assert g["info"].wide == 1
 
 
+@pytest.mark.parametrize("waves", ["0", "1", "8", "32"])
+def test_row_cache_builders_agree(waves, monkeypatch):
+    # The full-chip cache build: build_row_caches_wave (a wave per row, guessed floor, one sweep; CYTO_CACHE_WAVES waves per CU -- with 1 a
+    # wave takes many rows and its guesses matter, with 32 most rows are a wave's first and take the lane-minima floor) or, with 0, the
+    # workgroup-per-row builders of rounds 1-3.  Which columns a cache holds is a matter of speed only: both solvers give the oracle's
+    # answers bit for bit with every builder -- on uniform, few-cell-type, tie-heavy (the floor search cannot separate: caches
+    # without entries) and duplicated-row instances, ragged sizes (n % 4 != 0, n < 64) included.
+    monkeypatch.setenv("CYTO_CACHE_WAVES", waves)
+    monkeypatch.setenv("CYTO_CACHE_UNROLL", "4" if waves == "1" else "8")
+    rng = np.random.default_rng(91)
+    prof = rng.normal(size=(5, 48)).astype(np.float32)
+    typed = -((prof[rng.integers(0, 5, 3001)] + 0.05 * rng.normal(size=(3001, 48)).astype(np.float32)) @
+              (prof[rng.integers(0, 5, 3001)] + 0.05 * rng.normal(size=(3001, 48)).astype(np.float32)).T).astype(np.float32)
+    cases = [rng.random((6002, 6002)).astype(np.float32), typed, rng.integers(0, 6, (1500, 1500)).astype(np.float32),
+             np.repeat(rng.random((250, 1250)), 5, axis=0).astype(np.float32), rng.random((37, 37)).astype(np.float32),
+             rng.random((5, 5)).astype(np.float32)]
+    for c in cases:
+        _check_wide(c)
+        if c.shape[0] >= 5200 or c.shape[0] == 3001:             # (the chain solver builds caches from n = 5 121 on, and where forced)
+            _check(c, np.float32, opts=dict(augmentation=2) if c.shape[0] == 3001 else None)
+
+
 @pytest.mark.parametrize("rebuild", [0, 1, 3, -1])
 def test_wide_row_caches_rebuilt_between_searches(rebuild):
     # cyto_lap_opts.wide_rebuild: the search kernel returns to the driver when its row caches have gone stale (every search lowers
