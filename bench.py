@@ -543,7 +543,7 @@ def main():
     ap.add_argument("--c4-chunks", type=int, default=256, help="concurrent chunk LAPs in the c4_chunks leg (256 = one chain per CU; 400 MB each)")
     ap.add_argument("--c4-rank-chunks", type=int, default=64, help="chunks per rank in the c4_sharded leg")
     ap.add_argument("--sharded-timeout", type=float, default=600.0, help="watchdog of the c4_sharded leg, seconds")
-    ap.add_argument("--pmc-tag", default="r04ac", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
+    ap.add_argument("--pmc-tag", default="r04am", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
     args = ap.parse_args()
 
     # ONE JSON line on stdout: everything else this process (or a library under it: RCCL prints a version banner through C
