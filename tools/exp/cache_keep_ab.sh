@@ -1,3 +1,4 @@
+# (historical: the CYTO_CACHE_KEEP knob -- a rebuild leaving still-valid caches alone -- was measured with this script and removed again: DESIGN "Tried")
 mkdir -p gpurun_out/r04ae
 for kp in 0 32 48 0 32; do
   export CYTO_CACHE_KEEP=$kp
