@@ -1453,7 +1453,7 @@ __global__ __launch_bounds__(BLOCK2) void build_row_caches_stream(int n, int64_t
 // the distribution: two sweeps for a wave's first row and for every row whose neighbour's floor does not fit -- the rows of a
 // few-cell-type matrix).  Same cache contract as refresh_row.
 constexpr int CBW = 4;             // waves per workgroup (they share nothing but the launch)
-struct CbStage { uint32_t col[KC]; float val[KC]; };
+struct CbStage { uint32_t col[KC]; float val[KC]; float h[KC]; };
 
 // one sweep of the row: counts the columns with h < tau and stages the first 64 of them; TRACK: also the lane minima
 template <int U, bool TRACK>
@@ -1511,11 +1511,133 @@ __device__ __forceinline__ int cb_sweep(const __amdgpu_buffer_rsrc_t rrow, const
     return cnt;
 }
 
+// ascending bitonic sort of one float per lane
+__device__ __forceinline__ float cb_sort64(float x, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const float o = __shfl_xor(x, j);
+            const bool take_min = ((lane & j) == 0) == ((lane & k) == 0);
+            x = take_min ? fminf(x, o) : fmaxf(x, o);
+        }
+    }
+    return x;
+}
+// the staged set (cnt <= 64 entries) cut down to the columns below its (K + 1)-th smallest reduced cost, which becomes the threshold
+__device__ __forceinline__ void cb_compress(CbStage &st, int lane, int K, int &cnt, float &T) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t c = lane < cnt ? st.col[lane] : COLSENT;
+    const float r = lane < cnt ? st.val[lane] : 0.0f;
+    const float h = lane < cnt ? st.h[lane] : INFINITY;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float srt = cb_sort64(h, lane);
+    const float Tn = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(srt), K));
+    if (!(Tn < INFINITY)) return;                                  // no more than K entries: nothing to drop
+    T = Tn;
+    const bool keep = h < Tn;
+    const uint64_t m = __ballot(keep);
+    if (keep) { const int p = __popcll(m & ((1ull << lane) - 1ull)); st.col[p] = c; st.val[p] = r; st.h[p] = h; }
+    cnt = __popcll(m);
+}
+
+// The row in ONE sweep without a guess (rows of >= 256 U columns): the first U quads of every lane (read twice) give 64 lane minima, the 17th
+// smallest of them is the first threshold T (~19 of those 256 U columns lie below it, whatever the distribution); from then on every
+// column below T is staged as it passes, and when the 64 staging slots run over the staged set is cut down to the columns below its
+// 25th smallest reduced cost, which becomes T (a streaming selection: T only falls, so nothing that was passed over could qualify
+// later; two or three cuts per row, each keeping what leaves ~54 columns at the row's end).  At the end the stage holds EVERY column
+// below T, 16 ... 63 of them (~52 on average).  false: the slots
+// ran over twice in one step (an adversarial order of the columns) or fewer than 16 columns are left (ties) -- the caller falls
+// back on the sweeps of the search above, for which the lane minima of the whole row are returned in any case.
+template <int U>
+__device__ __forceinline__ bool cb_stream(const __amdgpu_buffer_rsrc_t rrow, const __amdgpu_buffer_rsrc_t rv, const float *__restrict__ row,
+                                          const float *__restrict__ v, int n, int lane, float &T_out, int &cnt_out, float &lmin, CbStage &st) {
+    const int nfull = n >> 2, ntail = n & 3;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    int cnt = 0, base = 0;                                           // base: the quad the sweep has reached (wave-uniform)
+    float T = INFINITY;
+    bool fail = false;
+    auto one = [&](uint32_t c, float raw, float h, bool valid) {     // (convergent: every lane of the wave calls it)
+        bool p = valid && h < T;
+        uint64_t m = __ballot(p);
+        if (!m) return;
+        if (cnt + __popcll(m) > KC) {
+            // how many to keep: the columns still to come bring K (n - m) / m more below the new threshold when m columns have passed
+            // (any order of the columns but an adversarial one), so K = 54 m / n leaves ~54 at the end of the row -- a cut early in
+            // the row is a deep one, but never below 24: the threshold that leaves 8 of 7 000 columns is known to +-35 %, and rows ended
+            // with anything from 25 to 63 columns (50 000^2: 356 full-row bids instead of 146).  (Cutting to 24 wherever the slots ran over left 16 ... 63, 40 on average: the build was faster
+            // and the solve slower -- 50 000^2: 1 585 instead of 146 full-row bids, row reduction 20.5 -> 25 ms.)
+            const int K = (int)min(48ll, max(24ll, 54ll * (4ll * base) / (long long)n));
+            cb_compress(st, lane, K, cnt, T);
+            p = p && h < T;
+            m = __ballot(p);
+            if (!m) return;
+            if (cnt + __popcll(m) > KC) { fail = true; return; }
+        }
+        if (p) { const int pos = cnt + __popcll(m & lt); st.col[pos] = c; st.val[pos] = raw; st.h[pos] = h; }
+        cnt += __popcll(m);
+    };
+    auto quad = [&](int q, const u32x4_t &xr, const u32x4_t &vr, bool inrange) {
+        const float r0 = __uint_as_float(xr.x), r1 = __uint_as_float(xr.y), r2 = __uint_as_float(xr.z), r3 = __uint_as_float(xr.w);
+        const float h0 = r0 - __uint_as_float(vr.x), h1 = r1 - __uint_as_float(vr.y), h2 = r2 - __uint_as_float(vr.z),
+                    h3 = r3 - __uint_as_float(vr.w);
+        float m4 = fminf(fminf(h0, h1), fminf(h2, h3));
+        if (!inrange) m4 = INFINITY;
+        lmin = fminf(lmin, m4);
+        if (__ballot(m4 < T)) {
+            const uint32_t c0 = (uint32_t)q * 4u;
+            one(c0, r0, h0, inrange); one(c0 + 1, r1, h1, inrange); one(c0 + 2, r2, h2, inrange); one(c0 + 3, r3, h3, inrange);
+        }
+    };
+    {   // the first U quads of every lane: lane minima and the first threshold; the sweep below starts over with them (8 KB that the
+        // wave has just read: keeping them in registers across the sort cost a third of the occupancy)
+        float m0 = INFINITY;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u32x4_t xr = __builtin_amdgcn_raw_buffer_load_b128(rrow, (64 * u + lane) * 16, 0, 0);
+            const u32x4_t vr = __builtin_amdgcn_raw_buffer_load_b128(rv, (64 * u + lane) * 16, 0, 0);
+            m0 = fminf(m0, fminf(fminf(__uint_as_float(xr.x) - __uint_as_float(vr.x), __uint_as_float(xr.y) - __uint_as_float(vr.y)),
+                                 fminf(__uint_as_float(xr.z) - __uint_as_float(vr.z), __uint_as_float(xr.w) - __uint_as_float(vr.w))));
+        }
+        const float srt = cb_sort64(m0, lane);
+        T = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(srt), 16));
+    }
+    for (; base + 64 * U <= nfull; base += 64 * U) {
+        u32x4_t xr[U], vr[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            xr[u] = __builtin_amdgcn_raw_buffer_load_b128(rrow, (base + 64 * u + lane) * 16, 0, 0);
+            vr[u] = __builtin_amdgcn_raw_buffer_load_b128(rv, (base + 64 * u + lane) * 16, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) quad(base + 64 * u + lane, xr[u], vr[u], true);
+    }
+    for (; base < nfull; base += 64) {
+        const int q = base + lane;
+        const u32x4_t xr = __builtin_amdgcn_raw_buffer_load_b128(rrow, q * 16, 0, 0);
+        const u32x4_t vr = __builtin_amdgcn_raw_buffer_load_b128(rv, q * 16, 0, 0);
+        quad(q, xr, vr, q < nfull);
+    }
+    if (ntail) {
+        const int c = nfull * 4 + lane;
+        const bool valid = lane < ntail;
+        const float raw = valid ? row[c] : 0.0f;
+        const float h = valid ? raw - v[c] : INFINITY;
+        lmin = fminf(lmin, h);
+        one((uint32_t)c, raw, h, valid);
+    }
+    if (!fail && cnt > KCU) cb_compress(st, lane, 48, cnt, T);     // (64 staged: the cache has 63 slots)
+    T_out = T; cnt_out = cnt;
+    return !fail && cnt <= KCU && cnt >= 16 && T < INFINITY;
+}
+
 template <int U>
 __global__ __launch_bounds__(64 * CBW) void build_row_caches_wave(int n, int64_t ld, const float *__restrict__ cost,
                                                                  const float *__restrict__ v, uint32_t *__restrict__ cache_col,
                                                                  float *__restrict__ cache_val, const int32_t *__restrict__ rowmap,
-                                                                 const int32_t *__restrict__ same_prev) {
+                                                                 const int32_t *__restrict__ same_prev, int stream) {
     __shared__ CbStage stage[CBW];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (scalar: row bases and descriptors stay in SGPRs)
     CbStage &st = stage[w];
@@ -1528,11 +1650,17 @@ __global__ __launch_bounds__(64 * CBW) void build_row_caches_wave(int n, int64_t
         if (same_prev && same_prev[i]) continue;                          // a copy of the previous row: replicate_group_caches
         const float *__restrict__ row = cost + row_off(rowmap, i, ld);
         const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(row), 0, (int)(ld * 4), 0x00020000);
-        const float tau0 = tau_guess;
-        float lmin = INFINITY, dummy = 0.0f;
-        int cnt = cb_sweep<U, true>(rrow, rv, row, v, n, lane, tau0 < INFINITY ? tau0 : -INFINITY, lmin, st);
-        float tau = tau0;
-        const bool have = tau0 < INFINITY && cnt <= KCU && (cnt >= KCU / 2 || cnt >= n);      // the guess fits: one sweep
+        float tau0 = tau_guess;
+        float lmin = INFINITY, dummy = 0.0f, tau = tau0;
+        int cnt = 0;
+        bool have = false;
+        if (stream && (n >> 2) >= 64 * U) {                                // one sweep, no guess (cb_stream); else the lane minima are complete
+            have = cb_stream<U>(rrow, rv, row, v, n, lane, tau, cnt, lmin, st);
+            if (!have) { tau0 = INFINITY; tau = INFINITY; cnt = 0; }
+        } else {
+            cnt = cb_sweep<U, true>(rrow, rv, row, v, n, lane, tau0 < INFINITY ? tau0 : -INFINITY, lmin, st);
+            have = tau0 < INFINITY && cnt <= KCU && (cnt >= KCU / 2 || cnt >= n);      // the guess fits: one sweep
+        }
         if (!have) {
             const float umin = ord2f(wave_min_u32(f2ord(lmin)));
             float lo = 0.0f, hi = INFINITY;
@@ -3154,6 +3282,7 @@ struct F32Job {
 
 struct F32Plan {            // what depends on n (and the options) only: identical for every problem of the batch
     int n, colblocks, rowblocks, rows_per_block, cache_grid;
+    int cache_stream = 1;           // build_row_caches_wave: the guess-free single sweep (cb_stream); 0: a neighbour's floor as the guess
     int cache_waves = 8, cache_unroll = 4, cus = 256;      // build_row_caches_wave: waves per CU, quads in flight per lane; CUs of the device
     bool force_l2, lds_variant, lazy, lz_lds_state, lz_cs_lds, no_cs_lds, wide;
     long long wide_rounds;
@@ -3185,10 +3314,10 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
                 const int g = std::max(1, std::min((n + CBW - 1) / CBW, pl.cache_waves * pl.cus / CBW));
                 if (pl.cache_unroll == 8)
                     hipLaunchKernelGGL(build_row_caches_wave<8>, dim3(g), dim3(64 * CBW), 0, stream, n, a.ld, a.cost, (const float *)a.fws,
-                                       a.cache_col, a.cache_val, a.rowmap, same);
+                                       a.cache_col, a.cache_val, a.rowmap, same, pl.cache_stream);
                 else
                     hipLaunchKernelGGL(build_row_caches_wave<4>, dim3(g), dim3(64 * CBW), 0, stream, n, a.ld, a.cost, (const float *)a.fws,
-                                       a.cache_col, a.cache_val, a.rowmap, same);
+                                       a.cache_col, a.cache_val, a.rowmap, same, pl.cache_stream);
             } else if constexpr (CH == 0)
                 hipLaunchKernelGGL(build_row_caches_stream, dim3(pl.cache_grid), dim3(BLOCK2), 0, stream, n, a.ld, a.cost,
                                    (const float *)a.fws, a.cache_col, a.cache_val, a.rowmap, same);
@@ -3431,6 +3560,7 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
     // (developer knobs, tools/cache_build_bench.py: CYTO_CACHE_WAVES = 0 selects the workgroup-per-row builders)
     if (const char *e = getenv("CYTO_CACHE_WAVES")) pl.cache_waves = std::max(0, std::min(32, atoi(e)));
     if (const char *e = getenv("CYTO_CACHE_UNROLL")) pl.cache_unroll = atoi(e) == 8 ? 8 : 4;
+    if (const char *e = getenv("CYTO_CACHE_STREAM")) pl.cache_stream = atoi(e) != 0;
     const int per2 = 4 * BLOCK2;
     // which chain variant: by size, or the large-n variants forced at a small n (opts.chain_variant; the test-suite
     // runs them on instances the CPU oracle solves in a second)

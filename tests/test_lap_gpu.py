@@ -581,13 +581,17 @@ def test_wide_search_on_several_workgroups(groups):
             assert g["info"].wide == 1
 
 
-@pytest.mark.parametrize("waves", ["0", "1", "8", "32"])
+@pytest.mark.parametrize("waves", ["0", "1", "8", "32", "8-guess"])
 def test_row_cache_builders_agree(waves, monkeypatch):
     # The full-chip cache build: build_row_caches_wave (a wave per row, guessed floor, one sweep; CYTO_CACHE_WAVES waves per CU -- with 1 a
     # wave takes many rows and its guesses matter, with 32 most rows are a wave's first and take the lane-minima floor) or, with 0, the
     # workgroup-per-row builders of rounds 1-3.  Which columns a cache holds is a matter of speed only: both solvers give the oracle's
     # answers bit for bit with every builder -- on uniform, few-cell-type, tie-heavy (the floor search cannot separate: caches
     # without entries) and duplicated-row instances, ragged sizes (n % 4 != 0, n < 64) included.
+    # ("8-guess": CYTO_CACHE_STREAM=0, a neighbouring row's floor as the guess and the lane minima's 35th as the fallback, instead of the
+    #  guess-free streaming selection of rows of >= 2 048 columns)
+    monkeypatch.setenv("CYTO_CACHE_STREAM", "0" if waves.endswith("guess") else "1")
+    waves = waves.split("-")[0]
     monkeypatch.setenv("CYTO_CACHE_WAVES", waves)
     monkeypatch.setenv("CYTO_CACHE_UNROLL", "4" if waves == "1" else "8")
     rng = np.random.default_rng(91)
