@@ -1445,13 +1445,13 @@ __global__ __launch_bounds__(BLOCK2) void build_row_caches_stream(int n, int64_t
 // The full-chip cache build as ONE WAVE PER ROW (round 4; what the build before and between the solver's phases runs).  The
 // workgroup forms above hold a row in 187 VGPRs (CH = 10: one workgroup per CU, its loads never overlap its threshold search --
 // 2.1 TB/s at n = 20 000) or sweep it several times between workgroup barriers (the streaming form: 3.0 TB/s at n = 50 000).
-// Here a wave streams its row ONCE with U quads per lane in flight and no barrier anywhere: the floor is guessed (the floor of
-// the wave's previous row: rows of one matrix want similar floors, and ANY floor that admits <= 63 columns makes a valid
-// cache), the columns under it are compacted into a 512-byte staging line of the wave by ballot as they pass (some 50 of
-// n), the lane minima are kept for the case that the guess fails -- then the floor is searched as before, by further sweeps
-// of the (L2 / MALL resident) row, starting from the 35th smallest of the 64 lane minima (49 +- 5 columns lie below it whatever
-// the distribution: two sweeps for a wave's first row and for every row whose neighbour's floor does not fit -- the rows of a
-// few-cell-type matrix).  Same cache contract as refresh_row.
+// Here a wave streams its row ONCE with U quads per lane in flight and no barrier anywhere.  Rows of >= 256 U columns: a streaming
+// selection without a guess (cb_stream below: the columns under a falling threshold are compacted into a 768-byte staging line of the
+// wave by ballot as they pass).  Shorter rows, and rows the selection gives up on (ties, an adversarial column order): the floor is
+// guessed (the floor of the wave's previous row; ANY floor that admits <= 63 columns makes a valid cache) and the columns under it are
+// staged during the sweep; a guess that does not fit is replaced by the 35th smallest of the row's 64 lane minima (49 +- 5 columns lie
+// below it whatever the distribution) and the (L2 / MALL resident) row is swept again; a bisection as before when that fails too.
+// Same cache contract as refresh_row.
 constexpr int CBW = 4;             // waves per workgroup (they share nothing but the launch)
 struct CbStage { uint32_t col[KC]; float val[KC]; float h[KC]; };
 
