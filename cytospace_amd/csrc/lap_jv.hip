@@ -1544,7 +1544,8 @@ __device__ __forceinline__ void cb_compress(CbStage &st, int lane, int K, int &c
 }
 
 // The row in ONE sweep without a guess (rows of >= 256 U columns): the first U quads of every lane (read twice) give 64 lane minima, the 17th
-// smallest of them is the first threshold T (~19 of those 256 U columns lie below it, whatever the distribution); from then on every
+// smallest of them (in a long row; up to the 35th in a row of little more than 256 U columns) is the first threshold T (~19 of those
+// 256 U columns lie below it, whatever the distribution); from then on every
 // column below T is staged as it passes, and when the 64 staging slots run over the staged set is cut down to the columns below its
 // 25th smallest reduced cost, which becomes T (a streaming selection: T only falls, so nothing that was passed over could qualify
 // later; two or three cuts per row, each keeping what leaves ~54 columns at the row's end).  At the end the stage holds EVERY column
@@ -1602,7 +1603,12 @@ __device__ __forceinline__ bool cb_stream(const __amdgpu_buffer_rsrc_t rrow, con
                                  fminf(__uint_as_float(xr.z) - __uint_as_float(vr.z), __uint_as_float(xr.w) - __uint_as_float(vr.w))));
         }
         const float srt = cb_sort64(m0, lane);
-        T = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(srt), 16));
+        // which lane minimum: ~c0 of the first 256 U columns are wanted below it, c0 = 54 * 256 U / n (the rest of the row brings its
+        // share), 18 at least and 49 at most (a row of just 256 U columns: the 35th smallest, the two-sweep form's choice); c columns lie
+        // below the (i + 1)-th smallest of 64 lane minima for i = 64 (1 - exp(-(c + 1) / 64)) (the draws it takes to hit i + 1 lanes)
+        const float c0 = fminf(49.0f, fmaxf(18.0f, 54.0f * (float)(256 * U) / (float)n));
+        const int i0 = __builtin_amdgcn_readfirstlane((int)(64.0f * (1.0f - __expf(-(c0 + 1.0f) * 0.015625f))));
+        T = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(srt), i0));
     }
     for (; base + 64 * U <= nfull; base += 64 * U) {
         u32x4_t xr[U], vr[U];
