@@ -2,29 +2,40 @@
 """bench.py -- headline benchmark of the CytoSPACE linear-assignment hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one full solve of BASELINE.json's configs[1]: a 20000 x 20000 dense synthetic float32 cost
-matrix already resident in HBM -> assignment (column reduction, row-cache build, the row-reduction phase -- reduction
-transfer, then the eps-scaled Jacobi rounds as two whole-chip launches each --, the augmentation kernel).  With N GPUs every rank solves its own, differently seeded, instance of the same size (the
-reference shards independent sub-LAPs across workers: cytospace.py:430-451; no data-path collective),
-so scaling is "weak" and value = N * n / max-over-ranks time.
+N > 1: `python bench.py --gpus N` starts its N ranks ITSELF (one child process per GPU, LOCAL_RANK = device), or runs as one
+rank of an external one-process-per-GPU launcher (`python -m <launcher> --nproc-per-node N ... bench.py --gpus N ...`: RANK /
+LOCAL_RANK / WORLD_SIZE from the environment).  Either way the ranks meet through cytospace_amd.rendezvous.FileStore (a directory of small
+files: the 128-byte RCCL id, the barriers around the timed region, the max over ranks) and through RCCL itself (the communicator of
+the chunk legs; `n_gpus` is checked against ncclCommCount).  No tensor framework is imported anywhere.
 
-Besides the headline (`value`, on configs[1]) the same JSON line carries, at N = 1, the other single-GPU
-workloads the north star names (skip them with --no-extras):
-  "c2_batch"  32 copies of the headline instance solved together (one launch per solver phase for all of them)
+A "step" is one full solve of the north star's problem: a 50 000 x 50 000 dense synthetic float32 cost matrix (SURVEY 8d
+"uniform") already resident in HBM -> assignment (column reduction, row-cache build, the row-reduction phase -- reduction transfer,
+then the eps-scaled Jacobi rounds on the whole chip --, the augmentation kernel).  It fits one GPU (10 GB), so by the measurement
+contract it is the N = 1 workload (BASELINE.json's target sentence names it); configs[1] (20 000 x 20 000) is the extra leg "c2".
+With N GPUs every rank solves its own copy of the instance (the reference shards independent sub-LAPs across workers:
+cytospace.py:430-451; inside ONE LAP the path does not shard: replicas only), so scaling is "weak" and value = N * n / max-over-
+ranks time.  Parity of the headline: indices == the committed uniqueness-certified golden (tests/golden/large_u50000.npz: classic
+oracle == scipy), duals / rowsol == the wide restatement's golden, bit for bit, on every rank and every step's last result; plus the
+in-run n = 3 000 gate against both oracles.
+
+`roofline` is FLOOR-based: every cost entry must be read once, 4 n^2 bytes; achieved = 4 n^2 / ms_per_step, frac = achieved / 8 TB/s
+(cannot exceed 1).  `traffic` = HBM bytes of the whole solve from the committed rocprofv3 --pmc passes; `latency_model` says what
+really bounds the solve (dependent rounds x microseconds per round); `dominant_kernel` is the longest single launch with its
+HIP-event time (compare with profiles/<tag>_kernel_stats*.csv).
+
+Besides the headline the same JSON line carries, at N = 1, the other single-GPU workloads the north star names (--no-extras skips):
+  "c2"        BASELINE configs[1]: the 20 000 x 20 000 uniform LAP against its goldens
+  "c2_batch"  32 copies of that instance solved together
   "c2_cytolike" a 20 000 x 20 000 cost of the few-cell-type ("cytospace-like") generator, slots == 1, against its
-              committed certified golden -- the instance class CytoSPACE's chunks belong to, beside the uniform headline
-  "n50000"    the 50 000 x 50 000 uniform LAP (ms, assignments/s, colsol compared with the committed oracle golden)
+              committed certified golden -- the instance class CytoSPACE's chunks belong to
   "c3"        configs[2] end to end: 20 000 genes x 50 000 cells x 5 000 spots, normalise + standardise, fp32-MFMA cost
               GEMM (its own "roofline" against the 157.3 TFLOP/s f32 matrix peak), LAP; wall time includes the H2D copies
   "c4_chunks" K concurrent 10 000-cell --sampling-sub-spots chunk LAPs (configs[3]'s unit of work) on one GPU, with the
               CPU oracle run on all host cores beside it (core count stated)
   "c5_chunks" configs[4]'s 50 single-cell-mode chunks (10 000 cells x 10 000 single-cell spots) in one batched call on one GPU
-and, at every N, "c4_sharded": configs[3]'s structure with the path's one collective -- rank 0 transforms the ST matrix and
-broadcasts the operand over xGMI (RCCL), every rank uploads its own cells and solves its chunks in one batched call.
-
-torch is used only for the rendezvous (barrier + max over ranks); the product never imports it.
+and, at every N, "c4_strong" / "c4_sharded": configs[3]'s structure with the path's one collective -- rank 0 transforms the ST
+matrix and broadcasts the operand over xGMI (RCCL), every rank uploads its own cells and solves its chunks in one batched call.
 """
 import argparse
 import json
@@ -46,41 +57,58 @@ def _sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def extra_n50000(dev):
-    """The north star's 50 000 x 50 000 LAP, resident in HBM; the answer is compared with the oracle's (golden file)."""
+def check_uniform_golden(n, r, wide, required):
+    """A uniform-instance result against the committed goldens of that size: indices (tests/golden/large_u<n>.npz is
+    uniqueness-certified: ANY exact solver's indices) and -- the wide solver -- rowsol and both duals bit for bit against the wide
+    restatement's golden.  Returns (indices_ok, duals_ok) -- None where there is no golden; a missing golden of a `required` size
+    and any mismatch end the run."""
+    gpath = os.path.join(ROOT, "tests", "golden", f"large_u{n}.npz")
+    if not os.path.exists(gpath):
+        if required:
+            raise SystemExit(f"bench.py: {gpath} is missing -- the parity of the headline size cannot be shown")
+        return None, None
+    d = np.load(gpath)
+    ok = bool(np.array_equal(r["colsol"], d["colsol"]))
+    duals = None
+    wpath = os.path.join(ROOT, "tests", "golden", f"large_u{n}_wide.npz")
+    if ok and wide:
+        if os.path.exists(wpath):
+            dw = np.load(wpath)
+            duals = bool(_sha(r["u"]) == str(dw["u_sha256"]) and _sha(r["v"]) == str(dw["v_sha256"]) and _sha(r["rowsol"]) == str(dw["rowsol_sha256"]))
+        elif required:
+            raise SystemExit(f"bench.py: {wpath} is missing")
+    if not ok or duals is False:
+        raise SystemExit(f"uniform {n} x {n}: HIP result differs from tests/golden/large_u{n}[_wide].npz")
+    return ok, duals
+
+
+def extra_uniform(dev, n):
+    """A uniform n x n LAP beside the headline (configs[1]'s 20 000 when the headline is the north star's 50 000, and the other way
+    round), resident in HBM; the answer is compared with the committed goldens."""
     from cytospace_amd.lap import lap_solve
     from tools import instances
-    n = 50000
     t = time.perf_counter()
     buf = instances.blocks_to_device(instances.uniform_cost_blocks(n), n, dev)
     t_gen = time.perf_counter() - t
     lap_solve(None, np.float32, device_id=dev, device_ptr=buf.ptr, n=n, ld=n)          # warm-up
-    t = time.perf_counter()
-    r = lap_solve(None, np.float32, device_id=dev, return_info=True, device_ptr=buf.ptr, n=n, ld=n)
-    wall = time.perf_counter() - t
-    buf.free()
+    walls, r = [], None
+    for _ in range(3):
+        t = time.perf_counter()
+        r = lap_solve(None, np.float32, device_id=dev, return_info=True, device_ptr=buf.ptr, n=n, ld=n)
+        walls.append(time.perf_counter() - t)
+    wall = float(np.median(walls))
     i = r["info"]
-    out = {"n": n, "ms_per_solve": round(wall * 1e3, 1), "assignments_per_s": round(n / wall, 1),
-           "kernel_ms": {"colred": round(i.ms_colred, 2), "row_caches": round(i.ms_cache, 2), "wide_rt+wide_arr" if i.wide else "jv_chain2": round(i.ms_arr, 1),
-                         "wide_aug" if i.wide else "jv_aug_lazy": round(i.ms_aug, 1)},
-           "row_scans": int(i.row_scans), "algorithmic_GBs": round(4.0 * n * i.row_scans / wall / 1e9, 1),
-           "hbm_frac_algorithmic": round(4.0 * n * i.row_scans / wall / 1e9 / HBM_PEAK_GBS, 5),
+    out = {"workload": f"{n} x {n} dense uniform float32 cost resident in HBM" + (" (BASELINE.json configs[1])" if n == 20000 else ""),
+           "n": n, "ms_per_solve": round(wall * 1e3, 2), "assignments_per_s": round(n / wall, 1),
+           "kernel_ms": {"colred": round(i.ms_colred, 2), "row_caches": round(i.ms_cache, 2), "row_reduction": round(i.ms_arr, 2),
+                         "wide_aug": round(i.ms_aug, 2)},
+           "rounds": int(i.wide_rounds), "bids": int(i.scans_arr), "full_row_bids": int(i.wide_dense_arr), "searches": int(i.augmentations),
+           "columns_settled": int(i.scans_aug_relax), "floor_4n2_frac": round(4.0 * n * n / wall / 1e9 / HBM_PEAK_GBS, 6),
            "instance_seconds": round(t_gen, 1)}
-    gpath = os.path.join(ROOT, "tests", "golden", "large_u50000.npz")
-    if os.path.exists(gpath):
-        d = np.load(gpath)
-        ok = bool(np.array_equal(r["colsol"], d["colsol"]))           # the golden is uniqueness-certified: ANY exact solver's indices
-        wpath = os.path.join(ROOT, "tests", "golden", "large_u50000_wide.npz")
-        if ok and i.wide and os.path.exists(wpath):                  # ... and the wide restatement's duals, bit for bit
-            dw = np.load(wpath)
-            ok = bool(_sha(r["u"]) == str(dw["u_sha256"]) and _sha(r["v"]) == str(dw["v_sha256"]) and _sha(r["rowsol"]) == str(dw["rowsol_sha256"]))
-            out["duals_bit_exact_vs_wide_oracle_golden"] = ok
-        out["bit_exact_vs_oracle_golden"] = ok
-        if not ok:
-            raise SystemExit("n50000: HIP result differs from tests/golden/large_u50000.npz")
-    else:
-        out["bit_exact_vs_oracle_golden"] = None
-    return out
+    ok, duals = check_uniform_golden(n, r, bool(i.wide), required=False)
+    out["bit_exact_vs_oracle_golden"] = ok
+    out["duals_bit_exact_vs_wide_oracle_golden"] = duals
+    return out, buf, r
 
 
 def extra_c2_cytolike(dev):
@@ -110,8 +138,7 @@ def extra_c2_cytolike(dev):
                          "wide_aug": round(i.ms_aug, 2)},
            "rounds": int(i.wide_rounds), "phases": int(i.wide_phases), "bids": int(i.scans_arr), "full_row_bids": int(i.wide_dense_arr),
            "searches": int(i.augmentations), "columns_settled": int(i.scans_aug_relax),
-           "row_scans": int(i.row_scans), "algorithmic_GBs": round(4.0 * n * i.row_scans / wall / 1e9, 1),
-           "hbm_frac_algorithmic": round(4.0 * n * i.row_scans / wall / 1e9 / HBM_PEAK_GBS, 5),
+           "row_scans_counted": int(i.row_scans), "hbm_rows_actually_read": int(i.hbm_row_reads),
            "floor_4n2_frac": round(4.0 * n * n / wall / 1e9 / HBM_PEAK_GBS, 6), "instance_seconds": round(t_gen, 1)}
     gpath = os.path.join(ROOT, "tests", "golden", "large_t20000.npz")
     if os.path.exists(gpath):
@@ -127,7 +154,7 @@ def extra_c2_cytolike(dev):
         if not ok:
             raise SystemExit("c2_cytolike: HIP result differs from tests/golden/large_t20000[_wide].npz")
     else:
-        out["bit_exact_vs_oracle_golden"] = None
+        raise SystemExit(f"c2_cytolike: {gpath} is missing")
     return out
 
 
@@ -437,7 +464,7 @@ def extra_c5_chunks(dev, K=50, G=500, chunk=10000, sets=8, cpu_n=10000, cpu_thre
             "instance_seconds": round(t_gen, 1)}
 
 
-def extra_c4_sharded(dev, rank, world, dist, chunks_per_rank, G=5000, S=50000, chunk=10000, cell_sets=8, total_chunks=0):
+def extra_c4_sharded(dev, rank, world, store, comm, chunks_per_rank, G=5000, S=50000, chunk=10000, cell_sets=8, total_chunks=0):
     """BASELINE configs[3]'s structure on N GPUs (weak scaling: chunks_per_rank chunks of 10 000 cells per GPU against
     50 000 spots): rank 0 transforms the ST matrix and broadcasts the float32 operand over xGMI (RCCL; the one collective of
     the path), every rank uploads only its own cells as raw counts and solves its chunks in one batched call.
@@ -476,16 +503,10 @@ def extra_c4_sharded(dev, rank, world, dist, chunks_per_rank, G=5000, S=50000, c
     else:
         subs = [np.bincount(r.integers(0, S, chunk), minlength=S) for _ in range(chunks_per_rank)]    # sub-spot slot counts
     t_gen = time.perf_counter() - t
-    # communicator: the 128-byte id travels through the launcher's own channel
-    uid = [_lib.Communicator.unique_id() if rank == 0 else None]
-    if dist is not None:
-        dist.broadcast_object_list(uid, src=0)
-    comm = _lib.Communicator(uid[0], rank, world, device_id=dev)
-
     def sync():
         _lib.check(_lib.lib().cyto_device_synchronize(dev))
-        if dist is not None:
-            dist.barrier()
+        if store is not None:
+            store.barrier()
 
     sync()
     t0 = time.perf_counter()
@@ -499,12 +520,8 @@ def extra_c4_sharded(dev, rank, world, dist, chunks_per_rank, G=5000, S=50000, c
     ok = all(np.array_equal(np.bincount(mp, minlength=S), subs[k]) for k, (mp, _, _) in enumerate(res))
     if not ok:
         raise SystemExit("c4_sharded: bincount(mapped) != the chunk's slot counts")
-    comm.close()
-    if dist is not None:
-        import torch
-        tt = torch.tensor([el], dtype=torch.float64, device=f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
+    if store is not None:
+        el = float(store.allreduce_max(el))
     i0 = res[0][2] if res else None
     if strong:
         return {"workload": f"configs[3] as configured: {total_chunks * chunk} cells = {total_chunks} sub-spot chunks of {chunk} cells against {S} spots, "
@@ -529,22 +546,86 @@ def make_cost(n, seed):
     return np.random.default_rng(seed).random((n, n)).astype(np.float32)
 
 
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (one child process per GPU, LOCAL_RANK = device;
+    rank 0 inherits stdout and prints the line), hand them a rendezvous directory, wait.  A failed or stuck rank ends the job."""
+    import shutil
+    import subprocess
+    import tempfile
+    from cytospace_amd import _lib
+    ndev = _lib.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if args.gpus > ndev and not args.oversubscribe:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node shows {ndev} HIP device(s) "
+                         "(--oversubscribe places several ranks on one device: a harness self-test, not a measurement)")
+    rdv = tempfile.mkdtemp(prefix="cytohip_rdv_")
+    procs = []
+    try:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), CYTO_RDV_DIR=rdv, CYTO_BENCH_SPAWNED="1")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=None if r == 0 else sys.stderr.fileno()))
+        deadline = time.monotonic() + args.rank_timeout
+        rcs = [None] * len(procs)
+        while any(rc is None for rc in rcs):
+            for k, pr in enumerate(procs):
+                if rcs[k] is None:
+                    rcs[k] = pr.poll()
+            if any(rc not in (None, 0) for rc in rcs) or time.monotonic() > deadline:
+                time.sleep(2.0)                             # (the others may be on their way out for the same reason)
+                for k, pr in enumerate(procs):
+                    if pr.poll() is None:
+                        pr.kill()                           # exactly the children started above, by handle
+                    rcs[k] = pr.wait()
+                why = "timed out" if all(rc in (0, -9) for rc in rcs) else "a rank failed"
+                raise SystemExit(f"bench.py --gpus {args.gpus}: {why} (exit codes {rcs})")
+            time.sleep(0.05)
+    finally:
+        shutil.rmtree(rdv, ignore_errors=True)
+    return 0
+
+
+def whole_solve_traffic(tag, n):
+    """HBM bytes of ONE whole solve from the committed rocprofv3 --pmc passes (tools/prof_round.sh -> tools/pmc_to_json.py:
+    per-kernel per-dispatch averages and dispatch counts of a run of `solves` solves; read = 2 x FETCH_SIZE, the gfx950 correction,
+    calibrated on colred_partial which reads the matrix exactly once)."""
+    src = f"profiles/{tag}_pmc_traffic_n{n}.json"
+    try:
+        pm = json.load(open(os.path.join(ROOT, src)))
+        if pm.get("n") != n:
+            return None, None, None
+        ks = pm["kernels"]
+        solves = max(1, int(ks.get("colred_partial<float>", {}).get("dispatches", 1)))
+        tot = sum((v.get("hbm_read_bytes", 0) + v.get("hbm_write_bytes_uncalibrated", 0)) * v.get("dispatches", 0) for v in ks.values()) / solves
+        return int(tot), src, ks
+    except (OSError, ValueError, KeyError):
+        return None, None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=20000, help="LAP size (default: BASELINE.json configs[1])")
+    ap.add_argument("--n", type=int, default=50000, help="LAP size (default: the north star's 50 000; BASELINE.json configs[1] is 20000)")
     ap.add_argument("--cpu-n", type=int, default=0,
-                    help="size of the bounded CPU-baseline sample (0: min(n, 20000); when it equals n the very same "
+                    help="size of the bounded CPU-baseline sample (0: min(n, 20000): ~16 s of one core; when it equals n the very same "
                          "instance is used and the GPU result is compared bit for bit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no n50000 / c3 / c4_chunks / c5_chunks)")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no c2 / c3 / c4_chunks / c5_chunks ...)")
     ap.add_argument("--c4-chunks", type=int, default=256, help="concurrent chunk LAPs in the c4_chunks leg (256 = one chain per CU; 400 MB each)")
     ap.add_argument("--c4-rank-chunks", type=int, default=64, help="chunks per rank in the c4_sharded leg")
     ap.add_argument("--sharded-timeout", type=float, default=600.0, help="watchdog of the c4_sharded leg, seconds")
-    ap.add_argument("--pmc-tag", default="r04am", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
+    ap.add_argument("--rank-timeout", type=float, default=3000.0, help="self-spawned ranks (--gpus N without a launcher) are ended after this many seconds")
+    ap.add_argument("--oversubscribe", action="store_true", help="allow more ranks than devices (rank r on device r %% devices; no RCCL "
+                                                                 "communicator: a self-test of the harness on a one-GPU box)")
+    ap.add_argument("--pmc-tag", default="r05", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
 
     # ONE JSON line on stdout: everything else this process (or a library under it: RCCL prints a version banner through C
     # stdio) writes to file descriptor 1 goes to stderr instead; the line itself is written to the saved descriptor.
@@ -553,34 +634,54 @@ def main():
     os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
     from cytospace_amd import _lib
     from cytospace_amd.lap import lap_solve
+    from cytospace_amd.rendezvous import FileStore
     from oracle.jv import jv_oracle, jv_oracle_wide   # checker + cpu_baseline leg only
 
     ndev = _lib.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if world > ndev and not args.oversubscribe:
+        raise SystemExit(f"bench.py: {world} ranks but {ndev} HIP device(s) visible")
     dev = local_rank % ndev
     n = args.n
+    store = FileStore.from_env() if world > 1 else None
+
+    # ---- the ranks' communicator (RCCL): made FIRST, under a watchdog, so that n_gpus is what RCCL itself counted ----
+    comm, rccl = None, None
+    if world > 1 and world <= ndev:
+        import threading
+        uid = store.bcast(_lib.Communicator.unique_id() if rank == 0 else None)
+        cbox = {}
+
+        def _mk():
+            try:
+                c = _lib.Communicator(uid, rank, world, device_id=dev)
+                cbox["count"] = c.count()
+                cbox["comm"] = c
+            except BaseException as e:   # noqa: BLE001
+                cbox["error"] = f"{type(e).__name__}: {e}"
+        th = threading.Thread(target=_mk, daemon=True)
+        th.start()
+        th.join(300.0)
+        states = store.allgather(cbox.get("count", cbox.get("error", "stuck")))
+        if all(x == world for x in states):
+            comm, rccl = cbox["comm"], {"ranks_counted_by_rccl": world, "kind": cbox["comm"].kind()}
+        else:
+            raise SystemExit(f"bench.py: the RCCL communicator of {world} ranks could not be made: {states}")
+    elif world > 1:
+        rccl = {"ranks_counted_by_rccl": None, "note": f"oversubscribed: {world} ranks on {ndev} device(s), RCCL refuses duplicate devices"}
 
     def barrier():
         _lib.check(_lib.lib().cyto_device_synchronize(dev))
-        if dist is not None:
-            import torch
-            t = torch.zeros(1, device="cuda" if torch.cuda.is_available() else "cpu")
-            dist.all_reduce(t)
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()
-        _lib.check(_lib.lib().cyto_device_synchronize(dev))
+        if store is not None:
+            store.barrier()
 
     # ---- parity gate on a size the oracles finish in a second (bit-exact, incl. duals): the wide solver (what every float32 leg
     # of this file runs: single solves, batches, chunks) against its restatement, the chain solver (cyto_lap_opts.mode = 1) against
@@ -599,62 +700,68 @@ def main():
     if not parity_small:
         raise SystemExit("parity gate failed: HIP solver differs from the CPU oracle")
 
-    # ---- the workload, resident in HBM before the timed region ----
-    cost = make_cost(n, n + rank)
-    buf = _lib.DeviceBuffer.from_numpy(cost, dev)
+    # ---- the workload, resident in HBM before the timed region (every rank: the same seeded instance, so every rank's result
+    # is checked against the committed golden of that size) ----
+    from tools import instances
+    buf = instances.blocks_to_device(instances.uniform_cost_blocks(n), n, dev)
     res = None
     for _ in range(args.warmup):
         res = lap_solve(None, np.float32, device_id=dev, return_info=True, device_ptr=buf.ptr, n=n, ld=n)
     barrier()
     t0 = time.perf_counter()
-    arr_ms_l, aug_ms_l, total_ms = [], [], []
+    infos = []
     for _ in range(args.steps):
         res = lap_solve(None, np.float32, device_id=dev, return_info=True, device_ptr=buf.ptr, n=n, ld=n)
-        arr_ms_l.append(res["info"].ms_arr)
-        aug_ms_l.append(res["info"].ms_aug)
-        total_ms.append(res["info"].ms_total)
+        infos.append(res["info"])
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if torch.cuda.is_available() else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if store is not None:
+        elapsed = float(store.allreduce_max(elapsed))
 
-    # ---- size-independent properties at full size (the oracle would need ~1 min here) ----
+    # ---- parity of the headline itself: the committed goldens (required at the default sizes), and size-independent properties
+    # on rows drawn again from the generator (the 10 GB matrix is not kept on the host) ----
     info = res["info"]
     colsol, rowsol = res["colsol"], res["rowsol"]
+    gold_idx, gold_duals = check_uniform_golden(n, res, bool(info.wide), required=n in (20000, 50000))
     perm_ok = bool(np.array_equal(np.sort(colsol), np.arange(n)) and np.array_equal(rowsol[colsol], np.arange(n)))
-    tot64 = float(cost[np.arange(n), rowsol].astype(np.float64).sum())
+    tot64, dual_ok = 0.0, True
+    u64, v64 = res["u"].astype(np.float64), res["v"].astype(np.float64)
+    for lo, blk in instances.uniform_cost_blocks(n):
+        rows = np.arange(lo, lo + len(blk))
+        tot64 += float(blk[np.arange(len(blk)), rowsol[rows]].astype(np.float64).sum())
+        if lo % (8 * 2048) == 0:             # dual feasibility (u_i + v_j <= c_ij) and complementary slackness on a sample of row blocks
+            red = blk[:256].astype(np.float64) - u64[rows[:256], None] - v64[None, :]
+            dual_ok = dual_ok and bool(red.min() > -1e-5 and np.abs(red[np.arange(len(red)), rowsol[rows[:256]]]).max() < 1e-5)
     total_ok = abs(tot64 - res["total"]) <= 1e-5 * max(1.0, abs(tot64))
-    # dual feasibility (u_i + v_j <= c_ij) and complementary slackness on a row sample
-    rs = np.random.default_rng(0).choice(n, size=min(n, 512), replace=False)
-    red = cost[rs].astype(np.float64) - res["u"][rs].astype(np.float64)[:, None] - res["v"].astype(np.float64)[None, :]
-    dual_ok = bool(red.min() > -1e-5 and np.abs(red[np.arange(len(rs)), rowsol[rs]]).max() < 1e-5)
     if not (perm_ok and total_ok and dual_ok):
         raise SystemExit(f"full-size property check failed: perm={perm_ok} total={total_ok} dual={dual_ok}")
-    c2_batch = None
-    if world == 1 and not args.no_extras:
-        c2_batch, r0 = extra_c2_batch(dev, buf, n)
-        if not (np.array_equal(r0["colsol"], colsol) and np.array_equal(r0["v"], res["v"])):
-            raise SystemExit("c2_batch: the batched solve differs from the single solve")
+    if store is not None and not all(store.allgather(bool(perm_ok and total_ok and dual_ok and gold_idx is not False))):
+        raise SystemExit("a rank's headline result failed its checks")
     buf.free()
 
+    extras = {}
+    c2_res = None
+    if world == 1 and not args.no_extras:
+        other = 20000 if n != 20000 else 50000
+        extras["c2" if other == 20000 else "n50000"], obuf, c2_res = extra_uniform(dev, other)
+        if other == 20000:
+            extras["c2_batch"], r0 = extra_c2_batch(dev, obuf, other)
+            if not (np.array_equal(r0["colsol"], c2_res["colsol"]) and np.array_equal(r0["v"], c2_res["v"])):
+                raise SystemExit("c2_batch: the batched solve differs from the single solve")
+        obuf.free()
+
     sharded, sharded_stuck, box = None, False, {}
-    if not args.no_extras:
+    if not args.no_extras and (world == 1 or comm is not None):
         # every rank takes part.  The headline above is already measured: a failure or a hang of this additional multi-rank leg
-        # (it cannot be exercised on the one-GPU development box beyond world size 1) must not cost the line, so it runs under a
-        # watchdog and reports what happened instead.
+        # must not cost the line, so it runs under a watchdog and reports what happened instead.
         import threading
+        if comm is None:                        # N = 1: a one-rank RCCL communicator (the broadcast still goes through RCCL)
+            comm = _lib.Communicator(_lib.Communicator.unique_id(), 0, 1, device_id=dev)
 
         def _leg():
             try:
-                if dist is not None:            # the current HIP device is per THREAD: without this every rank's collectives
-                    import torch                # of this leg would run on cuda:0
-                    if torch.cuda.is_available():
-                        torch.cuda.set_device(local_rank)
-                box["strong"] = extra_c4_sharded(dev, rank, world, dist, 0, G=2000, total_chunks=20)
-                box["r"] = extra_c4_sharded(dev, rank, world, dist, args.c4_rank_chunks)
+                box["strong"] = extra_c4_sharded(dev, rank, world, store, comm, 0, G=2000, total_chunks=20)
+                box["r"] = extra_c4_sharded(dev, rank, world, store, comm, args.c4_rank_chunks)
             except BaseException as e:          # noqa: BLE001 (SystemExit from the leg's own gates included)
                 box["r"] = {"error": f"{type(e).__name__}: {e}"}
 
@@ -664,12 +771,8 @@ def main():
         sharded_stuck = th.is_alive()
         sharded = {"error": f"no result within {args.sharded_timeout} s"} if sharded_stuck else box.get("r")
     failed = sharded_stuck or (isinstance(sharded, dict) and "error" in sharded)
-    if dist is not None and not failed:        # nothing collective happens after this point: leave the group together
-        try:
-            dist.barrier()
-            dist.destroy_process_group()
-        except Exception as e:                 # (a failed teardown must not cost the measured line)
-            print(f"process group teardown: {e}", file=sys.stderr)
+    if comm is not None and not failed:
+        comm.close()
     if rank != 0:
         if failed:
             os._exit(0)                         # (a stuck collective would keep the interpreter from exiting)
@@ -677,79 +780,62 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * n * args.steps / elapsed
 
-    # roofline of the dominant kernel, per launch, timed with HIP events on the launch stream (cyto_lap_info.ms_arr / ms_aug).
-    # wide_arr = the Jacobi rounds of augmenting row reduction (wide_rt, the reduction transfer, is a sub-millisecond launch
-    # before it inside the same event bracket), wide_aug = the augmentation.  Algorithmic bytes = 4 * n * row scans:
-    # a bid is one row scan, a settled column of a search (the oracle's count, not the speculative re-settlements) is one.
-    arr_scans = info.scans_redtransfer + info.scans_arr
-    aug_scans = info.scans_aug_init + info.scans_aug_relax
-    arr_ms = float(np.mean(arr_ms_l))
-    aug_ms = float(np.mean(aug_ms_l))
-    arr_name, aug_name = ("row_reduction(wide_rt + wide_sc_* + wide_arr)", "wide_aug") if info.wide else ("jv_chain2", "jv_aug_lazy" if n > 5120 else "jv_aug2")
-    # (the wide solver's row reduction is a PHASE of ~1 500 launches -- the phase machine's rounds on the whole chip, two small
-    #  launches each, then the wide_arr kernel for the tail: arr_ms brackets the phase, the wide_arr kernel alone is its own clock's
-    #  list + chain time; the dominant KERNEL is the longest single launch)
-    arr_kernel_ms = float(info.wide_ms_list + info.wide_ms_chain) if info.wide else arr_ms
-    dom = (arr_name, arr_scans, arr_ms) if arr_kernel_ms >= aug_ms else (aug_name, aug_scans, aug_ms)
-    dom_bytes = 4.0 * n * dom[1]
-    achieved = dom_bytes / (dom[2] * 1e-3) / 1e9
-    traffic = None
-    traffic_source = None
-    try:   # HBM bytes from the separate rocprofv3 --pmc pass committed under profiles/ (same n, same instance)
-        traffic_source = f"profiles/{args.pmc_tag}_pmc_traffic_n{n}.json"
-        if not os.path.exists(os.path.join(ROOT, traffic_source)):
-            traffic_source = f"profiles/r03h_pmc_traffic_n{n}.json"
-        pm = json.load(open(os.path.join(ROOT, traffic_source)))
-        if pm.get("n") == n:
-            key = [k for k in pm["kernels"] if k.startswith(dom[0] + "<") or k.startswith(dom[0] + "(") or k == dom[0]]
-            if key:
-                traffic = pm["kernels"][key[0]]["hbm_read_bytes"] + pm["kernels"][key[0]]["hbm_write_bytes_uncalibrated"]
-    except (OSError, ValueError, KeyError):
-        traffic = None
-    total_avg_ms = float(np.mean(total_ms))
+    # ---- roofline: the floor.  Every cost entry is read at least once: 4 n^2 bytes per solve.  achieved = floor bytes / step time
+    # (<= peak by construction).  What the solve really waits for is latency: dependent rounds, listed beside it. ----
+    def avg(f):
+        return float(np.mean([getattr(i_, f) for i_ in infos]))
+    arr_ms, aug_ms, total_ms = avg("ms_arr"), avg("ms_aug"), avg("ms_total")
+    floor_bytes = 4.0 * n * n
+    achieved = floor_bytes / (ms_per_step * 1e-3) / 1e9
+    traffic, traffic_source, pmk = whole_solve_traffic(args.pmc_tag, n)
+    dom_name = "wide_aug" if aug_ms >= max(info.ms_colred, info.ms_cache) else "colred_partial"
+    dom_ms = aug_ms if dom_name == "wide_aug" else float(info.ms_colred)
+    dom_pm = None
+    if pmk:
+        key = [k for k in pmk if k.startswith(dom_name)]
+        if key:
+            dom_pm = pmk[key[0]].get("hbm_read_bytes", 0) + pmk[key[0]].get("hbm_write_bytes_uncalibrated", 0)
+    rounds = max(1, int(info.wide_rounds))
+    aug_rounds = max(1, int(info.wide_aug_rounds))
     roofline = {
-        "bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-        "traffic_source": (traffic_source + " (separate rocprofv3 --pmc pass of this command, PMC, half-factor calibrated; "
-                                            "not re-measured in this run)") if traffic is not None else None,
-        "algorithmic_bytes_per_launch": dom_bytes, "row_scans_per_launch": int(dom[1]), "kernel_ms_avg": round(dom[2], 3),
-        "other_kernels": {
-            arr_name: {"ms": round(arr_ms, 3), "row_scans": int(arr_scans), "algorithmic_GBs": round(4.0 * n * arr_scans / (arr_ms * 1e-3) / 1e9, 2),
-                       "rounds": int(info.wide_rounds), "full_row_scans": int(info.wide_dense_arr),
-                       "note": "the row-reduction PHASE (HIP events around wide_rt, the phase machine -- every round two whole-chip launches, "
-                               "wide_sc_bid + wide_sc_resolve -- and wide_arr)", "scaled": bool(info.wide_scaled), "phases": int(info.wide_phases),
-                       "wide_arr_kernel_ms": round(arr_kernel_ms, 3), "us_per_round": round(arr_ms * 1e3 / max(1, int(info.wide_rounds)), 2)},
-            aug_name: {"ms": round(aug_ms, 3), "row_scans": int(aug_scans), "algorithmic_GBs": round(4.0 * n * aug_scans / max(aug_ms, 1e-9) / 1e-3 / 1e9, 2),
-                       "searches": int(info.augmentations), "columns_settled_speculatively": int(info.wide_aug_settled),
-                       "rounds_of_16_waves": int(info.wide_aug_rounds),
-                       "full_row_scans": int(info.wide_dense_aug if info.wide else info.aug_dense_scans + info.augmentations - info.aug_sparse_inits)},
-            "colred(3 kernels)": {"ms": round(float(info.ms_colred), 3), "GBs": round(4.0 * n * n / (info.ms_colred * 1e-3) / 1e9, 1)},
-            "build_row_caches": {"ms": round(float(info.ms_cache), 3), "GBs": round(4.0 * n * n / (info.ms_cache * 1e-3) / 1e9, 1)}},
-        "whole_solve": {"row_scans": int(info.row_scans), "bytes": 4.0 * n * info.row_scans, "kernel_ms_avg": round(total_avg_ms, 3),
-                        "achieved_GBs": round(4.0 * n * info.row_scans / (total_avg_ms * 1e-3) / 1e9, 2),
-                        "floor_4n2_frac": round(4.0 * n * n / (total_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
-        "hbm_rows_actually_read": int(info.hbm_row_reads),
+        "bound": "hbm", "kernel": "whole solve (colred_* + build_row_caches_wave + wide_rt + wide_sc_* + wide_arr + wide_aug)",
+        "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+        "definition": "floor: every cost entry read once = 4 n^2 bytes per solve, divided by ms_per_step (wall, max over ranks)",
+        "floor_bytes_per_solve": floor_bytes,
+        "traffic": traffic,
+        "traffic_source": (traffic_source + " (separate rocprofv3 --pmc passes of tools/quick_lap_bench.py at this size, summed over the "
+                                            "kernels of one solve; read = 2 x FETCH_SIZE, calibrated on colred_partial; not re-measured in this run)")
+        if traffic is not None else None,
+        "latency_model": {
+            "note": "what bounds the solve: dependent rounds, not bytes",
+            "row_reduction": {"ms": round(arr_ms, 3), "rounds": int(info.wide_rounds), "phases": int(info.wide_phases),
+                              "us_per_round": round(arr_ms * 1e3 / rounds, 2), "bids": int(info.scans_arr),
+                              "full_row_bids": int(info.wide_dense_arr), "scaled": bool(info.wide_scaled)},
+            "searches": {"ms": round(aug_ms, 3), "searches": int(info.augmentations), "batches_of_searches": int(info.wide_par_batches),
+                         "discarded_and_rerun": int(info.wide_par_discarded), "rounds": int(info.wide_aug_rounds),
+                         "us_per_round": round(aug_ms * 1e3 / aug_rounds, 2), "columns_settled": int(info.scans_aug_relax),
+                         "columns_settled_speculatively": int(info.wide_aug_settled), "full_row_relaxations": int(info.wide_dense_aug)},
+            "streaming": {"colred_ms": round(float(info.ms_colred), 3), "colred_GBs": round(floor_bytes / (info.ms_colred * 1e-3) / 1e9, 1),
+                          "row_caches_ms": round(float(info.ms_cache), 3), "row_caches_GBs": round(floor_bytes / (info.ms_cache * 1e-3) / 1e9, 1),
+                          "note": "the two kernels that really stream the matrix: bytes = 4 n^2 each"}},
+        "dominant_kernel": {"name": dom_name, "ms_per_launch_hip_events": round(dom_ms, 3), "hbm_bytes_per_launch_pmc": dom_pm,
+                            "note": "the longest single launch of a solve; its HIP-event time is what profiles/<tag>_kernel_stats_*.csv must show"},
+        "kernel_ms_sum": round(total_ms, 3), "hbm_rows_actually_read": int(info.hbm_row_reads),
+        "row_scans_counted": int(info.row_scans),
     }
 
     cpu = None
-    full_size_bit_exact = None
     if not args.no_cpu_baseline and world == 1:
         cn = args.cpu_n if args.cpu_n > 0 else min(n, 20000)
-        same = cn == n
-        cc = cost if same else make_cost(cn, cn)
+        cc = make_cost(cn, cn)
         t1 = time.perf_counter()
         oc = jv_oracle(cc, np.float32)
         dt = time.perf_counter() - t1
-        if same:   # the workload itself: the classic oracle's indices (the optimum is unique) and, bit for bit, the wide
-            # restatement's indices, duals and counters -- the solve above settled its columns speculatively, 16 at a time
-            t2 = time.perf_counter()
-            owf = jv_oracle_wide(cc, np.float32)
-            dt_wide = time.perf_counter() - t2
-            full_size_bit_exact = bool(np.array_equal(res["colsol"], oc["colsol"]) and np.array_equal(res["rowsol"], oc["rowsol"])
-                                       and all(np.array_equal(res[k], owf[k]) for k in ("rowsol", "colsol", "u", "v"))
-                                       and info.scans_arr == owf["stats"].scans_arr and info.scans_aug_relax == owf["stats"].scans_aug_relax)
-            if not full_size_bit_exact:
-                raise SystemExit("full-size parity failed: HIP solver differs from the CPU oracle on the bench instance")
+        same_as_gpu = None
+        if c2_res is not None and cn == 20000:            # the GPU solved this very instance in the c2 leg
+            same_as_gpu = bool(np.array_equal(c2_res["colsol"], oc["colsol"]) and np.array_equal(c2_res["rowsol"], oc["rowsol"]))
+            if not same_as_gpu:
+                raise SystemExit("cpu_baseline: the HIP solver's indices differ from the CPU oracle's on the 20 000 x 20 000 sample")
         scipy_leg = None
         try:   # an independent second CPU number, on a bounded sample of the same generator
             from scipy.optimize import linear_sum_assignment
@@ -764,48 +850,58 @@ def main():
                          "note": "scipy.optimize.linear_sum_assignment (float64) on a smaller instance of the same generator; assignments/s falls with n"}
         except Exception as e:   # noqa: BLE001
             scipy_leg = {"error": f"{type(e).__name__}: {e}"}
+        full = None
+        try:
+            gd = np.load(os.path.join(ROOT, "tests", "golden", f"large_u{n}.npz"))
+            full = {"seconds_in_the_build_container": round(float(gd["oracle_seconds"]), 1),
+                    "assignments_per_s": round(n / float(gd["oracle_seconds"]), 1),
+                    "note": f"the same oracle on the FULL {n} x {n} instance, one core, when the golden was made (not timed in this run)"}
+        except (OSError, KeyError):
+            pass
         cpu = {"value": round(cn / dt, 1), "unit": "assignments/s", "cores": 1, "kind": "port", "scipy": scipy_leg,
+               "sample_n": cn, "seconds": round(dt, 1), "same_indices_as_the_hip_solver_on_this_sample": same_as_gpu,
+               "full_instance": full,
                "sample": f"oracle/jv_oracle.c (C port of JV, -O3 -mavx2, 1 thread; lapjv wheel unavailable) on "
-                         + ("the bench instance itself" if same else "a smaller instance of the same generator")
-                         + f" ({cn}x{cn} uniform): {dt:.1f} s, {oc['stats'].row_scans} row scans "
-                         f"({4.0 * cn * oc['stats'].row_scans / dt / 1e9:.1f} GB/s algorithmic); assignments/s falls with n",
+                         + ("the bench instance itself" if cn == n else "a smaller instance of the same generator (bounded sample)")
+                         + f" ({cn}x{cn} uniform): {dt:.1f} s, {oc['stats'].row_scans} row scans; assignments/s falls with n "
+                           "(the golden file records the full-size time: cpu_baseline.full_instance)",
                "cpu_model": _cpu_model(), "host_cores": os.cpu_count()}
 
     out = {
         "metric": "cell-to-spot assignments/sec on NxN synthetic cost; bit-exact vs lapjv",
-        "metric_note": "bit-exact vs the in-tree CPU JV oracle: indices, duals and work counters of the wide solver vs the oracle's wide "
-                       "restatement, and the indices of the classic-order oracle (== scipy) on this uniqueness-certified instance; the lapjv "
-                       "wheel is not in this image.  Result contract of the default solver: an optimal assignment -- where the optimum is not "
-                       "unique (duplicated spot rows, integer costs) its choice among the optimal assignments differs from the classic "
-                       "Jonker-Volgenant tie-break (same spots, same total); cyto_lap_opts.mode = 1 gives the classic order",
+        "metric_note": "bit-exact vs the in-tree CPU JV oracle: indices == the committed uniqueness-certified golden of this instance (classic-order "
+                       "oracle == scipy), rowsol and duals == the wide restatement's golden; the lapjv wheel is not in this image.  Result contract "
+                       "of the default solver: an optimal assignment -- where the optimum is not unique (duplicated spot rows, integer costs) its "
+                       "choice among the optimal assignments differs from the classic Jonker-Volgenant tie-break (same spots, same total); "
+                       "cyto_lap_opts.mode = 1 gives the classic order",
         "value": round(value, 1), "unit": "assignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{n}x{n} dense uniform float32 cost resident in HBM, JV HIP solver "
-                               + ("(BASELINE.json configs[1])" if n == 20000 else "(size given with --n; BASELINE.json configs[1] is 20000)"),
-                   "n": n, "lap_per_gpu": 1, "parallelism": f"independent LAPs x{world}"},
-        "parity": {"bit_exact_vs_cpu_oracle_n3000": parity_small, "full_size_bit_exact_vs_cpu_oracle": full_size_bit_exact,
-                   "full_size_permutation": perm_ok,
+                               + ("(the north star's target size; fits one GPU: 10 GB)" if n == 50000 else
+                                  "(BASELINE.json configs[1])" if n == 20000 else "(size given with --n)"),
+                   "n": n, "lap_per_gpu": 1, "parallelism": f"independent LAPs x{world} (inside one LAP: replicas only)"},
+        "rccl": rccl,
+        "parity": {"bit_exact_vs_cpu_oracle_n3000": parity_small, "indices_equal_the_certified_golden": gold_idx,
+                   "duals_equal_the_wide_oracle_golden": gold_duals, "full_size_permutation": perm_ok,
                    "full_size_total_1e-5": bool(total_ok), "full_size_dual_feasible": dual_ok,
                    "note": "oracle = C restatement of JV; the lapjv wheel is not available in this image"},
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
-    if c2_batch is not None:
-        out["c2_batch"] = c2_batch
+    out.update(extras)
     if box.get("strong") is not None:
         out["c4_strong"] = box["strong"]
     if sharded is not None:
         out["c4_sharded"] = sharded
     if world == 1 and not args.no_extras:
         out["c2_cytolike"] = extra_c2_cytolike(dev)
-        out["n50000"] = extra_n50000(dev)
         out["c3"] = extra_c3(dev)
         out["c4_chunks"] = extra_c4_chunks(dev, args.c4_chunks)
         out["c5_chunks"] = extra_c5_chunks(dev)
     json_out.write(json.dumps(out) + "\n")
     json_out.flush()
-    if sharded_stuck or (dist is not None and failed):
+    if failed:
         os._exit(0)                             # the line is out; a stuck collective must not keep the process alive
 
 

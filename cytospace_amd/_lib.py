@@ -14,6 +14,7 @@ _lib = None
 
 CYTO_OK = 0
 _EXC = {1: ValueError, 2: ValueError, 3: MemoryError, 7: ValueError, 8: ValueError}
+CYTO_ERR_PEER = 9        # another rank of the communicator failed (raised as CytoHipError)
 
 
 class CytoHipError(RuntimeError):
@@ -50,7 +51,9 @@ class LapOpts(ctypes.Structure):
     """cyto_lap_opts (include/cytohip.h): kernel-selection options; results never depend on them."""
     _fields_ = [("chain_variant", ctypes.c_int32), ("augmentation", ctypes.c_int32), ("no_handover", ctypes.c_int32),
                 ("inject_exceptions", ctypes.c_int32), ("group_state_global", ctypes.c_int32), ("aux_state_global", ctypes.c_int32), ("mode", ctypes.c_int32), ("wide_rounds", ctypes.c_int32), ("wide_groups", ctypes.c_int32), ("wide_rebuild", ctypes.c_int32),
-                ("wide_par", ctypes.c_int32), ("wide_wipe", ctypes.c_int32)]
+                ("wide_par", ctypes.c_int32), ("wide_wipe", ctypes.c_int32),
+                ("cache_waves", ctypes.c_int32), ("cache_unroll", ctypes.c_int32), ("cache_stream", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 5)]
 
 
 class AssignInfo(ctypes.Structure):
@@ -139,8 +142,23 @@ def lib():
         L.cyto_lap_batch_f32_opts.restype = ctypes.c_int
         L.cyto_comm_unique_id.argtypes = [ctypes.c_char_p]
         L.cyto_comm_init.argtypes = [ctypes.c_char_p, i32, i32, i32, ctypes.POINTER(vp)]
+        L.cyto_comm_init_local.argtypes = [i32, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(vp)]
+        L.cyto_comm_count.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
+        L.cyto_comm_kind.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
+        L.cyto_comm_agree.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
+        L.cyto_comm_abort.argtypes = [vp]
         L.cyto_comm_bcast_f32.argtypes = [vp, vp, ctypes.c_size_t, i32, i32, vp]
         L.cyto_comm_destroy.argtypes = [vp]
+        for name in ("cyto_comm_init_local", "cyto_comm_count", "cyto_comm_kind", "cyto_comm_agree", "cyto_comm_abort"):
+            getattr(L, name).restype = ctypes.c_int
+        # ABI check: the structs mirrored above must be the library's (include/cytohip.h carries no size members)
+        sz = [ctypes.c_size_t() for _ in range(4)]
+        L.cyto_abi_sizes.argtypes = [ctypes.POINTER(ctypes.c_size_t)] * 4
+        L.cyto_abi_sizes(*[ctypes.byref(x) for x in sz])
+        mine = [ctypes.sizeof(t) for t in (LapInfo, LapOpts, AssignInfo, Chunk)]
+        if [x.value for x in sz] != mine:
+            raise CytoHipError(f"{LIB_PATH} was built from another include/cytohip.h: struct sizes {[x.value for x in sz]} != {mine} "
+                               "(rebuild: python -m cytospace_amd.build --force)")
         for name in ("cyto_normalize_data", "cyto_standardize", "cyto_cost_pearson", "cyto_assign_pearson",
                      "cyto_lap_batch_f32", "cyto_lap_batch_f32_opts", "cyto_comm_unique_id", "cyto_comm_init", "cyto_comm_bcast_f32",
                      "cyto_comm_destroy"):
@@ -213,14 +231,29 @@ class DeviceBuffer:
 
 
 class Communicator:
-    """RCCL communicator of a one-process-per-GPU job (C ABI: cyto_comm_*).  The 128-byte unique id is made on rank 0
-    (`Communicator.unique_id()`) and handed to the other ranks by the launcher (torch.distributed, MPI, a file ...)."""
+    """The communicator of the chunk fan-out (C ABI: cyto_comm_*; csrc/comm.hip).  One process per GPU: the 128-byte RCCL
+    unique id is made on rank 0 (`Communicator.unique_id()`) and handed to the other ranks by the launcher
+    (cytospace_amd.rendezvous.FileStore, MPI, a file ...).  One process, one thread per device: `Communicator.init_local`."""
 
-    def __init__(self, unique_id, rank, nranks, device_id=0):
+    def __init__(self, unique_id, rank, nranks, device_id=0, _handle=None):
         self.rank, self.nranks, self.device_id = int(rank), int(nranks), int(device_id)
+        if _handle is not None:
+            self._h = _handle
+            return
         self._h = ctypes.c_void_p()
         buf = ctypes.create_string_buffer(bytes(unique_id), 128)
         check(lib().cyto_comm_init(buf, self.rank, self.nranks, self.device_id, ctypes.byref(self._h)))
+
+    @classmethod
+    def init_local(cls, device_ids):
+        """One communicator per entry of device_ids, for the host threads of THIS process (rank r drives device_ids[r]).
+        Distinct devices: RCCL (ncclCommInitAll).  A device listed twice (logical ranks): the in-process kind, whose
+        broadcast is a device-to-device copy."""
+        n = len(device_ids)
+        devs = (ctypes.c_int * n)(*[int(d) for d in device_ids])
+        hs = (ctypes.c_void_p * n)()
+        check(lib().cyto_comm_init_local(n, devs, hs))
+        return [cls(None, r, n, int(device_ids[r]), _handle=ctypes.c_void_p(hs[r])) for r in range(n)]
 
     @staticmethod
     def unique_id():
@@ -231,6 +264,28 @@ class Communicator:
     @property
     def handle(self):
         return self._h
+
+    def count(self):
+        """Ranks the communicator spans, as RCCL itself counts them (ncclCommCount)."""
+        n = ctypes.c_int()
+        check(lib().cyto_comm_count(self._h, ctypes.byref(n)))
+        return n.value
+
+    def kind(self):
+        k = ctypes.c_int()
+        check(lib().cyto_comm_kind(self._h, ctypes.byref(k)))
+        return "rccl" if k.value == 0 else "in-process"
+
+    def agree(self, status=0):
+        """Collective: the largest status any rank brought (0: every rank is fine)."""
+        s = ctypes.c_int(int(status))
+        check(lib().cyto_comm_agree(self._h, ctypes.byref(s)))
+        return s.value
+
+    def abort(self):
+        """This rank cannot reach a collective its peers wait in: release them (they fail with CYTO_ERR_PEER)."""
+        if self._h:
+            lib().cyto_comm_abort(self._h)
 
     def close(self):
         if self._h:

@@ -1,12 +1,11 @@
-// batch.hip -- many independent LAPs on one GPU at once, and the RCCL broadcast of the shared
-// standardised spot matrix.
+// batch.hip -- many independent LAPs on one GPU at once (the communicator of the multi-GPU fan-out is comm.hip).
 //
 // CytoSPACE splits large inputs into independent square sub-LAPs ("chunks") and ships each to a worker
-// process (/root/reference/cytospace/cytospace.py:430-451).  On the GPU the sequential part of one solve
-// occupies ONE workgroup (one CU of 256), so the chunks of a batch go through every chain phase TOGETHER: one launch with
-// a workgroup per chunk (lap_jv.hip: lap_solve_f32_batch), up to 256 chains running side by side on the 256 CUs.
+// process (/root/reference/cytospace/cytospace.py:430-451).  Here the chunks of a batch go through the solver's phases
+// TOGETHER: problems of one size share their launches (lap_jv.hip: lap_batch_same_n -- the row reduction of every problem is the
+// same whole-chip phase machine, launch pair L carrying round L of whatever phase each problem is in; the searches run a
+// workgroup per problem), and a large batch runs as a few interleaved sub-batches on their own streams and host threads.
 #include "cyto_common.h"
-#include <rccl/rccl.h>
 #include <algorithm>
 #include <stdlib.h>
 #include <map>
@@ -16,7 +15,7 @@
 namespace cyto {
 
 // cyto_lap_batch_f32 with optional row maps (rowmap[b] != NULL: cost[b] holds nu[b] distinct rows, see cyto_lap_f32_rowmap)
-int lap_batch_any(int nb, const int *n, const float *const *cost, const int64_t *ld, int cost_on_device,
+static int lap_batch_any_impl(int nb, const int *n, const float *const *cost, const int64_t *ld, int cost_on_device,
                   const int32_t *const *rowmap, const int *nu, int32_t *const *rowsol, int32_t *const *colsol, float *const *u,
                   float *const *v, double *total, cyto_lap_info *info, int *status_out, int max_concurrent, int device_id,
                   const cyto_lap_opts *opts) {
@@ -63,7 +62,7 @@ int lap_batch_any(int nb, const int *n, const float *const *cost, const int64_t 
             //  50 c5 chunks 0.15 -> 0.21 s, configs[3]'s 20 chunks 0.31 -> 0.38 s): beyond a handful the host threads' launches get in each
             //  other's way)
             int G = kv.first > 16384 ? 1 : (cnt >= 128 ? 8 : (cnt >= 32 ? 4 : (cnt >= 16 ? 2 : 1)));
-            if (const char *e = getenv("CYTO_SUBBATCHES")) G = std::max(1, std::min(cnt, atoi(e)));       // (developer knob: tools/batch_chunks_bench.py)
+            if (CYTO_KNOB("CYTO_SUBBATCHES").set) G = std::max(1, std::min(cnt, CYTO_KNOB("CYTO_SUBBATCHES").value));       // (developer knob, read once per process: tools/batch_chunks_bench.py)
             std::vector<int> brcs((size_t)G, CYTO_OK);
             if (G == 1) {
                 brcs[0] = lap_batch_same_n(kv.first, cnt, c.data(), l.data(), cost_on_device, rs.data(), cs.data(), uu.data(), vv.data(),
@@ -134,19 +133,22 @@ int lap_batch_any(int nb, const int *n, const float *const *cost, const int64_t 
     return first;
 }
 
-// nwords (<= 4) int32 from `root` to every rank (the status word and the operand's extents that precede the operand broadcast:
-// cost.hip, ctx_create_impl).
-int comm_bcast_status(void *comm, int *status, int root, int device_id, int nwords) {
-    if (!comm || !status || nwords < 1 || nwords > 4) return CYTO_ERR_BAD_ARG;
-    int rc = select_device(device_id);
-    if (rc) return rc;
-    DevBuf word;
-    if ((rc = word.alloc(16))) return rc;
-    CYTO_HIP(hipMemcpy(word.p, status, sizeof(int) * (size_t)nwords, hipMemcpyHostToDevice));
-    if (ncclBroadcast(word.p, word.p, (size_t)nwords, ncclInt32, root, reinterpret_cast<ncclComm_t>(comm), nullptr) != ncclSuccess) return CYTO_ERR_HIP;
-    CYTO_HIP(hipStreamSynchronize(nullptr));
-    CYTO_HIP(hipMemcpy(status, word.p, sizeof(int) * (size_t)nwords, hipMemcpyDeviceToHost));
-    return CYTO_OK;
+// No exception may cross the C ABI: the containers above (and lap_batch_same_n's) throw std::bad_alloc on exhaustion.
+int lap_batch_any(int nb, const int *n, const float *const *cost, const int64_t *ld, int cost_on_device,
+                  const int32_t *const *rowmap, const int *nu, int32_t *const *rowsol, int32_t *const *colsol, float *const *u,
+                  float *const *v, double *total, cyto_lap_info *info, int *status_out, int max_concurrent, int device_id,
+                  const cyto_lap_opts *opts) {
+    int rc;
+    try {
+        return lap_batch_any_impl(nb, n, cost, ld, cost_on_device, rowmap, nu, rowsol, colsol, u, v, total, info, status_out, max_concurrent,
+                                  device_id, opts);
+    } catch (const std::bad_alloc &) {
+        rc = CYTO_ERR_NOMEM;
+    } catch (...) {
+        rc = CYTO_ERR_INTERNAL;
+    }
+    if (status_out) for (int b = 0; b < nb; b++) status_out[b] = rc;
+    return rc;
 }
 
 }  // namespace cyto
@@ -170,45 +172,6 @@ int cyto_lap_batch_f32_opts(int nb, const int *n, const float *const *cost, cons
                             cyto_lap_info *info, int *status_out, int max_concurrent, int device_id, const cyto_lap_opts *opts) {
     return cyto::lap_batch_any(nb, n, cost, ld, cost_on_device, nullptr, nullptr, rowsol, colsol, u, v, total, info, status_out,
                                max_concurrent, device_id, opts);
-}
-
-// ---- RCCL (xGMI): the only collective on the path is the broadcast of the shared standardised ST
-// matrix to the ranks that solve chunks against it. ----
-int cyto_comm_unique_id(char *id128) {
-    if (!id128) return CYTO_ERR_BAD_ARG;
-    ncclUniqueId id;
-    if (ncclGetUniqueId(&id) != ncclSuccess) return CYTO_ERR_HIP;
-    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
-    memcpy(id128, &id, 128);
-    return CYTO_OK;
-}
-
-int cyto_comm_init(const char *id128, int rank, int nranks, int device_id, void **comm_out) {
-    if (!id128 || !comm_out || nranks <= 0 || rank < 0 || rank >= nranks) return CYTO_ERR_BAD_ARG;
-    int rc = cyto::select_device(device_id);
-    if (rc) return rc;
-    ncclUniqueId id;
-    memcpy(&id, id128, 128);
-    ncclComm_t comm;
-    if (ncclCommInitRank(&comm, nranks, id, rank) != ncclSuccess) return CYTO_ERR_HIP;
-    *comm_out = comm;
-    return CYTO_OK;
-}
-
-int cyto_comm_bcast_f32(void *comm, float *dev_buf, size_t count, int root, int device_id, void *stream_) {
-    if (!comm || !dev_buf) return CYTO_ERR_BAD_ARG;
-    int rc = cyto::select_device(device_id);
-    if (rc) return rc;
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    if (ncclBroadcast(dev_buf, dev_buf, count, ncclFloat, root, reinterpret_cast<ncclComm_t>(comm), stream) != ncclSuccess)
-        return CYTO_ERR_HIP;
-    CYTO_HIP(hipStreamSynchronize(stream));
-    return CYTO_OK;
-}
-
-int cyto_comm_destroy(void *comm) {
-    if (comm) (void)ncclCommDestroy(reinterpret_cast<ncclComm_t>(comm));
-    return CYTO_OK;
 }
 
 }  // extern "C"

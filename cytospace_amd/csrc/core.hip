@@ -1,5 +1,6 @@
 // core.hip -- status strings, device selection and memory plumbing of the C ABI (include/cytohip.h).
 #include "cyto_common.h"
+#include <stdlib.h>
 #include <map>
 #include <mutex>
 #include <set>
@@ -13,6 +14,14 @@ void set_hip_error(hipError_t e, const char *what) {
     snprintf(g_hip_err, sizeof g_hip_err, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
 }
 
+Knob read_knob(const char *name) {
+    const char *e = getenv(name);
+    Knob k;
+    k.set = e != nullptr && *e != 0;
+    k.value = k.set ? atoi(e) : 0;
+    return k;
+}
+
 int select_device(int device_id) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -23,6 +32,18 @@ int select_device(int device_id) {
     if (device_id < 0 || device_id >= count) return CYTO_ERR_BAD_ARG;
     CYTO_HIP(hipSetDevice(device_id));
     return CYTO_OK;
+}
+
+int device_cus(int device_id) {
+    static std::mutex m;
+    static std::map<int, int> known;
+    std::lock_guard<std::mutex> lk(m);
+    auto it = known.find(device_id);
+    if (it != known.end()) return it->second;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+    known[device_id] = cus;
+    return cus;
 }
 
 // ---- device block cache ----
@@ -152,13 +173,22 @@ const char *cyto_strerror(int status) {
         case CYTO_ERR_NO_DEVICE: return "no HIP device available";
         case CYTO_ERR_UNSUPPORTED: return "problem size not supported by this build";
         case CYTO_ERR_SHAPE: return "the two matrices must have the same number of genes (rows)";
+        case CYTO_ERR_PEER: return "another rank of the communicator failed, aborted or did not arrive";
         default: return "unknown status";
     }
 }
 
 const char *cyto_last_hip_error(void) { return cyto::g_hip_err; }
 
-const char *cyto_version(void) { return "cytohip 0.1.0 (gfx950)"; }
+const char *cyto_version(void) { return "cytohip 0.2.0 (gfx950)"; }
+
+int cyto_abi_sizes(size_t *lap_info, size_t *lap_opts, size_t *assign_info, size_t *chunk) {
+    if (lap_info) *lap_info = sizeof(cyto_lap_info);
+    if (lap_opts) *lap_opts = sizeof(cyto_lap_opts);
+    if (assign_info) *assign_info = sizeof(cyto_assign_info);
+    if (chunk) *chunk = sizeof(cyto_chunk);
+    return CYTO_OK;
+}
 
 int cyto_device_count(int *count) {
     if (!count) return CYTO_ERR_BAD_ARG;

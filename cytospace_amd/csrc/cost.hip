@@ -948,19 +948,30 @@ struct cyto_expr_ctx {
 static int ctx_create_impl(int metric, int G, int C, int S, const void *sc, int64_t ldsc_in, int sc_is_f64, int sc_on_device,
                            const void *st, int64_t ldst_in, int st_is_f64, int st_on_device, int already_normalized,
                            void *comm, int root, int rank, int device_id, cyto_expr_ctx **out, double *bcast_ms) {
-    // With a communicator every rank MUST reach the collectives below whatever went wrong on it -- a rank that returned early
-    // would leave the others blocked inside ncclBroadcast.  So errors are collected in `rc`, the root's status travels first
-    // (one int32), and the operand follows only if the root succeeded: all ranks fail together, with the root's code.
+    // With a communicator every rank MUST reach every collective below whatever went wrong on it -- a rank that returned early
+    // would leave the others blocked inside RCCL.  So errors are collected in `rc` and NOTHING returns between here and the last
+    // collective; the ranks then agree in two small steps before any data moves:
+    //   1. the root's status, raw extents and metric travel first (4 words): a rank whose G / S / metric are not the root's fails
+    //      with CYTO_ERR_BAD_ARG (raw, not padded, extents: two different G inside one padding bucket would scale by different
+    //      1/sqrt(G) around the same operand);
+    //   2. a max-allreduce of "did anything fail here" (local validation, device selection, allocations, the transforms): only
+    //      if NO rank failed does anybody enter the operand broadcast -- all ranks enter it or none does, a failed rank needs no
+    //      scratch buffer to receive into, and every rank of a failed call returns an error (its own, else the root's, else
+    //      CYTO_ERR_PEER).
+    // The small collectives go through the communicator's own pre-allocated device word (comm.hip): nothing on the way into
+    // them can fail.
     int rc = CYTO_OK;
     if (!out) return CYTO_ERR_BAD_ARG;                                       // (a caller bug on this rank alone: nothing to agree on)
     *out = nullptr;
     if (G <= 0 || C <= 0 || S <= 0 || !sc || ldsc_in < C) rc = CYTO_ERR_BAD_ARG;
     if (metric < CYTO_METRIC_PEARSON || metric > CYTO_METRIC_EUCLIDEAN) rc = CYTO_ERR_BAD_ARG;
+    if (comm && (root < 0 || rank != comm_rank(comm))) rc = CYTO_ERR_BAD_ARG;
+    if (comm && device_id != comm_device(comm)) { rc = CYTO_ERR_BAD_ARG; device_id = comm_device(comm); }     // (the collectives run on the communicator's device)
     const bool have_st = !comm || rank == root;
     if (have_st && (!st || ldst_in < S)) rc = CYTO_ERR_BAD_ARG;
     if (!comm && rc) return rc;
-    int dev_rc = select_device(device_id);
-    if (dev_rc) return dev_rc;                                               // (no device: no communicator could have been made either)
+    const int dev_rc = select_device(device_id);
+    if (dev_rc) { if (!comm) return dev_rc; rc = rc ? rc : dev_rc; }
     cyto_expr_ctx *ctx = rc ? nullptr : new (std::nothrow) cyto_expr_ctx();
     if (!rc && !ctx) rc = CYTO_ERR_NOMEM;
     const int transform = metric == CYTO_METRIC_PEARSON ? CYTO_TRANSFORM_STANDARDIZE
@@ -983,31 +994,25 @@ static int ctx_create_impl(int metric, int G, int C, int S, const void *sc, int6
         rc = cyto_transform(transform, G, S, st, ldst_in, st_is_f64, st_on_device, already_normalized, ctx->zst.as<float>(), ctx->ldst,
                             ctx->Gpad, device_id, nullptr);
     if (comm) {
-        // the root's status AND the extents of its operand: a rank that failed locally (bad G / S of its own) still receives exactly
-        // what the root sends -- into a scratch block --, so that nobody is left waiting and no two ranks disagree on the count
-        int words[3] = {rc, (int)round_up(G > 0 ? G : 1, BK), (int)round_up(S > 0 ? S : 1, BM)};   // (only the root's values are sent)
-        const int my_gpad = words[1], my_ldst = words[2];
-        const int brc = comm_bcast_status(comm, words, root, device_id, 3);
-        const int root_rc = words[0];
-        if (brc) rc = rc ? rc : brc;
-        else if (root_rc) rc = rc ? rc : root_rc;                            // the root failed: nobody enters the data broadcast
-        else {
-            if (!rc && (words[1] != my_gpad || words[2] != my_ldst)) rc = CYTO_ERR_BAD_ARG;       // this rank's G / S are not the root's
-            DevBuf scratch;
-            float *dst = (!rc && ctx) ? ctx->zst.as<float>() : nullptr;
-            const size_t count = (size_t)words[1] * (size_t)words[2];
-            if (!dst && !scratch.alloc(count * 4)) dst = scratch.as<float>();
+        int32_t words[4] = {rc, G, S, metric};                               // (only the root's values are sent)
+        const int brc = comm_bcast_words(comm, words, 4, root);
+        const int root_rc = brc ? 0 : words[0];
+        if (!rc && !brc && !root_rc && (words[1] != G || words[2] != S || words[3] != metric)) rc = CYTO_ERR_BAD_ARG;   // not the root's problem
+        int any = (rc || brc || root_rc) ? 1 : 0;
+        const int arc = comm_allreduce_max(comm, &any);
+        if (!rc) rc = brc ? brc : arc;
+        if (!rc && root_rc) rc = root_rc;                                    // the root failed: every rank reports the root's code
+        if (!rc && any) rc = CYTO_ERR_PEER;                                  // some other rank failed
+        if (!rc) {                                                           // (`any` is the same on every rank: all enter, or none)
             Events<2> ev;
-            if (dst && !ev.create()) {
-                (void)hipEventRecord(ev[0], nullptr);
-                const int drc = cyto_comm_bcast_f32(comm, dst, count, root, device_id, nullptr);
+            const bool timed = ev.create() == CYTO_OK;
+            if (timed) (void)hipEventRecord(ev[0], nullptr);
+            rc = comm_bcast_dev(comm, ctx->zst.p, nst * 4, root, nullptr);
+            if (timed) {
                 (void)hipEventRecord(ev[1], nullptr);
-                if (!rc) rc = drc;
-                if (!rc && hipEventSynchronize(ev[1]) != hipSuccess) rc = CYTO_ERR_HIP;
                 float ms = 0;
-                (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
-                if (bcast_ms) *bcast_ms = ms;
-            } else if (!rc) rc = CYTO_ERR_NOMEM;
+                if (hipEventSynchronize(ev[1]) == hipSuccess && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess && bcast_ms) *bcast_ms = ms;
+            }
         }
     }
     if (!comm || rank == root) transform_sc();

@@ -79,6 +79,7 @@ constexpr int LDS_DYNAMIC_MAX = 160 * 1024 - 2048;
 int set_max_dynamic_lds(const void *kernel);
 
 int select_device(int device_id);
+int device_cus(int device_id);          // multiProcessorCount, queried once per device (256 if the query fails)
 
 // lap_jv.hip: float32 problems of ONE size solved as a batch (one launch per chain phase, a workgroup per problem)
 int lap_batch_same_n(int n, int nb, const float *const *cost, const int64_t *ld, int cost_on_device, int32_t *const *rowsol,
@@ -90,6 +91,17 @@ int lap_batch_any(int nb, const int *n, const float *const *cost, const int64_t 
                   const int32_t *const *rowmap, const int *nu, int32_t *const *rowsol, int32_t *const *colsol, float *const *u,
                   float *const *v, double *total, cyto_lap_info *info, int *status_out, int max_concurrent, int device_id,
                   const cyto_lap_opts *opts = nullptr);
-// batch.hip: nwords (<= 4) int32 from `root` to every rank of the communicator (status agreement before the operand broadcast)
-int comm_bcast_status(void *comm, int *status, int root, int device_id, int nwords = 1);
+// comm.hip: the communicator's collectives as the context builder uses them (every rank enters every one of them, whatever
+// went wrong on it before)
+int comm_device(void *comm);
+int comm_rank(void *comm);
+int comm_bcast_words(void *comm, int32_t *words, int nwords, int root);          // <= 16 host int32 from root to all
+int comm_allreduce_max(void *comm, int *val);                                    // *val := max over ranks
+int comm_bcast_dev(void *comm, void *dev_buf, size_t bytes, int root, hipStream_t stream);
+
+// Developer knobs (environment variables of the tools/ scripts): read ONCE per process, at first use -- no libc call per solve, and
+// a knob cannot change between two solves of one process.
+struct Knob { int value; bool set; };
+Knob read_knob(const char *name);
+#define CYTO_KNOB(name) ([]() -> const ::cyto::Knob & { static const ::cyto::Knob k = ::cyto::read_knob(name); return k; }())
 }  // namespace cyto

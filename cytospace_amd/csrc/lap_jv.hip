@@ -3255,7 +3255,7 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(const LazyArgs *__restrict
 // ------------------------------------------------------------------------------------------
 static std::atomic<int> g_par_busy[64];     // per device: a several-searches-at-once kernel (wide_aug<..,PAR>) is in flight
 
-static const cyto_lap_opts k_default_opts = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static const cyto_lap_opts k_default_opts = {};
 
 static int check_opts(const cyto_lap_opts &o) {
     if (o.chain_variant < 0 || o.chain_variant > 3 || o.augmentation < 0 || o.augmentation > 2 || o.inject_exceptions < 0 ||
@@ -3264,6 +3264,10 @@ static int check_opts(const cyto_lap_opts &o) {
     if (o.group_state_global < 0 || o.group_state_global > 1 || o.aux_state_global < 0 || o.aux_state_global > 1) return CYTO_ERR_BAD_ARG;
     if (o.mode < 0 || o.mode > 2 || o.wide_rounds < -1 || o.wide_groups < -1 || o.wide_groups > 32 || o.wide_rebuild < -1 ||
         o.wide_wipe < 0 || o.wide_wipe > 2048 || o.wide_par < -1 || o.wide_par > WIDE_PAR_GMAX) return CYTO_ERR_BAD_ARG;
+    if (o.cache_waves < -1 || o.cache_waves > 32 || (o.cache_unroll != 0 && o.cache_unroll != 4 && o.cache_unroll != 8) || o.cache_stream < -1 ||
+        o.cache_stream > 1)
+        return CYTO_ERR_BAD_ARG;
+    for (int r : o.reserved) if (r != 0) return CYTO_ERR_BAD_ARG;            // (must be zero: room for later knobs without another ABI break)
     return CYTO_OK;
 }
 
@@ -3289,7 +3293,7 @@ struct F32Job {
 struct F32Plan {            // what depends on n (and the options) only: identical for every problem of the batch
     int n, colblocks, rowblocks, rows_per_block, cache_grid;
     int cache_stream = 1;           // build_row_caches_wave: the guess-free single sweep (cb_stream); 0: a neighbour's floor as the guess
-    int cache_waves = 8, cache_unroll = 4, cus = 256;      // build_row_caches_wave: waves per CU, quads in flight per lane; CUs of the device
+    int cache_waves = 8, cache_unroll = 4, cus = 256;      // build_row_caches_wave: waves per CU, quads in flight per lane; CUs of the device (device_cus)
     bool force_l2, lds_variant, lazy, lz_lds_state, lz_cs_lds, no_cs_lds, wide;
     long long wide_rounds;
     int wide_groups, wide_rebuild, wide_wipe, wide_par;
@@ -3365,24 +3369,29 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
         std::vector<WideArgs> h_wa((size_t)nl);
         for (int k = 0; k < nl; k++) {
             F32Job &j = jobs[live[k]];
-            const int mcg = nl != 1 ? 0 : (pl.wide_groups > 0 ? pl.wide_groups : (pl.wide_groups < 0 ? 0 : wide_mc_groups(nl, n)));
-            const size_t mcb = mcg > 0 ? wide_mc_state_bytes(n) : 0;
+            // Both several-workgroup search kernels (wide_aug_mc: one search on G workgroups; wide_aug<.., PAR>: G searches at once) meet at
+            // hand-rolled grid barriers and are launched as plain kernels: their participating workgroups (blocks 0, 8, 16, ... -- one XCD)
+            // must all be RESIDENT, one 1024-thread workgroup per CU.  So G is clamped to the CUs of one XCD, and ONE such kernel runs per
+            // device at a time, whichever of the two it is: workgroups of two of them could each get partly scheduled and spin for the
+            // rest.  A solve that finds the slot taken runs one search at a time on one workgroup (same results).
+            const int xcd_cus = std::max(1, pl.cus / 8);
+            int mcg = nl != 1 ? 0 : (pl.wide_groups > 0 ? pl.wide_groups : (pl.wide_groups < 0 ? 0 : wide_mc_groups(nl, n)));
+            mcg = std::min(mcg, xcd_cus);
             // several searches of ONE problem at once (wide_aug<.., PAR>): by default for a single problem without runs of identical
             // rows (those finish their searches as runs of one-edge steps in the one-workgroup kernel) from 2 048 rows on
             // (runs of identical rows -- a Visium problem's slots: a tenth as many groups as rows -- finish most of their searches as
             //  runs of one-edge steps in the one-workgroup kernel; a sub-spot chunk's few doubled spots do not matter)
             const bool dup_rows = n >= 2 && (long long)j.h_ngroups * 5 < (long long)n * 4;
             int parg = (nl != 1 || mcg > 0) ? 0 : (pl.wide_par > 0 ? pl.wide_par : (pl.wide_par < 0 || dup_rows || n < 2048 ? 0 : 16));
-            // ONE such kernel per device at a time: its workgroups wait for each other at grid barriers and all sit on one XCD (32 CUs) --
-            // three of them launched from three host threads could each get a part of their workgroups scheduled and spin for the
-            // rest.  A solve that finds the slot taken runs its searches one at a time (same results).
-            if (parg > 1) {
-                if (g_par_busy[device_slot].exchange(1) != 0) parg = 0;
+            parg = std::min(std::min(parg, WIDE_PAR_GMAX), xcd_cus);
+            if (parg == 1) parg = 0;
+            if (mcg == 1) mcg = 0;
+            if (parg > 1 || mcg > 1) {
+                if (g_par_busy[device_slot].exchange(1) != 0) { parg = 0; mcg = 0; }
                 else par_slot_held = true;
             }
-            if (parg > WIDE_PAR_GMAX) parg = WIDE_PAR_GMAX;
-            if (parg == 1) parg = 0;
             if (par_slot_held) par_slot.p = &g_par_busy[device_slot];
+            const size_t mcb = mcg > 0 ? wide_mc_state_bytes(n) : 0;
             const size_t parb = parg > 0 ? wide_par_state_bytes(n, parg) : 0;
             const size_t sc_off = ((2 * nT + 255) / 256) * 256 + mcb;       // the phase machine's control block behind everything else
             const size_t par_off = sc_off + WIDE_SC_BYTES;
@@ -3406,7 +3415,7 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             // faster per element -- and the problems of a batch are rebuilt one after the other while their workgroups all wait)
             wa.aug_waste = (int)std::min<long long>(1 << 30, std::max<long long>(16, (2000000ll + (long long)nl * n * n / 100) / n));
             wa.arr_waste = std::max(8, wa.aug_waste / 3);          // (a full-row bid with its cache refresh: three sweeps)
-            if (const char *e = getenv("CYTO_ARR_WASTE")) wa.arr_waste = std::max(1, atoi(e));     // (developer knob: tools/batch_chunks_bench.py)
+            if (CYTO_KNOB("CYTO_ARR_WASTE").set) wa.arr_waste = std::max(1, CYTO_KNOB("CYTO_ARR_WASTE").value);     // (developer knob, read once per process: tools/batch_chunks_bench.py)
             wa.seg_quorum = nl > 1 ? std::max(1, nl / 4) : 0;
             wa.seg_sync = nullptr;
             wa.same_prev = (j.h_ngroups < n && n >= 2) ? j.b_same.as<int32_t>() : nullptr;
@@ -3563,10 +3572,12 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
     //  build with 8 waves, 24.0-24.8 ms after one with 20 -- 183 instead of 146 full-row bids, each holding up a round for one 200-KB sweep).
     pl.cache_unroll = 8;
     pl.cache_waves = n > 32768 ? 8 : 20;
-    // (developer knobs, tools/cache_build_bench.py: CYTO_CACHE_WAVES = 0 selects the workgroup-per-row builders)
-    if (const char *e = getenv("CYTO_CACHE_WAVES")) pl.cache_waves = std::max(0, std::min(32, atoi(e)));
-    if (const char *e = getenv("CYTO_CACHE_UNROLL")) pl.cache_unroll = atoi(e) == 8 ? 8 : 4;
-    if (const char *e = getenv("CYTO_CACHE_STREAM")) pl.cache_stream = atoi(e) != 0;
+    // (cyto_lap_opts.cache_waves / cache_unroll / cache_stream -- tools/cache_build_bench.py and the builder tests: -1 waves selects the
+    //  workgroup-per-row builders)
+    if (opts.cache_waves != 0) pl.cache_waves = opts.cache_waves < 0 ? 0 : opts.cache_waves;
+    if (opts.cache_unroll != 0) pl.cache_unroll = opts.cache_unroll;
+    if (opts.cache_stream != 0) pl.cache_stream = opts.cache_stream > 0 ? 1 : 0;
+    pl.cus = device_cus(device_id);
     const int per2 = 4 * BLOCK2;
     // which chain variant: by size, or the large-n variants forced at a small n (opts.chain_variant; the test-suite
     // runs them on instances the CPU oracle solves in a second)

@@ -2096,12 +2096,12 @@ int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, i
         //  nothing to do -- same box, gpurun_out/r04af, row-reduction phase with 4 096 / 2 048 / 1 024 / 256 workgroups: 20 000^2 7.9 / 7.5 /
         //  7.4 / 7.9 ms, 50 000^2 22.5-23.0 / 21.5 / 21.4-21.9 / 23.9 ms, few-cell-type 20 000^2 23.1-23.4 / 22.9 / 23.0-23.5 / 26.1 ms)
         int bid_total = 4096;
-        if (const char *e = getenv("CYTO_BID_TOTAL")) bid_total = std::max(64, atoi(e));        // (developer knob: tools/exp/bid_grid_batch_ab.sh)
+        if (CYTO_KNOB("CYTO_BID_TOTAL").set) bid_total = std::max(64, CYTO_KNOB("CYTO_BID_TOTAL").value);        // (developer knob, read once per process: tools/exp/bid_grid_batch_ab.sh)
         int bx = std::max(1, std::min((n + HEADB / 64 - 1) / (HEADB / 64), std::min(2048, std::max(64, bid_total / std::max(1, nb)))));
-        if (const char *e = getenv("CYTO_BID_GRID")) bx = std::max(1, std::min(bx, atoi(e)));        // (developer knob: tools/exp/bid_grid_ab.sh)
+        if (CYTO_KNOB("CYTO_BID_GRID").set) bx = std::max(1, std::min(bx, CYTO_KNOB("CYTO_BID_GRID").value));        // (developer knob, read once per process: tools/exp/bid_grid_ab.sh)
         const int bxr = std::max(1, std::min((n + HEADB - 1) / HEADB, 2048 / std::max(1, std::min(nb, 16))));
         // (quads of a full-row bid's sweep in flight per lane: developer knob CYTO_BID_UNROLL, tools/exp)
-        static const bool deep = [] { const char *e = getenv("CYTO_BID_UNROLL"); return e && atoi(e) == 8; }();
+        const bool deep = CYTO_KNOB("CYTO_BID_UNROLL").set && CYTO_KNOB("CYTO_BID_UNROLL").value == 8;
         void (*bidk)(const WideArgs *, int) = deep ? wide_sc_bid<8> : wide_sc_bid<4>;
         if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(bidk)))) return rc;
         hipLaunchKernelGGL(wide_sc_init, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args);

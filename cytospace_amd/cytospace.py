@@ -8,6 +8,8 @@ per chunk); across ranks (one process per GPU) the only collective is the broadc
 (cytospace.py:430-451 ships the whole ST matrix to every worker of a process pool).
 """
 import ctypes
+import os
+import threading
 import time
 
 import numpy as np
@@ -288,15 +290,23 @@ def _counts_matrix(a):
 
 
 class _RankContext:
-    """ExpressionContext over only the columns this rank's chunks touch (one process per GPU: a rank neither uploads nor
-    transforms the cells of other ranks' chunks), with the chunk index lists remapped accordingly.  With a communicator the
-    ST matrix is transformed on rank 0 only and broadcast (ExpressionContext, comm=...); every rank then keeps ALL spots."""
+    """ExpressionContext over only the columns this rank's chunks touch (a rank neither uploads nor transforms the cells of
+    other ranks' chunks), with the chunk index lists remapped accordingly.  --sampling-sub-spots chunks (every chunk against
+    ALL spots, cytospace.py:438) with a communicator: the ST matrix is transformed on rank 0 only and broadcast
+    (ExpressionContext, comm=...).  --single-cell chunks (index_st_list: every chunk against its OWN spots, cytospace.py:434-435)
+    need no collective at all: each rank uploads only the spots of its own chunks, the communicator is not used and
+    every rank must hold the ST matrix."""
 
     def __init__(self, sc, st, mine, index_sc_list, index_st_list, device_id, distance_metric, already_normalized=True,
                  comm=None, n_spots=None):
         sc = np.asarray(sc)
         self._sc_cols = self._st_cols = None
         self.ctx = None
+        if index_st_list is not None:
+            comm = None                               # (decided by the MODE, the same on every rank: nobody enters a collective)
+            if st is None and mine:
+                raise ValueError("--single-cell chunks take their spots from the ST matrix of the rank that solves them: "
+                                 "every rank needs st (no broadcast in this mode)")
         if not mine and comm is None:
             return                                    # nothing to solve on this rank: no upload, no transform
         if mine and len(mine) < len(index_sc_list):
@@ -380,20 +390,98 @@ def assign_chunks(scRNA, st, cell_number_to_node_assignment, index_sc_list, inde
         return dict(zip(mine, ctx.assign_chunks(chunks, max_concurrent)))
 
 
+def visible_devices(devices=None):
+    """The (logical) device list the chunk fan-out runs on: `devices` if given, else the environment variable
+    CYTOSPACE_HIP_DEVICES ("0,1,2,3"; a device may be listed more than once: several workers on one GPU), else every HIP
+    device this process sees.  Raises ValueError for a device that does not exist."""
+    nvis = _lib.device_count()
+    if devices is None:
+        env = os.environ.get("CYTOSPACE_HIP_DEVICES", "").strip()
+        devices = [int(x) for x in env.split(",") if x.strip() != ""] if env else list(range(nvis))
+    devices = [int(d) for d in devices]
+    if nvis < 1:
+        raise _lib.CytoHipError("no HIP device visible (there is no CPU fallback)")
+    bad = [d for d in devices if d < 0 or d >= nvis]
+    if bad or not devices:
+        raise ValueError(f"devices {devices}: this process sees {nvis} HIP device(s)")
+    return devices
+
+
+def assign_chunks_on_devices(scRNA, st, cell_number_to_node_assignment, index_sc_list, index_st_list=None,
+                             subsampled_slots_list=None, devices=None, max_concurrent=0,
+                             distance_metric="Pearson_correlation", already_normalized=True):
+    """The chunk fan-out of apply_linear_assignment over EVERY device of this process -- what the reference's
+    ProcessPoolExecutor(number_of_processors) (cytospace.py:430-451) becomes on a multi-GPU node, with no launcher: one host
+    thread per (logical) device, chunk -> device by the LPT schedule, all chunks of a device in one batched call.
+    --sampling-sub-spots chunks share the ST operand: device 0 transforms it ONCE and it reaches the others with one
+    broadcast (RCCL over xGMI between distinct devices; a device-to-device copy between logical ranks of one device);
+    the other devices never see the host ST matrix.  Returns {chunk index: mapped_st_index}, every chunk."""
+    devices = visible_devices(devices)
+    n_chunks = len(index_sc_list)
+    W = max(1, min(len(devices), n_chunks))
+    devices = devices[:W]
+    if W == 1:
+        return assign_chunks(scRNA, st, cell_number_to_node_assignment, index_sc_list, index_st_list, subsampled_slots_list,
+                             rank=0, world_size=1, device_id=devices[0], max_concurrent=max_concurrent,
+                             distance_metric=distance_metric, already_normalized=already_normalized)
+    # what every rank would reject is rejected HERE, before any thread can wait for a peer that never arrives
+    if (index_st_list is not None) and (subsampled_slots_list is not None):
+        raise ValueError("index_st_list and subsampled_cell_number_to_node_assignment_list cannot both be specified")
+    from .common import METRICS
+    if distance_metric not in METRICS:
+        raise ValueError(f"unknown distance_metric {distance_metric!r}")
+    if st is None or np.asarray(scRNA).shape[0] != np.asarray(st).shape[0]:
+        raise ValueError("The two matrices v1 and v2 must have equal dimensions; "
+                         "ST and scRNA data must have the same genes")
+    shared_st = index_st_list is None                       # sub-spot mode: one ST operand for everybody
+    comms = _lib.Communicator.init_local(devices) if shared_st else [None] * W
+    results, errors = [None] * W, [None] * W
+
+    def work(r):
+        try:
+            results[r] = assign_chunks(scRNA, st if (r == 0 or not shared_st) else None, cell_number_to_node_assignment,
+                                       index_sc_list, index_st_list, subsampled_slots_list, rank=r, world_size=W,
+                                       device_id=devices[r], max_concurrent=max_concurrent, distance_metric=distance_metric,
+                                       already_normalized=already_normalized, comm=comms[r])
+        except BaseException as e:      # noqa: BLE001 (re-raised on the calling thread)
+            errors[r] = e
+            if comms[r] is not None:
+                comms[r].abort()        # peers waiting in a collective this rank will not reach fail instead of hanging
+    threads = [threading.Thread(target=work, args=(r,), name=f"cytohip-dev{devices[r]}-rank{r}") for r in range(W)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for c in comms:
+        if c is not None:
+            c.close()
+    real = [e for e in errors if e is not None and f"status {_lib.CYTO_ERR_PEER}" not in str(e)]
+    if real or any(e is not None for e in errors):
+        raise (real[0] if real else next(e for e in errors if e is not None))
+    merged = {}
+    for r in range(W):
+        merged.update(results[r])
+    return merged
+
+
 def apply_linear_assignment(scRNA_data, st_data, coordinates_data, cell_number_to_node_assignment,
                             solver_method, solver, seed, distance_metric, number_of_processors,
                             index_sc_list, index_st_list=None, subsampled_cell_number_to_node_assignment_list=None,
-                            rank=0, world_size=1, device_id=0, comm=None):
+                            rank=0, world_size=1, device_id=None, comm=None, devices=None):
     """cytospace/cytospace.py:354-469 with the reference's arguments (pandas DataFrames as read by read_data):
     normalise once, solve every chunk, map the assigned spot indices to coordinates.
 
     Returns (assigned_locations: pd.DataFrame, cell_ids_selected: np.ndarray); the nth cell id is mapped to the
     nth row of assigned_locations.  The count matrices go to the GPU ONCE, as raw counts (float32 when exact), and are
     normalised and transformed there (common.py:142-147 on the device); nothing normalised comes back to the host.
-    The reference forks one process per chunk; here all chunks of a rank go through the solver together, a workgroup per
-    chunk (`number_of_processors` bounds how many are in flight).  With world_size > 1 (one process per GPU) each rank
-    returns the chunks the LPT schedule gives it, in chunk order (the reference concatenates in completion order: compare
-    as a set of (cell, spot) pairs); with `comm` only rank 0's ST matrix is used and its operand is broadcast."""
+
+    With the reference's own arguments (nothing after subsampled_...) the chunks are scheduled over EVERY HIP device this
+    process sees (`devices`, or CYTOSPACE_HIP_DEVICES; assign_chunks_on_devices): the reference forks one process per chunk,
+    here one host thread drives each device and all chunks of a device go through the solver together
+    (`number_of_processors` bounds how many are in flight per device); results come back in chunk (submission) order -- the
+    reference concatenates in completion order: compare as a set of (cell, spot) pairs.
+    One process per GPU under an external launcher instead: pass rank / world_size / device_id (and comm: then only rank 0's
+    ST matrix is used and its operand is broadcast); each rank then returns the chunks the LPT schedule gives it."""
     import pandas as pd
     if (index_st_list is not None) and (subsampled_cell_number_to_node_assignment_list is not None):
         raise ValueError("index_st_list and subsampled_cell_number_to_node_assignment_list cannot both be specified")
@@ -403,19 +491,27 @@ def apply_linear_assignment(scRNA_data, st_data, coordinates_data, cell_number_t
     st_counts = _counts_matrix(st_data.to_numpy()) if st_data is not None else None
     cell_ids = scRNA_data.columns.values
     slots_all = np.asarray(cell_number_to_node_assignment)
+    launcher = world_size > 1 or comm is not None or device_id is not None       # the caller places this rank itself
     if (index_st_list is None) and (subsampled_cell_number_to_node_assignment_list is None):
         print('Solving linear assignment problem ...')
         t0 = time.perf_counter()
+        one_dev = (0 if device_id is None else device_id) if launcher else visible_devices(devices)[0]   # one LAP: one GPU
         mapped = assign_pearson(sc_counts[:, index_sc_list[0]], st_counts, slots_all, already_normalized=False,
-                                device_id=device_id, distance_metric=distance_metric)
+                                device_id=one_dev, distance_metric=distance_metric)
         print(f"Time to solve linear assignment problem: {round(time.perf_counter() - t0, 2)} seconds")
         return coordinates_data.iloc[mapped.tolist()], cell_ids[index_sc_list[0]]
     n_chunks = len(index_st_list) if index_st_list is not None else len(subsampled_cell_number_to_node_assignment_list)
     print(f"Number of required processors: {n_chunks}")
-    res = assign_chunks(sc_counts, st_counts, slots_all, index_sc_list, index_st_list,
-                        subsampled_cell_number_to_node_assignment_list, rank=rank, world_size=world_size,
-                        device_id=device_id, max_concurrent=int(number_of_processors), distance_metric=distance_metric,
-                        already_normalized=False, comm=comm)
+    if launcher:
+        res = assign_chunks(sc_counts, st_counts, slots_all, index_sc_list, index_st_list,
+                            subsampled_cell_number_to_node_assignment_list, rank=rank, world_size=world_size,
+                            device_id=0 if device_id is None else device_id, max_concurrent=int(number_of_processors),
+                            distance_metric=distance_metric, already_normalized=False, comm=comm)
+    else:
+        res = assign_chunks_on_devices(sc_counts, st_counts, slots_all, index_sc_list, index_st_list,
+                                       subsampled_cell_number_to_node_assignment_list, devices=devices,
+                                       max_concurrent=int(number_of_processors), distance_metric=distance_metric,
+                                       already_normalized=False)
     assigned_locations_list, cell_ids_selected_list = [], []
     for idx in sorted(res):
         mapped = res[idx]

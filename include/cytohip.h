@@ -27,12 +27,18 @@ enum {
     CYTO_ERR_HIP = 5,           /* a HIP runtime call failed; cyto_last_hip_error() has the text */
     CYTO_ERR_NO_DEVICE = 6,     /* no gfx950 device visible */
     CYTO_ERR_UNSUPPORTED = 7,   /* size outside what this build supports (n > 262144 per LAP) */
-    CYTO_ERR_SHAPE = 8          /* gene counts differ; reference: ValueError, common/common.py:191-192 */
+    CYTO_ERR_SHAPE = 8,         /* gene counts differ; reference: ValueError, common/common.py:191-192 */
+    CYTO_ERR_PEER = 9           /* another rank of the communicator failed, aborted or did not arrive; reference: BrokenProcessPool */
 };
 
 const char *cyto_strerror(int status);
 const char *cyto_last_hip_error(void);   /* thread-local text of the last failing HIP call */
 const char *cyto_version(void);
+/* ABI check for callers that mirror the structs below (ctypes, cgo ...): the library's own sizeof(cyto_lap_info),
+ * sizeof(cyto_lap_opts), sizeof(cyto_assign_info), sizeof(cyto_chunk).  The structs carry no size member: a caller built
+ * against another header version must compare these at load time (cytospace_amd/_lib.py does) instead of passing a struct
+ * the library would overrun.  ABI history: INTEGRATION.md, "ABI versions". */
+int cyto_abi_sizes(size_t *lap_info, size_t *lap_opts, size_t *assign_info, size_t *chunk);
 
 /* ---- device + memory plumbing (so callers can keep the cost matrix resident in HBM) ---- */
 int cyto_device_count(int *count);
@@ -146,11 +152,18 @@ typedef struct {
                                    a rebuild costs.  -1: never.  k > 0: every k searches.  Results do not depend on it */
     int32_t wide_par;           /* wide solver, one problem: searches of consecutive free rows that run at once, a workgroup each, from one state and
                                    are committed in row order while their settled sets are disjoint (the rest runs again).  0: 16 for a problem
-                                   of >= 2 048 rows without runs of identical rows, else one at a time.  -1: one at a time.  k > 1: k (<= 64).
+                                   of >= 2 048 rows without runs of identical rows, else one at a time.  -1: one at a time.  k > 1: k (<= 64;
+                                   clamped to the CUs of one XCD -- the workgroups meet at grid barriers and must all be resident).
                                    Results do not depend on it */
     int32_t wide_wipe;          /* wide solver, row reduction: the per-column bid words carry a 12-bit round tag relative to their last wipe;
                                    0: wiped every 2048 launch pairs.  k > 0: every k pairs (a self-test of the protocol at sizes the CPU
                                    oracle checks).  Results do not depend on it */
+    int32_t cache_waves;        /* row-cache builder (float32): 0: by size (a wave per row, 8 or 20 waves per CU).  k > 0: k waves per CU (<= 32).
+                                   -1: the workgroup-per-row builders of round 3.  Results do not depend on it */
+    int32_t cache_unroll;       /* ... 16-byte quads in flight per lane of the wave builder: 0 (default: 8), 4 or 8 */
+    int32_t cache_stream;       /* ... 0 / 1: the guess-free streaming selection for rows of >= 2 048 columns.  -1: a neighbouring row's floor
+                                   as the guess (round 4's first form) */
+    int32_t reserved[5];        /* must be zero */
 } cyto_lap_opts;
 int cyto_lap_f32_opts(int n, const float *cost, int64_t ld, int cost_on_device,
                       int32_t *rowsol, int32_t *colsol, float *u, float *v, double *total,
@@ -192,7 +205,20 @@ int cyto_lap_batch_f32_opts(int nb, const int *n, const float *const *cost, cons
  * a file ...).  The reference has no counterpart: it pickles the matrix to every worker (cytospace.py:446-451). */
 int cyto_comm_unique_id(char *id128);
 int cyto_comm_init(const char *id128, int rank, int nranks, int device_id, void **comm_out);
+/* One PROCESS driving several devices, one host thread per rank -- what apply_linear_assignment's `number_of_processors` pool
+ * (cytospace.py:430-451) becomes on a multi-GPU node without a launcher: comms_out[r] is the handle rank r's thread uses, on
+ * device_ids[r].  Distinct devices: RCCL (ncclCommInitAll).  A device listed more than once ("logical" ranks: several workers
+ * on one GPU): the ranks meet inside the process and the broadcast is a device-to-device / peer copy out of the root's buffer. */
+int cyto_comm_init_local(int nranks, const int *device_ids, void **comms_out);
+int cyto_comm_count(void *comm, int *nranks_out);      /* ranks the communicator spans (RCCL: ncclCommCount) */
+int cyto_comm_kind(void *comm, int *kind_out);         /* 0: RCCL, 1: in-process (logical ranks) */
 int cyto_comm_bcast_f32(void *comm, float *dev_buf, size_t count, int root, int device_id, void *stream);
+/* *status := the largest status any rank brought (0: all fine).  Collective: how the ranks agree to enter or skip a data
+ * collective together. */
+int cyto_comm_agree(void *comm, int *status);
+/* For a rank that cannot reach a collective its peers wait in (its host code failed first): in-process kind -- the waiting ranks
+ * return CYTO_ERR_PEER; RCCL kind -- ncclCommAbort.  Afterwards the handle is good for cyto_comm_destroy only. */
+int cyto_comm_abort(void *comm);
 int cyto_comm_destroy(void *comm);
 
 /* ---- A1: normalize_data (cytospace/common/common.py:142-147): nan_to_num, per-column counts per

@@ -352,6 +352,125 @@ def test_two_ranks_broadcast_and_disjoint_chunks(tmp_path):
     assert pairs == want and S > 0
 
 
+def _gv11_frames(mode):
+    import pandas as pd
+    d = load("gv11_apply_linear_assignment.npz")
+    sc, st, slots = d[mode + "_counts"], d[mode + "_st_counts"], d[mode + "_slots"]
+    G, C = sc.shape
+    S = st.shape[1]
+    sc_df = pd.DataFrame(sc, index=[f"g{i}" for i in range(G)], columns=[f"c{i}" for i in range(C)])
+    st_df = pd.DataFrame(st, index=sc_df.index, columns=[f"s{i}" for i in range(S)])
+    ncol = 10 if mode == "sc" else 4
+    coords = pd.DataFrame({"row": np.arange(S) // ncol, "col": np.arange(S) % ncol}, index=st_df.columns)
+    idx_sc = np.split(d[mode + "_idx_sc"], np.cumsum(d[mode + "_idx_sc_lens"])[:-1])
+    kw = {}
+    if mode == "sc":
+        kw["index_st_list"] = np.split(d["sc_idx_st"], np.cumsum(d["sc_idx_st_lens"])[:-1])
+    else:
+        kw["subsampled_cell_number_to_node_assignment_list"] = list(d["ss_sub"])
+    want = {(int(c), int(r), int(k)) for c, (r, k) in zip(d[mode + "_out_cell"], d[mode + "_out_rowcol"])}
+    return sc_df, st_df, coords, slots, idx_sc, kw, want
+
+
+@pytest.mark.parametrize("mode", ["sc", "ss"])
+@pytest.mark.parametrize("how", ["devices=[0, 0]", "CYTOSPACE_HIP_DEVICES=0,0", "devices=[0, 0, 0]"])
+def test_gv11_reference_signature_drives_every_logical_device(mode, how, monkeypatch):
+    # SURVEY 8(b), the multi-chunk seam: apply_linear_assignment with the REFERENCE's arguments (cytospace.py:354-357) schedules
+    # the chunks over every device of the process, one host thread per device.  On this one-GPU box the device list names GPU 0
+    # twice (logical ranks): the scheduler, the rank that never sees the ST matrix, the broadcast (a device-to-device copy
+    # between logical ranks of one GPU; RCCL between distinct GPUs), and the merge in submission order all run -- and the
+    # (cell, spot) pairs are the ones the reference's own run produced (gv11).
+    sc_df, st_df, coords, slots, idx_sc, kw, want = _gv11_frames(mode)
+    extra = {}
+    if how.startswith("CYTOSPACE"):
+        monkeypatch.setenv("CYTOSPACE_HIP_DEVICES", "0,0")
+    else:
+        extra["devices"] = [0] * how.count("0")
+    loc, ids = gcyto.apply_linear_assignment(sc_df, st_df, coords, slots, "lapjv_hip", None, 1, "Pearson_correlation", 2,
+                                             idx_sc, **kw, **extra)
+    got = {(int(c[1:]), int(r), int(k)) for c, (r, k) in zip(ids, loc.to_numpy())}
+    assert len(got) == len(ids) == len(want) and got == want
+    # submission order: the cells come back chunk after chunk
+    assert [int(c[1:]) for c in ids] == [int(c) for ix in idx_sc for c in ix]
+
+
+def test_in_process_communicator_collectives_and_failing_together():
+    # csrc/comm.hip, the in-process kind (logical ranks on one GPU): count / kind / agree, the rank without ST receiving the
+    # root's operand, and the failure rules -- a rank whose genes are not the root's fails with ValueError while its peer fails
+    # with CYTO_ERR_PEER (nobody enters the data broadcast, nobody hangs); a rank that aborts releases a peer that waits.
+    import threading
+    from cytospace_amd import _lib
+    d, idx_sc = _gv11_ss()
+    sc, st = d["ss_counts"].astype(np.float32), d["ss_st_counts"].astype(np.float32)
+    subs = list(d["ss_sub"])
+    comms = _lib.Communicator.init_local([0, 0])
+    assert [c.count() for c in comms] == [2, 2] and comms[0].kind() == "in-process"
+    out = [None, None]
+
+    def run(r, fn):
+        try:
+            out[r] = fn(r)
+        except BaseException as e:     # noqa: BLE001
+            out[r] = e
+
+    def both(fn):
+        th = [threading.Thread(target=run, args=(r, fn)) for r in range(2)]
+        [t.start() for t in th]
+        [t.join(120) for t in th]
+        assert not any(t.is_alive() for t in th), "a rank hangs"
+        return list(out)
+    assert both(lambda r: comms[r].agree(0)) == [0, 0]
+    assert both(lambda r: comms[r].agree(3 * r)) == [3, 3]
+
+    def ctx_ok(r):
+        with gcyto.ExpressionContext(sc, st if r == 0 else None, False, 0, comm=comms[r], n_spots=st.shape[1]) as ctx:
+            return ctx.assign_chunks([(ix, subs[k]) for k, ix in enumerate(idx_sc)])
+    a, b = both(ctx_ok)
+    with gcyto.ExpressionContext(sc, st, False, 0) as local:
+        want = local.assign_chunks([(ix, subs[k]) for k, ix in enumerate(idx_sc)])
+    assert all(np.array_equal(x, y) and np.array_equal(x, z) for x, y, z in zip(a, b, want))
+
+    def ctx_bad_genes(r):       # rank 1's cells have one gene less than the root's matrices (same padding bucket of 32)
+        with gcyto.ExpressionContext(sc if r == 0 else sc[:-1], st if r == 0 else None, False, 0, comm=comms[r], n_spots=st.shape[1]):
+            return "built"
+    e0, e1 = both(ctx_bad_genes)
+    assert isinstance(e1, ValueError) and isinstance(e0, _lib.CytoHipError) and "status 9" in str(e0)
+    assert both(lambda r: comms[r].agree(0)) == [0, 0]            # the communicator is still usable: everybody left together
+
+    def one_aborts(r):
+        if r == 1:
+            comms[1].abort()
+            return "aborted"
+        return comms[0].agree(0)
+    r0, r1 = both(one_aborts)
+    assert r1 == "aborted" and isinstance(r0, _lib.CytoHipError) and "status 9" in str(r0)
+    for c in comms:
+        c.close()
+    # a worker that fails in its host code BEFORE the collective: the call raises that error, no thread is left waiting
+    with pytest.raises(ValueError):
+        gcyto.assign_chunks_on_devices(sc, st, d["ss_slots"], idx_sc + [np.array([10 ** 9])], subsampled_slots_list=subs + [subs[0]],
+                                       devices=[0, 0], already_normalized=False)
+    with pytest.raises(ValueError):
+        gcyto.visible_devices([0, 99])
+
+
+def test_one_process_distinct_devices_rccl_broadcast():
+    # the same seam on two REAL devices: ncclCommInitAll, ncclBroadcast of the ST operand over xGMI.  Needs two GPUs.
+    from cytospace_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    for mode in ("sc", "ss"):
+        sc_df, st_df, coords, slots, idx_sc, kw, want = _gv11_frames(mode)
+        loc, ids = gcyto.apply_linear_assignment(sc_df, st_df, coords, slots, "lapjv_hip", None, 1, "Pearson_correlation", 2,
+                                                 idx_sc, **kw)
+        got = {(int(c[1:]), int(r), int(k)) for c, (r, k) in zip(ids, loc.to_numpy())}
+        assert got == want
+    comms = _lib.Communicator.init_local([0, 1])
+    assert comms[0].kind() == "rccl" and comms[1].count() == 2
+    for c in comms:
+        c.close()
+
+
 @pytest.mark.parametrize("metric", ["Pearson_correlation", "Spearman_correlation", "Euclidean"])
 def test_expression_context_chunks_equal_per_chunk_uploads(metric):
     # multi-chunk seam: transform once + device-side column gathers == uploading and transforming every chunk

@@ -582,18 +582,17 @@ def test_wide_search_on_several_workgroups(groups):
 
 
 @pytest.mark.parametrize("waves", ["0", "1", "8", "32", "8-guess"])
-def test_row_cache_builders_agree(waves, monkeypatch):
-    # The full-chip cache build: build_row_caches_wave (a wave per row, guessed floor, one sweep; CYTO_CACHE_WAVES waves per CU -- with 1 a
-    # wave takes many rows and its guesses matter, with 32 most rows are a wave's first and take the lane-minima floor) or, with 0, the
-    # workgroup-per-row builders of rounds 1-3.  Which columns a cache holds is a matter of speed only: both solvers give the oracle's
-    # answers bit for bit with every builder -- on uniform, few-cell-type, tie-heavy (the floor search cannot separate: caches
-    # without entries) and duplicated-row instances, ragged sizes (n % 4 != 0, n < 64) included.
-    # ("8-guess": CYTO_CACHE_STREAM=0, a neighbouring row's floor as the guess and the lane minima's 35th as the fallback, instead of the
+def test_row_cache_builders_agree(waves):
+    # The full-chip cache build: build_row_caches_wave (a wave per row, guessed floor, one sweep; cyto_lap_opts.cache_waves waves per CU --
+    # with 1 a wave takes many rows and its guesses matter, with 32 most rows are a wave's first and take the lane-minima floor) or, with
+    # "0" (cache_waves = -1), the workgroup-per-row builders of rounds 1-3.  Which columns a cache holds is a matter of speed only: both
+    # solvers give the oracle's answers bit for bit with every builder -- on uniform, few-cell-type, tie-heavy (the floor search cannot
+    # separate: caches without entries) and duplicated-row instances, ragged sizes (n % 4 != 0, n < 64) included.
+    # ("8-guess": cache_stream = -1, a neighbouring row's floor as the guess and the lane minima's 35th as the fallback, instead of the
     #  guess-free streaming selection of rows of >= 2 048 columns)
-    monkeypatch.setenv("CYTO_CACHE_STREAM", "0" if waves.endswith("guess") else "1")
-    waves = waves.split("-")[0]
-    monkeypatch.setenv("CYTO_CACHE_WAVES", waves)
-    monkeypatch.setenv("CYTO_CACHE_UNROLL", "4" if waves == "1" else "8")
+    stream = -1 if waves.endswith("guess") else 1
+    waves = int(waves.split("-")[0])
+    bopts = dict(cache_waves=waves if waves > 0 else -1, cache_unroll=4 if waves == 1 else 8, cache_stream=stream)
     rng = np.random.default_rng(91)
     prof = rng.normal(size=(5, 48)).astype(np.float32)
     typed = -((prof[rng.integers(0, 5, 3001)] + 0.05 * rng.normal(size=(3001, 48)).astype(np.float32)) @
@@ -602,9 +601,9 @@ def test_row_cache_builders_agree(waves, monkeypatch):
              np.repeat(rng.random((250, 1250)), 5, axis=0).astype(np.float32), rng.random((37, 37)).astype(np.float32),
              rng.random((5, 5)).astype(np.float32)]
     for c in cases:
-        _check_wide(c)
+        _check_wide(c, opts=bopts)
         if c.shape[0] >= 5200 or c.shape[0] == 3001:             # (the chain solver builds caches from n = 5 121 on, and where forced)
-            _check(c, np.float32, opts=dict(augmentation=2) if c.shape[0] == 3001 else None)
+            _check(c, np.float32, opts=dict(bopts, augmentation=2) if c.shape[0] == 3001 else bopts)
 
 
 @pytest.mark.parametrize("rebuild", [0, 1, 3, -1])

@@ -106,7 +106,7 @@ def _wide_vs_golden(tag, n, solve, loc=None):
 @pytest.mark.parametrize("n", [20000, 33000, 50000, 70000])
 def test_wide_uniform_true_size(n):
     if not os.path.exists(os.path.join(GOLD, f"large_u{n}.npz")):
-        pytest.skip(f"large_u{n}.npz not generated")
+        pytest.fail(f"tests/golden/large_u{n}[_wide].npz is missing (a lost fixture must not silently drop this parity test)")
     buf = instances.blocks_to_device(instances.uniform_cost_blocks(n), n)
     try:
         g = _wide_vs_golden(f"u{n}", n, lambda: lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n))
@@ -120,7 +120,7 @@ def test_wide_cytolike_20000():
     count 1 -- the deep-search class CytoSPACE's chunks belong to (the classic oracle needs 40x the row scans of the uniform c2)."""
     n = 20000
     if not os.path.exists(os.path.join(GOLD, f"large_t{n}.npz")):
-        pytest.skip(f"large_t{n}.npz not generated")
+        pytest.fail(f"tests/golden/large_t{n}[_wide].npz is missing (a lost fixture must not silently drop this parity test)")
     cost = instances.typed_unique_cost(n, n, 20)[0]
     buf = _lib.DeviceBuffer.from_numpy(cost)
     del cost
@@ -153,7 +153,7 @@ def test_chain_uniform_70000_colsol_in_global_memory():
     """n > 65 535: the chain kernels with colsol in global memory too (chain_variant 3's range) at a true size, 19.6 GB of cost."""
     n = 70000
     if not os.path.exists(os.path.join(GOLD, f"large_u{n}.npz")):
-        pytest.skip(f"large_u{n}.npz not generated")
+        pytest.fail(f"tests/golden/large_u{n}[_wide].npz is missing (a lost fixture must not silently drop this parity test)")
     buf = instances.blocks_to_device(instances.uniform_cost_blocks(n), n)
     try:
         _compare_with_golden(f"u{n}", buf, n)
@@ -182,7 +182,7 @@ def test_float64_uniform_17000_warm_start():
     n = 17000
     path = os.path.join(GOLD, f"large_u{n}_f64_warm.npz")
     if not os.path.exists(path):
-        pytest.skip("large_u17000_f64_warm.npz not generated")
+        pytest.fail("tests/golden/large_u17000_f64_warm.npz is missing (a lost fixture must not silently drop this parity test)")
     d = np.load(path)
     c = instances.uniform_cost(n).astype(np.float64)
     c += np.random.default_rng(n).random((n, n)) * 2.0 ** -30

@@ -1,6 +1,6 @@
 """Row-cache build kernels side by side (developer tool): `cyto_lap_info.ms_cache` (HIP events around the build that follows the
 column reduction) for the wave-per-row builder at several (waves per CU, quads in flight) settings and for the workgroup-per-row
-builders (CYTO_CACHE_WAVES=0), on a uniform n x n matrix resident in HBM.  The solve's results must not depend on the builder:
+builders (cyto_lap_opts.cache_waves = -1), on a uniform n x n matrix resident in HBM.  The solve's results must not depend on the builder:
 rowsol/colsol/u/v and the counters of every setting are compared with the first one's.
 
     python tools/cache_build_bench.py 20000 50000 [--typed]
@@ -26,11 +26,10 @@ def main():
         buf = _lib.DeviceBuffer.from_numpy(c)
         ref = None
         for waves, unroll in SETTINGS:
-            os.environ["CYTO_CACHE_WAVES"] = waves
-            os.environ["CYTO_CACHE_UNROLL"] = unroll
+            o = dict(cache_waves=int(waves) if int(waves) > 0 else -1, cache_unroll=int(unroll))
             best = 1e9
             for rep in range(4):
-                r = lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n)
+                r = lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n, opts=o)
                 best = min(best, r["info"].ms_cache)
             i = r["info"]
             key = (r["rowsol"].tobytes(), r["colsol"].tobytes(), r["u"].tobytes(), r["v"].tobytes(), i.row_scans)
