@@ -446,8 +446,9 @@ def test_in_process_communicator_collectives_and_failing_together():
     assert r1 == "aborted" and isinstance(r0, _lib.CytoHipError) and "status 9" in str(r0)
     for c in comms:
         c.close()
-    # a worker that fails in its host code BEFORE the collective: the call raises that error, no thread is left waiting
-    with pytest.raises(ValueError):
+    # a worker that fails in its host code BEFORE the collective (a cell index outside the matrix: numpy's IndexError): the call
+    # raises that error, no thread is left waiting
+    with pytest.raises(IndexError):
         gcyto.assign_chunks_on_devices(sc, st, d["ss_slots"], idx_sc + [np.array([10 ** 9])], subsampled_slots_list=subs + [subs[0]],
                                        devices=[0, 0], already_normalized=False)
     with pytest.raises(ValueError):
