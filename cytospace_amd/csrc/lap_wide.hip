@@ -118,21 +118,18 @@ __device__ __forceinline__ float rdlane(float x, int l) { return __uint_as_float
 // wide_rt measures, and the state of the phase machine below (wide_sc_*).
 // ------------------------------------------------------------------------------------------------------------------
 enum { SC_LEGACY = 0, SC_EPS = 1, SC_FINAL = 2, SC_HANDOVER = 3, SC_DONE = 4 };   // modes (>= SC_HANDOVER: the machine is through)
-enum { SC_ACT_NONE = 0, SC_ACT_ROUND = 1, SC_ACT_RESET = 2 };                      // what a launch does
-// `fresh`: the list launch L reads was made by wide_sc_init (rows that have not bid yet); else its rows bid in launch L - 1
-struct ScSlot { int mode, k, rip, fresh, act; float eps; long long total, bids; };
-struct ScRound { int cnt, retired; };   // per launch (three cells in rotation: L % 3): rows that bid in it, how many of them retired
+enum { SC_ACT_NONE = 0, SC_ACT_ROUND = 1, SC_ACT_RESET = 2 };                      // what a launch pair does
+struct ScSlot { int mode, k, rip, cur, act; float eps; long long total, bids; };
 struct ScCtl {
     int hist[256];                 // rows per binary exponent (the exponent FIELD) of their gap u2 - u1 at the post-column-reduction prices
     uint32_t vmaxbits;             // bits of max_j |v0[j]|
     int e0;                        // exponent field of eps_0 (0: the instance never scales)
     float epsmin;                  // phases end below this eps (the resolution of the prices)
     int stop;                      // WIDE_STOP(n)
-    ScRound rnd[3];
-    int retired, dense, dense_mark, phases, free_cr;
-    int fin_buf, fin_cnt;          // where the machine stopped: the record buffer and the length of the list it leaves
-    unsigned long long wbase[2];   // per bid-word buffer: the launch at which it was last wiped (the words' 12-bit tag is relative to it)
-    ScSlot slot[2];                // launch L reads slot[L & 1] and leaves slot[(L + 1) & 1]
+    int cnt[2];                    // lengths of the two active lists
+    int retired, dense, dense_mark, phases, free_cr, pad_;
+    unsigned long long base;       // `total` when the bid words were last wiped (their 12-bit round tag is relative to it)
+    ScSlot slot[2];                // launch pair L reads slot[L & 1] and leaves slot[(L + 1) & 1]
 };
 static_assert(sizeof(ScCtl) <= 2048, "control block of the row-reduction phase");
 // the constants of the restatement (oracle/jv_oracle.h: JV_WIDE_*)
@@ -374,29 +371,20 @@ template <bool VLDS, bool CLDS> struct ArrCtx {
 //            gap + eps_k) until the list is down to wide_stop(n) rows -- the sequential tail of a phase is cut, the next phase
 //            takes every row up again.  eps_0 = 2^SC_EMULT x the median binade of the rows' gaps at the post-column-reduction prices.
 //   FINAL    the same with eps = 0 and the claim / retire rules: what it leaves free goes to the searches.
-// A round is ONE launch over all CUs (wide_sc_round).  Launch L does, a wave per row that bid in launch L - 1: the RESOLUTION of that
-// row's bid -- did it win its column (the column's bid word)?  then price, owner, displaced owner are written to the arrays -- and at
-// once the BID of the row that takes its place in the next round (the row itself if it lost, the owner it displaced if it won): no
-// list is built in between, the wave that knows the outcome makes the next bid.  So the arrays (v, colsol) run ONE ROUND LATE while a
-// launch is under way -- a column that received a bid in launch L - 1 has its new price and owner in its bid word (the winner's), and
-// that is where the bids of launch L read them (word of launch L - 1 -> fresh; else the arrays, complete through launch L - 2);
-// bid words are double-buffered by the launch's parity (launch L reads buffer (L - 1) & 1 and merges into buffer L & 1).  Full-row
-// bids read the arrays and, through a bitmap of the columns bid for in launch L - 1 (three bitmaps in rotation), the fresh words.
-// The bids of launch L are SPECULATIVE: whether the round they belong to takes place at all (or the phase ended with the list
-// launch L - 1 left: its length is known only when that launch is over) is what launch L + 1 decides, from the same pure function of
-// (state, list length) as the oracle -- if not, the bids are dropped: a bid changes nothing but bid words, records and counters kept
-// per launch.  A phase boundary is a launch too: everything unassigned, and every row bids (nothing to resolve, no owners).
-// The driver enqueues launches in groups and learns after each group who is through, one group late (the next group is queued
-// before it asks: the chip never waits for the host; launches of a machine that is through return at once).
-// The bid word of a column: | 12 bits ~(launch - base) | 32 bits ordered price | 20 bits row |, merged with an atomic min: within a
-// launch the lowest (price, row) wins, and ANY bid of a later launch beats what earlier ones left behind -- the words are never reset
-// between rounds; wide_sc_wipe (every 2048 launches per buffer) resets them and moves the buffer's `base`.
+// A round is two launches over all CUs -- bids (a wave per active row, prices and owners read from L2), resolution (a thread per
+// bid); a phase boundary is one such pair too (everything unassigned, the list = every row).  The driver enqueues pairs in groups and
+// asks after each group who is through.  Launch pair L reads the state in slot[L & 1]; every workgroup of its first kernel derives
+// the same step from it (a pure function of the slot and the list length), workgroup 0 leaves the next state in slot[(L + 1) & 1].
+// The bid word of a column: | 12 bits ~(round - base) | 32 bits ordered price | 20 bits row |, merged with an atomic min: within a
+// round the lowest (price, row) wins, and ANY bid of a later round beats what earlier rounds left behind -- the words are never reset
+// between rounds; wide_sc_wipe (every 2048 pairs) resets them and moves `base`.
 constexpr int HEADB = 256;             // threads of the machine's workgroups
 // ---- the machine's bids.  A row whose cache certifies its top-2 is one wave's work (the chain of a bid is L2 round trips: what
 // counts is how many bids are in flight, so a wave per bid while the chip has room).  A row whose cache cannot certify is read in
 // full -- by the WHOLE workgroup, after the wave's certified bids of the iteration: one wave sweeping an 80 KB row three times
 // (wide_arr's top2_full) is 170 us, and the round waits for its slowest bid.  Prices and owners do not change while the bids of
 // a round are made (the resolution is the next launch): plain loads, 16 bytes of the row and of the prices per lane and step.
+struct Top2 { float u1, c1, vj1, u2, c2, vj2; int j1, j2; };
 struct ScShared {
     int nq, cnt, fill_;
     uint32_t cand;
@@ -408,30 +396,12 @@ struct ScShared {
 };
 constexpr size_t SC_SHARED_BYTES = (sizeof(ScShared) + 15) / 16 * 16;
 
-// Where a launch's bids read prices and owners: the bid words of the launch before (fresh: that column's winner) or the arrays.
-struct ScView {
-    const unsigned long long *wsrc;   // bid words of launch L - 1 (null: none -- the first launch, a phase boundary)
-    const uint32_t *bm;               // bitmap of the columns bid for in launch L - 1 (full-row sweeps; null with wsrc)
-    uint32_t tg;                      // tag of launch L - 1 in those words
-    bool own_none;                    // a phase boundary: every column is unassigned (the arrays are being cleared by this very launch)
-};
-__device__ __forceinline__ bool sc_word_fresh(const ScView &vw, unsigned long long w) {
-    return (uint32_t)(w >> 52) == vw.tg && ((uint32_t)w & 0xFFFFFu) != 0xFFFFFu;
-}
-__device__ __forceinline__ float sc_word_price(unsigned long long w) { return ord2f((uint32_t)(w >> 20)); }
-// price and owner of column c as of the end of launch L - 1 (a dependent word load only where there is a word to ask)
-__device__ __forceinline__ void sc_price_owner(const WideArgs &a, const ScView &vw, int c, float &p, int &o) {
-    p = a.v[c]; o = vw.own_none ? -1 : a.colsol[c];
-    if (vw.wsrc) { const unsigned long long w = vw.wsrc[c]; if (sc_word_fresh(vw, w)) { p = sc_word_price(w); o = (int)((uint32_t)w & 0xFFFFFu); } }
-}
-
 // the decision of a bid from its row's lexicographic top-2 (oracle: JV_WIDE_ROUND): target column (-1: the row retires), price, raw cost
-// of the entry, the owner it would displace (o1 / o2: the owners of the two columns).  eps > 0 (a scaled phase): every bid lowers its
-// column's price by the gap + eps, by one ulp at least -- no claims, nobody retires
-struct Top2 { float u1, c1, vj1, u2, c2, vj2; int j1, j2, o1, o2; };
-__device__ __forceinline__ void sc_decide(const Top2 &t, float eps, int &jt, float &pt, float &ct, int &i0) {
+// of the entry, the owner it would displace.  eps > 0 (a scaled phase): every bid lowers its column's price by the gap + eps, by one
+// ulp at least -- no claims, nobody retires
+__device__ __forceinline__ void sc_decide(const WideArgs &a, const Top2 &t, float eps, int &jt, float &pt, float &ct, int &i0) {
     jt = -1; pt = 0.0f; ct = 0.0f; i0 = -1;
-    const int o1 = t.o1;
+    const int o1 = uni(a.colsol[t.j1]);
     if (eps > 0.0f) {
         float p = t.vj1 - ((t.u2 - t.u1) + eps);
         if (!(p < t.vj1)) p = pred_f32(t.vj1);
@@ -440,21 +410,15 @@ __device__ __forceinline__ void sc_decide(const Top2 &t, float eps, int &jt, flo
         const float p = t.vj1 - (t.u2 - t.u1);
         if (p < t.vj1) { jt = t.j1; pt = p; ct = t.c1; i0 = o1; }
         else if (o1 < 0) { jt = t.j1; pt = t.vj1; ct = t.c1; }
-        else if (t.j2 >= 0 && t.u2 == t.u1 && t.o2 < 0) { jt = t.j2; pt = t.vj2; ct = t.c2; }
+        else if (t.j2 >= 0 && t.u2 == t.u1 && uni(a.colsol[t.j2]) < 0) { jt = t.j2; pt = t.vj2; ct = t.c2; }
     }
     jt = uni(jt); pt = uni(pt); ct = uni(ct); i0 = uni(i0);
 }
-// one wave: the top-2 from the row's cache (lane = entry); false: the cache cannot certify it.  Prices, fresh words and owners of
-// the 63 cached columns are requested together (one round trip).
-__device__ __forceinline__ bool sc_top2_cached(const WideArgs &a, const ScView &vw, int lane, uint32_t col, float val, Top2 &t) {
+// one wave: the top-2 from the row's cache (lane = entry); false: the cache cannot certify it
+__device__ __forceinline__ bool sc_top2_cached(const WideArgs &a, int lane, uint32_t col, float val, Top2 &t) {
     const float tau = rdlane(val, KCU);
     const bool valid = lane < KCU && col != COLSENT;
-    float vj = valid ? a.v[col] : 0.0f;
-    int ow = (valid && !vw.own_none) ? a.colsol[col] : -1;
-    if (vw.wsrc) {
-        const unsigned long long w = valid ? vw.wsrc[col] : ~0ull;
-        if (sc_word_fresh(vw, w)) { vj = sc_word_price(w); ow = (int)((uint32_t)w & 0xFFFFFu); }
-    }
+    const float vj = valid ? a.v[col] : 0.0f;
     const uint32_t key = valid ? f2ord(val - vj) : 0xFFFFFFFFu;
     const uint32_t k1 = wave_min_u32(key);
     const int l1 = __ffsll((unsigned long long)__ballot(key == k1)) - 1;
@@ -462,35 +426,27 @@ __device__ __forceinline__ bool sc_top2_cached(const WideArgs &a, const ScView &
     const uint32_t k2 = wave_min_u32(key2);
     if (!(k2 != 0xFFFFFFFFu && ord2f(k2) < tau)) return false;
     const int l2 = __ffsll((unsigned long long)__ballot(key2 == k2)) - 1;
-    t.u1 = ord2f(k1); t.j1 = (int)rdlane(col, l1); t.c1 = rdlane(val, l1); t.vj1 = rdlane(vj, l1); t.o1 = (int)rdlane((uint32_t)ow, l1);
-    t.u2 = ord2f(k2); t.j2 = (int)rdlane(col, l2); t.c2 = rdlane(val, l2); t.vj2 = rdlane(vj, l2); t.o2 = (int)rdlane((uint32_t)ow, l2);
+    t.u1 = ord2f(k1); t.j1 = (int)rdlane(col, l1); t.c1 = rdlane(val, l1); t.vj1 = rdlane(vj, l1);
+    t.u2 = ord2f(k2); t.j2 = (int)rdlane(col, l2); t.c2 = rdlane(val, l2); t.vj2 = rdlane(vj, l2);
     return true;
 }
-// the whole workgroup (HEADB threads): f(column, cost, price) for every column of the row, 16 bytes of row and prices per lane and step;
-// a column flagged in the view's bitmap (it received a bid in the launch before) takes its price from its fresh bid word
-template <int U, typename F> __device__ __forceinline__ void block_row_sweep(const float *__restrict__ row, const float *__restrict__ v, const ScView &vw, int n, F &&f) {
+// the whole workgroup (HEADB threads): f(column, cost, price) for every column of the row, 16 bytes of row and prices per lane and step
+template <int U, typename F> __device__ __forceinline__ void block_row_sweep(const float *__restrict__ row, const float *__restrict__ v, int n, F &&f) {
     const int nq = (n + 3) >> 2;
     const float4 *__restrict__ r4 = reinterpret_cast<const float4 *>(row);
     const float4 *__restrict__ v4 = reinterpret_cast<const float4 *>(v);      // (16-byte aligned, followed by u in the workspace: whole quads stay in range)
     for (int q0 = threadIdx.x; q0 < nq; q0 += HEADB * U) {
         float4 x[U], p[U];
-        uint32_t fl[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int q = q0 + HEADB * u;
             x[u] = q < nq ? r4[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             p[u] = q < nq ? v4[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            fl[u] = (vw.bm && q < nq) ? ((vw.bm[q >> 3] >> ((q & 7) * 4)) & 0xFu) : 0u;       // the quad's four bits
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int q = q0 + HEADB * u, c = q * 4;
             if (q >= nq) continue;
-            if (fl[u]) {                                                          // (rare: a few hundred columns of the row at most)
-                float *pp = reinterpret_cast<float *>(&p[u]);
-                for (int e = 0; e < 4; e++)
-                    if (((fl[u] >> e) & 1u) && c + e < n) { const unsigned long long w = vw.wsrc[c + e]; if (sc_word_fresh(vw, w)) pp[e] = sc_word_price(w); }
-            }
             f(c, x[u].x, p[u].x);
             if (c + 1 < n) f(c + 1, x[u].y, p[u].y);
             if (c + 2 < n) f(c + 2, x[u].z, p[u].z);
@@ -502,11 +458,11 @@ template <int U, typename F> __device__ __forceinline__ void block_row_sweep(con
 // minima of the columns c with (c / 4) % 64 == l, sorted: the 35th, else the 17th, 8th ... smallest; the columns below it are collected in
 // a second sweep of the now L2-resident row; more than 63 of them -> the next candidate).  Every thread returns the same Top2.
 template <int U>
-__device__ __forceinline__ Top2 sc_top2_block(const WideArgs &a, const ScView &vw, ScShared &ss, int i, bool rebuild) {
+__device__ __forceinline__ Top2 sc_top2_block(const WideArgs &a, ScShared &ss, int i, bool rebuild) {
     const int n = a.n, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float *__restrict__ row = a.cost + wrow_off(a.rowmap, i, a.ld);
     K2 d; d.m1 = KEYMAX; d.m2 = KEYMAX;
-    block_row_sweep<U>(row, a.v, vw, n, [&](int c, float x, float vc) { k2_push(d, mkkey(x - vc, (uint32_t)c)); });
+    block_row_sweep<U>(row, a.v, n, [&](int c, float x, float vc) { k2_push(d, mkkey(x - vc, (uint32_t)c)); });
     const uint32_t my_min = (uint32_t)(d.m1 >> 32);              // the smallest reduced cost among THIS thread's columns (ordered)
     ss.lmin[tid] = my_min;
     d = k2_wave_allreduce(d);
@@ -516,9 +472,9 @@ __device__ __forceinline__ Top2 sc_top2_block(const WideArgs &a, const ScView &v
 #pragma unroll
     for (int k = 1; k < HEADB / 64; k++) { K2 o; o.m1 = ss.km1[k]; o.m2 = ss.km2[k]; k2_merge(g, o); }
     Top2 t;
-    t.u1 = key_val(g.m1); t.j1 = (int)(uint32_t)g.m1; t.c1 = row[t.j1]; sc_price_owner(a, vw, t.j1, t.vj1, t.o1);
-    t.u2 = INFINITY; t.j2 = -1; t.c2 = 0.0f; t.vj2 = 0.0f; t.o2 = -1;
-    if (g.m2 != KEYMAX) { t.u2 = key_val(g.m2); t.j2 = (int)(uint32_t)g.m2; t.c2 = row[t.j2]; sc_price_owner(a, vw, t.j2, t.vj2, t.o2); }
+    t.u1 = key_val(g.m1); t.j1 = (int)(uint32_t)g.m1; t.c1 = row[t.j1]; t.vj1 = a.v[t.j1];
+    t.u2 = INFINITY; t.j2 = -1; t.c2 = 0.0f; t.vj2 = 0.0f;
+    if (g.m2 != KEYMAX) { t.u2 = key_val(g.m2); t.j2 = (int)(uint32_t)g.m2; t.c2 = row[t.j2]; t.vj2 = a.v[t.j2]; }
     if (!rebuild) { __syncthreads(); return t; }                   // (the staging words are free again for the next row)
     // ---- the row's new cache ----
     uint32_t lm = 0xFFFFFFFFu;
@@ -542,7 +498,7 @@ __device__ __forceinline__ Top2 sc_top2_block(const WideArgs &a, const ScView &v
         __syncthreads();
         const uint32_t cand = ss.cand;
         if (cand != 0xFFFFFFFFu && my_min < cand)                    // (a thread none of whose columns lies below the candidate reads nothing: ~4 of 5)
-            block_row_sweep<U>(row, a.v, vw, n, [&](int c, float x, float vc) {
+            block_row_sweep<U>(row, a.v, n, [&](int c, float x, float vc) {
                 if (f2ord(x - vc) < cand) {
                     const int p = atomicAdd(&ss.cnt, 1);
                     if (p < KCU) { ss.ccol[p] = (uint32_t)c; ss.cval[p] = x; }
