@@ -3395,7 +3395,8 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             const size_t parb = parg > 0 ? wide_par_state_bytes(n, parg) : 0;
             const size_t sc_off = ((2 * nT + 255) / 256) * 256 + mcb;       // the phase machine's control block behind everything else
             const size_t par_off = sc_off + WIDE_SC_BYTES;
-            if ((rc = j.b_wide.alloc(par_off + parb, stream))) return rc;
+            const size_t scx_off = ((par_off + parb + 255) / 256) * 256;     // the machine's own arrays (lap_wide.hip: ScMem)
+            if ((rc = j.b_wide.alloc(scx_off + wide_sc_ext_bytes(n), stream))) return rc;
             const Chain2Args &c = j.c2;
             WideArgs &wa = h_wa[k];
             wa.n = n; wa.ld = c.ld; wa.cost = c.cost; wa.rowmap = c.rowmap;
@@ -3421,6 +3422,9 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             wa.same_prev = (j.h_ngroups < n && n >= 2) ? j.b_same.as<int32_t>() : nullptr;
             wa.sc = j.b_wide.as<char>() + sc_off;
             CYTO_HIP(hipMemsetAsync(wa.sc, 0, WIDE_SC_BYTES, stream));
+            wa.scx = j.b_wide.as<char>() + scx_off;
+            CYTO_HIP(hipMemsetAsync(wa.scx, 0, wide_sc_ext_bytes(n), stream));
+            CYTO_HIP(hipMemsetAsync(wa.scx, 0xFF, (((size_t)n + 63) & ~(size_t)63) * 8, stream));     // (the second buffer of bid words)
             wa.par_groups = parg; wa.par = nullptr;
             if (parg > 0) {
                 const size_t np_ = ((size_t)n + 63) & ~(size_t)63;

@@ -21,6 +21,8 @@ namespace cyto {
 //   seg_sync        shared by the launch, or null: [0] workgroups that asked for fresh caches (zeroed by the driver before every launch
 //                   of wide_arr / wide_aug), [1 + b] wide_arr: 1 = problem b's rounds paused; wide_aug: searches problem b still has to run
 //   sc              2 KB, zeroed by the driver: the control block of the row-reduction phase machine (lap_wide.hip: ScCtl)
+//   scx             the phase machine's own arrays (wide_sc_ext_bytes(n), 256-byte aligned; second word buffer all-ones, the rest zero):
+//                   lap_wide.hip: ScMem
 //   par_groups, par searches of one problem that run at once on as many workgroups (0 / 1: one at a time) and their state (lap_wide.hip: ParCtl)
 //   arr_waste       wide_arr: full-row bids (with their cache refresh) of one launch after which the list rounds pause (aug_seg == 0)
 //   aug_seg         when a launch of wide_aug returns to the driver for fresh row caches: -1 never, k > 0 after k searches, 0 when
@@ -36,7 +38,7 @@ namespace cyto {
     P(float, slot_c) P(uint32_t, cache_col) P(float, cache_val) P(char, misc) S(long long, max_rounds)                     \
     P(unsigned long long, gbmin) P(uint32_t, gdirty) P(uint32_t, gasg) P(uint32_t, gdense) P(char, ctl) S(int, mc_groups)  \
     P(const int32_t, same_prev) P(int32_t, seg_sync) S(int, aug_seg) S(int, aug_waste) S(int, arr_waste) S(int, seg_quorum)   \
-    P(char, sc) S(int, par_groups) P(char, par)
+    P(char, sc) S(int, par_groups) P(char, par) P(char, scx)
 #define WIDE_F_PTR(T, name) T *name;
 #define WIDE_F_VAL(T, name) T name;
 struct WideArgs { WIDE_FIELDS(WIDE_F_PTR, WIDE_F_VAL) };
@@ -46,6 +48,7 @@ enum { WC_ROUNDS = 0, WC_BIDS, WC_RETIRED, WC_ACTIVE_LEFT, WC_FREE_ARR, WC_DENSE
        WC_TRIVIAL, WC_VERIFY_PASSES, WC_AUG_LAUNCHES, WC_N };
 
 constexpr size_t WIDE_SC_BYTES = 2048;
+size_t wide_sc_ext_bytes(int n);
 size_t wide_aug_lds_bytes(int n);
 // phases, each one launch for the whole batch (d_args: device array of nb WideArgs)
 int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream);        // Jacobi reduction transfer (v0 snapshot in cassign)

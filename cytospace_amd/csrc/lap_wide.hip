@@ -11,9 +11,11 @@
 //              histogram of the rows' gaps u2 - u1 -- for the eps schedule.  A wave per row, full chip.
 //   wide_sc_*  AUGMENTING ROW REDUCTION as Jacobi rounds of an auction, eps-SCALED where the instance has generic costs: eight
 //              eps = 0 rounds, then up to 16 phases eps_0 / 2^k (every row unassigned at a phase's start, prices kept, the phase's
-//              sequential tail cut), then a final eps = 0 phase.  The phase machine: every round two launches over the whole chip
-//              (bids: a wave per active row; resolution: a thread per bid), the state in a control block per problem, so a batch's
-//              problems run through their phases independently in the same launches.  A round is a pure function of the state.
+//              sequential tail cut), then a final eps = 0 phase.  The phase machine: every round ONE launch over the whole chip (a wave
+//              per bid of the round before: it resolves that bid and bids at once for the row that takes its place; prices and owners
+//              of the columns just bid for are read from their bid words, the arrays run one round late), the state in a control
+//              block per problem, so a batch's problems run through their phases independently in the same launches.  A round is a
+//              pure function of the state.
 //   wide_arr   the chain rounds (<= 64 active rows) of instances that did not scale -- one 16-wave workgroup per problem, the
 //              rows in registers, bids meeting in LDS -- and every problem's list of free rows for the searches.
 //   wide_aug   AUGMENTATION: per free row a shortest-path search whose labels are the unique fixed point of a monotone
@@ -118,18 +120,21 @@ __device__ __forceinline__ float rdlane(float x, int l) { return __uint_as_float
 // wide_rt measures, and the state of the phase machine below (wide_sc_*).
 // ------------------------------------------------------------------------------------------------------------------
 enum { SC_LEGACY = 0, SC_EPS = 1, SC_FINAL = 2, SC_HANDOVER = 3, SC_DONE = 4 };   // modes (>= SC_HANDOVER: the machine is through)
-enum { SC_ACT_NONE = 0, SC_ACT_ROUND = 1, SC_ACT_RESET = 2 };                      // what a launch pair does
-struct ScSlot { int mode, k, rip, cur, act; float eps; long long total, bids; };
+enum { SC_ACT_NONE = 0, SC_ACT_ROUND = 1, SC_ACT_RESET = 2 };                      // what a launch does
+// `fresh`: the list launch L reads was made by wide_sc_init (rows that have not bid yet); else its rows bid in launch L - 1
+struct ScSlot { int mode, k, rip, fresh, act; float eps; long long total, bids; };
+struct ScRound { int cnt, retired; };   // per launch (three cells in rotation: L % 3): rows that bid in it, how many of them retired
 struct ScCtl {
     int hist[256];                 // rows per binary exponent (the exponent FIELD) of their gap u2 - u1 at the post-column-reduction prices
     uint32_t vmaxbits;             // bits of max_j |v0[j]|
     int e0;                        // exponent field of eps_0 (0: the instance never scales)
     float epsmin;                  // phases end below this eps (the resolution of the prices)
     int stop;                      // WIDE_STOP(n)
-    int cnt[2];                    // lengths of the two active lists
-    int retired, dense, dense_mark, phases, free_cr, pad_;
-    unsigned long long base;       // `total` when the bid words were last wiped (their 12-bit round tag is relative to it)
-    ScSlot slot[2];                // launch pair L reads slot[L & 1] and leaves slot[(L + 1) & 1]
+    ScRound rnd[3];
+    int retired, dense, dense_mark, phases, free_cr;
+    int fin_buf, fin_cnt;          // where the machine stopped: the record buffer and the length of the list it leaves
+    unsigned long long wbase[2];   // per bid-word buffer: the launch at which it was last wiped (the words' 12-bit tag is relative to it)
+    ScSlot slot[2];                // launch L reads slot[L & 1] and leaves slot[(L + 1) & 1]
 };
 static_assert(sizeof(ScCtl) <= 2048, "control block of the row-reduction phase");
 // the constants of the restatement (oracle/jv_oracle.h: JV_WIDE_*)
@@ -371,20 +376,29 @@ template <bool VLDS, bool CLDS> struct ArrCtx {
 //            gap + eps_k) until the list is down to wide_stop(n) rows -- the sequential tail of a phase is cut, the next phase
 //            takes every row up again.  eps_0 = 2^SC_EMULT x the median binade of the rows' gaps at the post-column-reduction prices.
 //   FINAL    the same with eps = 0 and the claim / retire rules: what it leaves free goes to the searches.
-// A round is two launches over all CUs -- bids (a wave per active row, prices and owners read from L2), resolution (a thread per
-// bid); a phase boundary is one such pair too (everything unassigned, the list = every row).  The driver enqueues pairs in groups and
-// asks after each group who is through.  Launch pair L reads the state in slot[L & 1]; every workgroup of its first kernel derives
-// the same step from it (a pure function of the slot and the list length), workgroup 0 leaves the next state in slot[(L + 1) & 1].
-// The bid word of a column: | 12 bits ~(round - base) | 32 bits ordered price | 20 bits row |, merged with an atomic min: within a
-// round the lowest (price, row) wins, and ANY bid of a later round beats what earlier rounds left behind -- the words are never reset
-// between rounds; wide_sc_wipe (every 2048 pairs) resets them and moves `base`.
+// A round is ONE launch over all CUs (wide_sc_round).  Launch L does, a wave per row that bid in launch L - 1: the RESOLUTION of that
+// row's bid -- did it win its column (the column's bid word)?  then price, owner, displaced owner are written to the arrays -- and at
+// once the BID of the row that takes its place in the next round (the row itself if it lost, the owner it displaced if it won): no
+// list is built in between, the wave that knows the outcome makes the next bid.  So the arrays (v, colsol) run ONE ROUND LATE while a
+// launch is under way -- a column that received a bid in launch L - 1 has its new price and owner in its bid word (the winner's), and
+// that is where the bids of launch L read them (word of launch L - 1 -> fresh; else the arrays, complete through launch L - 2);
+// bid words are double-buffered by the launch's parity (launch L reads buffer (L - 1) & 1 and merges into buffer L & 1).  Full-row
+// bids read the arrays and, through a bitmap of the columns bid for in launch L - 1 (three bitmaps in rotation), the fresh words.
+// The bids of launch L are SPECULATIVE: whether the round they belong to takes place at all (or the phase ended with the list
+// launch L - 1 left: its length is known only when that launch is over) is what launch L + 1 decides, from the same pure function of
+// (state, list length) as the oracle -- if not, the bids are dropped: a bid changes nothing but bid words, records and counters kept
+// per launch.  A phase boundary is a launch too: everything unassigned, and every row bids (nothing to resolve, no owners).
+// The driver enqueues launches in groups and learns after each group who is through, one group late (the next group is queued
+// before it asks: the chip never waits for the host; launches of a machine that is through return at once).
+// The bid word of a column: | 12 bits ~(launch - base) | 32 bits ordered price | 20 bits row |, merged with an atomic min: within a
+// launch the lowest (price, row) wins, and ANY bid of a later launch beats what earlier ones left behind -- the words are never reset
+// between rounds; wide_sc_wipe (every 2048 launches per buffer) resets them and moves the buffer's `base`.
 constexpr int HEADB = 256;             // threads of the machine's workgroups
 // ---- the machine's bids.  A row whose cache certifies its top-2 is one wave's work (the chain of a bid is L2 round trips: what
 // counts is how many bids are in flight, so a wave per bid while the chip has room).  A row whose cache cannot certify is read in
 // full -- by the WHOLE workgroup, after the wave's certified bids of the iteration: one wave sweeping an 80 KB row three times
 // (wide_arr's top2_full) is 170 us, and the round waits for its slowest bid.  Prices and owners do not change while the bids of
 // a round are made (the resolution is the next launch): plain loads, 16 bytes of the row and of the prices per lane and step.
-struct Top2 { float u1, c1, vj1, u2, c2, vj2; int j1, j2; };
 struct ScShared {
     int nq, cnt, fill_;
     uint32_t cand;
@@ -396,12 +410,30 @@ struct ScShared {
 };
 constexpr size_t SC_SHARED_BYTES = (sizeof(ScShared) + 15) / 16 * 16;
 
+// Where a launch's bids read prices and owners: the bid words of the launch before (fresh: that column's winner) or the arrays.
+struct ScView {
+    const unsigned long long *wsrc;   // bid words of launch L - 1 (null: none -- the first launch, a phase boundary)
+    const uint32_t *bm;               // bitmap of the columns bid for in launch L - 1 (full-row sweeps; null with wsrc)
+    uint32_t tg;                      // tag of launch L - 1 in those words
+    bool own_none;                    // a phase boundary: every column is unassigned (the arrays are being cleared by this very launch)
+};
+__device__ __forceinline__ bool sc_word_fresh(const ScView &vw, unsigned long long w) {
+    return (uint32_t)(w >> 52) == vw.tg && ((uint32_t)w & 0xFFFFFu) != 0xFFFFFu;
+}
+__device__ __forceinline__ float sc_word_price(unsigned long long w) { return ord2f((uint32_t)(w >> 20)); }
+// price and owner of column c as of the end of launch L - 1 (a dependent word load only where there is a word to ask)
+__device__ __forceinline__ void sc_price_owner(const WideArgs &a, const ScView &vw, int c, float &p, int &o) {
+    p = a.v[c]; o = vw.own_none ? -1 : a.colsol[c];
+    if (vw.wsrc) { const unsigned long long w = vw.wsrc[c]; if (sc_word_fresh(vw, w)) { p = sc_word_price(w); o = (int)((uint32_t)w & 0xFFFFFu); } }
+}
+
 // the decision of a bid from its row's lexicographic top-2 (oracle: JV_WIDE_ROUND): target column (-1: the row retires), price, raw cost
-// of the entry, the owner it would displace.  eps > 0 (a scaled phase): every bid lowers its column's price by the gap + eps, by one
-// ulp at least -- no claims, nobody retires
-__device__ __forceinline__ void sc_decide(const WideArgs &a, const Top2 &t, float eps, int &jt, float &pt, float &ct, int &i0) {
+// of the entry, the owner it would displace (o1 / o2: the owners of the two columns).  eps > 0 (a scaled phase): every bid lowers its
+// column's price by the gap + eps, by one ulp at least -- no claims, nobody retires
+struct Top2 { float u1, c1, vj1, u2, c2, vj2; int j1, j2, o1, o2; };
+__device__ __forceinline__ void sc_decide(const Top2 &t, float eps, int &jt, float &pt, float &ct, int &i0) {
     jt = -1; pt = 0.0f; ct = 0.0f; i0 = -1;
-    const int o1 = uni(a.colsol[t.j1]);
+    const int o1 = t.o1;
     if (eps > 0.0f) {
         float p = t.vj1 - ((t.u2 - t.u1) + eps);
         if (!(p < t.vj1)) p = pred_f32(t.vj1);
@@ -410,15 +442,21 @@ __device__ __forceinline__ void sc_decide(const WideArgs &a, const Top2 &t, floa
         const float p = t.vj1 - (t.u2 - t.u1);
         if (p < t.vj1) { jt = t.j1; pt = p; ct = t.c1; i0 = o1; }
         else if (o1 < 0) { jt = t.j1; pt = t.vj1; ct = t.c1; }
-        else if (t.j2 >= 0 && t.u2 == t.u1 && uni(a.colsol[t.j2]) < 0) { jt = t.j2; pt = t.vj2; ct = t.c2; }
+        else if (t.j2 >= 0 && t.u2 == t.u1 && t.o2 < 0) { jt = t.j2; pt = t.vj2; ct = t.c2; }
     }
     jt = uni(jt); pt = uni(pt); ct = uni(ct); i0 = uni(i0);
 }
-// one wave: the top-2 from the row's cache (lane = entry); false: the cache cannot certify it
-__device__ __forceinline__ bool sc_top2_cached(const WideArgs &a, int lane, uint32_t col, float val, Top2 &t) {
+// one wave: the top-2 from the row's cache (lane = entry); false: the cache cannot certify it.  Prices, fresh words and owners of
+// the 63 cached columns are requested together (one round trip).
+__device__ __forceinline__ bool sc_top2_cached(const WideArgs &a, const ScView &vw, int lane, uint32_t col, float val, Top2 &t) {
     const float tau = rdlane(val, KCU);
     const bool valid = lane < KCU && col != COLSENT;
-    const float vj = valid ? a.v[col] : 0.0f;
+    float vj = valid ? a.v[col] : 0.0f;
+    int ow = (valid && !vw.own_none) ? a.colsol[col] : -1;
+    if (vw.wsrc) {
+        const unsigned long long w = valid ? vw.wsrc[col] : ~0ull;
+        if (sc_word_fresh(vw, w)) { vj = sc_word_price(w); ow = (int)((uint32_t)w & 0xFFFFFu); }
+    }
     const uint32_t key = valid ? f2ord(val - vj) : 0xFFFFFFFFu;
     const uint32_t k1 = wave_min_u32(key);
     const int l1 = __ffsll((unsigned long long)__ballot(key == k1)) - 1;
@@ -426,27 +464,35 @@ __device__ __forceinline__ bool sc_top2_cached(const WideArgs &a, int lane, uint
     const uint32_t k2 = wave_min_u32(key2);
     if (!(k2 != 0xFFFFFFFFu && ord2f(k2) < tau)) return false;
     const int l2 = __ffsll((unsigned long long)__ballot(key2 == k2)) - 1;
-    t.u1 = ord2f(k1); t.j1 = (int)rdlane(col, l1); t.c1 = rdlane(val, l1); t.vj1 = rdlane(vj, l1);
-    t.u2 = ord2f(k2); t.j2 = (int)rdlane(col, l2); t.c2 = rdlane(val, l2); t.vj2 = rdlane(vj, l2);
+    t.u1 = ord2f(k1); t.j1 = (int)rdlane(col, l1); t.c1 = rdlane(val, l1); t.vj1 = rdlane(vj, l1); t.o1 = (int)rdlane((uint32_t)ow, l1);
+    t.u2 = ord2f(k2); t.j2 = (int)rdlane(col, l2); t.c2 = rdlane(val, l2); t.vj2 = rdlane(vj, l2); t.o2 = (int)rdlane((uint32_t)ow, l2);
     return true;
 }
-// the whole workgroup (HEADB threads): f(column, cost, price) for every column of the row, 16 bytes of row and prices per lane and step
-template <int U, typename F> __device__ __forceinline__ void block_row_sweep(const float *__restrict__ row, const float *__restrict__ v, int n, F &&f) {
+// the whole workgroup (HEADB threads): f(column, cost, price) for every column of the row, 16 bytes of row and prices per lane and step;
+// a column flagged in the view's bitmap (it received a bid in the launch before) takes its price from its fresh bid word
+template <int U, typename F> __device__ __forceinline__ void block_row_sweep(const float *__restrict__ row, const float *__restrict__ v, const ScView &vw, int n, F &&f) {
     const int nq = (n + 3) >> 2;
     const float4 *__restrict__ r4 = reinterpret_cast<const float4 *>(row);
     const float4 *__restrict__ v4 = reinterpret_cast<const float4 *>(v);      // (16-byte aligned, followed by u in the workspace: whole quads stay in range)
     for (int q0 = threadIdx.x; q0 < nq; q0 += HEADB * U) {
         float4 x[U], p[U];
+        uint32_t fl[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int q = q0 + HEADB * u;
             x[u] = q < nq ? r4[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             p[u] = q < nq ? v4[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            fl[u] = (vw.bm && q < nq) ? ((vw.bm[q >> 3] >> ((q & 7) * 4)) & 0xFu) : 0u;       // the quad's four bits
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int q = q0 + HEADB * u, c = q * 4;
             if (q >= nq) continue;
+            if (fl[u]) {                                                          // (rare: a few hundred columns of the row at most)
+                float *pp = reinterpret_cast<float *>(&p[u]);
+                for (int e = 0; e < 4; e++)
+                    if (((fl[u] >> e) & 1u) && c + e < n) { const unsigned long long w = vw.wsrc[c + e]; if (sc_word_fresh(vw, w)) pp[e] = sc_word_price(w); }
+            }
             f(c, x[u].x, p[u].x);
             if (c + 1 < n) f(c + 1, x[u].y, p[u].y);
             if (c + 2 < n) f(c + 2, x[u].z, p[u].z);
@@ -458,11 +504,11 @@ template <int U, typename F> __device__ __forceinline__ void block_row_sweep(con
 // minima of the columns c with (c / 4) % 64 == l, sorted: the 35th, else the 17th, 8th ... smallest; the columns below it are collected in
 // a second sweep of the now L2-resident row; more than 63 of them -> the next candidate).  Every thread returns the same Top2.
 template <int U>
-__device__ __forceinline__ Top2 sc_top2_block(const WideArgs &a, ScShared &ss, int i, bool rebuild) {
+__device__ __forceinline__ Top2 sc_top2_block(const WideArgs &a, const ScView &vw, ScShared &ss, int i, bool rebuild) {
     const int n = a.n, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float *__restrict__ row = a.cost + wrow_off(a.rowmap, i, a.ld);
     K2 d; d.m1 = KEYMAX; d.m2 = KEYMAX;
-    block_row_sweep<U>(row, a.v, n, [&](int c, float x, float vc) { k2_push(d, mkkey(x - vc, (uint32_t)c)); });
+    block_row_sweep<U>(row, a.v, vw, n, [&](int c, float x, float vc) { k2_push(d, mkkey(x - vc, (uint32_t)c)); });
     const uint32_t my_min = (uint32_t)(d.m1 >> 32);              // the smallest reduced cost among THIS thread's columns (ordered)
     ss.lmin[tid] = my_min;
     d = k2_wave_allreduce(d);
@@ -472,9 +518,9 @@ __device__ __forceinline__ Top2 sc_top2_block(const WideArgs &a, ScShared &ss, i
 #pragma unroll
     for (int k = 1; k < HEADB / 64; k++) { K2 o; o.m1 = ss.km1[k]; o.m2 = ss.km2[k]; k2_merge(g, o); }
     Top2 t;
-    t.u1 = key_val(g.m1); t.j1 = (int)(uint32_t)g.m1; t.c1 = row[t.j1]; t.vj1 = a.v[t.j1];
-    t.u2 = INFINITY; t.j2 = -1; t.c2 = 0.0f; t.vj2 = 0.0f;
-    if (g.m2 != KEYMAX) { t.u2 = key_val(g.m2); t.j2 = (int)(uint32_t)g.m2; t.c2 = row[t.j2]; t.vj2 = a.v[t.j2]; }
+    t.u1 = key_val(g.m1); t.j1 = (int)(uint32_t)g.m1; t.c1 = row[t.j1]; sc_price_owner(a, vw, t.j1, t.vj1, t.o1);
+    t.u2 = INFINITY; t.j2 = -1; t.c2 = 0.0f; t.vj2 = 0.0f; t.o2 = -1;
+    if (g.m2 != KEYMAX) { t.u2 = key_val(g.m2); t.j2 = (int)(uint32_t)g.m2; t.c2 = row[t.j2]; sc_price_owner(a, vw, t.j2, t.vj2, t.o2); }
     if (!rebuild) { __syncthreads(); return t; }                   // (the staging words are free again for the next row)
     // ---- the row's new cache ----
     uint32_t lm = 0xFFFFFFFFu;
@@ -498,7 +544,7 @@ __device__ __forceinline__ Top2 sc_top2_block(const WideArgs &a, ScShared &ss, i
         __syncthreads();
         const uint32_t cand = ss.cand;
         if (cand != 0xFFFFFFFFu && my_min < cand)                    // (a thread none of whose columns lies below the candidate reads nothing: ~4 of 5)
-            block_row_sweep<U>(row, a.v, n, [&](int c, float x, float vc) {
+            block_row_sweep<U>(row, a.v, vw, n, [&](int c, float x, float vc) {
                 if (f2ord(x - vc) < cand) {
                     const int p = atomicAdd(&ss.cnt, 1);
                     if (p < KCU) { ss.ccol[p] = (uint32_t)c; ss.cval[p] = x; }
@@ -538,6 +584,33 @@ __device__ __forceinline__ bool bid_won(unsigned long long word, int row) { retu
 
 struct ArrHead { int cnt[2]; int started, free_cr; long long round, bids; int retired, dense; int done, launches; long long list_rounds; int no_more, pad_; };
 
+// ---- the machine's memory beyond the driver's arrays (WideArgs.scx, wide_sc_ext_bytes(n) bytes, 256-byte aligned): the second buffer of
+// bid words (the first is a.bid), the bid records of a launch (two buffers by the launch's parity: 16 bytes { row, column or -1,
+// price, owner it would displace } and the raw cost of the entry), three bitmaps of the columns bid for.
+struct ScRec { int i, jt; float pt; int i0; };
+struct ScMem {
+    unsigned long long *word[2];
+    ScRec *rec[2];
+    float *rct[2];
+    uint32_t *bm[3];
+    int nw32;
+};
+__host__ __device__ inline size_t sc_nw32_pad(int n) { return (((size_t)n + 31) / 32 + 63) & ~(size_t)63; }
+__device__ __forceinline__ ScMem sc_mem(const WideArgs &a) {
+    ScMem m;
+    const size_t np = ((size_t)a.n + 63) & ~(size_t)63;
+    char *p = (char *)a.scx;
+    m.word[0] = a.bid; m.word[1] = reinterpret_cast<unsigned long long *>(p); p += np * 8;
+    m.rec[0] = reinterpret_cast<ScRec *>(p); p += np * 16;
+    m.rec[1] = reinterpret_cast<ScRec *>(p); p += np * 16;
+    m.rct[0] = reinterpret_cast<float *>(p); p += np * 4;
+    m.rct[1] = reinterpret_cast<float *>(p); p += np * 4;
+    const size_t nw = sc_nw32_pad(a.n);
+    for (int k = 0; k < 3; k++) { m.bm[k] = reinterpret_cast<uint32_t *>(p); p += nw * 4; }
+    m.nw32 = (a.n + 31) / 32;
+    return m;
+}
+
 __device__ __forceinline__ float sc_eps_of(const ScCtl *sc, int k) {       // eps of phase k, 0 = there is no such phase
     if (k >= SC_NPH) return 0.0f;
     const int ek = sc->e0 - SC_ESTEP * k;
@@ -545,10 +618,11 @@ __device__ __forceinline__ float sc_eps_of(const ScCtl *sc, int k) {       // ep
     const float eps = __uint_as_float((uint32_t)ek << 23);
     return eps < sc->epsmin ? 0.0f : eps;
 }
-// the step of launch pair L (every thread of the pair's first kernel computes the same)
+// the step the machine takes from state S with `na` active rows (oracle: the head of the phase machine's loop; every thread of a
+// launch computes the same)
 __device__ __forceinline__ ScSlot sc_step(const ScCtl *sc, const ScSlot &S, int na, int n, long long max_rounds) {
     ScSlot N = S;
-    N.act = SC_ACT_NONE;
+    N.act = SC_ACT_NONE; N.fresh = 0;
     if (S.mode >= SC_HANDOVER) return N;
     // (the budget of rounds ends the LEGACY rounds and the scaled phases, never the FINAL phase: the assignments a scaled phase leaves
     //  satisfy eps-complementary slackness only, the searches need the eps = 0 phase's)
@@ -565,10 +639,10 @@ __device__ __forceinline__ ScSlot sc_step(const ScCtl *sc, const ScSlot &S, int 
     if (next_phase) {
         N.k = N.k + 1;
         const float eps = last ? 0.0f : sc_eps_of(sc, N.k);
-        N.mode = eps > 0.0f ? SC_EPS : SC_FINAL; N.eps = eps; N.rip = 0; N.cur = S.cur ^ 1; N.act = SC_ACT_RESET;
+        N.mode = eps > 0.0f ? SC_EPS : SC_FINAL; N.eps = eps; N.rip = 0; N.act = SC_ACT_RESET;
         return N;
     }
-    N.act = SC_ACT_ROUND; N.rip = S.rip + 1; N.total = S.total + 1; N.bids = S.bids + na; N.cur = S.cur ^ 1;
+    N.act = SC_ACT_ROUND; N.rip = S.rip + 1; N.total = S.total + 1; N.bids = S.bids + na;
     return N;
 }
 
@@ -581,7 +655,7 @@ __global__ __launch_bounds__(HEADB) void wide_sc_init(const WideArgs *__restrict
         const bool fr = i < n && a.rowsol[i] < 0;
         const uint64_t m = __ballot(fr);
         int base = 0;
-        if (lane == 0 && m) base = atomicAdd(&sc->cnt[0], __popcll(m));
+        if (lane == 0 && m) base = atomicAdd(&sc->rnd[2].cnt, __popcll(m));        // (the list launch 0 reads: cell (0 - 1) mod 3)
         base = __shfl(base, 0);
         if (fr) a.act0[base + __popcll(m & lanemask_lt())] = i;
     }
@@ -592,67 +666,122 @@ __global__ __launch_bounds__(HEADB) void wide_sc_init(const WideArgs *__restrict
         sc->e0 = me > 0 ? (me + SC_EMULT > 254 ? 254 : me + SC_EMULT) : 0;
         sc->epsmin = __uint_as_float(sc->vmaxbits) * 1.1920928955078125e-07f;
         sc->stop = wide_stop(n);
-        ScSlot S; S.mode = SC_LEGACY; S.k = 0; S.rip = 0; S.cur = 0; S.act = SC_ACT_NONE; S.eps = 0.0f; S.total = 0; S.bids = 0;
+        ScSlot S; S.mode = SC_LEGACY; S.k = 0; S.rip = 0; S.fresh = 1; S.act = SC_ACT_NONE; S.eps = 0.0f; S.total = 0; S.bids = 0;
         sc->slot[0] = S;
     }
 }
 
+// Launch L of the machine (see the header above): the step the state and the length of the list that bid in launch L - 1 ask for --
+//   ROUND  those bids stand: a wave per bid resolves it and bids at once for the row that takes its place;
+//   RESET  a phase begins (those bids are dropped): everything unassigned, every row bids;
+//   none   the machine is through (those bids are dropped; their rows are the list it leaves) --
+// or, in launch 0, the first bids of the rows the column reduction left free.
 template <int U>
-__global__ __launch_bounds__(HEADB) void wide_sc_bid(const WideArgs *__restrict__ batch, int L) {
+__global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restrict__ batch, int L) {
     extern __shared__ __align__(16) unsigned char w_smem[];
     const WideArgs a = load_wide_args(batch, blockIdx.y);
     ScCtl *sc = reinterpret_cast<ScCtl *>(a.sc);
     const ScSlot S = sc->slot[L & 1];
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
     if (S.mode >= SC_HANDOVER) {                                 // through: the state stays (both slots)
-        if (blockIdx.x == 0 && threadIdx.x == 0 && sc->slot[(L + 1) & 1].mode != S.mode) { ScSlot N = S; N.act = SC_ACT_NONE; sc->slot[(L + 1) & 1] = N; }
+        if (lead && sc->slot[(L + 1) & 1].mode != S.mode) { ScSlot N = S; N.act = SC_ACT_NONE; sc->slot[(L + 1) & 1] = N; }
         return;
     }
-    const int n = a.n, cur = S.cur, na = sc->cnt[cur];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && S.total == 0 && S.rip == 0 && S.mode == SC_LEGACY) sc->free_cr = na;
-    const ScSlot N = sc_step(sc, S, na, n, a.max_rounds);
-    const int32_t *A = cur ? a.act1 : a.act0;
-    int32_t *B = cur ? a.act0 : a.act1;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int n = a.n;
+    const int pb = (L + 1) & 1, cb = L & 1;                      // record / word buffers: the launch before, this launch
+    const int rp = (L + 2) % 3, rc = L % 3, rn = (L + 1) % 3;    // per-launch cells and bitmaps: the launch before, this one, the next
+    const ScMem m = sc_mem(a);
+    const int np = sc->rnd[rp].cnt;                              // rows that bid in launch L - 1 (launch 0: rows on wide_sc_init's list)
+    const bool first = S.fresh != 0;
+    ScSlot N;
+    if (first) { N = S; N.fresh = 0; N.act = SC_ACT_NONE; } else N = sc_step(sc, S, np, n, a.max_rounds);
+    const int act = N.act;
+    const bool through = !first && act == SC_ACT_NONE;
+    if (lead) {
         sc->slot[(L + 1) & 1] = N;
-        if (N.act == SC_ACT_ROUND) sc->cnt[cur ^ 1] = 0;         // the list this round's resolution appends to starts empty
-        if (N.act == SC_ACT_RESET) { sc->cnt[cur ^ 1] = n; sc->phases += 1; }
+        sc->rnd[rn].cnt = 0; sc->rnd[rn].retired = 0;
+        if (first) { sc->free_cr = np; sc->rnd[rc].cnt = np; }
+        if (act == SC_ACT_ROUND) sc->retired += sc->rnd[rp].retired;   // the round took place: its retirements count
+        if (act == SC_ACT_RESET) { sc->phases += 1; sc->rnd[rc].cnt = n; }
+        if (through) { sc->fin_buf = pb; sc->fin_cnt = np; }
     }
-    if (N.act == SC_ACT_RESET) {                                 // a phase begins: everything unassigned, every row on the list
-        for (int i = blockIdx.x * HEADB + threadIdx.x; i < n; i += gridDim.x * HEADB) { a.rowsol[i] = -1; a.colsol[i] = -1; B[i] = i; }
-        return;
-    }
-    if (N.act != SC_ACT_ROUND) return;
+    if (through) return;
+    for (int q = blockIdx.x * HEADB + threadIdx.x; q < m.nw32; q += gridDim.x * HEADB) m.bm[rn][q] = 0u;       // the next launch's bitmap starts empty
+    if (act == SC_ACT_RESET)
+        for (int i = blockIdx.x * HEADB + threadIdx.x; i < n; i += gridDim.x * HEADB) { a.rowsol[i] = -1; a.colsol[i] = -1; }
     const int lane = threadIdx.x & 63, w = uni((int)(threadIdx.x >> 6));
     ScShared &ss = *reinterpret_cast<ScShared *>(w_smem);
     if (threadIdx.x == 0) { ss.nq = 0; ss.fill_ = 0; }
     __syncthreads();
-    const long long tag = S.total - (long long)sc->base;
-    const float eps = S.eps;
+    ScView vw;
+    vw.wsrc = act == SC_ACT_ROUND ? m.word[pb] : nullptr;
+    vw.bm = act == SC_ACT_ROUND ? m.bm[rp] : nullptr;
+    vw.tg = ~(uint32_t)((long long)(L - 1) - (long long)sc->wbase[pb]) & 0xFFFu;
+    vw.own_none = act == SC_ACT_RESET;
+    unsigned long long *wdst = m.word[cb];
+    uint32_t *bmd = m.bm[rc];
+    ScRec *rdst = m.rec[cb];
+    float *cdst = m.rct[cb];
+    const ScRec *rsrc = m.rec[pb];
+    const float *csrc = m.rct[pb];
+    const long long tag = (long long)L - (long long)sc->wbase[cb];
+    const float eps = N.eps;
     // a coarse phase (eps_k many times the span of a row's 63 cached columns) moves the prices past every cache within a bid or two:
     // there a full-row bid does not rebuild its row's cache (half its cost) -- the later phases do, and keep their caches
-    const bool refresh = !(S.mode == SC_EPS && S.k < SC_COARSE);
+    const bool refresh = !(N.mode == SC_EPS && N.k < SC_COARSE);
     int retired = 0, dense = 0;                                   // (lane 0 of every wave)
-    auto record = [&](int slot, int i, const Top2 &t) {
+    int *ocnt = &sc->rnd[rc].cnt;
+    auto record = [&](int oslot, int i, const Top2 &t) {
         int jt, i0; float pt, ct;
-        sc_decide(a, t, eps, jt, pt, ct, i0);
+        sc_decide(t, eps, jt, pt, ct, i0);
         if (lane == 0) {
             if (jt < 0) retired++;
-            else atomicMin(a.bid + jt, bidkey(tag, pt, i));
-            a.slot_j[slot] = jt; a.slot_p[slot] = pt; a.slot_c[slot] = ct;
-            a.touched[slot] = i0;                                 // (the owner the bid would displace: owners do not change before the resolution;
-                                                                  //  `touched` is the searches' list, idle during the row reduction)
+            else {
+                atomicMin(wdst + jt, bidkey(tag, pt, i));
+                atomicOr(bmd + (jt >> 5), 1u << (jt & 31));
+            }
+            ScRec r; r.i = i; r.jt = jt; r.pt = pt; r.i0 = i0;
+            *reinterpret_cast<int4 *>(rdst + oslot) = *reinterpret_cast<const int4 *>(&r);
+            cdst[oslot] = ct;
         }
     };
     const int per = (int)gridDim.x * (HEADB / 64);
-    for (int base = (int)blockIdx.x * (HEADB / 64); base < na; base += per) {      // (the same trips for every wave of the workgroup)
+    for (int base = (int)blockIdx.x * (HEADB / 64); base < np; base += per) {      // (the same trips for every wave of the workgroup)
         const int slot = base + w;
-        if (slot < na) {
-            const int i = uni(A[slot]);
-            const uint32_t col = a.cache_col[(int64_t)i * KC + lane];
-            const float val = a.cache_val[(int64_t)i * KC + lane];
-            Top2 t;
-            if (sc_top2_cached(a, lane, col, val, t)) record(slot, i, t);
-            else if (lane == 0) { const int q = atomicAdd(&ss.nq, 1); ss.qrow[q] = i; ss.qslot[q] = slot; }
+        if (slot < np) {
+            int i = -1, oslot = slot;                               // the row this wave bids for, where its record goes
+            uint32_t col = COLSENT; float val = 0.0f;
+            if (act == SC_ACT_ROUND) {
+                const int4 rr = *reinterpret_cast<const int4 *>(rsrc + slot);
+                const int ri = uni(rr.x), rj = uni(rr.y), r0 = uni(rr.w);
+                if (rj >= 0) {                                      // (a retired row stays free and bids no more)
+                    // everything the outcome decides between is requested with the word that decides it: both rows' caches
+                    const unsigned long long word = vw.wsrc[rj];
+                    const float rct = csrc[slot];
+                    const uint32_t colA = a.cache_col[(int64_t)ri * KC + lane];
+                    const float valA = a.cache_val[(int64_t)ri * KC + lane];
+                    uint32_t colB = COLSENT; float valB = 0.0f;
+                    if (r0 >= 0) { colB = a.cache_col[(int64_t)r0 * KC + lane]; valB = a.cache_val[(int64_t)r0 * KC + lane]; }
+                    const bool won = bid_won(uni(word), ri);
+                    if (won) {
+                        if (lane == 0) {
+                            a.v[rj] = __int_as_float(rr.z); a.colsol[rj] = ri; a.rowsol[ri] = rj; a.cassign[rj] = rct;
+                            if (r0 >= 0) a.rowsol[r0] = -1;
+                        }
+                        i = r0; col = colB; val = valB;
+                    } else { i = ri; col = colA; val = valA; }
+                }
+                if (i >= 0) { int o = 0; if (lane == 0) o = atomicAdd(ocnt, 1); oslot = uni(o); }
+            } else {
+                i = act == SC_ACT_RESET ? slot : uni(a.act0[slot]);
+                col = a.cache_col[(int64_t)i * KC + lane];
+                val = a.cache_val[(int64_t)i * KC + lane];
+            }
+            if (i >= 0) {
+                Top2 t;
+                if (sc_top2_cached(a, vw, lane, col, val, t)) record(oslot, i, t);
+                else if (lane == 0) { const int q = atomicAdd(&ss.nq, 1); ss.qrow[q] = i; ss.qslot[q] = oslot; }
+            }
         }
         __syncthreads();
         const int nq = ss.nq;
@@ -660,43 +789,19 @@ __global__ __launch_bounds__(HEADB) void wide_sc_bid(const WideArgs *__restrict_
         if (nq) {                                                  // rows whose caches could not certify: the whole workgroup, one after the other
             if (threadIdx.x == 0) ss.nq = 0;
             for (int q = 0; q < nq; q++) {
-                const int i = ss.qrow[q], slot = ss.qslot[q];
-                const Top2 t = sc_top2_block<U>(a, ss, i, refresh);
-                if (w == 0) { record(slot, i, t); dense++; }
+                const int i = ss.qrow[q], oslot = ss.qslot[q];
+                const Top2 t = sc_top2_block<U>(a, vw, ss, i, refresh);
+                if (w == 0) { record(oslot, i, t); dense++; }
             }
             __syncthreads();
         }
     }
-    if (lane == 0) { if (retired) atomicAdd(&sc->retired, retired); if (dense) atomicAdd(&sc->dense, dense); }
+    if (lane == 0) { if (retired) atomicAdd(&sc->rnd[rc].retired, retired); if (dense) atomicAdd(&sc->dense, dense); }
 }
 
-__global__ __launch_bounds__(HEADB) void wide_sc_resolve(const WideArgs *__restrict__ batch, int L) {
-    ArrCtx<false, false> cx;
-    cx.a = load_wide_args(batch, blockIdx.y);
-    const WideArgs &a = cx.a;
-    ScCtl *sc = reinterpret_cast<ScCtl *>(a.sc);
-    const ScSlot N = sc->slot[(L + 1) & 1];                      // (written by this pair's first kernel)
-    if (N.act != SC_ACT_ROUND) return;
-    const int cur = N.cur ^ 1, na = sc->cnt[cur];                // the list the bids were made from
-    cx.s_v = nullptr; cx.s_cs = nullptr; cx.s = nullptr; cx.lane = threadIdx.x & 63;
-    const int32_t *A = cur ? a.act1 : a.act0;
-    int32_t *B = cur ? a.act0 : a.act1;
-    for (int slot = blockIdx.x * HEADB + threadIdx.x; slot < na; slot += gridDim.x * HEADB) {
-        const int jt = a.slot_j[slot];
-        if (jt < 0) continue;                                    // retired: stays free, bids no more
-        const int i = A[slot];
-        if (bid_won(a.bid[jt], i)) {
-            const int i0 = a.touched[slot];                      // (recorded with the bid: one dependent load less than colsol[jt])
-            cx.apply(i, jt, a.slot_p[slot], a.slot_c[slot], i0);
-            if (i0 >= 0) B[atomicAdd(&sc->cnt[cur ^ 1], 1)] = i0;
-        } else {
-            B[atomicAdd(&sc->cnt[cur ^ 1], 1)] = i;
-        }
-    }
-}
-
-// after a group of pairs (the next pair is L): seg_sync[0] counts the problems whose machine is not through, seg_sync[1 + b] = 1: the
+// after a group of launches (the next one is L): seg_sync[0] counts the problems whose machine is not through, seg_sync[1 + b] = 1: the
 // full-row bids since the last rebuild have reached a.arr_waste -- problem b wants its row caches rebuilt before the next group
+// (against a.v, which runs one round late: prices only fall, a cache built against older prices holds for the newer ones)
 __global__ void wide_sc_check(const WideArgs *__restrict__ batch, int L) {
     const WideArgs a = load_wide_args(batch, blockIdx.x);
     ScCtl *sc = reinterpret_cast<ScCtl *>(a.sc);
@@ -714,27 +819,30 @@ __global__ void wide_sc_check(const WideArgs *__restrict__ batch, int L) {
     a.seg_sync[1 + blockIdx.x] = want;
 }
 
-// between two pairs (the next one is L): the bid words start over
+// before launch L: the bid words of ITS buffer start over (the other buffer holds the bids launch L resolves)
 __global__ __launch_bounds__(HEADB) void wide_sc_wipe(const WideArgs *__restrict__ batch, int L) {
     const WideArgs a = load_wide_args(batch, blockIdx.y);
     ScCtl *sc = reinterpret_cast<ScCtl *>(a.sc);
-    for (int j = blockIdx.x * HEADB + threadIdx.x; j < a.n; j += gridDim.x * HEADB) a.bid[j] = ~0ull;
-    if (blockIdx.x == 0 && threadIdx.x == 0) sc->base = (unsigned long long)sc->slot[L & 1].total;
+    const ScMem m = sc_mem(a);
+    for (int j = blockIdx.x * HEADB + threadIdx.x; j < a.n; j += gridDim.x * HEADB) m.word[L & 1][j] = ~0ull;
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc->wbase[L & 1] = (unsigned long long)L;
 }
 
-// the machine is through (the next pair would be L): what wide_arr picks up -- the short list of a LEGACY problem for its chain rounds
-// (on the list its round's parity names), the counters; no_more: the rounds are over (budget, or a scaled problem's last phase)
+// the machine is through (the next launch would be L): what wide_arr picks up -- the rows that were active when it stopped (for the
+// chain rounds of a LEGACY problem: on the list its round's parity names), the counters; no_more: the rounds are over (budget, or a
+// scaled problem's last phase)
 __global__ void wide_sc_finish(const WideArgs *__restrict__ batch, int L) {
     const WideArgs a = load_wide_args(batch, blockIdx.x);
     ScCtl *sc = reinterpret_cast<ScCtl *>(a.sc);
     ArrHead *h = reinterpret_cast<ArrHead *>(a.misc + 384);
     const ScSlot S = sc->slot[L & 1];
-    const int na = sc->cnt[S.cur], want = (int)(S.total & 1);
+    const ScMem m = sc_mem(a);
+    const int na = sc->fin_cnt, want = (int)(S.total & 1);
     const bool chain = S.mode == SC_HANDOVER;
-    if (chain && want != S.cur) {
-        const int32_t *A = S.cur ? a.act1 : a.act0;
-        int32_t *B = S.cur ? a.act0 : a.act1;
-        for (int q = threadIdx.x; q < na; q += blockDim.x) B[q] = A[q];
+    if (chain) {
+        const ScRec *R = m.rec[sc->fin_buf];
+        int32_t *B = want ? a.act1 : a.act0;
+        for (int q = threadIdx.x; q < na; q += blockDim.x) B[q] = R[q].i;
     }
     if (threadIdx.x == 0) {
         h->cnt[want] = na; h->cnt[want ^ 1] = 0; h->started = 1; h->free_cr = sc->free_cr; h->round = S.total; h->bids = S.bids;
@@ -2074,6 +2182,11 @@ __global__ __launch_bounds__(WT) void wide_aug_mc(const WideArgs *__restrict__ b
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+size_t wide_sc_ext_bytes(int n) {
+    const size_t np = ((size_t)n + 63) & ~(size_t)63;
+    return np * (8 + 2 * 16 + 2 * 4) + 3 * sc_nw32_pad(n) * 4;
+}
+
 int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream) {
     const int blocks = std::max(1, std::min((n + RTB / 64 - 1) / (RTB / 64), 2048 / std::max(1, std::min(nb, 8))));
     hipLaunchKernelGGL(wide_rt, dim3(blocks, nb), dim3(RTB), 0, stream, d_args);
@@ -2083,15 +2196,15 @@ int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream) {
 
 int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, int wipe_every, bool resume, int32_t *d_sync,
                     int (*rebuild)(void *ctx, const int32_t *flags), void *ctx) {
-    // The phase machine on the whole chip (two launches per round), in groups of pairs: after a group the driver asks which problems
+    // The phase machine on the whole chip (one launch per round), in groups of launches: after a group the driver asks which problems
     // are not through (one small read) and rebuilds the row caches of those whose floors have gone stale; then wide_arr -- one
     // workgroup per problem -- for the chain rounds of the problems that did not scale (<= 64 active rows) and the free lists.
     // resume: wide_arr's chain rounds paused for fresh row caches -- it alone picks them up
-    const int wipe = wipe_every > 0 ? wipe_every : 2048;
+    // (wipe: launches PER WORD BUFFER between two resets of its bid words -- the words' 12-bit tag counts launches since the reset)
+    const int wipe = std::max(1, std::min(wipe_every > 0 ? wipe_every : 1024, 2047));
     int rc;
     if (n >= 2 && !resume) {
-        // a wave per bid while the chip has room for them (a bid is a chain of L2 round trips: what counts is how many are in flight);
-        // the other kernels of the machine are a thread per row / slot
+        // a wave per bid while the chip has room for them (a bid is a chain of L2 round trips: what counts is how many are in flight)
         // (at most 2 048 workgroups: late in a phase a few hundred rows bid and a launch is mostly the dispatch of workgroups that find
         //  nothing to do -- same box, gpurun_out/r04af, row-reduction phase with 4 096 / 2 048 / 1 024 / 256 workgroups: 20 000^2 7.9 / 7.5 /
         //  7.4 / 7.9 ms, 50 000^2 22.5-23.0 / 21.5 / 21.4-21.9 / 23.9 ms, few-cell-type 20 000^2 23.1-23.4 / 22.9 / 23.0-23.5 / 26.1 ms)
@@ -2102,16 +2215,15 @@ int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, i
         const int bxr = std::max(1, std::min((n + HEADB - 1) / HEADB, 2048 / std::max(1, std::min(nb, 16))));
         // (quads of a full-row bid's sweep in flight per lane: developer knob CYTO_BID_UNROLL, tools/exp)
         const bool deep = CYTO_KNOB("CYTO_BID_UNROLL").set && CYTO_KNOB("CYTO_BID_UNROLL").value == 8;
-        void (*bidk)(const WideArgs *, int) = deep ? wide_sc_bid<8> : wide_sc_bid<4>;
-        if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(bidk)))) return rc;
+        void (*roundk)(const WideArgs *, int) = deep ? wide_sc_round<8> : wide_sc_round<4>;
+        if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(roundk)))) return rc;
         hipLaunchKernelGGL(wide_sc_init, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args);
         std::vector<int32_t> h_sync((size_t)nb + 1, 0);
-        int L = 0, group = 32;
+        int L = 0, group = 64;
         for (;;) {
             for (int g = 0; g < group; g++, L++) {
-                if (L > 0 && L % wipe == 0) hipLaunchKernelGGL(wide_sc_wipe, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args, L);
-                hipLaunchKernelGGL(bidk, dim3(bx, nb), dim3(HEADB), SC_SHARED_BYTES, stream, d_args, L);
-                hipLaunchKernelGGL(wide_sc_resolve, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args, L);
+                if ((L >> 1) > 0 && (L >> 1) % wipe == 0) hipLaunchKernelGGL(wide_sc_wipe, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args, L);
+                hipLaunchKernelGGL(roundk, dim3(bx, nb), dim3(HEADB), SC_SHARED_BYTES, stream, d_args, L);
             }
             if (!d_sync) return CYTO_ERR_INTERNAL;
             CYTO_HIP(hipMemsetAsync(d_sync, 0, sizeof(int32_t), stream));
@@ -2122,7 +2234,7 @@ int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, i
             bool want = false;
             for (int b = 0; b < nb; b++) want = want || h_sync[(size_t)b + 1] == 1;
             if (want && rebuild && (rc = rebuild(ctx, h_sync.data() + 1))) return rc;
-            group = 64;
+            group = 128;
             if (L > (1 << 22)) return CYTO_ERR_INTERNAL;               // (every phase is bounded: cannot happen)
         }
         hipLaunchKernelGGL(wide_sc_finish, dim3(nb), dim3(64), 0, stream, d_args, L);
