@@ -746,9 +746,10 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
         }
     };
     const int per = (int)gridDim.x * (HEADB / 64);
-    for (int base = (int)blockIdx.x * (HEADB / 64); base < np; base += per) {      // (the same trips for every wave of the workgroup)
+    const int nwork = act == SC_ACT_RESET ? n : np;             // a wave per bid to resolve; per row at a phase boundary
+    for (int base = (int)blockIdx.x * (HEADB / 64); base < nwork; base += per) {      // (the same trips for every wave of the workgroup)
         const int slot = base + w;
-        if (slot < np) {
+        if (slot < nwork) {
             int i = -1, oslot = slot;                               // the row this wave bids for, where its record goes
             uint32_t col = COLSENT; float val = 0.0f;
             if (act == SC_ACT_ROUND) {
@@ -2217,19 +2218,23 @@ int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, i
         const bool deep = CYTO_KNOB("CYTO_BID_UNROLL").set && CYTO_KNOB("CYTO_BID_UNROLL").value == 8;
         void (*roundk)(const WideArgs *, int) = deep ? wide_sc_round<8> : wide_sc_round<4>;
         if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(roundk)))) return rc;
+        if (CYTO_KNOB("CYTO_SC_DEBUG").set) { const hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[sc] before init: %s\n", hipGetErrorString(e_)); }
         hipLaunchKernelGGL(wide_sc_init, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args);
+        if (CYTO_KNOB("CYTO_SC_DEBUG").set) { const hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[sc] init: %s\n", hipGetErrorString(e_)); }
         std::vector<int32_t> h_sync((size_t)nb + 1, 0);
         int L = 0, group = 64;
         for (;;) {
             for (int g = 0; g < group; g++, L++) {
                 if ((L >> 1) > 0 && (L >> 1) % wipe == 0) hipLaunchKernelGGL(wide_sc_wipe, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args, L);
                 hipLaunchKernelGGL(roundk, dim3(bx, nb), dim3(HEADB), SC_SHARED_BYTES, stream, d_args, L);
+                if (CYTO_KNOB("CYTO_SC_DEBUG").set) { const hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[sc] launch %d: %s\n", L, hipGetErrorString(e_)); }
             }
             if (!d_sync) return CYTO_ERR_INTERNAL;
             CYTO_HIP(hipMemsetAsync(d_sync, 0, sizeof(int32_t), stream));
             hipLaunchKernelGGL(wide_sc_check, dim3(nb), dim3(64), 0, stream, d_args, L);
             CYTO_HIP(hipMemcpyAsync(h_sync.data(), d_sync, sizeof(int32_t) * ((size_t)nb + 1), hipMemcpyDeviceToHost, stream));
             CYTO_HIP(hipStreamSynchronize(stream));
+            if (CYTO_KNOB("CYTO_SC_DEBUG").set) fprintf(stderr, "[sc] check at %d: open %d want0 %d\n", L, h_sync[0], h_sync[1]);
             if (!h_sync[0]) break;
             bool want = false;
             for (int b = 0; b < nb; b++) want = want || h_sync[(size_t)b + 1] == 1;
@@ -2239,12 +2244,14 @@ int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, i
         }
         hipLaunchKernelGGL(wide_sc_finish, dim3(nb), dim3(64), 0, stream, d_args, L);
         CYTO_HIP(hipGetLastError());
+        if (CYTO_KNOB("CYTO_SC_DEBUG").set) { const hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[sc] finish: %s\n", hipGetErrorString(e_)); }
     }
     const bool vlds = wide_arr_vlds(n), clds = wide_arr_clds(n);
     void (*k)(const WideArgs *) = vlds ? wide_arr<true, true> : clds ? wide_arr<false, true> : wide_arr<false, false>;
     if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(k)))) return rc;
     hipLaunchKernelGGL(k, dim3(nb), dim3(WT), wide_arr_lds_bytes(n, vlds, clds), stream, d_args);
     CYTO_HIP(hipGetLastError());
+    if (CYTO_KNOB("CYTO_SC_DEBUG").set) { const hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[sc] wide_arr: %s\n", hipGetErrorString(e_)); }
     return CYTO_OK;
 }
 
