@@ -400,8 +400,9 @@ constexpr int HEADB = 256;             // threads of the machine's workgroups
 // (wide_arr's top2_full) is 170 us, and the round waits for its slowest bid.  Prices and owners do not change while the bids of
 // a round are made (the resolution is the next launch): plain loads, 16 bytes of the row and of the prices per lane and step.
 struct ScShared {
-    int nq, cnt, fill_;
+    int nq, cnt, fill_, obase;
     uint32_t cand;
+    int lrow[HEADB];                   // rows that bid out of the tile being resolved
     int qrow[HEADB / 64], qslot[HEADB / 64];
     unsigned long long km1[HEADB / 64], km2[HEADB / 64];
     uint32_t lmin[HEADB];
@@ -446,16 +447,21 @@ __device__ __forceinline__ void sc_decide(const Top2 &t, float eps, int &jt, flo
     }
     jt = uni(jt); pt = uni(pt); ct = uni(ct); i0 = uni(i0);
 }
-// one wave: the top-2 from the row's cache (lane = entry); false: the cache cannot certify it.  Prices, fresh words and owners of
-// the 63 cached columns are requested together (one round trip).
+// one wave: the top-2 from the row's cache (lane = entry); false: the cache cannot certify it.  The prices of the 63 cached columns
+// are gathered; which of them received a bid in the launch before says the bitmap (a few KB that every wave reads: it stays in the
+// CU's cache) -- only those lanes ask for their column's bid word (gathering word and owner for all 63 columns tripled the lines a
+// bid pulls in: a launch with 8 000 bids took 60 us); the owners of the two columns that matter are read last.
 __device__ __forceinline__ bool sc_top2_cached(const WideArgs &a, const ScView &vw, int lane, uint32_t col, float val, Top2 &t) {
     const float tau = rdlane(val, KCU);
     const bool valid = lane < KCU && col != COLSENT;
     float vj = valid ? a.v[col] : 0.0f;
-    int ow = (valid && !vw.own_none) ? a.colsol[col] : -1;
-    if (vw.wsrc) {
-        const unsigned long long w = valid ? vw.wsrc[col] : ~0ull;
-        if (sc_word_fresh(vw, w)) { vj = sc_word_price(w); ow = (int)((uint32_t)w & 0xFFFFFu); }
+    int ow = -2;                                                  // -2: the column's owner is the array's
+    if (vw.bm) {
+        const uint32_t bw = valid ? vw.bm[col >> 5] : 0u;
+        if ((bw >> (col & 31)) & 1u) {
+            const unsigned long long w = vw.wsrc[col];
+            if (sc_word_fresh(vw, w)) { vj = sc_word_price(w); ow = (int)((uint32_t)w & 0xFFFFFu); }
+        }
     }
     const uint32_t key = valid ? f2ord(val - vj) : 0xFFFFFFFFu;
     const uint32_t k1 = wave_min_u32(key);
@@ -466,6 +472,12 @@ __device__ __forceinline__ bool sc_top2_cached(const WideArgs &a, const ScView &
     const int l2 = __ffsll((unsigned long long)__ballot(key2 == k2)) - 1;
     t.u1 = ord2f(k1); t.j1 = (int)rdlane(col, l1); t.c1 = rdlane(val, l1); t.vj1 = rdlane(vj, l1); t.o1 = (int)rdlane((uint32_t)ow, l1);
     t.u2 = ord2f(k2); t.j2 = (int)rdlane(col, l2); t.c2 = rdlane(val, l2); t.vj2 = rdlane(vj, l2); t.o2 = (int)rdlane((uint32_t)ow, l2);
+    if (vw.own_none) { t.o1 = -1; t.o2 = -1; }
+    else {
+        const int c1 = a.colsol[t.j1], c2 = a.colsol[t.j2];        // (both requested together)
+        if (t.o1 == -2) t.o1 = uni(c1);
+        if (t.o2 == -2) t.o2 = uni(c2);
+    }
     return true;
 }
 // the whole workgroup (HEADB threads): f(column, cost, price) for every column of the row, 16 bytes of row and prices per lane and step;
@@ -588,28 +600,13 @@ struct ArrHead { int cnt[2]; int started, free_cr; long long round, bids; int re
 // bid words (the first is a.bid), the bid records of a launch (two buffers by the launch's parity: 16 bytes { row, column or -1,
 // price, owner it would displace } and the raw cost of the entry), three bitmaps of the columns bid for.
 struct ScRec { int i, jt; float pt; int i0; };
-struct ScMem {
-    unsigned long long *word[2];
-    ScRec *rec[2];
-    float *rct[2];
-    uint32_t *bm[3];
-    int nw32;
-};
+// (accessors instead of a table of pointers: a table indexed by the launch's parity would live in scratch memory)
 __host__ __device__ inline size_t sc_nw32_pad(int n) { return (((size_t)n + 31) / 32 + 63) & ~(size_t)63; }
-__device__ __forceinline__ ScMem sc_mem(const WideArgs &a) {
-    ScMem m;
-    const size_t np = ((size_t)a.n + 63) & ~(size_t)63;
-    char *p = (char *)a.scx;
-    m.word[0] = a.bid; m.word[1] = reinterpret_cast<unsigned long long *>(p); p += np * 8;
-    m.rec[0] = reinterpret_cast<ScRec *>(p); p += np * 16;
-    m.rec[1] = reinterpret_cast<ScRec *>(p); p += np * 16;
-    m.rct[0] = reinterpret_cast<float *>(p); p += np * 4;
-    m.rct[1] = reinterpret_cast<float *>(p); p += np * 4;
-    const size_t nw = sc_nw32_pad(a.n);
-    for (int k = 0; k < 3; k++) { m.bm[k] = reinterpret_cast<uint32_t *>(p); p += nw * 4; }
-    m.nw32 = (a.n + 31) / 32;
-    return m;
-}
+__device__ __forceinline__ size_t sc_np(const WideArgs &a) { return ((size_t)a.n + 63) & ~(size_t)63; }
+__device__ __forceinline__ unsigned long long *sc_words(const WideArgs &a, int b) { return b ? reinterpret_cast<unsigned long long *>(a.scx) : a.bid; }
+__device__ __forceinline__ ScRec *sc_recs(const WideArgs &a, int b) { return reinterpret_cast<ScRec *>(a.scx + sc_np(a) * (8 + 16 * (size_t)b)); }
+__device__ __forceinline__ float *sc_rcts(const WideArgs &a, int b) { return reinterpret_cast<float *>(a.scx + sc_np(a) * (40 + 4 * (size_t)b)); }
+__device__ __forceinline__ uint32_t *sc_bitmap(const WideArgs &a, int k) { return reinterpret_cast<uint32_t *>(a.scx + sc_np(a) * 48) + sc_nw32_pad(a.n) * (size_t)k; }
 
 __device__ __forceinline__ float sc_eps_of(const ScCtl *sc, int k) {       // eps of phase k, 0 = there is no such phase
     if (k >= SC_NPH) return 0.0f;
@@ -690,7 +687,7 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
     const int n = a.n;
     const int pb = (L + 1) & 1, cb = L & 1;                      // record / word buffers: the launch before, this launch
     const int rp = (L + 2) % 3, rc = L % 3, rn = (L + 1) % 3;    // per-launch cells and bitmaps: the launch before, this one, the next
-    const ScMem m = sc_mem(a);
+    const int nw32 = (n + 31) / 32;
     const int np = sc->rnd[rp].cnt;                              // rows that bid in launch L - 1 (launch 0: rows on wide_sc_init's list)
     const bool first = S.fresh != 0;
     ScSlot N;
@@ -706,7 +703,10 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
         if (through) { sc->fin_buf = pb; sc->fin_cnt = np; }
     }
     if (through) return;
-    for (int q = blockIdx.x * HEADB + threadIdx.x; q < m.nw32; q += gridDim.x * HEADB) m.bm[rn][q] = 0u;       // the next launch's bitmap starts empty
+    {
+        uint32_t *bmn = sc_bitmap(a, rn);                         // the next launch's bitmap starts empty
+        for (int q = blockIdx.x * HEADB + threadIdx.x; q < nw32; q += gridDim.x * HEADB) bmn[q] = 0u;
+    }
     if (act == SC_ACT_RESET)
         for (int i = blockIdx.x * HEADB + threadIdx.x; i < n; i += gridDim.x * HEADB) { a.rowsol[i] = -1; a.colsol[i] = -1; }
     const int lane = threadIdx.x & 63, w = uni((int)(threadIdx.x >> 6));
@@ -714,16 +714,16 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
     if (threadIdx.x == 0) { ss.nq = 0; ss.fill_ = 0; }
     __syncthreads();
     ScView vw;
-    vw.wsrc = act == SC_ACT_ROUND ? m.word[pb] : nullptr;
-    vw.bm = act == SC_ACT_ROUND ? m.bm[rp] : nullptr;
+    vw.wsrc = act == SC_ACT_ROUND ? sc_words(a, pb) : nullptr;
+    vw.bm = act == SC_ACT_ROUND ? sc_bitmap(a, rp) : nullptr;
     vw.tg = ~(uint32_t)((long long)(L - 1) - (long long)sc->wbase[pb]) & 0xFFFu;
     vw.own_none = act == SC_ACT_RESET;
-    unsigned long long *wdst = m.word[cb];
-    uint32_t *bmd = m.bm[rc];
-    ScRec *rdst = m.rec[cb];
-    float *cdst = m.rct[cb];
-    const ScRec *rsrc = m.rec[pb];
-    const float *csrc = m.rct[pb];
+    unsigned long long *wdst = sc_words(a, cb);
+    uint32_t *bmd = sc_bitmap(a, rc);
+    ScRec *rdst = sc_recs(a, cb);
+    float *cdst = sc_rcts(a, cb);
+    const ScRec *rsrc = sc_recs(a, pb);
+    const float *csrc = sc_rcts(a, pb);
     const long long tag = (long long)L - (long long)sc->wbase[cb];
     const float eps = N.eps;
     // a coarse phase (eps_k many times the span of a row's 63 cached columns) moves the prices past every cache within a bid or two:
@@ -740,61 +740,73 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
                 atomicMin(wdst + jt, bidkey(tag, pt, i));
                 atomicOr(bmd + (jt >> 5), 1u << (jt & 31));
             }
-            ScRec r; r.i = i; r.jt = jt; r.pt = pt; r.i0 = i0;
-            *reinterpret_cast<int4 *>(rdst + oslot) = *reinterpret_cast<const int4 *>(&r);
+            *reinterpret_cast<int4 *>(rdst + oslot) = make_int4(i, jt, __float_as_int(pt), i0);
             cdst[oslot] = ct;
         }
     };
-    const int per = (int)gridDim.x * (HEADB / 64);
-    const int nwork = act == SC_ACT_RESET ? n : np;             // a wave per bid to resolve; per row at a phase boundary
-    for (int base = (int)blockIdx.x * (HEADB / 64); base < nwork; base += per) {      // (the same trips for every wave of the workgroup)
-        const int slot = base + w;
-        if (slot < nwork) {
-            int i = -1, oslot = slot;                               // the row this wave bids for, where its record goes
-            uint32_t col = COLSENT; float val = 0.0f;
-            if (act == SC_ACT_ROUND) {
+    // Every workgroup takes a contiguous run of the work (bids to resolve; rows at a phase boundary) in tiles of HEADB.  ROUND, per tile:
+    // first a THREAD per bid resolves it (record and word: coalesced / one gather; a winner's thread writes price, owner, displaced
+    // owner) and the rows that bid next are gathered in LDS -- their records' slots come from ONE atomic on the launch's counter per
+    // tile (a wave per bid with an atomic each: 20 000 atomics on one address made a phase's first launches 130-170 us) -- then a
+    // WAVE per gathered row makes its bid.
+    const int nwork = act == SC_ACT_RESET ? n : np;
+    const int chunk = std::max(HEADB / 64, (nwork + (int)gridDim.x - 1) / (int)gridDim.x);
+    const int c_lo = std::min(nwork, (int)blockIdx.x * chunk), c_hi = std::min(nwork, c_lo + chunk);
+    for (int t0 = c_lo; t0 < c_hi; t0 += HEADB) {
+        const int tn = std::min(HEADB, c_hi - t0);               // work items of this tile
+        int nlist = tn;                                           // rows that bid out of this tile
+        if (act == SC_ACT_ROUND) {
+            if (threadIdx.x == 0) ss.cnt = 0;
+            __syncthreads();
+            int nxt = -1;
+            if ((int)threadIdx.x < tn) {
+                const int slot = t0 + (int)threadIdx.x;
                 const int4 rr = *reinterpret_cast<const int4 *>(rsrc + slot);
-                const int ri = uni(rr.x), rj = uni(rr.y), r0 = uni(rr.w);
-                if (rj >= 0) {                                      // (a retired row stays free and bids no more)
-                    // everything the outcome decides between is requested with the word that decides it: both rows' caches
-                    const unsigned long long word = vw.wsrc[rj];
+                if (rr.y >= 0) {                                    // (a retired row stays free and bids no more)
+                    const unsigned long long word = vw.wsrc[rr.y];
                     const float rct = csrc[slot];
-                    const uint32_t colA = a.cache_col[(int64_t)ri * KC + lane];
-                    const float valA = a.cache_val[(int64_t)ri * KC + lane];
-                    uint32_t colB = COLSENT; float valB = 0.0f;
-                    if (r0 >= 0) { colB = a.cache_col[(int64_t)r0 * KC + lane]; valB = a.cache_val[(int64_t)r0 * KC + lane]; }
-                    const bool won = bid_won(uni(word), ri);
-                    if (won) {
-                        if (lane == 0) {
-                            a.v[rj] = __int_as_float(rr.z); a.colsol[rj] = ri; a.rowsol[ri] = rj; a.cassign[rj] = rct;
-                            if (r0 >= 0) a.rowsol[r0] = -1;
-                        }
-                        i = r0; col = colB; val = valB;
-                    } else { i = ri; col = colA; val = valA; }
+                    if (bid_won(word, rr.x)) {
+                        a.v[rr.y] = __int_as_float(rr.z); a.colsol[rr.y] = rr.x; a.rowsol[rr.x] = rr.y; a.cassign[rr.y] = rct;
+                        if (rr.w >= 0) a.rowsol[rr.w] = -1;
+                        nxt = rr.w;                                 // the displaced owner bids next (or nobody)
+                    } else nxt = rr.x;
                 }
-                if (i >= 0) { int o = 0; if (lane == 0) o = atomicAdd(ocnt, 1); oslot = uni(o); }
-            } else {
-                i = act == SC_ACT_RESET ? slot : uni(a.act0[slot]);
-                col = a.cache_col[(int64_t)i * KC + lane];
-                val = a.cache_val[(int64_t)i * KC + lane];
             }
-            if (i >= 0) {
+            const uint64_t mb = __ballot(nxt >= 0);
+            int wbase = 0;
+            if (lane == 0 && mb) wbase = atomicAdd(&ss.cnt, __popcll(mb));
+            wbase = __shfl(wbase, 0);
+            const int lpos = wbase + __popcll(mb & lanemask_lt());
+            if (nxt >= 0) ss.lrow[lpos] = nxt;
+            __syncthreads();
+            nlist = ss.cnt;
+            if (threadIdx.x == 0 && nlist) ss.obase = atomicAdd(ocnt, nlist);
+            __syncthreads();
+        }
+        const int obase = act == SC_ACT_ROUND ? ss.obase : t0;
+        for (int e0 = 0; e0 < nlist; e0 += HEADB / 64) {         // (the same trips for every wave of the workgroup)
+            const int e = e0 + w;
+            if (e < nlist) {
+                const int i = act == SC_ACT_ROUND ? uni(ss.lrow[e]) : (act == SC_ACT_RESET ? t0 + e : uni(a.act0[t0 + e]));
+                const int oslot = obase + e;
+                const uint32_t col = a.cache_col[(int64_t)i * KC + lane];
+                const float val = a.cache_val[(int64_t)i * KC + lane];
                 Top2 t;
                 if (sc_top2_cached(a, vw, lane, col, val, t)) record(oslot, i, t);
                 else if (lane == 0) { const int q = atomicAdd(&ss.nq, 1); ss.qrow[q] = i; ss.qslot[q] = oslot; }
             }
-        }
-        __syncthreads();
-        const int nq = ss.nq;
-        __syncthreads();
-        if (nq) {                                                  // rows whose caches could not certify: the whole workgroup, one after the other
-            if (threadIdx.x == 0) ss.nq = 0;
-            for (int q = 0; q < nq; q++) {
-                const int i = ss.qrow[q], oslot = ss.qslot[q];
-                const Top2 t = sc_top2_block<U>(a, vw, ss, i, refresh);
-                if (w == 0) { record(oslot, i, t); dense++; }
-            }
             __syncthreads();
+            const int nq = ss.nq;
+            __syncthreads();
+            if (nq) {                                              // rows whose caches could not certify: the whole workgroup, one after the other
+                if (threadIdx.x == 0) ss.nq = 0;
+                for (int q = 0; q < nq; q++) {
+                    const int i = ss.qrow[q], oslot = ss.qslot[q];
+                    const Top2 t = sc_top2_block<U>(a, vw, ss, i, refresh);
+                    if (w == 0) { record(oslot, i, t); dense++; }
+                }
+                __syncthreads();
+            }
         }
     }
     if (lane == 0) { if (retired) atomicAdd(&sc->rnd[rc].retired, retired); if (dense) atomicAdd(&sc->dense, dense); }
@@ -824,8 +836,8 @@ __global__ void wide_sc_check(const WideArgs *__restrict__ batch, int L) {
 __global__ __launch_bounds__(HEADB) void wide_sc_wipe(const WideArgs *__restrict__ batch, int L) {
     const WideArgs a = load_wide_args(batch, blockIdx.y);
     ScCtl *sc = reinterpret_cast<ScCtl *>(a.sc);
-    const ScMem m = sc_mem(a);
-    for (int j = blockIdx.x * HEADB + threadIdx.x; j < a.n; j += gridDim.x * HEADB) m.word[L & 1][j] = ~0ull;
+    unsigned long long *wd = sc_words(a, L & 1);
+    for (int j = blockIdx.x * HEADB + threadIdx.x; j < a.n; j += gridDim.x * HEADB) wd[j] = ~0ull;
     if (blockIdx.x == 0 && threadIdx.x == 0) sc->wbase[L & 1] = (unsigned long long)L;
 }
 
@@ -837,11 +849,10 @@ __global__ void wide_sc_finish(const WideArgs *__restrict__ batch, int L) {
     ScCtl *sc = reinterpret_cast<ScCtl *>(a.sc);
     ArrHead *h = reinterpret_cast<ArrHead *>(a.misc + 384);
     const ScSlot S = sc->slot[L & 1];
-    const ScMem m = sc_mem(a);
     const int na = sc->fin_cnt, want = (int)(S.total & 1);
     const bool chain = S.mode == SC_HANDOVER;
     if (chain) {
-        const ScRec *R = m.rec[sc->fin_buf];
+        const ScRec *R = sc_recs(a, sc->fin_buf);
         int32_t *B = want ? a.act1 : a.act0;
         for (int q = threadIdx.x; q < na; q += blockDim.x) B[q] = R[q].i;
     }
