@@ -3424,7 +3424,7 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
             CYTO_HIP(hipMemsetAsync(wa.sc, 0, WIDE_SC_BYTES, stream));
             wa.scx = j.b_wide.as<char>() + scx_off;
             CYTO_HIP(hipMemsetAsync(wa.scx, 0, wide_sc_ext_bytes(n), stream));
-            CYTO_HIP(hipMemsetAsync(wa.scx, 0xFF, (((size_t)n + 63) & ~(size_t)63) * 8, stream));     // (the second buffer of bid words)
+            CYTO_HIP(hipMemsetAsync(wa.scx, 0xFF, wide_sc_ones_bytes(n), stream));     // (the machine's bid words and lowest-bid arrays)
             wa.par_groups = parg; wa.par = nullptr;
             if (parg > 0) {
                 const size_t np_ = ((size_t)n + 63) & ~(size_t)63;
@@ -3465,7 +3465,7 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
         for (int pass = 0;; pass++) {                              // the row-reduction rounds (they pause when the caches have gone stale)
             if (pass && (rc = build_caches(h_sync.data() + 1))) return rc;
             CYTO_HIP(hipMemsetAsync(d_sync.p, 0, sizeof(int32_t), stream));
-            if ((rc = wide_launch_arr(d_wa.as<WideArgs>(), nl, n, stream, pl.wide_wipe, pass > 0, d_sync.as<int32_t>(), rebuild_tramp, &build_caches))) return rc;
+            if ((rc = wide_launch_arr(d_wa.as<WideArgs>(), nl, n, stream, pl.wide_wipe, pass > 0, d_sync.as<int32_t>(), rebuild_tramp, &build_caches, nl == 1 ? &h_wa[0] : nullptr))) return rc;
             if (h_wa[0].aug_seg != 0) break;                       // (no pauses asked for: nothing to wait for)
             CYTO_HIP(hipMemcpyAsync(h_sync.data(), d_sync.p, sizeof(int32_t) * ((size_t)nl + 1), hipMemcpyDeviceToHost, stream));
             CYTO_HIP(hipStreamSynchronize(stream));

@@ -21,7 +21,7 @@ namespace cyto {
 //   seg_sync        shared by the launch, or null: [0] workgroups that asked for fresh caches (zeroed by the driver before every launch
 //                   of wide_arr / wide_aug), [1 + b] wide_arr: 1 = problem b's rounds paused; wide_aug: searches problem b still has to run
 //   sc              2 KB, zeroed by the driver: the control block of the row-reduction phase machine (lap_wide.hip: ScCtl)
-//   scx             the phase machine's own arrays (wide_sc_ext_bytes(n), 256-byte aligned; second word buffer all-ones, the rest zero):
+//   scx             the phase machine's own arrays (wide_sc_ext_bytes(n), 256-byte aligned; the first wide_sc_ones_bytes(n) all-ones, the rest zero):
 //                   lap_wide.hip: ScMem
 //   par_groups, par searches of one problem that run at once on as many workgroups (0 / 1: one at a time) and their state (lap_wide.hip: ParCtl)
 //   arr_waste       wide_arr: full-row bids (with their cache refresh) of one launch after which the list rounds pause (aug_seg == 0)
@@ -49,11 +49,12 @@ enum { WC_ROUNDS = 0, WC_BIDS, WC_RETIRED, WC_ACTIVE_LEFT, WC_FREE_ARR, WC_DENSE
 
 constexpr size_t WIDE_SC_BYTES = 2048;
 size_t wide_sc_ext_bytes(int n);
+size_t wide_sc_ones_bytes(int n);                                                      // the leading part of scx that starts all-ones
 size_t wide_aug_lds_bytes(int n);
 // phases, each one launch for the whole batch (d_args: device array of nb WideArgs)
 int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream);        // Jacobi reduction transfer (v0 snapshot in cassign)
 int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, int wipe_every, bool resume, int32_t *d_sync,
-                    int (*rebuild)(void *ctx, const int32_t *flags), void *ctx);   // rebuild: fresh row caches for the flagged problems   // Jacobi rounds of augmenting row reduction + free list
+                    int (*rebuild)(void *ctx, const int32_t *flags), void *ctx, const WideArgs *direct);   // direct: host copy of the one problem's block (nb == 1), or null   // rebuild: fresh row caches for the flagged problems   // Jacobi rounds of augmenting row reduction + free list
 int wide_launch_aug(const WideArgs *d_args, int nb, int n, hipStream_t stream, int mc_groups, int par_groups);   // shortest-path augmentation, duals, total
 size_t wide_par_state_bytes(int n, int G);                                              // control block, per-search labels / lists, claim words, change logs
 constexpr int WIDE_PAR_GMAX = 64;

@@ -122,7 +122,7 @@ __device__ __forceinline__ float rdlane(float x, int l) { return __uint_as_float
 enum { SC_LEGACY = 0, SC_EPS = 1, SC_FINAL = 2, SC_HANDOVER = 3, SC_DONE = 4 };   // modes (>= SC_HANDOVER: the machine is through)
 enum { SC_ACT_NONE = 0, SC_ACT_ROUND = 1, SC_ACT_RESET = 2 };                      // what a launch does
 // `fresh`: the list launch L reads was made by wide_sc_init (rows that have not bid yet); else its rows bid in launch L - 1
-struct ScSlot { int mode, k, rip, fresh, act; float eps; long long total, bids; };
+struct ScSlot { int mode, k, rip, fresh, act; float eps; long long total, bids; int heavy, pad_; };   // heavy: the instance bids from full rows a lot (as of the launch before: the same for every workgroup)
 struct ScRound { int cnt, retired; };   // per launch (three cells in rotation: L % 3): rows that bid in it, how many of them retired
 struct ScCtl {
     int hist[256];                 // rows per binary exponent (the exponent FIELD) of their gap u2 - u1 at the post-column-reduction prices
@@ -140,6 +140,7 @@ static_assert(sizeof(ScCtl) <= 2048, "control block of the row-reduction phase")
 // the constants of the restatement (oracle/jv_oracle.h: JV_WIDE_*)
 constexpr int SC_K0 = 8, SC_NPH = 16, SC_PHCAP = 1024, SC_EMULT = 3, SC_ESTEP = 1;
 constexpr int SC_STOP_FINAL = 16;       // the final eps = 0 phase ends at min(wide_stop(n), 16) active rows (JV_WIDE_STOP_FINAL)
+constexpr int SC_SMALL = 1024;         // launches with at most so many bids to resolve give every bid a wave of its own (a matter of speed only)
 constexpr int SC_COARSE = 4;           // phases whose full-row bids leave the row caches alone (a matter of speed only)
 __host__ __device__ inline int wide_stop(int n) { return n / 128 < 8 ? 8 : (n / 128 > 64 ? 64 : n / 128); }
 // the next representable value below x (+0 and -0 are one value): oracle pred_
@@ -414,7 +415,7 @@ constexpr size_t SC_SHARED_BYTES = (sizeof(ScShared) + 15) / 16 * 16;
 // Where a launch's bids read prices and owners: the bid words of the launch before (fresh: that column's winner) or the arrays.
 struct ScView {
     const unsigned long long *wsrc;   // bid words of launch L - 1 (null: none -- the first launch, a phase boundary)
-    const uint32_t *bm;               // bitmap of the columns bid for in launch L - 1 (full-row sweeps; null with wsrc)
+    const uint32_t *pm;               // per column the lowest price bid in launch L - 1 (ordered; all-ones: no bid; null with wsrc)
     uint32_t tg;                      // tag of launch L - 1 in those words
     bool own_none;                    // a phase boundary: every column is unassigned (the arrays are being cleared by this very launch)
 };
@@ -448,17 +449,20 @@ __device__ __forceinline__ void sc_decide(const Top2 &t, float eps, int &jt, flo
     jt = uni(jt); pt = uni(pt); ct = uni(ct); i0 = uni(i0);
 }
 // one wave: the top-2 from the row's cache (lane = entry); false: the cache cannot certify it.  The prices of the 63 cached columns
-// are gathered; which of them received a bid in the launch before says the bitmap (a few KB that every wave reads: it stays in the
-// CU's cache) -- only those lanes ask for their column's bid word (gathering word and owner for all 63 columns tripled the lines a
+// are gathered, and with them the launch-before's lowest bids on those columns (all-ones: none) -- only the lanes that find one ask
+// for their column's bid word (gathering word and owner for all 63 columns tripled the lines a
 // bid pulls in: a launch with 8 000 bids took 60 us); the owners of the two columns that matter are read last.
+// GOWN: the owners of all cached columns are gathered with the prices (a launch with few bids is a chain of round trips: one less)
+template <bool GOWN = false>
 __device__ __forceinline__ bool sc_top2_cached(const WideArgs &a, const ScView &vw, int lane, uint32_t col, float val, Top2 &t) {
     const float tau = rdlane(val, KCU);
     const bool valid = lane < KCU && col != COLSENT;
     float vj = valid ? a.v[col] : 0.0f;
     int ow = -2;                                                  // -2: the column's owner is the array's
-    if (vw.bm) {
-        const uint32_t bw = valid ? vw.bm[col >> 5] : 0u;
-        if ((bw >> (col & 31)) & 1u) {
+    if (GOWN) ow = valid ? a.colsol[col] : -1;
+    if (vw.pm) {
+        const uint32_t pm = valid ? vw.pm[col] : 0xFFFFFFFFu;
+        if (pm != 0xFFFFFFFFu) {
             const unsigned long long w = vw.wsrc[col];
             if (sc_word_fresh(vw, w)) { vj = sc_word_price(w); ow = (int)((uint32_t)w & 0xFFFFFu); }
         }
@@ -473,7 +477,7 @@ __device__ __forceinline__ bool sc_top2_cached(const WideArgs &a, const ScView &
     t.u1 = ord2f(k1); t.j1 = (int)rdlane(col, l1); t.c1 = rdlane(val, l1); t.vj1 = rdlane(vj, l1); t.o1 = (int)rdlane((uint32_t)ow, l1);
     t.u2 = ord2f(k2); t.j2 = (int)rdlane(col, l2); t.c2 = rdlane(val, l2); t.vj2 = rdlane(vj, l2); t.o2 = (int)rdlane((uint32_t)ow, l2);
     if (vw.own_none) { t.o1 = -1; t.o2 = -1; }
-    else {
+    else if (!GOWN) {
         const int c1 = a.colsol[t.j1], c2 = a.colsol[t.j2];        // (both requested together)
         if (t.o1 == -2) t.o1 = uni(c1);
         if (t.o2 == -2) t.o2 = uni(c2);
@@ -481,34 +485,31 @@ __device__ __forceinline__ bool sc_top2_cached(const WideArgs &a, const ScView &
     return true;
 }
 // the whole workgroup (HEADB threads): f(column, cost, price) for every column of the row, 16 bytes of row and prices per lane and step;
-// a column flagged in the view's bitmap (it received a bid in the launch before) takes its price from its fresh bid word
+// a column that received a bid in the launch before has its price in that launch's array of lowest bids (the lowest bid won), read
+// alongside: nothing dependent, 12 bytes per column instead of 8
 template <int U, typename F> __device__ __forceinline__ void block_row_sweep(const float *__restrict__ row, const float *__restrict__ v, const ScView &vw, int n, F &&f) {
     const int nq = (n + 3) >> 2;
     const float4 *__restrict__ r4 = reinterpret_cast<const float4 *>(row);
     const float4 *__restrict__ v4 = reinterpret_cast<const float4 *>(v);      // (16-byte aligned, followed by u in the workspace: whole quads stay in range)
+    const uint4 *__restrict__ m4 = reinterpret_cast<const uint4 *>(vw.pm);    // (padded to a multiple of 64 columns)
     for (int q0 = threadIdx.x; q0 < nq; q0 += HEADB * U) {
         float4 x[U], p[U];
-        uint32_t fl[U];
+        uint4 m[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int q = q0 + HEADB * u;
             x[u] = q < nq ? r4[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             p[u] = q < nq ? v4[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            fl[u] = (vw.bm && q < nq) ? ((vw.bm[q >> 3] >> ((q & 7) * 4)) & 0xFu) : 0u;       // the quad's four bits
+            m[u] = (m4 && q < nq) ? m4[q] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int q = q0 + HEADB * u, c = q * 4;
             if (q >= nq) continue;
-            if (fl[u]) {                                                          // (rare: a few hundred columns of the row at most)
-                float *pp = reinterpret_cast<float *>(&p[u]);
-                for (int e = 0; e < 4; e++)
-                    if (((fl[u] >> e) & 1u) && c + e < n) { const unsigned long long w = vw.wsrc[c + e]; if (sc_word_fresh(vw, w)) pp[e] = sc_word_price(w); }
-            }
-            f(c, x[u].x, p[u].x);
-            if (c + 1 < n) f(c + 1, x[u].y, p[u].y);
-            if (c + 2 < n) f(c + 2, x[u].z, p[u].z);
-            if (c + 3 < n) f(c + 3, x[u].w, p[u].w);
+            f(c, x[u].x, m[u].x != 0xFFFFFFFFu ? ord2f(m[u].x) : p[u].x);
+            if (c + 1 < n) f(c + 1, x[u].y, m[u].y != 0xFFFFFFFFu ? ord2f(m[u].y) : p[u].y);
+            if (c + 2 < n) f(c + 2, x[u].z, m[u].z != 0xFFFFFFFFu ? ord2f(m[u].z) : p[u].z);
+            if (c + 3 < n) f(c + 3, x[u].w, m[u].w != 0xFFFFFFFFu ? ord2f(m[u].w) : p[u].w);
         }
     }
 }
@@ -596,17 +597,17 @@ __device__ __forceinline__ bool bid_won(unsigned long long word, int row) { retu
 
 struct ArrHead { int cnt[2]; int started, free_cr; long long round, bids; int retired, dense; int done, launches; long long list_rounds; int no_more, pad_; };
 
-// ---- the machine's memory beyond the driver's arrays (WideArgs.scx, wide_sc_ext_bytes(n) bytes, 256-byte aligned): the second buffer of
-// bid words (the first is a.bid), the bid records of a launch (two buffers by the launch's parity: 16 bytes { row, column or -1,
-// price, owner it would displace } and the raw cost of the entry), three bitmaps of the columns bid for.
+// ---- the machine's memory beyond the driver's arrays (WideArgs.scx, wide_sc_ext_bytes(n) bytes, 256-byte aligned): the two buffers of
+// bid words and three arrays of the lowest price bid per column in a launch (ordered; all of them all-ones at the start: the first
+// wide_sc_ones_bytes(n) bytes), the bid records of a launch (two buffers by the launch's parity: 16 bytes { row, column or -1, price,
+// owner it would displace } and the raw cost of the entry).
 struct ScRec { int i, jt; float pt; int i0; };
 // (accessors instead of a table of pointers: a table indexed by the launch's parity would live in scratch memory)
-__host__ __device__ inline size_t sc_nw32_pad(int n) { return (((size_t)n + 31) / 32 + 63) & ~(size_t)63; }
-__device__ __forceinline__ size_t sc_np(const WideArgs &a) { return ((size_t)a.n + 63) & ~(size_t)63; }
-__device__ __forceinline__ unsigned long long *sc_words(const WideArgs &a, int b) { return b ? reinterpret_cast<unsigned long long *>(a.scx) : a.bid; }
-__device__ __forceinline__ ScRec *sc_recs(const WideArgs &a, int b) { return reinterpret_cast<ScRec *>(a.scx + sc_np(a) * (8 + 16 * (size_t)b)); }
-__device__ __forceinline__ float *sc_rcts(const WideArgs &a, int b) { return reinterpret_cast<float *>(a.scx + sc_np(a) * (40 + 4 * (size_t)b)); }
-__device__ __forceinline__ uint32_t *sc_bitmap(const WideArgs &a, int k) { return reinterpret_cast<uint32_t *>(a.scx + sc_np(a) * 48) + sc_nw32_pad(a.n) * (size_t)k; }
+__host__ __device__ inline size_t sc_np(int n) { return ((size_t)n + 63) & ~(size_t)63; }
+__device__ __forceinline__ unsigned long long *sc_words(char *scx, int n, int b) { return reinterpret_cast<unsigned long long *>(scx + sc_np(n) * 8 * (size_t)b); }
+__device__ __forceinline__ uint32_t *sc_pmin(char *scx, int n, int k) { return reinterpret_cast<uint32_t *>(scx + sc_np(n) * (16 + 4 * (size_t)k)); }
+__device__ __forceinline__ ScRec *sc_recs(char *scx, int n, int b) { return reinterpret_cast<ScRec *>(scx + sc_np(n) * (28 + 16 * (size_t)b)); }
+__device__ __forceinline__ float *sc_rcts(char *scx, int n, int b) { return reinterpret_cast<float *>(scx + sc_np(n) * (60 + 4 * (size_t)b)); }
 
 __device__ __forceinline__ float sc_eps_of(const ScCtl *sc, int k) {       // eps of phase k, 0 = there is no such phase
     if (k >= SC_NPH) return 0.0f;
@@ -663,7 +664,7 @@ __global__ __launch_bounds__(HEADB) void wide_sc_init(const WideArgs *__restrict
         sc->e0 = me > 0 ? (me + SC_EMULT > 254 ? 254 : me + SC_EMULT) : 0;
         sc->epsmin = __uint_as_float(sc->vmaxbits) * 1.1920928955078125e-07f;
         sc->stop = wide_stop(n);
-        ScSlot S; S.mode = SC_LEGACY; S.k = 0; S.rip = 0; S.fresh = 1; S.act = SC_ACT_NONE; S.eps = 0.0f; S.total = 0; S.bids = 0;
+        ScSlot S; S.mode = SC_LEGACY; S.k = 0; S.rip = 0; S.fresh = 1; S.act = SC_ACT_NONE; S.eps = 0.0f; S.total = 0; S.bids = 0; S.heavy = 0; S.pad_ = 0;
         sc->slot[0] = S;
     }
 }
@@ -673,21 +674,30 @@ __global__ __launch_bounds__(HEADB) void wide_sc_init(const WideArgs *__restrict
 //   RESET  a phase begins (those bids are dropped): everything unassigned, every row bids;
 //   none   the machine is through (those bids are dropped; their rows are the list it leaves) --
 // or, in launch 0, the first bids of the rows the column reduction left free.
-template <int U>
-__global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restrict__ batch, int L) {
+template <int U, bool DIRECT>
+__global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restrict__ batch, int L, int n_arg, char *sc_direct, char *scx_direct) {
     extern __shared__ __align__(16) unsigned char w_smem[];
+    // DIRECT (one problem): the control block, the machine's arrays and n are kernel arguments, so the state and -- unconditionally, a
+    // wave per slot -- the record a launch with few bids will resolve are requested before the argument block has arrived
     const WideArgs a = load_wide_args(batch, blockIdx.y);
-    ScCtl *sc = reinterpret_cast<ScCtl *>(a.sc);
+    const int n = DIRECT ? n_arg : a.n;
+    ScCtl *sc = reinterpret_cast<ScCtl *>(DIRECT ? sc_direct : (char *)a.sc);
+    char *scx = DIRECT ? scx_direct : (char *)a.scx;
+    const int lane = threadIdx.x & 63, w = uni((int)(threadIdx.x >> 6));
+    const int pb = (L + 1) & 1, cb = L & 1;                      // record / word buffers: the launch before, this launch
+    const int rp = (L + 2) % 3, rc = L % 3, rn = (L + 1) % 3;    // per-launch cells and bitmaps: the launch before, this one, the next
+    const ScRec *rsrc = sc_recs(scx, n, pb);
+    const float *csrc = sc_rcts(scx, n, pb);
+    const int slot_s = (int)blockIdx.x * (HEADB / 64) + w;
+    int4 rr_s = make_int4(-1, -1, 0, -1);
+    float rct_s = 0.0f;
+    if (slot_s < n) { rr_s = *reinterpret_cast<const int4 *>(rsrc + slot_s); rct_s = csrc[slot_s]; }
     const ScSlot S = sc->slot[L & 1];
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
     if (S.mode >= SC_HANDOVER) {                                 // through: the state stays (both slots)
         if (lead && sc->slot[(L + 1) & 1].mode != S.mode) { ScSlot N = S; N.act = SC_ACT_NONE; sc->slot[(L + 1) & 1] = N; }
         return;
     }
-    const int n = a.n;
-    const int pb = (L + 1) & 1, cb = L & 1;                      // record / word buffers: the launch before, this launch
-    const int rp = (L + 2) % 3, rc = L % 3, rn = (L + 1) % 3;    // per-launch cells and bitmaps: the launch before, this one, the next
-    const int nw32 = (n + 31) / 32;
     const int np = sc->rnd[rp].cnt;                              // rows that bid in launch L - 1 (launch 0: rows on wide_sc_init's list)
     const bool first = S.fresh != 0;
     ScSlot N;
@@ -695,6 +705,7 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
     const int act = N.act;
     const bool through = !first && act == SC_ACT_NONE;
     if (lead) {
+        N.heavy = (long long)sc->dense * 32 > N.bids ? 1 : 0;
         sc->slot[(L + 1) & 1] = N;
         sc->rnd[rn].cnt = 0; sc->rnd[rn].retired = 0;
         if (first) { sc->free_cr = np; sc->rnd[rc].cnt = np; }
@@ -704,26 +715,27 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
     }
     if (through) return;
     {
-        uint32_t *bmn = sc_bitmap(a, rn);                         // the next launch's bitmap starts empty
-        for (int q = blockIdx.x * HEADB + threadIdx.x; q < nw32; q += gridDim.x * HEADB) bmn[q] = 0u;
+        uint4 *pmn = reinterpret_cast<uint4 *>(sc_pmin(scx, n, rn));      // the next launch's lowest bids start empty
+        const int nq4 = (n + 3) >> 2;
+        for (int q = blockIdx.x * HEADB + threadIdx.x; q < nq4; q += gridDim.x * HEADB) pmn[q] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
     }
     if (act == SC_ACT_RESET)
         for (int i = blockIdx.x * HEADB + threadIdx.x; i < n; i += gridDim.x * HEADB) { a.rowsol[i] = -1; a.colsol[i] = -1; }
-    const int lane = threadIdx.x & 63, w = uni((int)(threadIdx.x >> 6));
+    // few bids to resolve: a wave per bid (below); else tiles
+    const bool small = act == SC_ACT_ROUND && np <= SC_SMALL && np <= (int)gridDim.x * (HEADB / 64);
+    if (small && (int)blockIdx.x * (HEADB / 64) >= np) return;
     ScShared &ss = *reinterpret_cast<ScShared *>(w_smem);
-    if (threadIdx.x == 0) { ss.nq = 0; ss.fill_ = 0; }
+    if (threadIdx.x == 0) { ss.nq = 0; ss.fill_ = 0; ss.cnt = 0; }
     __syncthreads();
     ScView vw;
-    vw.wsrc = act == SC_ACT_ROUND ? sc_words(a, pb) : nullptr;
-    vw.bm = act == SC_ACT_ROUND ? sc_bitmap(a, rp) : nullptr;
+    vw.wsrc = act == SC_ACT_ROUND ? sc_words(scx, n, pb) : nullptr;
+    vw.pm = act == SC_ACT_ROUND ? sc_pmin(scx, n, rp) : nullptr;
     vw.tg = ~(uint32_t)((long long)(L - 1) - (long long)sc->wbase[pb]) & 0xFFFu;
     vw.own_none = act == SC_ACT_RESET;
-    unsigned long long *wdst = sc_words(a, cb);
-    uint32_t *bmd = sc_bitmap(a, rc);
-    ScRec *rdst = sc_recs(a, cb);
-    float *cdst = sc_rcts(a, cb);
-    const ScRec *rsrc = sc_recs(a, pb);
-    const float *csrc = sc_rcts(a, pb);
+    unsigned long long *wdst = sc_words(scx, n, cb);
+    uint32_t *pmd = sc_pmin(scx, n, rc);
+    ScRec *rdst = sc_recs(scx, n, cb);
+    float *cdst = sc_rcts(scx, n, cb);
     const long long tag = (long long)L - (long long)sc->wbase[cb];
     const float eps = N.eps;
     // a coarse phase (eps_k many times the span of a row's 63 cached columns) moves the prices past every cache within a bid or two:
@@ -738,74 +750,119 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
             if (jt < 0) retired++;
             else {
                 atomicMin(wdst + jt, bidkey(tag, pt, i));
-                atomicOr(bmd + (jt >> 5), 1u << (jt & 31));
+                atomicMin(pmd + jt, f2ord(pt));
             }
             *reinterpret_cast<int4 *>(rdst + oslot) = make_int4(i, jt, __float_as_int(pt), i0);
             cdst[oslot] = ct;
         }
     };
-    // Every workgroup takes a contiguous run of the work (bids to resolve; rows at a phase boundary) in tiles of HEADB.  ROUND, per tile:
-    // first a THREAD per bid resolves it (record and word: coalesced / one gather; a winner's thread writes price, owner, displaced
-    // owner) and the rows that bid next are gathered in LDS -- their records' slots come from ONE atomic on the launch's counter per
-    // tile (a wave per bid with an atomic each: 20 000 atomics on one address made a phase's first launches 130-170 us) -- then a
-    // WAVE per gathered row makes its bid.
-    const int nwork = act == SC_ACT_RESET ? n : np;
-    const int chunk = std::max(HEADB / 64, (nwork + (int)gridDim.x - 1) / (int)gridDim.x);
-    const int c_lo = std::min(nwork, (int)blockIdx.x * chunk), c_hi = std::min(nwork, c_lo + chunk);
-    for (int t0 = c_lo; t0 < c_hi; t0 += HEADB) {
-        const int tn = std::min(HEADB, c_hi - t0);               // work items of this tile
-        int nlist = tn;                                           // rows that bid out of this tile
-        if (act == SC_ACT_ROUND) {
-            if (threadIdx.x == 0) ss.cnt = 0;
-            __syncthreads();
-            int nxt = -1;
-            if ((int)threadIdx.x < tn) {
-                const int slot = t0 + (int)threadIdx.x;
-                const int4 rr = *reinterpret_cast<const int4 *>(rsrc + slot);
-                if (rr.y >= 0) {                                    // (a retired row stays free and bids no more)
-                    const unsigned long long word = vw.wsrc[rr.y];
-                    const float rct = csrc[slot];
-                    if (bid_won(word, rr.x)) {
-                        a.v[rr.y] = __int_as_float(rr.z); a.colsol[rr.y] = rr.x; a.rowsol[rr.x] = rr.y; a.cassign[rr.y] = rct;
-                        if (rr.w >= 0) a.rowsol[rr.w] = -1;
-                        nxt = rr.w;                                 // the displaced owner bids next (or nobody)
-                    } else nxt = rr.x;
-                }
+    // rows whose caches could not certify (queued in LDS): the whole workgroup reads each in full, one after the other
+    auto full_rows = [&](int obase) {
+        __syncthreads();
+        const int nq = ss.nq;
+        __syncthreads();
+        if (nq) {
+            if (threadIdx.x == 0) ss.nq = 0;
+            for (int q = 0; q < nq; q++) {
+                const int i = ss.qrow[q], oslot = obase + ss.qslot[q];
+                const Top2 t = sc_top2_block<U>(a, vw, ss, i, refresh);
+                if (w == 0) { record(oslot, i, t); dense++; }
             }
-            const uint64_t mb = __ballot(nxt >= 0);
-            int wbase = 0;
-            if (lane == 0 && mb) wbase = atomicAdd(&ss.cnt, __popcll(mb));
-            wbase = __shfl(wbase, 0);
-            const int lpos = wbase + __popcll(mb & lanemask_lt());
-            if (nxt >= 0) ss.lrow[lpos] = nxt;
-            __syncthreads();
-            nlist = ss.cnt;
-            if (threadIdx.x == 0 && nlist) ss.obase = atomicAdd(ocnt, nlist);
             __syncthreads();
         }
-        const int obase = act == SC_ACT_ROUND ? ss.obase : t0;
-        for (int e0 = 0; e0 < nlist; e0 += HEADB / 64) {         // (the same trips for every wave of the workgroup)
-            const int e = e0 + w;
-            if (e < nlist) {
-                const int i = act == SC_ACT_ROUND ? uni(ss.lrow[e]) : (act == SC_ACT_RESET ? t0 + e : uni(a.act0[t0 + e]));
-                const int oslot = obase + e;
-                const uint32_t col = a.cache_col[(int64_t)i * KC + lane];
-                const float val = a.cache_val[(int64_t)i * KC + lane];
-                Top2 t;
-                if (sc_top2_cached(a, vw, lane, col, val, t)) record(oslot, i, t);
-                else if (lane == 0) { const int q = atomicAdd(&ss.nq, 1); ss.qrow[q] = i; ss.qslot[q] = oslot; }
-            }
-            __syncthreads();
-            const int nq = ss.nq;
-            __syncthreads();
-            if (nq) {                                              // rows whose caches could not certify: the whole workgroup, one after the other
-                if (threadIdx.x == 0) ss.nq = 0;
-                for (int q = 0; q < nq; q++) {
-                    const int i = ss.qrow[q], oslot = ss.qslot[q];
-                    const Top2 t = sc_top2_block<U>(a, vw, ss, i, refresh);
-                    if (w == 0) { record(oslot, i, t); dense++; }
+    };
+    if (small) {
+        // ---- a wave per bid of the launch before.  Everything the outcome decides between is requested with the word that decides
+        // it: the caches of the row (it bids again if it lost) and of the owner it displaces (who bids if it won); the slot of the
+        // new record comes from one atomic per workgroup that is in flight while the bid is made.
+        const int ri = uni(rr_s.x), rj = uni(rr_s.y), r0 = uni(rr_s.w);
+        int nxt = -1, rank = 0;
+        uint32_t col = COLSENT; float val = 0.0f;
+        if (slot_s < np && rj >= 0) {                               // (a retired row stays free and bids no more)
+            const unsigned long long word = vw.wsrc[rj];
+            const uint32_t colA = a.cache_col[(int64_t)ri * KC + lane];
+            const float valA = a.cache_val[(int64_t)ri * KC + lane];
+            uint32_t colB = COLSENT; float valB = 0.0f;
+            if (r0 >= 0) { colB = a.cache_col[(int64_t)r0 * KC + lane]; valB = a.cache_val[(int64_t)r0 * KC + lane]; }
+            if (bid_won(uni(word), ri)) {
+                if (lane == 0) {
+                    a.v[rj] = __int_as_float(rr_s.z); a.colsol[rj] = ri; a.rowsol[ri] = rj; a.cassign[rj] = rct_s;
+                    if (r0 >= 0) a.rowsol[r0] = -1;
                 }
+                nxt = r0; col = colB; val = valB;
+            } else { nxt = ri; col = colA; val = valA; }
+            if (nxt >= 0) { if (lane == 0) rank = atomicAdd(&ss.cnt, 1); rank = uni(rank); }
+        }
+        __syncthreads();
+        int obase_r = 0;
+        const int nl = ss.cnt;
+        if (threadIdx.x == 0 && nl) obase_r = atomicAdd(ocnt, nl);
+        Top2 t;
+        bool have = false;
+        if (nxt >= 0) {
+            have = sc_top2_cached<true>(a, vw, lane, col, val, t);
+            if (!have && lane == 0) { const int q = atomicAdd(&ss.nq, 1); ss.qrow[q] = nxt; ss.qslot[q] = rank; }
+        }
+        if (threadIdx.x == 0) ss.obase = obase_r;
+        __syncthreads();
+        const int obase = ss.obase;
+        if (have) record(obase + rank, nxt, t);
+        full_rows(obase);
+    } else {
+        // ---- every workgroup takes a contiguous run of the work (bids to resolve; rows at a phase boundary) in tiles of HEADB.
+        // ROUND, per tile: first a THREAD per bid resolves it (record and word: coalesced / one gather; a winner's thread writes price,
+        // owner, displaced owner) and the rows that bid next are gathered in LDS -- their records' slots come from ONE atomic on the
+        // launch's counter per tile (a wave per bid with an atomic each: 20 000 atomics on one address made a phase's first launches
+        // 130-170 us) -- then a WAVE per gathered row makes its bid.
+        const int nwork = act == SC_ACT_RESET ? n : np;
+        // (a run of at least 8 bids -- fewer atomics on the launch's counter -- unless the instance bids from full rows a lot: those a
+        //  workgroup reads one after the other, and the launch waits for the workgroup with the most of them)
+        const bool heavy = S.heavy != 0;
+        const int chunk = std::max(act == SC_ACT_ROUND && !heavy ? 8 : HEADB / 64, (nwork + (int)gridDim.x - 1) / (int)gridDim.x);
+        const int c_lo = std::min(nwork, (int)blockIdx.x * chunk), c_hi = std::min(nwork, c_lo + chunk);
+        for (int t0 = c_lo; t0 < c_hi; t0 += HEADB) {
+            const int tn = std::min(HEADB, c_hi - t0);           // work items of this tile
+            int nlist = tn;                                       // rows that bid out of this tile
+            if (act == SC_ACT_ROUND) {
+                if (threadIdx.x == 0) ss.cnt = 0;
                 __syncthreads();
+                int nxt = -1;
+                if ((int)threadIdx.x < tn) {
+                    const int slot = t0 + (int)threadIdx.x;
+                    const int4 rr = *reinterpret_cast<const int4 *>(rsrc + slot);
+                    if (rr.y >= 0) {                                // (a retired row stays free and bids no more)
+                        const unsigned long long word = vw.wsrc[rr.y];
+                        const float rct = csrc[slot];
+                        if (bid_won(word, rr.x)) {
+                            a.v[rr.y] = __int_as_float(rr.z); a.colsol[rr.y] = rr.x; a.rowsol[rr.x] = rr.y; a.cassign[rr.y] = rct;
+                            if (rr.w >= 0) a.rowsol[rr.w] = -1;
+                            nxt = rr.w;                             // the displaced owner bids next (or nobody)
+                        } else nxt = rr.x;
+                    }
+                }
+                const uint64_t mb = __ballot(nxt >= 0);
+                int wbase = 0;
+                if (lane == 0 && mb) wbase = atomicAdd(&ss.cnt, __popcll(mb));
+                wbase = __shfl(wbase, 0);
+                const int lpos = wbase + __popcll(mb & lanemask_lt());
+                if (nxt >= 0) ss.lrow[lpos] = nxt;
+                __syncthreads();
+                nlist = ss.cnt;
+                if (threadIdx.x == 0 && nlist) ss.obase = atomicAdd(ocnt, nlist);
+                __syncthreads();
+            }
+            const int obase = act == SC_ACT_ROUND ? ss.obase : t0;
+            for (int e0 = 0; e0 < nlist; e0 += HEADB / 64) {     // (the same trips for every wave of the workgroup)
+                const int e = e0 + w;
+                if (e < nlist) {
+                    const int i = act == SC_ACT_ROUND ? uni(ss.lrow[e]) : (act == SC_ACT_RESET ? t0 + e : uni(a.act0[t0 + e]));
+                    const uint32_t col = a.cache_col[(int64_t)i * KC + lane];
+                    const float val = a.cache_val[(int64_t)i * KC + lane];
+                    Top2 t;
+                    if (sc_top2_cached(a, vw, lane, col, val, t)) record(obase + e, i, t);
+                    else if (lane == 0) { const int q = atomicAdd(&ss.nq, 1); ss.qrow[q] = i; ss.qslot[q] = e; }
+                }
+                full_rows(obase);
             }
         }
     }
@@ -836,7 +893,7 @@ __global__ void wide_sc_check(const WideArgs *__restrict__ batch, int L) {
 __global__ __launch_bounds__(HEADB) void wide_sc_wipe(const WideArgs *__restrict__ batch, int L) {
     const WideArgs a = load_wide_args(batch, blockIdx.y);
     ScCtl *sc = reinterpret_cast<ScCtl *>(a.sc);
-    unsigned long long *wd = sc_words(a, L & 1);
+    unsigned long long *wd = sc_words((char *)a.scx, a.n, L & 1);
     for (int j = blockIdx.x * HEADB + threadIdx.x; j < a.n; j += gridDim.x * HEADB) wd[j] = ~0ull;
     if (blockIdx.x == 0 && threadIdx.x == 0) sc->wbase[L & 1] = (unsigned long long)L;
 }
@@ -852,7 +909,7 @@ __global__ void wide_sc_finish(const WideArgs *__restrict__ batch, int L) {
     const int na = sc->fin_cnt, want = (int)(S.total & 1);
     const bool chain = S.mode == SC_HANDOVER;
     if (chain) {
-        const ScRec *R = sc_recs(a, sc->fin_buf);
+        const ScRec *R = sc_recs((char *)a.scx, a.n, sc->fin_buf);
         int32_t *B = want ? a.act1 : a.act0;
         for (int q = threadIdx.x; q < na; q += blockDim.x) B[q] = R[q].i;
     }
@@ -2194,9 +2251,10 @@ __global__ __launch_bounds__(WT) void wide_aug_mc(const WideArgs *__restrict__ b
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+size_t wide_sc_ones_bytes(int n) { return (((size_t)n + 63) & ~(size_t)63) * (2 * 8 + 3 * 4); }
 size_t wide_sc_ext_bytes(int n) {
     const size_t np = ((size_t)n + 63) & ~(size_t)63;
-    return np * (8 + 2 * 16 + 2 * 4) + 3 * sc_nw32_pad(n) * 4;
+    return np * (2 * 8 + 3 * 4 + 2 * 16 + 2 * 4);
 }
 
 int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream) {
@@ -2207,7 +2265,7 @@ int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream) {
 }
 
 int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, int wipe_every, bool resume, int32_t *d_sync,
-                    int (*rebuild)(void *ctx, const int32_t *flags), void *ctx) {
+                    int (*rebuild)(void *ctx, const int32_t *flags), void *ctx, const WideArgs *direct) {
     // The phase machine on the whole chip (one launch per round), in groups of launches: after a group the driver asks which problems
     // are not through (one small read) and rebuilds the row caches of those whose floors have gone stale; then wide_arr -- one
     // workgroup per problem -- for the chain rounds of the problems that did not scale (<= 64 active rows) and the free lists.
@@ -2227,7 +2285,11 @@ int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, i
         const int bxr = std::max(1, std::min((n + HEADB - 1) / HEADB, 2048 / std::max(1, std::min(nb, 16))));
         // (quads of a full-row bid's sweep in flight per lane: developer knob CYTO_BID_UNROLL, tools/exp)
         const bool deep = CYTO_KNOB("CYTO_BID_UNROLL").set && CYTO_KNOB("CYTO_BID_UNROLL").value == 8;
-        void (*roundk)(const WideArgs *, int) = deep ? wide_sc_round<8> : wide_sc_round<4>;
+        // (one problem: the control block and the machine's arrays are kernel arguments -- one dependent load less per launch)
+        char *sc_direct = nullptr, *scx_direct = nullptr;
+        if (nb == 1 && direct) { sc_direct = direct->sc; scx_direct = direct->scx; }
+        void (*roundk)(const WideArgs *, int, int, char *, char *) =
+            sc_direct ? (deep ? wide_sc_round<8, true> : wide_sc_round<4, true>) : (deep ? wide_sc_round<8, false> : wide_sc_round<4, false>);
         if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(roundk)))) return rc;
         if (CYTO_KNOB("CYTO_SC_DEBUG").set) { const hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[sc] before init: %s\n", hipGetErrorString(e_)); }
         hipLaunchKernelGGL(wide_sc_init, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args);
@@ -2237,7 +2299,7 @@ int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, i
         for (;;) {
             for (int g = 0; g < group; g++, L++) {
                 if ((L >> 1) > 0 && (L >> 1) % wipe == 0) hipLaunchKernelGGL(wide_sc_wipe, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args, L);
-                hipLaunchKernelGGL(roundk, dim3(bx, nb), dim3(HEADB), SC_SHARED_BYTES, stream, d_args, L);
+                hipLaunchKernelGGL(roundk, dim3(bx, nb), dim3(HEADB), SC_SHARED_BYTES, stream, d_args, L, n, sc_direct, scx_direct);
                 if (CYTO_KNOB("CYTO_SC_DEBUG").set) { const hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[sc] launch %d: %s\n", L, hipGetErrorString(e_)); }
             }
             if (!d_sync) return CYTO_ERR_INTERNAL;

@@ -44,8 +44,15 @@ def main():
             wall = time.time() - t
             inf = g["info"]
             same = np.array_equal(g["colsol"], d["colsol"])
+            # the wide restatement's golden: duals and row solution by their hashes (a schedule-dependent kernel shows here first)
+            wpath = os.path.join(GOLD, f"large_{tag}_wide.npz")
+            duals = "n/a"
+            if mode == 2 and rounds == 0 and os.path.exists(wpath):
+                import hashlib
+                dw = np.load(wpath)
+                duals = all(hashlib.sha256(np.ascontiguousarray(g[k]).tobytes()).hexdigest() == str(dw[k + "_sha256"]) for k in ("u", "v", "rowsol"))
             spot = same if loc is None else np.array_equal(loc[g["colsol"]], loc[d["colsol"]])
-            print(f"{tag} mode={mode} rep={rep}: colsol==golden {same} spot-level {spot} total diff {g['total'] - float(d['total']):.3e} "
+            print(f"{tag} mode={mode} rep={rep}: colsol==golden {same} duals==wide-golden {duals} spot-level {spot} total diff {g['total'] - float(d['total']):.3e} "
                   f"ms colred={inf.ms_colred:.2f} cache={inf.ms_cache:.2f} arr={inf.ms_arr:.2f} aug={inf.ms_aug:.2f} total={inf.ms_total:.2f} wall={wall * 1e3:.1f} | "
                   f"free={inf.free_after_arr2} rounds={inf.wide_rounds} bids={inf.scans_arr} retired={inf.wide_retired} relax={inf.scans_aug_relax} "
                   f"settled={inf.wide_aug_settled} aug_rounds={inf.wide_aug_rounds} dense=({inf.wide_dense_arr},{inf.wide_dense_aug}) launches={inf.wide_aug_launches} "
