@@ -32,6 +32,7 @@
 #include "lap_dev.h"
 #include "lap_wide.h"
 #include <algorithm>
+#include <chrono>
 
 namespace cyto {
 
@@ -133,6 +134,7 @@ struct ScCtl {
     ScRound rnd[3];
     int retired, dense, dense_mark, phases, free_cr;
     int fin_buf, fin_cnt;          // where the machine stopped: the record buffer and the length of the list it leaves
+    int want_mark, pad2_;          // the launch at which fresh row caches were last asked for
     unsigned long long wbase[2];   // per bid-word buffer: the launch at which it was last wiped (the words' 12-bit tag is relative to it)
     ScSlot slot[2];                // launch L reads slot[L & 1] and leaves slot[(L + 1) & 1]
 };
@@ -140,7 +142,8 @@ static_assert(sizeof(ScCtl) <= 2048, "control block of the row-reduction phase")
 // the constants of the restatement (oracle/jv_oracle.h: JV_WIDE_*)
 constexpr int SC_K0 = 8, SC_NPH = 16, SC_PHCAP = 1024, SC_EMULT = 3, SC_ESTEP = 1;
 constexpr int SC_STOP_FINAL = 16;       // the final eps = 0 phase ends at min(wide_stop(n), 16) active rows (JV_WIDE_STOP_FINAL)
-constexpr int SC_SMALL = 1024;         // launches with at most so many bids to resolve give every bid a wave of its own (a matter of speed only)
+constexpr int SC_UNROLL = 4;           // quads of a full-row sweep in flight per lane (2: 67 registers, 7 waves per SIMD; 3: 79, 6; 4: 107, 4 -- and 4 is the fastest: gpurun_out/r05h)
+constexpr int SC_SMALL = 2048;         // launches with at most so many bids to resolve give every bid a wave of its own (a matter of speed only)
 constexpr int SC_COARSE = 4;           // phases whose full-row bids leave the row caches alone (a matter of speed only)
 __host__ __device__ inline int wide_stop(int n) { return n / 128 < 8 ? 8 : (n / 128 > 64 ? 64 : n / 128); }
 // the next representable value below x (+0 and -0 are one value): oracle pred_
@@ -675,7 +678,7 @@ __global__ __launch_bounds__(HEADB) void wide_sc_init(const WideArgs *__restrict
 //   none   the machine is through (those bids are dropped; their rows are the list it leaves) --
 // or, in launch 0, the first bids of the rows the column reduction left free.
 template <int U, bool DIRECT>
-__global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restrict__ batch, int L, int n_arg, char *sc_direct, char *scx_direct) {
+__global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restrict__ batch, int L, int n_arg, char *sc_direct, char *scx_direct, int *hs, int small_max) {
     extern __shared__ __align__(16) unsigned char w_smem[];
     // DIRECT (one problem): the control block, the machine's arrays and n are kernel arguments, so the state and -- unconditionally, a
     // wave per slot -- the record a launch with few bids will resolve are requested before the argument block has arrived
@@ -694,6 +697,8 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
     if (slot_s < n) { rr_s = *reinterpret_cast<const int4 *>(rsrc + slot_s); rct_s = csrc[slot_s]; }
     const ScSlot S = sc->slot[L & 1];
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    // (what the driver watches, pinned host memory: the launch under way -- reported by the batch's first problem whatever its state)
+    if (lead && hs && blockIdx.y == 0) __hip_atomic_store(hs, L + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (S.mode >= SC_HANDOVER) {                                 // through: the state stays (both slots)
         if (lead && sc->slot[(L + 1) & 1].mode != S.mode) { ScSlot N = S; N.act = SC_ACT_NONE; sc->slot[(L + 1) & 1] = N; }
         return;
@@ -705,6 +710,18 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
     const int act = N.act;
     const bool through = !first && act == SC_ACT_NONE;
     if (lead) {
+        // what the driver watches besides the launch under way (pinned host memory, no synchronisation): the machines that are through, and
+        // per problem "rebuild my row caches" -- the full-row bids since the last rebuild have reached a.arr_waste
+        // (measured on the few-cell-type 20 000^2 instance: a rebuild whenever a.arr_waste full-row bids have been made -- ~14
+        //  rebuilds of 1 ms -- gives a 25 ms row reduction; rebuilding only from n / 2 full-row bids per group on and never in the
+        //  coarse phases 34 ms: a round waits for the workgroup with the most full-row bids, so few of them already cost every round)
+        if (hs) {
+            if (through) __hip_atomic_fetch_add(hs + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            else if (a.aug_seg == 0 && L - sc->want_mark >= 64 && sc->dense - sc->dense_mark >= a.arr_waste) {      // (once per 64 launches at most)
+                sc->dense_mark = sc->dense; sc->want_mark = L;
+                __hip_atomic_store(hs + 4 + blockIdx.y, L + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
         N.heavy = (long long)sc->dense * 32 > N.bids ? 1 : 0;
         sc->slot[(L + 1) & 1] = N;
         sc->rnd[rn].cnt = 0; sc->rnd[rn].retired = 0;
@@ -722,7 +739,7 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
     if (act == SC_ACT_RESET)
         for (int i = blockIdx.x * HEADB + threadIdx.x; i < n; i += gridDim.x * HEADB) { a.rowsol[i] = -1; a.colsol[i] = -1; }
     // few bids to resolve: a wave per bid (below); else tiles
-    const bool small = act == SC_ACT_ROUND && np <= SC_SMALL && np <= (int)gridDim.x * (HEADB / 64);
+    const bool small = act == SC_ACT_ROUND && np <= small_max && np <= (int)gridDim.x * (HEADB / 64);
     if (small && (int)blockIdx.x * (HEADB / 64) >= np) return;
     ScShared &ss = *reinterpret_cast<ScShared *>(w_smem);
     if (threadIdx.x == 0) { ss.nq = 0; ss.fill_ = 0; ss.cnt = 0; }
@@ -867,26 +884,6 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
         }
     }
     if (lane == 0) { if (retired) atomicAdd(&sc->rnd[rc].retired, retired); if (dense) atomicAdd(&sc->dense, dense); }
-}
-
-// after a group of launches (the next one is L): seg_sync[0] counts the problems whose machine is not through, seg_sync[1 + b] = 1: the
-// full-row bids since the last rebuild have reached a.arr_waste -- problem b wants its row caches rebuilt before the next group
-// (against a.v, which runs one round late: prices only fall, a cache built against older prices holds for the newer ones)
-__global__ void wide_sc_check(const WideArgs *__restrict__ batch, int L) {
-    const WideArgs a = load_wide_args(batch, blockIdx.x);
-    ScCtl *sc = reinterpret_cast<ScCtl *>(a.sc);
-    if (threadIdx.x != 0 || !a.seg_sync) return;
-    const bool through = sc->slot[L & 1].mode >= SC_HANDOVER;
-    int want = 0;
-    if (!through) {
-        atomicAdd(a.seg_sync, 1);
-        // (measured on the few-cell-type 20 000^2 instance: a rebuild whenever a group of rounds saw a.arr_waste full-row bids -- ~14
-        //  rebuilds of 1 ms -- gives a 25 ms row reduction; rebuilding only from n / 2 full-row bids per group on and never in the
-        //  coarse phases 34 ms: a round waits for the workgroup with the most full-row bids, so few of them already cost every round)
-        const int since = sc->dense - sc->dense_mark;
-        if (a.aug_seg == 0 && since >= a.arr_waste) { want = 1; sc->dense_mark = sc->dense; }
-    }
-    a.seg_sync[1 + blockIdx.x] = want;
 }
 
 // before launch L: the bid words of ITS buffer start over (the other buffer holds the bids launch L resolves)
@@ -1273,8 +1270,10 @@ template <bool VLDS, bool CLDS, bool PAR>
 __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batch) {
     extern __shared__ __align__(16) unsigned char w_smem[];
     __shared__ AugShared s;
-    if (PAR && (blockIdx.x & 7)) return;                         // (PAR: workgroups 0, 8, 16 ... take part -- one XCD, one L2: see wide_aug_mc)
-    const int g = PAR ? uni((int)(blockIdx.x >> 3)) : 0;
+    // (PAR: the launch has par_groups * stride workgroups of which every stride-th takes part: stride 1 = spread over all XCDs, 8 = one XCD)
+    const int pstride = PAR ? (int)(gridDim.x / (unsigned)load_wide_args(batch, 0).par_groups) : 1;
+    if (PAR && (blockIdx.x % pstride)) return;
+    const int g = PAR ? uni((int)(blockIdx.x / pstride)) : 0;
     const WideArgs a = load_wide_args(batch, PAR ? 0 : blockIdx.x);
     const int n = a.n, tid = threadIdx.x, lane = tid & 63, w = uni((int)(threadIdx.x >> 6));
     const int nblk = (n + 63) / 64, nw32 = (n + 31) / 32;
@@ -2251,6 +2250,20 @@ __global__ __launch_bounds__(WT) void wide_aug_mc(const WideArgs *__restrict__ b
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// a few ints of pinned, device-visible host memory per driver thread (the machine's launches report into it)
+struct PinnedInts {
+    int *p = nullptr; size_t cap = 0;
+    int ensure(size_t count) {
+        if (count <= cap) return CYTO_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        const size_t want = std::max<size_t>(64, count * 2);
+        CYTO_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), want * sizeof(int), hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable));
+        cap = want;
+        return CYTO_OK;
+    }
+    ~PinnedInts() { if (p) (void)hipHostFree(p); }
+};
+
 size_t wide_sc_ones_bytes(int n) { return (((size_t)n + 63) & ~(size_t)63) * (2 * 8 + 3 * 4); }
 size_t wide_sc_ext_bytes(int n) {
     const size_t np = ((size_t)n + 63) & ~(size_t)63;
@@ -2275,56 +2288,66 @@ int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, i
     int rc;
     if (n >= 2 && !resume) {
         // a wave per bid while the chip has room for them (a bid is a chain of L2 round trips: what counts is how many are in flight)
-        // (at most 2 048 workgroups: late in a phase a few hundred rows bid and a launch is mostly the dispatch of workgroups that find
-        //  nothing to do -- same box, gpurun_out/r04af, row-reduction phase with 4 096 / 2 048 / 1 024 / 256 workgroups: 20 000^2 7.9 / 7.5 /
-        //  7.4 / 7.9 ms, 50 000^2 22.5-23.0 / 21.5 / 21.4-21.9 / 23.9 ms, few-cell-type 20 000^2 23.1-23.4 / 22.9 / 23.0-23.5 / 26.1 ms)
+        // (at most 1 024 workgroups: late in a phase a few hundred rows bid and a launch is mostly the dispatch of workgroups that find
+        //  nothing to do -- gpurun_out/r05i, the phase with 256 / 512 / 1 024 / 2 048 workgroups: 20 000^2 6.64 / 6.43 / 6.44 / 7.18 ms,
+        //  50 000^2 19.1 / 18.3 / 18.3 / 19.3 ms, few-cell-type 20 000^2 27.7 / 24.4 / 24.2 / 25.1 ms, a 10 000-cell chunk 12.4 / 11.5 / 11.3 / 12.3 ms)
         int bid_total = 4096;
         if (CYTO_KNOB("CYTO_BID_TOTAL").set) bid_total = std::max(64, CYTO_KNOB("CYTO_BID_TOTAL").value);        // (developer knob, read once per process: tools/exp/bid_grid_batch_ab.sh)
-        int bx = std::max(1, std::min((n + HEADB / 64 - 1) / (HEADB / 64), std::min(2048, std::max(64, bid_total / std::max(1, nb)))));
+        int bx = std::max(1, std::min((n + HEADB / 64 - 1) / (HEADB / 64), std::min(1024, std::max(64, bid_total / std::max(1, nb)))));
         if (CYTO_KNOB("CYTO_BID_GRID").set) bx = std::max(1, std::min(bx, CYTO_KNOB("CYTO_BID_GRID").value));        // (developer knob, read once per process: tools/exp/bid_grid_ab.sh)
         const int bxr = std::max(1, std::min((n + HEADB - 1) / HEADB, 2048 / std::max(1, std::min(nb, 16))));
-        // (quads of a full-row bid's sweep in flight per lane: developer knob CYTO_BID_UNROLL, tools/exp)
-        const bool deep = CYTO_KNOB("CYTO_BID_UNROLL").set && CYTO_KNOB("CYTO_BID_UNROLL").value == 8;
+        // (quads of a full-row bid's sweep in flight per lane: developer knob CYTO_BID_UNROLL, tools/exp/bid_unroll_ab.sh)
+        const int unroll = CYTO_KNOB("CYTO_BID_UNROLL").set ? CYTO_KNOB("CYTO_BID_UNROLL").value : SC_UNROLL;
         // (one problem: the control block and the machine's arrays are kernel arguments -- one dependent load less per launch)
         char *sc_direct = nullptr, *scx_direct = nullptr;
         if (nb == 1 && direct) { sc_direct = direct->sc; scx_direct = direct->scx; }
-        void (*roundk)(const WideArgs *, int, int, char *, char *) =
-            sc_direct ? (deep ? wide_sc_round<8, true> : wide_sc_round<4, true>) : (deep ? wide_sc_round<8, false> : wide_sc_round<4, false>);
+        using RoundK = void (*)(const WideArgs *, int, int, char *, char *, int *, int);
+        RoundK roundk = sc_direct ? (unroll == 8 ? (RoundK)wide_sc_round<8, true> : unroll == 4 ? (RoundK)wide_sc_round<4, true> : unroll == 3 ? (RoundK)wide_sc_round<3, true> : (RoundK)wide_sc_round<2, true>)
+                                  : (unroll == 8 ? (RoundK)wide_sc_round<8, false> : unroll == 4 ? (RoundK)wide_sc_round<4, false> : unroll == 3 ? (RoundK)wide_sc_round<3, false> : (RoundK)wide_sc_round<2, false>);
         if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(roundk)))) return rc;
-        if (CYTO_KNOB("CYTO_SC_DEBUG").set) { const hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[sc] before init: %s\n", hipGetErrorString(e_)); }
         hipLaunchKernelGGL(wide_sc_init, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args);
-        if (CYTO_KNOB("CYTO_SC_DEBUG").set) { const hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[sc] init: %s\n", hipGetErrorString(e_)); }
-        std::vector<int32_t> h_sync((size_t)nb + 1, 0);
-        int L = 0, group = 64;
+        // The driver never waits for the chip: the launches' first thread reports into pinned host memory which launch is under way,
+        // how many machines are through and who wants fresh row caches; the driver keeps a bounded number of launches queued ahead of
+        // the one under way (launches of a machine that is through return at once) and stops when every machine is through.
+        static thread_local PinnedInts t_hs;
+        if ((rc = t_hs.ensure(4 + (size_t)nb))) return rc;
+        volatile int *hs = t_hs.p;
+        for (int k = 0; k < 4 + nb; k++) hs[k] = 0;
+        std::vector<int32_t> seen((size_t)nb, 0), flags((size_t)nb, 0);
+        // (developer knobs: launches queued ahead -- 8 / 16 / 48 / 128: 20 000^2 6.32 / 6.39 / 6.47 / 6.57 ms, gpurun_out/r05k; up to how many
+        //  bids a launch gives every bid a wave of its own -- 512 / 1 024 / 2 048 / 4 096: 50 000^2 18.2 / 18.0 / 17.9 / 22.0 ms)
+        const int ahead = CYTO_KNOB("CYTO_SC_AHEAD").set ? std::max(2, CYTO_KNOB("CYTO_SC_AHEAD").value) : 16;
+        const int small_max = CYTO_KNOB("CYTO_SC_SMALL").set ? CYTO_KNOB("CYTO_SC_SMALL").value : SC_SMALL;
+        int L = 0;
+        long long spins = 0;
+        const auto t_begin = std::chrono::steady_clock::now();
         for (;;) {
-            for (int g = 0; g < group; g++, L++) {
-                if ((L >> 1) > 0 && (L >> 1) % wipe == 0) hipLaunchKernelGGL(wide_sc_wipe, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args, L);
-                hipLaunchKernelGGL(roundk, dim3(bx, nb), dim3(HEADB), SC_SHARED_BYTES, stream, d_args, L, n, sc_direct, scx_direct);
-                if (CYTO_KNOB("CYTO_SC_DEBUG").set) { const hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[sc] launch %d: %s\n", L, hipGetErrorString(e_)); }
+            if (hs[1] >= nb) break;
+            if (L - hs[0] >= ahead) {
+                if ((++spins & 0xFFFF) == 0) {
+                    if (hipStreamQuery(stream) != hipErrorNotReady && hs[1] < nb && L - hs[0] >= ahead) return CYTO_ERR_INTERNAL;      // (the queue has drained and nobody reported: a launch failed)
+                    if (std::chrono::steady_clock::now() - t_begin > std::chrono::seconds(120)) return CYTO_ERR_INTERNAL;
+                }
+                continue;
             }
-            if (!d_sync) return CYTO_ERR_INTERNAL;
-            CYTO_HIP(hipMemsetAsync(d_sync, 0, sizeof(int32_t), stream));
-            hipLaunchKernelGGL(wide_sc_check, dim3(nb), dim3(64), 0, stream, d_args, L);
-            CYTO_HIP(hipMemcpyAsync(h_sync.data(), d_sync, sizeof(int32_t) * ((size_t)nb + 1), hipMemcpyDeviceToHost, stream));
-            CYTO_HIP(hipStreamSynchronize(stream));
-            if (CYTO_KNOB("CYTO_SC_DEBUG").set) fprintf(stderr, "[sc] check at %d: open %d want0 %d\n", L, h_sync[0], h_sync[1]);
-            if (!h_sync[0]) break;
             bool want = false;
-            for (int b = 0; b < nb; b++) want = want || h_sync[(size_t)b + 1] == 1;
-            if (want && rebuild && (rc = rebuild(ctx, h_sync.data() + 1))) return rc;
-            group = 128;
+            for (int b = 0; b < nb; b++) { const int w_ = hs[4 + b]; flags[(size_t)b] = w_ != seen[(size_t)b] ? 1 : 0; seen[(size_t)b] = w_; want = want || flags[(size_t)b]; }
+            if (want && rebuild && (rc = rebuild(ctx, flags.data()))) return rc;
+            for (int g = 0; g < 8; g++, L++) {
+                if ((L >> 1) > 0 && (L >> 1) % wipe == 0) hipLaunchKernelGGL(wide_sc_wipe, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args, L);
+                hipLaunchKernelGGL(roundk, dim3(bx, nb), dim3(HEADB), SC_SHARED_BYTES, stream, d_args, L, n, sc_direct, scx_direct, t_hs.p, small_max);
+            }
             if (L > (1 << 22)) return CYTO_ERR_INTERNAL;               // (every phase is bounded: cannot happen)
         }
+        (void)d_sync;
         hipLaunchKernelGGL(wide_sc_finish, dim3(nb), dim3(64), 0, stream, d_args, L);
         CYTO_HIP(hipGetLastError());
-        if (CYTO_KNOB("CYTO_SC_DEBUG").set) { const hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[sc] finish: %s\n", hipGetErrorString(e_)); }
     }
     const bool vlds = wide_arr_vlds(n), clds = wide_arr_clds(n);
     void (*k)(const WideArgs *) = vlds ? wide_arr<true, true> : clds ? wide_arr<false, true> : wide_arr<false, false>;
     if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(k)))) return rc;
     hipLaunchKernelGGL(k, dim3(nb), dim3(WT), wide_arr_lds_bytes(n, vlds, clds), stream, d_args);
     CYTO_HIP(hipGetLastError());
-    if (CYTO_KNOB("CYTO_SC_DEBUG").set) { const hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[sc] wide_arr: %s\n", hipGetErrorString(e_)); }
     return CYTO_OK;
 }
 
@@ -2341,7 +2364,10 @@ int wide_launch_aug(const WideArgs *d_args, int nb, int n, hipStream_t stream, i
         void (*k)(const WideArgs *) = vlds ? wide_aug<true, true, true> : clds ? wide_aug<false, true, true> : wide_aug<false, false, true>;
         int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(k));
         if (rc) return rc;
-        hipLaunchKernelGGL(k, dim3(8 * par_groups), dim3(WT), shm, stream, d_args);
+        // (the searches' workgroups spread over all XCDs -- each with its own labels in its own L2 -- instead of packed on one: wide_aug 9.01 ->
+        //  8.84 ms at 20 000^2, 20.6 -> 20.1 at 50 000^2, gpurun_out/r05l; developer knob CYTO_PAR_STRIDE = 8: the one-XCD placement)
+        const int pstride = CYTO_KNOB("CYTO_PAR_STRIDE").set ? std::max(1, CYTO_KNOB("CYTO_PAR_STRIDE").value) : 1;
+        hipLaunchKernelGGL(k, dim3(pstride * par_groups), dim3(WT), shm, stream, d_args);
         CYTO_HIP(hipGetLastError());
         return CYTO_OK;
     }

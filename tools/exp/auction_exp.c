@@ -350,7 +350,21 @@ int main(int argc, char **argv) {
                 trounds += ps.rounds; tbids += ps.bids;
             }
             if (raise_mode >= 2) { raise_unassigned("phase"); if (Fl) rebuild_all(); }
+            if (getenv("FINAL_KEEP")) {
+                /* the last phase keeps every assignment that satisfies complementary slackness exactly (the row sits on its minimum); the
+                 * others and the rows the last scaled phase left unassigned bid */
+                int viol = 0, unas = 0;
+#pragma omp parallel for schedule(dynamic, 8) reduction(+:viol)
+                for (int i = 0; i < n; i++) {
+                    if (rowsol[i] < 0) { active[i] = 1; continue; }
+                    float umin, usub; int j1, j2; top2(cost + (size_t)i * n, &umin, &j1, &usub, &j2);
+                    int j = rowsol[i]; float mine = cost[(size_t)i * n + j] - v[j]; active[i] = !(mine <= umin); viol += active[i];
+                }
+                for (int i = 0; i < n; i++) { if (rowsol[i] < 0) unas++; else if (active[i]) { colsol[rowsol[i]] = -1; rowsol[i] = -1; } }
+                printf("   last phase keeps assignments: %d violators, %d unassigned\n", viol, unas);
+            } else {
             for (int i = 0; i < n; i++) { rowsol[i] = -1; active[i] = 1; } for (int j = 0; j < n; j++) colsol[j] = -1;
+            }
             stop_na = stop_last;
             { long d0 = dense_bids; rounds(0.0f, capr, active, &ps, 1); if (Fl) printf("      dense bids in last phase: %ld (total %ld)\n", dense_bids - d0, dense_bids); }
             trounds += ps.rounds; tbids += ps.bids;

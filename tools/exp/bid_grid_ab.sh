@@ -1,7 +1,7 @@
-mkdir -p gpurun_out/r04af
-for g in 4096 2048 1024 512 256 4096 1024; do
-  export CYTO_BID_GRID=$g
+# workgroups per launch of the row reduction's round kernel (one problem): CYTO_BID_GRID
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/${1:-grid_ab}; mkdir -p $O
+for g in 256 512 1024 2048; do
   echo "== CYTO_BID_GRID=$g"
-  timeout 200 python tools/wide_large.py u20000 u50000 t20000 c4s10000 --reps 3 2>&1 | grep -v "^    wide_arr" | grep "rep=[2]" | sed 's/colsol==golden [A-Za-z]* spot-level [A-Za-z]* total diff [^ ]* //' | cut -c1-110
-done > gpurun_out/r04af/ab.log 2>&1
-cat gpurun_out/r04af/ab.log
+  CYTO_BID_GRID=$g timeout 600 python tools/wide_large.py u20000 u50000 t20000 c4s10000 --reps 3 2>&1 | grep "rep=2" | cut -c1-200 | tee -a $O/grid_$g.log
+done

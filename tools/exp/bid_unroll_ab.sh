@@ -1,8 +1,7 @@
-mkdir -p gpurun_out/r04aa
-for u in 4 8 4 8; do
-  export CYTO_BID_UNROLL=$u
+# quads in flight per lane in the full-row sweeps of wide_sc_round (registers -> waves per SIMD): 2 / 3 / 4
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/${1:-unroll_ab}; mkdir -p $O
+for u in 2 3 4; do
   echo "== CYTO_BID_UNROLL=$u"
-  timeout 200 python tools/wide_large.py t20000 c4s10000 u20000 --reps 3 2>&1 | grep -v "^    wide_arr" | grep "rep=[12]" | sed 's/colsol==golden [A-Za-z]* spot-level [A-Za-z]* total diff [^ ]* //' | cut -c1-150
-  timeout 100 python tools/batch_chunks_bench.py 2>&1 | tail -3 | cut -c1-200
-done > gpurun_out/r04aa/ab.log 2>&1
-cat gpurun_out/r04aa/ab.log
+  CYTO_BID_UNROLL=$u timeout 600 python tools/wide_large.py u20000 u50000 t20000 c4s10000 --reps 3 2>&1 | grep "rep=2" | cut -c1-200 | tee -a $O/unroll_$u.log
+done
