@@ -418,7 +418,7 @@ constexpr size_t SC_SHARED_BYTES = (sizeof(ScShared) + 15) / 16 * 16;
 // Where a launch's bids read prices and owners: the bid words of the launch before (fresh: that column's winner) or the arrays.
 struct ScView {
     const unsigned long long *wsrc;   // bid words of launch L - 1 (null: none -- the first launch, a phase boundary)
-    const uint32_t *pm;               // per column the lowest price bid in launch L - 1 (ordered; all-ones: no bid; null with wsrc)
+    const uint32_t *pr;               // the prices as of the end of launch L - 1 (ordered; the machine's own price arrays); null: a.v holds them
     uint32_t tg;                      // tag of launch L - 1 in those words
     bool own_none;                    // a phase boundary: every column is unassigned (the arrays are being cleared by this very launch)
 };
@@ -428,8 +428,8 @@ __device__ __forceinline__ bool sc_word_fresh(const ScView &vw, unsigned long lo
 __device__ __forceinline__ float sc_word_price(unsigned long long w) { return ord2f((uint32_t)(w >> 20)); }
 // price and owner of column c as of the end of launch L - 1 (a dependent word load only where there is a word to ask)
 __device__ __forceinline__ void sc_price_owner(const WideArgs &a, const ScView &vw, int c, float &p, int &o) {
-    p = a.v[c]; o = vw.own_none ? -1 : a.colsol[c];
-    if (vw.wsrc) { const unsigned long long w = vw.wsrc[c]; if (sc_word_fresh(vw, w)) { p = sc_word_price(w); o = (int)((uint32_t)w & 0xFFFFFu); } }
+    p = vw.pr ? ord2f(vw.pr[c]) : a.v[c]; o = vw.own_none ? -1 : a.colsol[c];
+    if (vw.wsrc) { const unsigned long long w = vw.wsrc[c]; if (sc_word_fresh(vw, w)) o = (int)((uint32_t)w & 0xFFFFFu); }
 }
 
 // the decision of a bid from its row's lexicographic top-2 (oracle: JV_WIDE_ROUND): target column (-1: the row retires), price, raw cost
@@ -452,23 +452,19 @@ __device__ __forceinline__ void sc_decide(const Top2 &t, float eps, int &jt, flo
     jt = uni(jt); pt = uni(pt); ct = uni(ct); i0 = uni(i0);
 }
 // one wave: the top-2 from the row's cache (lane = entry); false: the cache cannot certify it.  The prices of the 63 cached columns
-// are gathered, and with them the launch-before's lowest bids on those columns (all-ones: none) -- only the lanes that find one ask
-// for their column's bid word (gathering word and owner for all 63 columns tripled the lines a
-// bid pulls in: a launch with 8 000 bids took 60 us); the owners of the two columns that matter are read last.
-// GOWN: the owners of all cached columns are gathered with the prices (a launch with few bids is a chain of round trips: one less)
+// are gathered from the machine's price array (complete through the launch before); the owners of the two columns that matter are
+// read last -- a column's bid word of the launch before if it is fresh (its winner), else the owner array.
+// GOWN: words and owners of all cached columns are gathered with the prices (a launch with few bids is a chain of round trips: one less;
+// for a launch with many bids that tripled the lines a bid pulls in: 8 000 bids took 60 us)
 template <bool GOWN = false>
 __device__ __forceinline__ bool sc_top2_cached(const WideArgs &a, const ScView &vw, int lane, uint32_t col, float val, Top2 &t) {
     const float tau = rdlane(val, KCU);
     const bool valid = lane < KCU && col != COLSENT;
-    float vj = valid ? a.v[col] : 0.0f;
-    int ow = -2;                                                  // -2: the column's owner is the array's
-    if (GOWN) ow = valid ? a.colsol[col] : -1;
-    if (vw.pm) {
-        const uint32_t pm = valid ? vw.pm[col] : 0xFFFFFFFFu;
-        if (pm != 0xFFFFFFFFu) {
-            const unsigned long long w = vw.wsrc[col];
-            if (sc_word_fresh(vw, w)) { vj = sc_word_price(w); ow = (int)((uint32_t)w & 0xFFFFFu); }
-        }
+    const float vj = valid ? (vw.pr ? ord2f(vw.pr[col]) : a.v[col]) : 0.0f;
+    int ow = -1;
+    if (GOWN && !vw.own_none) {
+        ow = valid ? a.colsol[col] : -1;
+        if (vw.wsrc) { const unsigned long long w = valid ? vw.wsrc[col] : ~0ull; if (sc_word_fresh(vw, w)) ow = (int)((uint32_t)w & 0xFFFFFu); }
     }
     const uint32_t key = valid ? f2ord(val - vj) : 0xFFFFFFFFu;
     const uint32_t k1 = wave_min_u32(key);
@@ -481,38 +477,38 @@ __device__ __forceinline__ bool sc_top2_cached(const WideArgs &a, const ScView &
     t.u2 = ord2f(k2); t.j2 = (int)rdlane(col, l2); t.c2 = rdlane(val, l2); t.vj2 = rdlane(vj, l2); t.o2 = (int)rdlane((uint32_t)ow, l2);
     if (vw.own_none) { t.o1 = -1; t.o2 = -1; }
     else if (!GOWN) {
-        const int c1 = a.colsol[t.j1], c2 = a.colsol[t.j2];        // (both requested together)
-        if (t.o1 == -2) t.o1 = uni(c1);
-        if (t.o2 == -2) t.o2 = uni(c2);
+        const int c1 = a.colsol[t.j1], c2 = a.colsol[t.j2];        // (all four requested together)
+        unsigned long long w1 = ~0ull, w2 = ~0ull;
+        if (vw.wsrc) { w1 = vw.wsrc[t.j1]; w2 = vw.wsrc[t.j2]; }
+        t.o1 = sc_word_fresh(vw, uni(w1)) ? (int)((uint32_t)uni(w1) & 0xFFFFFu) : uni(c1);
+        t.o2 = sc_word_fresh(vw, uni(w2)) ? (int)((uint32_t)uni(w2) & 0xFFFFFu) : uni(c2);
     }
     return true;
 }
-// the whole workgroup (HEADB threads): f(column, cost, price) for every column of the row, 16 bytes of row and prices per lane and step;
-// a column that received a bid in the launch before has its price in that launch's array of lowest bids (the lowest bid won), read
-// alongside: nothing dependent, 12 bytes per column instead of 8
+// the whole workgroup (HEADB threads): f(column, cost, price) for every column of the row, 16 bytes of row and prices per lane and step
+// (the prices: the machine's ordered price array, or a.v at a phase boundary)
 template <int U, typename F> __device__ __forceinline__ void block_row_sweep(const float *__restrict__ row, const float *__restrict__ v, const ScView &vw, int n, F &&f) {
     const int nq = (n + 3) >> 2;
     const float4 *__restrict__ r4 = reinterpret_cast<const float4 *>(row);
-    const float4 *__restrict__ v4 = reinterpret_cast<const float4 *>(v);      // (16-byte aligned, followed by u in the workspace: whole quads stay in range)
-    const uint4 *__restrict__ m4 = reinterpret_cast<const uint4 *>(vw.pm);    // (padded to a multiple of 64 columns)
+    const float4 *__restrict__ v4 = reinterpret_cast<const float4 *>(vw.pr ? reinterpret_cast<const float *>(vw.pr) : v);   // (16-byte aligned, whole quads stay in range)
+    const bool ordered = vw.pr != nullptr;
     for (int q0 = threadIdx.x; q0 < nq; q0 += HEADB * U) {
         float4 x[U], p[U];
-        uint4 m[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int q = q0 + HEADB * u;
             x[u] = q < nq ? r4[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             p[u] = q < nq ? v4[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            m[u] = (m4 && q < nq) ? m4[q] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int q = q0 + HEADB * u, c = q * 4;
             if (q >= nq) continue;
-            f(c, x[u].x, m[u].x != 0xFFFFFFFFu ? ord2f(m[u].x) : p[u].x);
-            if (c + 1 < n) f(c + 1, x[u].y, m[u].y != 0xFFFFFFFFu ? ord2f(m[u].y) : p[u].y);
-            if (c + 2 < n) f(c + 2, x[u].z, m[u].z != 0xFFFFFFFFu ? ord2f(m[u].z) : p[u].z);
-            if (c + 3 < n) f(c + 3, x[u].w, m[u].w != 0xFFFFFFFFu ? ord2f(m[u].w) : p[u].w);
+            if (ordered) { p[u].x = ord2f(__float_as_uint(p[u].x)); p[u].y = ord2f(__float_as_uint(p[u].y)); p[u].z = ord2f(__float_as_uint(p[u].z)); p[u].w = ord2f(__float_as_uint(p[u].w)); }
+            f(c, x[u].x, p[u].x);
+            if (c + 1 < n) f(c + 1, x[u].y, p[u].y);
+            if (c + 2 < n) f(c + 2, x[u].z, p[u].z);
+            if (c + 3 < n) f(c + 3, x[u].w, p[u].w);
         }
     }
 }
@@ -601,16 +597,16 @@ __device__ __forceinline__ bool bid_won(unsigned long long word, int row) { retu
 struct ArrHead { int cnt[2]; int started, free_cr; long long round, bids; int retired, dense; int done, launches; long long list_rounds; int no_more, pad_; };
 
 // ---- the machine's memory beyond the driver's arrays (WideArgs.scx, wide_sc_ext_bytes(n) bytes, 256-byte aligned): the two buffers of
-// bid words and three arrays of the lowest price bid per column in a launch (ordered; all of them all-ones at the start: the first
-// wide_sc_ones_bytes(n) bytes), the bid records of a launch (two buffers by the launch's parity: 16 bytes { row, column or -1, price,
+// bid words (all-ones at the start: the first wide_sc_ones_bytes(n) bytes), the machine's two price arrays (ordered floats; wide_sc_init
+// copies the prices in), the bid records of a launch (two buffers by the launch's parity: 16 bytes { row, column or -1, price,
 // owner it would displace } and the raw cost of the entry).
 struct ScRec { int i, jt; float pt; int i0; };
 // (accessors instead of a table of pointers: a table indexed by the launch's parity would live in scratch memory)
 __host__ __device__ inline size_t sc_np(int n) { return ((size_t)n + 63) & ~(size_t)63; }
 __device__ __forceinline__ unsigned long long *sc_words(char *scx, int n, int b) { return reinterpret_cast<unsigned long long *>(scx + sc_np(n) * 8 * (size_t)b); }
-__device__ __forceinline__ uint32_t *sc_pmin(char *scx, int n, int k) { return reinterpret_cast<uint32_t *>(scx + sc_np(n) * (16 + 4 * (size_t)k)); }
-__device__ __forceinline__ ScRec *sc_recs(char *scx, int n, int b) { return reinterpret_cast<ScRec *>(scx + sc_np(n) * (28 + 16 * (size_t)b)); }
-__device__ __forceinline__ float *sc_rcts(char *scx, int n, int b) { return reinterpret_cast<float *>(scx + sc_np(n) * (60 + 4 * (size_t)b)); }
+__device__ __forceinline__ uint32_t *sc_price(char *scx, int n, int k) { return reinterpret_cast<uint32_t *>(scx + sc_np(n) * (16 + 4 * (size_t)k)); }
+__device__ __forceinline__ ScRec *sc_recs(char *scx, int n, int b) { return reinterpret_cast<ScRec *>(scx + sc_np(n) * (24 + 16 * (size_t)b)); }
+__device__ __forceinline__ float *sc_rcts(char *scx, int n, int b) { return reinterpret_cast<float *>(scx + sc_np(n) * (56 + 4 * (size_t)b)); }
 
 __device__ __forceinline__ float sc_eps_of(const ScCtl *sc, int k) {       // eps of phase k, 0 = there is no such phase
     if (k >= SC_NPH) return 0.0f;
@@ -659,6 +655,7 @@ __global__ __launch_bounds__(HEADB) void wide_sc_init(const WideArgs *__restrict
         if (lane == 0 && m) base = atomicAdd(&sc->rnd[2].cnt, __popcll(m));        // (the list launch 0 reads: cell (0 - 1) mod 3)
         base = __shfl(base, 0);
         if (fr) a.act0[base + __popcll(m & lanemask_lt())] = i;
+        if (i < n) { const uint32_t o = f2ord(a.v[i]); sc_price((char *)a.scx, n, 0)[i] = o; sc_price((char *)a.scx, n, 1)[i] = o; }     // the machine's price arrays
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // the median binade of the gaps (wide_rt's histogram), eps_0 = 2^SC_EMULT times it; no scaling when half the gaps are zero
@@ -731,13 +728,16 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
         if (through) { sc->fin_buf = pb; sc->fin_cnt = np; }
     }
     if (through) return;
-    {
-        uint4 *pmn = reinterpret_cast<uint4 *>(sc_pmin(scx, n, rn));      // the next launch's lowest bids start empty
-        const int nq4 = (n + 3) >> 2;
-        for (int q = blockIdx.x * HEADB + threadIdx.x; q < nq4; q += gridDim.x * HEADB) pmn[q] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    // The machine's two price arrays (ordered floats, merged with atomic mins: prices only fall): launch L reads P[(L - 1) & 1] -- complete
+    // through round L - 1 -- and merges into P[L & 1] (complete through round L - 2 when the launch starts) the bids it resolves (round L - 1)
+    // and the bids it makes: complete through round L when it ends.  Dropped bids (a phase ended) have spoilt the array they were merged
+    // into, P[(L - 1) & 1] at the phase boundary L: that launch reads the price array proper (a.v: complete, the resolutions wrote it)
+    // and copies it over the spoilt one.
+    uint32_t *pw = sc_price(scx, n, cb);
+    if (act == SC_ACT_RESET) {
+        uint32_t *pfix = sc_price(scx, n, pb);
+        for (int i = blockIdx.x * HEADB + threadIdx.x; i < n; i += gridDim.x * HEADB) { a.rowsol[i] = -1; a.colsol[i] = -1; pfix[i] = f2ord(a.v[i]); }
     }
-    if (act == SC_ACT_RESET)
-        for (int i = blockIdx.x * HEADB + threadIdx.x; i < n; i += gridDim.x * HEADB) { a.rowsol[i] = -1; a.colsol[i] = -1; }
     // few bids to resolve: a wave per bid (below); else tiles
     const bool small = act == SC_ACT_ROUND && np <= small_max && np <= (int)gridDim.x * (HEADB / 64);
     if (small && (int)blockIdx.x * (HEADB / 64) >= np) return;
@@ -746,11 +746,10 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
     __syncthreads();
     ScView vw;
     vw.wsrc = act == SC_ACT_ROUND ? sc_words(scx, n, pb) : nullptr;
-    vw.pm = act == SC_ACT_ROUND ? sc_pmin(scx, n, rp) : nullptr;
+    vw.pr = act == SC_ACT_RESET ? nullptr : sc_price(scx, n, pb);
     vw.tg = ~(uint32_t)((long long)(L - 1) - (long long)sc->wbase[pb]) & 0xFFFu;
     vw.own_none = act == SC_ACT_RESET;
     unsigned long long *wdst = sc_words(scx, n, cb);
-    uint32_t *pmd = sc_pmin(scx, n, rc);
     ScRec *rdst = sc_recs(scx, n, cb);
     float *cdst = sc_rcts(scx, n, cb);
     const long long tag = (long long)L - (long long)sc->wbase[cb];
@@ -767,7 +766,7 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
             if (jt < 0) retired++;
             else {
                 atomicMin(wdst + jt, bidkey(tag, pt, i));
-                atomicMin(pmd + jt, f2ord(pt));
+                atomicMin(pw + jt, f2ord(pt));
             }
             *reinterpret_cast<int4 *>(rdst + oslot) = make_int4(i, jt, __float_as_int(pt), i0);
             cdst[oslot] = ct;
@@ -796,6 +795,7 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
         int nxt = -1, rank = 0;
         uint32_t col = COLSENT; float val = 0.0f;
         if (slot_s < np && rj >= 0) {                               // (a retired row stays free and bids no more)
+            if (lane == 0) atomicMin(pw + rj, f2ord(__int_as_float(rr_s.z)));     // (every bid of the round, won or lost: the lowest is the price)
             const unsigned long long word = vw.wsrc[rj];
             const uint32_t colA = a.cache_col[(int64_t)ri * KC + lane];
             const float valA = a.cache_val[(int64_t)ri * KC + lane];
@@ -848,6 +848,7 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
                     const int slot = t0 + (int)threadIdx.x;
                     const int4 rr = *reinterpret_cast<const int4 *>(rsrc + slot);
                     if (rr.y >= 0) {                                // (a retired row stays free and bids no more)
+                        atomicMin(pw + rr.y, f2ord(__int_as_float(rr.z)));      // (every bid of the round, won or lost: the lowest is the price)
                         const unsigned long long word = vw.wsrc[rr.y];
                         const float rct = csrc[slot];
                         if (bid_won(word, rr.x)) {
@@ -2264,10 +2265,10 @@ struct PinnedInts {
     ~PinnedInts() { if (p) (void)hipHostFree(p); }
 };
 
-size_t wide_sc_ones_bytes(int n) { return (((size_t)n + 63) & ~(size_t)63) * (2 * 8 + 3 * 4); }
+size_t wide_sc_ones_bytes(int n) { return (((size_t)n + 63) & ~(size_t)63) * (2 * 8); }
 size_t wide_sc_ext_bytes(int n) {
     const size_t np = ((size_t)n + 63) & ~(size_t)63;
-    return np * (2 * 8 + 3 * 4 + 2 * 16 + 2 * 4);
+    return np * (2 * 8 + 2 * 4 + 2 * 16 + 2 * 4);
 }
 
 int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream) {
