@@ -3482,6 +3482,12 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
                 if ((rc = build_caches(need.data()))) return rc;
             } else if ((rc = build_caches(reinterpret_cast<const int *>(h_sync.data() + 1)))) return rc;
             if (pass == 0) CYTO_HIP(hipEventRecord(ev_arr_done, stream));   // (ms_aug: the search kernel -- and what later passes add)
+            if (pass == 0 && h_wa[0].mc_groups == 0 && h_wa[0].par_groups == 0) {
+                // repeated spot rows (CytoSPACE's slots): their one-edge searches all at once, before the search kernel
+                bool dup = false;
+                for (int k = 0; k < nl; k++) dup = dup || h_wa[(size_t)k].same_prev != nullptr;
+                if (dup && (rc = wide_launch_claims(d_wa.as<WideArgs>(), nl, n, stream, d_sync.as<int32_t>()))) return rc;
+            }
             CYTO_HIP(hipMemsetAsync(d_sync.p, 0, sizeof(int32_t), stream));
             if ((rc = wide_launch_aug(d_wa.as<WideArgs>(), nl, n, stream, h_wa[0].mc_groups, h_wa[0].par_groups))) return rc;
             if (h_wa[0].mc_groups > 0 || h_wa[0].par_groups > 0) { CYTO_HIP(hipStreamSynchronize(stream)); break; }

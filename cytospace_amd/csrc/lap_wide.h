@@ -55,6 +55,7 @@ size_t wide_aug_lds_bytes(int n);
 int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream);        // Jacobi reduction transfer (v0 snapshot in cassign)
 int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, int wipe_every, bool resume, int32_t *d_sync,
                     int (*rebuild)(void *ctx, const int32_t *flags), void *ctx, const WideArgs *direct);   // direct: host copy of the one problem's block (nb == 1), or null   // rebuild: fresh row caches for the flagged problems   // Jacobi rounds of augmenting row reduction + free list
+int wide_launch_claims(const WideArgs *d_args, int nb, int n, hipStream_t stream, int32_t *d_sync);   // the one-edge searches of problems with repeated rows, on the whole chip (before the first wide_launch_aug; one search at a time per problem only)
 int wide_launch_aug(const WideArgs *d_args, int nb, int n, hipStream_t stream, int mc_groups, int par_groups);   // shortest-path augmentation, duals, total
 size_t wide_par_state_bytes(int n, int G);                                              // control block, per-search labels / lists, claim words, change logs
 constexpr int WIDE_PAR_GMAX = 64;

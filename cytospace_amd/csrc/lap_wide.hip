@@ -2251,6 +2251,126 @@ __global__ __launch_bounds__(WT) void wide_aug_mc(const WideArgs *__restrict__ b
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------------------
+// ONE-EDGE SEARCHES ON THE WHOLE CHIP (CytoSPACE's repeated spot rows: reference linear_assignment_solvers.py:61-66 expands a spot into one
+// identical row per slot; at config c3 35 000 of the 50 000 rows reach the searches and every one of their searches is a single edge).
+// wide_aug's wave 0 disposes of such searches one after the other -- the free row's cache certifies its minimum, a column tied at that
+// minimum is unassigned: the row takes the lowest such column, no price changes -- 0.22 us per row in runs, 7.7 ms at c3.  With the
+// prices fixed that loop is a SERIAL DICTATORSHIP: row after row, in free-list order, takes the first column of a fixed list (its cached
+// columns tied at its minimum, by column) that nobody before it took, and the loop ends at the first row that finds none.  Deferred
+// acceptance computes the same assignment in parallel: every row proposes down its list, a column keeps the EARLIEST row that ever
+// proposed (an atomic min of free-list positions -- claims only improve, so a column lost to an earlier row is lost for good), a row
+// that lost its column moves on; at the fixed point the rows before the first one that ran out of columns hold exactly what the serial
+// loop gives them (a later row never takes anything from an earlier one), and those are committed; wide_aug starts behind them.  The
+// t-th row of a run of identical rows starts at its list's t-th column (the t rows before it want the same columns and come first).
+// Scratch: the machine's arrays (a.scx; the row reduction is over): claims [n], lists as lane masks [n], {next candidate, lane held} [n].
+// ------------------------------------------------------------------------------------------------------------------
+struct ClaimCtl { int changed, blocked, rounds, pad_; };
+__device__ __forceinline__ int *cl_claim(const WideArgs &a) { return reinterpret_cast<int *>(a.scx); }
+__device__ __forceinline__ unsigned long long *cl_mask(const WideArgs &a) { return reinterpret_cast<unsigned long long *>(a.scx + sc_np(a.n) * 8); }
+__device__ __forceinline__ int2 *cl_state(const WideArgs &a) { return reinterpret_cast<int2 *>(a.scx + sc_np(a.n) * 16); }
+__device__ __forceinline__ ClaimCtl *cl_ctl(const WideArgs &a) { return reinterpret_cast<ClaimCtl *>(a.scx + sc_np(a.n) * 24); }
+// the k-th set bit of m at or after ... : lane of the (k + 1)-th set bit, -1 if there are not that many
+__device__ __forceinline__ int nth_set(unsigned long long m, int k) {
+    for (int t = 0; t < k && m; t++) m &= m - 1;
+    return m ? __ffsll((long long)m) - 1 : -1;
+}
+
+// a wave per free row: its list (the cached columns tied at the row's minimum and unassigned, as a lane mask -- cache rows are sorted by
+// column; 0: the cache does not certify the minimum, or nothing is free: the serial loop would stop here) and where it starts
+__global__ __launch_bounds__(HEADB) void wide_claim_lists(const WideArgs *__restrict__ batch) {
+    const WideArgs a = load_wide_args(batch, blockIdx.y);
+    const int numfree = *reinterpret_cast<const int *>(a.misc + 128);
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * (HEADB / 64) + (threadIdx.x >> 6), nw = gridDim.x * (HEADB / 64);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ClaimCtl *c = cl_ctl(a); c->changed = 0; c->blocked = 0x7FFFFFFF; c->rounds = 0; }
+    for (int i = blockIdx.x * HEADB + threadIdx.x; i < a.n; i += gridDim.x * HEADB) cl_claim(a)[i] = 0x7FFFFFFF;
+    for (int p = gw; p < numfree; p += nw) {
+        const int fr = uni(a.freerows[p]);
+        const uint32_t col = a.cache_col[(int64_t)fr * KC + lane];
+        const float val = a.cache_val[(int64_t)fr * KC + lane];
+        const float tau = rdlane(val, KCU);
+        const bool valid = lane < KCU && col != COLSENT;
+        const float vv = valid ? a.v[col] : 0.0f;
+        const int ow = valid ? a.colsol[col] : 0;
+        const uint32_t od = valid ? f2ord(val - vv) : 0xFFFFFFFFu;
+        const uint32_t omin = wave_min_u32(od);
+        unsigned long long mu = __ballot(valid && od == omin && ow < 0);
+        if (!(omin != 0xFFFFFFFFu && tau > ord2f(omin))) mu = 0;
+        if (lane == 0) {
+            // rank in the run of identical rows this row belongs to (consecutive in the free list, each the copy of the row before it)
+            int t = 0;
+            if (a.same_prev)
+                while (t < 63 && p - t - 1 >= 0 && a.same_prev[fr - t] != 0 && a.freerows[p - t - 1] == fr - t - 1) t++;
+            cl_mask(a)[p] = mu;
+            cl_state(a)[p] = make_int2(t, -1);                   // x: candidates of the list passed over so far; y: the lane it holds (-1: none, -2: ran out)
+        }
+    }
+}
+
+// a round: a thread per free row -- still holding its column?  else down the list to the next column no earlier row has
+__global__ __launch_bounds__(HEADB) void wide_claim_round(const WideArgs *__restrict__ batch) {
+    const WideArgs a = load_wide_args(batch, blockIdx.y);
+    const int numfree = *reinterpret_cast<const int *>(a.misc + 128);
+    int *claim = cl_claim(a);
+    int changed = 0;
+    for (int p = blockIdx.x * HEADB + threadIdx.x; p < numfree; p += gridDim.x * HEADB) {
+        int2 st = cl_state(a)[p];
+        if (st.y == -2) continue;
+        const int fr = a.freerows[p];
+        const unsigned long long m = cl_mask(a)[p];
+        if (st.y >= 0) {
+            if (claim[a.cache_col[(int64_t)fr * KC + st.y]] == p) continue;      // (still the earliest row that asked)
+            st.x++; st.y = -1; changed = 1;
+        }
+        for (;;) {
+            const int l = nth_set(m, st.x);
+            if (l < 0) { st.y = -2; changed = 1; break; }
+            const int c = (int)a.cache_col[(int64_t)fr * KC + l];
+            if (claim[c] > p && atomicMin(claim + c, p) > p) { st.y = l; changed = 1; break; }
+            st.x++;
+        }
+        cl_state(a)[p] = st;
+    }
+    if (__ballot(changed) && (threadIdx.x & 63) == 0) atomicAdd(&cl_ctl(a)->changed, 1);
+}
+
+// after a few rounds: did anything move?  (seg_sync[1 + b]: 1 = problem b is not at its fixed point; the driver reads it)
+__global__ void wide_claim_check(const WideArgs *__restrict__ batch) {
+    const WideArgs a = load_wide_args(batch, blockIdx.x);
+    if (threadIdx.x != 0) return;
+    ClaimCtl *c = cl_ctl(a);
+    a.seg_sync[1 + blockIdx.x] = c->changed ? 1 : 0;
+    c->changed = 0; c->rounds += 1;
+}
+
+// the fixed point: the first row that ran out of columns ...
+__global__ __launch_bounds__(HEADB) void wide_claim_blocked(const WideArgs *__restrict__ batch) {
+    const WideArgs a = load_wide_args(batch, blockIdx.y);
+    const int numfree = *reinterpret_cast<const int *>(a.misc + 128);
+    int first = 0x7FFFFFFF;
+    for (int p = blockIdx.x * HEADB + threadIdx.x; p < numfree; p += gridDim.x * HEADB)
+        if (cl_state(a)[p].y < 0) { first = p; break; }           // (positions ascend along a thread's stride: its first is its lowest)
+    if (first != 0x7FFFFFFF) atomicMin(&cl_ctl(a)->blocked, first);
+}
+// ... and the rows before it take their columns: the serial loop's assignments (no price changes; one hop each)
+__global__ __launch_bounds__(HEADB) void wide_claim_commit(const WideArgs *__restrict__ batch) {
+    const WideArgs a = load_wide_args(batch, blockIdx.y);
+    const int numfree = *reinterpret_cast<const int *>(a.misc + 128);
+    const int pb = min(cl_ctl(a)->blocked, numfree);
+    for (int p = blockIdx.x * HEADB + threadIdx.x; p < pb; p += gridDim.x * HEADB) {
+        const int fr = a.freerows[p], l = cl_state(a)[p].y;
+        const int c = (int)a.cache_col[(int64_t)fr * KC + l];
+        a.rowsol[fr] = c; a.colsol[c] = fr; a.cassign[c] = a.cache_val[(int64_t)fr * KC + l];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        long long *ctr = reinterpret_cast<long long *>(a.misc + 16);
+        long long *wc = reinterpret_cast<long long *>(a.misc + 160);
+        ctr[C_HOPS] += pb; wc[WC_TRIVIAL] += pb;
+        *reinterpret_cast<int *>(a.misc + 132) = pb;             // wide_aug starts behind them
+    }
+}
+
 // a few ints of pinned, device-visible host memory per driver thread (the machine's launches report into it)
 struct PinnedInts {
     int *p = nullptr; size_t cap = 0;
@@ -2269,6 +2389,28 @@ size_t wide_sc_ones_bytes(int n) { return (((size_t)n + 63) & ~(size_t)63) * (2 
 size_t wide_sc_ext_bytes(int n) {
     const size_t np = ((size_t)n + 63) & ~(size_t)63;
     return np * (2 * 8 + 2 * 4 + 2 * 16 + 2 * 4);
+}
+
+int wide_launch_claims(const WideArgs *d_args, int nb, int n, hipStream_t stream, int32_t *d_sync) {
+    // the one-edge searches of every problem, on the whole chip (above); rounds in groups of four, then "did anything move?"
+    if (n < 2 || !d_sync) return CYTO_OK;
+    const int bxw = std::max(1, std::min((n + HEADB / 64 - 1) / (HEADB / 64), std::max(64, 4096 / std::max(1, nb))));
+    const int bxt = std::max(1, std::min((n + HEADB - 1) / HEADB, std::max(16, 1024 / std::max(1, nb))));
+    hipLaunchKernelGGL(wide_claim_lists, dim3(bxw, nb), dim3(HEADB), 0, stream, d_args);
+    std::vector<int32_t> h((size_t)nb + 1, 0);
+    for (int it = 0; it < (1 << 16); it++) {
+        for (int k = 0; k < 4; k++) hipLaunchKernelGGL(wide_claim_round, dim3(bxt, nb), dim3(HEADB), 0, stream, d_args);
+        hipLaunchKernelGGL(wide_claim_check, dim3(nb), dim3(64), 0, stream, d_args);
+        CYTO_HIP(hipMemcpyAsync(h.data(), d_sync, sizeof(int32_t) * ((size_t)nb + 1), hipMemcpyDeviceToHost, stream));
+        CYTO_HIP(hipStreamSynchronize(stream));
+        bool any = false;
+        for (int b = 0; b < nb; b++) any = any || h[(size_t)b + 1] != 0;
+        if (!any) break;
+    }
+    hipLaunchKernelGGL(wide_claim_blocked, dim3(bxt, nb), dim3(HEADB), 0, stream, d_args);
+    hipLaunchKernelGGL(wide_claim_commit, dim3(bxt, nb), dim3(HEADB), 0, stream, d_args);
+    CYTO_HIP(hipGetLastError());
+    return CYTO_OK;
 }
 
 int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream) {

@@ -1,7 +1,10 @@
-mkdir -p gpurun_out/r04w
-for w in 0 50 25 12 6; do
-  if [ $w = 0 ]; then unset CYTO_ARR_WASTE; else export CYTO_ARR_WASTE=$w; fi
+# full-row bids of a problem after which the row reduction asks the driver for fresh row caches (CYTO_ARR_WASTE), batches and single problems
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/${1:-waste}; mkdir -p $O
+for w in default 500 5000 20000 1000000; do
   echo "== CYTO_ARR_WASTE=$w"
-  timeout 200 python tools/wide_large.py t20000 c4s10000 u20000 --reps 2 2>&1 | grep -v "^    wide_arr" | grep "rep=1"
-done > gpurun_out/r04w/arr_waste.log 2>&1
-cat gpurun_out/r04w/arr_waste.log | cut -c1-330
+  if [ $w = default ]; then unset CYTO_ARR_WASTE; else export CYTO_ARR_WASTE=$w; fi
+  timeout 300 python tools/batch_chunks_bench.py 16 5000 2>&1 | grep "rep=1" | cut -c1-150
+  timeout 300 python tools/batch_chunks_bench.py 64 10000 2>&1 | grep "rep=1" | cut -c1-150
+  timeout 300 python tools/wide_large.py t20000 c4s10000 --reps 2 2>&1 | grep "rep=1" | cut -c1-25,128-175
+done 2>&1 | tee $O/sweep.log
