@@ -14,7 +14,8 @@ LIB = os.path.join(HERE, "libcytohip.so")
 SOURCES = ["core.hip", "lap_jv.hip", "lap_wide.hip", "cost.hip", "batch.hip", "comm.hip"]
 # -ffp-contract=off: the JV kernels must evaluate exactly the subtract/compare sequence of the
 # oracle (no FMA contraction, no re-association).  MFMA use in the cost kernels is explicit.
-FLAGS = (["-DCYTO_WIDE_PROF"] if os.environ.get("CYTO_WIDE_PROF") else []) + [
+# (CYTO_EXTRA_FLAGS: developer builds, e.g. -DWIDE_STOP_CAP=128 for tools/exp -- use with --force and rebuild afterwards)
+FLAGS = (["-DCYTO_WIDE_PROF"] if os.environ.get("CYTO_WIDE_PROF") else []) + os.environ.get("CYTO_EXTRA_FLAGS", "").split() + [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-result"]
 
 

@@ -145,7 +145,10 @@ constexpr int SC_STOP_FINAL = 16;       // the final eps = 0 phase ends at min(w
 constexpr int SC_UNROLL = 4;           // quads of a full-row sweep in flight per lane (2: 67 registers, 7 waves per SIMD; 3: 79, 6; 4: 107, 4 -- and 4 is the fastest: gpurun_out/r05h)
 constexpr int SC_SMALL = 2048;         // launches with at most so many bids to resolve give every bid a wave of its own (a matter of speed only)
 constexpr int SC_COARSE = 4;           // phases whose full-row bids leave the row caches alone (a matter of speed only)
-__host__ __device__ inline int wide_stop(int n) { return n / 128 < 8 ? 8 : (n / 128 > 64 ? 64 : n / 128); }
+#ifndef WIDE_STOP_CAP
+#define WIDE_STOP_CAP 64
+#endif
+__host__ __device__ inline int wide_stop(int n) { return n / 128 < 8 ? 8 : (n / 128 > WIDE_STOP_CAP ? WIDE_STOP_CAP : n / 128); }
 // the next representable value below x (+0 and -0 are one value): oracle pred_
 __device__ __forceinline__ float pred_f32(float x) {
     const uint32_t o = f2ord(x);

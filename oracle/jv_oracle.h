@@ -54,7 +54,10 @@ typedef struct {
  * phase ends (and below which an instance never scales), phases at most, rounds per phase at most, eps_0 = 2^EMULT x the median gap's
  * binade, eps_k = eps_0 / 2^(ESTEP k) */
 #define JV_WIDE_K0 8
-#define JV_WIDE_STOP(n) ((n) / 128 < 8 ? 8 : ((n) / 128 > 64 ? 64 : (n) / 128))
+#ifndef JV_WIDE_STOP_CAP
+#define JV_WIDE_STOP_CAP 64
+#endif
+#define JV_WIDE_STOP(n) ((n) / 128 < 8 ? 8 : ((n) / 128 > JV_WIDE_STOP_CAP ? JV_WIDE_STOP_CAP : (n) / 128))
 #define JV_WIDE_STOP_FINAL(n) (JV_WIDE_STOP(n) < 16 ? JV_WIDE_STOP(n) : 16)   /* the final eps = 0 phase goes on a little longer: what it leaves are searches */
 #define JV_WIDE_NPH 16
 #define JV_WIDE_PHCAP 1024

@@ -1,17 +1,31 @@
 #!/bin/bash
-# Round-end measurement set: bench line, rocprofv3 kernel stats of the same command (headline only, and with the extra
-# legs), PMC traffic passes of the 20 000 LAP, PMC pass of the c3-sized cost GEMM.  Usage (gpurun): bash tools/prof_round.sh r02a
-TAG=${1:-r03b}
+# Round-end measurement set: the default bench line; rocprofv3 kernel stats + trace of the same command (headline only: n = 50 000, and
+# n = 20 000; with the extra legs: stats only); PMC traffic passes (FETCH_SIZE / WRITE_SIZE, each in its own run, with --kernel-trace
+# only) of one LAP at n = 20 000, n = 50 000 and of the few-cell-type 20 000 instance; PMC pass of the c3-sized cost GEMM.
+# Usage (gpurun): bash tools/prof_round.sh r05 ; then tools/prof_collect.sh r05 copies the summaries into profiles/
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
-python $R/bench.py --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $TAG -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $OUT/prof.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_extras -o ${TAG}x -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/prof_extras.log 2>&1
-mkdir -p $OUT/pmc
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc -o fetch -- python $R/tools/quick_lap_bench.py 20000 > $OUT/pmc/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc -o write -- python $R/tools/quick_lap_bench.py 20000 > $OUT/pmc/write.log 2>&1
+python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
+for n in 50000 20000; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_n$n -o n$n -- python $R/bench.py --n $n --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $OUT/prof_n$n.log 2>&1
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_extras -o extras -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/prof_extras.log 2>&1
+for n in 20000 50000; do
+  mkdir -p $OUT/pmc_n$n
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_n$n -o fetch -- python $R/tools/quick_lap_bench.py $n > $OUT/pmc_n$n/fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_n$n -o write -- python $R/tools/quick_lap_bench.py $n > $OUT/pmc_n$n/write.log 2>&1
+done
+mkdir -p $OUT/pmc_t20000
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_t20000 -o fetch -- python $R/tools/wide_large.py t20000 --reps 2 > $OUT/pmc_t20000/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_t20000 -o write -- python $R/tools/wide_large.py t20000 --reps 2 > $OUT/pmc_t20000/write.log 2>&1
 mkdir -p $OUT/gemm_pmc
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/gemm_pmc -o gemm -- python $R/tools/gemm_only.py > $OUT/gemm_pmc/gemm.log 2>&1
-find $OUT -name "*.csv" | head -30
-# wave-stall reasons and LDS bank conflicts of the same GEMM (second PMC pass: the SQ block has 8 counters)
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/gemm_pmc -o gemm_stall -- python $R/tools/gemm_only.py > $OUT/gemm_pmc/gemm_stall.log 2>&1
+# the trace CSVs are large: keep the round kernel's per-launch summary and drop what gpurun would not carry back (64 MiB)
+for n in 50000 20000; do
+  f=$(find $OUT/prof_n$n -name "*kernel_trace.csv" | head -1)
+  python $R/tools/trace_rounds.py $f wide_sc_round > $OUT/rounds_n$n.txt 2>&1
+done
+find $OUT -name "*.csv" -size +20M -exec rm {} \;
+find $OUT -name "*.csv" | head -40; du -sh $OUT
