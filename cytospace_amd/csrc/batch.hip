@@ -3,7 +3,7 @@
 // CytoSPACE splits large inputs into independent square sub-LAPs ("chunks") and ships each to a worker
 // process (/root/reference/cytospace/cytospace.py:430-451).  Here the chunks of a batch go through the solver's phases
 // TOGETHER: problems of one size share their launches (lap_jv.hip: lap_batch_same_n -- the row reduction of every problem is the
-// same whole-chip phase machine, launch pair L carrying round L of whatever phase each problem is in; the searches run a
+// same whole-chip phase machine, launch L carrying round L of whatever phase each problem is in; the searches run a
 // workgroup per problem), and a large batch runs as a few interleaved sub-batches on their own streams and host threads.
 #include "cyto_common.h"
 #include <algorithm>

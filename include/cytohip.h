@@ -153,10 +153,10 @@ typedef struct {
     int32_t wide_par;           /* wide solver, one problem: searches of consecutive free rows that run at once, a workgroup each, from one state and
                                    are committed in row order while their settled sets are disjoint (the rest runs again).  0: 16 for a problem
                                    of >= 2 048 rows without runs of identical rows, else one at a time.  -1: one at a time.  k > 1: k (<= 64;
-                                   clamped to the CUs of one XCD -- the workgroups meet at grid barriers and must all be resident).
+                                   clamped to an eighth of the device's CUs -- the workgroups, one per CU, spread over the XCDs, meet at grid barriers and must all be resident).
                                    Results do not depend on it */
     int32_t wide_wipe;          /* wide solver, row reduction: the per-column bid words carry a 12-bit round tag relative to their last wipe;
-                                   0: wiped every 2048 launch pairs.  k > 0: every k pairs (a self-test of the protocol at sizes the CPU
+                                   0: each of the two word buffers is wiped every 1 024 of its launches.  k > 0: every k (a self-test of the protocol at sizes the CPU
                                    oracle checks).  Results do not depend on it */
     int32_t cache_waves;        /* row-cache builder (float32): 0: by size (a wave per row, 8 or 20 waves per CU).  k > 0: k waves per CU (<= 32).
                                    -1: the workgroup-per-row builders of round 3.  Results do not depend on it */

@@ -678,8 +678,8 @@ def test_wide_scaled_row_reduction(n):
 @pytest.mark.parametrize("wipe", [1, 3, 50])
 def test_wide_bid_words_wiped_every_few_rounds(wipe):
     # the per-column bid words carry a 12-bit round tag RELATIVE to their last wipe (a later round's bid beats whatever earlier
-    # rounds left, so the words are never reset between rounds); cyto_lap_opts.wide_wipe moves the wipes from every 2048 launch
-    # pairs to every few: the tags start over again and again in the middle of phases -- same rounds, same answer
+    # rounds left, so the words are never reset between rounds); cyto_lap_opts.wide_wipe moves the wipes of a word buffer from every
+    # 1 024 of its launches to every few: the tags start over again and again in the middle of phases -- same rounds, same answer
     rng = np.random.default_rng(60 + wipe)
     for n in (700, 2600):
         _check_wide(rng.random((n, n)).astype(np.float32), opts=dict(wide_wipe=wipe))
