@@ -541,6 +541,31 @@ def test_wide_row_map_and_duplicated_rows():
         assert abs(oc["total"] - o["total"]) <= 1e-5 * max(1.0, abs(o["total"]))
 
 
+def test_wide_one_edge_searches_on_the_whole_chip():
+    # repeated spot rows: the searches that end at the free row's own best column are disposed of by deferred acceptance on the whole
+    # chip before the search kernel (wide_claim_*) -- the same rows take the same columns as in the serial loop they replace, and the
+    # loop goes on behind the first row that needs a search proper.  (a) every search is one edge (the c3 shape); (b) real searches
+    # among them; (c) a batch that mixes repeated-row problems with plain ones; (d) runs longer than a wave looks ahead
+    from cytospace_amd.lap import lap_solve_batch
+    from tools import instances
+    c, _ = instances.c3_shaped_cost(3000, 10, 3)
+    g, o = _check_wide(c)
+    assert g["info"].wide_trivial == 2100 and g["info"].wide_aug_rounds == 0
+    rng = np.random.default_rng(91)
+    dup = np.repeat(rng.random((250, 1000)), 4, axis=0).astype(np.float32)
+    g, o = _check_wide(dup)
+    assert g["info"].wide_trivial > 0 and g["info"].wide_aug_rounds > 0
+    long_runs = np.repeat(-(rng.random((12, 1200)) ** 3), 100, axis=0).astype(np.float32)
+    _check_wide(long_runs)
+    cs = [dup, rng.random((1000, 1000)).astype(np.float32), c[:1000, :1000].copy(), np.repeat(rng.random((100, 1000)), 10, axis=0).astype(np.float32)]
+    oracle = [jv_oracle_wide(x, np.float32) for x in cs]
+    res = lap_solve_batch(cs, return_info=True, opts=dict(mode=2))
+    for x, g, o in zip(cs, res, oracle):
+        for key in ("rowsol", "colsol", "u", "v"):
+            assert np.array_equal(g[key], o[key]), key
+        assert g["info"].path_hops == o["stats"].path_hops and g["info"].scans_aug_relax == o["stats"].scans_aug_relax
+
+
 def test_wide_full_row_fallbacks_on_near_equal_columns():
     # few cell types: hundreds of near-equal columns per row, the 63-column caches cannot certify -- bids and relaxations read
     # the full cost row, the search re-converges after every certificate pass; still the oracle's answer bit for bit
