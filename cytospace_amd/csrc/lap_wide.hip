@@ -18,6 +18,8 @@
 //              pure function of the state.
 //   wide_arr   the chain rounds (<= 64 active rows) of instances that did not scale -- one 16-wave workgroup per problem, the
 //              rows in registers, bids meeting in LDS -- and every problem's list of free rows for the searches.
+//   wide_claim_*  the searches that are ONE EDGE (CytoSPACE's repeated spot rows: a free slot takes the next free column tied at its
+//              spot's minimum) on the whole chip, before the search kernel: the serial loop's assignments by deferred acceptance.
 //   wide_aug   AUGMENTATION: per free row a shortest-path search whose labels are the unique fixed point of a monotone
 //              system ((distance, tight-hop count) labels), so the search is run SPECULATIVELY: every round each of the 16 waves
 //              settles the best unsettled columns of the column blocks it owns and relaxes their owner rows from the
