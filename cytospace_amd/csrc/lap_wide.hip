@@ -145,6 +145,9 @@ static_assert(sizeof(ScCtl) <= 2048, "control block of the row-reduction phase")
 constexpr int SC_K0 = 8, SC_NPH = 16, SC_PHCAP = 1024, SC_EMULT = 3, SC_ESTEP = 1;
 constexpr int SC_STOP_FINAL = 16;       // the final eps = 0 phase ends at min(wide_stop(n), 16) active rows (JV_WIDE_STOP_FINAL)
 constexpr int SC_UNROLL = 4;           // quads of a full-row sweep in flight per lane (2: 67 registers, 7 waves per SIMD; 3: 79, 6; 4: 107, 4 -- and 4 is the fastest: gpurun_out/r05h)
+#ifndef HEAVY_SPREAD
+#define HEAVY_SPREAD 1
+#endif
 constexpr int SC_SMALL = 2048;         // launches with at most so many bids to resolve give every bid a wave of its own (a matter of speed only)
 constexpr int SC_COARSE = 4;           // phases whose full-row bids leave the row caches alone (a matter of speed only)
 #ifndef WIDE_STOP_CAP
@@ -744,7 +747,9 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
         for (int i = blockIdx.x * HEADB + threadIdx.x; i < n; i += gridDim.x * HEADB) { a.rowsol[i] = -1; a.colsol[i] = -1; pfix[i] = f2ord(a.v[i]); }
     }
     // few bids to resolve: a wave per bid (below); else tiles
-    const bool small = act == SC_ACT_ROUND && np <= small_max && np <= (int)gridDim.x * (HEADB / 64);
+    // (an instance that bids from full rows a lot -- S.heavy -- takes the tiles even for few bids when it has the chip to itself (a batch's
+    //  problems have 64-256 workgroups each: measured slower there): ONE bid per workgroup while there are workgroups enough: a full-row bid is the whole workgroup's work, and the launch waits for the workgroup with the most of them)
+    const bool small = act == SC_ACT_ROUND && !(S.heavy && HEAVY_SPREAD && gridDim.x >= 512) && np <= small_max && np <= (int)gridDim.x * (HEADB / 64);
     if (small && (int)blockIdx.x * (HEADB / 64) >= np) return;
     ScShared &ss = *reinterpret_cast<ScShared *>(w_smem);
     if (threadIdx.x == 0) { ss.nq = 0; ss.fill_ = 0; ss.cnt = 0; }
@@ -840,7 +845,7 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
         // (a run of at least 8 bids -- fewer atomics on the launch's counter -- unless the instance bids from full rows a lot: those a
         //  workgroup reads one after the other, and the launch waits for the workgroup with the most of them)
         const bool heavy = S.heavy != 0;
-        const int chunk = std::max(act == SC_ACT_ROUND && !heavy ? 8 : HEADB / 64, (nwork + (int)gridDim.x - 1) / (int)gridDim.x);
+        const int chunk = std::max(act == SC_ACT_ROUND && !heavy ? 8 : (heavy && HEAVY_SPREAD && gridDim.x >= 512 && act == SC_ACT_ROUND ? 1 : HEADB / 64), (nwork + (int)gridDim.x - 1) / (int)gridDim.x);
         const int c_lo = std::min(nwork, (int)blockIdx.x * chunk), c_hi = std::min(nwork, c_lo + chunk);
         for (int t0 = c_lo; t0 < c_hi; t0 += HEADB) {
             const int tn = std::min(HEADB, c_hi - t0);           // work items of this tile
