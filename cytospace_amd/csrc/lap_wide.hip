@@ -2392,7 +2392,7 @@ struct PinnedInts {
         cap = want;
         return CYTO_OK;
     }
-    ~PinnedInts() { if (p) (void)hipHostFree(p); }
+    // (no destructor: a driver thread that ends while the process unloads the HIP runtime must not call into it; 256 bytes per thread)
 };
 
 size_t wide_sc_ones_bytes(int n) { return (((size_t)n + 63) & ~(size_t)63) * (2 * 8); }
