@@ -1554,6 +1554,10 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                 // dirty bits are read here, the labels after them, the result is merged with an atomic min -- an offer either set
                 // its dirty bit before this read (then its label, completed before the bit, is seen) or lowers the minimum itself
                 // after the void store.  The block yields no pick for one round; no round ends the search while a rebuild is due.
+                // (When the number of waves taking part changes between two rounds -- 4 <-> 16 -- a block's NEW owner may pick from it in the very
+                //  round its old owner's rebuild is merged: the rebuild can then put back a column that is being settled.  Labels are a
+                //  fixed point, so results do not depend on it; the column is settled once more, which is why wide_aug_rounds and
+                //  wide_aug_settled -- and nothing else -- may differ from run to run by a few units.)
                 bool db[AP]; unsigned long long lbr[AP];
 #pragma unroll
                 for (int q = 0; q < AP; q++) {

@@ -95,8 +95,8 @@ typedef struct {
     int64_t wide_retired;        /* rows that left the rounds on a tie (handed to the augmentation) */
     int64_t wide_dense_arr;      /* bids whose row cache could not certify the top-2 (full row read) */
     int64_t wide_dense_aug;      /* augmentation: relaxations from the full cost row (cache certificate failed) */
-    int64_t wide_aug_rounds;     /* augmentation: rounds of the speculative search (16 columns settled per round at most) */
-    int64_t wide_aug_settled;    /* augmentation: columns settled, re-settlements after a label improved included */
+    int64_t wide_aug_rounds;     /* augmentation: rounds of the speculative search (16 columns settled per round at most); schedule-dependent */
+    int64_t wide_aug_settled;    /* augmentation: columns settled, re-settlements after a label improved included; schedule-dependent (results are not) */
     int64_t wide_trivial;        /* augmentation: searches that ended at the free row's own best column */
     int64_t wide_verify_passes;  /* augmentation: certificate passes (>= one per non-trivial search) */
     int64_t wide_list_rounds, wide_chain_rounds;   /* row-reduction rounds in the list / chain regime */
