@@ -1209,6 +1209,14 @@ __global__ __launch_bounds__(WT) void wide_arr(const WideArgs *__restrict__ batc
 // is below s_T's; clears the dirty bit, reads the label, relaxes the owner row's cached columns.  Barrier.  The block
 // minimum of the block a wave took from is rebuilt.  Barrier.  No wave found work: converged.
 // ------------------------------------------------------------------------------------------------------------------
+// (scratch of the one-edge searches: the machine's arrays a.scx, free once the row reduction is over -- wide_claim_* below, and wide_aug's loop)
+struct ClaimCtl { int changed, blocked, rounds, pad_; };
+__device__ __forceinline__ int *cl_claim(const WideArgs &a) { return reinterpret_cast<int *>(a.scx); }
+__device__ __forceinline__ unsigned long long *cl_mask(const WideArgs &a) { return reinterpret_cast<unsigned long long *>(a.scx + sc_np(a.n) * 8); }
+__device__ __forceinline__ int2 *cl_state(const WideArgs &a) { return reinterpret_cast<int2 *>(a.scx + sc_np(a.n) * 16); }
+__device__ __forceinline__ ClaimCtl *cl_ctl(const WideArgs &a) { return reinterpret_cast<ClaimCtl *>(a.scx + sc_np(a.n) * 24); }
+// per free-list position: how many rows of its run of identical rows are left from it on (itself included)
+__device__ __forceinline__ int *cl_rem(const WideArgs &a) { return reinterpret_cast<int *>(a.scx + sc_np(a.n) * 32); }
 constexpr int AP = 2;              // columns a wave settles per round (their loads are in flight together)
 
 size_t wide_aug_lds_bytes(int n, bool vlds, bool clds) {
@@ -1383,39 +1391,54 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
         // ---- wave 0 disposes of the searches that end at once: the free row's best cached column is unassigned and its
         // cache certifies that (no column settled, no price changes: the path is one edge) ----
         if (!PAR && w == 0) {
-            // a two-deep pipeline over the free list (35 000 such searches at c3): while search f is decided, the prices of search
-            // f + 1's cached columns and the cache row of search f + 2 are in flight -- prices do not change in this loop
-            auto row_of = [&](int ff) -> int { return ff < numfree ? uni(a.freerows[ff]) : -1; };
+            // A pipeline over the free list (35 000 such searches at c3), three steps deep: while step k is decided, the prices of step
+            // k + 1's cached columns, the cache row of step k + 2 and the position / row / length of step k + 3 are in flight --
+            // prices do not change in this loop.  A STEP is a run of identical rows (ten slots per spot at c3: free together, identical
+            // caches, consecutive in the free list; their lengths come from the whole-chip pass before the kernel, cl_rem): with the
+            // prices fixed, the t-th row of the run takes the t-th lowest of the unassigned columns that tie at the minimum -- the whole
+            // run is one step, and the step after it is known before this one is decided.  (Rounds 3-4 found a run's end inside the
+            // step and started the pipeline again behind every run: four dependent loads per run, 1.5 us.)
             auto flush_one_edge = [&](int cnt) {
                 if (lane < cnt) {
                     const int r = s.st_row[lane], cc = s.st_col[lane];
                     a.rowsol[r] = cc; a.colsol[cc] = r; a.cassign[cc] = s.st_val[lane];
                 }
             };
+            const int *remp = (a.same_prev && a.scx) ? cl_rem(a) : nullptr;
             int nst = 0;
-            int fr1 = row_of(f), fr2 = row_of(f + 1);
-            uint32_t col1 = COLSENT, col2 = COLSENT;
-            float val1 = 0.0f, val2 = 0.0f, vv1 = 0.0f;
-            if (fr1 >= 0) { col1 = a.cache_col[(int64_t)fr1 * KC + lane]; val1 = a.cache_val[(int64_t)fr1 * KC + lane]; }
-            if (fr2 >= 0) { col2 = a.cache_col[(int64_t)fr2 * KC + lane]; val2 = a.cache_val[(int64_t)fr2 * KC + lane]; }
-            if (fr1 >= 0 && lane < KCU && col1 != COLSENT) vv1 = getv((int)col1);
+            // stage 0: decided now; stage 1: cache row here, prices in flight; stage 2: row known, cache row in flight; stage 3: position
+            // known, row and length in flight (as loaded: made uniform when the stage moves up)
+            int p0, l0, r0, p1, l1, r1, p2, l2, r2, p3, l3v, r3v;
+            uint32_t col0, col1, col2; float val0, val1, val2, vv0, vv1;
+            auto start = [&](int ff) {                               // (cold: a chain of loads -- at the start and behind a run cut short)
+                auto len_of = [&](int pp) -> int { return pp < numfree ? (remp ? uni(remp[pp]) : 1) : 1; };
+                auto row_at = [&](int pp) -> int { return pp < numfree ? uni(a.freerows[pp]) : -1; };
+                p0 = ff; l0 = len_of(p0); r0 = row_at(p0);
+                p1 = p0 + l0; l1 = len_of(p1); r1 = row_at(p1);
+                p2 = p1 + l1; l2 = len_of(p2); r2 = row_at(p2);
+                p3 = p2 + l2; l3v = p3 < numfree ? (remp ? remp[p3] : 1) : 1; r3v = p3 < numfree ? a.freerows[p3] : -1;
+                col0 = COLSENT; col1 = COLSENT; col2 = COLSENT; val0 = 0.0f; val1 = 0.0f; val2 = 0.0f;
+                if (r0 >= 0) { col0 = a.cache_col[(int64_t)r0 * KC + lane]; val0 = a.cache_val[(int64_t)r0 * KC + lane]; }
+                if (r1 >= 0) { col1 = a.cache_col[(int64_t)r1 * KC + lane]; val1 = a.cache_val[(int64_t)r1 * KC + lane]; }
+                if (r2 >= 0) { col2 = a.cache_col[(int64_t)r2 * KC + lane]; val2 = a.cache_val[(int64_t)r2 * KC + lane]; }
+                vv0 = (r0 >= 0 && lane < KCU && col0 != COLSENT) ? getv((int)col0) : 0.0f;
+                vv1 = (r1 >= 0 && lane < KCU && col1 != COLSENT) ? getv((int)col1) : 0.0f;
+            };
+            start(f);
             while (f < numfree) {
-                const int fr = fr1;
-                const uint32_t col = col1;
-                const float val = val1, vv = vv1;
-                // runs of identical rows (ten slots per spot at c3) are free together and have identical caches (built once per run):
-                // with the prices fixed in this loop, the t-th of them takes the t-th lowest of the unassigned columns that tie at
-                // the minimum -- the whole run is one step.  Lane t looks at the t-th free row after this one.
-                bool follower = false;
-                if (a.same_prev) {
-                    const int ft = f + lane;
-                    follower = lane > 0 && ft < numfree && a.freerows[ft] == fr + lane && a.same_prev[fr + lane] != 0;
-                }
-                // advance the pipeline: search f + 1's prices, search f + 2's cache row
-                fr1 = fr2; col1 = col2; val1 = val2;
-                vv1 = (fr1 >= 0 && lane < KCU && col1 != COLSENT) ? getv((int)col1) : 0.0f;
-                fr2 = row_of(f + 2);
-                if (fr2 >= 0) { col2 = a.cache_col[(int64_t)fr2 * KC + lane]; val2 = a.cache_val[(int64_t)fr2 * KC + lane]; }
+                const int fr = r0, L = l0 < 1 ? 1 : l0;
+                const uint32_t col = col0;
+                const float val = val0, vv = vv0;
+                // the stages move up (as if this step took its whole run: else the pipeline starts again below)
+                const int n_p3 = p3, n_l3 = uni(l3v), n_r3 = uni(r3v);          // stage 3's row and length have arrived
+                p0 = p1; l0 = l1; r0 = r1; col0 = col1; val0 = val1; vv0 = vv1;
+                p1 = p2; l1 = l2; r1 = r2; col1 = col2; val1 = val2;
+                vv1 = (r1 >= 0 && lane < KCU && col1 != COLSENT) ? getv((int)col1) : 0.0f;
+                p2 = n_p3; l2 = n_l3 < 1 ? 1 : n_l3; r2 = n_r3;
+                col2 = COLSENT; val2 = 0.0f;
+                if (r2 >= 0) { col2 = a.cache_col[(int64_t)r2 * KC + lane]; val2 = a.cache_val[(int64_t)r2 * KC + lane]; }
+                p3 = p2 + l2;
+                l3v = p3 < numfree ? (remp ? remp[p3] : 1) : 1; r3v = p3 < numfree ? a.freerows[p3] : -1;
                 const float tau = rdlane(val, KCU);
                 const bool valid = lane < KCU && col != COLSENT;
                 const uint32_t od = valid ? f2ord(val - vv) : 0xFFFFFFFFu;
@@ -1424,12 +1447,8 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                 const uint64_t mu = __ballot(un);
                 if (!(omin != 0xFFFFFFFFu && mu && tau > ord2f(omin))) break;
                 // this row and the identical free rows right behind it, as many as there are tied unassigned columns
-                int m = 1;
-                if (a.same_prev) {
-                    const int cntmu = __popcll(mu);
-                    const uint64_t okm = __ballot(follower && lane < cntmu) | 1ull;
-                    m = __ffsll((unsigned long long)~okm) - 1;          // leading ones (bit 63 is never set: lane 63 < cntmu <= 63 fails)
-                }
+                const int cntmu = __popcll(mu);
+                const int m = L < cntmu ? L : cntmu;
                 if (nst + m > 64) { flush_one_edge(nst); nst = 0; }
                 const int rank = __popcll(mu & lanemask_lt());           // cache rows are sorted by column: ranks go by column
                 if (un && rank < m) {
@@ -1443,13 +1462,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                 f += m;
                 nst += m;
                 if (nst == 64) { flush_one_edge(nst); nst = 0; }
-                if (m > 1) {                                             // the rows in flight were part of the run: start the pipeline again
-                    fr1 = row_of(f); fr2 = row_of(f + 1);
-                    col1 = COLSENT; col2 = COLSENT; val1 = 0.0f; val2 = 0.0f; vv1 = 0.0f;
-                    if (fr1 >= 0) { col1 = a.cache_col[(int64_t)fr1 * KC + lane]; val1 = a.cache_val[(int64_t)fr1 * KC + lane]; }
-                    if (fr2 >= 0) { col2 = a.cache_col[(int64_t)fr2 * KC + lane]; val2 = a.cache_val[(int64_t)fr2 * KC + lane]; }
-                    if (fr1 >= 0 && lane < KCU && col1 != COLSENT) vv1 = getv((int)col1);
-                }
+                if (m != L && f < numfree) start(f);                     // (the run's other rows are not one-edge searches: most likely the loop ends with the next step)
             }
             flush_one_edge(nst);
             if (lane == 0) {
@@ -2279,11 +2292,6 @@ __global__ __launch_bounds__(WT) void wide_aug_mc(const WideArgs *__restrict__ b
 // t-th row of a run of identical rows starts at its list's t-th column (the t rows before it want the same columns and come first).
 // Scratch: the machine's arrays (a.scx; the row reduction is over): claims [n], lists as lane masks [n], {next candidate, lane held} [n].
 // ------------------------------------------------------------------------------------------------------------------
-struct ClaimCtl { int changed, blocked, rounds, pad_; };
-__device__ __forceinline__ int *cl_claim(const WideArgs &a) { return reinterpret_cast<int *>(a.scx); }
-__device__ __forceinline__ unsigned long long *cl_mask(const WideArgs &a) { return reinterpret_cast<unsigned long long *>(a.scx + sc_np(a.n) * 8); }
-__device__ __forceinline__ int2 *cl_state(const WideArgs &a) { return reinterpret_cast<int2 *>(a.scx + sc_np(a.n) * 16); }
-__device__ __forceinline__ ClaimCtl *cl_ctl(const WideArgs &a) { return reinterpret_cast<ClaimCtl *>(a.scx + sc_np(a.n) * 24); }
 // the k-th set bit of m at or after ... : lane of the (k + 1)-th set bit, -1 if there are not that many
 __device__ __forceinline__ int nth_set(unsigned long long m, int k) {
     for (int t = 0; t < k && m; t++) m &= m - 1;
@@ -2318,6 +2326,12 @@ __global__ __launch_bounds__(HEADB) void wide_claim_lists(const WideArgs *__rest
                 while (t < 63 && p - t - 1 >= 0 && a.same_prev[fr - t] != 0 && a.freerows[p - t - 1] == fr - t - 1) t++;
             cl_mask(a)[p] = mu;
             cl_state(a)[p] = make_int2(t, -1);                   // x: candidates of the list passed over so far; y: the lane it holds (-1: none, -2: ran out)
+            if (t == 0) {                                        // the head of a run: its length, for wide_aug's loop over the rows left
+                int len = 1;
+                if (a.same_prev)
+                    while (p + len < numfree && a.same_prev[fr + len] != 0 && a.freerows[p + len] == fr + len) len++;
+                for (int k = 0; k < len; k++) cl_rem(a)[p + k] = len - k;
+            }
         }
     }
 }
