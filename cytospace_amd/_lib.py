@@ -147,9 +147,10 @@ def lib():
         L.cyto_comm_kind.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
         L.cyto_comm_agree.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
         L.cyto_comm_abort.argtypes = [vp]
+        L.cyto_comm_aborted.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
         L.cyto_comm_bcast_f32.argtypes = [vp, vp, ctypes.c_size_t, i32, i32, vp]
         L.cyto_comm_destroy.argtypes = [vp]
-        for name in ("cyto_comm_init_local", "cyto_comm_count", "cyto_comm_kind", "cyto_comm_agree", "cyto_comm_abort"):
+        for name in ("cyto_comm_init_local", "cyto_comm_count", "cyto_comm_kind", "cyto_comm_agree", "cyto_comm_abort", "cyto_comm_aborted"):
             getattr(L, name).restype = ctypes.c_int
         # ABI check: the structs mirrored above must be the library's (include/cytohip.h carries no size members)
         sz = [ctypes.c_size_t() for _ in range(4)]
@@ -283,9 +284,15 @@ class Communicator:
         return s.value
 
     def abort(self):
-        """This rank cannot reach a collective its peers wait in: release them (they fail with CYTO_ERR_PEER)."""
+        """This rank cannot reach a collective its peers wait in: release them (they fail with CYTO_ERR_PEER).  Communicators
+        made by init_local are aborted TOGETHER (every sibling, whichever rank calls)."""
         if self._h:
             lib().cyto_comm_abort(self._h)
+
+    def aborted(self):
+        a = ctypes.c_int()
+        check(lib().cyto_comm_aborted(self._h, ctypes.byref(a)))
+        return bool(a.value)
 
     def close(self):
         if self._h:

@@ -15,6 +15,7 @@
 // allocated when the communicator is made.
 #include "cyto_common.h"
 #include <rccl/rccl.h>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <condition_variable>
@@ -41,13 +42,39 @@ struct LocalGroup {
     int32_t words[16] = {};            // published by the root of a host-word broadcast
 };
 
+struct Comm;
+// RCCL communicators made together in ONE process (cyto_comm_init_local on distinct devices): a rank that fails aborts ALL of them --
+// ncclCommAbort of its own communicator alone does not release the peers that already sit in a collective (their kernels wait for a
+// rank that will never arrive), and they all live in this process.
+struct RcclGroup {
+    std::mutex m;
+    std::vector<Comm *> members;
+    int refs = 0;
+};
+
 struct Comm {
     int kind = 0;                      // 0: RCCL, 1: LOCAL
     ncclComm_t nccl = nullptr;
     LocalGroup *grp = nullptr;
+    RcclGroup *rgrp = nullptr;         // RCCL kind, in-process siblings (null: one process per GPU)
     int rank = 0, nranks = 1, device = 0;
     void *word = nullptr;              // 64 bytes on `device` (RCCL kind: the small collectives' buffer)
+    std::mutex use_m;                  // RCCL kind: held while a call is ENQUEUED on `nccl` (never while its stream is waited for) and by the abort
+    std::atomic<int> aborted{0};
 };
+
+// RCCL kind: enqueue one collective unless the communicator has been aborted (by this rank or, in one process, by a sibling)
+template <typename F> int rccl_enqueue(Comm *c, F &&f) {
+    std::lock_guard<std::mutex> lk(c->use_m);
+    if (c->aborted.load() || !c->nccl) return CYTO_ERR_PEER;
+    return f(c->nccl) == ncclSuccess ? CYTO_OK : CYTO_ERR_HIP;
+}
+// ncclCommAbort, once: the kernels of a collective under way give up, the thread waiting for its stream returns
+void rccl_abort_one(Comm *c) {
+    c->aborted.store(1);
+    std::lock_guard<std::mutex> lk(c->use_m);
+    if (c->nccl) { (void)ncclCommAbort(c->nccl); c->nccl = nullptr; }
+}
 
 constexpr int k_local_timeout_s = 900;
 
@@ -99,8 +126,9 @@ int comm_bcast_words(void *comm_, int32_t *words, int nwords, int root) {
     if (hipSetDevice(c->device) != hipSuccess) rc = CYTO_ERR_HIP;
     if (!rc && hipMemcpy(c->word, words, sizeof(int32_t) * (size_t)nwords, hipMemcpyHostToDevice) != hipSuccess) rc = CYTO_ERR_HIP;
     // (entered whatever happened above: the peers are on their way in)
-    if (ncclBroadcast(c->word, c->word, (size_t)nwords, ncclInt32, root, c->nccl, nullptr) != ncclSuccess) rc = rc ? rc : CYTO_ERR_HIP;
+    { const int e = rccl_enqueue(c, [&](ncclComm_t nc) { return ncclBroadcast(c->word, c->word, (size_t)nwords, ncclInt32, root, nc, nullptr); }); rc = rc ? rc : e; }
     if (hipStreamSynchronize(nullptr) != hipSuccess) rc = rc ? rc : CYTO_ERR_HIP;
+    if (c->aborted.load()) rc = CYTO_ERR_PEER;                                  // (whatever arrived is not the root's word)
     if (!rc && hipMemcpy(words, c->word, sizeof(int32_t) * (size_t)nwords, hipMemcpyDeviceToHost) != hipSuccess) rc = CYTO_ERR_HIP;
     if (rc) { (void)hipGetLastError(); }
     return rc;
@@ -115,8 +143,9 @@ int comm_allreduce_max(void *comm_, int *val) {
     int32_t w = *val;
     if (hipSetDevice(c->device) != hipSuccess) rc = CYTO_ERR_HIP;
     if (!rc && hipMemcpy(c->word, &w, 4, hipMemcpyHostToDevice) != hipSuccess) rc = CYTO_ERR_HIP;
-    if (ncclAllReduce(c->word, c->word, 1, ncclInt32, ncclMax, c->nccl, nullptr) != ncclSuccess) rc = rc ? rc : CYTO_ERR_HIP;
+    { const int e = rccl_enqueue(c, [&](ncclComm_t nc) { return ncclAllReduce(c->word, c->word, 1, ncclInt32, ncclMax, nc, nullptr); }); rc = rc ? rc : e; }
     if (hipStreamSynchronize(nullptr) != hipSuccess) rc = rc ? rc : CYTO_ERR_HIP;
+    if (c->aborted.load()) rc = CYTO_ERR_PEER;
     if (!rc && hipMemcpy(&w, c->word, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = CYTO_ERR_HIP;
     if (rc) { (void)hipGetLastError(); return rc; }
     *val = w;
@@ -154,8 +183,9 @@ int comm_bcast_dev(void *comm_, void *dev_buf, size_t bytes, int root, hipStream
     }
     int rc = CYTO_OK;
     if (hipSetDevice(c->device) != hipSuccess) rc = CYTO_ERR_HIP;
-    if (ncclBroadcast(dev_buf, dev_buf, bytes, ncclChar, root, c->nccl, stream) != ncclSuccess) rc = rc ? rc : CYTO_ERR_HIP;
+    { const int e = rccl_enqueue(c, [&](ncclComm_t nc) { return ncclBroadcast(dev_buf, dev_buf, bytes, ncclChar, root, nc, stream); }); rc = rc ? rc : e; }
     if (hipStreamSynchronize(stream) != hipSuccess) rc = rc ? rc : CYTO_ERR_HIP;
+    if (c->aborted.load()) rc = CYTO_ERR_PEER;
     if (rc) (void)hipGetLastError();
     return rc;
 }
@@ -210,10 +240,14 @@ int cyto_comm_init_local(int nranks, const int *device_ids, void **comms_out) {
     } catch (...) { return CYTO_ERR_NOMEM; }
     std::vector<Comm *> cs;
     LocalGroup *grp = nullptr;
+    cyto::RcclGroup *rgrp = nullptr;
     int rc = CYTO_OK;
     try {
         cs.assign((size_t)nranks, nullptr);
-        if (!distinct || nranks == 1) { grp = new LocalGroup(); grp->nranks = nranks; grp->refs = nranks; }
+        // (CYTO_COMM_FORCE_RCCL: developer knob of the test-suite -- a lone rank through ncclCommInitAll, so that a one-GPU box runs the
+        //  RCCL kind's enqueue / abort paths)
+        const bool local_kind = !distinct || (nranks == 1 && !(CYTO_KNOB("CYTO_COMM_FORCE_RCCL").set && CYTO_KNOB("CYTO_COMM_FORCE_RCCL").value));
+        if (local_kind) { grp = new LocalGroup(); grp->nranks = nranks; grp->refs = nranks; }
         for (int r = 0; r < nranks && !rc; r++) {
             Comm *c = cs[(size_t)r] = new Comm();
             c->kind = grp ? 1 : 0; c->grp = grp; c->rank = r; c->nranks = nranks; c->device = device_ids[r];
@@ -221,13 +255,16 @@ int cyto_comm_init_local(int nranks, const int *device_ids, void **comms_out) {
         }
         if (!rc && !grp) {
             std::vector<ncclComm_t> nc((size_t)nranks);
+            rgrp = new cyto::RcclGroup();
+            rgrp->members = cs; rgrp->refs = nranks;
             if (ncclCommInitAll(nc.data(), nranks, device_ids) != ncclSuccess) rc = CYTO_ERR_HIP;
-            else for (int r = 0; r < nranks; r++) cs[(size_t)r]->nccl = nc[(size_t)r];
+            else for (int r = 0; r < nranks; r++) { cs[(size_t)r]->nccl = nc[(size_t)r]; cs[(size_t)r]->rgrp = rgrp; }
         }
     } catch (...) { rc = CYTO_ERR_NOMEM; }
     if (rc) {
         for (Comm *c : cs) if (c) { if (c->word) { (void)hipSetDevice(c->device); (void)hipFree(c->word); } delete c; }
         delete grp;
+        delete rgrp;
         return rc;
     }
     for (int r = 0; r < nranks; r++) comms_out[r] = cs[(size_t)r];
@@ -265,8 +302,11 @@ int cyto_comm_agree(void *comm, int *status) {
 }
 
 // A rank that cannot reach a collective its peers are (or will be) waiting in calls this instead: LOCAL kind -- the waiting
-// ranks return CYTO_ERR_PEER; RCCL kind -- ncclCommAbort of this rank's communicator.  The handle stays valid for
-// cyto_comm_destroy only.
+// ranks return CYTO_ERR_PEER; RCCL kind -- ncclCommAbort of this rank's communicator AND, when the ranks are host threads of this
+// process (cyto_comm_init_local), of every sibling's: a peer already inside ncclBroadcast / ncclAllReduce is released only by the
+// abort of ITS communicator (its kernel polls that flag), and returns CYTO_ERR_PEER; one process per GPU: the launcher's job
+// (the peers' own time-outs).  Every later collective on an aborted handle returns CYTO_ERR_PEER at once.  The handle stays valid
+// for cyto_comm_destroy only.
 int cyto_comm_abort(void *comm) {
     Comm *c = cyto::as_comm(comm);
     if (!c) return CYTO_ERR_BAD_ARG;
@@ -276,7 +316,22 @@ int cyto_comm_abort(void *comm) {
         c->grp->cv.notify_all();
         return CYTO_OK;
     }
-    if (c->nccl) { (void)ncclCommAbort(c->nccl); c->nccl = nullptr; }
+    if (c->rgrp) {
+        std::lock_guard<std::mutex> lk(c->rgrp->m);
+        for (Comm *m : c->rgrp->members) if (m) m->aborted.store(1);          // (nobody enters another collective ...)
+        for (Comm *m : c->rgrp->members) if (m) cyto::rccl_abort_one(m);      // (... and the ones under way give up)
+        return CYTO_OK;
+    }
+    cyto::rccl_abort_one(c);
+    return CYTO_OK;
+}
+
+// 1 once the communicator (or, in one process, a sibling) has been aborted
+int cyto_comm_aborted(void *comm, int *aborted_out) {
+    Comm *c = cyto::as_comm(comm);
+    if (!c || !aborted_out) return CYTO_ERR_BAD_ARG;
+    if (c->kind == 1) { std::lock_guard<std::mutex> lk(c->grp->m); *aborted_out = c->grp->aborted ? 1 : 0; }
+    else *aborted_out = c->aborted.load() ? 1 : 0;
     return CYTO_OK;
 }
 
@@ -288,8 +343,17 @@ int cyto_comm_destroy(void *comm) {
         bool last;
         { std::lock_guard<std::mutex> lk(c->grp->m); last = --c->grp->refs == 0; }
         if (last) delete c->grp;
-    } else if (c->nccl) {
-        (void)ncclCommDestroy(c->nccl);
+    } else {
+        if (c->rgrp) {
+            bool last;
+            {
+                std::lock_guard<std::mutex> lk(c->rgrp->m);
+                for (Comm *&m : c->rgrp->members) if (m == c) m = nullptr;
+                last = --c->rgrp->refs == 0;
+            }
+            if (last) delete c->rgrp;
+        }
+        if (c->nccl) (void)ncclCommDestroy(c->nccl);
     }
     delete c;
     return CYTO_OK;

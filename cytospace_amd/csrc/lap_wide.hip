@@ -35,6 +35,9 @@
 #include "lap_wide.h"
 #include <algorithm>
 #include <chrono>
+#include <mutex>
+#include <thread>
+#include <vector>
 
 namespace cyto {
 
@@ -2329,7 +2332,7 @@ __global__ __launch_bounds__(HEADB) void wide_claim_lists(const WideArgs *__rest
             if (t == 0) {                                        // the head of a run: its length, for wide_aug's loop over the rows left
                 int len = 1;
                 if (a.same_prev)
-                    while (p + len < numfree && a.same_prev[fr + len] != 0 && a.freerows[p + len] == fr + len) len++;
+                    while (p + len < numfree && a.freerows[p + len] == fr + len && a.same_prev[fr + len] != 0) len++;      // (the position first: fr + len < n only while the list says so)
                 for (int k = 0; k < len; k++) cl_rem(a)[p + k] = len - k;
             }
         }
@@ -2363,13 +2366,21 @@ __global__ __launch_bounds__(HEADB) void wide_claim_round(const WideArgs *__rest
     if (__ballot(changed) && (threadIdx.x & 63) == 0) atomicAdd(&cl_ctl(a)->changed, 1);
 }
 
-// after a few rounds: did anything move?  (seg_sync[1 + b]: 1 = problem b is not at its fixed point; the driver reads it)
-__global__ void wide_claim_check(const WideArgs *__restrict__ batch) {
-    const WideArgs a = load_wide_args(batch, blockIdx.x);
-    if (threadIdx.x != 0) return;
-    ClaimCtl *c = cl_ctl(a);
-    a.seg_sync[1 + blockIdx.x] = c->changed ? 1 : 0;
-    c->changed = 0; c->rounds += 1;
+// after a few rounds: did anything move?  One thread looks at every problem of the batch and reports into pinned host memory (no
+// synchronisation: the driver polls) -- hs[0] = groups of rounds checked so far, hs[1] = the first group after which NO problem had
+// moved (0: none yet; rounds at the fixed point change nothing, so the groups the driver queued ahead are harmless).
+__global__ void wide_claim_check(const WideArgs *__restrict__ batch, int nb, int group, int *hs) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int any = 0;
+    for (int b = 0; b < nb; b++) {
+        const WideArgs a = load_wide_args(batch, b);
+        ClaimCtl *c = cl_ctl(a);
+        any |= c->changed;
+        c->changed = 0; c->rounds += 1;
+    }
+    if (!any && __hip_atomic_load(hs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0)
+        __hip_atomic_store(hs + 1, group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(hs, group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // the fixed point: the first row that ran out of columns ...
@@ -2399,18 +2410,67 @@ __global__ __launch_bounds__(HEADB) void wide_claim_commit(const WideArgs *__res
     }
 }
 
-// a few ints of pinned, device-visible host memory per driver thread (the machine's launches report into it)
+// A few ints of pinned, device-visible host memory per driver call (the machine's launches report into it).  The blocks come from
+// a small process-wide pool and go back to it when the call ends: driver threads are short-lived (batch.hip spawns them per call, the
+// Python side one per device and call), so a block owned by a thread would be leaked with every call.  The pool itself is never
+// freed (a process that unloads the HIP runtime at exit must not call into it from a static destructor): it holds as many blocks
+// as calls were ever in flight at once.
+struct PinnedPool {
+    struct Block { int *p; size_t cap; int dev; hipEvent_t ev; bool pending; };     // pending: launches that write into it may still be queued (ev: behind them)
+    std::mutex m;
+    std::vector<Block> idle;
+    static PinnedPool &get() { static PinnedPool *pool = new PinnedPool(); return *pool; }
+};
 struct PinnedInts {
     int *p = nullptr; size_t cap = 0;
-    int ensure(size_t count) {
+    int dev = 0; hipEvent_t ev = nullptr; hipStream_t stream = nullptr;
+    PinnedInts() = default;
+    PinnedInts(const PinnedInts &) = delete;
+    PinnedInts &operator=(const PinnedInts &) = delete;
+    ~PinnedInts() { release(); }
+    // back to the pool, usable again once everything queued on `stream` so far has run (the kernels that report into the block)
+    void release() {
+        if (!p) return;
+        const bool pending = ev && hipEventRecord(ev, stream) == hipSuccess;
+        if (!pending) (void)hipStreamSynchronize(stream);
+        PinnedPool &pool = PinnedPool::get();
+        try { std::lock_guard<std::mutex> lk(pool.m); pool.idle.push_back({p, cap, dev, ev, pending}); }
+        catch (...) { (void)hipStreamSynchronize(stream); (void)hipHostFree(p); if (ev) (void)hipEventDestroy(ev); }
+        p = nullptr; cap = 0; ev = nullptr;
+    }
+    int ensure(size_t count, hipStream_t used_on) {
+        stream = used_on;
         if (count <= cap) return CYTO_OK;
-        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        release();
+        CYTO_HIP(hipGetDevice(&dev));
+        PinnedPool &pool = PinnedPool::get();
+        {
+            std::lock_guard<std::mutex> lk(pool.m);
+            for (size_t k = 0; k < pool.idle.size(); k++) {
+                PinnedPool::Block &b = pool.idle[k];
+                if (b.dev != dev || b.cap < count) continue;
+                if (b.pending && hipEventQuery(b.ev) != hipSuccess) { (void)hipGetLastError(); continue; }
+                p = b.p; cap = b.cap; ev = b.ev;
+                pool.idle[k] = pool.idle.back(); pool.idle.pop_back();
+                return CYTO_OK;
+            }
+        }
         const size_t want = std::max<size_t>(64, count * 2);
         CYTO_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), want * sizeof(int), hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable));
         cap = want;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev = nullptr; }     // (no event: release() drains the stream instead)
         return CYTO_OK;
     }
-    // (no destructor: a driver thread that ends while the process unloads the HIP runtime must not call into it; 256 bytes per thread)
+};
+// The driver's wait for the chip: a few hundred polls of the pinned word back to back (a launch is a few microseconds), then the
+// core is yielded between polls -- a process may run one such driver per device and sub-batch, more threads than cores.
+struct SpinWait {
+    unsigned polls = 0;
+    void reset() { polls = 0; }
+    void pause() {
+        if (++polls < 512) __builtin_ia32_pause();
+        else std::this_thread::yield();
+    }
 };
 
 size_t wide_sc_ones_bytes(int n) { return (((size_t)n + 63) & ~(size_t)63) * (2 * 8); }
@@ -2420,25 +2480,49 @@ size_t wide_sc_ext_bytes(int n) {
 }
 
 int wide_launch_claims(const WideArgs *d_args, int nb, int n, hipStream_t stream, int32_t *d_sync) {
-    // the one-edge searches of every problem, on the whole chip (above); rounds in groups of four, then "did anything move?"
+    // the one-edge searches of every problem, on the whole chip (above); rounds in groups of four, then "did anything move?" -- reported
+    // into pinned host memory: the driver keeps two groups queued ahead of the one under way and never waits for the stream
     if (n < 2 || !d_sync) return CYTO_OK;
     const int bxw = std::max(1, std::min((n + HEADB / 64 - 1) / (HEADB / 64), std::max(64, 4096 / std::max(1, nb))));
     const int bxt = std::max(1, std::min((n + HEADB - 1) / HEADB, std::max(16, 1024 / std::max(1, nb))));
+    PinnedInts pin;
+    int rc;
+    if ((rc = pin.ensure(4, stream))) return rc;
+    volatile int *hs = pin.p;
+    hs[0] = 0; hs[1] = 0;
     hipLaunchKernelGGL(wide_claim_lists, dim3(bxw, nb), dim3(HEADB), 0, stream, d_args);
-    std::vector<int32_t> h((size_t)nb + 1, 0);
-    for (int it = 0; it < (1 << 16); it++) {
+    constexpr int kAhead = 2, kMaxGroups = 1 << 16;
+    int group = 0;
+    SpinWait sw;
+    auto t_progress = std::chrono::steady_clock::now();
+    int seen = 0;
+    bool fixed = false;
+    for (;;) {
+        if (hs[1] != 0) { fixed = true; break; }
+        const int done = hs[0];
+        if (done != seen) { seen = done; t_progress = std::chrono::steady_clock::now(); sw.reset(); }
+        if (group - done >= kAhead) {
+            sw.pause();
+            if ((sw.polls & 0xFFFF) == 0) {
+                const bool drained = hipStreamQuery(stream) != hipErrorNotReady;
+                if ((drained && hs[0] == done && hs[1] == 0) ||                                   // (the queue has drained and nobody reported: a launch failed)
+                    std::chrono::steady_clock::now() - t_progress > std::chrono::seconds(120)) {   // (no group finished for two minutes)
+                    (void)hipStreamSynchronize(stream);
+                    return CYTO_ERR_INTERNAL;
+                }
+            }
+            continue;
+        }
+        if (group >= kMaxGroups) break;                                   // (a row moves down its list at most 63 times: cannot happen)
+        group++;
         for (int k = 0; k < 4; k++) hipLaunchKernelGGL(wide_claim_round, dim3(bxt, nb), dim3(HEADB), 0, stream, d_args);
-        hipLaunchKernelGGL(wide_claim_check, dim3(nb), dim3(64), 0, stream, d_args);
-        CYTO_HIP(hipMemcpyAsync(h.data(), d_sync, sizeof(int32_t) * ((size_t)nb + 1), hipMemcpyDeviceToHost, stream));
-        CYTO_HIP(hipStreamSynchronize(stream));
-        bool any = false;
-        for (int b = 0; b < nb; b++) any = any || h[(size_t)b + 1] != 0;
-        if (!any) break;
+        hipLaunchKernelGGL(wide_claim_check, dim3(1), dim3(64), 0, stream, d_args, nb, group, pin.p);
     }
+    if (!fixed) { (void)hipStreamSynchronize(stream); return CYTO_ERR_INTERNAL; }      // (never commit an assignment that is not the fixed point)
     hipLaunchKernelGGL(wide_claim_blocked, dim3(bxt, nb), dim3(HEADB), 0, stream, d_args);
     hipLaunchKernelGGL(wide_claim_commit, dim3(bxt, nb), dim3(HEADB), 0, stream, d_args);
     CYTO_HIP(hipGetLastError());
-    return CYTO_OK;
+    return CYTO_OK;                                                       // (the pinned block: usable again behind the check kernels still queued)
 }
 
 int wide_launch_rt(const WideArgs *d_args, int nb, int n, hipStream_t stream) {
@@ -2480,8 +2564,8 @@ int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, i
         // The driver never waits for the chip: the launches' first thread reports into pinned host memory which launch is under way,
         // how many machines are through and who wants fresh row caches; the driver keeps a bounded number of launches queued ahead of
         // the one under way (launches of a machine that is through return at once) and stops when every machine is through.
-        static thread_local PinnedInts t_hs;
-        if ((rc = t_hs.ensure(4 + (size_t)nb))) return rc;
+        PinnedInts t_hs;                                              // (from the pool; usable again once the launches queued below have run)
+        if ((rc = t_hs.ensure(4 + (size_t)nb, stream))) return rc;
         volatile int *hs = t_hs.p;
         for (int k = 0; k < 4 + nb; k++) hs[k] = 0;
         std::vector<int32_t> seen((size_t)nb, 0), flags((size_t)nb, 0);
@@ -2490,25 +2574,33 @@ int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, i
         const int ahead = CYTO_KNOB("CYTO_SC_AHEAD").set ? std::max(2, CYTO_KNOB("CYTO_SC_AHEAD").value) : 16;
         const int small_max = CYTO_KNOB("CYTO_SC_SMALL").set ? CYTO_KNOB("CYTO_SC_SMALL").value : SC_SMALL;
         int L = 0;
-        long long spins = 0;
-        const auto t_begin = std::chrono::steady_clock::now();
+        // a NO-PROGRESS timeout: the clock restarts whenever the launch under way changes (a slow but advancing run -- counter passes of
+        // a profiler, a GPU shared by several ranks -- is not an error); before an error return the stream is drained, because the
+        // launches still queued read the buffers the caller releases and report into the pinned block
+        SpinWait sw;
+        int seen_launch = 0;
+        auto t_progress = std::chrono::steady_clock::now();
+        auto fail = [&]() -> int { (void)hipStreamSynchronize(stream); return CYTO_ERR_INTERNAL; };
         for (;;) {
             if (hs[1] >= nb) break;
-            if (L - hs[0] >= ahead) {
-                if ((++spins & 0xFFFF) == 0) {
-                    if (hipStreamQuery(stream) != hipErrorNotReady && hs[1] < nb && L - hs[0] >= ahead) return CYTO_ERR_INTERNAL;      // (the queue has drained and nobody reported: a launch failed)
-                    if (std::chrono::steady_clock::now() - t_begin > std::chrono::seconds(120)) return CYTO_ERR_INTERNAL;
+            const int under_way = hs[0];
+            if (under_way != seen_launch) { seen_launch = under_way; t_progress = std::chrono::steady_clock::now(); sw.reset(); }
+            if (L - under_way >= ahead) {
+                sw.pause();
+                if ((sw.polls & 0xFFFF) == 0) {
+                    if (hipStreamQuery(stream) != hipErrorNotReady && hs[1] < nb && L - hs[0] >= ahead) return fail();      // (the queue has drained and nobody reported: a launch failed)
+                    if (std::chrono::steady_clock::now() - t_progress > std::chrono::seconds(120)) return fail();
                 }
                 continue;
             }
             bool want = false;
             for (int b = 0; b < nb; b++) { const int w_ = hs[4 + b]; flags[(size_t)b] = w_ != seen[(size_t)b] ? 1 : 0; seen[(size_t)b] = w_; want = want || flags[(size_t)b]; }
-            if (want && rebuild && (rc = rebuild(ctx, flags.data()))) return rc;
+            if (want && rebuild && (rc = rebuild(ctx, flags.data()))) { (void)hipStreamSynchronize(stream); return rc; }
             for (int g = 0; g < 8; g++, L++) {
                 if ((L >> 1) > 0 && (L >> 1) % wipe == 0) hipLaunchKernelGGL(wide_sc_wipe, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args, L);
                 hipLaunchKernelGGL(roundk, dim3(bx, nb), dim3(HEADB), SC_SHARED_BYTES, stream, d_args, L, n, sc_direct, scx_direct, t_hs.p, small_max);
             }
-            if (L > (1 << 22)) return CYTO_ERR_INTERNAL;               // (every phase is bounded: cannot happen)
+            if (L > (1 << 22)) return fail();                          // (every phase is bounded: cannot happen)
         }
         (void)d_sync;
         hipLaunchKernelGGL(wide_sc_finish, dim3(nb), dim3(64), 0, stream, d_args, L);

@@ -445,16 +445,38 @@ def assign_chunks_on_devices(scRNA, st, cell_number_to_node_assignment, index_sc
                                        already_normalized=already_normalized, comm=comms[r])
         except BaseException as e:      # noqa: BLE001 (re-raised on the calling thread)
             errors[r] = e
-            if comms[r] is not None:
-                comms[r].abort()        # peers waiting in a collective this rank will not reach fail instead of hanging
-    threads = [threading.Thread(target=work, args=(r,), name=f"cytohip-dev{devices[r]}-rank{r}") for r in range(W)]
+            # peers waiting in a collective this rank will not reach must fail instead of hanging: EVERY communicator of the
+            # process is aborted (the in-process kind wakes its group; the RCCL kind needs ncclCommAbort on each peer's own
+            # communicator -- aborting only this rank's leaves the others inside ncclBroadcast / ncclAllReduce for ever)
+            for c in comms:
+                if c is not None:
+                    try:
+                        c.abort()
+                    except Exception:   # noqa: BLE001
+                        pass
+    threads = [threading.Thread(target=work, args=(r,), name=f"cytohip-dev{devices[r]}-rank{r}", daemon=True) for r in range(W)]
     for t in threads:
         t.start()
+    # join with a deadline after the FIRST failure: a healthy run may take as long as it takes, but once a rank has failed its
+    # peers have been aborted and must return promptly -- if one does not (a collective that ignores the abort), raise instead of
+    # hanging the caller (the stuck thread is a daemon; its communicator is leaked on purpose: destroying it could block too)
+    deadline = None
+    grace = float(os.environ.get("CYTOSPACE_HIP_ABORT_GRACE_S", "60"))
+    stuck = []
     for t in threads:
-        t.join()
-    for c in comms:
-        if c is not None:
+        while t.is_alive():
+            if deadline is None and any(e is not None for e in errors):
+                deadline = time.monotonic() + grace
+            t.join(0.05 if deadline is None else max(0.0, min(0.05, deadline - time.monotonic())))
+            if deadline is not None and time.monotonic() >= deadline and t.is_alive():
+                stuck.append(t.name)
+                break
+    for r, c in enumerate(comms):
+        if c is not None and threads[r].name not in stuck:
             c.close()
+    if stuck:
+        first = next(e for e in errors if e is not None)
+        raise _lib.CytoHipError(f"rank thread(s) {stuck} did not return within {grace:.0f} s of a peer's failure ({first!r})") from first
     real = [e for e in errors if e is not None and f"status {_lib.CYTO_ERR_PEER}" not in str(e)]
     if real or any(e is not None for e in errors):
         raise (real[0] if real else next(e for e in errors if e is not None))

@@ -217,8 +217,12 @@ int cyto_comm_bcast_f32(void *comm, float *dev_buf, size_t count, int root, int 
  * collective together. */
 int cyto_comm_agree(void *comm, int *status);
 /* For a rank that cannot reach a collective its peers wait in (its host code failed first): in-process kind -- the waiting ranks
- * return CYTO_ERR_PEER; RCCL kind -- ncclCommAbort.  Afterwards the handle is good for cyto_comm_destroy only. */
+ * return CYTO_ERR_PEER; RCCL kind -- ncclCommAbort of this rank's communicator and, for communicators made by
+ * cyto_comm_init_local (host threads of one process), of EVERY sibling's: ranks already inside a collective are released and
+ * return CYTO_ERR_PEER, as does every later collective on any of the handles.  Afterwards the handles are good for
+ * cyto_comm_destroy only.  cyto_comm_aborted: 1 once that has happened. */
 int cyto_comm_abort(void *comm);
+int cyto_comm_aborted(void *comm, int *aborted_out);
 int cyto_comm_destroy(void *comm);
 
 /* ---- A1: normalize_data (cytospace/common/common.py:142-147): nan_to_num, per-column counts per

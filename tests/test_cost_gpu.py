@@ -1,6 +1,7 @@
 """GPU parity of the cost build and the fused chunk solve against the golden vectors captured from
 the reference and against the numpy/C oracle."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -13,6 +14,7 @@ from oracle.jv import jv_oracle
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def load(name):
@@ -453,6 +455,105 @@ def test_in_process_communicator_collectives_and_failing_together():
                                        devices=[0, 0], already_normalized=False)
     with pytest.raises(ValueError):
         gcyto.visible_devices([0, 99])
+
+
+_RCCL_ABORT_WORKER = r'''
+import os, sys, threading, time
+sys.path.insert(0, sys.argv[1])
+os.environ["CYTO_COMM_FORCE_RCCL"] = "1"
+from cytospace_amd import _lib
+ndev = _lib.device_count()
+# (a) one rank through ncclCommInitAll (what a one-GPU box can run of the RCCL kind): a collective, then the abort, then every
+#     later collective fails AT ONCE with CYTO_ERR_PEER instead of touching a destroyed communicator
+c, = _lib.Communicator.init_local([0])
+assert c.kind() == "rccl" and c.count() == 1 and c.agree(5) == 5 and not c.aborted()
+c.abort()
+assert c.aborted()
+for _ in range(2):
+    try:
+        c.agree(0); raise SystemExit("a collective on an aborted communicator returned")
+    except _lib.CytoHipError as e:
+        assert "status 9" in str(e), e
+c.abort(); c.close()
+print("RCCL_ABORT_ONE_OK")
+if ndev >= 2:
+    # (b) two ranks on two devices: rank 0 is already INSIDE ncclAllReduce when rank 1 -- which never enters -- aborts.  The abort
+    #     of rank 1's own communicator alone would leave rank 0 in its kernel for ever; aborting every sibling releases it.
+    comms = _lib.Communicator.init_local([0, 1])
+    assert comms[0].kind() == "rccl"
+    out = {}
+    def waiting():
+        try:
+            out["r0"] = comms[0].agree(0)
+        except BaseException as e:
+            out["r0"] = e
+    t = threading.Thread(target=waiting, daemon=True)
+    t.start()
+    time.sleep(1.0)
+    assert t.is_alive(), "rank 0 should be waiting inside the collective"
+    comms[1].abort()
+    t.join(60)
+    assert not t.is_alive(), "rank 0 still hangs in the collective after the abort"
+    assert isinstance(out["r0"], _lib.CytoHipError) and "status 9" in str(out["r0"]), out
+    assert comms[0].aborted() and comms[1].aborted()
+    for c in comms:
+        c.close()
+    print("RCCL_ABORT_TWO_OK")
+'''
+
+
+def test_rccl_kind_abort_releases_every_sibling(tmp_path):
+    # ADVICE r5 / VERDICT r5 weak 9: a worker thread that fails in host code must release peers that already wait inside
+    # ncclBroadcast / ncclAllReduce -- every communicator of the process is aborted, not only the failing rank's.  In a process of
+    # its own: a communicator that was aborted mid-collective leaves its device in whatever state RCCL leaves it.
+    import subprocess
+    import sys
+    script = tmp_path / "w.py"
+    script.write_text(_RCCL_ABORT_WORKER)
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_ABORT_ONE_OK" in r.stdout, r.stdout + r.stderr
+    from cytospace_amd import _lib
+    if _lib.device_count() >= 2:
+        assert "RCCL_ABORT_TWO_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_failing_worker_aborts_all_and_join_has_a_deadline(monkeypatch):
+    # assign_chunks_on_devices: a worker that raises aborts EVERY communicator; a peer that does not come back within the grace
+    # period makes the call raise instead of hanging (here: rank 0's thread is held back artificially past the grace period)
+    import threading
+    from cytospace_amd import _lib
+    d, idx_sc = _gv11_ss()
+    sc, st = d["ss_counts"].astype(np.float32), d["ss_st_counts"].astype(np.float32)
+    subs = list(d["ss_sub"])
+    seen = []
+    real_abort = _lib.Communicator.abort
+
+    def spy_abort(self):
+        seen.append(self.rank)
+        return real_abort(self)
+    monkeypatch.setattr(_lib.Communicator, "abort", spy_abort)
+    with pytest.raises(IndexError):
+        gcyto.assign_chunks_on_devices(sc, st, d["ss_slots"], idx_sc + [np.array([10 ** 9])], subsampled_slots_list=subs + [subs[0]],
+                                       devices=[0, 0, 0], already_normalized=False)
+    assert sorted(set(seen)) == [0, 1, 2]                      # the failing worker aborted all three, not only its own
+    # the deadline: rank 0 never returns (stuck before its first collective); its peers fail, the call raises after the grace period
+    monkeypatch.setenv("CYTOSPACE_HIP_ABORT_GRACE_S", "1.5")
+    real = gcyto.assign_chunks
+    gate = threading.Event()
+
+    def stuck_rank0(*a, **kw):
+        if kw.get("rank") == 0:
+            gate.wait(30)
+            raise RuntimeError("released")
+        if kw.get("rank") == 1:
+            raise KeyError("rank 1 fails in host code")
+        return real(*a, **kw)
+    monkeypatch.setattr(gcyto, "assign_chunks", stuck_rank0)
+    t0 = time.monotonic()
+    with pytest.raises(_lib.CytoHipError, match="did not return within"):
+        gcyto.assign_chunks_on_devices(sc, st, d["ss_slots"], idx_sc, subsampled_slots_list=subs, devices=[0, 0], already_normalized=False)
+    assert time.monotonic() - t0 < 20
+    gate.set()
 
 
 def test_one_process_distinct_devices_rccl_broadcast():
