@@ -166,13 +166,25 @@ def extra_c3(dev):
     t = time.perf_counter()
     sc, st, slots = instances.synth_expression(G, C, S, seed=1)
     t_gen = time.perf_counter() - t
+    # Raw counts are small integers: they cross PCIe as the narrowest unsigned integer type that holds them (uint16 here: the largest
+    # count of the instance is a few thousand), widened on the device -- what cytospace_amd.cytospace._counts_matrix hands over for a
+    # DataFrame of integer counts.  The conversion belongs to the reader (untimed, like the generator); the float32 form is timed beside it.
+    cmax = int(max(sc.max(), st.max()))
+    cdt = np.uint8 if cmax < 256 else np.uint16 if cmax < 65536 else np.float32
+    sc_n, st_n = np.ascontiguousarray(sc, dtype=cdt), np.ascontiguousarray(st, dtype=cdt)
     assign_pearson(sc, st, slots, already_normalized=False, device_id=dev)                # warm-up
     t = time.perf_counter()
-    mapped, total, info = assign_pearson(sc, st, slots, already_normalized=False, device_id=dev, return_info=True)
+    mapped32, total32, info32 = assign_pearson(sc, st, slots, already_normalized=False, device_id=dev, return_info=True)
+    wall32 = time.perf_counter() - t
+    assign_pearson(sc_n, st_n, slots, already_normalized=False, device_id=dev)            # warm-up
+    t = time.perf_counter()
+    mapped, total, info = assign_pearson(sc_n, st_n, slots, already_normalized=False, device_id=dev, return_info=True)
     wall = time.perf_counter() - t
     ok = bool(np.array_equal(np.bincount(mapped, minlength=S), slots))
     if not ok:
         raise SystemExit("c3: bincount(mapped) != slots")
+    if not (np.array_equal(mapped, mapped32) and total == total32):
+        raise SystemExit("c3: integer counts and float32 counts gave different results")
     tf = info.gemm_flops / (info.ms_gemm * 1e-3) / 1e12
     # K1 alone (normalise + standardise: colsum, moments, write) on counts already RESIDENT in HBM -- in the fused call above it
     # hides behind the PCIe upload.  SURVEY 8(d): bytes = (3 reads + 1 write) x 4 x G x columns
@@ -256,8 +268,11 @@ def extra_c3(dev):
         cpu_cost = {"error": f"{type(e).__name__}: {e}"}
     # the cells go up in blocks of 8192 and block b's contraction runs while block b + 1 is copied and transformed, so the
     # upload + transform time already contains all contractions but the last block's: the parts do not add up to the wall time
-    return {"workload": f"{G} genes x {C} cells x {S} spots (10 slots each), float32 counts -> spots",
+    return {"workload": f"{G} genes x {C} cells x {S} spots (10 slots each), raw counts as {np.dtype(cdt).name} -> spots",
             "wall_ms_incl_h2d": round(wall * 1e3, 1), "assignments_per_s_wall": round(C / wall, 1),
+            "counts_dtype": np.dtype(cdt).name, "largest_count": cmax,
+            "float32_counts": {"wall_ms_incl_h2d": round(wall32 * 1e3, 1), "upload_and_transform_ms": round(info32.ms_standardize, 1),
+                               "same_mapping_and_total": True, "note": "the same call with the counts as float32 (rounds 1-5): twice the upload"},
             "kernel_ms": {"upload_and_transform_with_the_gemm_blocks_inside": round(info.ms_standardize, 1),
                           "pearson_gemm_blocks_sum": round(info.ms_gemm, 2), "lap": round(info.lap.ms_total, 1)},
             "roofline": {"bound": "mfma", "kernel": "pearson_gemm", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF,

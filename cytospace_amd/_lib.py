@@ -36,7 +36,8 @@ class LapInfo(ctypes.Structure):
         [(k, ctypes.c_double) for k in ("wide_ms_list", "wide_ms_chain", "wide_ms_aug_rounds", "wide_ms_aug_verify", "wide_ms_aug_finish",
                                         "wide_ms_aug_trivial")] + [("wide_arr_launches", ctypes.c_int64), ("wide_aug_launches", ctypes.c_int64),
          ("wide_scaled", ctypes.c_int64), ("wide_phases", ctypes.c_int64), ("wide_par_batches", ctypes.c_int64),
-         ("wide_par_discarded", ctypes.c_int64), ("f64_warm", ctypes.c_int64), ("f64_warm_ms", ctypes.c_double)]
+         ("wide_par_discarded", ctypes.c_int64), ("f64_warm", ctypes.c_int64), ("f64_warm_ms", ctypes.c_double),
+         ("certified", ctypes.c_int64), ("gap_f64", ctypes.c_double), ("gap_max_f64", ctypes.c_double), ("gap_rows", ctypes.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -53,7 +54,7 @@ class LapOpts(ctypes.Structure):
                 ("inject_exceptions", ctypes.c_int32), ("group_state_global", ctypes.c_int32), ("aux_state_global", ctypes.c_int32), ("mode", ctypes.c_int32), ("wide_rounds", ctypes.c_int32), ("wide_groups", ctypes.c_int32), ("wide_rebuild", ctypes.c_int32),
                 ("wide_par", ctypes.c_int32), ("wide_wipe", ctypes.c_int32),
                 ("cache_waves", ctypes.c_int32), ("cache_unroll", ctypes.c_int32), ("cache_stream", ctypes.c_int32),
-                ("reserved", ctypes.c_int32 * 5)]
+                ("certify", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
 
 
 class AssignInfo(ctypes.Structure):
@@ -119,6 +120,9 @@ def lib():
         L.cyto_transform.argtypes = [i32, i32, i32, vp, i64, i32, i32, i32, vp, i64, i32, i32, vp]
         L.cyto_cost_metric.argtypes = [i32, i32, i32, i32, vp, i64, vp, i64, vp, vp, i64, dp, i32, vp]
         L.cyto_assign_metric.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32, vp, dp, ctypes.POINTER(AssignInfo), i32]
+        L.cyto_assign_metric_ex.argtypes = [i32, i32, ctypes.POINTER(Matrix), i32, ctypes.POINTER(Matrix), i32, vp, i32, vp, dp,
+                                            ctypes.POINTER(AssignInfo), i32]
+        L.cyto_assign_metric_ex.restype = ctypes.c_int
         L.cyto_ctx_create.argtypes = [i32, i32, i32, i32, vp, vp, i32, i32, ctypes.POINTER(vp)]
         L.cyto_ctx_assign_chunk.argtypes = [vp, vp, i32, vp, i32, vp, vp, dp, ctypes.POINTER(AssignInfo)]
         L.cyto_ctx_destroy.argtypes = [vp]

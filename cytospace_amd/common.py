@@ -18,6 +18,10 @@ def _as_matrix(a):
         raise ValueError("expected a 2-D genes x columns matrix")
     if a.dtype == np.float32:
         return np.ascontiguousarray(a), 0
+    if a.dtype == np.uint16:                       # (raw counts: CYTO_DTYPE_U16 / _U8, widened on the device)
+        return np.ascontiguousarray(a), 2
+    if a.dtype == np.uint8:
+        return np.ascontiguousarray(a), 3
     return np.ascontiguousarray(a, dtype=np.float64), 1
 
 

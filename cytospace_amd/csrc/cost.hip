@@ -157,6 +157,12 @@ constexpr int TRS = 4;     // waves per block = row subgroups
 template <typename TIn, int VEC> __device__ __forceinline__ void load_cols(const TIn *__restrict__ p, TIn (&r)[VEC]) {
     if constexpr (VEC == 1) {
         r[0] = p[0];
+    } else if constexpr (sizeof(TIn) == 2) {                        // uint16 counts: four columns = one 8-byte load
+        const ushort4 t = *reinterpret_cast<const ushort4 *>(p);
+        r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+    } else if constexpr (sizeof(TIn) == 1) {                        // uint8 counts: one 4-byte load
+        const uchar4 t = *reinterpret_cast<const uchar4 *>(p);
+        r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
     } else if constexpr (sizeof(TIn) == 4) {
         const float4 t = *reinterpret_cast<const float4 *>(p);
         r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
@@ -654,7 +660,7 @@ static int standardize_dev(int G, int C, const TIn *dx, int64_t ldx, int already
         return rc;
     // four columns per lane when every row of x (and of z) can be read (written) as 16-byte quads; else a column per lane -- a column's
     // numbers do not depend on which
-    const bool vec = C % 4 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(dx) % 16) == 0 &&
+    const bool vec = C % 4 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(dx) % (sizeof(TIn) >= 4 ? 16 : 4 * sizeof(TIn))) == 0 &&
                      (!z || (ldz % 4 == 0 && (reinterpret_cast<uintptr_t>(z) % 16) == 0));
     const int cols_per_block = vec ? 256 : 64;
     const dim3 grid((C + cols_per_block - 1) / cols_per_block, nblk), blk(64 * TRS);
@@ -687,6 +693,22 @@ static int standardize_dev(int G, int C, const TIn *dx, int64_t ldx, int already
     return CYTO_OK;
 }
 
+// The element type of a count matrix at the boundary (cytohip.h: CYTO_DTYPE_*; the parameters still called `x_is_f64` carry it: 0 and 1
+// mean what they always meant).  Raw counts are small integers: uint16 / uint8 matrices are a half / a quarter of the float32 upload
+// (config c3: 4.4 GB at ~50 GB/s were 93 of 120 ms), widened in the transform kernels' loads -- the same numbers, bit for bit.
+static inline size_t dtype_size(int dt) { return dt == CYTO_DTYPE_F64 ? 8 : dt == CYTO_DTYPE_U16 ? 2 : dt == CYTO_DTYPE_U8 ? 1 : 4; }
+static inline bool dtype_ok(int dt) { return dt >= CYTO_DTYPE_F32 && dt <= CYTO_DTYPE_U8; }
+static int standardize_any(int dt, int G, int C, const void *dx, int64_t ldx, int already, float *z, int64_t ldz, double *ynorm, int64_t ldy,
+                           hipStream_t stream, int transform) {
+    switch (dt) {
+    case CYTO_DTYPE_F64: return standardize_dev<double>(G, C, (const double *)dx, ldx, already, z, ldz, ynorm, ldy, stream, transform);
+    case CYTO_DTYPE_U16: return standardize_dev<uint16_t>(G, C, (const uint16_t *)dx, ldx, already, z, ldz, ynorm, ldy, stream, transform);
+    case CYTO_DTYPE_U8: return standardize_dev<uint8_t>(G, C, (const uint8_t *)dx, ldx, already, z, ldz, ynorm, ldy, stream, transform);
+    case CYTO_DTYPE_F32: return standardize_dev<float>(G, C, (const float *)dx, ldx, already, z, ldz, ynorm, ldy, stream, transform);
+    default: return CYTO_ERR_BAD_ARG;
+    }
+}
+
 }  // namespace cyto
 
 using namespace cyto;
@@ -698,13 +720,12 @@ int cyto_normalize_data(int G, int C, const void *x, int64_t ldx, int x_is_f64, 
     if (G <= 0 || C <= 0 || !x || !out || ldx < C || ldo < C) return CYTO_ERR_BAD_ARG;
     int rc = select_device(device_id);
     if (rc) return rc;
-    const size_t esz = x_is_f64 ? 8 : 4;
+    if (!dtype_ok(x_is_f64)) return CYTO_ERR_BAD_ARG;
+    const size_t esz = dtype_size(x_is_f64);
     DevBuf dx, dy;
     if ((rc = dx.alloc((size_t)G * C * esz)) || (rc = dy.alloc((size_t)G * C * 8))) return rc;
     CYTO_HIP(hipMemcpy2D(dx.p, (size_t)C * esz, x, (size_t)ldx * esz, (size_t)C * esz, G, hipMemcpyHostToDevice));
-    if (x_is_f64) rc = standardize_dev<double>(G, C, dx.as<double>(), C, 0, nullptr, 0, dy.as<double>(), C, nullptr);
-    else rc = standardize_dev<float>(G, C, dx.as<float>(), C, 0, nullptr, 0, dy.as<double>(), C, nullptr);
-    if (rc) return rc;
+    if ((rc = standardize_any(x_is_f64, G, C, dx.p, C, 0, nullptr, 0, dy.as<double>(), C, nullptr, 0))) return rc;
     CYTO_HIP(hipMemcpy2D(out, (size_t)ldo * 8, dy.p, (size_t)C * 8, (size_t)C * 8, G, hipMemcpyDeviceToHost));
     return CYTO_OK;
 }
@@ -714,11 +735,11 @@ int cyto_normalize_data(int G, int C, const void *x, int64_t ldx, int x_is_f64, 
 int cyto_transform(int transform, int G, int C, const void *x, int64_t ldx, int x_is_f64, int x_on_device, int already_normalized,
                    float *z_dev, int64_t ldz, int Gpad, int device_id, void *stream_) {
     if (G <= 0 || C <= 0 || !x || !z_dev || ldx < C || ldz < C || Gpad < G) return CYTO_ERR_BAD_ARG;
-    if (transform < CYTO_TRANSFORM_STANDARDIZE || transform > CYTO_TRANSFORM_RAW) return CYTO_ERR_BAD_ARG;
+    if (transform < CYTO_TRANSFORM_STANDARDIZE || transform > CYTO_TRANSFORM_RAW || !dtype_ok(x_is_f64)) return CYTO_ERR_BAD_ARG;
     int rc = select_device(device_id);
     if (rc) return rc;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    const size_t esz = x_is_f64 ? 8 : 4;
+    const size_t esz = dtype_size(x_is_f64);
     DevBuf dx;
     const void *src = x;
     int64_t sld = ldx;
@@ -732,8 +753,7 @@ int cyto_transform(int transform, int G, int C, const void *x, int64_t ldx, int 
     // a memset of the whole buffer was a fifth pass over a matrix the transform reads three times and writes once)
     if (ldz > C) CYTO_HIP(hipMemset2DAsync(z_dev + C, (size_t)ldz * sizeof(float), 0, (size_t)(ldz - C) * sizeof(float), (size_t)G, stream));
     if (Gpad > G) CYTO_HIP(hipMemsetAsync(z_dev + (size_t)G * ldz, 0, (size_t)(Gpad - G) * ldz * sizeof(float), stream));
-    if (x_is_f64) return standardize_dev<double>(G, C, (const double *)src, sld, already_normalized, z_dev, ldz, nullptr, 0, stream, transform);
-    return standardize_dev<float>(G, C, (const float *)src, sld, already_normalized, z_dev, ldz, nullptr, 0, stream, transform);
+    return standardize_any(x_is_f64, G, C, src, sld, already_normalized, z_dev, ldz, nullptr, 0, stream, transform);
 }
 
 int cyto_standardize(int G, int C, const void *x, int64_t ldx, int x_is_f64, int x_on_device, int already_normalized,
@@ -825,9 +845,9 @@ int cyto_cost_metric(int metric, int Gpad, int S, int C, const float *zst, int64
 // JV solve on the device, mapped_spot[c] = spot of the LAP row given to cell c.
 // sc: G x C, st: G x S (host, row-major, float64 like the reference's arrays).  sum(slots) must be C.
 // The 1e-16 perturbation of cytospace.py:325-327 is not applied: it is a no-op in float32.
-int cyto_assign_metric_typed(int metric, int G, int C, int S, const void *sc, const void *st, int x_is_f64, const int64_t *slots,
-                             int already_normalized, int64_t *mapped_spot, double *total_cost, cyto_assign_info *info, int device_id) {
-    if (metric < CYTO_METRIC_PEARSON || metric > CYTO_METRIC_EUCLIDEAN) return CYTO_ERR_BAD_ARG;
+static int assign_metric_impl(int metric, int G, int C, int S, const void *sc, int sc_dt, const void *st, int st_dt, const int64_t *slots,
+                              int already_normalized, int64_t *mapped_spot, double *total_cost, cyto_assign_info *info, int device_id) {
+    if (metric < CYTO_METRIC_PEARSON || metric > CYTO_METRIC_EUCLIDEAN || !dtype_ok(sc_dt) || !dtype_ok(st_dt)) return CYTO_ERR_BAD_ARG;
     const int transform = metric == CYTO_METRIC_PEARSON ? CYTO_TRANSFORM_STANDARDIZE
                         : metric == CYTO_METRIC_SPEARMAN ? CYTO_TRANSFORM_RANK : CYTO_TRANSFORM_RAW;
     if (G <= 0 || C <= 0 || S <= 0 || !sc || !st || !slots || !mapped_spot) return CYTO_ERR_BAD_ARG;
@@ -860,7 +880,7 @@ int cyto_assign_metric_typed(int metric, int G, int C, int S, const void *sc, co
         (rc = cost.alloc((size_t)S * ldc * 4, stream)))
         return rc;
     CYTO_HIP(hipEventRecord(e0, stream));
-    if ((rc = cyto_transform(transform, G, S, st, S, x_is_f64, 0, already_normalized, zst.as<float>(), ldzst, Gpad, device_id, stream))) return rc;
+    if ((rc = cyto_transform(transform, G, S, st, S, st_dt, 0, already_normalized, zst.as<float>(), ldzst, Gpad, device_id, stream))) return rc;
     float ms_std = 0;
     double ms_gemm = 0;
     constexpr int WBLK = 8192;                            // cells per block: 64 column tiles x 40 row tiles at c3 = five full rounds
@@ -874,7 +894,7 @@ int cyto_assign_metric_typed(int metric, int G, int C, int S, const void *sc, co
         StreamGuard gcomp;
         CYTO_HIP(hipStreamCreateWithFlags(&gcomp.s, hipStreamNonBlocking));
         gcomp.own = true;
-        const size_t esz = x_is_f64 ? 8 : 4;
+        const size_t esz = dtype_size(sc_dt);
         DevBuf dx;
         if ((rc = dx.alloc((size_t)G * WBLK * esz, stream))) return rc;
         CYTO_HIP(hipMemsetAsync(zsc.p, 0, (size_t)Gpad * ldzsc * sizeof(float), stream));
@@ -889,8 +909,7 @@ int cyto_assign_metric_typed(int metric, int G, int C, int S, const void *sc, co
             const int c0 = b * WBLK, w = std::min(WBLK, C - c0);
             const char *src = reinterpret_cast<const char *>(sc) + (size_t)c0 * esz;
             CYTO_HIP(hipMemcpy2DAsync(dx.p, (size_t)w * esz, src, (size_t)C * esz, (size_t)w * esz, G, hipMemcpyHostToDevice, stream));
-            if (x_is_f64) rc = standardize_dev<double>(G, w, dx.as<double>(), w, already_normalized, zsc.as<float>() + c0, ldzsc, nullptr, 0, stream, transform);
-            else rc = standardize_dev<float>(G, w, dx.as<float>(), w, already_normalized, zsc.as<float>() + c0, ldzsc, nullptr, 0, stream, transform);
+            rc = standardize_any(sc_dt, G, w, dx.p, w, already_normalized, zsc.as<float>() + c0, ldzsc, nullptr, 0, stream, transform);
             if (rc) return rc;                            // (standardize_dev has waited for its kernels: block b's operand is complete)
             CYTO_HIP(hipEventRecord(evs[2 * b], gcomp.s));
             gemm_unique_rows_async(Gpad, S, w, zst.as<float>(), ldzst, zsc.as<float>() + c0, ldzsc, nullptr, cost.as<float>() + c0, ldc, gcomp.s);
@@ -903,7 +922,7 @@ int cyto_assign_metric_typed(int metric, int G, int C, int S, const void *sc, co
         (void)hipEventElapsedTime(&ms_std, e0, e1);     // upload + transforms; the contractions of all blocks but the last ran inside it
         for (int b = 0; b < nblocks; b++) { float ms = 0; (void)hipEventElapsedTime(&ms, evs[2 * b], evs[2 * b + 1]); ms_gemm += ms; }
     } else {
-        if ((rc = cyto_transform(transform, G, C, sc, C, x_is_f64, 0, already_normalized, zsc.as<float>(), ldzsc, Gpad, device_id, stream))) return rc;
+        if ((rc = cyto_transform(transform, G, C, sc, C, sc_dt, 0, already_normalized, zsc.as<float>(), ldzsc, Gpad, device_id, stream))) return rc;
         CYTO_HIP(hipEventRecord(e1, stream));
         CYTO_HIP(hipEventSynchronize(e1));
         (void)hipEventElapsedTime(&ms_std, e0, e1);
@@ -931,6 +950,19 @@ int cyto_assign_metric_typed(int metric, int G, int C, int S, const void *sc, co
         info->gemm_flops = 2.0 * Gpad * (double)S * (double)C;
     }
     return CYTO_OK;
+}
+
+int cyto_assign_metric_typed(int metric, int G, int C, int S, const void *sc, const void *st, int x_is_f64, const int64_t *slots,
+                             int already_normalized, int64_t *mapped_spot, double *total_cost, cyto_assign_info *info, int device_id) {
+    return assign_metric_impl(metric, G, C, S, sc, x_is_f64, st, x_is_f64, slots, already_normalized, mapped_spot, total_cost, info, device_id);
+}
+
+// the same with a dtype per matrix (host matrices, row-major, ld == columns): counts as uint8 / uint16 where they fit
+int cyto_assign_metric_ex(int metric, int G, const cyto_matrix *sc, int C, const cyto_matrix *st, int S, const int64_t *slots,
+                          int already_normalized, int64_t *mapped_spot, double *total_cost, cyto_assign_info *info, int device_id) {
+    if (!sc || !st || sc->on_device || st->on_device || sc->ld != C || st->ld != S) return CYTO_ERR_BAD_ARG;
+    return assign_metric_impl(metric, G, C, S, sc->data, sc->is_f64, st->data, st->is_f64, slots, already_normalized, mapped_spot, total_cost, info,
+                              device_id);
 }
 
 // ---- multi-chunk seam (apply_linear_assignment, cytospace/cytospace.py:354-469): the two expression matrices are

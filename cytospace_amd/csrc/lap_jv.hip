@@ -3251,6 +3251,71 @@ __global__ __launch_bounds__(BLOCK2) void jv_aug_lazy(const LazyArgs *__restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// The float64 certificate of a float32 solve (cyto_lap_opts.certify).  The solvers compare fl32(c - v): an assigned row sits on a
+// minimum of its reduced costs AS ROUNDED, so in exact arithmetic its column can lose to another by a fraction of an ulp -- the
+// duals (u_i := c[i][rowsol_i] - v[rowsol_i], v) are feasible to ~1e-9, not exactly.  One more pass over the matrix turns that into a
+// PROOF of how far from optimal the assignment can be: with every difference evaluated in float64 (exact for float32 operands
+// whose exponents lie within 29 binades of each other),
+//     gap = sum_i ( u_i - min_j (c[i][j] - v[j]) )  >=  total - optimum  >=  0
+// (lower every u_i to its row's true minimum: the duals become feasible, their objective is total - gap).  gap == 0: the
+// assignment is optimal for the float32 matrix in exact arithmetic; an instance whose optimum is unique by more than `gap` has
+// exactly these indices whatever the solver's constants.  A wave per row, one sweep; the rows' terms are summed in row order
+// (one workgroup, fixed tree): the same bits on every run.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dual_gap_rows(int n, int64_t ld, const float *__restrict__ cost, const int32_t *__restrict__ rowmap,
+                                                     const int32_t *__restrict__ rowsol, const float *__restrict__ v,
+                                                     double *__restrict__ viol) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    const int nq = (n + 3) >> 2;
+    const float4 *__restrict__ v4 = reinterpret_cast<const float4 *>(v);
+    for (int i = gw; i < n; i += nw) {
+        const float *__restrict__ row = cost + (int64_t)(rowmap ? rowmap[i] : i) * ld;
+        const float4 *__restrict__ r4 = reinterpret_cast<const float4 *>(row);
+        double m = INFINITY;
+        for (int q0 = lane; q0 < nq; q0 += 64 * 8) {
+            float4 x[8], p[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int q = q0 + 64 * k;
+                const bool in = q < nq && q * 4 + 3 < n;                 // (whole quads; the row's last, partial quad below)
+                x[k] = in ? r4[q] : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+                p[k] = in ? v4[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                m = fmin(m, fmin(fmin((double)x[k].x - (double)p[k].x, (double)x[k].y - (double)p[k].y),
+                                 fmin((double)x[k].z - (double)p[k].z, (double)x[k].w - (double)p[k].w)));
+            }
+        }
+        if (lane < (n & 3)) { const int c = (n & ~3) + lane; m = fmin(m, (double)row[c] - (double)v[c]); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_xor(m, off));
+        if (lane == 0) {
+            const int j = rowsol[i];
+            const double ui = (double)row[j] - (double)v[j];
+            viol[i] = ui > m ? ui - m : 0.0;
+        }
+    }
+}
+// out[0] = sum (rows in ascending order within a thread, then a fixed tree), out[1] = max, out[2] = rows with a positive term
+__global__ __launch_bounds__(1024) void dual_gap_finish(int n, const double *__restrict__ viol, double *__restrict__ out) {
+    __shared__ double s_sum[1024], s_max[1024];
+    __shared__ int s_cnt[1024];
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024, lo = t * per, hi = min(n, lo + per);
+    double s = 0.0, mx = 0.0; int c = 0;
+    for (int i = lo; i < hi; i++) { const double x = viol[i]; s += x; mx = fmax(mx, x); c += x > 0.0; }
+    s_sum[t] = s; s_max[t] = mx; s_cnt[t] = c;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (t < w) { s_sum[t] += s_sum[t + w]; s_max[t] = fmax(s_max[t], s_max[t + w]); s_cnt[t] += s_cnt[t + w]; }
+        __syncthreads();
+    }
+    if (t == 0) { out[0] = s_sum[0]; out[1] = s_max[0]; out[2] = (double)s_cnt[0]; }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 static std::atomic<int> g_par_busy[64];     // per device: a several-searches-at-once kernel (wide_aug<..,PAR>) is in flight
@@ -3267,6 +3332,7 @@ static int check_opts(const cyto_lap_opts &o) {
     if (o.cache_waves < -1 || o.cache_waves > 32 || (o.cache_unroll != 0 && o.cache_unroll != 4 && o.cache_unroll != 8) || o.cache_stream < -1 ||
         o.cache_stream > 1)
         return CYTO_ERR_BAD_ARG;
+    if (o.certify < 0 || o.certify > 1) return CYTO_ERR_BAD_ARG;
     for (int r : o.reserved) if (r != 0) return CYTO_ERR_BAD_ARG;            // (must be zero: room for later knobs without another ABI break)
     return CYTO_OK;
 }
@@ -3792,6 +3858,19 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
         float *d_v = j.b_fws.as<float>();
         CYTO_HIP(hipMemcpy(&h_status, j.b_misc.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost));
         CYTO_HIP(hipMemcpy(h_counters, j.b_misc.as<char>() + 16, sizeof(h_counters), hipMemcpyDeviceToHost));
+        double h_gap[3] = {-1.0, -1.0, -1.0};
+        if (opts.certify && j.info && !h_status) {
+            // the float64 certificate (above): one more streaming pass, on the stream, behind the solve
+            DevBuf b_viol;
+            if ((rc = b_viol.alloc(((size_t)n + 4) * sizeof(double), stream))) return rc;
+            const int g = std::max(1, std::min((n + 3) / 4, pl.cus * 8));
+            hipLaunchKernelGGL(dual_gap_rows, dim3(g), dim3(256), 0, stream, n, j.dld, j.dcost, j.rowmap_host ? j.b_rowmap.as<int32_t>() : (const int32_t *)nullptr,
+                               d_rowsol, d_v, b_viol.as<double>());
+            hipLaunchKernelGGL(dual_gap_finish, dim3(1), dim3(1024), 0, stream, n, b_viol.as<double>(), b_viol.as<double>() + n);
+            CYTO_HIP(hipGetLastError());
+            CYTO_HIP(hipMemcpyAsync(h_gap, b_viol.as<double>() + n, sizeof h_gap, hipMemcpyDeviceToHost, stream));
+            CYTO_HIP(hipStreamSynchronize(stream));
+        }
         if (j.rowsol) CYTO_HIP(hipMemcpy(j.rowsol, d_rowsol, nI, hipMemcpyDeviceToHost));
         if (j.colsol) CYTO_HIP(hipMemcpy(j.colsol, d_rowsol + n, nI, hipMemcpyDeviceToHost));
         if (j.u) CYTO_HIP(hipMemcpy(j.u, d_v + n, nT, hipMemcpyDeviceToHost));
@@ -3825,6 +3904,9 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
                 if (h[2] < h[0]) info->aug_handover = h[2];
             }
             info->row_groups = j.h_ngroups;
+            info->certified = h_gap[0] >= 0.0 ? 1 : 0;
+            info->gap_f64 = h_gap[0] >= 0.0 ? h_gap[0] : 0.0; info->gap_max_f64 = h_gap[0] >= 0.0 ? h_gap[1] : 0.0;
+            info->gap_rows = h_gap[0] >= 0.0 ? (int64_t)h_gap[2] : 0;
             if (pl.wide) {
                 long long wc[WC_N] = {0};
                 CYTO_HIP(hipMemcpy(wc, j.b_misc.as<char>() + 160, sizeof wc, hipMemcpyDeviceToHost));

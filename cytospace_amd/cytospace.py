@@ -38,18 +38,35 @@ def partition_indices(indices, split_by_category_list=None, split_by_interval_in
     return np.array_split(indices, sorted(cuts)[1:-1])
 
 
-def _pair(sc, st):
-    """Both matrices C-contiguous and of ONE dtype: float32 if both are float32 already (half the upload), else float64
-    (the dtype of the reference's arrays)."""
-    sc = np.asarray(sc)
-    st = np.asarray(st)
-    if sc.ndim != 2 or st.ndim != 2:
+_DTYPE_CODE = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.uint16): 2, np.dtype(np.uint8): 3}   # CYTO_DTYPE_*
+
+
+def _boundary_matrix(a):
+    """A genes x columns matrix as the C ABI takes it: C-contiguous float32 / uint16 / uint8 as they are (raw counts: the narrower,
+    the less crosses PCIe), anything else as float64 (the dtype of the reference's arrays).  Returns (array, CYTO_DTYPE_* code)."""
+    a = np.asarray(a)
+    if a.ndim != 2:
         raise ValueError("sc and st must be 2-D genes x columns matrices")
+    if a.dtype not in _DTYPE_CODE:
+        a = a.astype(np.float64)
+    a = np.ascontiguousarray(a)
+    return a, _DTYPE_CODE[a.dtype]
+
+
+def _matrix_struct(a, code):
+    m = _lib.Matrix()
+    m.data, m.ld, m.is_f64, m.on_device = a.ctypes.data, a.shape[1], code, 0
+    return m
+
+
+def _pair(sc, st):
+    """Both matrices as the boundary takes them (each in its own dtype)."""
+    sc, csc = _boundary_matrix(sc)
+    st, cst = _boundary_matrix(st)
     if sc.shape[0] != st.shape[0]:
         raise ValueError("The two matrices v1 and v2 must have equal dimensions; "
                          "ST and scRNA data must have the same genes")
-    dt = np.float32 if (sc.dtype == np.float32 and st.dtype == np.float32) else np.float64
-    return np.ascontiguousarray(sc, dtype=dt), np.ascontiguousarray(st, dtype=dt), int(dt == np.float64)
+    return sc, st, csc, cst
 
 
 def assign_pearson(sc, st, slots, already_normalized=True, device_id=0, return_info=False,
@@ -58,7 +75,7 @@ def assign_pearson(sc, st, slots, already_normalized=True, device_id=0, return_i
     from .common import METRICS
     if distance_metric not in METRICS:
         raise ValueError(f"unknown distance_metric {distance_metric!r}")
-    sc, st, is64 = _pair(sc, st)
+    sc, st, csc, cst = _pair(sc, st)
     slots = np.ascontiguousarray(slots, dtype=np.int64)
     G, C = sc.shape
     S = st.shape[1]
@@ -67,9 +84,10 @@ def assign_pearson(sc, st, slots, already_normalized=True, device_id=0, return_i
     mapped = np.empty(C, np.int64)
     total = ctypes.c_double()
     info = _lib.AssignInfo()
-    _lib.check(_lib.lib().cyto_assign_metric_typed(METRICS[distance_metric], G, C, S, sc.ctypes.data, st.ctypes.data, is64,
-                                                   slots.ctypes.data, int(already_normalized), mapped.ctypes.data,
-                                                   ctypes.byref(total), ctypes.byref(info), device_id))
+    msc, mst = _matrix_struct(sc, csc), _matrix_struct(st, cst)
+    _lib.check(_lib.lib().cyto_assign_metric_ex(METRICS[distance_metric], G, ctypes.byref(msc), C, ctypes.byref(mst), S,
+                                                slots.ctypes.data, int(already_normalized), mapped.ctypes.data,
+                                                ctypes.byref(total), ctypes.byref(info), device_id))
     if return_info:
         return mapped, total.value, info
     return mapped
@@ -93,34 +111,30 @@ class ExpressionContext:
         if _common.is_sparse(sc) or (st is not None and _common.is_sparse(st)):
             self._create_from_mixed(sc, st, already_normalized, device_id, METRICS[distance_metric], comm, root, n_spots)
             return
-        if comm is None:
-            sc, st, is64 = _pair(sc, st)
-            self.G, self.C = sc.shape
-            self.S = st.shape[1]
-            _lib.check(_lib.lib().cyto_ctx_create_typed(METRICS[distance_metric], self.G, self.C, self.S, sc.ctypes.data,
-                                                        st.ctypes.data, is64, int(already_normalized), device_id,
-                                                        ctypes.byref(self._h)))
-            return
-        sc = np.asarray(sc)
+        sc, csc = _boundary_matrix(sc)
         have_st = st is not None
         if have_st:
-            sc, st, is64 = _pair(sc, st)
+            sc, st, csc, cst = _pair(sc, st)
             n_spots = st.shape[1]
+        elif comm is None:
+            raise ValueError("the ST matrix is required without a communicator")
         else:
             # (neither a root without the ST matrix nor a rank without n_spots is rejected HERE: the other ranks are already on
             #  their way into the collective, so the call goes through -- with an invalid extent the library turns into its status --
             #  and the status word / the root's extents fail every rank together instead of leaving the others blocked)
             n_spots = (1 if comm.rank == root else 0) if n_spots is None else n_spots
-            is64 = int(sc.dtype != np.float32)
-            sc = np.ascontiguousarray(sc, dtype=np.float64 if is64 else np.float32)
         self.G, self.C = sc.shape
         self.S = int(n_spots)
+        msc = _matrix_struct(sc, csc)
+        mst = _matrix_struct(st, cst) if have_st else None
         ms = ctypes.c_double()
-        _lib.check(_lib.lib().cyto_ctx_create_shared(METRICS[distance_metric], self.G, self.C, self.S, sc.ctypes.data,
-                                                     st.ctypes.data if have_st else None, is64, int(already_normalized),
-                                                     comm.handle, int(root), comm.rank, device_id, ctypes.byref(self._h),
-                                                     ctypes.byref(ms)))
-        self.bcast_ms = ms.value
+        _lib.check(_lib.lib().cyto_ctx_create_ex(METRICS[distance_metric], self.G, ctypes.byref(msc), self.C,
+                                                 ctypes.byref(mst) if have_st else None, self.S, int(already_normalized),
+                                                 comm.handle if comm is not None else None, int(root),
+                                                 comm.rank if comm is not None else 0, device_id, ctypes.byref(self._h),
+                                                 ctypes.byref(ms)))
+        if comm is not None:
+            self.bcast_ms = ms.value
 
     def _create_from_mixed(self, sc, st, already_normalized, device_id, metric, comm, root, n_spots):
         """Inputs of which at least one is a scipy.sparse matrix: sparse ones are uploaded as non-zeros and expanded on the
@@ -135,10 +149,9 @@ class ExpressionContext:
                 keep.append(buf)
                 m.data, m.ld, m.is_f64, m.on_device = buf.ptr, ld, 0, 1
                 return m, G, C
-            a = np.asarray(x)
-            a = np.ascontiguousarray(a, dtype=np.float32 if a.dtype == np.float32 else np.float64)
+            a, code = _boundary_matrix(x)
             keep.append(a)
-            m.data, m.ld, m.is_f64, m.on_device = a.ctypes.data, a.shape[1], int(a.dtype == np.float64), 0
+            m.data, m.ld, m.is_f64, m.on_device = a.ctypes.data, a.shape[1], code, 0
             return m, a.shape[0], a.shape[1]
         msc, self.G, self.C = describe(sc)
         mst = None
@@ -275,13 +288,21 @@ def solve_linear_assignment_problem(scRNA_norm_data, st_norm_data, cell_number_t
 
 
 def _counts_matrix(a):
-    """A genes x columns count matrix as the narrowest dtype that holds it exactly: float32 when every value survives the
-    cast (raw counts do: half the PCIe traffic), else float64 (the reference's dtype)."""
+    """A genes x columns count matrix as the narrowest dtype that holds it exactly: uint8 / uint16 for integer counts that fit
+    (a quarter / half of the float32 upload; the device widens them), float32 when every value survives the cast, else float64
+    (the reference's dtype)."""
     a = np.asarray(a)
-    if a.dtype == np.float32:
+    if a.dtype in (np.float32, np.uint8, np.uint16):
         return np.ascontiguousarray(a)
     if a.dtype.kind in "iub":
-        if a.size == 0 or np.abs(a).max() < (1 << 24):
+        if a.size == 0:
+            return np.ascontiguousarray(a, dtype=np.float32)
+        lo, hi = int(a.min()), int(a.max())
+        if lo >= 0 and hi < (1 << 8):
+            return np.ascontiguousarray(a, dtype=np.uint8)
+        if lo >= 0 and hi < (1 << 16):
+            return np.ascontiguousarray(a, dtype=np.uint16)
+        if max(-lo, hi) < (1 << 24):
             return np.ascontiguousarray(a, dtype=np.float32)
         return np.ascontiguousarray(a, dtype=np.float64)
     a64 = np.ascontiguousarray(a, dtype=np.float64)

@@ -111,6 +111,12 @@ typedef struct {
     int64_t wide_par_discarded;  /* ... searches that met an earlier search of their batch and ran again in the next one */
     int64_t f64_warm;            /* float64: 1 = warm-started from the prices of the float32 wide solve of the narrowed matrix */
     double f64_warm_ms;          /* float64: kernel time of that float32 solve */
+    /* float32, cyto_lap_opts.certify: the float64 certificate of the result */
+    int64_t certified;           /* 1: the three fields below were computed */
+    double gap_f64;              /* sum_i (u_i - min_j (c[i][j] - v[j])) with u_i = c[i][rowsol[i]] - v[rowsol[i]], every difference in
+                                    float64: total - optimum <= gap_f64 (0: optimal for the float32 matrix in exact arithmetic) */
+    double gap_max_f64;          /* the largest term of that sum */
+    int64_t gap_rows;            /* rows with a positive term (their column loses to another by a fraction of a float32 ulp) */
 } cyto_lap_info;
 
 int cyto_lap_f32(int n, const float *cost, int64_t ld, int cost_on_device,
@@ -163,7 +169,11 @@ typedef struct {
     int32_t cache_unroll;       /* ... 16-byte quads in flight per lane of the wave builder: 0 (default: 8), 4 or 8 */
     int32_t cache_stream;       /* ... 0 / 1: the guess-free streaming selection for rows of >= 2 048 columns.  -1: a neighbouring row's floor
                                    as the guess (round 4's first form) */
-    int32_t reserved[5];        /* must be zero */
+    int32_t certify;            /* float32: 1 = one more pass over the matrix behind the solve proves in float64 how far from optimal the
+                                   assignment can be (cyto_lap_info.gap_f64: total - optimum <= gap, rounding of the float32 duals and nothing
+                                   else; ~2 ms at n = 50 000).  An instance whose optimum is unique by more than the gap has exactly the
+                                   returned indices, whatever the solver's constants.  (took the first of the reserved words: same size) */
+    int32_t reserved[4];        /* must be zero */
 } cyto_lap_opts;
 int cyto_lap_f32_opts(int n, const float *cost, int64_t ld, int cost_on_device,
                       int32_t *rowsol, int32_t *colsol, float *u, float *v, double *total,
@@ -225,9 +235,14 @@ int cyto_comm_abort(void *comm);
 int cyto_comm_aborted(void *comm, int *aborted_out);
 int cyto_comm_destroy(void *comm);
 
+/* ---- element types of the expression matrices at this boundary.  Every `x_is_f64` parameter below and cyto_matrix.is_f64 carry one
+ * of these (0 and 1 mean what the name says; 2 and 3 came in round 6): raw counts are small integers, and a uint16 / uint8 matrix is a
+ * half / a quarter of the float32 upload -- the transform kernels widen in their loads, the numbers are the same bit for bit. */
+enum { CYTO_DTYPE_F32 = 0, CYTO_DTYPE_F64 = 1, CYTO_DTYPE_U16 = 2, CYTO_DTYPE_U8 = 3 };
+
 /* ---- A1: normalize_data (cytospace/common/common.py:142-147): nan_to_num, per-column counts per
  * million over the gene axis, log2(x + 1), nan_to_num.  x: G x C host matrix (float64 if x_is_f64
- * else float32), out: G x C host float64.  Computed on the device in float64. */
+ * else float32; CYTO_DTYPE_*), out: G x C host float64.  Computed on the device in float64. */
 int cyto_normalize_data(int G, int C, const void *x, int64_t ldx, int x_is_f64, double *out, int64_t ldo,
                         int device_id);
 
@@ -309,7 +324,7 @@ int cyto_ctx_create_shared(int metric, int G, int C, int S, const void *sc, cons
 typedef struct {
     const void *data;
     int64_t ld;              /* elements per row (>= number of columns) */
-    int32_t is_f64;          /* 1: float64, 0: float32 */
+    int32_t is_f64;          /* the element type, CYTO_DTYPE_*: 0 float32, 1 float64 (what the name says), 2 uint16, 3 uint8 */
     int32_t on_device;       /* 1: device pointer */
 } cyto_matrix;
 int cyto_ctx_create_ex(int metric, int G, const cyto_matrix *sc, int C, const cyto_matrix *st, int S, int already_normalized,
@@ -343,6 +358,10 @@ int cyto_assign_metric_typed(int metric, int G, int C, int S, const void *sc, co
                              cyto_assign_info *info, int device_id);
 int cyto_ctx_create_typed(int metric, int G, int C, int S, const void *sc, const void *st, int x_is_f64,
                           int already_normalized, int device_id, cyto_expr_ctx **out);
+/* ... and with an element type PER MATRIX (host matrices, ld == columns): scRNA counts as uint8 beside ST counts as uint16, say --
+ * what cytospace_amd.cytospace.assign_pearson passes for integer count matrices (config c3: the upload bounds the call). */
+int cyto_assign_metric_ex(int metric, int G, const cyto_matrix *sc, int C, const cyto_matrix *st, int S, const int64_t *slots,
+                          int already_normalized, int64_t *mapped_spot, double *total_cost, cyto_assign_info *info, int device_id);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,6 @@
 """Goldens for the LARGE LAP instances (BASELINE configs c2/c3/c4 at true size), made in the build container.
 
-Run:  python tests/golden/make_golden_large.py [tag ...]      (tags: u20000 u24000 u30000 u33000 u50000 u70000 c3s50000 c4s10000 t20000)
+Run:  python tests/golden/make_golden_large.py [tag ...]      (tags: u20000 u24000 u30000 u33000 u50000 u70000 c3s50000 c4s10000 t10000 t20000 t30000 k5t20000)
       python tests/golden/make_golden_large.py --wide [tag ...]   the same instances through the oracle's WIDE mode -> large_<tag>_wide.npz
       python tests/golden/make_golden_large.py --f64 [tag ...]    float64 solves (uniform tags only) -> large_<tag>_f64.npz
 
@@ -101,9 +101,8 @@ def make(tag):
     elif tag.startswith("c4s"):
         n = int(tag[3:])
         cost, loc = instances.c4_chunk_cost(n)
-    elif tag.startswith("t"):                 # SURVEY 8(d) "cytospace-like" solver-only instance: few cell types, slots == 1
-        n = int(tag[1:])
-        cost, loc = instances.typed_unique_cost(n, n, 20)[0], None
+    elif tag.startswith("t") or tag.startswith("k"):     # SURVEY 8(d) "cytospace-like" solver-only instances: few cell types, slots == 1
+        n, cost, loc = instance(tag)
     else:
         raise SystemExit(f"unknown tag {tag}")
     print(f"[{tag}] instance in {time.time() - t0:.1f}s, sha256(cost)={sha(cost)[:16]}", flush=True)
@@ -133,7 +132,7 @@ def make(tag):
             raise SystemExit(f"[{tag}] oracle and scipy disagree: not a golden")
     t = time.time()
     # (any exact solver will do for the re-solve: the wide restatement is the faster one on few-cell-type instances)
-    p = (jv_oracle_wide if tag.startswith("t") else jv_oracle)(perturbed(cost, 99), np.float32)
+    p = (jv_oracle_wide if tag[0] in "tk" else jv_oracle)(perturbed(cost, 99), np.float32)
     unique = bool(np.array_equal(key(p["colsol"]), key(colsol)))
     print(f"[{tag}] one-ulp perturbation re-solve {time.time() - t:.1f}s: answer unchanged = {unique}", flush=True)
     st = o["stats"].as_dict()
@@ -159,6 +158,9 @@ def instance(tag):
     if tag.startswith("t"):
         n = int(tag[1:])
         return n, instances.typed_unique_cost(n, n, 20)[0], None
+    if tag.startswith("k"):                   # k<K>t<n>: the same generator with K cell types instead of ten (seed 20 + K)
+        K, n = (int(x) for x in tag[1:].split("t"))
+        return n, instances.typed_unique_cost(n, n, 20 + K, K=K)[0], None
     raise SystemExit(f"unknown tag {tag}")
 
 

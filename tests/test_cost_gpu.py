@@ -628,3 +628,41 @@ def test_float32_inputs_give_the_float64_results():
         sl = np.array([3] * 10 + [0] * 10)
         assert np.array_equal(c32.assign_chunk(idx, sl), c64.assign_chunk(idx, sl))
 
+
+def test_integer_count_dtypes_give_the_float64_results():
+    # round 6: raw counts are small integers -- uint16 / uint8 matrices are a half / a quarter of the float32
+    # upload (CYTO_DTYPE_U16 / _U8; the transform kernels widen in their loads).  Same numbers bit for bit: the standardised
+    # operands, normalize_data, the fused solves of every metric (also with different dtypes for the two matrices, odd shapes that
+    # take the column-per-lane kernels, and the block pipeline of large problems), the chunked context.
+    rng = np.random.default_rng(29)
+    for G, S, k in ((150, 20, 3), (97, 13, 5)):
+        sc = rng.poisson(2.0, (G, S * k)).astype(np.float64)
+        st = rng.poisson(7.0, (G, S)).astype(np.float64)
+        sc[:, 3] = 0                                              # a cell without counts: NaN -> 0 whatever the dtype
+        slots = np.full(S, k)
+        for dt in (np.uint16, np.uint8):
+            assert np.array_equal(gcommon.normalize_data(sc.astype(dt)), gcommon.normalize_data(sc))
+            for metric in ("Pearson_correlation", "Euclidean"):
+                a = gcommon.StandardizedMatrix(sc.astype(dt), False, 0, metric).to_numpy()
+                b = gcommon.StandardizedMatrix(sc, False, 0, metric).to_numpy()
+                assert np.array_equal(a, b, equal_nan=True)
+        sc[:, 3] = rng.poisson(2.0, G)
+        for metric in ("Pearson_correlation", "Spearman_correlation", "Euclidean"):
+            m64, t64, _ = gcyto.assign_pearson(sc, st, slots, already_normalized=False, return_info=True, distance_metric=metric)
+            for dsc, dst in ((np.uint16, np.uint16), (np.uint8, np.uint16), (np.uint8, np.float32), (np.float64, np.uint8)):
+                m, t, _ = gcyto.assign_pearson(sc.astype(dsc), st.astype(dst), slots, already_normalized=False, return_info=True,
+                                               distance_metric=metric)
+                assert np.array_equal(m, m64) and t == t64, (metric, dsc, dst)
+        with gcyto.ExpressionContext(sc.astype(np.uint8), st.astype(np.uint16), already_normalized=False) as cu, \
+             gcyto.ExpressionContext(sc, st, already_normalized=False) as c64:
+            idx = np.arange(0, 3 * (S // 2))
+            sl = np.array([3] * (S // 2) + [0] * (S - S // 2))
+            assert np.array_equal(cu.assign_chunk(idx, sl), c64.assign_chunk(idx, sl))
+    # _counts_matrix: what apply_linear_assignment uploads for a DataFrame of integer counts
+    assert gcyto._counts_matrix(np.array([[0, 255], [3, 4]], np.int64)).dtype == np.uint8
+    assert gcyto._counts_matrix(np.array([[0, 256], [3, 4]], np.int64)).dtype == np.uint16
+    assert gcyto._counts_matrix(np.array([[0, 65536], [3, 4]], np.int64)).dtype == np.float32
+    assert gcyto._counts_matrix(np.array([[-1, 5], [3, 4]], np.int64)).dtype == np.float32
+    assert gcyto._counts_matrix(np.array([[0.0, 5.0], [3.0, 4.0]])).dtype == np.float32
+    assert gcyto._counts_matrix(np.array([[0.1, 5.0], [3.0, 4.0]])).dtype == np.float64
+

@@ -775,3 +775,48 @@ def test_wide_plateaus_every_distance_equal(groups):
         else:
             c = rng.integers(0, k, (n, n)).astype(np.float32)
         _check_wide(c, opts=dict(wide_groups=groups))
+
+
+def test_float64_certificate_of_a_float32_solve():
+    # cyto_lap_opts.certify: one more pass over the matrix proves in float64 how far from optimal the float32 result can be --
+    # gap = sum_i (u_i - min_j (c_ij - v_j)) >= total - optimum, every difference exact in float64.  Against numpy on the same duals;
+    # and the bound holds: an independent exact solver's total lies within it.
+    from scipy.optimize import linear_sum_assignment
+    from tools import instances
+    for c in (np.random.default_rng(41).random((1500, 1500)).astype(np.float32), instances.typed_unique_cost(1203, 1203, 7)[0],
+              np.repeat(np.random.default_rng(42).random((301, 1204)).astype(np.float32), 4, axis=0)):
+        n = len(c)
+        for opts in (dict(certify=1), dict(certify=1, mode=1)):
+            g = lap_solve(c, np.float32, return_info=True, opts=opts)
+            i = g["info"]
+            red = c.astype(np.float64) - g["v"].astype(np.float64)[None, :]
+            viol = np.maximum(red[np.arange(n), g["rowsol"]] - red.min(1), 0.0)
+            assert i.certified == 1 and i.gap_rows == int((viol > 0).sum()) and i.gap_max_f64 == viol.max()
+            assert abs(i.gap_f64 - viol.sum()) <= 1e-12 * max(1.0, viol.sum())
+            r, cc = linear_sum_assignment(c.astype(np.float64))
+            opt = float(c.astype(np.float64)[r, cc].sum())
+            mine = float(c.astype(np.float64)[np.arange(n), g["rowsol"]].sum())
+            assert -1e-9 <= mine - opt <= i.gap_f64 + 1e-9 and i.gap_f64 <= 1e-5 * max(1.0, abs(opt))
+    g = lap_solve(np.random.default_rng(43).random((300, 300)).astype(np.float32), np.float32, return_info=True)
+    assert g["info"].certified == 0                                   # (off by default: one pass less)
+    # a row map (duplicated spot rows stored once) certifies like the materialised matrix
+    rows = np.random.default_rng(44).random((250, 1000)).astype(np.float32)
+    rowmap = np.repeat(np.arange(250), 4).astype(np.int32)
+    a = lap_solve_rows(rows, rowmap, return_info=True, opts=dict(certify=1))["info"]
+    b = lap_solve(rows[rowmap], np.float32, return_info=True, opts=dict(certify=1))["info"]
+    assert a.certified == b.certified == 1 and a.gap_f64 == b.gap_f64 and a.gap_rows == b.gap_rows
+
+
+def test_default_solver_indices_on_certified_unique_instances():
+    # the wide solver against the CLASSIC oracle's == scipy's indices on instances whose optimum is certified
+    # unique (tests/golden/cross_unique.npz, made on the CPU by tools/cross_unique.py --make: uniform and few-cell-type, n up to 8 200) --
+    # the first 60 here, all of them in tools/cross_unique.py
+    import hashlib
+    from tools import cross_unique
+    d = np.load(cross_unique.OUT)
+    assert len(d["n"]) >= 300
+    for k in range(60):
+        c = cross_unique.instance(str(d["kind"][k]), int(d["n"][k]), int(d["seed"][k]), int(d["K"][k]))
+        g = lap_solve(c, np.float32, return_info=True, opts=dict(certify=1))
+        assert hashlib.sha256(np.ascontiguousarray(g["colsol"], dtype=np.int32).tobytes()).hexdigest() == str(d["colsol_sha256"][k]), k
+        assert g["info"].certified == 1 and g["info"].gap_f64 <= 1e-5 * max(1.0, abs(g["total"]))

@@ -375,6 +375,10 @@ def test_fused_block_pipeline_equals_the_split_path(metric):
     g = lap_solve_rows(rows, loc)                                        # the same unique rows, built in one piece
     assert np.array_equal(loc[g["colsol"]], mapped)
     assert abs(g["total"] - total) <= 1e-5 * max(1.0, abs(total))
+    # the same counts as uint16 / uint8 (CYTO_DTYPE_*): the block pipeline uploads half / a quarter of the bytes, same mapping, same total
+    assert sc.max() < 256 and st.max() < 65536
+    m2, t2, _ = assign_pearson(sc.astype(np.uint8), st.astype(np.uint16), slots, already_normalized=False, return_info=True, distance_metric=metric)
+    assert np.array_equal(m2, mapped) and t2 == total
 
 
 def test_fused_block_pipeline_failure_then_another_thread_solves():
