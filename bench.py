@@ -57,6 +57,15 @@ def _sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def floor_roofline(problems, n, seconds, what):
+    """The headline's floor-based roofline for a leg that solves `problems` LAPs of n rows: every entry of every cost matrix must be
+    read once -- problems x 4 n^2 bytes -- over the leg's wall time, against the HBM peak (cannot exceed 1)."""
+    b = 4.0 * n * n * problems
+    gbs = b / seconds / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+            "floor_bytes": b, "definition": f"floor: {problems} x 4 n^2 bytes (n = {n}: {what}) read once, divided by the leg's wall time"}
+
+
 def check_uniform_golden(n, r, wide, required):
     """A uniform-instance result against the committed goldens of that size: indices (tests/golden/large_u<n>.npz is
     uniqueness-certified: ANY exact solver's indices) and -- the wide solver -- rowsol and both duals bit for bit against the wide
@@ -139,7 +148,8 @@ def extra_c2_cytolike(dev):
            "rounds": int(i.wide_rounds), "phases": int(i.wide_phases), "bids": int(i.scans_arr), "full_row_bids": int(i.wide_dense_arr),
            "searches": int(i.augmentations), "columns_settled": int(i.scans_aug_relax),
            "row_scans_counted": int(i.row_scans), "hbm_rows_actually_read": int(i.hbm_row_reads),
-           "floor_4n2_frac": round(4.0 * n * n / wall / 1e9 / HBM_PEAK_GBS, 6), "instance_seconds": round(t_gen, 1)}
+           "floor_4n2_frac": round(4.0 * n * n / wall / 1e9 / HBM_PEAK_GBS, 6), "roofline": floor_roofline(1, n, wall, "the cost matrix"),
+           "instance_seconds": round(t_gen, 1)}
     gpath = os.path.join(ROOT, "tests", "golden", "large_t20000.npz")
     if os.path.exists(gpath):
         d = np.load(gpath)
@@ -301,7 +311,8 @@ def extra_c2_batch(dev, cost_buf, n, B=32):
     i = res[0]["info"]
     return {"workload": f"{B} copies of the headline instance ({n} x {n}) solved together, each on its own copy of the matrix",
             "wall_s": round(wall, 3), "assignments_per_s": round(B * n / wall, 1), "batch_kernel_ms": round(i.ms_total, 1),
-            "row_reduction_ms": round(i.ms_arr, 1), "augmentation_ms": round(i.ms_aug, 1), "wide_solver": bool(i.wide), "copies_identical": same}, res[0]
+            "row_reduction_ms": round(i.ms_arr, 1), "augmentation_ms": round(i.ms_aug, 1), "wide_solver": bool(i.wide), "copies_identical": same,
+            "roofline": floor_roofline(B, n, wall, "the batch's cost matrices")}, res[0]
 
 
 def _usable_cores():
@@ -393,10 +404,14 @@ def extra_c4_chunks(dev, K, distinct=4, cpu_n=5000, cpu_threads=64):
     return {"workload": f"{K} concurrent {n} x {n} sub-spot chunk LAPs ({distinct} distinct seeded instances, every chain on its own copy), "
                         "cost resident in HBM, ONE launch per solver phase with a workgroup per chunk",
             "chunks": K, "wall_s": round(wall, 2), "assignments_per_s": round(K * n / wall, 1),
+            "roofline": floor_roofline(K, n, wall, "every chunk's cost matrix, resident in HBM"),
+            "full_row_bids_chunk0": int(res[0]["info"].wide_dense_arr), "bids_chunk0": int(res[0]["info"].scans_arr),
+            "rounds_chunk0": int(res[0]["info"].wide_rounds),
             # what the 256 chains together draw from HBM: every full-row scan reads its 4 n bytes (the cached scans read none)
             "hbm_rows_read": int(sum(r["info"].hbm_row_reads for r in res)),
             "hbm_GBs_rows_read": round(sum(r["info"].hbm_row_reads for r in res) * 4.0 * n / wall / 1e9, 1),
-            "one_chunk_alone": {"wall_s": round(wall1, 2), "assignments_per_s": round(n / wall1, 1), "kernel_ms": round(i0.ms_total, 1),
+            "one_chunk_alone": {"wall_s": round(wall1, 4), "assignments_per_s": round(n / wall1, 1), "kernel_ms": round(i0.ms_total, 1),
+                                "roofline": floor_roofline(1, n, wall1, "the chunk's cost matrix"),
                                 "row_reduction_ms": round(i0.ms_arr, 1), "augmentation_ms": round(i0.ms_aug, 1), "wide_solver": bool(i0.wide),
                                 "row_scans": int(i0.row_scans), "aug_scans": int(i0.scans_aug_relax),
                                 "aug_full_row_scans": int(i0.wide_dense_aug if i0.wide else i0.aug_dense_scans),
@@ -466,7 +481,8 @@ def extra_c5_chunks(dev, K=50, G=500, chunk=10000, sets=8, cpu_n=10000, cpu_thre
     i0 = res[0][2]
     return {"workload": f"{K} single-cell-mode chunks ({chunk} cells x {chunk} single-cell spots, {G}-gene panel; configs[4] = 50 such chunks) "
                         "through one batched context call on one GPU: per-chunk gather + MFMA cost build, then every LAP together",
-            "chunks": K, "wall_s": round(wall, 2), "assignments_per_s": round(K * chunk / wall, 1),
+            "chunks": K, "wall_s": round(wall, 3), "assignments_per_s": round(K * chunk / wall, 1),
+            "roofline": floor_roofline(K, chunk, wall, "every chunk's cost matrix as the cost build leaves it in HBM; the wall time includes the cost builds"),
             "context_s": round(t1 - t0, 2), "cost_build_ms_total": round(sum(r[2].ms_standardize + r[2].ms_gemm for r in res), 1),
             "chunk0": {"lap_batch_kernel_ms": round(i0.lap.ms_total, 1), "row_reduction_ms": round(i0.lap.ms_arr, 1), "wide_solver": bool(i0.lap.wide),
                        "augmentation_ms": round(i0.lap.ms_aug, 1), "row_scans": int(i0.lap.row_scans),
@@ -541,19 +557,51 @@ def extra_c4_sharded(dev, rank, world, store, comm, chunks_per_rank, G=5000, S=5
     if strong:
         return {"workload": f"configs[3] as configured: {total_chunks * chunk} cells = {total_chunks} sub-spot chunks of {chunk} cells against {S} spots, "
                             f"{G} genes, on {world} GPU(s): chunk k on rank k % {world}; ST transformed on rank 0 + RCCL broadcast",
-                "assignments_per_s": round(total_chunks * chunk / el, 1), "seconds": round(el, 2), "scaling": "strong",
+                "assignments_per_s": round(total_chunks * chunk / el, 1), "seconds": round(el, 3), "scaling": "strong",
+                "roofline": floor_roofline(total_chunks, chunk, el, "every chunk's LAP as the reference materialises it; the time includes upload, transforms, broadcast and cost builds"),
                 "chunks_on_rank0": len(mine), "bcast_ms_rank0": None if bcast_ms is None else round(bcast_ms, 3),
                 "rank0_longest_lap_kernel_ms": round(max(r_[2].lap.ms_total for r_ in res), 1) if res else None,
                 "bincount_equals_slots": ok, "instance_seconds_rank0": round(t_gen, 1)}
     return {"workload": f"{world} GPU(s) x {chunks_per_rank} sub-spot chunks of {chunk} cells against {S} spots, {G} genes: "
                         "ST transformed on rank 0 + RCCL broadcast, per-rank raw-count upload, batched chunk solves",
-            "assignments_per_s": round(world * chunks_per_rank * chunk / el, 1), "seconds": round(el, 2), "scaling": "weak",
+            "assignments_per_s": round(world * chunks_per_rank * chunk / el, 1), "seconds": round(el, 3), "scaling": "weak",
+            "roofline": floor_roofline(world * chunks_per_rank, chunk, el, "every chunk's LAP as the reference materialises it; the time includes upload, transforms, broadcast and cost builds; peak = ONE GPU's: divide by the GPUs for a per-device fraction"),
             "cost_build_ms_per_rank": round(sum(r[2].ms_standardize + r[2].ms_gemm for r in res), 1),
             "context_s_rank0": round(t1 - t0, 3), "bcast_ms_rank0": None if bcast_ms is None else round(bcast_ms, 3),
             "bcast_bytes": int(-(-G // 32) * 32) * int(-(-S // 128) * 128) * 4,
             "chunk0": {"gather_ms": round(i0.ms_standardize, 2), "gemm_ms": round(i0.ms_gemm, 2), "spots_with_cells": int((subs[0] > 0).sum()),
                        "lap_batch_kernel_ms": round(i0.lap.ms_total, 1), "lap_row_scans": int(i0.lap.row_scans)},
             "bincount_equals_slots": ok, "instance_seconds_rank0": round(t_gen, 1)}
+
+
+class ThreadStore:
+    """barrier / allgather / max for LOGICAL ranks that are threads of one process (--oversubscribe: more ranks than devices -- RCCL
+    refuses duplicate devices, so the multi-rank chunk legs run on the in-process communicator, cyto_comm_init_local, one thread per rank)"""
+
+    def __init__(self, world):
+        import threading
+        self.world, self._bar, self._vals = world, threading.Barrier(world), [None] * world
+
+    def view(self, rank):
+        return _ThreadStoreView(self, rank)
+
+
+class _ThreadStoreView:
+    def __init__(self, s, rank):
+        self.s, self.rank, self.world = s, rank, s.world
+
+    def barrier(self):
+        self.s._bar.wait()
+
+    def allgather(self, x):
+        self.s._vals[self.rank] = x
+        self.s._bar.wait()
+        out = list(self.s._vals)
+        self.s._bar.wait()
+        return out
+
+    def allreduce_max(self, x):
+        return max(self.allgather(x))
 
 
 def make_cost(n, seed):
@@ -766,6 +814,41 @@ def main():
         obuf.free()
 
     sharded, sharded_stuck, box = None, False, {}
+    logical = world > 1 and comm is None and args.oversubscribe
+    if not args.no_extras and logical and rank == 0:
+        # more ranks than devices (a harness self-test): the multi-rank chunk legs -- rank r's chunks, the rank that never sees the ST
+        # matrix, the status agreement, the operand broadcast -- run as `world` THREADS of this process on the in-process communicator
+        # (logical ranks of one device: comm.hip's LOCAL kind); the other processes of the job have nothing to do here
+        import threading
+        lcomms = _lib.Communicator.init_local([dev] * world)
+        tstore = ThreadStore(world)
+        lbox = [dict() for _ in range(world)]
+
+        def _lrank(r):
+            try:
+                lbox[r]["strong"] = extra_c4_sharded(dev, r, world, tstore.view(r), lcomms[r], 0, G=2000, total_chunks=20)
+                lbox[r]["r"] = extra_c4_sharded(dev, r, world, tstore.view(r), lcomms[r], max(1, args.c4_rank_chunks // world))
+            except BaseException as e:          # noqa: BLE001
+                lbox[r]["r"] = {"error": f"{type(e).__name__}: {e}"}
+                for c in lcomms:
+                    c.abort()
+                tstore._bar.abort()
+        ths = [threading.Thread(target=_lrank, args=(r,), daemon=True) for r in range(world)]
+        for t_ in ths:
+            t_.start()
+        for t_ in ths:
+            t_.join(args.sharded_timeout)
+        sharded_stuck = any(t_.is_alive() for t_ in ths)
+        errs = [b["r"] for b in lbox if isinstance(b.get("r"), dict) and "error" in b["r"]]
+        if sharded_stuck:
+            sharded = {"error": f"no result within {args.sharded_timeout} s"}
+        elif errs:
+            sharded = errs[0]
+        else:
+            sharded = dict(lbox[0]["r"], logical_ranks=f"{world} ranks as threads of rank 0's process on device {dev} (in-process communicator)")
+            box["strong"] = dict(lbox[0]["strong"], logical_ranks=sharded["logical_ranks"])
+            for c in lcomms:
+                c.close()
     if not args.no_extras and (world == 1 or comm is not None):
         # every rank takes part.  The headline above is already measured: a failure or a hang of this additional multi-rank leg
         # must not cost the line, so it runs under a watchdog and reports what happened instead.

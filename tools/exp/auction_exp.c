@@ -28,6 +28,8 @@ typedef struct { long rounds, bids, wide_rounds, chain_rounds, wide_bids, chain_
 /* Jacobi rounds with increment eps (eps == 0: the retire rules of the wide restatement).  active[] in/out. */
 static int stop_na = 0;
 static float *Fl = NULL; static long dense_bids = 0; static int cache_k = 48;
+static float *V0 = NULL;            /* NEED=1: the post-column-reduction prices (the epoch of the first cache build) */
+static long need_hist[8];           /* per phase: bids whose second-best value lies below the k-th smallest ORIGINAL reduced cost, k <= 48,128,512,1024,2048,4096,8192,inf */
 static int cmpf_(const void *a, const void *b) { float x = *(const float *)a, y = *(const float *)b; return x < y ? -1 : x > y; }
 static float kth_reduced(const float *c, int k) {   /* k-th smallest (0-based) of c[j]-v[j] */
     float *t = malloc(sizeof(float) * n); for (int j = 0; j < n; j++) t[j] = c[j] - v[j];
@@ -65,6 +67,13 @@ static void rounds(float eps, long max_rounds, uint8_t *active, phase_stats *ps,
                 else if (colsol[j1] < 0) { jt = j1; pt = v[j1]; }
                 else if (j2 >= 0 && usub == umin && colsol[j2] < 0) { jt = j2; pt = v[j2]; }
             }
+            if (V0) {
+                const float *c = cost + (size_t)i * n; int need = 0;
+                for (int j = 0; j < n; j++) need += (c[j] - V0[j]) < usub;
+                int b = need <= 48 ? 0 : need <= 128 ? 1 : need <= 512 ? 2 : need <= 1024 ? 3 : need <= 2048 ? 4 : need <= 4096 ? 5 : need <= 8192 ? 6 : 7;
+#pragma omp atomic
+                need_hist[b]++;
+            }
             if (Fl && !(usub < Fl[i])) {
 #pragma omp atomic
                 dense_bids++;
@@ -88,6 +97,11 @@ static void rounds(float eps, long max_rounds, uint8_t *active, phase_stats *ps,
         if (na > 64) { ps->wide_rounds++; ps->wide_bids += na; } else { ps->chain_rounds++; ps->chain_bids += na; }
         int b = na <= 1 ? 0 : na <= 4 ? 1 : na <= 16 ? 2 : na <= 64 ? 3 : na <= 256 ? 4 : na <= 1024 ? 5 : na <= 4096 ? 6 : 7;
         hist[b]++;
+    }
+    if (verbose && V0) {
+        printf("      band needed (columns whose reduced cost at v0 < the bid's second-best now): <=48:%ld <=128:%ld <=512:%ld <=1024:%ld <=2048:%ld <=4096:%ld <=8192:%ld more:%ld\n",
+               need_hist[0], need_hist[1], need_hist[2], need_hist[3], need_hist[4], need_hist[5], need_hist[6], need_hist[7]);
+        memset(need_hist, 0, sizeof need_hist);
     }
     if (verbose) {
         int left = 0; for (int i = 0; i < n; i++) left += active[i];
@@ -275,6 +289,7 @@ int main(int argc, char **argv) {
         printf("   cost range [%g, %g]; colmin range [%g, %g]; gap quantiles: min %g 10%% %g 50%% %g 90%% %g 99%% %g max %g\n", cmin, cmax, vmin, vmax, gap[0], gap[n / 10], gap[n / 2], gap[n * 9 / 10], gap[n * 99 / 100], gap[n - 1]);
         free(gap);
     }
+    if (getenv("NEED")) { V0 = malloc(sizeof(float) * n); memcpy(V0, v, sizeof(float) * n); }
     phase_stats ps; double t0 = omp_get_wtime();
     if (mode == 0) {
         long R = argc > 4 ? atol(argv[4]) : 4096 + n / 4;
