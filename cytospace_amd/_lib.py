@@ -37,7 +37,8 @@ class LapInfo(ctypes.Structure):
                                         "wide_ms_aug_trivial")] + [("wide_arr_launches", ctypes.c_int64), ("wide_aug_launches", ctypes.c_int64),
          ("wide_scaled", ctypes.c_int64), ("wide_phases", ctypes.c_int64), ("wide_par_batches", ctypes.c_int64),
          ("wide_par_discarded", ctypes.c_int64), ("f64_warm", ctypes.c_int64), ("f64_warm_ms", ctypes.c_double),
-         ("certified", ctypes.c_int64), ("gap_f64", ctypes.c_double), ("gap_max_f64", ctypes.c_double), ("gap_rows", ctypes.c_int64)]
+         ("certified", ctypes.c_int64), ("gap_f64", ctypes.c_double), ("gap_max_f64", ctypes.c_double), ("gap_rows", ctypes.c_int64),
+         ("polished", ctypes.c_int64), ("polish_ms", ctypes.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -54,7 +55,7 @@ class LapOpts(ctypes.Structure):
                 ("inject_exceptions", ctypes.c_int32), ("group_state_global", ctypes.c_int32), ("aux_state_global", ctypes.c_int32), ("mode", ctypes.c_int32), ("wide_rounds", ctypes.c_int32), ("wide_groups", ctypes.c_int32), ("wide_rebuild", ctypes.c_int32),
                 ("wide_par", ctypes.c_int32), ("wide_wipe", ctypes.c_int32),
                 ("cache_waves", ctypes.c_int32), ("cache_unroll", ctypes.c_int32), ("cache_stream", ctypes.c_int32),
-                ("certify", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
+                ("certify", ctypes.c_int32), ("polish", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
 
 
 class AssignInfo(ctypes.Structure):

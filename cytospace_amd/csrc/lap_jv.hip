@@ -3332,7 +3332,7 @@ static int check_opts(const cyto_lap_opts &o) {
     if (o.cache_waves < -1 || o.cache_waves > 32 || (o.cache_unroll != 0 && o.cache_unroll != 4 && o.cache_unroll != 8) || o.cache_stream < -1 ||
         o.cache_stream > 1)
         return CYTO_ERR_BAD_ARG;
-    if (o.certify < 0 || o.certify > 1) return CYTO_ERR_BAD_ARG;
+    if (o.certify < 0 || o.certify > 1 || o.polish < 0 || o.polish > 1) return CYTO_ERR_BAD_ARG;
     for (int r : o.reserved) if (r != 0) return CYTO_ERR_BAD_ARG;            // (must be zero: room for later knobs without another ABI break)
     return CYTO_OK;
 }
@@ -3961,7 +3961,9 @@ __global__ __launch_bounds__(256) void widen_prices(int n, const float *__restri
 // cyto_lap_opts.mode = 1 (or any chain option): the cold classic chain, the parity reference of rounds 1-3.
 static int lap_solve_f64(int n, const double *cost, int64_t ld, int cost_on_device, int32_t *rowsol, int32_t *colsol,
                          double *u, double *v, double *total, cyto_lap_info *info, int device_id, hipStream_t stream,
-                         const cyto_lap_opts &opts) {
+                         const cyto_lap_opts &opts, const float *warm_prices_host = nullptr) {
+    // warm_prices_host: the start prices are the caller's (the float32 solve of this very matrix: lap_polish_f64) -- no narrowing, no
+    // float32 solve here
     typedef double T;
     constexpr int VW = VecOf<T>::W;
     if (n <= 0 || !cost || ld < n) return CYTO_ERR_BAD_ARG;
@@ -4015,11 +4017,18 @@ static int lap_solve_f64(int n, const double *cost, int64_t ld, int cost_on_devi
         DevBuf d32, dv32;
         std::vector<float> h_v32((size_t)n);
         cyto_lap_info li32;
+        if (warm_prices_host) {
+            memset(&li32, 0, sizeof li32);
+            memcpy(h_v32.data(), warm_prices_host, (size_t)n * sizeof(float));
+            if ((rc = dv32.alloc((size_t)n * sizeof(float), stream))) return rc;
+            rc = CYTO_OK;
+        } else {
         if ((rc = d32.alloc((size_t)n * ld32 * sizeof(float), stream)) || (rc = dv32.alloc((size_t)n * sizeof(float), stream))) return rc;
         hipLaunchKernelGGL(narrow_f64_to_f32, dim3((n + 255) / 256 > 64 ? 64 : (n + 255) / 256, n > 32768 ? 32768 : n), dim3(256), 0, stream,
                            n, dld, dcost, ld32, d32.as<float>());
         CYTO_HIP(hipGetLastError());
         rc = lap_solve_f32(n, d32.as<float>(), ld32, 1, nullptr, nullptr, nullptr, h_v32.data(), nullptr, &li32, device_id, stream, k_default_opts);
+        }
         if (rc == CYTO_ERR_NONFINITE) { warm = false; rc = CYTO_OK; }       // finite float64 costs beyond float32's range: the cold start
         else if (rc) return rc;
         else {
@@ -4103,17 +4112,84 @@ static int lap_solve_f64(int n, const double *cost, int64_t ld, int cost_on_devi
     return h_status ? CYTO_ERR_INTERNAL : CYTO_OK;
 }
 
+// The float64 POLISH of a float32 solve (cyto_lap_opts.polish): the float32 solvers compare rounded reduced costs, so on a near-tie
+// (two assignments whose totals differ by less than the rounding of the float32 duals, ~1e-8) which optimal-looking assignment comes
+// out depends on their constants (DESIGN "Tried", round 5: phases ending at 128 rows instead of 64 left the few-cell-type 20 000^2
+// instance 2e-8 above its optimum).  When the certificate (dual_gap_rows) cannot prove the result optimal, the matrix is widened to
+// float64 on the device (exactly), the float32 prices are the start with every row free, and the float64 augmenting row reduction and
+// augmentation of the force_doubles path run from there (any prices with nothing assigned are a valid JV state): ~1.2 n steps.  The
+// result is the optimum of the float32 matrix in float64 arithmetic -- indices that depend on the MATRIX, not on the float32 solver.
+// Costs n^2 x 8 bytes of device memory and several times the solve: an option, not the default.
+__global__ __launch_bounds__(256) void widen_f32_rows(int n, int64_t lds_, const float *__restrict__ src, const int32_t *__restrict__ rowmap,
+                                                      int64_t ldd, double *__restrict__ dst) {
+    for (int64_t row = blockIdx.y; row < n; row += gridDim.y) {
+        const float *__restrict__ r = src + (int64_t)(rowmap ? rowmap[row] : row) * lds_;
+        for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) dst[row * ldd + c] = (double)r[c];
+    }
+}
+static int lap_polish_f64(int n, const float *cost, int64_t ld, int cost_on_device, const int32_t *rowmap_host, int nu, const float *v32,
+                          int32_t *rowsol, int32_t *colsol, float *u, float *v, double *total, double *ms_out, int device_id,
+                          hipStream_t stream) {
+    int rc = select_device(device_id);
+    if (rc) return rc;
+    const int nstored = rowmap_host ? nu : n;
+    const int64_t ldd = ((int64_t)n + 1) & ~(int64_t)1;
+    DevBuf d64, staged, d_map;
+    const float *dsrc = cost;
+    int64_t dls = ld;
+    if ((rc = d64.alloc((size_t)n * ldd * sizeof(double), stream))) return rc;
+    if (!cost_on_device) {
+        if ((rc = staged.alloc((size_t)nstored * n * sizeof(float), stream))) return rc;
+        CYTO_HIP(hipMemcpy2DAsync(staged.p, (size_t)n * sizeof(float), cost, (size_t)ld * sizeof(float), (size_t)n * sizeof(float), nstored,
+                                  hipMemcpyHostToDevice, stream));
+        dsrc = staged.as<float>(); dls = n;
+    }
+    if (rowmap_host) {
+        if ((rc = d_map.alloc((size_t)n * sizeof(int32_t), stream))) return rc;
+        CYTO_HIP(hipMemcpyAsync(d_map.p, rowmap_host, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    }
+    hipLaunchKernelGGL(widen_f32_rows, dim3((n + 255) / 256 > 64 ? 64 : (n + 255) / 256, n > 32768 ? 32768 : n), dim3(256), 0, stream, n, dls, dsrc,
+                       rowmap_host ? d_map.as<int32_t>() : (const int32_t *)nullptr, ldd, d64.as<double>());
+    CYTO_HIP(hipGetLastError());
+    CYTO_HIP(hipStreamSynchronize(stream));
+    staged.reset();
+    std::vector<double> u64((size_t)n), v64((size_t)n);
+    cyto_lap_info li;
+    rc = lap_solve_f64(n, d64.as<double>(), ldd, 1, rowsol, colsol, u64.data(), v64.data(), total, &li, device_id, stream, k_default_opts, v32);
+    if (rc) return rc;
+    if (u) for (int i = 0; i < n; i++) u[i] = (float)u64[(size_t)i];
+    if (v) for (int i = 0; i < n; i++) v[i] = (float)v64[(size_t)i];
+    if (ms_out) *ms_out = li.ms_total;
+    return CYTO_OK;
+}
+
 // one float32 problem = a batch of one
-static int lap_solve_f32(int n, const float *cost, int64_t ld, int cost_on_device, int32_t *rowsol, int32_t *colsol,
-                         float *u, float *v, double *total, cyto_lap_info *info, int device_id, hipStream_t stream,
-                         const cyto_lap_opts &opts) {
+static int lap_solve_f32_one(int n, const float *cost, int64_t ld, int cost_on_device, const int32_t *rowmap_host, int nu, int32_t *rowsol,
+                             int32_t *colsol, float *u, float *v, double *total, cyto_lap_info *info, int device_id, hipStream_t stream,
+                             const cyto_lap_opts &opts) {
     if (n <= 0 || !cost || ld < n) return CYTO_ERR_BAD_ARG;
     std::vector<F32Job> jobs(1);
     F32Job &j = jobs[0];
-    j.cost = cost; j.ld = ld; j.cost_on_device = cost_on_device;
-    j.rowsol = rowsol; j.colsol = colsol; j.u = u; j.v = v; j.total = total; j.info = info;
-    const int rc = lap_solve_f32_batch(n, jobs, device_id, stream, opts);
-    return rc ? rc : j.status;
+    j.cost = cost; j.ld = ld; j.cost_on_device = cost_on_device; j.rowmap_host = rowmap_host; j.nu = nu;
+    cyto_lap_info li;
+    std::vector<float> v_keep;
+    cyto_lap_opts o = opts;
+    if (opts.polish) { o.certify = 1; if (!v) { v_keep.resize((size_t)n); v = v_keep.data(); } }
+    j.rowsol = rowsol; j.colsol = colsol; j.u = u; j.v = v; j.total = total; j.info = (info || opts.polish) ? &li : nullptr;
+    int rc = lap_solve_f32_batch(n, jobs, device_id, stream, o);
+    rc = rc ? rc : j.status;
+    if (!rc && opts.polish && li.certified && li.gap_f64 > 0.0) {
+        double ms = 0.0;
+        rc = lap_polish_f64(n, cost, ld, cost_on_device, rowmap_host, nu, v, rowsol, colsol, u, v_keep.empty() ? v : nullptr, total, &ms, device_id, stream);
+        li.polished = 1; li.polish_ms = ms;
+    }
+    if (info && (info != &li)) *info = li;
+    return rc;
+}
+static int lap_solve_f32(int n, const float *cost, int64_t ld, int cost_on_device, int32_t *rowsol, int32_t *colsol,
+                         float *u, float *v, double *total, cyto_lap_info *info, int device_id, hipStream_t stream,
+                         const cyto_lap_opts &opts) {
+    return lap_solve_f32_one(n, cost, ld, cost_on_device, nullptr, 0, rowsol, colsol, u, v, total, info, device_id, stream, opts);
 }
 
 // C ABI helper of cyto_lap_batch_f32 (batch.hip): problems of equal size go through the chains together
@@ -4215,12 +4291,8 @@ int cyto_lap_f32_rowmap(int n, const float *cost_rows, int64_t ld, int nu, int c
                         int32_t *rowsol, int32_t *colsol, float *u, float *v, double *total, cyto_lap_info *info, int device_id,
                         void *stream, const cyto_lap_opts *opts) {
     if (n <= 0 || !cost_rows || ld < n || !rowmap || nu <= 0) return CYTO_ERR_BAD_ARG;
-    std::vector<cyto::F32Job> jobs(1);
-    cyto::F32Job &j = jobs[0];
-    j.cost = cost_rows; j.ld = ld; j.cost_on_device = cost_on_device; j.rowmap_host = rowmap; j.nu = nu;
-    j.rowsol = rowsol; j.colsol = colsol; j.u = u; j.v = v; j.total = total; j.info = info;
-    const int rc = cyto::lap_solve_f32_batch(n, jobs, device_id, reinterpret_cast<hipStream_t>(stream), opts ? *opts : cyto::k_default_opts);
-    return rc ? rc : j.status;
+    return cyto::lap_solve_f32_one(n, cost_rows, ld, cost_on_device, rowmap, nu, rowsol, colsol, u, v, total, info, device_id,
+                                   reinterpret_cast<hipStream_t>(stream), opts ? *opts : cyto::k_default_opts);
 }
 
 int cyto_lap_f32_opts(int n, const float *cost, int64_t ld, int cost_on_device, int32_t *rowsol, int32_t *colsol,

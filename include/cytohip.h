@@ -117,6 +117,9 @@ typedef struct {
                                     float64: total - optimum <= gap_f64 (0: optimal for the float32 matrix in exact arithmetic) */
     double gap_max_f64;          /* the largest term of that sum */
     int64_t gap_rows;            /* rows with a positive term (their column loses to another by a fraction of a float32 ulp) */
+    int64_t polished;            /* cyto_lap_opts.polish: 1 = the certificate left a gap and the float64 polish ran (rowsol / colsol / total and
+                                    the duals -- narrowed to float32 -- are the float64 solve's; gap_f64 is the float32 result's, before it) */
+    double polish_ms;            /* kernel time of the polish */
 } cyto_lap_info;
 
 int cyto_lap_f32(int n, const float *cost, int64_t ld, int cost_on_device,
@@ -173,7 +176,12 @@ typedef struct {
                                    assignment can be (cyto_lap_info.gap_f64: total - optimum <= gap, rounding of the float32 duals and nothing
                                    else; ~2 ms at n = 50 000).  An instance whose optimum is unique by more than the gap has exactly the
                                    returned indices, whatever the solver's constants.  (took the first of the reserved words: same size) */
-    int32_t reserved[4];        /* must be zero */
+    int32_t polish;             /* float32, single problems: 1 = certify, and where the certificate cannot prove the result optimal (gap_f64 > 0)
+                                   finish in float64 -- the matrix widened on the device (n^2 x 8 more bytes), the float32 prices as the start with
+                                   every row free, the float64 augmenting row reduction and augmentation of the force_doubles path (~1.2 n steps):
+                                   the optimum of the float32 matrix in float64 arithmetic, indices that do not depend on the float32 solver's
+                                   constants.  Several times the cost of the solve: off by default.  (the second of the reserved words) */
+    int32_t reserved[3];        /* must be zero */
 } cyto_lap_opts;
 int cyto_lap_f32_opts(int n, const float *cost, int64_t ld, int cost_on_device,
                       int32_t *rowsol, int32_t *colsol, float *u, float *v, double *total,

@@ -820,3 +820,34 @@ def test_default_solver_indices_on_certified_unique_instances():
         g = lap_solve(c, np.float32, return_info=True, opts=dict(certify=1))
         assert hashlib.sha256(np.ascontiguousarray(g["colsol"], dtype=np.int32).tobytes()).hexdigest() == str(d["colsol_sha256"][k]), k
         assert g["info"].certified == 1 and g["info"].gap_f64 <= 1e-5 * max(1.0, abs(g["total"]))
+
+
+def test_float64_polish_of_a_float32_solve():
+    # cyto_lap_opts.polish: where the float64 certificate leaves a gap (the rule: rounding of the float32 duals), the
+    # solve is finished in float64 from the float32 prices -- the matrix widened exactly, every row free, the float64 augmenting row
+    # reduction and augmentation.  That IS the warm-started float64 restatement (oracle/jv_oracle.c: jv_oracle_warm_f64) applied to the
+    # widened matrix: indices bit for bit, duals after narrowing; and an independent exact solver finds no better total in float64.
+    from scipy.optimize import linear_sum_assignment
+    from tools import instances
+    for c in (instances.typed_unique_cost(2003, 2003, 9)[0], np.random.default_rng(51).random((1500, 1500)).astype(np.float32),
+              instances.typed_unique_cost(4700, 4700, 10, K=4)[0]):
+        n = len(c)
+        c64 = c.astype(np.float64)
+        g = lap_solve(c, np.float32, return_info=True, opts=dict(polish=1))
+        i = g["info"]
+        assert i.certified == 1 and i.gap_f64 >= 0.0 and (i.polished == 1) == (i.gap_f64 > 0.0)
+        o = jv_oracle(c64, np.float64, warm=True)
+        assert np.array_equal(g["rowsol"], o["rowsol"]) and np.array_equal(g["colsol"], o["colsol"])
+        if i.polished:
+            assert np.array_equal(g["v"], o["v"].astype(np.float32)) and np.array_equal(g["u"], o["u"].astype(np.float32))
+        r, cc = linear_sum_assignment(c64)
+        opt = float(c64[r, cc].sum())
+        assert abs(float(c64[np.arange(n), g["rowsol"]].sum()) - opt) <= 1e-12 * max(1.0, abs(opt)) and abs(g["total"] - opt) <= 1e-9
+    # repeated spot rows through the row map: same spots, the float64 optimum's total
+    rows = instances.typed_unique_cost(300, 1200, 11)[0]
+    rowmap = np.repeat(np.arange(300), 4).astype(np.int32)
+    g = lap_solve_rows(rows, rowmap, return_info=True, opts=dict(polish=1))
+    c64 = rows[rowmap].astype(np.float64)
+    r, cc = linear_sum_assignment(c64)
+    assert abs(float(c64[np.arange(1200), g["rowsol"]].sum()) - float(c64[r, cc].sum())) <= 1e-12 * abs(float(c64[r, cc].sum()))
+    assert np.array_equal(np.sort(g["colsol"]), np.arange(1200))
