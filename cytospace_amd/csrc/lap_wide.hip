@@ -153,7 +153,6 @@ constexpr int SC_UNROLL = 4;           // quads of a full-row sweep in flight pe
 #endif
 constexpr int SC_SMALL = 2048;         // launches with at most so many bids to resolve give every bid a wave of its own (a matter of speed only)
 constexpr int SC_COARSE = 4;           // phases whose full-row bids leave the row caches alone (a matter of speed only)
-constexpr int SC_WAVE_ROWS = 12;       // a launch with at least so many rows per workgroup: an uncertified row is read by its own wave (a matter of speed only)
 #ifndef WIDE_STOP_CAP
 #define WIDE_STOP_CAP 64
 #endif
@@ -424,9 +423,6 @@ struct ScShared {
     uint32_t lmin[HEADB];
     uint32_t ccol[KC];
     float cval[KC];
-    int wcnt[HEADB / 64];              // a wave's own full-row bid (sc_top2_wave): the columns of its row's fresh cache
-    uint32_t wcol[HEADB / 64][KC];
-    float wval[HEADB / 64][KC];
 };
 constexpr size_t SC_SHARED_BYTES = (sizeof(ScShared) + 15) / 16 * 16;
 
@@ -604,100 +600,6 @@ __device__ __forceinline__ Top2 sc_top2_block(const WideArgs &a, const ScView &v
     return t;
 }
 
-// ONE WAVE: f(column, cost, price) for every column of the row -- 16 bytes of row and of prices per lane and step, U steps in flight
-template <int U, typename F> __device__ __forceinline__ void wave_row_sweep_p(const float *__restrict__ row, const float *__restrict__ v, const ScView &vw, int n, int lane, F &&f) {
-    const int nq = (n + 3) >> 2;
-    const float4 *__restrict__ r4 = reinterpret_cast<const float4 *>(row);
-    const float4 *__restrict__ v4 = reinterpret_cast<const float4 *>(vw.pr ? reinterpret_cast<const float *>(vw.pr) : v);
-    const bool ordered = vw.pr != nullptr;
-    for (int q0 = lane; q0 < nq; q0 += 64 * U) {
-        float4 x[U], p[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int q = q0 + 64 * u;
-            x[u] = q < nq ? r4[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            p[u] = q < nq ? v4[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int q = q0 + 64 * u, c = q * 4;
-            if (q >= nq) continue;
-            if (ordered) { p[u].x = ord2f(__float_as_uint(p[u].x)); p[u].y = ord2f(__float_as_uint(p[u].y)); p[u].z = ord2f(__float_as_uint(p[u].z)); p[u].w = ord2f(__float_as_uint(p[u].w)); }
-            f(c, x[u].x, p[u].x);
-            if (c + 1 < n) f(c + 1, x[u].y, p[u].y);
-            if (c + 2 < n) f(c + 2, x[u].z, p[u].z);
-            if (c + 3 < n) f(c + 3, x[u].w, p[u].w);
-        }
-    }
-}
-// ONE WAVE: the exact lexicographic top-2 of row i -- and a fresh cache for it -- without a barrier: the form for launches whose
-// uncertified rows are MANY (a phase boundary of a few-cell-type instance: every row bids and nearly every cache is stale; the early
-// rounds of its phases).  Such a launch is a pass over the matrix, and what counts is bytes in flight on the whole chip, not the latency
-// of one bid: a workgroup per row, one row after the other with three barriers each, streamed 32 x 10 000 rows at 1.9 TB/s (the 6.8-ms
-// launches of a 256-chunk batch, profiles/r06a_*); a wave per row with nothing to wait for but its own loads is the row-cache builder's
-// form.  The floor of the fresh cache: one of the wave's 64 sorted lane minima, as in wide_arr's top2_full (results never depend on
-// what a cache holds -- only on what it certifies).
-template <int U>
-__device__ __forceinline__ Top2 sc_top2_wave(const WideArgs &a, const ScView &vw, ScShared &ss, int w, int i, bool rebuild, int lane) {
-    const int n = a.n;
-    const float *__restrict__ row = a.cost + wrow_off(a.rowmap, i, a.ld);
-    K2 d; d.m1 = KEYMAX; d.m2 = KEYMAX;
-    wave_row_sweep_p<U>(row, a.v, vw, n, lane, [&](int c, float x, float vc) { k2_push(d, mkkey(x - vc, (uint32_t)c)); });
-    uint32_t lm = (uint32_t)(d.m1 >> 32);                            // this lane's smallest reduced cost (ordered)
-    d = k2_wave_allreduce(d);
-    Top2 t;
-    t.u1 = key_val(d.m1); t.j1 = (int)(uint32_t)d.m1; t.c1 = row[t.j1]; sc_price_owner(a, vw, t.j1, t.vj1, t.o1);
-    t.u2 = INFINITY; t.j2 = -1; t.c2 = 0.0f; t.vj2 = 0.0f; t.o2 = -1;
-    if (d.m2 != KEYMAX) { t.u2 = key_val(d.m2); t.j2 = (int)(uint32_t)d.m2; t.c2 = row[t.j2]; sc_price_owner(a, vw, t.j2, t.vj2, t.o2); }
-    t.c1 = uni(t.c1); t.vj1 = uni(t.vj1); t.o1 = uni(t.o1); t.c2 = uni(t.c2); t.vj2 = uni(t.vj2); t.o2 = uni(t.o2);
-    if (!rebuild) return t;
-    // ---- the row's new cache ----
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {                               // bitonic sort of the 64 lane minima, ascending over the lanes
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const uint32_t o = (uint32_t)__shfl_xor((int)lm, j);
-            const bool take_min = ((lane & j) == 0) == ((lane & k) == 0);
-            lm = take_min ? umin32(lm, o) : (lm > o ? lm : o);
-        }
-    }
-    uint32_t tk = 0;                                                   // ordered floor; 0 = none found
-    int cnt = 0;
-    for (int pos = SC_FLOOR_POS; pos >= 2 && !tk; pos = (pos + 1) / 2 - 1) {
-        const uint32_t cand = rdlane(lm, pos);
-        if (cand == 0xFFFFFFFFu) continue;
-        if (lane == 0) ss.wcnt[w] = 0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        wave_row_sweep_p<U>(row, a.v, vw, n, lane, [&](int c, float x, float vc) {
-            if (f2ord(x - vc) < cand) {
-                const int p = atomicAdd(&ss.wcnt[w], 1);
-                if (p < KCU) { ss.wcol[w][p] = (uint32_t)c; ss.wval[w][p] = x; }
-            }
-        });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        cnt = uni(ss.wcnt[w]);
-        if (cnt <= KCU) tk = cand;
-    }
-    const float tau = tk ? ord2f(tk) : -INFINITY;
-    uint32_t kc = (tk && lane < cnt) ? ss.wcol[w][lane] : COLSENT;
-    float kv = (tk && lane < cnt) ? ss.wval[w][lane] : 0.0f;
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {                               // cache rows are kept sorted by column (unused slots last)
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const uint32_t pk = (uint32_t)__shfl_xor((int)kc, j);
-            const float pv = __shfl_xor(kv, j);
-            const bool take_min = ((lane & j) == 0) == ((lane & k) == 0);
-            const bool sw = take_min ? (pk < kc) : (pk > kc);
-            kc = sw ? pk : kc; kv = sw ? pv : kv;
-        }
-    }
-    if (lane == KCU) { kc = COLSENT; kv = tau; }                       // (at most 63 entries: lane 63 held a sentinel)
-    a.cache_col[(int64_t)i * KC + lane] = kc;
-    a.cache_val[(int64_t)i * KC + lane] = kv;
-    return t;
-}
-
 __device__ __forceinline__ unsigned long long bidkey(long long round, float price, int row) {
     return ((unsigned long long)(~(uint32_t)round & 0xFFFu) << 52) | ((unsigned long long)f2ord(price) << 20) | (uint32_t)row;
 }
@@ -784,7 +686,7 @@ __global__ __launch_bounds__(HEADB) void wide_sc_init(const WideArgs *__restrict
 //   none   the machine is through (those bids are dropped; their rows are the list it leaves) --
 // or, in launch 0, the first bids of the rows the column reduction left free.
 template <int U, bool DIRECT>
-__global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restrict__ batch, int L, int n_arg, char *sc_direct, char *scx_direct, int *hs, int small_max, int wave_rows_min) {
+__global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restrict__ batch, int L, int n_arg, char *sc_direct, char *scx_direct, int *hs, int small_max) {
     extern __shared__ __align__(16) unsigned char w_smem[];
     // DIRECT (one problem): the control block, the machine's arrays and n are kernel arguments, so the state and -- unconditionally, a
     // wave per slot -- the record a launch with few bids will resolve are requested before the argument block has arrived
@@ -948,8 +850,6 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
         const bool heavy = S.heavy != 0;
         const int chunk = std::max(act == SC_ACT_ROUND && !heavy ? 8 : (heavy && HEAVY_SPREAD && gridDim.x >= 512 && act == SC_ACT_ROUND ? 1 : HEADB / 64), (nwork + (int)gridDim.x - 1) / (int)gridDim.x);
         const int c_lo = std::min(nwork, (int)blockIdx.x * chunk), c_hi = std::min(nwork, c_lo + chunk);
-        // (the same decision in every workgroup of the launch: a function of the state and the launch's shape)
-        const bool wave_rows = wave_rows_min > 0 && (nwork + (int)gridDim.x - 1) / (int)gridDim.x >= wave_rows_min;
         for (int t0 = c_lo; t0 < c_hi; t0 += HEADB) {
             const int tn = std::min(HEADB, c_hi - t0);           // work items of this tile
             int nlist = tn;                                       // rows that bid out of this tile
@@ -983,20 +883,6 @@ __global__ __launch_bounds__(HEADB) void wide_sc_round(const WideArgs *__restric
                 __syncthreads();
             }
             const int obase = act == SC_ACT_ROUND ? ss.obase : t0;
-            if (wave_rows) {
-                // many rows per wave: every wave goes through its rows on its own -- an uncertified row is read in full by THAT wave
-                // (sc_top2_wave), no queue, no barrier: the launch is a pass over (part of) the matrix, bound by bytes in flight
-                for (int e = w; e < nlist; e += HEADB / 64) {
-                    const int i = act == SC_ACT_ROUND ? uni(ss.lrow[e]) : (act == SC_ACT_RESET ? t0 + e : uni(a.act0[t0 + e]));
-                    const uint32_t col = a.cache_col[(int64_t)i * KC + lane];
-                    const float val = a.cache_val[(int64_t)i * KC + lane];
-                    Top2 t;
-                    if (!sc_top2_cached(a, vw, lane, col, val, t)) { t = sc_top2_wave<U>(a, vw, ss, w, i, refresh, lane); dense++; }
-                    record(obase + e, i, t);
-                }
-                if (act == SC_ACT_ROUND) __syncthreads();          // (ss.lrow / ss.cnt belong to the next tile from here on)
-                continue;
-            }
             for (int e0 = 0; e0 < nlist; e0 += HEADB / 64) {     // (the same trips for every wave of the workgroup)
                 const int e = e0 + w;
                 if (e < nlist) {
@@ -2670,7 +2556,7 @@ int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, i
         // (one problem: the control block and the machine's arrays are kernel arguments -- one dependent load less per launch)
         char *sc_direct = nullptr, *scx_direct = nullptr;
         if (nb == 1 && direct) { sc_direct = direct->sc; scx_direct = direct->scx; }
-        using RoundK = void (*)(const WideArgs *, int, int, char *, char *, int *, int, int);
+        using RoundK = void (*)(const WideArgs *, int, int, char *, char *, int *, int);
         RoundK roundk = sc_direct ? (unroll == 8 ? (RoundK)wide_sc_round<8, true> : unroll == 4 ? (RoundK)wide_sc_round<4, true> : unroll == 3 ? (RoundK)wide_sc_round<3, true> : (RoundK)wide_sc_round<2, true>)
                                   : (unroll == 8 ? (RoundK)wide_sc_round<8, false> : unroll == 4 ? (RoundK)wide_sc_round<4, false> : unroll == 3 ? (RoundK)wide_sc_round<3, false> : (RoundK)wide_sc_round<2, false>);
         if ((rc = set_max_dynamic_lds(reinterpret_cast<const void *>(roundk)))) return rc;
@@ -2687,9 +2573,6 @@ int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, i
         //  bids a launch gives every bid a wave of its own -- 512 / 1 024 / 2 048 / 4 096: 50 000^2 18.2 / 18.0 / 17.9 / 22.0 ms)
         const int ahead = CYTO_KNOB("CYTO_SC_AHEAD").set ? std::max(2, CYTO_KNOB("CYTO_SC_AHEAD").value) : 16;
         const int small_max = CYTO_KNOB("CYTO_SC_SMALL").set ? CYTO_KNOB("CYTO_SC_SMALL").value : SC_SMALL;
-        // (from how many rows per workgroup on a launch's uncertified rows are read by the wave that holds them instead of the whole
-        //  workgroup, one after the other: developer knob CYTO_SC_WAVE_ROWS, 0 = never; tools/exp/wave_rows_ab.sh)
-        const int wave_rows_min = CYTO_KNOB("CYTO_SC_WAVE_ROWS").set ? std::max(0, CYTO_KNOB("CYTO_SC_WAVE_ROWS").value) : SC_WAVE_ROWS;
         int L = 0;
         // a NO-PROGRESS timeout: the clock restarts whenever the launch under way changes (a slow but advancing run -- counter passes of
         // a profiler, a GPU shared by several ranks -- is not an error); before an error return the stream is drained, because the
@@ -2715,7 +2598,7 @@ int wide_launch_arr(const WideArgs *d_args, int nb, int n, hipStream_t stream, i
             if (want && rebuild && (rc = rebuild(ctx, flags.data()))) { (void)hipStreamSynchronize(stream); return rc; }
             for (int g = 0; g < 8; g++, L++) {
                 if ((L >> 1) > 0 && (L >> 1) % wipe == 0) hipLaunchKernelGGL(wide_sc_wipe, dim3(bxr, nb), dim3(HEADB), 0, stream, d_args, L);
-                hipLaunchKernelGGL(roundk, dim3(bx, nb), dim3(HEADB), SC_SHARED_BYTES, stream, d_args, L, n, sc_direct, scx_direct, t_hs.p, small_max, wave_rows_min);
+                hipLaunchKernelGGL(roundk, dim3(bx, nb), dim3(HEADB), SC_SHARED_BYTES, stream, d_args, L, n, sc_direct, scx_direct, t_hs.p, small_max);
             }
             if (L > (1 << 22)) return fail();                          // (every phase is bounded: cannot happen)
         }
