@@ -52,11 +52,17 @@ struct Block { void *p; size_t bytes; };
 struct DeviceCache {
     std::multimap<size_t, void *> free_blocks;     // size -> block
     std::map<void *, size_t> live;                 // every block this cache handed out (or holds): its size
+    size_t free_bytes = 0;                         // sum over free_blocks
 };
 std::mutex g_cache_mutex;
 std::map<int, DeviceCache> g_cache;                // by device
 
-constexpr size_t k_keep_max = (size_t)1 << 30;    // larger blocks are not kept after the call that used them
+// Blocks of up to 16 GiB are kept (config c3's standardised scRNA operand is 4 GB: handing it back to the runtime after every call and
+// asking for it again cost the fused call ~10 ms of hipFree / hipMalloc -- round 6, tools/c3_walls.py), as long as the blocks the cache
+// holds idle stay under 64 GiB of the device's 288 (beyond that the largest idle blocks go back to the runtime; a materialised 10 GB cost
+// matrix of a one-off solve does not starve the caller's own allocations for long).
+constexpr size_t k_keep_max = (size_t)16 << 30;
+constexpr size_t k_idle_cap = (size_t)64 << 30;
 
 size_t round_size(size_t b) {
     // 256-byte granules below 1 MiB, 1/8-octave steps above: a slightly larger n finds the block of the last solve
@@ -69,6 +75,7 @@ size_t round_size(size_t b) {
 void trim_locked(DeviceCache &c) {
     for (auto &kv : c.free_blocks) { c.live.erase(kv.second); (void)hipFree(kv.second); }
     c.free_blocks.clear();
+    c.free_bytes = 0;
 }
 }  // namespace
 
@@ -83,6 +90,7 @@ void *cache_alloc(size_t bytes, int *status) {
         // best fit, but never a block more than 25 % larger than asked for (a 10 GB block must not serve a 1 MB request)
         if (it != c.free_blocks.end() && it->first <= want + want / 4 + 4096) {
             void *p = it->second;
+            c.free_bytes -= it->first;
             c.free_blocks.erase(it);
             *status = CYTO_OK;
             return p;
@@ -122,7 +130,20 @@ void cache_release(void *p, hipStream_t used_on) {
             // nobody asked for starves the caller's own allocations
             if (it->second > k_keep_max) { kv.second.live.erase(it); break; }
             kv.second.free_blocks.emplace(it->second, p);
-            return;
+            kv.second.free_bytes += it->second;
+            // over the idle cap: the largest idle blocks go back to the runtime (outside the lock, below)
+            std::vector<void *> evict;
+            while (kv.second.free_bytes > k_idle_cap && !kv.second.free_blocks.empty()) {
+                auto big = std::prev(kv.second.free_blocks.end());
+                kv.second.free_bytes -= big->first;
+                kv.second.live.erase(big->second);
+                evict.push_back(big->second);
+                kv.second.free_blocks.erase(big);
+            }
+            if (evict.empty()) return;
+            p = nullptr;
+            for (void *q : evict) { if (!p) p = q; else (void)hipFree(q); }      // (hipFree synchronises the device: rare by construction)
+            break;
         }
     }
     (void)hipFree(p);                               // a large block (or not ours: cannot happen); outside the lock
