@@ -25,8 +25,7 @@ static int lap_batch_any_impl(int nb, const int *n, const float *const *cost, co
     if (rc) return rc;
     const int conc = std::max(1, std::min(nb, max_concurrent > 0 ? max_concurrent : 256));
     StreamGuard guard;
-    CYTO_HIP(hipStreamCreateWithFlags(&guard.s, hipStreamNonBlocking));
-    guard.own = true;
+    if ((rc = guard.acquire())) return rc;
     std::vector<int> st((size_t)nb, CYTO_OK);
     std::map<int, std::vector<int>> by_n;                 // size -> problems, in input order
     for (int b = 0; b < nb; b++) {
@@ -77,8 +76,7 @@ static int lap_batch_any_impl(int nb, const int *n, const float *const *cost, co
                         const int m = (int)ks.size();
                         if (select_device(device_id)) return CYTO_ERR_HIP;
                         StreamGuard sg;
-                        if (hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking) != hipSuccess) return CYTO_ERR_HIP;
-                        sg.own = true;
+                        if (sg.acquire()) return CYTO_ERR_HIP;
                         std::vector<const float *> c2((size_t)m); std::vector<int64_t> l2((size_t)m);
                         std::vector<int32_t *> rs2((size_t)m), cs2((size_t)m); std::vector<float *> u2((size_t)m), v2((size_t)m);
                         std::vector<double> tot2((size_t)m); std::vector<cyto_lap_info> inf2((size_t)m);

@@ -1,6 +1,7 @@
 // core.hip -- status strings, device selection and memory plumbing of the C ABI (include/cytohip.h).
 #include "cyto_common.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <set>
@@ -128,7 +129,9 @@ void cache_release(void *p, hipStream_t used_on) {
             // blocks above 1 GiB (a materialised c3 cost matrix is 10 GB) go straight back to the runtime: the hipFree's
             // device-wide synchronisation is nothing beside the solve that used such a block, and a resident 10 GB block
             // nobody asked for starves the caller's own allocations
-            if (it->second > k_keep_max) { kv.second.live.erase(it); break; }
+            // (developer knob CYTO_CACHE_KEEP_MB: the largest block kept, in MiB -- 1024 = rounds 1-5)
+            const size_t keep_max = CYTO_KNOB("CYTO_CACHE_KEEP_MB").set ? (size_t)std::max(1, CYTO_KNOB("CYTO_CACHE_KEEP_MB").value) << 20 : k_keep_max;
+            if (it->second > keep_max) { kv.second.live.erase(it); break; }
             kv.second.free_blocks.emplace(it->second, p);
             kv.second.free_bytes += it->second;
             // over the idle cap: the largest idle blocks go back to the runtime (outside the lock, below)
@@ -147,6 +150,40 @@ void cache_release(void *p, hipStream_t used_on) {
         }
     }
     (void)hipFree(p);                               // a large block (or not ours: cannot happen); outside the lock
+}
+
+// ---- stream pool: non-blocking streams by device, handed out to the calls that want a private stream and taken back drained ----
+namespace {
+std::mutex g_stream_mutex;
+std::map<int, std::vector<hipStream_t>> g_idle_streams;
+std::map<hipStream_t, int> g_stream_device;
+}  // namespace
+
+hipStream_t stream_pool_acquire() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    {
+        std::lock_guard<std::mutex> lk(g_stream_mutex);
+        std::vector<hipStream_t> &idle = g_idle_streams[dev];
+        if (!idle.empty()) { hipStream_t s = idle.back(); idle.pop_back(); return s; }
+    }
+    hipStream_t s = nullptr;
+    const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) { set_hip_error(e, "hipStreamCreateWithFlags"); (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> lk(g_stream_mutex);
+    g_stream_device[s] = dev;
+    return s;
+}
+
+void stream_pool_release(hipStream_t s) {
+    if (!s) return;
+    std::lock_guard<std::mutex> lk(g_stream_mutex);
+    auto it = g_stream_device.find(s);
+    if (it == g_stream_device.end()) return;                      // (not ours: cannot happen)
+    std::vector<hipStream_t> &idle = g_idle_streams[it->second];
+    if (idle.size() < 64) { idle.push_back(s); return; }            // (64 hardware queues at most: _lib.py sets GPU_MAX_HW_QUEUES)
+    g_stream_device.erase(it);
+    (void)hipStreamDestroy(s);
 }
 
 int set_max_dynamic_lds(const void *kernel) {

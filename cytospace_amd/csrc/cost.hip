@@ -25,6 +25,7 @@
 #include "cyto_common.h"
 #include <math.h>
 #include <algorithm>
+#include <chrono>
 #include <vector>
 #include <thread>
 #include <new>
@@ -861,8 +862,7 @@ static int assign_metric_impl(int metric, int G, int C, int S, const void *sc, i
     // a private stream, so that several host threads can run chunks concurrently on one GPU
     // (declared before the buffers: they go back to the block cache while their stream still exists)
     StreamGuard guard;
-    CYTO_HIP(hipStreamCreateWithFlags(&guard.s, hipStreamNonBlocking));
-    guard.own = true;
+    if ((rc = guard.acquire())) return rc;
     const hipStream_t stream = guard.s;
     Events<2> ev;
     if ((rc = ev.create())) return rc;
@@ -892,8 +892,7 @@ static int assign_metric_impl(int metric, int G, int C, int S, const void *sc, i
         // (Copying on a third stream with the transforms enqueued without a host wait was measured too: no faster -- while a
         //  contraction runs the upload itself slows down from 57 to ~40 GB/s.)
         StreamGuard gcomp;
-        CYTO_HIP(hipStreamCreateWithFlags(&gcomp.s, hipStreamNonBlocking));
-        gcomp.own = true;
+        if ((rc = gcomp.acquire())) return rc;
         const size_t esz = dtype_size(sc_dt);
         DevBuf dx;
         if ((rc = dx.alloc((size_t)G * WBLK * esz, stream))) return rc;
@@ -1143,10 +1142,15 @@ int cyto_ctx_assign_chunks(cyto_expr_ctx *ctx, int nchunks, cyto_chunk *chunks, 
     if (nchunks == 0) return CYTO_OK;
     int rc = select_device(ctx->device_id);
     if (rc) return rc;
+    // (developer knob CYTO_TRACE_CHUNKS: wall-clock stamps of this call's steps on stderr -- tools/c3_walls.py)
+    const bool trace = CYTO_KNOB("CYTO_TRACE_CHUNKS").set && CYTO_KNOB("CYTO_TRACE_CHUNKS").value;
+    const auto t_entry = std::chrono::steady_clock::now();
+    auto stamp = [&](const char *what) {
+        if (trace) fprintf(stderr, "[chunks] %8.3f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count(), what);
+    };
     const int conc = std::max(1, std::min(nchunks, max_concurrent > 0 ? max_concurrent : 64));
     StreamGuard guard;
-    CYTO_HIP(hipStreamCreateWithFlags(&guard.s, hipStreamNonBlocking));
-    guard.own = true;
+    if ((rc = guard.acquire())) return rc;
     const hipStream_t stream = guard.s;
     Events<3> ev;
     if ((rc = ev.create())) return rc;
@@ -1198,6 +1202,7 @@ int cyto_ctx_assign_chunks(cyto_expr_ctx *ctx, int nchunks, cyto_chunk *chunks, 
             if ((size_t)n_sc * 4 > cap_isc) { CYTO_HIP(hipStreamSynchronize(stream)); if ((rc = dsc.alloc((size_t)n_sc * 4, stream))) return rc; cap_isc = (size_t)n_sc * 4; }
             if ((size_t)p.Su * 4 > cap_ist) { CYTO_HIP(hipStreamSynchronize(stream)); if ((rc = dst.alloc((size_t)p.Su * 4, stream))) return rc; cap_ist = (size_t)p.Su * 4; }
             if ((rc = p.cost.alloc((size_t)p.Su * p.ldc * 4, stream))) return rc;
+            stamp("index lists validated, buffers allocated");
             p.ones.assign((size_t)p.Su, 1);
             p.rowpos_u.resize((size_t)p.N);
             {
@@ -1226,6 +1231,7 @@ int cyto_ctx_assign_chunks(cyto_expr_ctx *ctx, int nchunks, cyto_chunk *chunks, 
                 return rc;
             (void)hipEventElapsedTime(&p.ms_gather, ev[0], ev[1]);
             p.ms_gemm = (float)ms_gemm;
+            stamp("gathers + contraction done (stream synchronised)");
             p.colsol.resize((size_t)p.N);
             return CYTO_OK;
         };
@@ -1247,8 +1253,10 @@ int cyto_ctx_assign_chunks(cyto_expr_ctx *ctx, int nchunks, cyto_chunk *chunks, 
                 nn[(size_t)q] = (int)p.N; cst[(size_t)q] = p.cost.as<float>(); lds_[(size_t)q] = p.ldc; cs[(size_t)q] = p.colsol.data();
                 if (!p.identity) { rmaps[(size_t)q] = p.rowpos_u.data(); nus[(size_t)q] = p.Su; }
             }
+            stamp("LAP batch begins");
             (void)lap_batch_any(nl, nn.data(), cst.data(), lds_.data(), 1, rmaps.data(), nus.data(), nullptr, cs.data(), nullptr, nullptr,
                                 tot.data(), li.data(), stat.data(), nl, ctx->device_id);
+            stamp("LAP batch returned");
             for (int q = 0; q < nl; q++) {
                 const int k = ids[(size_t)q];
                 cyto_chunk &ch = chunks[lo + k];
@@ -1292,7 +1300,9 @@ int cyto_ctx_assign_chunks(cyto_expr_ctx *ctx, int nchunks, cyto_chunk *chunks, 
             }
         }
         for (int k = 0; k < cnt; k++) if (!first && chunks[lo + k].status) first = chunks[lo + k].status;
+        stamp("round of chunks done; buffers go back to the block cache");
     }
+    stamp("return");
     return first;
 }
 

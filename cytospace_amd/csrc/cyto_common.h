@@ -60,10 +60,19 @@ template <int N> struct Events {
 
 // A private non-blocking stream for one call when the caller gave none.  The stream is drained before it is destroyed: work that
 // an early return left queued must not outlive the call.
+// (round 6: the stream comes from a per-device pool and goes back to it -- creating and destroying a stream per call cost a chunk call's
+//  LAP ~7 ms, tools/c3_walls.py: the first launches on a fresh stream wait for its hardware queue)
+hipStream_t stream_pool_acquire();            // a non-blocking stream of the CURRENT device (created if none is idle); nullptr on failure
+void stream_pool_release(hipStream_t s);     // back to the pool of the device it was made on (the caller has drained it)
 struct StreamGuard {
     hipStream_t s = nullptr;
     bool own = false;
-    ~StreamGuard() { if (own && s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } }
+    int acquire() {                            // CYTO_OK / CYTO_ERR_HIP
+        s = stream_pool_acquire();
+        own = s != nullptr;
+        return own ? CYTO_OK : CYTO_ERR_HIP;
+    }
+    ~StreamGuard() { if (own && s) { (void)hipStreamSynchronize(s); stream_pool_release(s); } }
 };
 // Declared AFTER the device buffers a second stream works on (so destroyed BEFORE them): whatever path leaves the scope, the
 // stream has drained before a buffer goes back to the block cache, where another thread's call may be handed it.
