@@ -446,6 +446,9 @@ def extra_c5_chunks(dev, K=50, G=500, chunk=10000, sets=8, cpu_n=10000, cpu_thre
     t = time.perf_counter()
     sc, st = instances.single_cell_expression(G, sets * chunk, sets * chunk, seed=5)
     t_gen = time.perf_counter() - t
+    from cytospace_amd.cytospace import _counts_matrix
+    if float(max(sc.max(), st.max())) < 65536:                     # (integer counts as the reader hands them over: see extra_c4_sharded)
+        sc, st = _counts_matrix(sc.astype(np.int64)), _counts_matrix(st.astype(np.int64))
     ones = np.ones(chunk, np.int64)
     work = [(np.arange((k % sets) * chunk, (k % sets + 1) * chunk), ones,
              np.arange(((k // sets) % sets) * chunk, ((k // sets) % sets + 1) * chunk)) for k in range(K)]
@@ -483,7 +486,7 @@ def extra_c5_chunks(dev, K=50, G=500, chunk=10000, sets=8, cpu_n=10000, cpu_thre
                         "through one batched context call on one GPU: per-chunk gather + MFMA cost build, then every LAP together",
             "chunks": K, "wall_s": round(wall, 3), "assignments_per_s": round(K * chunk / wall, 1),
             "roofline": floor_roofline(K, chunk, wall, "every chunk's cost matrix as the cost build leaves it in HBM; the wall time includes the cost builds"),
-            "context_s": round(t1 - t0, 2), "cost_build_ms_total": round(sum(r[2].ms_standardize + r[2].ms_gemm for r in res), 1),
+            "context_s": round(t1 - t0, 2), "counts_dtype": sc.dtype.name, "cost_build_ms_total": round(sum(r[2].ms_standardize + r[2].ms_gemm for r in res), 1),
             "chunk0": {"lap_batch_kernel_ms": round(i0.lap.ms_total, 1), "row_reduction_ms": round(i0.lap.ms_arr, 1), "wide_solver": bool(i0.lap.wide),
                        "augmentation_ms": round(i0.lap.ms_aug, 1), "row_scans": int(i0.lap.row_scans),
                        "aug_scans": int(i0.lap.scans_aug_relax), "searches": int(i0.lap.augmentations)},
@@ -533,6 +536,12 @@ def extra_c4_sharded(dev, rank, world, store, comm, chunks_per_rank, G=5000, S=5
         subs = [np.bincount(np.random.default_rng(9000 + k).integers(0, S, chunk), minlength=S) for k in mine]
     else:
         subs = [np.bincount(r.integers(0, S, chunk), minlength=S) for _ in range(chunks_per_rank)]    # sub-spot slot counts
+    # raw counts cross PCIe as the narrowest unsigned integer type that holds them (what cytospace_amd.cytospace._counts_matrix hands
+    # apply_linear_assignment for a table of integer counts; untimed like the generator: it is the reader's job)
+    from cytospace_amd.cytospace import _counts_matrix
+    sc = _counts_matrix(sc.astype(np.int64) if sc.dtype.kind == "f" and float(sc.max()) < 65536 else sc)
+    if st is not None:
+        st = _counts_matrix(st.astype(np.int64) if st.dtype.kind == "f" and float(st.max()) < 65536 else st)
     t_gen = time.perf_counter() - t
     def sync():
         _lib.check(_lib.lib().cyto_device_synchronize(dev))
@@ -559,7 +568,7 @@ def extra_c4_sharded(dev, rank, world, store, comm, chunks_per_rank, G=5000, S=5
                             f"{G} genes, on {world} GPU(s): chunk k on rank k % {world}; ST transformed on rank 0 + RCCL broadcast",
                 "assignments_per_s": round(total_chunks * chunk / el, 1), "seconds": round(el, 3), "scaling": "strong",
                 "roofline": floor_roofline(total_chunks, chunk, el, "every chunk's LAP as the reference materialises it; the time includes upload, transforms, broadcast and cost builds"),
-                "chunks_on_rank0": len(mine), "bcast_ms_rank0": None if bcast_ms is None else round(bcast_ms, 3),
+                "chunks_on_rank0": len(mine), "counts_dtype": sc.dtype.name, "bcast_ms_rank0": None if bcast_ms is None else round(bcast_ms, 3),
                 "rank0_longest_lap_kernel_ms": round(max(r_[2].lap.ms_total for r_ in res), 1) if res else None,
                 "bincount_equals_slots": ok, "instance_seconds_rank0": round(t_gen, 1)}
     return {"workload": f"{world} GPU(s) x {chunks_per_rank} sub-spot chunks of {chunk} cells against {S} spots, {G} genes: "
@@ -567,7 +576,7 @@ def extra_c4_sharded(dev, rank, world, store, comm, chunks_per_rank, G=5000, S=5
             "assignments_per_s": round(world * chunks_per_rank * chunk / el, 1), "seconds": round(el, 3), "scaling": "weak",
             "roofline": floor_roofline(world * chunks_per_rank, chunk, el, "every chunk's LAP as the reference materialises it; the time includes upload, transforms, broadcast and cost builds; peak = ONE GPU's: divide by the GPUs for a per-device fraction"),
             "cost_build_ms_per_rank": round(sum(r[2].ms_standardize + r[2].ms_gemm for r in res), 1),
-            "context_s_rank0": round(t1 - t0, 3), "bcast_ms_rank0": None if bcast_ms is None else round(bcast_ms, 3),
+            "context_s_rank0": round(t1 - t0, 3), "counts_dtype": sc.dtype.name, "bcast_ms_rank0": None if bcast_ms is None else round(bcast_ms, 3),
             "bcast_bytes": int(-(-G // 32) * 32) * int(-(-S // 128) * 128) * 4,
             "chunk0": {"gather_ms": round(i0.ms_standardize, 2), "gemm_ms": round(i0.ms_gemm, 2), "spots_with_cells": int((subs[0] > 0).sum()),
                        "lap_batch_kernel_ms": round(i0.lap.ms_total, 1), "lap_row_scans": int(i0.lap.row_scans)},
@@ -683,7 +692,7 @@ def main():
     ap.add_argument("--rank-timeout", type=float, default=3000.0, help="self-spawned ranks (--gpus N without a launcher) are ended after this many seconds")
     ap.add_argument("--oversubscribe", action="store_true", help="allow more ranks than devices (rank r on device r %% devices; no RCCL "
                                                                  "communicator: a self-test of the harness on a one-GPU box)")
-    ap.add_argument("--pmc-tag", default="r05", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
+    ap.add_argument("--pmc-tag", default="r06", help="profiles/<tag>_pmc_traffic_n<n>.json supplies roofline.traffic")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
