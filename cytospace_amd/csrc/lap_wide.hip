@@ -2468,7 +2468,9 @@ struct SpinWait {
     unsigned polls = 0;
     void reset() { polls = 0; }
     void pause() {
-        if (++polls < 512) __builtin_ia32_pause();
+        // (developer knob CYTO_SPIN_POLLS: polls before the first yield; 0 = never yield)
+        static const unsigned k_spin = CYTO_KNOB("CYTO_SPIN_POLLS").set ? (unsigned)std::max(0, CYTO_KNOB("CYTO_SPIN_POLLS").value) : 512u;
+        if (k_spin == 0 || ++polls < k_spin) __builtin_ia32_pause();
         else std::this_thread::yield();
     }
 };
