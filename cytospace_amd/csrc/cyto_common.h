@@ -31,11 +31,12 @@ void cache_release(void *p, hipStream_t used_on);
 struct DevBuf {
     void *p = nullptr;
     hipStream_t stream = nullptr;          // the stream the buffer is used on (for the drain check at release)
+    bool owned = true;                     // false: a VIEW into another buffer's block (a solve's work buffers are carved out of one block)
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { reset(); }
-    void reset() { if (p) cache_release(p, stream); p = nullptr; }
+    void reset() { if (p && owned) cache_release(p, stream); p = nullptr; owned = true; }
     int alloc(size_t bytes, hipStream_t used_on = nullptr) {
         reset();
         int st = CYTO_OK;
@@ -43,6 +44,7 @@ struct DevBuf {
         p = cache_alloc(bytes ? bytes : 16, &st);
         return st;
     }
+    void view(void *q, hipStream_t used_on = nullptr) { reset(); p = q; stream = used_on; owned = false; }
     template <typename U> U *as() const { return reinterpret_cast<U *>(p); }
 };
 

@@ -3346,6 +3346,8 @@ struct F32Job {
     int32_t *rowsol = nullptr, *colsol = nullptr; float *u = nullptr, *v = nullptr; double *total = nullptr; cyto_lap_info *info = nullptr;
     int status = CYTO_OK;
     // device state
+    DevBuf slab;                // ONE block per problem for the ten work buffers every solve needs (views below): a batch of 256 problems made
+                                // 3 300 hipMallocs on a process's first call -- 160 ms of a 0.67-s call (round 6, bench c4_chunks.first_call_wall_s)
     DevBuf staged, b_fws, b_iws, b_imin, b_pmin, b_parg, b_misc, b_same, b_gid, b_ccol, b_cval, b_ghb, b_ghs, b_lzhb, b_lzhs;
     DevBuf b_rowmap, b_ulist, b_ufirst, b_wide;
     int nused = 0;
@@ -3722,11 +3724,19 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
             CYTO_HIP(hipStreamSynchronize(stream));       // ulist / ufirst are locals
         }
         // workspace (blocks of the device cache: no hipMalloc / hipFree once a size has been seen)
-        if ((rc = j.b_fws.alloc(6 * nT + 64, stream)) || (rc = j.b_iws.alloc(10 * nI + 64, stream)) || (rc = j.b_imin.alloc(nI, stream)) ||
-            (rc = j.b_pmin.alloc((size_t)pl.rowblocks * nT, stream)) || (rc = j.b_parg.alloc((size_t)pl.rowblocks * nI, stream)) ||
-            (rc = j.b_misc.alloc(512, stream)) || (rc = j.b_same.alloc(nI, stream)) || (rc = j.b_gid.alloc(nI, stream)) ||
-            (rc = j.b_ccol.alloc((size_t)n * KC * sizeof(uint32_t), stream)) || (rc = j.b_cval.alloc((size_t)n * KC * sizeof(float), stream)))
-            return rc;
+        {
+            size_t off = 0;
+            auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+            const size_t o_fws = take(6 * nT + 64), o_iws = take(10 * nI + 64), o_imin = take(nI), o_pmin = take((size_t)pl.rowblocks * nT),
+                         o_parg = take((size_t)pl.rowblocks * nI), o_misc = take(512), o_same = take(nI), o_gid = take(nI),
+                         o_ccol = take((size_t)n * KC * sizeof(uint32_t)), o_cval = take((size_t)n * KC * sizeof(float));
+            if ((rc = j.slab.alloc(off, stream))) return rc;
+            char *base = j.slab.as<char>();
+            j.b_fws.view(base + o_fws, stream); j.b_iws.view(base + o_iws, stream); j.b_imin.view(base + o_imin, stream);
+            j.b_pmin.view(base + o_pmin, stream); j.b_parg.view(base + o_parg, stream); j.b_misc.view(base + o_misc, stream);
+            j.b_same.view(base + o_same, stream); j.b_gid.view(base + o_gid, stream); j.b_ccol.view(base + o_ccol, stream);
+            j.b_cval.view(base + o_cval, stream);
+        }
         // float workspace: v | u | ... ; int workspace: rowsol | colsol | matches | freerows | rtrows | pred | ...
         float *d_v = j.b_fws.as<float>();
         int32_t *d_rowsol = j.b_iws.as<int32_t>(), *d_colsol = d_rowsol + n, *d_matches = d_rowsol + 2 * (size_t)n;
