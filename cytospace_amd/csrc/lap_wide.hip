@@ -96,6 +96,25 @@ template <typename F> __device__ __forceinline__ void wave_row_sweep(const float
         }
     }
 }
+// the quads [q_lo, q_hi) of a row by one wave (a slice: the whole workgroup shares a row)
+template <typename F> __device__ __forceinline__ void wave_row_sweep_q(const float *__restrict__ row, int q_lo, int q_hi, int n, int lane, F &&f) {
+    constexpr int U = 4;
+    const float4 *__restrict__ r4 = reinterpret_cast<const float4 *>(row);
+    for (int q0 = q_lo + lane; q0 < q_hi; q0 += 64 * U) {
+        float4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int q = q0 + 64 * u; x[u] = q < q_hi ? r4[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int q = q0 + 64 * u, c = q * 4;
+            if (q >= q_hi) continue;
+            f(c, x[u].x);
+            if (c + 1 < n) f(c + 1, x[u].y);
+            if (c + 2 < n) f(c + 2, x[u].z);
+            if (c + 3 < n) f(c + 3, x[u].w);
+        }
+    }
+}
 // Search labels (oracle/jv_oracle_impl.h, WIDE MODE): a 44-bit label value LV = ordered distance (32) | tight-hop count k (12),
 // then 20 bits of identity (the predecessor row in `label`, the column itself in the block minima and in the best unassigned
 // column): one unsigned 64-bit compare orders (distance, k, identity) lexicographically; key >> 32 is the ordered distance.
@@ -1239,6 +1258,12 @@ struct AugShared {
     int scans;
     int st_row[64], st_col[64];    // one-edge searches: their results, stored to global memory 64 at a time
     float st_val[64];
+    // full-row relaxations of a round (an owner whose cache could not certify): queued by the wave that settled the column, done by the
+    // WHOLE workgroup behind the round's barrier -- a 200-KB row at n = 50 000 took its one wave ~60 us while fifteen others waited at the
+    // barrier (config c3: 40 of them were 2.4 of its searches' 6.1 ms)
+    int ndn, dn_oi[WNW * 2], dn_pj[WNW * 2];
+    uint32_t dn_dord[WNW * 2], dn_k[WNW * 2];
+    float dn_h[WNW * 2];
 };
 
 // ---- SEVERAL SEARCHES AT ONCE (one problem, PAR): the free rows' searches are independent until they are committed, and most of
@@ -1347,7 +1372,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             return;
         }
     }
-    if (tid == 0) { s.waste = 0; s.stop = 0; }
+    if (tid == 0) { s.waste = 0; s.stop = 0; s.ndn = 0; }
     if (tid == 0) { s.T = ~0ull; s.ntouch = 0; s.any[0] = 0; s.any[1] = 0; s.any[2] = 0; s.npk[0] = 0; s.npk[1] = 0; s.npk[2] = 0; s.fail = 0; s.anydense = 0; s.rootdense = 0; s.doroot = 0; s.f = f0; s.err = 0; s.scans = 0; }
     __syncthreads();
     auto getv = [&](int j) -> float { return VLDS ? s_v[j] : ld_sc1(a.v + j); };
@@ -1379,6 +1404,28 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
         }
     };
     auto relax_to = [&](int col, unsigned long long lv, int row) { after_offer(col, lv, row, offer(col, lv, row)); };
+    // behind a round's barrier (every wave of the workgroup, the idle ones too): the full-row relaxations the round queued, a slice of the
+    // row per wave.  (A round that queued one has settled a column: the rounds go on, and what these relaxations label is picked up.)
+    auto coop_dense = [&]() {
+        const int nd = uni(s.ndn);
+        if (!nd) return;
+        const int nq = (n + 3) >> 2, per = (nq + WNW - 1) / WNW, q_lo = w * per, q_hi = min(nq, q_lo + per);
+        for (int e = 0; e < nd; e++) {
+            const int oiq = uni(s.dn_oi[e]), pjq = uni(s.dn_pj[e]);
+            const uint32_t dord = uni(s.dn_dord[e]), kq = uni(s.dn_k[e]);
+            const float h = uni(s.dn_h[e]);
+            const float *__restrict__ row = a.cost + wrow_off(a.rowmap, oiq, a.ld);
+            // (a full row offers hundreds of candidates below the best unassigned distance when many columns are near-equal:
+            //  the label is read first -- a plain L2 load -- and the atomic follows only where it would change something)
+            wave_row_sweep_q(row, q_lo, q_hi, n, lane, [&](int c, float x) {
+                const unsigned long long lv = edge_lv(f2ord((x - getv(c)) - h), dord, kq);
+                if (c != pjq && lv <= lv_of(s.T) && (lkey(lv, (uint32_t)oiq) < ld_sc1(lbl + c))) relax_to(c, lv, oiq);
+            });
+        }
+        __syncthreads();
+        if (tid == 0) s.ndn = 0;
+        __syncthreads();
+    };
 
     int f = f0;
     int ph = 0;                                                  // round flag in use (three take turns: one barrier per round)
@@ -1516,6 +1563,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                 const int W = wact;
                 if (w >= W && rb[0] < 0 && rb[1] < 0) {              // nothing to pick from, no minimum to rebuild: straight to the barrier
                     __syncthreads();
+                    coop_dense();
                     const int any0 = uni(s.any[ph]), np0 = uni(s.npk[ph]);
                     ph = (ph + 1) % 3;
                     c_rounds++;
@@ -1647,16 +1695,12 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     if (!dn[q]) continue;                          // the owner's cache could not certify: its whole cost row
                     const uint32_t dord = (uint32_t)(lab[q] >> 32), kq = (uint32_t)(lab[q] >> 20) & LKMAX;
                     const float h = (ca[q] - vp[q]) - ord2f(dord);
-                    const float *__restrict__ row = a.cost + wrow_off(a.rowmap, oi[q], a.ld);
-                    const int pjq = pj[q], oiq = oi[q];
-                    // (a full row offers hundreds of candidates below the best unassigned distance when many columns are near-equal:
-                    //  the label is read first -- a plain L2 load -- and the atomic follows only where it would change something)
-                    wave_row_sweep(row, n, lane, [&](int c, float x) {
-                        const unsigned long long lv = edge_lv(f2ord((x - getv(c)) - h), dord, kq);
-                        if (c != pjq && lv <= lv_of(s.T) && (lkey(lv, (uint32_t)oiq) < ld_sc1(lbl + c))) relax_to(c, lv, oiq);
-                    });
+                    if (lane == 0) {                               // (relaxed by the whole workgroup behind the round's barrier: coop_dense)
+                        const int e = atomicAdd(&s.ndn, 1);
+                        s.dn_oi[e] = oi[q]; s.dn_pj[e] = pj[q]; s.dn_dord[e] = dord; s.dn_k[e] = kq; s.dn_h[e] = h;
+                        atomicAdd(&s.waste, 1);
+                    }
                     c_dense++;
-                    if (lane == 0) atomicAdd(&s.waste, 1);
                 }
 #pragma unroll
                 for (int q = 0; q < AP; q++) {                       // last round's blocks: smallest (distance, k) among their dirty columns
@@ -1674,6 +1718,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     rb[q] = pk[q] ? (pj[q] >> 6) : -1;
                 }
                 __syncthreads();
+                coop_dense();
                 const int any = uni(s.any[ph]), np = uni(s.npk[ph]);
                 if (tid == 0) { s.any[(ph + 2) % 3] = 0; s.npk[(ph + 2) % 3] = 0; }   // (last read before this barrier, next set after the next one)
                 ph = (ph + 1) % 3;
