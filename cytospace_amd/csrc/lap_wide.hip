@@ -1261,10 +1261,11 @@ struct AugShared {
     // full-row relaxations of a round (an owner whose cache could not certify): queued by the wave that settled the column, done by the
     // WHOLE workgroup behind the round's barrier -- a 200-KB row at n = 50 000 took its one wave ~60 us while fifteen others waited at the
     // barrier (config c3: 40 of them were 2.4 of its searches' 6.1 ms)
-    int ndn, dn_oi[WNW * 2], dn_pj[WNW * 2];
-    uint32_t dn_dord[WNW * 2], dn_k[WNW * 2];
-    float dn_h[WNW * 2];
+    // (the queue lives in st_row / st_col / st_val: the one-edge loop between two searches and the rounds of a search never overlap, and
+    //  the kernel's static LDS has no room for another 640 bytes beside the dynamic region)
+    int ndn;
 };
+static_assert(WNW * 2 <= 32, "the queue of a round's full-row relaxations: two halves of the 64-entry staging arrays");
 
 // ---- SEVERAL SEARCHES AT ONCE (one problem, PAR): the free rows' searches are independent until they are committed, and most of
 // them are shallow (a few dozen settled columns after the scaled row reduction), so G workgroups run the searches of free rows
@@ -1411,9 +1412,9 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
         if (!nd) return;
         const int nq = (n + 3) >> 2, per = (nq + WNW - 1) / WNW, q_lo = w * per, q_hi = min(nq, q_lo + per);
         for (int e = 0; e < nd; e++) {
-            const int oiq = uni(s.dn_oi[e]), pjq = uni(s.dn_pj[e]);
-            const uint32_t dord = uni(s.dn_dord[e]), kq = uni(s.dn_k[e]);
-            const float h = uni(s.dn_h[e]);
+            const int oiq = uni(s.st_row[e]), pjq = uni(s.st_row[32 + e]);
+            const uint32_t dord = (uint32_t)uni(s.st_col[e]), kq = (uint32_t)uni(s.st_col[32 + e]);
+            const float h = uni(s.st_val[e]);
             const float *__restrict__ row = a.cost + wrow_off(a.rowmap, oiq, a.ld);
             // (a full row offers hundreds of candidates below the best unassigned distance when many columns are near-equal:
             //  the label is read first -- a plain L2 load -- and the atomic follows only where it would change something)
@@ -1697,7 +1698,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     const float h = (ca[q] - vp[q]) - ord2f(dord);
                     if (lane == 0) {                               // (relaxed by the whole workgroup behind the round's barrier: coop_dense)
                         const int e = atomicAdd(&s.ndn, 1);
-                        s.dn_oi[e] = oi[q]; s.dn_pj[e] = pj[q]; s.dn_dord[e] = dord; s.dn_k[e] = kq; s.dn_h[e] = h;
+                        s.st_row[e] = oi[q]; s.st_row[32 + e] = pj[q]; s.st_col[e] = (int)dord; s.st_col[32 + e] = (int)kq; s.st_val[e] = h;
                         atomicAdd(&s.waste, 1);
                     }
                     c_dense++;
