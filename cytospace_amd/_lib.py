@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcytohip.so")
+LIB_PATH = os.environ.get("CYTOHIP_LIB") or os.path.join(_HERE, "libcytohip.so")     # (CYTOHIP_LIB: a developer's A/B build)
 _lib = None
 
 CYTO_OK = 0

@@ -1262,8 +1262,7 @@ struct AugShared {
     // WHOLE workgroup behind the round's barrier -- a 200-KB row at n = 50 000 took its one wave ~60 us while fifteen others waited at the
     // barrier (config c3: 40 of them were 2.4 of its searches' 6.1 ms)
     // (the queue lives in st_row / st_col / st_val: the one-edge loop between two searches and the rounds of a search never overlap, and
-    //  the kernel's static LDS has no room for another 640 bytes beside the dynamic region)
-    int ndn;
+    //  the kernel's static LDS has no room for another 640 bytes beside the dynamic region; their count: npk[] >> 16)
 };
 static_assert(WNW * 2 <= 32, "the queue of a round's full-row relaxations: two halves of the 64-entry staging arrays");
 
@@ -1311,6 +1310,51 @@ __device__ __forceinline__ void par_barrier(ParCtl *c, int G, unsigned &gen) {
     }
     gen++;
     __syncthreads();
+}
+
+// The full-row relaxations a round of wide_aug queued (nd of them, in st_row / st_col / st_val), by the whole workgroup behind
+// the round's barrier: a slice of the row per wave.  A round that queued one has settled a column: the rounds go on, and what these
+// relaxations label is picked up.  Their count travels in the upper half of the round's pick counter (AugShared::npk), which every wave
+// reads behind the barrier anyway: a counter of its own, read before the other two, cost every round of every search a serial LDS round
+// trip (10 000-cell chunk: 10.8 -> 11.7 ms of searches that never come here).
+// Rows shorter than this stay with the wave that settled the column, inside the round (a 40-KB row is ~12 us of one wave; and with that
+// sweep gone from the round loop the compiler's allocation made every phase of wide_aug 7-10 % slower on the instances that have no
+// full-row relaxation at all -- 10 000-cell chunk 10.8 -> 11.7 ms, profiles/r06q_coop_ab.txt).  -DCYTO_COOP_MIN_N=0: a developer build
+// that takes every full row through the cooperative path (tools/run/r06r.sh runs the randomised stress on it).
+#ifndef CYTO_COOP_MIN_N
+#define CYTO_COOP_MIN_N 16384
+#endif
+constexpr int COOP_MIN_N = CYTO_COOP_MIN_N;
+template <bool VLDS>
+__device__ __forceinline__ void coop_dense_rows(AugShared *sp, int nd, const float *__restrict__ cost, const int32_t *__restrict__ rowmap, int64_t ld,
+                                             int n, int w, int lane, unsigned long long *lbl, int32_t *tch, uint32_t *dirty,
+                                             unsigned long long *bmin, const uint32_t *asg, const float *s_v, const float *v) {
+    AugShared &s = *sp;
+    const int nq = (n + 3) >> 2, per = (nq + WNW - 1) / WNW, q_lo = w * per, q_hi = min(nq, q_lo + per);
+    for (int e = 0; e < nd; e++) {
+        const int oiq = uni(s.st_row[e]), pjq = uni(s.st_row[32 + e]);
+        const uint32_t dord = (uint32_t)uni(s.st_col[e]), kq = (uint32_t)uni(s.st_col[32 + e]);
+        const float h = uni(s.st_val[e]);
+        const float *__restrict__ row = cost + wrow_off(rowmap, oiq, ld);
+        // (a full row offers hundreds of candidates below the best unassigned distance when many columns are near-equal:
+        //  the label is read first -- a plain L2 load -- and the atomic follows only where it would change something)
+        wave_row_sweep_q(row, q_lo, q_hi, n, lane, [&](int c, float x) {
+            const float vc = VLDS ? s_v[c] : ld_sc1(v + c);
+            const unsigned long long lv = edge_lv(f2ord((x - vc) - h), dord, kq);
+            const unsigned long long key = lkey(lv, (uint32_t)oiq);
+            if (c == pjq || lv > lv_of(s.T) || !(key < ld_sc1(lbl + c))) return;
+            const unsigned long long old = atomicMin(lbl + c, key);                 // (as relax_to in wide_aug)
+            if (key < old) {
+                if (old == ~0ull) tch[atomicAdd(&s.ntouch, 1)] = c;
+                if (lv_of(old) > lv) {
+                    const unsigned long long ck = lkey(lv, (uint32_t)c);
+                    if ((asg[c >> 5] >> (c & 31)) & 1u) { atomicOr(&dirty[c >> 5], 1u << (c & 31)); atomicMin(&bmin[c >> 6], ck); }
+                    else atomicMin(&s.T, ck);
+                }
+            }
+        });
+    }
+    __syncthreads();                                                                // (the next round reads the block minima these set)
 }
 
 // VLDS: prices (f32) and column owners (u16) also in LDS (every update goes to both copies), as in wide_arr.
@@ -1373,7 +1417,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             return;
         }
     }
-    if (tid == 0) { s.waste = 0; s.stop = 0; s.ndn = 0; }
+    if (tid == 0) { s.waste = 0; s.stop = 0; }
     if (tid == 0) { s.T = ~0ull; s.ntouch = 0; s.any[0] = 0; s.any[1] = 0; s.any[2] = 0; s.npk[0] = 0; s.npk[1] = 0; s.npk[2] = 0; s.fail = 0; s.anydense = 0; s.rootdense = 0; s.doroot = 0; s.f = f0; s.err = 0; s.scans = 0; }
     __syncthreads();
     auto getv = [&](int j) -> float { return VLDS ? s_v[j] : ld_sc1(a.v + j); };
@@ -1405,28 +1449,8 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
         }
     };
     auto relax_to = [&](int col, unsigned long long lv, int row) { after_offer(col, lv, row, offer(col, lv, row)); };
-    // behind a round's barrier (every wave of the workgroup, the idle ones too): the full-row relaxations the round queued, a slice of the
-    // row per wave.  (A round that queued one has settled a column: the rounds go on, and what these relaxations label is picked up.)
-    auto coop_dense = [&]() {
-        const int nd = uni(s.ndn);
-        if (!nd) return;
-        const int nq = (n + 3) >> 2, per = (nq + WNW - 1) / WNW, q_lo = w * per, q_hi = min(nq, q_lo + per);
-        for (int e = 0; e < nd; e++) {
-            const int oiq = uni(s.st_row[e]), pjq = uni(s.st_row[32 + e]);
-            const uint32_t dord = (uint32_t)uni(s.st_col[e]), kq = (uint32_t)uni(s.st_col[32 + e]);
-            const float h = uni(s.st_val[e]);
-            const float *__restrict__ row = a.cost + wrow_off(a.rowmap, oiq, a.ld);
-            // (a full row offers hundreds of candidates below the best unassigned distance when many columns are near-equal:
-            //  the label is read first -- a plain L2 load -- and the atomic follows only where it would change something)
-            wave_row_sweep_q(row, q_lo, q_hi, n, lane, [&](int c, float x) {
-                const unsigned long long lv = edge_lv(f2ord((x - getv(c)) - h), dord, kq);
-                if (c != pjq && lv <= lv_of(s.T) && (lkey(lv, (uint32_t)oiq) < ld_sc1(lbl + c))) relax_to(c, lv, oiq);
-            });
-        }
-        __syncthreads();
-        if (tid == 0) s.ndn = 0;
-        __syncthreads();
-    };
+    // behind a round's barrier (every wave of the workgroup, the idle ones too): the full-row relaxations the round queued
+    // (coop_dense_rows, out of line: the rounds that queued none -- nearly all -- pay one LDS read for it)
 
     int f = f0;
     int ph = 0;                                                  // round flag in use (three take turns: one barrier per round)
@@ -1554,6 +1578,7 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
 
         for (;;) {
             // ================= rounds until no wave finds work =================
+            int nd = 0;                                              // full-row relaxations the last round queued (leaves the rounds for them)
             for (;;) {
                 const unsigned long long Tlv = uni(lv_of(s.T));          // label value of the best unassigned column so far
                 // the two best dirty columns among the wave's blocks (one key per lane: the smallest of the blocks it looks at)
@@ -1564,12 +1589,12 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                 const int W = wact;
                 if (w >= W && rb[0] < 0 && rb[1] < 0) {              // nothing to pick from, no minimum to rebuild: straight to the barrier
                     __syncthreads();
-                    coop_dense();
-                    const int any0 = uni(s.any[ph]), np0 = uni(s.npk[ph]);
+                    const int any0 = uni(s.any[ph]), npd0 = uni(s.npk[ph]), np0 = npd0 & 0xFFFF;
                     ph = (ph + 1) % 3;
                     c_rounds++;
                     wact = np0 > 6 ? WNW : 4;
-                    if (!any0) break;
+                    nd = npd0 >> 16;
+                    if (!any0 || nd) break;
                     continue;
                 }
                 unsigned long long mk = ~0ull;
@@ -1696,12 +1721,23 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     if (!dn[q]) continue;                          // the owner's cache could not certify: its whole cost row
                     const uint32_t dord = (uint32_t)(lab[q] >> 32), kq = (uint32_t)(lab[q] >> 20) & LKMAX;
                     const float h = (ca[q] - vp[q]) - ord2f(dord);
-                    if (lane == 0) {                               // (relaxed by the whole workgroup behind the round's barrier: coop_dense)
-                        const int e = atomicAdd(&s.ndn, 1);
-                        s.st_row[e] = oi[q]; s.st_row[32 + e] = pj[q]; s.st_col[e] = (int)dord; s.st_col[32 + e] = (int)kq; s.st_val[e] = h;
-                        atomicAdd(&s.waste, 1);
+                    if (n >= COOP_MIN_N) {                         // a long row: by the whole workgroup, behind the round's barrier (coop_dense_rows)
+                        if (lane == 0) {
+                            const int e = atomicAdd(&s.npk[ph], 1 << 16) >> 16;
+                            s.st_row[e] = oi[q]; s.st_row[32 + e] = pj[q]; s.st_col[e] = (int)dord; s.st_col[32 + e] = (int)kq; s.st_val[e] = h;
+                        }
+                    } else {
+                        const float *__restrict__ row = a.cost + wrow_off(a.rowmap, oi[q], a.ld);
+                        const int pjq = pj[q], oiq = oi[q];
+                        // (a full row offers hundreds of candidates below the best unassigned distance when many columns are near-equal:
+                        //  the label is read first -- a plain L2 load -- and the atomic follows only where it would change something)
+                        wave_row_sweep(row, n, lane, [&](int c, float x) {
+                            const unsigned long long lv = edge_lv(f2ord((x - getv(c)) - h), dord, kq);
+                            if (c != pjq && lv <= lv_of(s.T) && (lkey(lv, (uint32_t)oiq) < ld_sc1(lbl + c))) relax_to(c, lv, oiq);
+                        });
                     }
                     c_dense++;
+                    if (lane == 0) atomicAdd(&s.waste, 1);
                 }
 #pragma unroll
                 for (int q = 0; q < AP; q++) {                       // last round's blocks: smallest (distance, k) among their dirty columns
@@ -1719,13 +1755,17 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
                     rb[q] = pk[q] ? (pj[q] >> 6) : -1;
                 }
                 __syncthreads();
-                coop_dense();
-                const int any = uni(s.any[ph]), np = uni(s.npk[ph]);
+                const int any = uni(s.any[ph]), npd = uni(s.npk[ph]), np = npd & 0xFFFF;     // picks of the round | full rows it queued << 16
                 if (tid == 0) { s.any[(ph + 2) % 3] = 0; s.npk[(ph + 2) % 3] = 0; }   // (last read before this barrier, next set after the next one)
                 ph = (ph + 1) % 3;
                 c_rounds++;
                 wact = np > 6 ? WNW : 4;
-                if (!any) break;
+                nd = npd >> 16;
+                if (!any || nd) break;
+            }
+            if (nd) {                                                // (outside the round loop: its code must not weigh on the rounds)
+                coop_dense_rows<VLDS>(&s, nd, a.cost, a.rowmap, a.ld, n, w, lane, lbl, tch, dirty, bmin, asg, s_v, a.v);
+                continue;
             }
             // ================= converged: do the caches certify what was skipped? =================
             AUG_LAP(t_rounds)
