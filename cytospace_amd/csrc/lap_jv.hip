@@ -1643,7 +1643,7 @@ template <int U>
 __global__ __launch_bounds__(64 * CBW) void build_row_caches_wave(int n, int64_t ld, const float *__restrict__ cost,
                                                                  const float *__restrict__ v, uint32_t *__restrict__ cache_col,
                                                                  float *__restrict__ cache_val, const int32_t *__restrict__ rowmap,
-                                                                 const int32_t *__restrict__ same_prev, int stream) {
+                                                                 const int32_t *__restrict__ same_prev, int stream, int keep_min) {
     __shared__ CbStage stage[CBW];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (scalar: row bases and descriptors stay in SGPRs)
     CbStage &st = stage[w];
@@ -1654,6 +1654,19 @@ __global__ __launch_bounds__(64 * CBW) void build_row_caches_wave(int n, int64_t
     float tau_guess = INFINITY, delta = 0.0f;
     for (int i = gw * per; i < i_end; i++) {
         if (same_prev && same_prev[i]) continue;                          // a copy of the previous row: replicate_group_caches
+        if (keep_min > 0) {
+            // A REBUILD (keep_min > 0: the caches hold an earlier build): prices only fall, so a floor stays a lower bound of every
+            // uncached column for good and a cache is as good as the number of its columns that still lie below its floor -- two
+            // certify a bid, one a relaxation.  A row that has keep_min of them is left alone: 512 bytes and 63 price gathers
+            // instead of the row.  (A developer's knob, CYTO_CACHE_KEEP, off by default: by the time a rebuild is due hardly a row
+            // has 32 such columns left -- nothing is skipped -- and leaving rows with 2 ... 16 alone brings more full-row bids than
+            // it saves: few-cell-type 20 000^2 17.7 -> 29.0 / 23.8 / 19.8 / 18.9 ms; the 256-chunk batch is flat.  DESIGN "Tried".)
+            const uint32_t kc0 = cache_col[(int64_t)i * KC + lane];
+            const float kv0 = cache_val[(int64_t)i * KC + lane];
+            const float fl0 = __shfl(kv0, KCU);
+            const bool below = lane < KCU && kc0 != COLSENT && (kv0 - v[kc0]) < fl0;
+            if (__popcll(__ballot(below)) >= keep_min) continue;
+        }
         const float *__restrict__ row = cost + row_off(rowmap, i, ld);
         const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(row), 0, (int)(ld * 4), 0x00020000);
         float tau0 = tau_guess;
@@ -3362,6 +3375,7 @@ struct F32Plan {            // what depends on n (and the options) only: identic
     int n, colblocks, rowblocks, rows_per_block, cache_grid;
     int cache_stream = 1;           // build_row_caches_wave: the guess-free single sweep (cb_stream); 0: a neighbour's floor as the guess
     int cache_waves = 8, cache_unroll = 4, cus = 256;      // build_row_caches_wave: waves per CU, quads in flight per lane; CUs of the device (device_cus)
+    int cache_keep = 0;             // a REBUILD leaves a row alone that still has this many cached columns below its floor (0: every row)
     bool force_l2, lds_variant, lazy, lz_lds_state, lz_cs_lds, no_cs_lds, wide;
     long long wide_rounds;
     int wide_groups, wide_rebuild, wide_wipe, wide_par;
@@ -3380,7 +3394,10 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
     const bool cs_lds = !LDS_STATE && n <= 65535 && !pl.no_cs_lds;
     void (*kern)(const Chain2Args *) = jv_chain2<CH, LDS_STATE, false>;
     if constexpr (!LDS_STATE) { if (cs_lds) kern = jv_chain2<CH, false, true>; }
+    bool caches_built = false;                                   // (the first build finds uninitialised memory: nothing to keep)
     auto build_caches = [&](const int *remaining) -> int {      // remaining: per live problem, 0 = nothing left to do for it (or null)
+        const int keep = (caches_built && pl.wide) ? pl.cache_keep : 0;
+        caches_built = true;
         for (int k = 0; k < nl; k++) {
             if (remaining && remaining[k] == 0) continue;
             const int b = live[k];
@@ -3392,10 +3409,10 @@ static int launch_batch(const F32Plan &pl, std::vector<F32Job> &jobs, hipStream_
                 const int g = std::max(1, std::min((n + CBW - 1) / CBW, pl.cache_waves * pl.cus / CBW));
                 if (pl.cache_unroll == 8)
                     hipLaunchKernelGGL(build_row_caches_wave<8>, dim3(g), dim3(64 * CBW), 0, stream, n, a.ld, a.cost, (const float *)a.fws,
-                                       a.cache_col, a.cache_val, a.rowmap, same, pl.cache_stream);
+                                       a.cache_col, a.cache_val, a.rowmap, same, pl.cache_stream, keep);
                 else
                     hipLaunchKernelGGL(build_row_caches_wave<4>, dim3(g), dim3(64 * CBW), 0, stream, n, a.ld, a.cost, (const float *)a.fws,
-                                       a.cache_col, a.cache_val, a.rowmap, same, pl.cache_stream);
+                                       a.cache_col, a.cache_val, a.rowmap, same, pl.cache_stream, keep);
             } else if constexpr (CH == 0)
                 hipLaunchKernelGGL(build_row_caches_stream, dim3(pl.cache_grid), dim3(BLOCK2), 0, stream, n, a.ld, a.cost,
                                    (const float *)a.fws, a.cache_col, a.cache_val, a.rowmap, same);
@@ -3650,6 +3667,7 @@ static int lap_solve_f32_batch(int n, std::vector<F32Job> &jobs, int device_id, 
     //  build with 8 waves, 24.0-24.8 ms after one with 20 -- 183 instead of 146 full-row bids, each holding up a round for one 200-KB sweep).
     pl.cache_unroll = 8;
     pl.cache_waves = n > 32768 ? 8 : 20;
+    if (CYTO_KNOB("CYTO_CACHE_KEEP").set) pl.cache_keep = std::max(0, std::min(63, CYTO_KNOB("CYTO_CACHE_KEEP").value));     // (developer knob)
     // (cyto_lap_opts.cache_waves / cache_unroll / cache_stream -- tools/cache_build_bench.py and the builder tests: -1 waves selects the
     //  workgroup-per-row builders)
     if (opts.cache_waves != 0) pl.cache_waves = opts.cache_waves < 0 ? 0 : opts.cache_waves;
