@@ -1855,6 +1855,9 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             commit = active && have && g < Pb;
             if (active && !commit) c_discarded++;
         }
+#ifdef CYTO_AUG_FIN_SPLIT                                        // (developer build: the finish by parts -- the wait for the batch's slowest search, the
+        AUG_LAP(t_verify)                                        //  claims and the conflict check go into the certificate timer, ...
+#endif
         if (commit) {
             int myscans = 0;
             for (int q = tid; q < nt; q += WT) {
@@ -1901,6 +1904,9 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             atomicAnd(&dirty[k >> 5], ~(1u << (k & 31)));
             bmin[k >> 6] = ~0ull;
         }
+#ifdef CYTO_AUG_FIN_SPLIT                                        //  ... update + flip stay, reset + logs + the batch's last barrier into the one-edge timer)
+        AUG_LAP(t_finish)
+#endif
         // (keeping the dense bits across searches was measured: fewer rounds, but more full-row relaxations -- slower)
         if (s.anydense) for (int q = tid; q < nw32; q += WT) dense[q] = 0;
         __syncthreads();
@@ -1924,7 +1930,11 @@ __global__ __launch_bounds__(WT) void wide_aug(const WideArgs *__restrict__ batc
             if (Pb < 1) perr = 1;
             batchno++; c_batches++;
         }
+#ifdef CYTO_AUG_FIN_SPLIT
+        AUG_LAP(t_triv)
+#else
         AUG_LAP(t_finish)
+#endif
     }
 
     // ---- duals, total, counters ----
