@@ -157,6 +157,60 @@ def test_wide_c3_shaped_and_c4_chunk_true_size():
         buf.free()
 
 
+def test_wide_chunk_of_16384_cells_whatever_the_schedule():
+    """A 16 384-cell sub-spot chunk (the few-cell-type class at the size from which a search's full-row relaxations go to the whole
+    workgroup): rowsol / u / v, the indices and the semantic counters == the wide restatement's golden -- with the default schedule, with
+    row caches that are never rebuilt during the searches, and one search at a time."""
+    tag, n = "c4s16384", 16384
+    wpath = os.path.join(GOLD, f"large_{tag}_wide.npz")
+    if not os.path.exists(wpath):
+        pytest.fail(f"{wpath} is missing (make_golden_large.py --wide {tag}): a lost fixture must not silently drop this parity test")
+    dw = np.load(wpath)
+    cost, loc = instances.c4_chunk_cost(n)
+    buf = _lib.DeviceBuffer.from_numpy(cost)
+    del cost
+    want = dict(zip([str(k) for k in dw["stats_keys"]], dw["stats_vals"].tolist()))
+    try:
+        for opts in (dict(), dict(wide_rebuild=-1), dict(wide_rebuild=-1, wide_par=-1)):
+            g = lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n, opts=opts)
+            i = g["info"]
+            assert i.wide == 1 and i.wide_scaled == 1
+            assert np.array_equal(g["colsol"], dw["colsol"]), (opts, int((g["colsol"] != dw["colsol"]).sum()))
+            assert sha(g["rowsol"]) == str(dw["rowsol_sha256"]) and sha(g["u"]) == str(dw["u_sha256"]) and sha(g["v"]) == str(dw["v_sha256"]), opts
+            got = i.as_dict()
+            for kg, ko in (("scans_arr", "scans_arr"), ("scans_aug_relax", "scans_aug_relax"), ("augmentations", "augmentations"),
+                           ("path_hops", "path_hops"), ("free_after_arr2", "free_after_arr"), ("wide_rounds", "arr_rounds"),
+                           ("wide_retired", "arr_retired"), ("wide_phases", "arr_phases")):
+                assert got[kg] == want[ko], (opts, kg, got[kg], want[ko])
+    finally:
+        buf.free()
+
+
+def test_wide_full_row_relaxations_by_the_whole_workgroup():
+    """Rows of 16 384 columns and more that a search relaxes in full are swept by the WHOLE workgroup behind the round's barrier
+    (lap_wide.hip: coop_dense_rows; shorter rows by the wave that settled the column).  Integer costs with a few dozen distinct
+    values tie everywhere: no row cache certifies anything, every column a search settles sends its owner's whole row through that path.
+    n = 16 400, against the wide restatement run here (seconds: the instance never scales and most of its searches are one edge): every
+    output bit for bit, one search at a time and several at once."""
+    from oracle.jv import jv_oracle_wide
+    from tools.stress_lap import make
+    n = 16400
+    c = make("ints", n, np.random.default_rng(777))
+    o = jv_oracle_wide(c, np.float32)
+    st = o["stats"]
+    dense = []
+    for opts in (dict(), dict(wide_par=-1), dict(wide_par=5)):
+        g = lap_solve(c, np.float32, return_info=True, opts=opts)
+        i = g["info"]
+        assert i.wide == 1
+        for k in ("rowsol", "colsol", "u", "v"):
+            assert np.array_equal(g[k], o[k]), (opts, k)
+        assert (i.scans_arr, i.scans_aug_relax, i.wide_rounds, i.wide_retired, i.path_hops, i.wide_scaled, i.wide_phases) == \
+               (st.scans_arr, st.scans_aug_relax, st.arr_rounds, st.arr_retired, st.path_hops, st.arr_scaled, st.arr_phases), opts
+        dense.append(int(i.wide_dense_aug))
+    assert min(dense) > 0, dense                                   # the cooperative path really ran
+
+
 def test_chain_uniform_70000_colsol_in_global_memory():
     """n > 65 535: the chain kernels with colsol in global memory too (chain_variant 3's range) at a true size, 19.6 GB of cost."""
     n = 70000
