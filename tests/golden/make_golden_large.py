@@ -1,6 +1,6 @@
 """Goldens for the LARGE LAP instances (BASELINE configs c2/c3/c4 at true size), made in the build container.
 
-Run:  python tests/golden/make_golden_large.py [tag ...]      (tags: u20000 u24000 u30000 u33000 u50000 u70000 c3s50000 c4s10000 t10000 t20000 t30000 k5t20000)
+Run:  python tests/golden/make_golden_large.py [tag ...]      (tags: u20000 u24000 u30000 u33000 u50000 u70000 c3s50000 c4s10000 c4s16384 t10000 t20000 t30000 k5t20000)
       python tests/golden/make_golden_large.py --wide [tag ...]   the same instances through the oracle's WIDE mode -> large_<tag>_wide.npz
       python tests/golden/make_golden_large.py --f64 [tag ...]    float64 solves (uniform tags only) -> large_<tag>_f64.npz
 

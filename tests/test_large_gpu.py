@@ -159,29 +159,20 @@ def test_wide_c3_shaped_and_c4_chunk_true_size():
 
 def test_wide_chunk_of_16384_cells_whatever_the_schedule():
     """A 16 384-cell sub-spot chunk (the few-cell-type class at the size from which a search's full-row relaxations go to the whole
-    workgroup): rowsol / u / v, the indices and the semantic counters == the wide restatement's golden -- with the default schedule, with
-    row caches that are never rebuilt during the searches, and one search at a time."""
+    workgroup): the spot of every cell == the certified classic golden (== scipy at spot level; unique by the one-ulp re-solve), rowsol
+    / u / v and the semantic counters == the wide restatement's golden -- with the default schedule, with row caches that are never
+    rebuilt during the searches, and one search at a time."""
     tag, n = "c4s16384", 16384
-    wpath = os.path.join(GOLD, f"large_{tag}_wide.npz")
-    if not os.path.exists(wpath):
-        pytest.fail(f"{wpath} is missing (make_golden_large.py --wide {tag}): a lost fixture must not silently drop this parity test")
-    dw = np.load(wpath)
+    for f in (f"large_{tag}.npz", f"large_{tag}_wide.npz"):
+        if not os.path.exists(os.path.join(GOLD, f)):
+            pytest.fail(f"tests/golden/{f} is missing (make_golden_large.py [--wide] {tag}): a lost fixture must not silently drop this parity test")
     cost, loc = instances.c4_chunk_cost(n)
     buf = _lib.DeviceBuffer.from_numpy(cost)
     del cost
-    want = dict(zip([str(k) for k in dw["stats_keys"]], dw["stats_vals"].tolist()))
     try:
         for opts in (dict(), dict(wide_rebuild=-1), dict(wide_rebuild=-1, wide_par=-1)):
-            g = lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n, opts=opts)
-            i = g["info"]
-            assert i.wide == 1 and i.wide_scaled == 1
-            assert np.array_equal(g["colsol"], dw["colsol"]), (opts, int((g["colsol"] != dw["colsol"]).sum()))
-            assert sha(g["rowsol"]) == str(dw["rowsol_sha256"]) and sha(g["u"]) == str(dw["u_sha256"]) and sha(g["v"]) == str(dw["v_sha256"]), opts
-            got = i.as_dict()
-            for kg, ko in (("scans_arr", "scans_arr"), ("scans_aug_relax", "scans_aug_relax"), ("augmentations", "augmentations"),
-                           ("path_hops", "path_hops"), ("free_after_arr2", "free_after_arr"), ("wide_rounds", "arr_rounds"),
-                           ("wide_retired", "arr_retired"), ("wide_phases", "arr_phases")):
-                assert got[kg] == want[ko], (opts, kg, got[kg], want[ko])
+            g = _wide_vs_golden(tag, n, lambda: lap_solve(None, np.float32, return_info=True, device_ptr=buf.ptr, n=n, ld=n, opts=opts), loc)
+            assert g["info"].wide_scaled == 1
     finally:
         buf.free()
 
